@@ -1,0 +1,242 @@
+"""Deterministic synthetic stereo bundle-adjustment problems.
+
+The reference ships no data and no generator (its drivers read external CSVs:
+/root/reference scripts/ba_all_sims.sh:3-5), so the inputs of every test and of
+bench.py come from here.  Conventions follow the reference exactly:
+
+* camera intrinsics are the KITTI values of tests/camera_test.cpp:11-15;
+* a pose block is 12 doubles ``[t(3) | R row-major(9)]`` holding ``T_c_g``
+  (camera-from-global; include/ceres_slam/geometry/se3group.hpp:425-429);
+* an observation is ``(u_l, v_l, disparity)`` (stereo_camera.hpp:77-84);
+* observations are ordered by state ``k`` then landmark ``j``, the file order
+  the reference readers assume (src/ceres_slam/dataset_problem.cpp:89-98);
+* the first pose is exact and held constant by the drivers
+  (tests/dataset_vo.cpp:62).
+
+Everything is float64 / uint32 numpy; the RNG is ``numpy.random.PCG64(seed)``
+(seed 42 is the reference's own RANSAC seed, point_cloud_aligner.cpp:72).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# tests/camera_test.cpp:11-15
+KITTI_CAMERA = dict(fu=707.0912, fv=707.0912, cu=601.8873, cv=183.1104, b=0.535105804)
+IMAGE_W, IMAGE_H = 1242.0, 375.0
+
+#: named BASELINE.json configurations -> (poses, landmarks)
+CONFIGS = {
+    "C1": (50, 2_000),
+    "C2": (1_000, 100_000),
+    "C4": (10_000, 1_000_000),
+}
+
+
+@dataclass
+class StereoBAProblem:
+    """Host-side problem in the reference's data model (dataset_problem.hpp:31-54)."""
+
+    camera: dict
+    poses_gt: np.ndarray        # (P,12)
+    poses_init: np.ndarray      # (P,12)
+    points_gt: np.ndarray       # (L,3)
+    points_init: np.ndarray     # (L,3)
+    obs_pose: np.ndarray        # (N,) uint32  state index k
+    obs_point: np.ndarray       # (N,) uint32  landmark index j
+    obs_uvd: np.ndarray         # (N,3) float64 noisy (u,v,d)
+    stereo_obs_var: np.ndarray  # (3,) variances
+    outlier_mask: np.ndarray = field(default=None)  # (N,) bool, config C5 only
+
+    @property
+    def num_poses(self) -> int:
+        return self.poses_init.shape[0]
+
+    @property
+    def num_points(self) -> int:
+        return self.points_init.shape[0]
+
+    @property
+    def num_obs(self) -> int:
+        return self.obs_pose.shape[0]
+
+    def stiffness(self) -> np.ndarray:
+        """3x3 row-major stiffness = Sigma^{-1/2} (tests/dataset_vo.cpp:29-32)."""
+        return np.diag(1.0 / np.sqrt(self.stereo_obs_var))
+
+
+# ---------------------------------------------------------------- geometry ---
+def so3_exp(phi: np.ndarray) -> np.ndarray:
+    """Rodrigues with the reference's first-order branch (so3group.hpp:273-291)."""
+    phi = np.asarray(phi, dtype=np.float64)
+    angle = np.linalg.norm(phi)
+    W = np.array([[0, -phi[2], phi[1]], [phi[2], 0, -phi[0]], [-phi[1], phi[0], 0]])
+    if angle <= np.finfo(np.float64).eps:
+        return np.eye(3) + W
+    a = phi / angle
+    A = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.cos(angle) * np.eye(3) + (1 - np.cos(angle)) * np.outer(a, a) + np.sin(angle) * A
+
+
+def _batch_so3_exp(phi: np.ndarray) -> np.ndarray:
+    ang = np.linalg.norm(phi, axis=1)
+    safe = np.where(ang > 0, ang, 1.0)
+    a = phi / safe[:, None]
+    c, s = np.cos(ang), np.sin(ang)
+    R = np.zeros((phi.shape[0], 3, 3))
+    eye = np.eye(3)[None]
+    A = np.zeros_like(R)
+    A[:, 0, 1], A[:, 0, 2] = -a[:, 2], a[:, 1]
+    A[:, 1, 0], A[:, 1, 2] = a[:, 2], -a[:, 0]
+    A[:, 2, 0], A[:, 2, 1] = -a[:, 1], a[:, 0]
+    R = c[:, None, None] * eye + (1 - c)[:, None, None] * (a[:, :, None] * a[:, None, :]) + s[:, None, None] * A
+    small = ang <= np.finfo(np.float64).eps
+    if small.any():
+        W = np.zeros((small.sum(), 3, 3))
+        p = phi[small]
+        W[:, 0, 1], W[:, 0, 2] = -p[:, 2], p[:, 1]
+        W[:, 1, 0], W[:, 1, 2] = p[:, 2], -p[:, 0]
+        W[:, 2, 0], W[:, 2, 1] = -p[:, 1], p[:, 0]
+        R[small] = eye + W
+    return R
+
+
+def pose_pack(t: np.ndarray, R: np.ndarray) -> np.ndarray:
+    """(…,3),(…,3,3) -> (…,12) in the reference's [t | R row-major] layout."""
+    return np.concatenate([t, R.reshape(R.shape[:-2] + (9,))], axis=-1)
+
+
+def pose_unpack(x: np.ndarray):
+    return x[..., :3], x[..., 3:].reshape(x.shape[:-1] + (3, 3))
+
+
+def project(cam: dict, q: np.ndarray) -> np.ndarray:
+    """stereo_camera.hpp:77-84"""
+    iz = 1.0 / q[..., 2]
+    return np.stack([cam["fu"] * q[..., 0] * iz + cam["cu"],
+                     cam["fv"] * q[..., 1] * iz + cam["cv"],
+                     cam["fu"] * cam["b"] * iz], axis=-1)
+
+
+def triangulate(cam: dict, uvd: np.ndarray) -> np.ndarray:
+    """stereo_camera.hpp:112-120"""
+    b_over_d = cam["b"] / uvd[..., 2]
+    return np.stack([(uvd[..., 0] - cam["cu"]) * b_over_d,
+                     (uvd[..., 1] - cam["cv"]) * b_over_d * (cam["fu"] / cam["fv"]),
+                     cam["fu"] * b_over_d], axis=-1)
+
+
+def circle_trajectory(P: int, spacing: float = 0.5, min_radius: float = 80.0):
+    """Planar circular loop, yaw following the path (author's sims: ba_all_sims.sh:8-13).
+
+    Camera axes: z forward, x right, y down.  Short sequences follow an arc of a
+    ``min_radius`` circle instead of closing a tiny loop.
+    Returns (t_cg (P,3), R_cg (P,3,3)).
+    """
+    r = max(P * spacing / (2 * np.pi), min_radius)
+    th = spacing * np.arange(P) / r
+    c = np.stack([r * (1 - np.cos(th)), np.zeros(P), r * np.sin(th)], axis=1)
+    xc = np.stack([np.cos(th), np.zeros(P), -np.sin(th)], axis=1)
+    yc = np.tile(np.array([0.0, 1.0, 0.0]), (P, 1))
+    zc = np.stack([np.sin(th), np.zeros(P), np.cos(th)], axis=1)
+    R_cg = np.stack([xc, yc, zc], axis=1)          # rows are camera axes in global
+    t_cg = -np.einsum("kij,kj->ki", R_cg, c)
+    return t_cg, R_cg
+
+
+# --------------------------------------------------------------- generator ---
+def make_problem(num_poses: int, num_points: int, *, track_len: int = 12, seed: int = 42,
+                 obs_var=(4.0, 4.0, 4.0), pose_sigma=(0.05, 0.01),
+                 outlier_fraction: float = 0.0, depth_range=(5.0, 40.0),
+                 min_depth: float = 0.5) -> StereoBAProblem:
+    """Build one synthetic stereo BA problem.
+
+    Landmark ``j`` is anchored at pose ``a_j = floor(j*P/L)``: a uniform pixel and a
+    depth in ``depth_range`` are back-projected through ``triangulate`` from the
+    anchor camera; it is then observed by the ``track_len`` poses ending at the
+    anchor (``a_j-T+1 .. a_j``), clipped by visibility (inside the image, depth >
+    ``min_depth``).  Looking *back* along the track keeps most tracks at full
+    length so that N_obs ~= track_len * L, the observation count BASELINE.json
+    quotes for C2.
+    """
+    P, L, T = int(num_poses), int(num_points), int(track_len)
+    cam = dict(KITTI_CAMERA)
+    rng = np.random.Generator(np.random.PCG64(seed))
+
+    t_gt, R_gt = circle_trajectory(P)
+    poses_gt = pose_pack(t_gt, R_gt)
+
+    anchor = (np.arange(L, dtype=np.int64) * P) // L
+    u0 = rng.uniform(0.0, IMAGE_W, L)
+    v0 = rng.uniform(0.0, IMAGE_H, L)
+    z0 = rng.uniform(depth_range[0], depth_range[1], L)
+    d0 = cam["fu"] * cam["b"] / z0
+    p_c = triangulate(cam, np.stack([u0, v0, d0], axis=1))
+    # global = R^T (p_c - t)
+    Ra, ta = R_gt[anchor], t_gt[anchor]
+    points_gt = np.einsum("nji,nj->ni", Ra, p_c - ta)
+
+    # candidate observations (landmark-major), then visibility clipping
+    offs = np.arange(-(T - 1), 1, dtype=np.int64)
+    k_all = (anchor[:, None] + offs[None, :]).reshape(-1)
+    j_all = np.repeat(np.arange(L, dtype=np.int64), T)
+    ok = (k_all >= 0) & (k_all < P)
+    k_all, j_all = k_all[ok], j_all[ok]
+    q = np.einsum("nij,nj->ni", R_gt[k_all], points_gt[j_all]) + t_gt[k_all]
+    front = q[:, 2] > min_depth
+    k_all, j_all, q = k_all[front], j_all[front], q[front]
+    uvd = project(cam, q)
+    vis = (uvd[:, 0] >= 0) & (uvd[:, 0] < IMAGE_W) & (uvd[:, 1] >= 0) & (uvd[:, 1] < IMAGE_H) & (uvd[:, 2] >= 1.0)
+    k_all, j_all, uvd = k_all[vis], j_all[vis], uvd[vis]
+
+    # reference file order: by state, then by landmark
+    order = np.lexsort((j_all, k_all))
+    k_all, j_all, uvd = k_all[order], j_all[order], uvd[order]
+
+    sig = np.sqrt(np.asarray(obs_var, dtype=np.float64))
+    uvd_noisy = uvd + rng.standard_normal(uvd.shape) * sig[None, :]
+    uvd_noisy[:, 2] = np.maximum(uvd_noisy[:, 2], 0.25)   # keep disparity positive
+
+    outlier_mask = None
+    if outlier_fraction > 0.0:
+        n = uvd_noisy.shape[0]
+        outlier_mask = rng.uniform(size=n) < outlier_fraction
+        m = int(outlier_mask.sum())
+        uvd_noisy[outlier_mask, 0] = rng.uniform(0.0, IMAGE_W, m)
+        uvd_noisy[outlier_mask, 1] = rng.uniform(0.0, IMAGE_H, m)
+        uvd_noisy[outlier_mask, 2] = rng.uniform(1.0, 100.0, m)
+
+    # initial poses: exp(eps) * T_gt with the reference's "exp" (se3group.hpp:323-325)
+    eps = rng.standard_normal((P, 6)) * np.array([pose_sigma[0]] * 3 + [pose_sigma[1]] * 3)[None, :]
+    eps[0] = 0.0
+    E = _batch_so3_exp(eps[:, 3:])
+    R_init = np.einsum("kij,kjl->kil", E, R_gt)
+    t_init = np.einsum("kij,kj->ki", E, t_gt) + eps[:, :3]
+    R_init[0], t_init[0] = R_gt[0], t_gt[0]
+    poses_init = pose_pack(t_init, R_init)
+
+    # initial landmarks: first (lowest-k) noisy observation triangulated and mapped
+    # through the *initial* pose of that state (mirrors dataset_problem.cpp:263)
+    first = np.full(L, -1, dtype=np.int64)
+    # observations are sorted by k, so the first occurrence of j is its lowest k
+    jj, idx = np.unique(j_all, return_index=True)
+    first[jj] = idx
+    points_init = points_gt.copy()
+    has = first >= 0
+    fo = first[has]
+    pc = triangulate(cam, uvd_noisy[fo] if outlier_mask is None else np.where(outlier_mask[fo, None], uvd[fo], uvd_noisy[fo]))
+    kf = k_all[fo]
+    points_init[has] = np.einsum("nji,nj->ni", R_init[kf], pc - t_init[kf])
+
+    return StereoBAProblem(
+        camera=cam, poses_gt=poses_gt, poses_init=poses_init,
+        points_gt=points_gt, points_init=points_init,
+        obs_pose=k_all.astype(np.uint32), obs_point=j_all.astype(np.uint32),
+        obs_uvd=np.ascontiguousarray(uvd_noisy), stereo_obs_var=np.asarray(obs_var, dtype=np.float64),
+        outlier_mask=outlier_mask)
+
+
+def make_config(name: str, **kw) -> StereoBAProblem:
+    P, L = CONFIGS[name]
+    return make_problem(P, L, **kw)

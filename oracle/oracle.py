@@ -1,0 +1,253 @@
+"""ctypes binding of the CPU oracle (oracle/ssba_oracle.c).
+
+TEST INFRASTRUCTURE -- only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.  PARITY UNPINNED at the Ceres boundary
+(see oracle/ssba_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libssba_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_u32p = C.POINTER(C.c_uint32)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+
+
+class Camera(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fu", "fv", "cu", "cv", "b")]
+
+
+class Problem(C.Structure):
+    _fields_ = [("cam", Camera), ("num_poses", C.c_int32), ("num_points", C.c_int32),
+                ("num_obs", C.c_int64), ("poses", _dp), ("points", _dp),
+                ("obs_pose", _u32p), ("obs_point", _u32p), ("obs_uvd", _dp),
+                ("stiffness", C.c_double * 9), ("pose_const", _u8p), ("huber_a", C.c_double)]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_num_iterations", C.c_int32), ("use_nonmonotonic_steps", C.c_int32),
+                ("max_consecutive_nonmonotonic_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
+                ("num_threads", C.c_int32), ("max_num_consecutive_invalid_steps", C.c_int32),
+                ("initial_trust_region_radius", C.c_double), ("max_trust_region_radius", C.c_double),
+                ("min_trust_region_radius", C.c_double), ("min_relative_decrease", C.c_double),
+                ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double)]
+
+
+class Summary(C.Structure):
+    _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32),
+                ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("total_time_s", C.c_double), ("linearize_time_s", C.c_double),
+                ("schur_time_s", C.c_double), ("solve_time_s", C.c_double),
+                ("update_time_s", C.c_double)]
+
+
+class IterationLog(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("cost", _dp), ("cost_change", _dp),
+                ("gradient_max_norm", _dp), ("step_norm", _dp), ("relative_decrease", _dp),
+                ("trust_region_radius", _dp), ("step_is_successful", _i32p)]
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with the committed recipe (oracle/Makefile)."""
+    src = os.path.join(_HERE, "ssba_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_se3_transform.argtypes = [_dp, _dp, _dp]
+        L.orc_so3_exp.argtypes = [_dp, _dp]
+        L.orc_se3_plus.argtypes = [_dp, _dp, _dp]
+        L.orc_se3_inverse.argtypes = [_dp, _dp]
+        L.orc_project.argtypes = [C.POINTER(Camera), _dp, _dp, _dp]
+        L.orc_triangulate.argtypes = [C.POINTER(Camera), _dp, _dp, _dp]
+        L.orc_stereo_residual.argtypes = [C.POINTER(Camera), _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_huber.argtypes = [C.c_double, C.c_double, _dp]
+        L.orc_default_options.argtypes = [C.POINTER(Options)]
+        L.orc_cost.argtypes = [C.POINTER(Problem), C.c_int]
+        L.orc_cost.restype = C.c_double
+        L.orc_linearize.argtypes = [C.POINTER(Problem), _dp, _dp, _dp, _dp, C.c_int]
+        L.orc_linearize.restype = C.c_double
+        L.orc_reduced_system.argtypes = [C.POINTER(Problem), C.c_double, C.POINTER(Options), _dp, _dp, _i32p]
+        L.orc_lm_step.argtypes = [C.POINTER(Problem), C.c_double, C.POINTER(Options), _dp, _dp, _dp]
+        L.orc_solve.argtypes = [C.POINTER(Problem), C.POINTER(Options), C.POINTER(Summary), C.POINTER(IterationLog)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp)
+
+
+def default_options(**kw) -> Options:
+    o = Options()
+    lib().orc_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def driver_options(**kw) -> Options:
+    """The options the reference drivers set (tests/dataset_vo.cpp:65-70)."""
+    base = dict(max_num_iterations=1000, use_nonmonotonic_steps=1, num_threads=8)
+    base.update(kw)
+    return default_options(**base)
+
+
+class OracleProblem:
+    """Owns numpy copies of a problem and the ctypes view the C oracle reads."""
+
+    def __init__(self, camera: dict, poses, points, obs_pose, obs_point, obs_uvd, stiffness,
+                 pose_const=None, huber_a: float = 0.0):
+        self.poses = np.ascontiguousarray(poses, dtype=np.float64).copy()
+        self.points = np.ascontiguousarray(points, dtype=np.float64).copy()
+        self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
+        self.obs_point = np.ascontiguousarray(obs_point, dtype=np.uint32)
+        self.obs_uvd = np.ascontiguousarray(obs_uvd, dtype=np.float64)
+        P = self.poses.shape[0]
+        if pose_const is None:
+            pose_const = np.zeros(P, dtype=np.uint8)
+            if P:
+                pose_const[0] = 1          # tests/dataset_vo.cpp:62
+        self.pose_const = np.ascontiguousarray(pose_const, dtype=np.uint8)
+        self.c = Problem()
+        self.c.cam = Camera(**camera)
+        self.c.num_poses, self.c.num_points = P, self.points.shape[0]
+        self.c.num_obs = self.obs_pose.shape[0]
+        self.c.poses, self.c.points = _p(self.poses), _p(self.points)
+        self.c.obs_pose = self.obs_pose.ctypes.data_as(_u32p)
+        self.c.obs_point = self.obs_point.ctypes.data_as(_u32p)
+        self.c.obs_uvd = _p(self.obs_uvd)
+        self.c.stiffness = (C.c_double * 9)(*np.asarray(stiffness, dtype=np.float64).reshape(9))
+        self.c.pose_const = self.pose_const.ctypes.data_as(_u8p)
+        self.c.huber_a = float(huber_a)
+
+    @classmethod
+    def from_synth(cls, prob, huber_a: float = 0.0, pose_const=None):
+        return cls(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point,
+                   prob.obs_uvd, prob.stiffness(), pose_const=pose_const, huber_a=huber_a)
+
+    # ---- evaluation hooks -------------------------------------------------
+    def cost(self, num_threads: int = 1) -> float:
+        return lib().orc_cost(C.byref(self.c), num_threads)
+
+    def linearize(self, num_threads: int = 1):
+        P, L = self.c.num_poses, self.c.num_points
+        g_p, g_l = np.zeros((P, 6)), np.zeros((L, 3))
+        H_pp, H_ll = np.zeros((P, 6, 6)), np.zeros((L, 3, 3))
+        cost = lib().orc_linearize(C.byref(self.c), _p(g_p), _p(g_l), _p(H_pp), _p(H_ll), num_threads)
+        return cost, g_p, g_l, H_pp, H_ll
+
+    def reduced_system(self, radius: float, options: Options = None):
+        o = options or default_options()
+        P = self.c.num_poses
+        nmax = 6 * P
+        S, rhs = np.zeros((nmax, nmax)), np.zeros(nmax)
+        free_idx = np.zeros(P, dtype=np.int32)
+        rc = lib().orc_reduced_system(C.byref(self.c), radius, C.byref(o), _p(S), _p(rhs),
+                                      free_idx.ctypes.data_as(_i32p))
+        if rc:
+            raise RuntimeError("orc_reduced_system failed")
+        n = 6 * int((free_idx >= 0).sum())
+        return S.reshape(-1)[: n * n].reshape(n, n).copy(), rhs[:n].copy(), free_idx
+
+    def lm_step(self, radius: float, options: Options = None):
+        o = options or default_options()
+        dp, dl = np.zeros((self.c.num_poses, 6)), np.zeros((self.c.num_points, 3))
+        mcc = C.c_double(0.0)
+        rc = lib().orc_lm_step(C.byref(self.c), radius, C.byref(o), _p(dp), _p(dl), C.byref(mcc))
+        if rc:
+            raise RuntimeError("orc_lm_step failed")
+        return dp, dl, mcc.value
+
+    def solve(self, options: Options = None, log_capacity: int = 1024):
+        o = options or driver_options()
+        s = Summary()
+        arrs = {k: np.zeros(log_capacity) for k in ("cost", "cost_change", "gradient_max_norm",
+                                                     "step_norm", "relative_decrease", "trust_region_radius")}
+        ok = np.zeros(log_capacity, dtype=np.int32)
+        lg = IterationLog(log_capacity, *[_p(arrs[k]) for k in ("cost", "cost_change", "gradient_max_norm",
+                                                                 "step_norm", "relative_decrease",
+                                                                 "trust_region_radius")],
+                          ok.ctypes.data_as(_i32p))
+        lib().orc_solve(C.byref(self.c), C.byref(o), C.byref(s), C.byref(lg))
+        n = min(s.num_iterations, log_capacity)
+        log = {k: v[:n].copy() for k, v in arrs.items()}
+        log["step_is_successful"] = ok[:n].copy()
+        return s, log
+
+
+# ---- thin functional wrappers over the L1/L2 restatements ---------------------
+def se3_transform(T, p):
+    out = np.zeros(3)
+    lib().orc_se3_transform(_p(np.ascontiguousarray(T, dtype=np.float64)), _p(np.ascontiguousarray(p, dtype=np.float64)), _p(out))
+    return out
+
+
+def so3_exp(phi):
+    out = np.zeros(9)
+    lib().orc_so3_exp(_p(np.ascontiguousarray(phi, dtype=np.float64)), _p(out))
+    return out.reshape(3, 3)
+
+
+def se3_plus(T, eps):
+    out = np.zeros(12)
+    lib().orc_se3_plus(_p(np.ascontiguousarray(T, dtype=np.float64)), _p(np.ascontiguousarray(eps, dtype=np.float64)), _p(out))
+    return out
+
+
+def se3_inverse(T):
+    out = np.zeros(12)
+    lib().orc_se3_inverse(_p(np.ascontiguousarray(T, dtype=np.float64)), _p(out))
+    return out
+
+
+def project(camera: dict, q, jac: bool = False):
+    cam = Camera(**camera)
+    out, J = np.zeros(3), np.zeros(9)
+    lib().orc_project(C.byref(cam), _p(np.ascontiguousarray(q, dtype=np.float64)), _p(out), _p(J) if jac else None)
+    return (out, J.reshape(3, 3)) if jac else out
+
+
+def triangulate(camera: dict, uvd, jac: bool = False):
+    cam = Camera(**camera)
+    out, J = np.zeros(3), np.zeros(9)
+    lib().orc_triangulate(C.byref(cam), _p(np.ascontiguousarray(uvd, dtype=np.float64)), _p(out), _p(J) if jac else None)
+    return (out, J.reshape(3, 3)) if jac else out
+
+
+def stereo_residual(camera: dict, T, p, z, S, jac: bool = False):
+    cam = Camera(**camera)
+    r, Jp, Jl = np.zeros(3), np.zeros(18), np.zeros(9)
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (T, p, z, np.asarray(S).reshape(9))]
+    lib().orc_stereo_residual(C.byref(cam), *[_p(a) for a in args], _p(r),
+                              _p(Jp) if jac else None, _p(Jl) if jac else None)
+    return (r, Jp.reshape(3, 6), Jl.reshape(3, 3)) if jac else r
+
+
+def huber(a: float, s: float):
+    rho = np.zeros(3)
+    lib().orc_huber(a, s, _p(rho))
+    return rho

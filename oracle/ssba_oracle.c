@@ -1,0 +1,1016 @@
+/*
+ * ssba_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see ssba_oracle.h).
+ *
+ * CPU restatement of the ceres-slam stereo bundle-adjustment hot path.
+ * PARITY UNPINNED at the Ceres boundary (header comment of ssba_oracle.h).
+ * File:line citations are into /root/reference.
+ */
+#include "ssba_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------------ */
+/* L1 math                                                                    */
+/* ------------------------------------------------------------------------ */
+
+/* include/ceres_slam/geometry/se3group.hpp:191-193  p' = R p + t, block layout
+ * [t | R row-major] (se3group.hpp:425-429, so3group.hpp:34). */
+void orc_se3_transform(const double T[12], const double p[3], double out[3]) {
+    const double *t = T, *R = T + 3;
+    out[0] = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
+    out[1] = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
+    out[2] = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+}
+
+/* include/ceres_slam/geometry/so3group.hpp:273-291 (wedge :248-254).
+ * angle <= DBL_EPSILON -> I + phi^ ; else cos*I + (1-cos) a a^T + sin * a^ */
+void orc_so3_exp(const double phi[3], double R[9]) {
+    double angle = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+    if (angle <= DBL_EPSILON) {
+        R[0] = 1.0;     R[1] = -phi[2]; R[2] = phi[1];
+        R[3] = phi[2];  R[4] = 1.0;     R[5] = -phi[0];
+        R[6] = -phi[1]; R[7] = phi[0];  R[8] = 1.0;
+        return;
+    }
+    double a[3] = {phi[0] / angle, phi[1] / angle, phi[2] / angle};
+    double cp = cos(angle), sp = sin(angle), omc = 1.0 - cp;
+    R[0] = cp + omc * a[0] * a[0];
+    R[1] = omc * a[0] * a[1] - sp * a[2];
+    R[2] = omc * a[0] * a[2] + sp * a[1];
+    R[3] = omc * a[1] * a[0] + sp * a[2];
+    R[4] = cp + omc * a[1] * a[1];
+    R[5] = omc * a[1] * a[2] - sp * a[0];
+    R[6] = omc * a[2] * a[0] - sp * a[1];
+    R[7] = omc * a[2] * a[1] + sp * a[0];
+    R[8] = cp + omc * a[2] * a[2];
+}
+
+/* include/ceres_slam/perturbations.hpp:45-65: T_new = exp(eps) * T with
+ * exp(xi) = (xi[0:3], Exp_SO3(xi[3:6])) (se3group.hpp:323-325, NOT the true SE(3)
+ * exponential) and the product of se3group.hpp:176-183:
+ *   R_new = E R,  t_new = E t + rho. */
+void orc_se3_plus(const double T[12], const double eps[6], double out[12]) {
+    double E[9];
+    orc_so3_exp(eps + 3, E);
+    const double *t = T, *R = T + 3;
+    double tn[3], Rn[9];
+    for (int i = 0; i < 3; ++i) {
+        tn[i] = E[3 * i] * t[0] + E[3 * i + 1] * t[1] + E[3 * i + 2] * t[2] + eps[i];
+        for (int j = 0; j < 3; ++j)
+            Rn[3 * i + j] = E[3 * i] * R[j] + E[3 * i + 1] * R[3 + j] + E[3 * i + 2] * R[6 + j];
+    }
+    memcpy(out, tn, sizeof tn);
+    memcpy(out + 3, Rn, sizeof Rn);
+}
+
+/* se3group.hpp:152-158: R^-1 = R^T (so3group.hpp inverse = transpose), t' = -(R^T t) */
+void orc_se3_inverse(const double T[12], double out[12]) {
+    const double *t = T, *R = T + 3;
+    double o[12];
+    for (int i = 0; i < 3; ++i) {
+        o[i] = -(R[i] * t[0] + R[3 + i] * t[1] + R[6 + i] * t[2]);
+        for (int j = 0; j < 3; ++j) o[3 + 3 * i + j] = R[3 * j + i];
+    }
+    memcpy(out, o, sizeof o);
+}
+
+/* include/ceres_slam/stereo_camera.hpp:77-108 */
+void orc_project(const orc_camera *c, const double q[3], double uvd[3], double J[9]) {
+    double one_over_z = 1.0 / q[2];
+    uvd[0] = c->fu * q[0] * one_over_z + c->cu;
+    uvd[1] = c->fv * q[1] * one_over_z + c->cv;
+    uvd[2] = c->fu * c->b * one_over_z;
+    if (J) {
+        double one_over_z2 = one_over_z * one_over_z;
+        J[0] = c->fu * one_over_z; J[1] = 0.0;                J[2] = -c->fu * q[0] * one_over_z2;
+        J[3] = 0.0;                J[4] = c->fv * one_over_z; J[5] = -c->fv * q[1] * one_over_z2;
+        J[6] = 0.0;                J[7] = 0.0;                J[8] = -c->fu * c->b * one_over_z2;
+    }
+}
+
+/* include/ceres_slam/stereo_camera.hpp:112-144 */
+void orc_triangulate(const orc_camera *c, const double uvd[3], double q[3], double J[9]) {
+    double b_over_d = c->b / uvd[2];
+    double fu_over_fv = c->fu / c->fv;
+    q[0] = (uvd[0] - c->cu) * b_over_d;
+    q[1] = (uvd[1] - c->cv) * b_over_d * fu_over_fv;
+    q[2] = c->fu * b_over_d;
+    if (J) {
+        double b_over_d2 = b_over_d / uvd[2];
+        J[0] = b_over_d; J[1] = 0.0;                   J[2] = (c->cu - uvd[0]) * b_over_d2;
+        J[3] = 0.0;      J[4] = b_over_d * fu_over_fv; J[5] = (c->cv - uvd[1]) * b_over_d2 * fu_over_fv;
+        J[6] = 0.0;      J[7] = 0.0;                   J[8] = -c->fu * b_over_d2;
+    }
+}
+
+/* include/ceres_slam/stereo_reprojection_error.hpp:27-55:
+ *     r = S * (project(T_c_g * pt_g) - z).
+ * Local Jacobians (what AutoDiffCostFunction<...,3,12,3> x
+ * AutoDiffLocalParameterization<SE3Perturbation,12,6> produce at eps = 0, where
+ * so3group.hpp:277-280 takes the first-order branch):
+ *     q(eps) = (I + phi^)(R p + t) + rho  =>  dq/deps = [ I | -q^ ],  dq/dp = R
+ *     Jp = S Jpi [ I | -q^ ]  (3x6),   Jl = S Jpi R  (3x3). */
+void orc_stereo_residual(const orc_camera *c, const double T[12], const double p[3],
+                         const double z[3], const double S[9], double r[3],
+                         double *Jp, double *Jl) {
+    double q[3], pred[3], Jpi[9];
+    orc_se3_transform(T, p, q);
+    orc_project(c, q, pred, (Jp || Jl) ? Jpi : NULL);
+    double e[3] = {pred[0] - z[0], pred[1] - z[1], pred[2] - z[2]};
+    for (int i = 0; i < 3; ++i) r[i] = S[3 * i] * e[0] + S[3 * i + 1] * e[1] + S[3 * i + 2] * e[2];
+    if (!(Jp || Jl)) return;
+    double A[9]; /* S * Jpi */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            A[3 * i + j] = S[3 * i] * Jpi[j] + S[3 * i + 1] * Jpi[3 + j] + S[3 * i + 2] * Jpi[6 + j];
+    if (Jp) {
+        /* -q^ = [[0, q2, -q1], [-q2, 0, q0], [q1, -q0, 0]] */
+        for (int i = 0; i < 3; ++i) {
+            const double *a = A + 3 * i;
+            Jp[6 * i + 0] = a[0];
+            Jp[6 * i + 1] = a[1];
+            Jp[6 * i + 2] = a[2];
+            Jp[6 * i + 3] = -a[1] * q[2] + a[2] * q[1];
+            Jp[6 * i + 4] = a[0] * q[2] - a[2] * q[0];
+            Jp[6 * i + 5] = -a[0] * q[1] + a[1] * q[0];
+        }
+    }
+    if (Jl) {
+        const double *R = T + 3;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                Jl[3 * i + j] = A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j];
+    }
+}
+
+/* [Ceres 1.x loss_function.cc, HuberLoss::Evaluate; call-site shape
+ * tests/dataset_vo_sun.cpp:89-95]  s = |r|^2, b = a^2 */
+void orc_huber(double a, double s, double rho[3]) {
+    double b = a * a;
+    if (s > b) {
+        double r = sqrt(s);
+        rho[0] = 2.0 * a * r - b;
+        rho[1] = fmax(DBL_MIN, a / r);
+        rho[2] = -rho[1] / (2.0 * s);
+    } else {
+        rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+}
+
+/* [Ceres 1.x corrector.cc] rescale r and J so that Gauss-Newton on the corrected
+ * system is the Triggs correction of the robustified cost. */
+static void corrector(const double rho[3], double sq_norm, double r[3], double *Jp, double *Jl) {
+    double sqrt_rho1 = sqrt(rho[1]);
+    double residual_scaling, alpha_sq_norm;
+    if (sq_norm == 0.0 || rho[2] <= 0.0) {
+        residual_scaling = sqrt_rho1;
+        alpha_sq_norm = 0.0;
+    } else {
+        double D = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+        double alpha = 1.0 - sqrt(D);
+        residual_scaling = sqrt_rho1 / (1.0 - alpha);
+        alpha_sq_norm = alpha / sq_norm;
+    }
+    /* Jacobians first (they use the uncorrected residual), then the residual */
+    double *Js[2] = {Jp, Jl};
+    int cols[2] = {6, 3};
+    for (int m = 0; m < 2; ++m) {
+        double *J = Js[m];
+        if (!J) continue;
+        int nc = cols[m];
+        if (alpha_sq_norm == 0.0) {
+            for (int i = 0; i < 3 * nc; ++i) J[i] *= sqrt_rho1;
+        } else {
+            for (int c = 0; c < nc; ++c) {
+                double rtj = r[0] * J[c] + r[1] * J[nc + c] + r[2] * J[2 * nc + c];
+                for (int i = 0; i < 3; ++i)
+                    J[i * nc + c] = sqrt_rho1 * (J[i * nc + c] - alpha_sq_norm * r[i] * rtj);
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i) r[i] *= residual_scaling;
+}
+
+void orc_default_options(orc_options *o) {
+    /* Ceres 1.x Solver::Options defaults; the reference drivers override
+     * max_num_iterations = 1000, use_nonmonotonic_steps = true, num_threads = 8
+     * (tests/dataset_vo.cpp:65-70). */
+    o->max_num_iterations = 50;
+    o->use_nonmonotonic_steps = 0;
+    o->max_consecutive_nonmonotonic_steps = 5;
+    o->jacobi_scaling = 1;
+    o->num_threads = 1;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+}
+
+/* ------------------------------------------------------------------------ */
+/* evaluation                                                                 */
+/* ------------------------------------------------------------------------ */
+
+static void set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* Evaluate all residual blocks.  r (N*3), Jp (N*18), Jl (N*9) may be NULL.
+ * Returns cost = 1/2 sum rho(|r|^2); r/J are the loss-CORRECTED quantities, as
+ * Ceres's ResidualBlock::Evaluate hands them to the minimiser. */
+static double evaluate(const orc_problem *p, const double *poses, const double *points,
+                       double *r_out, double *Jp_out, double *Jl_out) {
+    const int64_t N = p->num_obs;
+    double cost = 0.0;
+#pragma omp parallel for reduction(+ : cost) schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        double r[3], Jp[18], Jl[9];
+        int wantJ = (Jp_out != NULL);
+        orc_stereo_residual(&p->cam, poses + 12 * (int64_t)p->obs_pose[i],
+                            points + 3 * (int64_t)p->obs_point[i], p->obs_uvd + 3 * i,
+                            p->stiffness, r, wantJ ? Jp : NULL, wantJ ? Jl : NULL);
+        double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        if (p->huber_a > 0.0) {
+            double rho[3];
+            orc_huber(p->huber_a, sq, rho);
+            cost += 0.5 * rho[0];
+            corrector(rho, sq, r, wantJ ? Jp : NULL, wantJ ? Jl : NULL);
+        } else {
+            cost += 0.5 * sq;
+        }
+        if (r_out) memcpy(r_out + 3 * i, r, sizeof r);
+        if (wantJ) {
+            memcpy(Jp_out + 18 * i, Jp, sizeof Jp);
+            memcpy(Jl_out + 9 * i, Jl, sizeof Jl);
+        }
+    }
+    return cost;
+}
+
+double orc_cost(const orc_problem *p, int num_threads) {
+    set_threads(num_threads);
+    return evaluate(p, p->poses, p->points, NULL, NULL, NULL);
+}
+
+/* ------------------------------------------------------------------------ */
+/* graph bookkeeping                                                          */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    int P, L, nfree;
+    int64_t N;
+    int *free_idx;       /* P: index among free poses or -1 (constant / unobserved) */
+    int *free_pose;      /* nfree -> pose id                                      */
+    uint8_t *pt_active;  /* L: has at least one observation                       */
+    int64_t *pose_start; /* P+1 CSR over observations (pose-major)                */
+    int64_t *pose_obs;   /* N                                                     */
+    int64_t *pt_start;   /* L+1 CSR (landmark-major)                              */
+    int64_t *pt_obs;     /* N                                                     */
+    int bw_poses;        /* max |free_idx(a)-free_idx(b)| over co-observing poses */
+} graph_t;
+
+static void graph_free(graph_t *g) {
+    free(g->free_idx); free(g->free_pose); free(g->pt_active);
+    free(g->pose_start); free(g->pose_obs); free(g->pt_start); free(g->pt_obs);
+}
+
+static void graph_build(const orc_problem *p, graph_t *g) {
+    memset(g, 0, sizeof *g);
+    int P = p->num_poses, L = p->num_points;
+    int64_t N = p->num_obs;
+    g->P = P; g->L = L; g->N = N;
+    g->pose_start = calloc((size_t)P + 1, sizeof(int64_t));
+    g->pt_start = calloc((size_t)L + 1, sizeof(int64_t));
+    g->pose_obs = malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
+    g->pt_obs = malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
+    for (int64_t i = 0; i < N; ++i) {
+        g->pose_start[p->obs_pose[i] + 1]++;
+        g->pt_start[p->obs_point[i] + 1]++;
+    }
+    for (int k = 0; k < P; ++k) g->pose_start[k + 1] += g->pose_start[k];
+    for (int j = 0; j < L; ++j) g->pt_start[j + 1] += g->pt_start[j];
+    int64_t *pc = malloc((size_t)P * sizeof(int64_t)), *lc = malloc((size_t)L * sizeof(int64_t));
+    memcpy(pc, g->pose_start, (size_t)P * sizeof(int64_t));
+    memcpy(lc, g->pt_start, (size_t)L * sizeof(int64_t));
+    for (int64_t i = 0; i < N; ++i) { /* stable: keeps the reference's file order */
+        g->pose_obs[pc[p->obs_pose[i]]++] = i;
+        g->pt_obs[lc[p->obs_point[i]]++] = i;
+    }
+    free(pc); free(lc);
+    g->free_idx = malloc((size_t)P * sizeof(int));
+    g->free_pose = malloc((size_t)(P > 0 ? P : 1) * sizeof(int));
+    g->pt_active = malloc((size_t)(L > 0 ? L : 1));
+    int nf = 0;
+    for (int k = 0; k < P; ++k) {
+        int in_problem = g->pose_start[k + 1] > g->pose_start[k];
+        int is_const = p->pose_const && p->pose_const[k];
+        if (in_problem && !is_const) { g->free_idx[k] = nf; g->free_pose[nf++] = k; }
+        else g->free_idx[k] = -1;
+    }
+    g->nfree = nf;
+    int bw = 0;
+    for (int j = 0; j < L; ++j) {
+        g->pt_active[j] = g->pt_start[j + 1] > g->pt_start[j];
+        int lo = 1 << 30, hi = -1;
+        for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
+            int f = g->free_idx[p->obs_pose[g->pt_obs[e]]];
+            if (f < 0) continue;
+            if (f < lo) lo = f;
+            if (f > hi) hi = f;
+        }
+        if (hi >= 0 && hi - lo > bw) bw = hi - lo;
+    }
+    g->bw_poses = bw;
+}
+
+/* ------------------------------------------------------------------------ */
+/* small dense helpers                                                        */
+/* ------------------------------------------------------------------------ */
+
+/* inverse of a 3x3 SPD matrix through its Cholesky factor
+ * [Ceres: InvertPSDMatrix -> LLT solve for fixed-size blocks] */
+static int inv3_spd(const double C[9], double Ci[9]) {
+    double l00 = C[0];
+    if (!(l00 > 0.0)) return -1;
+    l00 = sqrt(l00);
+    double l10 = C[3] / l00, l20 = C[6] / l00;
+    double d1 = C[4] - l10 * l10;
+    if (!(d1 > 0.0)) return -1;
+    double l11 = sqrt(d1);
+    double l21 = (C[7] - l20 * l10) / l11;
+    double d2 = C[8] - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return -1;
+    double l22 = sqrt(d2);
+    /* M = L^-1 (lower) */
+    double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+    double m10 = -l10 * m00 * m11;
+    double m21 = -l21 * m11 * m22;
+    double m20 = -(l20 * m00 + l21 * m10) * m22;
+    /* C^-1 = M^T M */
+    Ci[0] = m00 * m00 + m10 * m10 + m20 * m20;
+    Ci[1] = Ci[3] = m10 * m11 + m20 * m21;
+    Ci[2] = Ci[6] = m20 * m22;
+    Ci[4] = m11 * m11 + m21 * m21;
+    Ci[5] = Ci[7] = m21 * m22;
+    Ci[8] = m22 * m22;
+    return 0;
+}
+
+/* banded Cholesky, lower band storage A[i*(bw+1) + (j-i+bw)], j in [i-bw, i] */
+static int band_cholesky(double *A, int n, int bw) {
+    const int ld = bw + 1;
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * ld + bw];
+        int k0 = j - bw < 0 ? 0 : j - bw;
+        for (int k = k0; k < j; ++k) {
+            double l = A[(size_t)j * ld + (k - j + bw)];
+            d -= l * l;
+        }
+        if (!(d > 0.0) || !isfinite(d)) return -1;
+        d = sqrt(d);
+        A[(size_t)j * ld + bw] = d;
+        int iend = j + bw < n - 1 ? j + bw : n - 1;
+#pragma omp parallel for schedule(static) if (iend - j > 256)
+        for (int i = j + 1; i <= iend; ++i) {
+            double s = A[(size_t)i * ld + (j - i + bw)];
+            int kk0 = i - bw < 0 ? 0 : i - bw;
+            if (kk0 < k0) kk0 = k0;
+            for (int k = kk0; k < j; ++k)
+                s -= A[(size_t)i * ld + (k - i + bw)] * A[(size_t)j * ld + (k - j + bw)];
+            A[(size_t)i * ld + (j - i + bw)] = s / d;
+        }
+    }
+    return 0;
+}
+
+static void band_solve(const double *A, int n, int bw, double *x) {
+    const int ld = bw + 1;
+    for (int i = 0; i < n; ++i) {
+        double s = x[i];
+        int k0 = i - bw < 0 ? 0 : i - bw;
+        for (int k = k0; k < i; ++k) s -= A[(size_t)i * ld + (k - i + bw)] * x[k];
+        x[i] = s / A[(size_t)i * ld + bw];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        int kend = i + bw < n - 1 ? i + bw : n - 1;
+        for (int k = i + 1; k <= kend; ++k) s -= A[(size_t)k * ld + (i - k + bw)] * x[k];
+        x[i] = s / A[(size_t)i * ld + bw];
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* linearisation + LM step                                                    */
+/* ------------------------------------------------------------------------ */
+
+typedef struct {
+    double *r;       /* N*3  corrected residuals                     */
+    double *Jp;      /* N*18 corrected, unscaled                     */
+    double *Jl;      /* N*9                                          */
+    double *g_p;     /* nfree*6 unscaled gradient J^T r              */
+    double *g_l;     /* L*3                                          */
+    double *sq_p;    /* nfree*6 squared column norms of unscaled J   */
+    double *sq_l;    /* L*3                                          */
+    double cost;
+} lin_t;
+
+static void lin_alloc(lin_t *w, const graph_t *g) {
+    size_t N = (size_t)(g->N > 0 ? g->N : 1), nf = (size_t)(g->nfree > 0 ? g->nfree : 1),
+           L = (size_t)(g->L > 0 ? g->L : 1);
+    w->r = malloc(N * 3 * sizeof(double));
+    w->Jp = malloc(N * 18 * sizeof(double));
+    w->Jl = malloc(N * 9 * sizeof(double));
+    w->g_p = malloc(nf * 6 * sizeof(double));
+    w->g_l = malloc(L * 3 * sizeof(double));
+    w->sq_p = malloc(nf * 6 * sizeof(double));
+    w->sq_l = malloc(L * 3 * sizeof(double));
+}
+static void lin_free(lin_t *w) {
+    free(w->r); free(w->Jp); free(w->Jl); free(w->g_p); free(w->g_l); free(w->sq_p); free(w->sq_l);
+}
+
+/* [Ceres evaluator: residuals, cost, Jacobian, gradient = J^T r at x] */
+static void linearize(const orc_problem *p, const graph_t *g, const double *poses,
+                      const double *points, lin_t *w) {
+    w->cost = evaluate(p, poses, points, w->r, w->Jp, w->Jl);
+#pragma omp parallel for schedule(static)
+    for (int f = 0; f < g->nfree; ++f) {
+        int k = g->free_pose[f];
+        double gp[6] = {0}, sq[6] = {0};
+        for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
+            int64_t i = g->pose_obs[e];
+            const double *J = w->Jp + 18 * i, *r = w->r + 3 * i;
+            for (int c = 0; c < 6; ++c) {
+                gp[c] += J[c] * r[0] + J[6 + c] * r[1] + J[12 + c] * r[2];
+                sq[c] += J[c] * J[c] + J[6 + c] * J[6 + c] + J[12 + c] * J[12 + c];
+            }
+        }
+        memcpy(w->g_p + 6 * f, gp, sizeof gp);
+        memcpy(w->sq_p + 6 * f, sq, sizeof sq);
+    }
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < g->L; ++j) {
+        double gl[3] = {0}, sq[3] = {0};
+        for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
+            int64_t i = g->pt_obs[e];
+            const double *J = w->Jl + 9 * i, *r = w->r + 3 * i;
+            for (int c = 0; c < 3; ++c) {
+                gl[c] += J[c] * r[0] + J[3 + c] * r[1] + J[6 + c] * r[2];
+                sq[c] += J[c] * J[c] + J[3 + c] * J[3 + c] + J[6 + c] * J[6 + c];
+            }
+        }
+        memcpy(w->g_l + 3 * j, gl, sizeof gl);
+        memcpy(w->sq_l + 3 * j, sq, sizeof sq);
+    }
+}
+
+double orc_linearize(const orc_problem *p, double *g_p, double *g_l, double *H_pp,
+                     double *H_ll, int num_threads) {
+    set_threads(num_threads);
+    const int64_t N = p->num_obs;
+    size_t n = (size_t)(N > 0 ? N : 1);
+    double *r = malloc(n * 3 * sizeof(double)), *Jp = malloc(n * 18 * sizeof(double)),
+           *Jl = malloc(n * 9 * sizeof(double));
+    double cost = evaluate(p, p->poses, p->points, r, Jp, Jl);
+    memset(g_p, 0, (size_t)p->num_poses * 6 * sizeof(double));
+    memset(g_l, 0, (size_t)p->num_points * 3 * sizeof(double));
+    memset(H_pp, 0, (size_t)p->num_poses * 36 * sizeof(double));
+    memset(H_ll, 0, (size_t)p->num_points * 9 * sizeof(double));
+    for (int64_t i = 0; i < N; ++i) { /* serial, reference residual-block order */
+        const double *a = Jp + 18 * i, *b = Jl + 9 * i, *ri = r + 3 * i;
+        double *gp = g_p + 6 * (size_t)p->obs_pose[i], *gl = g_l + 3 * (size_t)p->obs_point[i];
+        double *hp = H_pp + 36 * (size_t)p->obs_pose[i], *hl = H_ll + 9 * (size_t)p->obs_point[i];
+        for (int c = 0; c < 6; ++c) {
+            gp[c] += a[c] * ri[0] + a[6 + c] * ri[1] + a[12 + c] * ri[2];
+            for (int d = 0; d < 6; ++d)
+                hp[6 * c + d] += a[c] * a[d] + a[6 + c] * a[6 + d] + a[12 + c] * a[12 + d];
+        }
+        for (int c = 0; c < 3; ++c) {
+            gl[c] += b[c] * ri[0] + b[3 + c] * ri[1] + b[6 + c] * ri[2];
+            for (int d = 0; d < 3; ++d)
+                hl[3 * c + d] += b[c] * b[d] + b[3 + c] * b[3 + d] + b[6 + c] * b[6 + d];
+        }
+    }
+    free(r); free(Jp); free(Jl);
+    return cost;
+}
+
+/* Jacobi scaling [Ceres trust_region_minimizer.cc IterationZero]:
+ *   scale = 1 / (1 + sqrt(squared column norm)) computed once at iteration 0 */
+static void jacobi_scale(const graph_t *g, const lin_t *w, int enabled, double *sp, double *sl) {
+    for (int i = 0; i < g->nfree * 6; ++i) sp[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_p[i])) : 1.0;
+    for (int i = 0; i < g->L * 3; ++i) sl[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_l[i])) : 1.0;
+}
+
+typedef struct {
+    double *S;    /* band storage n x (bw+1)                               */
+    double *rhs;  /* n                                                     */
+    double *Ci;   /* L*9   inverse of damped landmark blocks (scaled)       */
+    double *W;    /* N*18  Jp_s^T Jl_s (6x3)                                */
+    double *gl_s; /* L*3   scaled landmark gradient                         */
+    int n, bw;
+    double t_schur, t_solve;
+} schur_t;
+
+/* Build the Schur-complemented reduced camera system in SCALED coordinates
+ * [Ceres schur_eliminator_impl.h restated; LM diagonal of
+ * levenberg_marquardt_strategy.cc: D^2 = clamp(diag(J_s^T J_s), min, max)/radius]. */
+static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
+                         const double *sp, const double *sl, double radius,
+                         const orc_options *o, schur_t *sc) {
+    const int nf = g->nfree, L = g->L;
+    const int n = 6 * nf;
+    int bw = 6 * (g->bw_poses + 1) - 1;
+    if (bw > n - 1) bw = n - 1;
+    if (bw < 0) bw = 0;
+    sc->n = n; sc->bw = bw;
+    const int ld = bw + 1;
+    sc->S = calloc((size_t)(n > 0 ? n : 1) * ld, sizeof(double));
+    sc->rhs = calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    sc->Ci = malloc((size_t)(L > 0 ? L : 1) * 9 * sizeof(double));
+    sc->W = malloc((size_t)(g->N > 0 ? g->N : 1) * 18 * sizeof(double));
+    sc->gl_s = malloc((size_t)(L > 0 ? L : 1) * 3 * sizeof(double));
+    int bad = 0;
+
+    /* landmark blocks C_j = sum Jl_s^T Jl_s + D_l^2 and their inverses */
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int j = 0; j < L; ++j) {
+        double C[9] = {0};
+        const double *s = sl + 3 * j;
+        for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
+            const double *J = w->Jl + 9 * g->pt_obs[e];
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b)
+                    C[3 * a + b] += (J[a] * J[b] + J[3 + a] * J[3 + b] + J[6 + a] * J[6 + b]) * s[a] * s[b];
+        }
+        for (int a = 0; a < 3; ++a) {
+            double d = w->sq_l[3 * j + a] * s[a] * s[a];
+            d = fmin(fmax(d, o->min_lm_diagonal), o->max_lm_diagonal);
+            C[4 * a] += d / radius;
+            sc->gl_s[3 * j + a] = w->g_l[3 * j + a] * s[a];
+        }
+        if (!g->pt_active[j]) { memset(sc->Ci + 9 * j, 0, 9 * sizeof(double)); continue; }
+        if (inv3_spd(C, sc->Ci + 9 * j)) bad |= 1;
+    }
+    if (bad) return -1;
+
+    /* W_i = Jp_s^T Jl_s for observations of free poses */
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < g->N; ++i) {
+        int f = g->free_idx[p->obs_pose[i]];
+        double *Wi = sc->W + 18 * i;
+        if (f < 0) { memset(Wi, 0, 18 * sizeof(double)); continue; }
+        const double *a = w->Jp + 18 * i, *b = w->Jl + 9 * i;
+        const double *s6 = sp + 6 * f, *s3 = sl + 3 * (size_t)p->obs_point[i];
+        for (int c = 0; c < 6; ++c)
+            for (int d = 0; d < 3; ++d)
+                Wi[3 * c + d] = (a[c] * b[d] + a[6 + c] * b[3 + d] + a[12 + c] * b[6 + d]) * s6[c] * s3[d];
+    }
+
+    /* block-rows of S: each free pose owns its row (lower band) */
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int f = 0; f < nf; ++f) {
+        int k = g->free_pose[f];
+        double B[36] = {0}, gr[6];
+        const double *s6 = sp + 6 * f;
+        for (int c = 0; c < 6; ++c) gr[c] = w->g_p[6 * f + c] * s6[c];
+        for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
+            int64_t i = g->pose_obs[e];
+            const double *J = w->Jp + 18 * i;
+            for (int c = 0; c < 6; ++c)
+                for (int d = 0; d <= c; ++d)
+                    B[6 * c + d] += (J[c] * J[d] + J[6 + c] * J[6 + d] + J[12 + c] * J[12 + d]) * s6[c] * s6[d];
+        }
+        for (int c = 0; c < 6; ++c) {
+            double d = w->sq_p[6 * f + c] * s6[c] * s6[c];
+            d = fmin(fmax(d, o->min_lm_diagonal), o->max_lm_diagonal);
+            B[7 * c] += d / radius;
+        }
+        for (int c = 0; c < 6; ++c)
+            for (int d = 0; d <= c; ++d)
+                sc->S[(size_t)(6 * f + c) * ld + (d - c + bw)] += B[6 * c + d];
+        for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
+            int64_t i = g->pose_obs[e];
+            int j = (int)p->obs_point[i];
+            const double *Wi = sc->W + 18 * i, *Ci = sc->Ci + 9 * j;
+            double Y[18]; /* W_i C^-1 */
+            for (int c = 0; c < 6; ++c)
+                for (int d = 0; d < 3; ++d)
+                    Y[3 * c + d] = Wi[3 * c] * Ci[d] + Wi[3 * c + 1] * Ci[3 + d] + Wi[3 * c + 2] * Ci[6 + d];
+            for (int c = 0; c < 6; ++c)
+                gr[c] -= Y[3 * c] * sc->gl_s[3 * j] + Y[3 * c + 1] * sc->gl_s[3 * j + 1] + Y[3 * c + 2] * sc->gl_s[3 * j + 2];
+            for (int64_t e2 = g->pt_start[j]; e2 < g->pt_start[j + 1]; ++e2) {
+                int64_t i2 = g->pt_obs[e2];
+                int f2 = g->free_idx[p->obs_pose[i2]];
+                if (f2 < 0 || f2 > f) continue;
+                const double *W2 = sc->W + 18 * i2;
+                for (int c = 0; c < 6; ++c) {
+                    int dmax = (f2 == f) ? c : 5;
+                    for (int d = 0; d <= dmax; ++d) {
+                        double v = Y[3 * c] * W2[3 * d] + Y[3 * c + 1] * W2[3 * d + 1] + Y[3 * c + 2] * W2[3 * d + 2];
+                        sc->S[(size_t)(6 * f + c) * ld + ((6 * f2 + d) - (6 * f + c) + bw)] -= v;
+                    }
+                }
+            }
+        }
+        memcpy(sc->rhs + 6 * f, gr, sizeof gr);
+    }
+    return 0;
+}
+
+static void schur_free(schur_t *sc) {
+    free(sc->S); free(sc->rhs); free(sc->Ci); free(sc->W); free(sc->gl_s);
+}
+
+/* One LM step [Ceres LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver].
+ * Outputs the UNSCALED step (delta = scale .* step_scaled) and the model cost
+ * change  -(J d)^T (r + J d / 2)  [TrustRegionMinimizer::ComputeTrustRegionStep]. */
+static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const double *sp,
+                   const double *sl, double radius, const orc_options *o, double *dp,
+                   double *dl, double *model_cost_change, double *t_schur, double *t_solve) {
+    schur_t sc;
+    memset(&sc, 0, sizeof sc);
+    double t0 = now_s();
+    int rc = build_reduced(p, g, w, sp, sl, radius, o, &sc);
+    double t1 = now_s();
+    if (t_schur) *t_schur += t1 - t0;
+    if (rc) { schur_free(&sc); return -1; }
+    if (sc.n > 0) {
+        if (band_cholesky(sc.S, sc.n, sc.bw)) { schur_free(&sc); return -1; }
+        band_solve(sc.S, sc.n, sc.bw, sc.rhs);
+    }
+    double t2 = now_s();
+    if (t_solve) *t_solve += t2 - t1;
+    /* y_p = rhs ; y_l = C^-1 (g_l - sum W^T y_p); step = -y; delta = scale * step */
+    const double *yp = sc.rhs;
+    int ok = 1;
+#pragma omp parallel for schedule(static) reduction(& : ok)
+    for (int j = 0; j < g->L; ++j) {
+        double t[3] = {sc.gl_s[3 * j], sc.gl_s[3 * j + 1], sc.gl_s[3 * j + 2]};
+        for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
+            int64_t i = g->pt_obs[e];
+            int f = g->free_idx[p->obs_pose[i]];
+            if (f < 0) continue;
+            const double *Wi = sc.W + 18 * i, *y = yp + 6 * f;
+            for (int d = 0; d < 3; ++d)
+                for (int c = 0; c < 6; ++c) t[d] -= Wi[3 * c + d] * y[c];
+        }
+        const double *Ci = sc.Ci + 9 * j;
+        for (int a = 0; a < 3; ++a) {
+            double y = Ci[3 * a] * t[0] + Ci[3 * a + 1] * t[1] + Ci[3 * a + 2] * t[2];
+            double v = -y * sl[3 * j + a];
+            if (!g->pt_active[j]) v = 0.0;
+            if (!isfinite(v)) ok = 0;
+            dl[3 * j + a] = v;
+        }
+    }
+    memset(dp, 0, (size_t)g->P * 6 * sizeof(double));
+    for (int f = 0; f < g->nfree; ++f)
+        for (int c = 0; c < 6; ++c) {
+            double v = -yp[6 * f + c] * sp[6 * f + c];
+            if (!isfinite(v)) ok = 0;
+            dp[6 * g->free_pose[f] + c] = v;
+        }
+    schur_free(&sc);
+    if (!ok) return -1;
+    double mcc = 0.0;
+#pragma omp parallel for reduction(+ : mcc) schedule(static)
+    for (int64_t i = 0; i < g->N; ++i) {
+        const double *a = w->Jp + 18 * i, *b = w->Jl + 9 * i, *r = w->r + 3 * i;
+        const double *d6 = dp + 6 * (size_t)p->obs_pose[i], *d3 = dl + 3 * (size_t)p->obs_point[i];
+        for (int m = 0; m < 3; ++m) {
+            double jd = b[3 * m] * d3[0] + b[3 * m + 1] * d3[1] + b[3 * m + 2] * d3[2];
+            if (g->free_idx[p->obs_pose[i]] >= 0)
+                for (int c = 0; c < 6; ++c) jd += a[6 * m + c] * d6[c];
+            mcc -= jd * (r[m] + 0.5 * jd);
+        }
+    }
+    *model_cost_change = mcc;
+    return 0;
+}
+
+int orc_lm_step(const orc_problem *p, double radius, const orc_options *o, double *delta_p,
+                double *delta_l, double *model_cost_change) {
+    set_threads(o->num_threads);
+    graph_t g;
+    graph_build(p, &g);
+    lin_t w;
+    lin_alloc(&w, &g);
+    linearize(p, &g, p->poses, p->points, &w);
+    double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
+    double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * 3 * sizeof(double));
+    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
+    int rc = lm_step(p, &g, &w, sp, sl, radius, o, delta_p, delta_l, model_cost_change, NULL, NULL);
+    free(sp); free(sl);
+    lin_free(&w);
+    graph_free(&g);
+    return rc;
+}
+
+int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o, double *S,
+                       double *rhs, int32_t *free_pose_index) {
+    set_threads(o->num_threads);
+    graph_t g;
+    graph_build(p, &g);
+    lin_t w;
+    lin_alloc(&w, &g);
+    linearize(p, &g, p->poses, p->points, &w);
+    double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
+    double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * 3 * sizeof(double));
+    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
+    schur_t sc;
+    memset(&sc, 0, sizeof sc);
+    int rc = build_reduced(p, &g, &w, sp, sl, radius, o, &sc);
+    if (!rc) {
+        /* un-scale: S_unscaled = diag(1/s) S_s diag(1/s), rhs_unscaled = -(1/s) rhs_s
+         * so that S_unscaled * delta_p = rhs_unscaled (delta = -s .* y). */
+        int n = sc.n, ld = sc.bw + 1;
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = 0.0;
+            rhs[i] = -sc.rhs[i] / sp[i];
+        }
+        for (int i = 0; i < n; ++i) {
+            int j0 = i - sc.bw < 0 ? 0 : i - sc.bw;
+            for (int j = j0; j <= i; ++j) {
+                double v = sc.S[(size_t)i * ld + (j - i + sc.bw)] / (sp[i] * sp[j]);
+                S[(size_t)i * n + j] = v;
+                S[(size_t)j * n + i] = v;
+            }
+        }
+        for (int k = 0; k < g.P; ++k) free_pose_index[k] = g.free_idx[k];
+    }
+    schur_free(&sc);
+    free(sp); free(sl);
+    lin_free(&w);
+    graph_free(&g);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* trust-region minimiser [Ceres 1.13/1.14 trust_region_minimizer.cc]         */
+/* ------------------------------------------------------------------------ */
+
+/* Evaluator::Plus: SE3Perturbation on free poses, Euclidean on active points */
+static void plus_all(const graph_t *g, const double *poses, const double *points,
+                     const double *dp, const double *dl, double *poses_out, double *points_out) {
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < g->P; ++k) {
+        if (g->free_idx[k] >= 0) orc_se3_plus(poses + 12 * k, dp + 6 * k, poses_out + 12 * k);
+        else memcpy(poses_out + 12 * k, poses + 12 * k, 12 * sizeof(double));
+    }
+#pragma omp parallel for schedule(static)
+    for (int j = 0; j < g->L; ++j)
+        for (int a = 0; a < 3; ++a)
+            points_out[3 * j + a] = g->pt_active[j] ? points[3 * j + a] + dl[3 * j + a] : points[3 * j + a];
+}
+
+/* ambient-space norms over the reduced program's parameter blocks */
+static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, const double *pb,
+                        const double *qb, double *max_abs) {
+    double s = 0.0, m = 0.0;
+    for (int f = 0; f < g->nfree; ++f) {
+        int k = g->free_pose[f];
+        for (int c = 0; c < 12; ++c) {
+            double d = pa[12 * k + c] - (pb ? pb[12 * k + c] : 0.0);
+            s += d * d;
+            if (fabs(d) > m) m = fabs(d);
+        }
+    }
+    for (int j = 0; j < g->L; ++j) {
+        if (!g->pt_active[j]) continue;
+        for (int c = 0; c < 3; ++c) {
+            double d = qa[3 * j + c] - (qb ? qb[3 * j + c] : 0.0);
+            s += d * d;
+            if (fabs(d) > m) m = fabs(d);
+        }
+    }
+    if (max_abs) *max_abs = m;
+    return s;
+}
+
+/* TrustRegionStepEvaluator (Conn, Gould & Toint alg. 10.1.2) */
+typedef struct {
+    int max_nonmono, num_nonmono;
+    double minimum_cost, current_cost, reference_cost, candidate_cost;
+    double acc_reference_mcc, acc_candidate_mcc;
+} step_eval_t;
+
+static void se_init(step_eval_t *e, double cost, int max_nonmono) {
+    e->max_nonmono = max_nonmono; e->num_nonmono = 0;
+    e->minimum_cost = e->current_cost = e->reference_cost = e->candidate_cost = cost;
+    e->acc_reference_mcc = e->acc_candidate_mcc = 0.0;
+}
+static double se_quality(const step_eval_t *e, double cost, double mcc) {
+    double rd = (e->current_cost - cost) / mcc;
+    double hrd = (e->reference_cost - cost) / (e->acc_reference_mcc + mcc);
+    return rd > hrd ? rd : hrd;
+}
+static void se_accepted(step_eval_t *e, double cost, double mcc) {
+    e->current_cost = cost;
+    e->acc_candidate_mcc += mcc;
+    e->acc_reference_mcc += mcc;
+    if (e->current_cost < e->minimum_cost) {
+        e->minimum_cost = e->current_cost;
+        e->num_nonmono = 0;
+        e->candidate_cost = e->current_cost;
+        e->acc_candidate_mcc = 0.0;
+    } else {
+        ++e->num_nonmono;
+        if (e->current_cost > e->candidate_cost) {
+            e->candidate_cost = e->current_cost;
+            e->acc_candidate_mcc = 0.0;
+        }
+    }
+    if (e->num_nonmono == e->max_nonmono) {
+        e->reference_cost = e->candidate_cost;
+        e->acc_reference_mcc = e->acc_candidate_mcc;
+    }
+}
+
+static void log_push(orc_iteration_log *log, orc_summary *s, double cost, double cost_change,
+                     double gmax, double step_norm, double rd, double radius, int ok) {
+    int i = s->num_iterations++;
+    if (!log || i >= log->capacity) return;
+    log->cost[i] = cost; log->cost_change[i] = cost_change; log->gradient_max_norm[i] = gmax;
+    log->step_norm[i] = step_norm; log->relative_decrease[i] = rd;
+    log->trust_region_radius[i] = radius; log->step_is_successful[i] = ok;
+}
+
+int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteration_log *log) {
+    set_threads(o->num_threads);
+    memset(s, 0, sizeof *s);
+    double t_start = now_s();
+    graph_t g;
+    graph_build(p, &g);
+    const int P = g.P, L = g.L;
+    lin_t w;
+    lin_alloc(&w, &g);
+    size_t szP = (size_t)(P > 0 ? P : 1), szL = (size_t)(L > 0 ? L : 1);
+    double *x_pose = malloc(szP * 12 * sizeof(double)), *x_pt = malloc(szL * 3 * sizeof(double));
+    double *c_pose = malloc(szP * 12 * sizeof(double)), *c_pt = malloc(szL * 3 * sizeof(double));
+    double *best_pose = malloc(szP * 12 * sizeof(double)), *best_pt = malloc(szL * 3 * sizeof(double));
+    double *dp = calloc(szP * 6, sizeof(double)), *dl = calloc(szL * 3, sizeof(double));
+    double *ngp = calloc(szP * 6, sizeof(double)), *ngl = calloc(szL * 3, sizeof(double));
+    double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
+    double *sl = malloc(szL * 3 * sizeof(double));
+    memcpy(x_pose, p->poses, (size_t)P * 12 * sizeof(double));
+    memcpy(x_pt, p->points, (size_t)L * 3 * sizeof(double));
+    memcpy(best_pose, x_pose, (size_t)P * 12 * sizeof(double));
+    memcpy(best_pt, x_pt, (size_t)L * 3 * sizeof(double));
+
+    /* ---- IterationZero ---- */
+    double t0 = now_s();
+    linearize(p, &g, x_pose, x_pt, &w);
+    s->linearize_time_s += now_s() - t0;
+    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
+    double x_cost = w.cost, minimum_cost = x_cost;
+    double x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, NULL, NULL, NULL));
+    s->initial_cost = x_cost;
+    /* projected gradient: |x - Plus(x, -g)|_inf [EvaluateGradientAndJacobian] */
+    double gmax;
+#define GRADIENT_MAX_NORM()                                                              \
+    do {                                                                                 \
+        for (int f = 0; f < g.nfree; ++f)                                                \
+            for (int c = 0; c < 6; ++c) ngp[6 * g.free_pose[f] + c] = -w.g_p[6 * f + c]; \
+        for (int i = 0; i < 3 * L; ++i) ngl[i] = -w.g_l[i];                              \
+        plus_all(&g, x_pose, x_pt, ngp, ngl, c_pose, c_pt);                              \
+        x_sq_diff(&g, x_pose, x_pt, c_pose, c_pt, &gmax);                                \
+    } while (0)
+    GRADIENT_MAX_NORM();
+    double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
+    step_eval_t se;
+    se_init(&se, x_cost, o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0);
+    int iteration = 0, num_invalid = 0;
+    int term = -1;
+    /* iteration 0 is recorded with step_is_successful = false and therefore counts
+     * as an "unsuccessful step" in the Ceres 1.13 summary */
+    log_push(log, s, x_cost, 0.0, gmax, 0.0, 0.0, radius, 0);
+    s->num_unsuccessful_steps = 1;
+    int last_successful = 0;
+
+    for (;;) {
+        /* ---- FinalizeIterationAndCheckIfMinimizerCanContinue ---- */
+        if (last_successful && x_cost < minimum_cost) {
+            minimum_cost = x_cost;
+            memcpy(best_pose, x_pose, (size_t)P * 12 * sizeof(double));
+            memcpy(best_pt, x_pt, (size_t)L * 3 * sizeof(double));
+        }
+        if (iteration >= o->max_num_iterations) { term = ORC_NO_CONVERGENCE; break; }
+        if (gmax <= o->gradient_tolerance) { term = ORC_CONVERGENCE; break; }
+        if (radius <= o->min_trust_region_radius) { term = ORC_CONVERGENCE; break; }
+        ++iteration;
+        last_successful = 0;
+
+        /* ---- ComputeTrustRegionStep ---- */
+        double mcc = 0.0;
+        int rc = lm_step(p, &g, &w, sp, sl, radius, o, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s);
+        int step_is_valid = (rc == 0) && (mcc > 0.0);
+        if (!step_is_valid) {
+            /* HandleInvalidStep */
+            if (++num_invalid >= o->max_num_consecutive_invalid_steps) {
+                term = ORC_FAILURE;
+                log_push(log, s, x_cost, 0.0, gmax, 0.0, 0.0, radius, 0);
+                ++s->num_unsuccessful_steps;
+                break;
+            }
+            radius /= decrease_factor;  /* strategy_->StepIsInvalid() == StepRejected */
+            decrease_factor *= 2.0;
+            log_push(log, s, x_cost, 0.0, gmax, 0.0, 0.0, radius, 0);
+            ++s->num_unsuccessful_steps;
+            continue;
+        }
+        num_invalid = 0;
+
+        /* ---- ComputeCandidatePointAndEvaluateCost ---- */
+        t0 = now_s();
+        plus_all(&g, x_pose, x_pt, dp, dl, c_pose, c_pt);
+        double candidate_cost = evaluate(p, c_pose, c_pt, NULL, NULL, NULL);
+        if (!isfinite(candidate_cost)) candidate_cost = DBL_MAX;
+        s->update_time_s += now_s() - t0;
+
+        /* ---- ParameterToleranceReached ---- */
+        double step_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, c_pose, c_pt, NULL));
+        if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) {
+            term = ORC_CONVERGENCE;
+            break;
+        }
+        /* ---- FunctionToleranceReached ---- */
+        double cost_change = x_cost - candidate_cost;
+        if (fabs(cost_change) <= o->function_tolerance * x_cost) {
+            term = ORC_CONVERGENCE;
+            break;
+        }
+        /* ---- IsStepSuccessful ---- */
+        double rd = se_quality(&se, candidate_cost, mcc);
+        if (rd > o->min_relative_decrease) {
+            /* HandleSuccessfulStep */
+            memcpy(x_pose, c_pose, (size_t)P * 12 * sizeof(double));
+            memcpy(x_pt, c_pt, (size_t)L * 3 * sizeof(double));
+            x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, NULL, NULL, NULL));
+            t0 = now_s();
+            linearize(p, &g, x_pose, x_pt, &w);
+            s->linearize_time_s += now_s() - t0;
+            x_cost = w.cost;
+            GRADIENT_MAX_NORM();
+            /* LevenbergMarquardtStrategy::StepAccepted */
+            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rd - 1.0, 3));
+            radius = fmin(o->max_trust_region_radius, radius);
+            decrease_factor = 2.0;
+            se_accepted(&se, candidate_cost, mcc);
+            last_successful = 1;
+            ++s->num_successful_steps;
+            log_push(log, s, x_cost, cost_change, gmax, step_norm, rd, radius, 1);
+        } else {
+            /* HandleUnsuccessfulStep: StepRejected */
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+            ++s->num_unsuccessful_steps;
+            log_push(log, s, candidate_cost, cost_change, gmax, step_norm, rd, radius, 0);
+        }
+    }
+#undef GRADIENT_MAX_NORM
+    s->termination_type = term;
+    /* solver.cc SetSummaryFinalCost: min over recorded iteration costs */
+    s->final_cost = s->initial_cost;
+    if (log) {
+        int n = s->num_iterations < log->capacity ? s->num_iterations : log->capacity;
+        for (int i = 0; i < n; ++i)
+            if (log->cost[i] < s->final_cost) s->final_cost = log->cost[i];
+    } else if (minimum_cost < s->final_cost) {
+        s->final_cost = minimum_cost;
+    }
+    /* user state <- lowest-cost iterate (solution usable unless FAILURE) */
+    if (term != ORC_FAILURE) {
+        memcpy(p->poses, best_pose, (size_t)P * 12 * sizeof(double));
+        memcpy(p->points, best_pt, (size_t)L * 3 * sizeof(double));
+    }
+    free(x_pose); free(x_pt); free(c_pose); free(c_pt); free(best_pose); free(best_pt);
+    free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl);
+    lin_free(&w);
+    graph_free(&g);
+    s->total_time_s = now_s() - t_start;
+    return 0;
+}

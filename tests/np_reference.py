@@ -1,0 +1,239 @@
+"""Independent numpy/scipy restatement used to cross-check the C oracle.
+
+Deliberately written a different way from oracle/ssba_oracle.c: residuals are
+evaluated through the reference's *global* 12+3 parameterisation and the
+Jacobians come from complex-step differentiation through ``Plus`` (the route
+Ceres's AutoDiffCostFunction + AutoDiffLocalParameterization take), the damped
+normal equations are solved WITHOUT a Schur complement by a sparse direct solve,
+and the trust-region loop is re-implemented on top of that.
+
+Citations are into /root/reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+EPS = np.finfo(np.float64).eps
+
+
+def wedge(phi):
+    # so3group.hpp:248-254
+    return np.array([[0, -phi[2], phi[1]], [phi[2], 0, -phi[0]], [-phi[1], phi[0], 0]], dtype=phi.dtype)
+
+
+def so3_exp(phi):
+    # so3group.hpp:273-291; complex-safe (norm via sqrt of sum of squares)
+    angle = np.sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2])
+    if abs(angle) <= EPS:
+        return np.eye(3, dtype=phi.dtype) + wedge(phi)
+    a = phi / angle
+    return np.cos(angle) * np.eye(3) + (1 - np.cos(angle)) * np.outer(a, a) + np.sin(angle) * wedge(a)
+
+
+def se3_plus(T, eps):
+    # perturbations.hpp:61-62 with se3group.hpp:176-183,323-325
+    t, R = T[:3], T[3:].reshape(3, 3)
+    E = so3_exp(eps[3:])
+    return np.concatenate([E @ t + eps[:3], (E @ R).reshape(9)])
+
+
+def residual_global(cam, T, p, z, S):
+    # stereo_reprojection_error.hpp:38-50 ; stereo_camera.hpp:79-84
+    t, R = T[:3], T[3:].reshape(3, 3)
+    q = R @ p + t
+    iz = 1.0 / q[2]
+    pred = np.array([cam["fu"] * q[0] * iz + cam["cu"], cam["fv"] * q[1] * iz + cam["cv"], cam["fu"] * cam["b"] * iz])
+    return S @ (pred - z)
+
+
+def jacobians_complex_step(cam, T, p, z, S, h=1e-30):
+    """Local Jacobians d r / d eps (3x6) and d r / d p (3x3) by complex step.
+
+    At eps = 0 the first-order branch of so3_exp is taken, exactly as when Ceres
+    evaluates the plus-Jacobian with Jets.
+    """
+    Jp, Jl = np.zeros((3, 6)), np.zeros((3, 3))
+    Tc, pc = T.astype(complex), p.astype(complex)
+    for c in range(6):
+        e = np.zeros(6, dtype=complex)
+        e[c] = 1j * h
+        Jp[:, c] = residual_global(cam, se3_plus(Tc, e), pc, z, S).imag / h
+    for c in range(3):
+        d = pc.copy()
+        d[c] += 1j * h
+        Jl[:, c] = residual_global(cam, Tc, d, z, S).imag / h
+    return Jp, Jl
+
+
+def huber(a, s):
+    # [Ceres loss_function.cc]
+    b = a * a
+    if s > b:
+        r = np.sqrt(s)
+        rho1 = max(np.finfo(np.float64).tiny, a / r)
+        return 2 * a * r - b, rho1, -rho1 / (2 * s)
+    return s, 1.0, 0.0
+
+
+class NumpyBA:
+    """Whole-problem evaluation with vectorised closed forms + sparse algebra."""
+
+    def __init__(self, cam, poses, points, obs_pose, obs_point, obs_uvd, S, pose_const=None, huber_a=0.0):
+        self.cam = cam
+        self.poses, self.points = poses.copy(), points.copy()
+        self.k, self.j = obs_pose.astype(np.int64), obs_point.astype(np.int64)
+        self.z, self.S = obs_uvd, np.asarray(S).reshape(3, 3)
+        P, L = poses.shape[0], points.shape[0]
+        if pose_const is None:
+            pose_const = np.zeros(P, dtype=bool)
+            pose_const[0] = True
+        seen = np.bincount(self.k, minlength=P) > 0
+        self.free = (~np.asarray(pose_const, dtype=bool)) & seen
+        self.free_idx = np.full(P, -1)
+        self.free_idx[self.free] = np.arange(self.free.sum())
+        self.active = np.bincount(self.j, minlength=L) > 0
+        self.nf = int(self.free.sum())
+        self.huber_a = huber_a
+
+    def residuals(self, poses, points, jac=False):
+        cam = self.cam
+        t, R = poses[self.k, :3], poses[self.k, 3:].reshape(-1, 3, 3)
+        p = points[self.j]
+        q = np.einsum("nij,nj->ni", R, p) + t
+        iz = 1.0 / q[:, 2]
+        pred = np.stack([cam["fu"] * q[:, 0] * iz + cam["cu"], cam["fv"] * q[:, 1] * iz + cam["cv"], cam["fu"] * cam["b"] * iz], 1)
+        r = (pred - self.z) @ self.S.T
+        sq = (r * r).sum(1)
+        if self.huber_a > 0:
+            a, b = self.huber_a, self.huber_a ** 2
+            out = sq > b
+            rho0 = np.where(out, 2 * a * np.sqrt(np.where(out, sq, 1.0)) - b, sq)
+            rho1 = np.where(out, a / np.sqrt(np.where(out, sq, 1.0)), 1.0)
+            cost = 0.5 * rho0.sum()
+        else:
+            rho1 = np.ones_like(sq)
+            cost = 0.5 * sq.sum()
+        if not jac:
+            return cost, r * np.sqrt(rho1)[:, None]
+        N = q.shape[0]
+        Jpi = np.zeros((N, 3, 3))
+        Jpi[:, 0, 0] = cam["fu"] * iz
+        Jpi[:, 0, 2] = -cam["fu"] * q[:, 0] * iz * iz
+        Jpi[:, 1, 1] = cam["fv"] * iz
+        Jpi[:, 1, 2] = -cam["fv"] * q[:, 1] * iz * iz
+        Jpi[:, 2, 2] = -cam["fu"] * cam["b"] * iz * iz
+        A = np.einsum("ij,njk->nik", self.S, Jpi)
+        G = np.zeros((N, 3, 6))
+        G[:, 0, 0] = G[:, 1, 1] = G[:, 2, 2] = 1.0
+        G[:, 0, 4], G[:, 0, 5] = q[:, 2], -q[:, 1]
+        G[:, 1, 3], G[:, 1, 5] = -q[:, 2], q[:, 0]
+        G[:, 2, 3], G[:, 2, 4] = q[:, 1], -q[:, 0]
+        Jp = np.einsum("nij,njk->nik", A, G)
+        Jl = np.einsum("nij,njk->nik", A, R)
+        # Huber (rho'' <= 0 always): scale by sqrt(rho')  [Ceres corrector.cc]
+        s1 = np.sqrt(rho1)
+        return cost, r * s1[:, None], Jp * s1[:, None, None], Jl * s1[:, None, None]
+
+    def sparse_jacobian(self, Jp, Jl):
+        """J over [free poses (6 each) | all landmarks (3 each)] as CSR."""
+        N = Jp.shape[0]
+        nf, L = self.nf, self.points.shape[0]
+        rows = np.arange(3 * N).reshape(N, 3)
+        f = self.free_idx[self.k]
+        m = f >= 0
+        rp = np.repeat(rows[m][:, :, None], 6, axis=2).reshape(-1)
+        cp = (6 * f[m][:, None, None] + np.arange(6)[None, None, :]).repeat(3, axis=1).reshape(-1)
+        vp = Jp[m].reshape(-1)
+        rl = np.repeat(rows[:, :, None], 3, axis=2).reshape(-1)
+        cl = (6 * nf + 3 * self.j[:, None, None] + np.arange(3)[None, None, :]).repeat(3, axis=1).reshape(-1)
+        vl = Jl.reshape(-1)
+        J = sp.csr_matrix((np.concatenate([vp, vl]), (np.concatenate([rp, rl]), np.concatenate([cp, cl]))),
+                          shape=(3 * N, 6 * nf + 3 * L))
+        return J
+
+    def lm_step(self, poses, points, radius, scale=None, min_diag=1e-6, max_diag=1e32):
+        """One Ceres LM step; returns (dp (P,6), dl (L,3), model_cost_change, scale)."""
+        cost, r, Jp, Jl = self.residuals(poses, points, jac=True)
+        J = self.sparse_jacobian(Jp, Jl)
+        nf, L = self.nf, points.shape[0]
+        keep = np.concatenate([np.ones(6 * nf, bool), np.repeat(self.active, 3)])
+        J = J[:, keep]
+        colsq = np.asarray(J.multiply(J).sum(0)).ravel()
+        if scale is None:
+            scale = 1.0 / (1.0 + np.sqrt(colsq))
+        Js = J @ sp.diags(scale)
+        diag = np.clip(np.asarray(Js.multiply(Js).sum(0)).ravel(), min_diag, max_diag)
+        H = (Js.T @ Js + sp.diags(diag / radius)).tocsc()
+        y = spla.spsolve(H, Js.T @ r.reshape(-1))
+        delta = -y * scale
+        Jd = J @ delta
+        mcc = -Jd @ (r.reshape(-1) + 0.5 * Jd)
+        full = np.zeros(6 * nf + 3 * L)
+        full[keep] = delta
+        dp = np.zeros((poses.shape[0], 6))
+        dp[self.free] = full[: 6 * nf].reshape(nf, 6)
+        dl = full[6 * nf:].reshape(L, 3)
+        return dp, dl, mcc, scale, cost
+
+    def plus(self, poses, points, dp, dl):
+        out = poses.copy()
+        for k in np.nonzero(self.free)[0]:
+            out[k] = se3_plus(poses[k], dp[k])
+        pts = points.copy()
+        pts[self.active] += dl[self.active]
+        return out, pts
+
+    def solve(self, max_iter=1000, nonmonotonic=True, f_tol=1e-6, p_tol=1e-8, min_rd=1e-3):
+        """Independent re-implementation of the trust-region loop (cost log only)."""
+        x_p, x_l = self.poses.copy(), self.points.copy()
+        radius, dec = 1e4, 2.0
+        scale = None
+        max_nm = 5 if nonmonotonic else 0
+        cost0, _ = self.residuals(x_p, x_l)
+        x_cost = cost0
+        minimum = current = reference = candidate = x_cost
+        acc_ref = acc_cand = 0.0
+        n_nm = 0
+        log = [(x_cost, False)]
+        xs = np.concatenate([x_p[self.free].ravel(), x_l[self.active].ravel()])
+        x_norm = np.linalg.norm(xs)
+        for it in range(1, max_iter + 1):
+            dp, dl, mcc, scale, _ = self.lm_step(x_p, x_l, radius, scale)
+            if not (mcc > 0):
+                radius /= dec
+                dec *= 2
+                log.append((x_cost, False))
+                continue
+            c_p, c_l = self.plus(x_p, x_l, dp, dl)
+            c_cost, _ = self.residuals(c_p, c_l)
+            step = np.sqrt(((c_p[self.free] - x_p[self.free]) ** 2).sum() + ((c_l[self.active] - x_l[self.active]) ** 2).sum())
+            if step <= p_tol * (x_norm + p_tol):
+                break
+            if abs(x_cost - c_cost) <= f_tol * x_cost:
+                break
+            rd = max((current - c_cost) / mcc, (reference - c_cost) / (acc_ref + mcc))
+            if rd > min_rd:
+                x_p, x_l, x_cost = c_p, c_l, c_cost
+                xs = np.concatenate([x_p[self.free].ravel(), x_l[self.active].ravel()])
+                x_norm = np.linalg.norm(xs)
+                radius = min(1e16, radius / max(1 / 3, 1 - (2 * rd - 1) ** 3))
+                dec = 2.0
+                current = c_cost
+                acc_cand += mcc
+                acc_ref += mcc
+                if current < minimum:
+                    minimum, n_nm, candidate, acc_cand = current, 0, current, 0.0
+                else:
+                    n_nm += 1
+                    if current > candidate:
+                        candidate, acc_cand = current, 0.0
+                if n_nm == max_nm:
+                    reference, acc_ref = candidate, acc_cand
+                log.append((x_cost, True))
+            else:
+                radius /= dec
+                dec *= 2
+                log.append((c_cost, False))
+        return x_p, x_l, log

@@ -1,0 +1,149 @@
+"""Cross-checks the oracle's normal equations, Schur complement, LM step and
+trust-region loop against the independent numpy/scipy restatement
+(tests/np_reference.py) and against committed golden vectors.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import np_reference as npr
+from ceres_slam_amd import synth
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _np_ba(prob, huber_a=0.0):
+    return npr.NumpyBA(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point,
+                       prob.obs_uvd, prob.stiffness(), huber_a=huber_a)
+
+
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+def test_linearize_blocks_match_numpy(tiny_problem, huber_a):
+    prob = tiny_problem
+    op = orc.OracleProblem.from_synth(prob, huber_a=huber_a)
+    cost, g_p, g_l, H_pp, H_ll = op.linearize()
+    ref = _np_ba(prob, huber_a)
+    c2, r, Jp, Jl = ref.residuals(prob.poses_init, prob.points_init, jac=True)
+    assert cost == pytest.approx(c2, rel=1e-13)
+    assert op.cost() == pytest.approx(c2, rel=1e-13)
+    P, L = prob.num_poses, prob.num_points
+    gp2, gl2 = np.zeros((P, 6)), np.zeros((L, 3))
+    Hp2, Hl2 = np.zeros((P, 6, 6)), np.zeros((L, 3, 3))
+    np.add.at(gp2, ref.k, np.einsum("nij,ni->nj", Jp, r))
+    np.add.at(gl2, ref.j, np.einsum("nij,ni->nj", Jl, r))
+    np.add.at(Hp2, ref.k, np.einsum("nij,nik->njk", Jp, Jp))
+    np.add.at(Hl2, ref.j, np.einsum("nij,nik->njk", Jl, Jl))
+    np.testing.assert_allclose(g_p, gp2, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(g_l, gl2, rtol=1e-11, atol=1e-9)
+    np.testing.assert_allclose(H_pp, Hp2, rtol=1e-11, atol=1e-8)
+    np.testing.assert_allclose(H_ll, Hl2, rtol=1e-11, atol=1e-8)
+
+
+@pytest.mark.parametrize("radius", [1e4, 3.0])
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+def test_lm_step_matches_sparse_direct_solve(tiny_problem, radius, huber_a):
+    prob = tiny_problem
+    op = orc.OracleProblem.from_synth(prob, huber_a=huber_a)
+    dp, dl, mcc = op.lm_step(radius)
+    ref = _np_ba(prob, huber_a)
+    dp2, dl2, mcc2, _, _ = ref.lm_step(prob.poses_init, prob.points_init, radius)
+    np.testing.assert_allclose(dp, dp2, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dl, dl2, rtol=1e-8, atol=1e-9)
+    assert mcc == pytest.approx(mcc2, rel=1e-9)
+    assert np.all(dp[0] == 0)           # constant first pose (tests/dataset_vo.cpp:62)
+
+
+def test_reduced_system_solves_for_the_pose_step(tiny_problem):
+    prob = tiny_problem
+    op = orc.OracleProblem.from_synth(prob)
+    S, rhs, free_idx = op.reduced_system(50.0)
+    np.testing.assert_allclose(S, S.T, atol=0)
+    assert np.all(np.linalg.eigvalsh(S) > 0)
+    dp, _, _ = op.lm_step(50.0)
+    x = np.linalg.solve(S, rhs).reshape(-1, 6)
+    np.testing.assert_allclose(dp[free_idx >= 0], x, rtol=1e-8, atol=1e-11)
+
+
+@pytest.mark.parametrize("nonmono", [True, False])
+def test_trust_region_loop_matches_independent_loop(tiny_problem, nonmono):
+    prob = tiny_problem
+    op = orc.OracleProblem.from_synth(prob)
+    s, log = op.solve(orc.driver_options(use_nonmonotonic_steps=int(nonmono), num_threads=2))
+    ref = _np_ba(prob)
+    x_p, x_l, rlog = ref.solve(nonmonotonic=nonmono)
+    assert s.termination_type == 0
+    assert len(rlog) == s.num_iterations
+    np.testing.assert_allclose(log["cost"], [c for c, _ in rlog], rtol=1e-9)
+    assert log["step_is_successful"].tolist() == [int(ok) for _, ok in rlog]
+    assert s.final_cost == pytest.approx(min(c for c, _ in rlog), rel=1e-10)
+    np.testing.assert_allclose(op.poses, x_p, atol=1e-8)
+    np.testing.assert_allclose(op.points, x_l, atol=1e-7)
+
+
+def test_solve_is_thread_count_invariant_to_rounding(c1_problem):
+    a = orc.OracleProblem.from_synth(c1_problem)
+    b = orc.OracleProblem.from_synth(c1_problem)
+    sa, la = a.solve(orc.driver_options(num_threads=1))
+    sb, lb = b.solve(orc.driver_options(num_threads=4))
+    assert sa.num_iterations == sb.num_iterations
+    np.testing.assert_allclose(la["cost"], lb["cost"], rtol=1e-11)
+
+
+def test_c1_solve_matches_golden(c1_problem):
+    """Golden vectors made by tests/golden/make_golden.py (oracle output, cross-checked
+    above by the independent solve; NOT reference output -- parity unpinned)."""
+    with open(os.path.join(GOLDEN, "c1_solve.json")) as f:
+        gold = json.load(f)
+    assert c1_problem.num_obs == gold["num_obs"]
+    op = orc.OracleProblem.from_synth(c1_problem)
+    assert op.cost() == pytest.approx(gold["initial_cost"], rel=1e-12)
+    s, log = op.solve(orc.driver_options(num_threads=2))
+    assert s.termination_type == gold["termination_type"]
+    assert s.num_iterations == gold["num_iterations"]
+    np.testing.assert_allclose(log["cost"], gold["cost"], rtol=1e-9)
+    assert log["step_is_successful"].tolist() == gold["step_is_successful"]
+    assert s.final_cost == pytest.approx(gold["final_cost"], rel=1e-10)
+    np.testing.assert_allclose(op.poses[[1, 25, 49]], gold["poses_1_25_49"], atol=1e-8)
+
+
+def test_huber_with_outliers_matches_independent_loop_and_beats_truth_cost():
+    # BASELINE.json config 5: Huber a = 1.345 (scripts/ba_all_devon.sh:86), 30 % outliers
+    prob = synth.make_problem(8, 60, track_len=5, seed=11, outlier_fraction=0.3)
+    op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
+    s, log = op.solve(orc.driver_options(num_threads=2))
+    ref = _np_ba(prob, huber_a=1.345)
+    _, _, rlog = ref.solve()
+    # long, slowly converging run: compare the first 40 iterations step by step,
+    # then only the end point (rounding differences accumulate over ~340 steps)
+    np.testing.assert_allclose(log["cost"][:12], [c for c, _ in rlog][:12], rtol=1e-9)
+    np.testing.assert_allclose(log["cost"][:40], [c for c, _ in rlog][:40], rtol=1e-5)
+    assert log["step_is_successful"][:40].tolist() == [int(ok) for _, ok in rlog][:40]
+    assert s.final_cost == pytest.approx(min(c for c, _ in rlog), rel=1e-5)
+    # the minimiser must end below the robustified cost of the ground truth
+    prob = synth.make_config("C1", outlier_fraction=0.3)
+    op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
+    s, log = op.solve(orc.driver_options(num_threads=4))
+    gt = orc.OracleProblem(prob.camera, prob.poses_gt, prob.points_gt, prob.obs_pose, prob.obs_point,
+                           prob.obs_uvd, prob.stiffness(), huber_a=1.345)
+    assert s.termination_type == 0
+    assert s.final_cost < gt.cost() < s.initial_cost
+
+
+def test_empty_and_degenerate_inputs():
+    cam = synth.KITTI_CAMERA
+    # no observations: cost 0, solve terminates immediately by gradient tolerance
+    op = orc.OracleProblem(cam, np.zeros((2, 12)), np.zeros((3, 3)), np.zeros(0, np.uint32),
+                           np.zeros(0, np.uint32), np.zeros((0, 3)), np.eye(3))
+    assert op.cost() == 0.0
+    s, log = op.solve()
+    assert s.termination_type == 0 and s.num_iterations == 1
+    # single observation, pose constant: only the landmark moves, cost -> ~0
+    T = synth.pose_pack(np.zeros(3), np.eye(3))[None]
+    z = synth.project(cam, np.array([[0.3, -0.2, 9.0]]))
+    op = orc.OracleProblem(cam, T, np.array([[0.0, 0.0, 7.0]]), np.zeros(1, np.uint32),
+                           np.zeros(1, np.uint32), z, np.eye(3) * 0.5)
+    s, log = op.solve()
+    assert s.final_cost < 1e-12 * max(s.initial_cost, 1.0)
+    np.testing.assert_allclose(op.points[0], [0.3, -0.2, 9.0], atol=1e-6)
