@@ -1,0 +1,1004 @@
+// C ABI (include/ssba.h) of the MI355X stereo-BA back end: host-side problem graph,
+// symbolic phase (landmark windows, reduced-system structure, BCR level plan), device
+// mirrors and the enqueue-only trust-region loop.  No CPU fallback exists by design.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ssba.h"
+#include "ssba_launch.h"
+#include "ssba_types.h"
+
+using namespace ssba;
+
+static thread_local std::string g_last_error;
+static void set_error(const std::string &s) { g_last_error = s; }
+
+#define HIPCHECK(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+            return SSBA_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+struct ssba_problem {
+    ssba_camera cam{};
+    int device = 0;
+    // caller-owned parameter memory
+    double *user_poses = nullptr, *user_points = nullptr;
+    uint32_t P = 0, L = 0;
+    // residual blocks, in the caller's order
+    std::vector<uint32_t> obs_pose, obs_point;
+    std::vector<double> obs_uvd;
+    double S[9] = {0};
+    bool have_S = false;
+    std::vector<uint8_t> pose_const;
+    double huber_a = 0.0;
+    bool finalized = false;
+    // host structure
+    std::vector<int> pose_free, free_pose;
+    std::vector<uint32_t> user_of_dev;   // Lpad -> user landmark or 0xFFFFFFFF
+    ssba_stats stats{};
+    // device
+    Dev d{};
+    Launcher launcher;
+    hipStream_t own_stream = nullptr;
+    std::vector<void *> allocs;
+    uint64_t dev_bytes = 0;
+    State *h_state = nullptr;   // pinned
+    double *h_stage = nullptr;  // pinned staging for parameter upload/download
+    size_t h_stage_count = 0;
+    ssba_exchange_fn xfn = nullptr;
+    void *xctx = nullptr;
+    // solve bookkeeping
+    bool began = false;
+    ssba_options opt{};
+    int ignore_convergence = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::chrono::steady_clock::time_point t_begin;
+    std::vector<double> log_cost, log_cost_change, log_gmax, log_step, log_rd, log_radius;
+    std::vector<int32_t> log_ok;
+    int log_capacity = 0;
+};
+
+template <class T>
+static int dalloc(ssba_problem *p, T **out, size_t n) {
+    void *ptr = nullptr;
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIPCHECK(hipMalloc(&ptr, bytes));
+    p->allocs.push_back(ptr);
+    p->dev_bytes += bytes;
+    *out = (T *)ptr;
+    return SSBA_OK;
+}
+template <class T>
+static int dupload(ssba_problem *p, const T **out, const std::vector<T> &v) {
+    T *ptr = nullptr;
+    int rc = dalloc(p, &ptr, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHECK(hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = ptr;
+    return SSBA_OK;
+}
+template <class T>
+static int dzero(ssba_problem *p, T **out, size_t n) {
+    int rc = dalloc(p, out, n);
+    if (rc) return rc;
+    HIPCHECK(hipMemset(*out, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    return SSBA_OK;
+}
+
+static void free_device(ssba_problem *p) {
+    for (void *a : p->allocs) hipFree(a);
+    p->allocs.clear();
+    p->dev_bytes = 0;
+    if (p->h_state) { hipHostFree(p->h_state); p->h_state = nullptr; }
+    if (p->h_stage) { hipHostFree(p->h_stage); p->h_stage = nullptr; }
+    p->finalized = false;
+}
+
+extern "C" {
+
+const char *ssba_status_string(int s) {
+    switch (s) {
+        case SSBA_OK: return "ok";
+        case SSBA_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case SSBA_ERR_HIP: return "HIP runtime error";
+        case SSBA_ERR_NUMERICAL_FAILURE: return "numerical failure";
+        case SSBA_ERR_NOT_FINALIZED: return "problem not finalized";
+        case SSBA_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case SSBA_ERR_UNSUPPORTED: return "problem structure not supported by this build";
+        case SSBA_ERR_STATE: return "call sequence error";
+    }
+    return "unknown status";
+}
+const char *ssba_last_error(void) { return g_last_error.c_str(); }
+
+void ssba_default_options(ssba_options *o) {
+    if (!o) return;
+    o->max_num_iterations = 50;
+    o->use_nonmonotonic_steps = 0;
+    o->max_consecutive_nonmonotonic_steps = 5;
+    o->jacobi_scaling = 1;
+    o->max_num_consecutive_invalid_steps = 5;
+    o->minimizer_progress_to_stdout = 0;
+    o->num_threads = 1;
+    o->num_linear_solver_threads = 1;
+    o->initial_trust_region_radius = 1e4;
+    o->max_trust_region_radius = 1e16;
+    o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6;
+    o->gradient_tolerance = 1e-10;
+    o->parameter_tolerance = 1e-8;
+}
+
+int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
+    if (!camera || !out) return SSBA_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("hipGetDeviceCount found no device");
+        return SSBA_ERR_NO_DEVICE;
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return SSBA_ERR_NO_DEVICE;
+    }
+    if (device >= n) return SSBA_ERR_INVALID_ARGUMENT;
+    HIPCHECK(hipSetDevice(device));
+    ssba_problem *p = new ssba_problem();
+    p->cam = *camera;
+    p->device = device;
+    if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete p;
+        return SSBA_ERR_HIP;
+    }
+    p->launcher.stream = p->own_stream;
+    hipEventCreate(&p->ev_begin);
+    hipEventCreate(&p->ev_end);
+    *out = p;
+    return SSBA_OK;
+}
+
+int ssba_destroy(ssba_problem *p) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    hipSetDevice(p->device);
+    hipStreamSynchronize(p->launcher.stream);
+    p->launcher.destroy();
+    free_device(p);
+    if (p->ev_begin) hipEventDestroy(p->ev_begin);
+    if (p->ev_end) hipEventDestroy(p->ev_end);
+    if (p->own_stream) hipStreamDestroy(p->own_stream);
+    delete p;
+    return SSBA_OK;
+}
+
+int ssba_add_pose_blocks(ssba_problem *p, double *poses, uint32_t num) {
+    if (!p || (!poses && num)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    p->user_poses = poses;
+    p->P = num;
+    p->pose_const.assign(num, 0);
+    return SSBA_OK;
+}
+
+int ssba_add_point_blocks(ssba_problem *p, double *points, uint32_t num) {
+    if (!p || (!points && num)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    p->user_points = points;
+    p->L = num;
+    return SSBA_OK;
+}
+
+int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index, const uint32_t *point_index,
+                                 const double *uvd, uint64_t num, const double stiffness[9]) {
+    if (!p || !stiffness || (num && (!pose_index || !point_index || !uvd))) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    if (p->have_S && memcmp(p->S, stiffness, sizeof p->S) != 0) {
+        set_error("all stereo residual blocks must share one stiffness matrix (as the reference drivers do)");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    for (uint64_t i = 0; i < num; ++i) {
+        if (pose_index[i] >= p->P || point_index[i] >= p->L) {
+            set_error("observation references a parameter block that was not added");
+            return SSBA_ERR_INVALID_ARGUMENT;
+        }
+        for (int c = 0; c < 3; ++c)
+            if (!std::isfinite(uvd[3 * i + c])) return SSBA_ERR_INVALID_ARGUMENT;
+    }
+    memcpy(p->S, stiffness, sizeof p->S);
+    p->have_S = true;
+    p->obs_pose.insert(p->obs_pose.end(), pose_index, pose_index + num);
+    p->obs_point.insert(p->obs_point.end(), point_index, point_index + num);
+    p->obs_uvd.insert(p->obs_uvd.end(), uvd, uvd + 3 * num);
+    return SSBA_OK;
+}
+
+int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant) {
+    if (!p || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;   // the reduced-system structure depends on it
+    p->pose_const[pose] = is_constant ? 1 : 0;
+    return SSBA_OK;
+}
+
+int ssba_set_huber_loss(ssba_problem *p, double a) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    p->huber_a = a > 0.0 ? a : 0.0;
+    if (p->finalized) p->d.huber_a = p->huber_a;
+    return SSBA_OK;
+}
+
+int ssba_set_stream(ssba_problem *p, void *hip_stream) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->began) return SSBA_ERR_STATE;
+    p->launcher.stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+    return SSBA_OK;
+}
+
+int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    p->xfn = fn;
+    p->xctx = ctx;
+    return SSBA_OK;
+}
+
+int ssba_exchange_size(ssba_problem *p, uint64_t *count) {
+    if (!p || !count) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    *count = p->d.xv_count;
+    return SSBA_OK;
+}
+
+int ssba_get_stats(ssba_problem *p, ssba_stats *st) {
+    if (!p || !st) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    *st = p->stats;
+    st->device_bytes = p->dev_bytes;
+    return SSBA_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// symbolic phase
+// ---------------------------------------------------------------------------------
+int ssba_finalize(ssba_problem *p) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_OK;
+    if (!p->have_S && !p->obs_pose.empty()) return SSBA_ERR_INVALID_ARGUMENT;
+    HIPCHECK(hipSetDevice(p->device));
+    const uint32_t P = p->P, L = p->L;
+    const uint64_t N = p->obs_pose.size();
+    if (N >= (1ull << 28) || L >= (1u << 27)) {
+        set_error("problem too large for the 32-bit observation references of this build");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+
+    // landmark-major observation lists (stable: keeps the caller's order)
+    std::vector<uint32_t> lm_start(L + 1, 0), pose_cnt(P, 0);
+    for (uint64_t i = 0; i < N; ++i) { lm_start[p->obs_point[i] + 1]++; pose_cnt[p->obs_pose[i]]++; }
+    for (uint32_t j = 0; j < L; ++j) lm_start[j + 1] += lm_start[j];
+    std::vector<uint32_t> lm_obs(N), cur(lm_start.begin(), lm_start.end() - 1);
+    for (uint64_t i = 0; i < N; ++i) lm_obs[cur[p->obs_point[i]]++] = (uint32_t)i;
+
+    // free poses: in the problem (observed) and not constant
+    p->pose_free.assign(P, -1);
+    p->free_pose.clear();
+    for (uint32_t k = 0; k < P; ++k)
+        if (pose_cnt[k] > 0 && !p->pose_const[k]) {
+            p->pose_free[k] = (int)p->free_pose.size();
+            p->free_pose.push_back((int)k);
+        }
+    const int nfree = (int)p->free_pose.size();
+
+    // per-landmark sorted pose sets; envelope checks
+    struct LmInfo { uint32_t j, kmin, kmax; };
+    std::vector<LmInfo> order;
+    order.reserve(L);
+    std::vector<std::vector<uint32_t>> lm_poses(L);
+    for (uint32_t j = 0; j < L; ++j) {
+        const uint32_t n = lm_start[j + 1] - lm_start[j];
+        if (n == 0) continue;
+        if (n > (uint32_t)TW) {
+            set_error("a landmark has more than SSBA_MAX_TRACK observations");
+            return SSBA_ERR_UNSUPPORTED;
+        }
+        auto &ks = lm_poses[j];
+        for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) ks.push_back(p->obs_pose[lm_obs[e]]);
+        std::sort(ks.begin(), ks.end());
+        if (std::adjacent_find(ks.begin(), ks.end()) != ks.end()) {
+            set_error("a landmark is observed twice from the same pose");
+            return SSBA_ERR_UNSUPPORTED;
+        }
+        order.push_back({j, ks.front(), ks.back()});
+    }
+    std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) {
+        if (a.kmin != b.kmin) return a.kmin < b.kmin;
+        if (a.kmax != b.kmax) return a.kmax < b.kmax;
+        return a.j < b.j;
+    });
+    const uint32_t Lact = (uint32_t)order.size();
+    const uint32_t Lpad = std::max<uint32_t>(256, (Lact + 255) / 256 * 256);
+
+    // greedy windows: consecutive landmarks whose pose sets fit one list of <= TW poses
+    std::vector<uint32_t> win_pose, win_begin;   // win_begin has n_windows+1 entries
+    std::vector<uint32_t> lm_win(Lpad, 0);
+    {
+        std::vector<uint32_t> cur_set, merged;
+        uint32_t begin = 0;
+        auto close = [&](uint32_t end) {
+            const uint32_t w = (uint32_t)win_begin.size();
+            win_begin.push_back(begin);
+            for (int s = 0; s < TW; ++s) win_pose.push_back(s < (int)cur_set.size() ? cur_set[s] : 0xFFFFFFFFu);
+            for (uint32_t l = begin; l < end; ++l) lm_win[l] = w;
+            begin = end;
+        };
+        for (uint32_t l = 0; l < Lact; ++l) {
+            const auto &ks = lm_poses[order[l].j];
+            merged.clear();
+            std::set_union(cur_set.begin(), cur_set.end(), ks.begin(), ks.end(), std::back_inserter(merged));
+            if (merged.size() > (size_t)TW) {
+                close(l);
+                cur_set = ks;
+            } else {
+                cur_set.swap(merged);
+            }
+        }
+        if (Lact > 0) close(Lact);
+        win_begin.push_back(Lact);
+    }
+    const uint32_t n_windows = (uint32_t)win_begin.size() - 1;
+
+    // ELL observation arrays, masks
+    const uint32_t n_groups = Lpad / LMG;
+    std::vector<double> ou((size_t)n_groups * TW * LMG, 0.0), ov(ou.size(), 0.0), od(ou.size(), 1.0);
+    std::vector<uint32_t> lm_mask(Lpad, 0);
+    p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
+    std::vector<std::vector<uint32_t>> pose_refs(P);
+    for (uint32_t l = 0; l < Lact; ++l) {
+        const uint32_t j = order[l].j, w = lm_win[l];
+        p->user_of_dev[l] = j;
+        for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
+            const uint32_t i = lm_obs[e], k = p->obs_pose[i];
+            const uint32_t *wp = &win_pose[(size_t)w * TW];
+            const int s = (int)(std::lower_bound(wp, wp + TW, k) - wp);
+            const size_t oi = (size_t)(l / LMG) * (TW * LMG) + (size_t)s * LMG + (l % LMG);
+            ou[oi] = p->obs_uvd[3 * (size_t)i];
+            ov[oi] = p->obs_uvd[3 * (size_t)i + 1];
+            od[oi] = p->obs_uvd[3 * (size_t)i + 2];
+            lm_mask[l] |= 1u << s;
+            pose_refs[k].push_back(l * 16u + (uint32_t)s);
+        }
+    }
+    std::vector<uint32_t> pose_obs_start(P + 1, 0), pose_obs_ref;
+    pose_obs_ref.reserve(N);
+    for (uint32_t k = 0; k < P; ++k) {
+        std::sort(pose_refs[k].begin(), pose_refs[k].end());
+        pose_obs_ref.insert(pose_obs_ref.end(), pose_refs[k].begin(), pose_refs[k].end());
+        pose_obs_start[k + 1] = (uint32_t)pose_obs_ref.size();
+    }
+
+    // Schur work items (slabs): windows, split when long
+    const uint32_t kItemMax = 128;
+    std::vector<uint32_t> slab_win, slab_b, slab_e;
+    for (uint32_t w = 0; w < n_windows; ++w) {
+        const uint32_t b = win_begin[w], e = win_begin[w + 1], len = e - b;
+        const uint32_t parts = (len + kItemMax - 1) / kItemMax;
+        for (uint32_t q = 0; q < parts; ++q) {
+            slab_win.push_back(w);
+            slab_b.push_back(b + (uint32_t)((uint64_t)len * q / parts));
+            slab_e.push_back(b + (uint32_t)((uint64_t)len * (q + 1) / parts));
+        }
+    }
+    const uint32_t n_slabs = (uint32_t)slab_win.size();
+
+    // reduced-system block structure
+    struct Contrib { uint32_t a, b, c; };
+    std::vector<Contrib> contribs;
+    std::vector<std::pair<uint32_t, uint32_t>> prow;   // (free pose, slab*TW+slot)
+    uint32_t bandwidth = 0;
+    for (uint32_t it = 0; it < n_slabs; ++it) {
+        const uint32_t w = slab_win[it];
+        uint32_t slot_any = 0;
+        bool pair_any[NPAIR] = {false};
+        for (uint32_t l = slab_b[it]; l < slab_e[it]; ++l) {
+            const uint32_t m = lm_mask[l];
+            slot_any |= m;
+            int n = 0;
+            for (int a = 0; a < TW; ++a)
+                for (int b = a; b < TW; ++b, ++n)
+                    if (((m >> a) & 1u) && ((m >> b) & 1u)) pair_any[n] = true;
+        }
+        int n = 0;
+        for (int a = 0; a < TW; ++a)
+            for (int b = a; b < TW; ++b, ++n) {
+                if (!pair_any[n]) continue;
+                const uint32_t ka = win_pose[(size_t)w * TW + a], kb = win_pose[(size_t)w * TW + b];
+                const int fa = p->pose_free[ka], fb = p->pose_free[kb];
+                if (fa < 0 || fb < 0) continue;
+                contribs.push_back({(uint32_t)fa, (uint32_t)fb, it * NPAIR + (uint32_t)n});
+                bandwidth = std::max<uint32_t>(bandwidth, (uint32_t)(fb - fa));
+            }
+        for (int s = 0; s < TW; ++s) {
+            if (!((slot_any >> s) & 1u)) continue;
+            const int f = p->pose_free[win_pose[(size_t)w * TW + s]];
+            if (f >= 0) prow.push_back({(uint32_t)f, it * TW + (uint32_t)s});
+        }
+    }
+    if (bandwidth > (uint32_t)SBP) {
+        set_error("pose co-visibility bandwidth exceeds the block-tridiagonal envelope of this build");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    std::sort(contribs.begin(), contribs.end(), [](const Contrib &x, const Contrib &y) {
+        if (x.a != y.a) return x.a < y.a;
+        if (x.b != y.b) return x.b < y.b;
+        return x.c < y.c;
+    });
+    std::vector<uint32_t> sblk_a, sblk_b, sblk_start, sblk_contrib;
+    // every free pose gets its diagonal block even without landmark contributions
+    {
+        size_t ci = 0;
+        std::vector<Contrib> all;
+        all.reserve(contribs.size() + nfree);
+        for (int f = 0; f < nfree; ++f) all.push_back({(uint32_t)f, (uint32_t)f, 0xFFFFFFFFu});
+        all.insert(all.end(), contribs.begin(), contribs.end());
+        std::sort(all.begin(), all.end(), [](const Contrib &x, const Contrib &y) {
+            if (x.a != y.a) return x.a < y.a;
+            if (x.b != y.b) return x.b < y.b;
+            return x.c < y.c;
+        });
+        (void)ci;
+        for (size_t i = 0; i < all.size(); ++i) {
+            if (i == 0 || all[i].a != all[i - 1].a || all[i].b != all[i - 1].b) {
+                sblk_a.push_back(all[i].a);
+                sblk_b.push_back(all[i].b);
+                sblk_start.push_back((uint32_t)sblk_contrib.size());
+            }
+            if (all[i].c != 0xFFFFFFFFu) sblk_contrib.push_back(all[i].c);
+        }
+        sblk_start.push_back((uint32_t)sblk_contrib.size());
+    }
+    const uint32_t n_sblk = (uint32_t)sblk_a.size();
+    std::sort(prow.begin(), prow.end());
+    std::vector<uint32_t> prow_start(nfree + 1, 0), prow_contrib;
+    for (auto &pr : prow) prow_start[pr.first + 1]++;
+    for (int f = 0; f < nfree; ++f) prow_start[f + 1] += prow_start[f];
+    for (auto &pr : prow) prow_contrib.push_back(pr.second);
+
+    // ---- device mirrors ------------------------------------------------------------
+    free_device(p);
+    Dev &d = p->d;
+    d = Dev{};
+    d.fu = p->cam.fu; d.fv = p->cam.fv; d.cu = p->cam.cu; d.cv = p->cam.cv; d.b = p->cam.b;
+    memcpy(d.S, p->S, sizeof d.S);
+    d.huber_a = p->huber_a;
+    d.P = (int)P; d.nfree = nfree;
+    d.Nsb = std::max(1, (nfree + SBP - 1) / SBP);
+    d.nf_pad = d.Nsb * SBP;
+    d.Lpad = (int)Lpad; d.n_groups = (int)n_groups; d.n_windows = (int)n_windows;
+    d.n_slabs = (int)n_slabs; d.n_sblk = (int)n_sblk;
+    d.n_lm_blocks = (int)(Lpad / 256);
+    d.n_pose_blocks = (int)((P + 255) / 256);
+    if (d.n_pose_blocks < 1) d.n_pose_blocks = 1;
+    d.n_obs = (uint32_t)N;
+    int rc;
+#define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    TRY(dzero(p, &d.poses, (size_t)P * 12)); TRY(dzero(p, &d.cand_poses, (size_t)P * 12));
+    TRY(dzero(p, &d.best_poses, (size_t)P * 12)); TRY(dzero(p, &d.init_poses, (size_t)P * 12));
+    TRY(dzero(p, &d.pts, (size_t)Lpad * 3)); TRY(dzero(p, &d.cand_pts, (size_t)Lpad * 3));
+    TRY(dzero(p, &d.best_pts, (size_t)Lpad * 3)); TRY(dzero(p, &d.init_pts, (size_t)Lpad * 3));
+    TRY(dupload(p, &d.pose_free, p->pose_free));
+    TRY(dupload(p, &d.free_pose, p->free_pose));
+    TRY(dupload(p, &d.ou, ou)); TRY(dupload(p, &d.ov, ov)); TRY(dupload(p, &d.od, od));
+    TRY(dupload(p, &d.lm_mask, lm_mask)); TRY(dupload(p, &d.lm_win, lm_win));
+    if (win_pose.empty()) win_pose.assign(TW, 0xFFFFFFFFu);
+    TRY(dupload(p, &d.win_pose, win_pose));
+    TRY(dupload(p, &d.pose_obs_start, pose_obs_start)); TRY(dupload(p, &d.pose_obs_ref, pose_obs_ref));
+    TRY(dzero(p, &d.hll, (size_t)Lpad * 6)); TRY(dzero(p, &d.gl, (size_t)Lpad * 3));
+    TRY(dzero(p, &d.sl, (size_t)Lpad * 3));
+    TRY(dzero(p, &d.hpp, (size_t)P * 21)); TRY(dzero(p, &d.gp, (size_t)P * 6));
+    TRY(dzero(p, &d.sp, (size_t)d.nf_pad * 6));
+    TRY(dupload(p, &d.slab_win, slab_win)); TRY(dupload(p, &d.slab_lm_begin, slab_b));
+    TRY(dupload(p, &d.slab_lm_end, slab_e));
+    TRY(dzero(p, &d.slab, (size_t)n_slabs * SLAB_DOUBLES));
+    TRY(dupload(p, &d.sblk_a, sblk_a)); TRY(dupload(p, &d.sblk_b, sblk_b));
+    TRY(dupload(p, &d.sblk_start, sblk_start)); TRY(dupload(p, &d.sblk_contrib, sblk_contrib));
+    TRY(dupload(p, &d.prow_start, prow_start)); TRY(dupload(p, &d.prow_contrib, prow_contrib));
+    // exchange vector
+    const uint64_t blk = (uint64_t)BD * BD;
+    d.off_D = 0;
+    d.off_L = d.off_D + (uint64_t)d.Nsb * blk;
+    d.off_rhs = d.off_L + (uint64_t)d.Nsb * blk;
+    d.off_gp = d.off_rhs + (uint64_t)d.Nsb * BD;
+    d.off_hdiag = d.off_gp + (uint64_t)d.Nsb * BD;
+    d.off_scal = d.off_hdiag + (uint64_t)d.Nsb * BD;
+    d.xv_count = d.off_scal + NSCAL;
+    TRY(dzero(p, &d.xv, d.xv_count));
+    TRY(dzero(p, &d.x0, (size_t)d.nf_pad * 6));
+    // BCR level plan
+    {
+        int n = d.Nsb, lev = 0;
+        d.lev[0].n = n;
+        d.lev[0].D = d.xv + d.off_D;
+        d.lev[0].L = d.xv + d.off_L;
+        d.lev[0].r = d.xv + d.off_rhs;
+        for (;;) {
+            TRY(dzero(p, &d.lev[lev].YU, (size_t)std::max(1, n / 2) * blk));
+            if (n == 1) break;
+            const int n2 = (n + 1) / 2;
+            ++lev;
+            if (lev >= MAX_LEVELS) return SSBA_ERR_UNSUPPORTED;
+            d.lev[lev].n = n2;
+            TRY(dzero(p, &d.lev[lev].D, (size_t)n2 * blk));
+            TRY(dzero(p, &d.lev[lev].L, (size_t)n2 * blk));
+            TRY(dzero(p, &d.lev[lev].r, (size_t)n2 * BD));
+            n = n2;
+        }
+        d.n_levels = lev + 1;
+    }
+    TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
+    TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
+    TRY(dzero(p, &d.part_pose, (size_t)d.n_pose_blocks * 2));
+    TRY(dzero(p, &d.scal2, (size_t)NSCAL));
+    TRY(dzero(p, &d.gmax_l, (size_t)1));
+    TRY(dzero(p, &d.st, (size_t)1));
+    HIPCHECK(hipHostMalloc((void **)&p->h_state, sizeof(State), hipHostMallocDefault));
+    p->h_stage_count = std::max<size_t>((size_t)P * 12, (size_t)Lpad * 3);
+    HIPCHECK(hipHostMalloc((void **)&p->h_stage, std::max<size_t>(p->h_stage_count, 1) * sizeof(double), hipHostMallocDefault));
+    if (upload_pair_table(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
+    if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
+#undef TRY
+    p->stats.num_poses = P; p->stats.num_free_poses = (uint32_t)nfree;
+    p->stats.num_points = L; p->stats.num_active_points = Lact;
+    p->stats.num_observations = N; p->stats.num_windows = n_windows;
+    p->stats.num_superblocks = (uint32_t)d.Nsb; p->stats.num_reduced_blocks = n_sblk;
+    p->stats.pose_bandwidth = bandwidth;
+    p->finalized = true;
+    return SSBA_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// parameter transfer
+// ---------------------------------------------------------------------------------
+static int upload_params(ssba_problem *p) {
+    Dev &d = p->d;
+    hipStream_t s = p->launcher.stream;
+    if (p->P) HIPCHECK(hipMemcpyAsync(d.poses, p->user_poses, (size_t)p->P * 12 * sizeof(double), hipMemcpyHostToDevice, s));
+    double *st = p->h_stage;
+    const size_t Lp = (size_t)d.Lpad;
+    for (size_t l = 0; l < Lp; ++l) {
+        const uint32_t j = p->user_of_dev[l];
+        for (int c = 0; c < 3; ++c) st[c * Lp + l] = (j == 0xFFFFFFFFu) ? (c == 2 ? 1.0 : 0.0) : p->user_points[3 * (size_t)j + c];
+    }
+    HIPCHECK(hipStreamSynchronize(s));   // poses copied from pageable memory
+    HIPCHECK(hipMemcpyAsync(d.pts, st, Lp * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    return SSBA_OK;
+}
+
+static int download_params(ssba_problem *p, const double *dev_poses, const double *dev_pts) {
+    Dev &d = p->d;
+    hipStream_t s = p->launcher.stream;
+    const size_t Lp = (size_t)d.Lpad;
+    HIPCHECK(hipMemcpyAsync(p->h_stage, dev_pts, Lp * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    for (size_t l = 0; l < Lp; ++l) {
+        const uint32_t j = p->user_of_dev[l];
+        if (j == 0xFFFFFFFFu) continue;
+        for (int c = 0; c < 3; ++c) p->user_points[3 * (size_t)j + c] = p->h_stage[c * Lp + l];
+    }
+    if (p->P) {
+        // constant / unobserved poses are never touched on the device, so a plain copy is exact
+        HIPCHECK(hipMemcpyAsync(p->user_poses, dev_poses, (size_t)p->P * 12 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+    }
+    return SSBA_OK;
+}
+
+static Options to_device_options(const ssba_options *o, int ignore_convergence) {
+    Options d{};
+    d.max_num_iterations = o->max_num_iterations;
+    d.max_nonmono = o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0;
+    d.jacobi_scaling = o->jacobi_scaling;
+    d.max_invalid = o->max_num_consecutive_invalid_steps;
+    d.ignore_convergence = ignore_convergence;
+    d.initial_radius = o->initial_trust_region_radius;
+    d.max_radius = o->max_trust_region_radius;
+    d.min_radius = o->min_trust_region_radius;
+    d.min_relative_decrease = o->min_relative_decrease;
+    d.min_lm_diag = o->min_lm_diagonal;
+    d.max_lm_diag = o->max_lm_diagonal;
+    d.function_tolerance = o->function_tolerance;
+    d.gradient_tolerance = o->gradient_tolerance;
+    d.parameter_tolerance = o->parameter_tolerance;
+    return d;
+}
+
+static int ensure_log(ssba_problem *p, int capacity) {
+    if (capacity <= p->log_capacity) return SSBA_OK;
+    Dev &d = p->d;
+    int rc;
+    if ((rc = dzero(p, &d.log.cost, (size_t)capacity))) return rc;
+    if ((rc = dzero(p, &d.log.cost_change, (size_t)capacity))) return rc;
+    if ((rc = dzero(p, &d.log.gmax, (size_t)capacity))) return rc;
+    if ((rc = dzero(p, &d.log.step_norm, (size_t)capacity))) return rc;
+    if ((rc = dzero(p, &d.log.relative_decrease, (size_t)capacity))) return rc;
+    if ((rc = dzero(p, &d.log.radius, (size_t)capacity))) return rc;
+    if ((rc = dzero(p, &d.log.successful, (size_t)capacity))) return rc;
+    d.log.capacity = capacity;
+    p->log_capacity = capacity;
+    return SSBA_OK;
+}
+
+// one trust-region iteration, enqueue only
+static int enqueue_iteration(ssba_problem *p) {
+    Dev &d = p->d;
+    Launcher &L = p->launcher;
+    launch_linearize(L, d);
+    launch_schur(L, d);
+    if (p->xfn) {
+        if (p->xfn(p->xctx, d.xv, d.xv_count, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        if (p->xfn(p->xctx, d.gmax_l, 1, 1)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+    }
+    launch_finish_check(L, d);
+    launch_bcr(L, d);
+    launch_update_eval(L, d);
+    if (p->xfn) {
+        if (p->xfn(p->xctx, d.scal2, NSCAL, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+    }
+    launch_decide_commit(L, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+    return SSBA_OK;
+}
+
+static int reset_solver(ssba_problem *p) {
+    Dev &d = p->d;
+    hipStream_t s = p->launcher.stream;
+    HIPCHECK(hipMemcpyAsync(d.poses, d.init_poses, (size_t)d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d.pts, d.init_pts, (size_t)d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d.best_poses, d.init_poses, (size_t)d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d.best_pts, d.init_pts, (size_t)d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d.cand_poses, d.init_poses, (size_t)d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(d.cand_pts, d.init_pts, (size_t)d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    launch_reset(p->launcher, d, to_device_options(&p->opt, p->ignore_convergence));
+    return SSBA_OK;
+}
+
+int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence) {
+    if (!p || !o) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    if (o->max_num_iterations < 0 || !(o->initial_trust_region_radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
+    HIPCHECK(hipSetDevice(p->device));
+    p->opt = *o;
+    p->ignore_convergence = ignore_convergence;
+    p->d.huber_a = p->huber_a;
+    int cap = o->max_num_iterations + 4;
+    if (cap > (1 << 20)) cap = 1 << 20;
+    int rc = ensure_log(p, cap);
+    if (rc) return rc;
+    p->t_begin = std::chrono::steady_clock::now();
+    rc = upload_params(p);
+    if (rc) return rc;
+    hipStream_t s = p->launcher.stream;
+    HIPCHECK(hipMemcpyAsync(p->d.init_poses, p->d.poses, (size_t)p->d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(p->d.init_pts, p->d.pts, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    rc = reset_solver(p);
+    if (rc) return rc;
+    HIPCHECK(hipEventRecord(p->ev_begin, s));
+    p->began = true;
+    return SSBA_OK;
+}
+
+int ssba_solve_restart(ssba_problem *p) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->began) return SSBA_ERR_STATE;
+    return reset_solver(p);
+}
+
+int ssba_solve_step(ssba_problem *p, int n) {
+    if (!p || n < 0) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->began) return SSBA_ERR_STATE;
+    for (int i = 0; i < n; ++i) {
+        int rc = enqueue_iteration(p);
+        if (rc) return rc;
+    }
+    return SSBA_OK;
+}
+
+int ssba_synchronize(ssba_problem *p) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    HIPCHECK(hipStreamSynchronize(p->launcher.stream));
+    p->launcher.collect();
+    return SSBA_OK;
+}
+
+static int fetch_state(ssba_problem *p) {
+    HIPCHECK(hipMemcpyAsync(p->h_state, p->d.st, sizeof(State), hipMemcpyDeviceToHost, p->launcher.stream));
+    HIPCHECK(hipStreamSynchronize(p->launcher.stream));
+    return SSBA_OK;
+}
+
+int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->began) return SSBA_ERR_STATE;
+    hipStream_t st = p->launcher.stream;
+    HIPCHECK(hipEventRecord(p->ev_end, st));
+    int rc = fetch_state(p);
+    if (rc) return rc;
+    p->launcher.collect();
+    const State &S = *p->h_state;
+    const int n = std::min(S.log_count, p->d.log.capacity);
+    p->log_cost.resize(n); p->log_cost_change.resize(n); p->log_gmax.resize(n); p->log_step.resize(n);
+    p->log_rd.resize(n); p->log_radius.resize(n); p->log_ok.resize(n);
+    if (n > 0) {
+        HIPCHECK(hipMemcpy(p->log_cost.data(), p->d.log.cost, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(p->log_cost_change.data(), p->d.log.cost_change, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(p->log_gmax.data(), p->d.log.gmax, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(p->log_step.data(), p->d.log.step_norm, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(p->log_rd.data(), p->d.log.relative_decrease, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(p->log_radius.data(), p->d.log.radius, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(p->log_ok.data(), p->d.log.successful, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    const int term = S.terminated ? S.termination_type : SSBA_NO_CONVERGENCE;
+    // the solution is usable unless the minimiser failed: write the lowest-cost iterate back
+    if (term != SSBA_FAILURE) {
+        rc = download_params(p, p->d.best_poses, p->d.best_pts);
+        if (rc) return rc;
+    }
+    if (s) {
+        memset(s, 0, sizeof *s);
+        s->termination_type = term;
+        s->num_iterations = n;
+        s->num_successful_steps = S.num_successful;
+        s->num_unsuccessful_steps = S.num_unsuccessful;
+        s->initial_cost = S.initial_cost;
+        // solver.cc SetSummaryFinalCost: minimum over the recorded iteration costs
+        double fc = S.initial_cost;
+        for (int i = 0; i < n; ++i) fc = std::min(fc, p->log_cost[i]);
+        s->final_cost = fc;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p->ev_begin, p->ev_end) == hipSuccess) s->device_time_s = 1e-3 * ms;
+        s->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - p->t_begin).count();
+    }
+    p->began = false;
+    return term == SSBA_FAILURE ? SSBA_ERR_NUMERICAL_FAILURE : SSBA_OK;
+}
+
+int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
+    int rc = ssba_solve_begin(p, o, 0);
+    if (rc) return rc;
+    // Enqueue-ahead loop: the device decides accept/reject/convergence itself; the host
+    // only polls the `terminated` word, one iteration behind the device.
+    hipStream_t st = p->launcher.stream;
+    hipEvent_t ev[2];
+    hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+    hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+    State *ring = nullptr;
+    if (hipHostMalloc((void **)&ring, 2 * sizeof(State), hipHostMallocDefault) != hipSuccess) return SSBA_ERR_HIP;
+    const long max_enqueue = (long)o->max_num_iterations + 3;
+    bool done = false;
+    for (long it = 0; it < max_enqueue && !done; ++it) {
+        rc = enqueue_iteration(p);
+        if (rc) break;
+        const int slot = (int)(it & 1);
+        hipMemcpyAsync(&ring[slot], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st);
+        hipEventRecord(ev[slot], st);
+        if (it >= 1) {
+            const int prev = (int)((it - 1) & 1);
+            hipEventSynchronize(ev[prev]);
+            if (ring[prev].terminated) done = true;
+            if (o->minimizer_progress_to_stdout)
+                printf("iter %4d cost %.6e radius %.3e\n", ring[prev].iteration, ring[prev].x_cost, ring[prev].radius);
+        }
+    }
+    hipStreamSynchronize(st);
+    hipEventDestroy(ev[0]);
+    hipEventDestroy(ev[1]);
+    hipHostFree(ring);
+    if (rc) { p->began = false; return rc; }
+    return ssba_solve_end(p, s);
+}
+
+int ssba_brief_report(const ssba_summary *s, char *buf, size_t n) {
+    if (!s || !buf || n == 0) return SSBA_ERR_INVALID_ARGUMENT;
+    static const char *names[] = {"CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+    const char *t = (s->termination_type >= 0 && s->termination_type <= 2) ? names[s->termination_type] : "UNKNOWN";
+    // format of ceres::Solver::Summary::BriefReport()
+    snprintf(buf, n, "Ceres Solver Report: Iterations: %d, Initial cost: %e, Final cost: %e, Termination: %s",
+             s->num_successful_steps + s->num_unsuccessful_steps, s->initial_cost, s->final_cost, t);
+    return SSBA_OK;
+}
+
+int ssba_iteration_log(ssba_problem *p, int32_t capacity, double *cost, double *cost_change,
+                       double *gradient_max_norm, double *step_norm, double *relative_decrease,
+                       double *trust_region_radius, int32_t *step_is_successful) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    const int n = (int)p->log_cost.size();
+    const int m = std::min(n, (int)capacity);
+    for (int i = 0; i < m; ++i) {
+        if (cost) cost[i] = p->log_cost[i];
+        if (cost_change) cost_change[i] = p->log_cost_change[i];
+        if (gradient_max_norm) gradient_max_norm[i] = p->log_gmax[i];
+        if (step_norm) step_norm[i] = p->log_step[i];
+        if (relative_decrease) relative_decrease[i] = p->log_rd[i];
+        if (trust_region_radius) trust_region_radius[i] = p->log_radius[i];
+        if (step_is_successful) step_is_successful[i] = p->log_ok[i];
+    }
+    return n;
+}
+
+int ssba_set_kernel_timing(ssba_problem *p, int mode) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    hipStreamSynchronize(p->launcher.stream);
+    p->launcher.collect();
+    p->launcher.timing = mode ? 1 : 0;
+    for (int i = 0; i < KC_COUNT; ++i) { p->launcher.total_ms[i] = 0; p->launcher.launches[i] = 0; }
+    return SSBA_OK;
+}
+
+int ssba_kernel_times(ssba_problem *p, ssba_kernel_time *rows, int32_t capacity, int32_t *num) {
+    if (!p || !num) return SSBA_ERR_INVALID_ARGUMENT;
+    hipStreamSynchronize(p->launcher.stream);
+    p->launcher.collect();
+    int n = 0;
+    for (int i = 0; i < KC_COUNT && n < capacity; ++i) {
+        if (rows) {
+            memset(&rows[n], 0, sizeof rows[n]);
+            snprintf(rows[n].name, sizeof rows[n].name, "%s", kKernelClassName[i]);
+            rows[n].launches = p->launcher.launches[i];
+            rows[n].total_ms = p->launcher.total_ms[i];
+        }
+        ++n;
+    }
+    *num = n;
+    return SSBA_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// test hooks
+// ---------------------------------------------------------------------------------
+static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
+    if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    if (p->began) return SSBA_ERR_STATE;
+    HIPCHECK(hipSetDevice(p->device));
+    ssba_options opt;
+    if (o) opt = *o; else ssba_default_options(&opt);
+    if (radius > 0.0) opt.initial_trust_region_radius = radius;
+    p->opt = opt;
+    p->ignore_convergence = 1;
+    p->d.huber_a = p->huber_a;
+    int rc = ensure_log(p, 16);
+    if (rc) return rc;
+    rc = upload_params(p);
+    if (rc) return rc;
+    hipStream_t s = p->launcher.stream;
+    HIPCHECK(hipMemcpyAsync(p->d.init_poses, p->d.poses, (size_t)p->d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(p->d.init_pts, p->d.pts, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    return reset_solver(p);
+}
+
+int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, double *H_pp, double *H_ll) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    int rc = begin_hook(p, nullptr, 0.0);
+    if (rc) return rc;
+    Dev &d = p->d;
+    launch_linearize(p->launcher, d);
+    HIPCHECK(hipStreamSynchronize(p->launcher.stream));
+    HIPCHECK(hipGetLastError());
+    const size_t Lp = (size_t)d.Lpad;
+    if (cost) HIPCHECK(hipMemcpy(cost, d.xv + d.off_scal, sizeof(double), hipMemcpyDeviceToHost));
+    if (g_p || H_pp) {
+        std::vector<double> gp((size_t)p->P * 6), hp((size_t)p->P * 21);
+        if (p->P) {
+            HIPCHECK(hipMemcpy(gp.data(), d.gp, gp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(hp.data(), d.hpp, hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        for (uint32_t k = 0; k < p->P; ++k) {
+            const bool fr = p->pose_free[k] >= 0;
+            if (g_p) for (int c = 0; c < 6; ++c) g_p[6 * (size_t)k + c] = fr ? gp[6 * (size_t)k + c] : 0.0;
+            if (H_pp) {
+                int n = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int c = a; c < 6; ++c, ++n) {
+                        const double v = fr ? hp[21 * (size_t)k + n] : 0.0;
+                        H_pp[36 * (size_t)k + 6 * a + c] = v;
+                        H_pp[36 * (size_t)k + 6 * c + a] = v;
+                    }
+            }
+        }
+    }
+    if (g_l || H_ll) {
+        std::vector<double> gl(Lp * 3), hl(Lp * 6);
+        HIPCHECK(hipMemcpy(gl.data(), d.gl, gl.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(hl.data(), d.hll, hl.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (g_l) memset(g_l, 0, (size_t)p->L * 3 * sizeof(double));
+        if (H_ll) memset(H_ll, 0, (size_t)p->L * 9 * sizeof(double));
+        static const int map6[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+        for (size_t l = 0; l < Lp; ++l) {
+            const uint32_t j = p->user_of_dev[l];
+            if (j == 0xFFFFFFFFu) continue;
+            if (g_l) for (int c = 0; c < 3; ++c) g_l[3 * (size_t)j + c] = gl[c * Lp + l];
+            if (H_ll)
+                for (int c = 0; c < 6; ++c) {
+                    H_ll[9 * (size_t)j + 3 * map6[c][0] + map6[c][1]] = hl[c * Lp + l];
+                    H_ll[9 * (size_t)j + 3 * map6[c][1] + map6[c][0]] = hl[c * Lp + l];
+                }
+        }
+    }
+    return SSBA_OK;
+}
+
+int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S, double *rhs,
+                 double *delta_p, double *delta_l, double *model_cost_change) {
+    if (!p || !(radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
+    int rc = begin_hook(p, o, radius);
+    if (rc) return rc;
+    Dev &d = p->d;
+    Launcher &L = p->launcher;
+    launch_linearize(L, d);
+    launch_schur(L, d);
+    launch_finish_check(L, d);
+    HIPCHECK(hipStreamSynchronize(L.stream));
+    HIPCHECK(hipGetLastError());
+    const int nf = d.nfree, n = 6 * nf;
+    if (S || rhs) {
+        const size_t blk = (size_t)BD * BD;
+        std::vector<double> D((size_t)d.Nsb * blk), Lb((size_t)d.Nsb * blk), r((size_t)d.Nsb * BD);
+        HIPCHECK(hipMemcpy(D.data(), d.xv + d.off_D, D.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(Lb.data(), d.xv + d.off_L, Lb.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(r.data(), d.xv + d.off_rhs, r.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (S) {
+            memset(S, 0, (size_t)n * n * sizeof(double));
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    const int I = i / BD, J = j / BD;
+                    double v = 0.0;
+                    if (I == J) v = D[(size_t)I * blk + (size_t)(i % BD) * BD + (j % BD)];
+                    else if (I == J + 1) v = Lb[(size_t)I * blk + (size_t)(i % BD) * BD + (j % BD)];
+                    else if (J == I + 1) v = Lb[(size_t)J * blk + (size_t)(j % BD) * BD + (i % BD)];
+                    S[(size_t)i * n + j] = v;
+                }
+        }
+        if (rhs) for (int i = 0; i < n; ++i) rhs[i] = r[i];
+    }
+    launch_bcr(L, d);
+    launch_update_eval(L, d);
+    HIPCHECK(hipStreamSynchronize(L.stream));
+    HIPCHECK(hipGetLastError());
+    rc = fetch_state(p);
+    if (rc) return rc;
+    double sc[NSCAL];
+    HIPCHECK(hipMemcpy(sc, d.scal2, sizeof sc, hipMemcpyDeviceToHost));
+    if (p->h_state->step_failed || sc[3] != 0.0) return SSBA_ERR_NUMERICAL_FAILURE;
+    if (model_cost_change) *model_cost_change = sc[1];
+    if (delta_p) {
+        std::vector<double> x((size_t)d.nf_pad * 6);
+        HIPCHECK(hipMemcpy(x.data(), d.x0, x.size() * sizeof(double), hipMemcpyDeviceToHost));
+        memset(delta_p, 0, (size_t)p->P * 6 * sizeof(double));
+        for (int f = 0; f < nf; ++f)
+            for (int c = 0; c < 6; ++c) delta_p[6 * (size_t)p->free_pose[f] + c] = x[6 * (size_t)f + c];
+    }
+    if (delta_l) {
+        const size_t Lp = (size_t)d.Lpad;
+        std::vector<double> a(Lp * 3), b(Lp * 3);
+        HIPCHECK(hipMemcpy(a.data(), d.cand_pts, a.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(b.data(), d.pts, b.size() * sizeof(double), hipMemcpyDeviceToHost));
+        memset(delta_l, 0, (size_t)p->L * 3 * sizeof(double));
+        for (size_t l = 0; l < Lp; ++l) {
+            const uint32_t j = p->user_of_dev[l];
+            if (j == 0xFFFFFFFFu) continue;
+            for (int c = 0; c < 3; ++c) delta_l[3 * (size_t)j + c] = a[c * Lp + l] - b[c * Lp + l];
+        }
+    }
+    return SSBA_OK;
+}
+
+}  // extern "C"

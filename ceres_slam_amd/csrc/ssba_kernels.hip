@@ -1,0 +1,1205 @@
+// HIP kernels of the stereo-BA hot path for gfx950 (MI355X).  fp64 throughout.
+//
+// Kernel classes (one LM iteration, in launch order; DESIGN.md has the roofline
+// of each):
+//   k_linearize_landmarks  per-landmark H_ll, g_l, cost        (HBM stream, 1 lane/landmark)
+//   k_linearize_poses      per-pose H_pp, g_p                   (gather, 1 block/pose)
+//   k_schur_windows        sum_j (W C^-1)_a W_b^T per window    (fp64 FMA bound, output-stationary)
+//   k_assemble_reduced     slabs -> block-tridiagonal S, rhs    (HBM)
+//   k_finish_reduced       Jacobi scale + LM damping on diag(S)
+//   k_check                Ceres FinalizeIterationAndCheck...   (1 block)
+//   k_bcr_factor/reduce/backsub  block cyclic reduction of S    (latency bound, log2 levels)
+//   k_pose_update          candidate poses = Plus(x, delta_p)
+//   k_backsub_eval         delta_l, model cost change, candidate cost (HBM stream)
+//   k_decide               step quality, accept/reject, radius  (1 block)
+//   k_commit / k_best      x <- candidate, best <- x
+//
+// Arithmetic follows /root/reference include/ceres_slam/{stereo_reprojection_error,
+// stereo_camera,perturbations}.hpp and geometry/{se3group,so3group}.hpp; the
+// trust-region logic follows Ceres 1.13/1.14 (see oracle/ssba_oracle.h).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssba_types.h"
+#include "ssba_launch.h"
+
+namespace ssba {
+
+__constant__ uint8_t c_pair_a[NPAIR];
+__constant__ uint8_t c_pair_b[NPAIR];
+
+int upload_pair_table(hipStream_t s) {
+    uint8_t a[NPAIR], b[NPAIR];
+    int n = 0;
+    for (int i = 0; i < TW; ++i)
+        for (int j = i; j < TW; ++j) { a[n] = (uint8_t)i; b[n] = (uint8_t)j; ++n; }
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pair_a), a, NPAIR, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pair_b), b, NPAIR, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
+}
+
+// ------------------------------------------------------------------ helpers ---
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    return v;
+}
+// Deterministic block sum; result valid on thread 0.  sm needs blockDim/64 doubles.
+__device__ __forceinline__ double block_sum(double v, double *sm) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) t += sm[i];
+    return t;
+}
+__device__ __forceinline__ double block_max(double v, double *sm) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) t = fmax(t, sm[i]);
+    return t;
+}
+
+struct ObsLin {
+    double r[3];     // loss-corrected residual
+    double A[9];     // sqrt(rho') * S * J_pi(q)
+    double q[3];     // point in the camera frame
+    double half_rho; // 1/2 rho(|r|^2)
+};
+
+// stereo_reprojection_error.hpp:38-50, stereo_camera.hpp:77-104, Huber corrector
+// [Ceres corrector.cc with rho'' <= 0].  T is the 12-double pose block.
+__device__ __forceinline__ void obs_linearize(const Dev &d, const double *__restrict__ T,
+                                              double px, double py, double pz, double u, double v,
+                                              double dd, ObsLin &o) {
+    const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
+    const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
+    const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
+    const double iz = 1.0 / q2;
+    const double e0 = d.fu * q0 * iz + d.cu - u;
+    const double e1 = d.fv * q1 * iz + d.cv - v;
+    const double e2 = d.fu * d.b * iz - dd;
+    const double j00 = d.fu * iz, j11 = d.fv * iz;
+    const double iz2 = iz * iz;
+    const double j02 = -d.fu * q0 * iz2, j12 = -d.fv * q1 * iz2, j22 = -d.fu * d.b * iz2;
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double s0 = d.S[3 * i], s1 = d.S[3 * i + 1], s2 = d.S[3 * i + 2];
+        o.r[i] = s0 * e0 + s1 * e1 + s2 * e2;
+        o.A[3 * i] = s0 * j00;
+        o.A[3 * i + 1] = s1 * j11;
+        o.A[3 * i + 2] = s0 * j02 + s1 * j12 + s2 * j22;
+        sq += o.r[i] * o.r[i];
+    }
+    o.q[0] = q0; o.q[1] = q1; o.q[2] = q2;
+    o.half_rho = 0.5 * sq;
+    if (d.huber_a > 0.0 && sq > d.huber_a * d.huber_a) {
+        const double rs = sqrt(sq);
+        const double rho1 = fmax(DBL_MIN, d.huber_a / rs);
+        const double sc = sqrt(rho1);
+        o.half_rho = 0.5 * (2.0 * d.huber_a * rs - d.huber_a * d.huber_a);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.r[i] *= sc;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) o.A[i] *= sc;
+    }
+}
+
+// 1/2 rho(|r|^2) only (candidate evaluation)
+__device__ __forceinline__ double obs_cost(const Dev &d, const double *__restrict__ T, double px,
+                                           double py, double pz, double u, double v, double dd) {
+    const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
+    const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
+    const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
+    const double iz = 1.0 / q2;
+    const double e0 = d.fu * q0 * iz + d.cu - u;
+    const double e1 = d.fv * q1 * iz + d.cv - v;
+    const double e2 = d.fu * d.b * iz - dd;
+    double sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double r = d.S[3 * i] * e0 + d.S[3 * i + 1] * e1 + d.S[3 * i + 2] * e2;
+        sq += r * r;
+    }
+    if (d.huber_a > 0.0 && sq > d.huber_a * d.huber_a)
+        return 0.5 * (2.0 * d.huber_a * sqrt(sq) - d.huber_a * d.huber_a);
+    return 0.5 * sq;
+}
+
+// J_l = A R (3x3)   [dq/dp = R]
+__device__ __forceinline__ void jac_point(const ObsLin &o, const double *__restrict__ T, double Jl[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Jl[3 * i + j] = o.A[3 * i] * T[3 + j] + o.A[3 * i + 1] * T[6 + j] + o.A[3 * i + 2] * T[9 + j];
+}
+// J_p = A [I | -q^] (3x6)   [dq/deps at eps = 0: perturbations.hpp:61-62, so3group.hpp:277-280]
+__device__ __forceinline__ void jac_pose(const ObsLin &o, double Jp[18]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a0 = o.A[3 * i], a1 = o.A[3 * i + 1], a2 = o.A[3 * i + 2];
+        Jp[6 * i + 0] = a0;
+        Jp[6 * i + 1] = a1;
+        Jp[6 * i + 2] = a2;
+        Jp[6 * i + 3] = -a1 * o.q[2] + a2 * o.q[1];
+        Jp[6 * i + 4] = a0 * o.q[2] - a2 * o.q[0];
+        Jp[6 * i + 5] = -a0 * o.q[1] + a1 * o.q[0];
+    }
+}
+
+// so3group.hpp:273-291 ; perturbations.hpp:61-62 with se3group.hpp:176-183,323-325
+__device__ __forceinline__ void se3_plus(const double *__restrict__ T, const double *__restrict__ eps,
+                                         double *__restrict__ out) {
+    const double p0 = eps[3], p1 = eps[4], p2 = eps[5];
+    const double angle = sqrt(p0 * p0 + p1 * p1 + p2 * p2);
+    double E[9];
+    if (angle <= DBL_EPSILON) {
+        E[0] = 1.0; E[1] = -p2; E[2] = p1;
+        E[3] = p2;  E[4] = 1.0; E[5] = -p0;
+        E[6] = -p1; E[7] = p0;  E[8] = 1.0;
+    } else {
+        const double a0 = p0 / angle, a1 = p1 / angle, a2 = p2 / angle;
+        const double cp = cos(angle), sn = sin(angle), omc = 1.0 - cp;
+        E[0] = cp + omc * a0 * a0;      E[1] = omc * a0 * a1 - sn * a2; E[2] = omc * a0 * a2 + sn * a1;
+        E[3] = omc * a1 * a0 + sn * a2; E[4] = cp + omc * a1 * a1;      E[5] = omc * a1 * a2 - sn * a0;
+        E[6] = omc * a2 * a0 - sn * a1; E[7] = omc * a2 * a1 + sn * a0; E[8] = cp + omc * a2 * a2;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        out[i] = E[3 * i] * T[0] + E[3 * i + 1] * T[1] + E[3 * i + 2] * T[2] + eps[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            out[3 + 3 * i + j] = E[3 * i] * T[3 + j] + E[3 * i + 1] * T[6 + j] + E[3 * i + 2] * T[9 + j];
+    }
+}
+
+// inverse of the damped 3x3 landmark block through its Cholesky factor.
+// h = (h00,h01,h02,h11,h12,h22), dmp = LM diagonal.  Returns false on breakdown.
+__device__ __forceinline__ bool inv3_spd(const double h[6], const double dmp[3], double Ci[6]) {
+    const double c00 = h[0] + dmp[0], c11 = h[3] + dmp[1], c22 = h[5] + dmp[2];
+    if (!(c00 > 0.0)) return false;
+    const double l00 = sqrt(c00);
+    const double l10 = h[1] / l00, l20 = h[2] / l00;
+    const double d1 = c11 - l10 * l10;
+    if (!(d1 > 0.0)) return false;
+    const double l11 = sqrt(d1);
+    const double l21 = (h[4] - l20 * l10) / l11;
+    const double d2 = c22 - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return false;
+    const double l22 = sqrt(d2);
+    const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
+    const double m10 = -l10 * m00 * m11;
+    const double m21 = -l21 * m11 * m22;
+    const double m20 = -(l20 * m00 + l21 * m10) * m22;
+    Ci[0] = m00 * m00 + m10 * m10 + m20 * m20;
+    Ci[1] = m10 * m11 + m20 * m21;
+    Ci[2] = m20 * m22;
+    Ci[3] = m11 * m11 + m21 * m21;
+    Ci[4] = m21 * m22;
+    Ci[5] = m22 * m22;
+    return true;
+}
+
+// LM diagonal of a landmark in unscaled coordinates:
+//   D^2 = clamp(s^2 h, min, max) / (radius s^2)   [levenberg_marquardt_strategy.cc on the
+//   Jacobi-scaled Jacobian, mapped back through delta = s .* step]
+__device__ __forceinline__ void landmark_damping(const Dev &d, const State &st, int l, const double h[6],
+                                                 double dmp[3]) {
+    const double hd[3] = {h[0], h[3], h[5]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double s = d.sl[(size_t)c * d.Lpad + l];
+        const double s2 = s * s;
+        dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (st.radius * s2);
+    }
+}
+
+// ------------------------------------------------------------------ kernels ---
+
+// One lane per landmark.  Streams the ELL observation arrays (coalesced), gathers the
+// (few, shared) pose blocks through L1/L2.  Writes H_ll (6), g_l (3) component-major and
+// per-block partials {cost, |x_l|^2, max|g_l|}.  At iteration 0 also the Jacobi scale.
+__global__ __launch_bounds__(256) void k_linearize_landmarks(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double cost = 0.0, xn = 0.0, gm = 0.0;
+    if (mask) {
+        const uint32_t win = d.lm_win[l];
+        const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const double *T = d.poses + (size_t)k * 12;
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            double Jl[9];
+            jac_point(o, T, Jl);
+            cost += o.half_rho;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                h[0] += Jl[3 * i] * Jl[3 * i];
+                h[1] += Jl[3 * i] * Jl[3 * i + 1];
+                h[2] += Jl[3 * i] * Jl[3 * i + 2];
+                h[3] += Jl[3 * i + 1] * Jl[3 * i + 1];
+                h[4] += Jl[3 * i + 1] * Jl[3 * i + 2];
+                h[5] += Jl[3 * i + 2] * Jl[3 * i + 2];
+                g[0] += Jl[3 * i] * o.r[i];
+                g[1] += Jl[3 * i + 1] * o.r[i];
+                g[2] += Jl[3 * i + 2] * o.r[i];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) d.hll[(size_t)c * d.Lpad + l] = h[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d.gl[(size_t)c * d.Lpad + l] = g[c];
+        if (st.iteration == 0) {   // Jacobi scaling, computed once [trust_region_minimizer.cc]
+            const double hd[3] = {h[0], h[3], h[5]};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                d.sl[(size_t)c * d.Lpad + l] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[c])) : 1.0;
+        }
+        xn = px * px + py * py + pz * pz;
+        gm = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+    }
+    const double c0 = block_sum(cost, sm);
+    const double c1 = block_sum(xn, sm);
+    const double c2 = block_max(gm, sm);
+    if (threadIdx.x == 0) {
+        d.part_lin[blockIdx.x * 4 + 0] = c0;
+        d.part_lin[blockIdx.x * 4 + 1] = c1;
+        d.part_lin[blockIdx.x * 4 + 2] = c2;
+    }
+}
+
+// One block per pose: gathers that pose's observations through the pose-major
+// reference list, accumulates the 21 unique entries of H_pp and g_p in registers and
+// reduces them across the block in a fixed order (no float atomics).
+__global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    const int k = blockIdx.x;
+    if (d.pose_free[k] < 0) return;
+    __shared__ double sm[4][27];
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = d.poses[(size_t)k * 12 + i];
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    const uint32_t b = d.pose_obs_start[k], e = d.pose_obs_start[k + 1];
+    for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+        const uint32_t ref = d.pose_obs_ref[i];
+        const int l = (int)(ref >> 4), s = (int)(ref & 15u);
+        const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+        ObsLin o;
+        obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], d.ou[oi],
+                      d.ov[oi], d.od[oi], o);
+        double Jp[18];
+        jac_pose(o, Jp);
+        int n = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) {
+                acc[n] += Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c] + Jp[12 + a] * Jp[12 + c];
+                ++n;
+            }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += Jp[a] * o.r[0] + Jp[6 + a] * o.r[1] + Jp[12 + a] * o.r[2];
+    }
+#pragma unroll
+    for (int i = 0; i < 27; ++i) {
+        const double v = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        const double v = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        if (threadIdx.x < 21) d.hpp[(size_t)k * 21 + threadIdx.x] = v;
+        else d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
+    }
+}
+
+// Schur complement contributions, output-stationary: one block per work item (a window
+// or a slice of it), lanes = the 78 pose pairs (sa <= sb) of the window, each lane keeps
+// its 6x6 block  sum_j (W_aj C_j^-1) W_bj^T  in registers while the block streams over the
+// landmarks; batches of SCHUR_BATCH landmarks are half-linearised by (landmark, slot)
+// lanes and staged through LDS.  W = J_p^T J_l is recomputed from the observation, never
+// stored in HBM.  Result: one slab (78 blocks + 12 rhs vectors) per work item.
+constexpr int SCHUR_BATCH = 10;   // 10 landmarks x 12 slots = 120 of 128 lanes
+constexpr int WY_STRIDE = 38;     // 36 doubles + 2 pad (bank spread for ds_read_b128)
+
+__global__ __launch_bounds__(128) void k_schur_windows(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sWY[SCHUR_BATCH * TW * WY_STRIDE];   // [li][slot][ W(18) | Y(18) ]
+    __shared__ double sGL[SCHUR_BATCH * 4];
+    const int item = blockIdx.x;
+    const uint32_t win = d.slab_win[item];
+    const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
+    const int t = threadIdx.x;
+    const int li = t / TW, s = t - li * TW;           // producer role (t < 120)
+    const int pa = t < NPAIR ? c_pair_a[t] : 0;       // consumer role (t < 78)
+    const int pb = t < NPAIR ? c_pair_b[t] : 0;
+    double acc[36], racc[6];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) racc[i] = 0.0;
+
+    uint32_t k = 0xFFFFFFFFu;
+    bool pose_ok = false;
+    double T[12];
+    if (t < SCHUR_BATCH * TW) {
+        k = d.win_pose[win * TW + s];
+        pose_ok = (k != 0xFFFFFFFFu) && d.pose_free[k] >= 0;
+        if (pose_ok) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = d.poses[(size_t)k * 12 + i];
+        }
+    }
+
+    for (int l0 = lb; l0 < le; l0 += SCHUR_BATCH) {
+        if (t < SCHUR_BATCH * TW) {
+            const int l = l0 + li;
+            double *dst = sWY + (li * TW + s) * WY_STRIDE;
+            bool live = false;
+            if (l < le) {
+                const uint32_t mask = d.lm_mask[l];
+                if (s == 0) {
+                    sGL[li * 4 + 0] = d.gl[l];
+                    sGL[li * 4 + 1] = d.gl[(size_t)d.Lpad + l];
+                    sGL[li * 4 + 2] = d.gl[2 * (size_t)d.Lpad + l];
+                }
+                if (pose_ok && ((mask >> s) & 1u)) {
+                    live = true;
+                    double h[6], dmp[3], Ci[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
+                    landmark_damping(d, st, l, h, dmp);
+                    if (!inv3_spd(h, dmp, Ci)) {
+                        d.st->step_failed = 1;
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) Ci[c] = 0.0;
+                    }
+                    const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+                    ObsLin o;
+                    obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l],
+                                  d.ou[oi], d.ov[oi], d.od[oi], o);
+                    double Jp[18], Jl[9];
+                    jac_pose(o, Jp);
+                    jac_point(o, T, Jl);
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        double w[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            w[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
+                        dst[3 * a + 0] = w[0];
+                        dst[3 * a + 1] = w[1];
+                        dst[3 * a + 2] = w[2];
+                        dst[18 + 3 * a + 0] = w[0] * Ci[0] + w[1] * Ci[1] + w[2] * Ci[2];
+                        dst[18 + 3 * a + 1] = w[0] * Ci[1] + w[1] * Ci[3] + w[2] * Ci[4];
+                        dst[18 + 3 * a + 2] = w[0] * Ci[2] + w[1] * Ci[4] + w[2] * Ci[5];
+                    }
+                }
+            } else if (s == 0) {
+                sGL[li * 4 + 0] = 0.0; sGL[li * 4 + 1] = 0.0; sGL[li * 4 + 2] = 0.0;
+            }
+            if (!live) {
+#pragma unroll
+                for (int i = 0; i < 36; ++i) dst[i] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (t < NPAIR) {
+            const int nb = min(SCHUR_BATCH, le - l0);
+            for (int j = 0; j < nb; ++j) {
+                const double *Y = sWY + (j * TW + pa) * WY_STRIDE + 18;
+                const double *W = sWY + (j * TW + pb) * WY_STRIDE;
+                double y[18], w[18];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) { y[i] = Y[i]; w[i] = W[i]; }
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+                        acc[6 * a + c] += y[3 * a] * w[3 * c] + y[3 * a + 1] * w[3 * c + 1] + y[3 * a + 2] * w[3 * c + 2];
+                if (pa == pb) {
+                    const double g0 = sGL[j * 4], g1 = sGL[j * 4 + 1], g2 = sGL[j * 4 + 2];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) racc[a] += y[3 * a] * g0 + y[3 * a + 1] * g1 + y[3 * a + 2] * g2;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t < NPAIR) {
+        double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)t * 36;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) out[i] = acc[i];
+        if (pa == pb) {
+            double *ro = d.slab + (size_t)item * SLAB_DOUBLES + NPAIR * 36 + pa * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) ro[a] = racc[a];
+        }
+    }
+}
+
+__device__ __forceinline__ int tri21(int r, int c) {   // packed upper index, r <= c
+    return r * 6 - (r * (r - 1)) / 2 + (c - r);
+}
+
+// Gathers the slabs into the block-tridiagonal reduced system (pure stores, fixed
+// summation order): one thread per (6x6 block, element), plus one thread per rhs entry.
+// S = H_pp - sum slabs (pose damping is added after the exchange, in k_finish_reduced).
+__global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_el = (size_t)d.n_sblk * 36;
+    double *D0 = d.xv + d.off_D, *L0 = d.xv + d.off_L;
+    if (gid < n_el) {
+        const uint32_t blk = (uint32_t)(gid / 36);
+        const int e = (int)(gid - (size_t)blk * 36);
+        int r = e / 6, c = e - r * 6;
+        const uint32_t fa = d.sblk_a[blk], fb = d.sblk_b[blk];
+        int er = r, ec = c;
+        if (fa == fb && c > r) { er = c; ec = r; }   // read the lower triangle: exact symmetry
+        double v = 0.0;
+        for (uint32_t i = d.sblk_start[blk]; i < d.sblk_start[blk + 1]; ++i)
+            v += d.slab[(size_t)(d.sblk_contrib[i] / NPAIR) * SLAB_DOUBLES + (size_t)(d.sblk_contrib[i] % NPAIR) * 36 + er * 6 + ec];
+        v = -v;
+        if (fa == fb) {
+            const int k = d.free_pose[fa];
+            v += d.hpp[(size_t)k * 21 + tri21(min(r, c), max(r, c))];
+        }
+        const uint32_t Ia = fa / SBP, Ib = fb / SBP;
+        const int row = (int)(fa - Ia * SBP) * 6 + r, col = (int)(fb - Ib * SBP) * 6 + c;
+        if (Ia == Ib) {
+            D0[(size_t)Ia * BD * BD + (size_t)row * BD + col] = v;
+            if (fa != fb) D0[(size_t)Ia * BD * BD + (size_t)col * BD + row] = v;
+        } else {   // Ib == Ia + 1: entry (row in block Ia, col in block Ib) = L[Ib]^T
+            L0[(size_t)Ib * BD * BD + (size_t)col * BD + row] = v;
+        }
+    } else if (gid < n_el + (size_t)d.nfree * 6) {
+        const size_t i = gid - n_el;
+        const uint32_t f = (uint32_t)(i / 6);
+        const int c = (int)(i - (size_t)f * 6);
+        const int k = d.free_pose[f];
+        const double g = d.gp[(size_t)k * 6 + c];
+        double v = g;
+        for (uint32_t j = d.prow_start[f]; j < d.prow_start[f + 1]; ++j) {
+            const uint32_t cw = d.prow_contrib[j];
+            v -= d.slab[(size_t)(cw / TW) * SLAB_DOUBLES + NPAIR * 36 + (cw % TW) * 6 + c];
+        }
+        d.xv[d.off_rhs + i] = v;             // reduced gradient; negated in k_finish_reduced
+        d.xv[d.off_gp + i] = g;
+        d.xv[d.off_hdiag + i] = d.hpp[(size_t)k * 21 + tri21(c, c)];
+    }
+}
+
+// After the (optional) all-reduce: Jacobi scale of the poses at iteration 0, LM damping
+// on the diagonal, rhs = -reduced gradient, identity rows for the padding.
+__global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nf_pad * 6) return;
+    const int f = i / 6, c = i - f * 6;
+    const int I = f / SBP, row = (f - I * SBP) * 6 + c;
+    double *Dd = d.xv + d.off_D + (size_t)I * BD * BD + (size_t)row * BD + row;
+    if (f < d.nfree) {
+        const double h = d.xv[d.off_hdiag + i];
+        if (st.iteration == 0) d.sp[i] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+        const double s = d.sp[i], s2 = s * s;
+        *Dd += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (st.radius * s2);
+        d.xv[d.off_rhs + i] = -d.xv[d.off_rhs + i];
+    } else {
+        *Dd = 1.0;
+        d.xv[d.off_rhs + i] = 0.0;
+    }
+}
+
+__device__ void log_push(Dev &d, State &st, double cost, double cost_change, double step_norm, double rd,
+                         int ok) {
+    const int i = st.log_count++;
+    if (i < d.log.capacity) {
+        d.log.cost[i] = cost; d.log.cost_change[i] = cost_change; d.log.gmax[i] = st.gmax;
+        d.log.step_norm[i] = step_norm; d.log.relative_decrease[i] = rd; d.log.radius[i] = st.radius;
+        d.log.successful[i] = ok;
+    }
+}
+
+// Ceres TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue (plus the
+// reductions of EvaluateGradientAndJacobian): one block.
+__global__ __launch_bounds__(256) void k_check(Dev d) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double gm = 0.0, xn = 0.0, cost = 0.0;
+    const bool lin = st.just_linearized != 0;
+    if (lin) {
+        // landmark partials (already all-reduced in scal[] when sharded: see host)
+        for (int i = threadIdx.x; i < d.nfree; i += 256) {
+            const int k = d.free_pose[i];
+            const double *T = d.poses + (size_t)k * 12;
+            double ng[6], Tn[12];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ng[c] = -d.xv[d.off_gp + (size_t)i * 6 + c];
+            se3_plus(T, ng, Tn);    // projected gradient: |x - Plus(x, -g)|_inf
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                gm = fmax(gm, fabs(T[c] - Tn[c]));
+                xn += T[c] * T[c];
+            }
+        }
+    }
+    const double gmp = block_max(gm, sm);
+    const double xnp = block_sum(xn, sm);
+    (void)cost;
+    if (threadIdx.x != 0) return;
+    if (lin) {
+        const double *sc = d.xv + d.off_scal;
+        st.x_cost = sc[0];
+        st.x_norm = sqrt(sc[1] + xnp);
+        st.gmax = fmax(gmp, *d.gmax_l);
+        st.just_linearized = 0;
+    }
+    if (st.iteration == 0) {
+        // IterationZero
+        st.initial_cost = st.x_cost;
+        st.minimum_cost = st.x_cost;
+        st.se_minimum = st.se_current = st.se_reference = st.se_candidate = st.x_cost;
+        st.se_acc_ref = st.se_acc_cand = 0.0;
+        st.se_num_nonmono = 0;
+        st.copy_best = 0;
+        log_push(d, st, st.x_cost, 0.0, 0.0, 0.0, 0);
+        st.num_unsuccessful = 1;   // iteration 0 is recorded with step_is_successful = false
+    } else if (st.last_successful) {
+        // log row of the successful iteration uses the re-evaluated cost and gradient
+        log_push(d, st, st.x_cost, st.cost_change, st.step_norm, st.relative_decrease, 1);
+        if (st.x_cost < st.minimum_cost) {
+            st.minimum_cost = st.x_cost;
+            st.copy_best = 1;
+        }
+    }
+    if (!st.opt.ignore_convergence) {
+        if (st.iteration >= st.opt.max_num_iterations) {
+            st.terminated = 1; st.termination_type = 1; return;   // NO_CONVERGENCE
+        }
+        if (st.gmax <= st.opt.gradient_tolerance) {
+            st.terminated = 1; st.termination_type = 0; return;
+        }
+        if (st.radius <= st.opt.min_radius) {
+            st.terminated = 1; st.termination_type = 0; return;
+        }
+    }
+    ++st.iteration;
+    st.last_successful = 0;
+    st.accepted = 0;
+    // step_failed may already carry a landmark-block breakdown from k_schur_windows
+}
+
+__global__ __launch_bounds__(256) void k_best(Dev d) {
+    const State &st = *d.st;
+    if (!st.copy_best) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)d.P * 12) d.best_poses[i] = d.poses[i];
+    if (i < (size_t)d.Lpad * 3) d.best_pts[i] = d.pts[i];
+}
+__global__ void k_best_done(Dev d) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d.st->copy_best = 0;
+}
+
+// ---------------------------------------------------- block cyclic reduction ---
+// S is block tridiagonal with BD x BD blocks.  Level l eliminates its odd blocks:
+//   factor  (per odd i):  D_i = G G^T ; YL = G^-1 L_i ; YU = G^-1 L_{i+1}^T ; yr = G^-1 r_i
+//   reduce  (per even e): D' = D_e - YU(e-1)^T YU(e-1) - YL(e+1)^T YL(e+1)
+//                         L' = -YU(e-1)^T YL(e-1) ;  r' likewise
+//   backsub (per odd i):  x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1})
+// The top level (one block) is a plain Cholesky solve.  G, YL, yr overwrite D_i, L_i, r_i.
+constexpr int LDA = BD + 1;    // LDS row stride of the factor (bank spread)
+constexpr int NRHS = 2 * BD + 1;
+constexpr int LDR = NRHS + 1;  // 146
+
+__global__ __launch_bounds__(256) void k_bcr_factor(Dev d, int lev, int top) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    extern __shared__ double lds[];
+    double *A = lds;                // BD x LDA
+    double *R = lds + BD * LDA;     // BD x LDR : [ L_i | L_{i+1}^T | r_i ]
+    const BcrLevel &L = d.lev[lev];
+    const int i = top ? 0 : 2 * blockIdx.x + 1;
+    const bool hasL = !top, hasU = !top && (i + 1 < L.n);
+    double *Dg = L.D + (size_t)i * BD * BD;
+    double *Lg = L.L + (size_t)i * BD * BD;
+    const double *Ug = hasU ? L.L + (size_t)(i + 1) * BD * BD : nullptr;
+    double *rg = L.r + (size_t)i * BD;
+    const int t = threadIdx.x;
+    for (int e = t; e < BD * BD; e += 256) {
+        const int r = e / BD, c = e - r * BD;
+        A[r * LDA + c] = Dg[e];
+        R[r * LDR + c] = hasL ? Lg[e] : 0.0;
+        R[r * LDR + BD + c] = hasU ? Ug[(size_t)c * BD + r] : 0.0;   // transpose of L_{i+1}
+    }
+    if (t < BD) R[t * LDR + 2 * BD] = rg[t];
+    __syncthreads();
+    bool bad = false;
+    for (int k = 0; k < BD; ++k) {
+        const double akk = A[k * LDA + k];
+        if (!(akk > 0.0) || !isfinite(akk)) { bad = true; break; }   // uniform: all threads read the same value
+        const double dk = sqrt(akk), inv = 1.0 / dk;
+        __syncthreads();
+        // scale column k of A (rows > k) and row k of R
+        for (int e = t; e < (BD - 1 - k) + NRHS; e += 256) {
+            if (e < BD - 1 - k) A[(k + 1 + e) * LDA + k] *= inv;
+            else R[k * LDR + (e - (BD - 1 - k))] *= inv;
+        }
+        if (t == 0) A[k * LDA + k] = dk;
+        __syncthreads();
+        // trailing update: A[i][j] -= A[i][k] A[j][k] (k < j <= i) ; R[i][:] -= A[i][k] R[k][:]
+        const int m = BD - 1 - k;            // remaining rows
+        const int wA = m;                    // use full m x m square for simple indexing (lower part only)
+        const int total = m * (wA + NRHS);
+        for (int e = t; e < total; e += 256) {
+            const int ri = e / (wA + NRHS), cj = e - ri * (wA + NRHS);
+            const int row = k + 1 + ri;
+            const double aik = A[row * LDA + k];
+            if (cj < wA) {
+                const int col = k + 1 + cj;
+                if (col <= row) A[row * LDA + col] -= aik * A[col * LDA + k];
+            } else {
+                const int c = cj - wA;
+                R[row * LDR + c] -= aik * R[k * LDR + c];
+            }
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        if (t == 0) st.step_failed = 1;
+        return;
+    }
+    // write back: G (lower) -> D_i, YL -> L_i, YU -> YU slot, yr -> r_i
+    double *YUg = top ? nullptr : L.YU + (size_t)blockIdx.x * BD * BD;
+    for (int e = t; e < BD * BD; e += 256) {
+        const int r = e / BD, c = e - r * BD;
+        Dg[e] = (c <= r) ? A[r * LDA + c] : 0.0;
+        if (hasL) Lg[e] = R[r * LDR + c];
+        if (YUg) YUg[e] = hasU ? R[r * LDR + BD + c] : 0.0;
+    }
+    if (t < BD) rg[t] = R[t * LDR + 2 * BD];
+}
+
+// C = [C0] - A1^T B1 - A2^T B2 for BD x BD operands in global memory (L2 resident),
+// 6x6 register tiles, 144 active lanes of 192.
+__device__ void gemm_tn_sub(double *acc, const double *__restrict__ A, const double *__restrict__ B,
+                            int tr, int tc, double *sA, double *sB) {
+    // stage A and B (BD x BD each) into LDS
+    for (int e = threadIdx.x; e < BD * BD; e += blockDim.x) { sA[e] = A[e]; sB[e] = B[e]; }
+    __syncthreads();
+    if (tr >= 0) {
+        for (int k = 0; k < BD; ++k) {
+            double a[6], b[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { a[i] = sA[k * BD + tr * 6 + i]; b[i] = sB[k * BD + tc * 6 + i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[6 * i + j] -= a[i] * b[j];
+        }
+    }
+    __syncthreads();
+}
+
+// grid = (n_next, 2): y = 0 -> D' and r' ; y = 1 -> L'
+__global__ __launch_bounds__(192) void k_bcr_reduce(Dev d, int lev) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed) return;
+    extern __shared__ double lds[];
+    double *sA = lds, *sB = lds + BD * BD;
+    const BcrLevel &L = d.lev[lev];
+    const BcrLevel &N = d.lev[lev + 1];
+    const int m = blockIdx.x, e = 2 * m;
+    const int t = threadIdx.x;
+    const int tr = t < 144 ? t / 12 : -1, tc = t < 144 ? t % 12 : 0;
+    const bool hasPrev = e - 1 >= 0, hasNext = e + 1 < L.n;
+    const int tp = (e - 2) / 2, tn = e / 2;     // YU slot of odd block e-1 / e+1
+    double acc[36];
+    if (blockIdx.y == 0) {
+        const double *De = L.D + (size_t)e * BD * BD;
+        if (tr >= 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) acc[6 * i + j] = De[(size_t)(tr * 6 + i) * BD + tc * 6 + j];
+        }
+        if (hasPrev) {
+            const double *YU = L.YU + (size_t)tp * BD * BD;
+            gemm_tn_sub(acc, YU, YU, tr, tc, sA, sB);
+        }
+        if (hasNext) {
+            const double *YL = L.L + (size_t)(e + 1) * BD * BD;
+            gemm_tn_sub(acc, YL, YL, tr, tc, sA, sB);
+        }
+        if (tr >= 0) {
+            double *Dn = N.D + (size_t)m * BD * BD;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Dn[(size_t)(tr * 6 + i) * BD + tc * 6 + j] = acc[6 * i + j];
+        }
+        // r' = r_e - YU(e-1)^T yr(e-1) - YL(e+1)^T yr(e+1)
+        if (t < BD) {
+            double v = L.r[(size_t)e * BD + t];
+            if (hasPrev) {
+                const double *YU = L.YU + (size_t)tp * BD * BD, *yr = L.r + (size_t)(e - 1) * BD;
+                for (int k = 0; k < BD; ++k) v -= YU[(size_t)k * BD + t] * yr[k];
+            }
+            if (hasNext) {
+                const double *YL = L.L + (size_t)(e + 1) * BD * BD, *yr = L.r + (size_t)(e + 1) * BD;
+                for (int k = 0; k < BD; ++k) v -= YL[(size_t)k * BD + t] * yr[k];
+            }
+            N.r[(size_t)m * BD + t] = v;
+        }
+    } else {
+        if (m == 0) return;   // L'[0] unused
+        // L' = -YU(e-1)^T YL(e-1): rows = block e, cols = block e-2
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+        const double *YU = L.YU + (size_t)tp * BD * BD, *YL = L.L + (size_t)(e - 1) * BD * BD;
+        gemm_tn_sub(acc, YU, YL, tr, tc, sA, sB);
+        if (tr >= 0) {
+            double *Ln = N.L + (size_t)m * BD * BD;
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Ln[(size_t)(tr * 6 + i) * BD + tc * 6 + j] = acc[6 * i + j];
+        }
+    }
+}
+
+// x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1}); x lives in d.x0 at level-0 block positions.
+__global__ __launch_bounds__(128) void k_bcr_backsub(Dev d, int lev, int top) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed) return;
+    __shared__ double v[BD];
+    const BcrLevel &L = d.lev[lev];
+    const int i = top ? 0 : 2 * blockIdx.x + 1;
+    const int t = threadIdx.x;
+    const double *G = L.D + (size_t)i * BD * BD;
+    double *xi = d.x0 + ((size_t)i << lev) * BD;
+    if (t < BD) {
+        double a = L.r[(size_t)i * BD + t];
+        if (!top) {
+            const double *YL = L.L + (size_t)i * BD * BD;
+            const double *xm = d.x0 + ((size_t)(i - 1) << lev) * BD;
+            for (int k = 0; k < BD; ++k) a -= YL[(size_t)t * BD + k] * xm[k];
+            if (i + 1 < L.n) {
+                const double *YU = L.YU + (size_t)blockIdx.x * BD * BD;
+                const double *xp = d.x0 + ((size_t)(i + 1) << lev) * BD;
+                for (int k = 0; k < BD; ++k) a -= YU[(size_t)t * BD + k] * xp[k];
+            }
+        }
+        v[t] = a;
+    }
+    __syncthreads();
+    // solve G^T x = v (upper triangular, column sweep from the bottom)
+    for (int k = BD - 1; k >= 0; --k) {
+        if (t == 0) v[k] = v[k] / G[(size_t)k * BD + k];
+        __syncthreads();
+        if (t < k) v[t] -= G[(size_t)k * BD + t] * v[k];
+        __syncthreads();
+    }
+    if (t < BD) xi[t] = v[t];
+}
+
+// candidate poses = Plus(x, delta_p)  [Evaluator::Plus with SE3Perturbation]
+__global__ __launch_bounds__(256) void k_pose_update(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double dn = 0.0, nonfinite = 0.0;
+    if (k < d.P) {
+        const int f = d.pose_free[k];
+        const double *T = d.poses + (size_t)k * 12;
+        double *C = d.cand_poses + (size_t)k * 12;
+        if (f >= 0 && !st.step_failed) {
+            double eps[6], Tn[12];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                eps[c] = d.x0[(size_t)f * 6 + c];
+                if (!isfinite(eps[c])) nonfinite = 1.0;
+            }
+            se3_plus(T, eps, Tn);
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+                C[c] = Tn[c];
+                const double df = Tn[c] - T[c];
+                dn += df * df;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) C[c] = T[c];
+        }
+    }
+    const double a = block_sum(dn, sm);
+    const double b = block_sum(nonfinite, sm);
+    if (threadIdx.x == 0) {
+        d.part_pose[blockIdx.x * 2] = a;
+        d.part_pose[blockIdx.x * 2 + 1] = b;
+    }
+}
+
+// One lane per landmark: back-substitution delta_l = -C^-1 (g_l + sum_s W_s^T delta_p,s),
+// candidate point, model cost change -(J d)^T (r + J d / 2) and candidate cost, all in
+// one pass over the landmark's observations (second sweep hits L1/L2).
+__global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
+    const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+    double nx = px, ny = py, nz = pz;
+    if (mask && !st.step_failed) {
+        const uint32_t win = d.lm_win[l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        double tt[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            if (f < 0) continue;
+            const double *T = d.poses + (size_t)k * 12;
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            double Jp[18], Jl[9], jd[3];
+            jac_pose(o, Jp);
+            jac_point(o, T, Jl);
+            const double *dp = d.x0 + (size_t)f * 6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                jd[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tt[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+        }
+        double h[6], dmp[3], Ci[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
+        landmark_damping(d, st, l, h, dmp);
+        double dl[3] = {0, 0, 0};
+        if (inv3_spd(h, dmp, Ci)) {
+            dl[0] = -(Ci[0] * tt[0] + Ci[1] * tt[1] + Ci[2] * tt[2]);
+            dl[1] = -(Ci[1] * tt[0] + Ci[3] * tt[1] + Ci[4] * tt[2]);
+            dl[2] = -(Ci[2] * tt[0] + Ci[4] * tt[1] + Ci[5] * tt[2]);
+        } else {
+            nonfinite = 1.0;
+        }
+        if (!isfinite(dl[0]) || !isfinite(dl[1]) || !isfinite(dl[2])) nonfinite = 1.0;
+        nx = px + dl[0]; ny = py + dl[1]; nz = pz + dl[2];
+        dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            const double *T = d.poses + (size_t)k * 12;
+            const double u = d.ou[obase + s * LMG], v = d.ov[obase + s * LMG], dd = d.od[obase + s * LMG];
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, u, v, dd, o);
+            double Jl[9], jd[3];
+            jac_point(o, T, Jl);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) jd[i] = Jl[3 * i] * dl[0] + Jl[3 * i + 1] * dl[1] + Jl[3 * i + 2] * dl[2];
+            if (f >= 0) {
+                double Jp[18];
+                jac_pose(o, Jp);
+                const double *dp = d.x0 + (size_t)f * 6;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) mcc -= jd[i] * (o.r[i] + 0.5 * jd[i]);
+            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, u, v, dd);
+        }
+    }
+    d.cand_pts[l] = nx;
+    d.cand_pts[(size_t)d.Lpad + l] = ny;
+    d.cand_pts[2 * (size_t)d.Lpad + l] = nz;
+    const double a = block_sum(ccost, sm);
+    const double b = block_sum(mcc, sm);
+    const double c = block_sum(dn, sm);
+    const double e = block_sum(nonfinite, sm);
+    if (threadIdx.x == 0) {
+        d.part_eval[blockIdx.x * 4 + 0] = a;
+        d.part_eval[blockIdx.x * 4 + 1] = b;
+        d.part_eval[blockIdx.x * 4 + 2] = c;
+        d.part_eval[blockIdx.x * 4 + 3] = e;
+    }
+}
+
+// Sums the per-block partials of the linearisation into the exchange scalars
+// scal[0] = cost, scal[1] = |x_points|^2 and gmax_l (fixed order, one block).
+__global__ __launch_bounds__(256) void k_reduce_lin(Dev d) {
+    State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    __shared__ double sm[4];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+        a += d.part_lin[i * 4];
+        b += d.part_lin[i * 4 + 1];
+        c = fmax(c, d.part_lin[i * 4 + 2]);
+    }
+    a = block_sum(a, sm);
+    b = block_sum(b, sm);
+    c = block_max(c, sm);
+    if (threadIdx.x == 0) {
+        d.xv[d.off_scal + 0] = a;
+        d.xv[d.off_scal + 1] = b;
+        *d.gmax_l = c;
+        st.need_linearize = 0;
+        st.just_linearized = 1;
+    }
+}
+// keeps the (already reduced) scalars of the last linearisation in the exchange vector
+// on iterations that do not re-linearise, so that a sum over ranks stays correct
+__global__ void k_hold_scalars(Dev d, int nranks_dummy) { (void)d; (void)nranks_dummy; }
+
+__global__ __launch_bounds__(256) void k_reduce_eval(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
+    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+        a += d.part_eval[i * 4];
+        b += d.part_eval[i * 4 + 1];
+        c += d.part_eval[i * 4 + 2];
+        e += d.part_eval[i * 4 + 3];
+    }
+    a = block_sum(a, sm);
+    b = block_sum(b, sm);
+    c = block_sum(c, sm);
+    e = block_sum(e, sm);
+    if (threadIdx.x == 0) {
+        d.scal2[0] = a; d.scal2[1] = b; d.scal2[2] = c; d.scal2[3] = e;
+    }
+}
+
+// The body of the Ceres trust-region loop after the candidate evaluation: step validity,
+// parameter / function tolerance, step quality, accept / reject, radius update.
+__global__ __launch_bounds__(256) void k_decide(Dev d) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) {
+        a += d.part_pose[i * 2];
+        b += d.part_pose[i * 2 + 1];
+    }
+    a = block_sum(a, sm);
+    b = block_sum(b, sm);
+    if (threadIdx.x != 0) return;
+    const Options &o = st.opt;
+    const double candidate_cost_raw = d.scal2[0];
+    const double mcc = d.scal2[1];
+    const double step_norm = sqrt(d.scal2[2] + a);
+    const bool finite_step = (d.scal2[3] + b) == 0.0 && !st.step_failed;
+    st.model_cost_change = mcc;
+    // ComputeTrustRegionStep: LINEAR_SOLVER_FAILURE or model_cost_change <= 0 -> invalid
+    const bool step_is_valid = finite_step && (mcc > 0.0);
+    st.step_failed = 0;
+    if (!step_is_valid) {
+        // HandleInvalidStep
+        if (++st.num_invalid >= o.max_invalid && !o.ignore_convergence) {
+            st.terminated = 1; st.termination_type = 2;   // FAILURE
+        }
+        st.radius /= st.decrease_factor;
+        st.decrease_factor *= 2.0;
+        ++st.num_unsuccessful;
+        log_push(d, st, st.x_cost, 0.0, 0.0, 0.0, 0);
+        return;
+    }
+    st.num_invalid = 0;
+    const double candidate_cost = isfinite(candidate_cost_raw) ? candidate_cost_raw : DBL_MAX;
+    st.candidate_cost = candidate_cost;
+    st.step_norm = step_norm;
+    st.cost_change = st.x_cost - candidate_cost;
+    if (!o.ignore_convergence) {
+        // ParameterToleranceReached
+        if (step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) {
+            st.terminated = 1; st.termination_type = 0; return;
+        }
+        // FunctionToleranceReached
+        if (fabs(st.cost_change) <= o.function_tolerance * st.x_cost) {
+            st.terminated = 1; st.termination_type = 0; return;
+        }
+    }
+    // TrustRegionStepEvaluator::StepQuality
+    const double rd0 = (st.se_current - candidate_cost) / mcc;
+    const double rd1 = (st.se_reference - candidate_cost) / (st.se_acc_ref + mcc);
+    const double rd = rd0 > rd1 ? rd0 : rd1;
+    st.relative_decrease = rd;
+    if (rd > o.min_relative_decrease) {
+        // HandleSuccessfulStep (re-linearisation happens at the top of the next iteration)
+        st.accepted = 1;
+        st.last_successful = 1;
+        st.need_linearize = 1;
+        ++st.num_successful;
+        // LevenbergMarquardtStrategy::StepAccepted
+        const double tq = 2.0 * rd - 1.0;
+        st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
+        st.radius = fmin(o.max_radius, st.radius);
+        st.decrease_factor = 2.0;
+        // TrustRegionStepEvaluator::StepAccepted
+        st.se_current = candidate_cost;
+        st.se_acc_cand += mcc;
+        st.se_acc_ref += mcc;
+        if (st.se_current < st.se_minimum) {
+            st.se_minimum = st.se_current;
+            st.se_num_nonmono = 0;
+            st.se_candidate = st.se_current;
+            st.se_acc_cand = 0.0;
+        } else {
+            ++st.se_num_nonmono;
+            if (st.se_current > st.se_candidate) {
+                st.se_candidate = st.se_current;
+                st.se_acc_cand = 0.0;
+            }
+        }
+        if (st.se_num_nonmono == o.max_nonmono) {
+            st.se_reference = st.se_candidate;
+            st.se_acc_ref = st.se_acc_cand;
+        }
+    } else {
+        // HandleUnsuccessfulStep: LevenbergMarquardtStrategy::StepRejected
+        st.radius /= st.decrease_factor;
+        st.decrease_factor *= 2.0;
+        ++st.num_unsuccessful;
+        log_push(d, st, candidate_cost, st.cost_change, step_norm, rd, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_commit(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || !st.accepted) return;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)d.P * 12) d.poses[i] = d.cand_poses[i];
+    if (i < (size_t)d.Lpad * 3) d.pts[i] = d.cand_pts[i];
+}
+
+// (re)start of a solve: reset the trust-region state on the device
+__global__ void k_reset_state(Dev d, Options opt) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    State &st = *d.st;
+    st.opt = opt;
+    st.iteration = 0; st.terminated = 0; st.termination_type = 1;
+    st.need_linearize = 1; st.just_linearized = 0; st.last_successful = 0; st.accepted = 0;
+    st.copy_best = 0; st.step_failed = 0;
+    st.num_successful = 0; st.num_unsuccessful = 0; st.num_invalid = 0; st.log_count = 0;
+    st.radius = opt.initial_radius; st.decrease_factor = 2.0;
+    st.x_cost = 0.0; st.x_norm = 0.0; st.gmax = 0.0; st.minimum_cost = 0.0;
+    st.candidate_cost = 0.0; st.model_cost_change = 0.0; st.step_norm = 0.0;
+    st.relative_decrease = 0.0; st.cost_change = 0.0; st.initial_cost = 0.0;
+}
+
+// ----------------------------------------------------------------- launchers ---
+#define LAUNCH(cls, kern, grid, block, shmem, ...)                               \
+    do {                                                                         \
+        const dim3 _g = (grid);                                                  \
+        if (_g.x > 0 && _g.y > 0) {                                              \
+            L.begin(cls);                                                        \
+            hipLaunchKernelGGL(kern, _g, block, shmem, L.stream, __VA_ARGS__);   \
+            L.end(cls);                                                          \
+        }                                                                        \
+    } while (0)
+
+void launch_reset(Launcher &L, const Dev &d, const Options &o) {
+    hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(64), 0, L.stream, d, o);
+}
+
+void launch_linearize(Launcher &L, const Dev &d) {
+    LAUNCH(KC_LIN_LM, k_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_LIN_POSE, k_linearize_poses, dim3(d.P), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d);
+}
+
+void launch_schur(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(128), 0, d);
+    hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
+    const size_t n = (size_t)d.n_sblk * 36 + (size_t)d.nfree * 6;
+    LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+}
+
+void launch_finish_check(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
+    const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
+    LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+    hipLaunchKernelGGL(k_best_done, dim3(1), dim3(64), 0, L.stream, d);
+}
+
+void launch_bcr(Launcher &L, const Dev &d) {
+    const size_t sh_factor = (size_t)(BD * LDA + BD * LDR) * sizeof(double);
+    const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
+    const int nl = d.n_levels;
+    for (int l = 0; l + 1 < nl; ++l) {
+        const int n = d.lev[l].n;
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(256), sh_factor, d, l, 0);
+        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(192), sh_reduce, d, l);
+    }
+    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(256), sh_factor, d, nl - 1, 1);
+    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(128), 0, d, nl - 1, 1);
+    for (int l = nl - 2; l >= 0; --l)
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(128), 0, d, l, 0);
+}
+
+void launch_update_eval(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
+    LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
+}
+
+void launch_decide_commit(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d);
+    const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
+    LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+}
+
+int configure_kernels() {
+    const int sh_factor = (int)((BD * LDA + BD * LDR) * sizeof(double));
+    const int sh_reduce = (int)(2 * BD * BD * sizeof(double));
+    if (hipFuncSetAttribute((const void *)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, sh_factor) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, sh_reduce) != hipSuccess) return -1;
+    return 0;
+}
+
+}  // namespace ssba

@@ -1,0 +1,88 @@
+// Host-side launch interface between ssba_api.hip and ssba_kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "ssba_types.h"
+
+namespace ssba {
+
+enum KernelClass {
+    KC_LIN_LM = 0,
+    KC_LIN_POSE,
+    KC_SCHUR,
+    KC_ASSEMBLE,
+    KC_BCR_FACTOR,
+    KC_BCR_REDUCE,
+    KC_BCR_BACKSUB,
+    KC_BACKSUB_EVAL,
+    KC_COPY,
+    KC_SMALL,
+    KC_COUNT
+};
+
+static const char *const kKernelClassName[KC_COUNT] = {
+    "k_linearize_landmarks", "k_linearize_poses", "k_schur_windows", "k_assemble_reduced",
+    "k_bcr_factor", "k_bcr_reduce", "k_bcr_backsub", "k_backsub_eval", "copy(k_best,k_commit)",
+    "small(control,reductions)"};
+
+// Stream + optional per-kernel-class HIP-event timing (events are recorded on the
+// same stream the kernels run on and resolved lazily by collect()).
+struct Launcher {
+    hipStream_t stream = nullptr;
+    int timing = 0;
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[KC_COUNT] = {0};
+    unsigned long long launches[KC_COUNT] = {0};
+
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+    void begin(int cls) {
+        if (!timing) return;
+        Pending p{cls, get_event(), get_event()};
+        hipEventRecord(p.a, stream);
+        pending.push_back(p);
+    }
+    void end(int cls) {
+        (void)cls;
+        if (!timing) return;
+        hipEventRecord(pending.back().b, stream);
+    }
+    void collect() {   // caller has synchronised the stream
+        for (auto &p : pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                total_ms[p.cls] += ms;
+                launches[p.cls] += 1;
+            }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    void destroy() {
+        for (auto &p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+        pending.clear();
+        for (auto e : pool) hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+int upload_pair_table(hipStream_t s);
+int configure_kernels();
+void launch_reset(Launcher &L, const Dev &d, const Options &o);
+void launch_linearize(Launcher &L, const Dev &d);
+void launch_schur(Launcher &L, const Dev &d);
+void launch_finish_check(Launcher &L, const Dev &d);
+void launch_bcr(Launcher &L, const Dev &d);
+void launch_update_eval(Launcher &L, const Dev &d);
+void launch_decide_commit(Launcher &L, const Dev &d);
+
+}  // namespace ssba

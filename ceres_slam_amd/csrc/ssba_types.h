@@ -1,0 +1,123 @@
+// Internal device-side data model of the stereo-BA back end (not part of the ABI).
+//
+// HBM layout (all fp64 unless noted; see DESIGN.md "Data layout"):
+//   * landmarks are re-ordered on the host into *windows*: runs of consecutive
+//     landmarks whose observing poses all lie in one list of <= TW poses.  Inside a
+//     window an observation is addressed by (landmark, slot) where slot indexes the
+//     window's pose list, so the pose index never has to be stored per observation.
+//   * observations live in a transposed ELL layout in groups of 64 landmarks:
+//         ou/ov/od[(l/64)*TW*64 + slot*64 + (l%64)]
+//     so that a wavefront with one landmark per lane reads 512 contiguous bytes per
+//     array per slot; a 12-bit mask per landmark marks the occupied slots.
+//   * points and per-landmark results are structure-of-arrays over the padded
+//     landmark count (component-major), poses stay in the reference's 12-double
+//     [t | R row-major] block.
+//   * the reduced camera system S is block tridiagonal over super-blocks of SBP
+//     consecutive free poses (BD = 6*SBP rows): D[I] (BD x BD, full) and
+//     L[I] = S[I, I-1] (BD x BD), followed by rhs / g_p / diag(H_pp) vectors; that
+//     whole region is one contiguous "exchange vector" (the only thing ranks have
+//     to all-reduce when landmarks are sharded).
+#pragma once
+#include <stdint.h>
+
+namespace ssba {
+
+constexpr int TW = 12;                  // window width = max track length (ssba.h SSBA_MAX_TRACK)
+constexpr int NPAIR = TW * (TW + 1) / 2;  // 78 pose pairs (sa <= sb) per window
+constexpr int SBP = 12;                 // poses per super-block of the reduced system
+constexpr int BD = 6 * SBP;             // 72 rows per super-block
+constexpr int LMG = 64;                 // landmarks per ELL group (= wavefront)
+constexpr int SLAB_DOUBLES = NPAIR * 36 + TW * 6;   // per Schur work item
+constexpr int MAX_LEVELS = 24;
+constexpr int NSCAL = 16;
+
+struct Options {   // device copy of ssba_options
+    int max_num_iterations, max_nonmono, jacobi_scaling, max_invalid, ignore_convergence;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diag,
+        max_lm_diag, function_tolerance, gradient_tolerance, parameter_tolerance;
+};
+
+// Trust-region state, lives in device memory; the host only reads it.
+struct State {
+    Options opt;
+    int iteration;            // number of the iteration being worked on
+    int terminated, termination_type;
+    int need_linearize;       // x changed since the last linearisation
+    int just_linearized;      // set by the linearisation kernels, cleared by k_check
+    int last_successful;      // previous iteration accepted its step
+    int accepted;             // decision of the current iteration (for k_commit)
+    int copy_best;            // x improved on the best cost -> k_best copies
+    int step_failed;          // Cholesky breakdown / non-finite step this iteration
+    int num_successful, num_unsuccessful, num_invalid;
+    int log_count;
+    double radius, decrease_factor;
+    double x_cost, x_norm, gmax, minimum_cost;
+    double candidate_cost, model_cost_change, step_norm, relative_decrease, cost_change;
+    // TrustRegionStepEvaluator
+    double se_minimum, se_current, se_reference, se_candidate, se_acc_ref, se_acc_cand;
+    int se_num_nonmono;
+    int pad0;
+    double initial_cost;
+};
+
+struct IterLog {   // device arrays, capacity entries
+    int capacity;
+    double *cost, *cost_change, *gmax, *step_norm, *relative_decrease, *radius;
+    int *successful;
+};
+
+struct BcrLevel {
+    int n;            // blocks at this level
+    double *D, *L, *r;  // n blocks each (L[0] unused)
+    double *YU;       // n/2 blocks: G^-1 L[i+1]^T for odd i
+};
+
+struct Dev {
+    // camera, stiffness, loss
+    double fu, fv, cu, cv, b;
+    double S[9];
+    double huber_a;
+    // sizes
+    int P, nfree, Nsb, nf_pad;       // nf_pad = Nsb*SBP
+    int Lpad, n_groups, n_windows, n_slabs, n_sblk;
+    int n_lm_blocks;                 // blocks of 256 landmarks (partials)
+    uint32_t n_obs;
+    // parameters
+    double *poses, *cand_poses, *best_poses, *init_poses;   // P*12
+    double *pts, *cand_pts, *best_pts, *init_pts;           // 3*Lpad, component-major
+    const int *pose_free;            // P   -> free index or -1
+    const int *free_pose;            // nfree -> pose id
+    // observations
+    const double *ou, *ov, *od;      // n_groups*TW*64
+    const uint32_t *lm_mask;         // Lpad
+    const uint32_t *lm_win;          // Lpad
+    const uint32_t *win_pose;        // n_windows*TW (0xFFFFFFFF = empty slot)
+    const uint32_t *pose_obs_start;  // P+1
+    const uint32_t *pose_obs_ref;    // n_obs: landmark*16 + slot
+    // linearisation
+    double *hll, *gl, *sl;           // 6*Lpad, 3*Lpad, 3*Lpad (component-major)
+    double *hpp, *gp;                // P*21 (upper, row-major packed), P*6
+    double *sp;                      // nf_pad*6 Jacobi scale of free poses
+    // Schur
+    const uint32_t *slab_win, *slab_lm_begin, *slab_lm_end;  // n_slabs
+    double *slab;                    // n_slabs*SLAB_DOUBLES
+    const uint32_t *sblk_a, *sblk_b, *sblk_start, *sblk_contrib;  // n_sblk(+1), contributions
+    const uint32_t *prow_start, *prow_contrib;                   // nfree+1, (slab*TW+slot)
+    // reduced system (exchange vector) and solution
+    double *xv;                      // [D0 | L0 | rhs | gpx | hdiag | scal]
+    uint64_t off_D, off_L, off_rhs, off_gp, off_hdiag, off_scal, xv_count;
+    double *x0;                      // nf_pad*6 pose step
+    int n_levels;
+    BcrLevel lev[MAX_LEVELS];
+    // reductions
+    double *part_lin;                // n_lm_blocks*4: cost, |x_pts|^2, max|g_l|, -
+    double *part_eval;               // n_lm_blocks*4: cand cost, mcc, |dl|^2, nonfinite
+    double *part_pose;               // ceil(P/256)*2: |dx_pose|^2, nonfinite
+    double *scal2;                   // NSCAL: second exchange vector
+    double *gmax_l;                  // 1: landmark part of the gradient max norm
+    int n_pose_blocks;
+    State *st;
+    IterLog log;
+};
+
+}  // namespace ssba

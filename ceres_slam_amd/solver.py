@@ -1,0 +1,170 @@
+"""Array-level handle over the C ABI (include/ssba.h) for the bench harness, the parity
+tests and multi-GPU drivers: one ``StereoBA`` = one ``ssba_problem``.
+
+Everything here is a direct call into libssba.so; numpy is used for host buffers only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class StereoBA:
+    def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
+                 stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True):
+        self.lib = capi.load()
+        self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
+        self.points = np.ascontiguousarray(points, dtype=np.float64)
+        self._obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
+        self._obs_point = np.ascontiguousarray(obs_point, dtype=np.uint32)
+        self._obs_uvd = np.ascontiguousarray(obs_uvd, dtype=np.float64)
+        self._S = np.ascontiguousarray(np.asarray(stiffness, dtype=np.float64).reshape(9))
+        self.h = C.c_void_p()
+        cam = capi.Camera(**camera)
+        capi.check(self.lib.ssba_create(C.byref(cam), device, C.byref(self.h)), "ssba_create")
+        P, L = self.poses.shape[0], self.points.shape[0]
+        capi.check(self.lib.ssba_add_pose_blocks(self.h, capi.dptr(self.poses), P), "ssba_add_pose_blocks")
+        capi.check(self.lib.ssba_add_point_blocks(self.h, capi.dptr(self.points), L), "ssba_add_point_blocks")
+        capi.check(self.lib.ssba_add_stereo_observations(
+            self.h, self._obs_pose.ctypes.data_as(capi._u32p), self._obs_point.ctypes.data_as(capi._u32p),
+            capi.dptr(self._obs_uvd), self._obs_pose.shape[0], capi.dptr(self._S)), "ssba_add_stereo_observations")
+        if pose_const is None:
+            pose_const = np.zeros(P, dtype=bool)
+            if P:
+                pose_const[0] = True              # tests/dataset_vo.cpp:62
+        for k in np.nonzero(np.asarray(pose_const))[0]:
+            capi.check(self.lib.ssba_set_pose_constant(self.h, int(k), 1), "ssba_set_pose_constant")
+        if huber_a > 0:
+            capi.check(self.lib.ssba_set_huber_loss(self.h, float(huber_a)), "ssba_set_huber_loss")
+        self._xcb = None
+        if finalize:
+            self.finalize()
+
+    @classmethod
+    def from_synth(cls, prob, **kw):
+        return cls(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point,
+                   prob.obs_uvd, prob.stiffness(), **kw)
+
+    def finalize(self):
+        capi.check(self.lib.ssba_finalize(self.h), "ssba_finalize")
+
+    def close(self):
+        if self.h:
+            self.lib.ssba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- solving ----------------------------------------------------------------
+    def solve(self, options: capi.Options = None):
+        o = options or capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1)
+        s = capi.Summary()
+        rc = self.lib.ssba_solve(self.h, C.byref(o), C.byref(s))
+        if rc not in (0, -3):
+            capi.check(rc, "ssba_solve")
+        return s, self.iteration_log()
+
+    def solve_begin(self, options: capi.Options, ignore_convergence: bool = False):
+        self._opts = options
+        capi.check(self.lib.ssba_solve_begin(self.h, C.byref(options), int(ignore_convergence)), "ssba_solve_begin")
+
+    def step(self, n: int = 1):
+        capi.check(self.lib.ssba_solve_step(self.h, n), "ssba_solve_step")
+
+    def restart(self):
+        capi.check(self.lib.ssba_solve_restart(self.h), "ssba_solve_restart")
+
+    def synchronize(self):
+        capi.check(self.lib.ssba_synchronize(self.h), "ssba_synchronize")
+
+    def solve_end(self):
+        s = capi.Summary()
+        rc = self.lib.ssba_solve_end(self.h, C.byref(s))
+        if rc not in (0, -3):
+            capi.check(rc, "ssba_solve_end")
+        return s
+
+    def iteration_log(self):
+        n = self.lib.ssba_iteration_log(self.h, 0, None, None, None, None, None, None, None)
+        names = ("cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease", "trust_region_radius")
+        cols = {k: np.zeros(n) for k in names}
+        ok = np.zeros(n, dtype=np.int32)
+        self.lib.ssba_iteration_log(self.h, n, *[capi.dptr(cols[k]) for k in names], ok.ctypes.data_as(capi._i32p))
+        cols["step_is_successful"] = ok
+        return cols
+
+    @staticmethod
+    def brief_report(s: capi.Summary) -> str:
+        buf = C.create_string_buffer(256)
+        capi.load().ssba_brief_report(C.byref(s), buf, 256)
+        return buf.value.decode()
+
+    # ---- streams / exchange / instrumentation --------------------------------------
+    def set_stream(self, stream_ptr: int):
+        capi.check(self.lib.ssba_set_stream(self.h, C.c_void_p(stream_ptr)), "ssba_set_stream")
+
+    def set_exchange(self, fn):
+        """fn(device_ptr: int, count: int, op: int) -> None, op 0 = sum, 1 = max."""
+        if fn is None:
+            self._xcb = None
+            capi.check(self.lib.ssba_set_exchange(self.h, capi.EXCHANGE_FN(0), None), "ssba_set_exchange")
+            return
+
+        def tramp(ctx, ptr, count, op):
+            try:
+                fn(int(ptr), int(count), int(op))
+                return 0
+            except Exception:            # never let an exception cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._xcb = capi.EXCHANGE_FN(tramp)
+        capi.check(self.lib.ssba_set_exchange(self.h, self._xcb, None), "ssba_set_exchange")
+
+    def exchange_size(self) -> int:
+        n = C.c_uint64()
+        capi.check(self.lib.ssba_exchange_size(self.h, C.byref(n)), "ssba_exchange_size")
+        return n.value
+
+    def set_kernel_timing(self, on: bool):
+        capi.check(self.lib.ssba_set_kernel_timing(self.h, int(on)), "ssba_set_kernel_timing")
+
+    def kernel_times(self) -> dict:
+        rows = (capi.KernelTime * 32)()
+        n = C.c_int32()
+        capi.check(self.lib.ssba_kernel_times(self.h, rows, 32, C.byref(n)), "ssba_kernel_times")
+        return {rows[i].name.decode(): (int(rows[i].launches), float(rows[i].total_ms)) for i in range(n.value)}
+
+    def stats(self) -> capi.Stats:
+        st = capi.Stats()
+        capi.check(self.lib.ssba_get_stats(self.h, C.byref(st)), "ssba_get_stats")
+        return st
+
+    # ---- test hooks -------------------------------------------------------------------
+    def evaluate(self):
+        P, L = self.poses.shape[0], self.points.shape[0]
+        cost = C.c_double()
+        g_p, g_l = np.zeros((P, 6)), np.zeros((L, 3))
+        H_pp, H_ll = np.zeros((P, 6, 6)), np.zeros((L, 3, 3))
+        capi.check(self.lib.ssba_evaluate(self.h, C.byref(cost), capi.dptr(g_p), capi.dptr(g_l), capi.dptr(H_pp),
+                                          capi.dptr(H_ll)), "ssba_evaluate")
+        return cost.value, g_p, g_l, H_pp, H_ll
+
+    def lm_step(self, radius: float, options: capi.Options = None, want_S: bool = True):
+        P, L = self.poses.shape[0], self.points.shape[0]
+        n = 6 * self.stats().num_free_poses
+        S = np.zeros((n, n)) if want_S else None
+        rhs = np.zeros(n)
+        dp, dl = np.zeros((P, 6)), np.zeros((L, 3))
+        mcc = C.c_double()
+        o = options or capi.default_options()
+        capi.check(self.lib.ssba_lm_step(self.h, C.byref(o), radius, capi.dptr(S) if want_S else None, capi.dptr(rhs),
+                                         capi.dptr(dp), capi.dptr(dl), C.byref(mcc)), "ssba_lm_step")
+        return S, rhs, dp, dl, mcc.value

@@ -1,0 +1,212 @@
+/*
+ * ssba.h -- C ABI of the MI355X-native stereo bundle-adjustment back end.
+ *
+ * This is the drop-in boundary for the one hot path of utiasSTARS/ceres-slam:
+ * everything that happens inside `ceres::Solve` for the stereo BA problems its
+ * drivers build.  The reference has no FFI or plugin table;
+ * its "plugin point" is the Ceres C++ API as used by tests/dataset_vo.cpp:22-85 and
+ * tests/dataset_ba_phong.cpp:26-255.  Each entry point below names the reference
+ * call(s) it replaces (file:line into the reference repo).  A header-only C++ shim
+ * with the reference's call shapes on top of this ABI is include/ceres_slam_amd/
+ * ceres_shim.hpp; the binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no exceptions cross the ABI; every function returns an ssba_status
+ *    (0 = ok, negative = error); ssba_status_string() names it.
+ *  - parameter memory stays OWNED BY THE CALLER (the reference hands Ceres raw
+ *    pointers into std::vector<SE3>/Point: dataset_vo.cpp:51-53); the library keeps
+ *    device mirrors and writes the caller's blocks back in place when a solve ends
+ *    with a usable solution -- exactly Ceres's contract.
+ *  - a pose block is 12 doubles [t(3) | R row-major(9)] = T_c_g
+ *    (include/ceres_slam/geometry/se3group.hpp:425-429); a point block is 3 doubles.
+ *  - a handle is single-owner and not thread-safe (like ceres::Problem).
+ *  - all arithmetic is IEEE fp64 on the GPU; there is NO CPU fallback: without a
+ *    usable HIP device every compute entry point returns SSBA_ERR_NO_DEVICE.
+ */
+#ifndef SSBA_H_
+#define SSBA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSBA_VERSION 1
+/* longest landmark track (observations of one landmark) this build accepts */
+#define SSBA_MAX_TRACK 12
+
+typedef struct ssba_problem ssba_problem;
+
+typedef enum {
+    SSBA_OK = 0,
+    SSBA_ERR_INVALID_ARGUMENT = -1,
+    SSBA_ERR_HIP = -2,              /* a HIP runtime call failed (see ssba_last_error) */
+    SSBA_ERR_NUMERICAL_FAILURE = -3,
+    SSBA_ERR_NOT_FINALIZED = -4,
+    SSBA_ERR_NO_DEVICE = -5,        /* no usable gfx950 device: no CPU fallback exists  */
+    SSBA_ERR_UNSUPPORTED = -6,      /* structure outside this build's envelope          */
+    SSBA_ERR_STATE = -7             /* call sequence error                              */
+} ssba_status;
+
+/* StereoCamera<double> intrinsics (include/ceres_slam/stereo_camera.hpp:159-163) */
+typedef struct { double fu, fv, cu, cv, b; } ssba_camera;
+
+/* The ceres::Solver::Options fields the reference drivers set
+ * (tests/dataset_vo.cpp:65-74, tests/dataset_ba_phong.cpp:79-88) plus the Ceres 1.x
+ * defaults that shape the trust-region loop.  Unlisted Ceres options keep their
+ * defaults.  trust_region_strategy_type / linear_solver_type: this build
+ * implements LEVENBERG_MARQUARDT with an exact Schur-complement solve (what
+ * dataset_vo.cpp runs; DOGLEG is SURVEY.md 8(f) row N1). */
+typedef struct {
+    int32_t max_num_iterations;                 /* 50; drivers: 1000                   */
+    int32_t use_nonmonotonic_steps;             /* 0;  drivers: 1                      */
+    int32_t max_consecutive_nonmonotonic_steps; /* 5                                   */
+    int32_t jacobi_scaling;                     /* 1                                   */
+    int32_t max_num_consecutive_invalid_steps;  /* 5                                   */
+    int32_t minimizer_progress_to_stdout;       /* 0                                   */
+    int32_t num_threads;                        /* accepted, ignored (GPU)             */
+    int32_t num_linear_solver_threads;          /* accepted, ignored (GPU)             */
+    double initial_trust_region_radius;         /* 1e4                                 */
+    double max_trust_region_radius;             /* 1e16                                */
+    double min_trust_region_radius;             /* 1e-32                               */
+    double min_relative_decrease;               /* 1e-3                                */
+    double min_lm_diagonal;                     /* 1e-6                                */
+    double max_lm_diagonal;                     /* 1e32                                */
+    double function_tolerance;                  /* 1e-6                                */
+    double gradient_tolerance;                  /* 1e-10                               */
+    double parameter_tolerance;                 /* 1e-8                                */
+} ssba_options;
+
+/* ceres::TerminationType values the path can produce */
+enum { SSBA_CONVERGENCE = 0, SSBA_NO_CONVERGENCE = 1, SSBA_FAILURE = 2 };
+
+/* ceres::Solver::Summary fields the drivers print (summary.BriefReport():
+ * tests/dataset_vo.cpp:82) plus per-phase device timings. */
+typedef struct {
+    int32_t termination_type;
+    int32_t num_iterations;          /* recorded iterations incl. iteration 0          */
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    double initial_cost;
+    double final_cost;
+    double total_time_s;             /* wall time of ssba_solve incl. write-back       */
+    double device_time_s;            /* GPU time of the iteration loop (HIP events)    */
+} ssba_summary;
+
+/* ---- lifetime --------------------------------------------------------------------- */
+/* replaces: ceres::Problem problem; + the shared StereoCamera captured by every
+ * functor (tests/dataset_vo.cpp:26, stereo_reprojection_error.hpp:73).
+ * device < 0 selects the current HIP device. */
+int ssba_create(const ssba_camera *camera, int device, ssba_problem **out);
+int ssba_destroy(ssba_problem *p);
+
+/* ---- problem building ------------------------------------------------------------- */
+/* replaces: the pose blocks passed to AddResidualBlock + SetParameterization(pose,
+ * SE3Perturbation) (tests/dataset_vo.cpp:51-58; include/ceres_slam/perturbations.hpp:45-76).
+ * `poses` is num*12 doubles, caller-owned, updated in place by a solve. */
+int ssba_add_pose_blocks(ssba_problem *p, double *poses, uint32_t num);
+/* replaces: the point blocks passed to AddResidualBlock (tests/dataset_vo.cpp:53);
+ * `points` is num*3 doubles, caller-owned, updated in place. */
+int ssba_add_point_blocks(ssba_problem *p, double *points, uint32_t num);
+/* replaces: StereoReprojectionErrorAutomatic::Create(camera, obs, stiffness) +
+ * problem.AddResidualBlock(cost, NULL, pose_k, point_j) for every observation
+ * (include/ceres_slam/stereo_reprojection_error.hpp:59-69; tests/dataset_vo.cpp:39-56).
+ * uvd is num*3 (u_l, v_l, d); stiffness is the shared 3x3 row-major Sigma^{-1/2}
+ * (tests/dataset_vo.cpp:29-32).  May be called several times; order is kept. */
+int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index,
+                                 const uint32_t *point_index, const double *uvd,
+                                 uint64_t num, const double stiffness[9]);
+/* replaces: problem.SetParameterBlockConstant / SetParameterBlockVariable(pose)
+ * (tests/dataset_vo.cpp:62; tests/dataset_ba_phong.cpp:76,219-243) */
+int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant);
+/* replaces: passing `new ceres::HuberLoss(a)` instead of NULL to AddResidualBlock
+ * (call-site shape tests/dataset_vo_sun.cpp:89-95); a <= 0 restores the NULL loss */
+int ssba_set_huber_loss(ssba_problem *p, double a);
+/* Uploads the problem graph and builds the device-side structure (once per graph). */
+int ssba_finalize(ssba_problem *p);
+
+/* ---- solving ---------------------------------------------------------------------- */
+/* Ceres 1.x defaults */
+void ssba_default_options(ssba_options *o);
+/* replaces: ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81).
+ * Blocking.  Re-uploads the caller's current parameter values first. */
+int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s);
+/* replaces: summary.BriefReport() (tests/dataset_vo.cpp:82) */
+int ssba_brief_report(const ssba_summary *s, char *buf, size_t buf_len);
+
+/* Stepwise form of ssba_solve for the bench harness and for multi-GPU drivers:
+ * begin (upload + iteration 0), `step` enqueues n trust-region iterations on the
+ * stream without host synchronisation, end synchronises and writes back.
+ * With ignore_convergence != 0 the convergence tests are skipped so that exactly n
+ * iterations of full work are executed (bench.py's timed region). */
+int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence);
+int ssba_solve_step(ssba_problem *p, int n);
+int ssba_solve_end(ssba_problem *p, ssba_summary *s);
+/* restores the parameter values uploaded by ssba_solve_begin and restarts the
+ * trust-region state (device-to-device, asynchronous) */
+int ssba_solve_restart(ssba_problem *p);
+int ssba_synchronize(ssba_problem *p);
+
+/* Per-iteration log of the last solve (the columns of Ceres's progress table).
+ * Arrays of `capacity` entries or NULL; returns the number of recorded iterations. */
+int ssba_iteration_log(ssba_problem *p, int32_t capacity, double *cost, double *cost_change,
+                       double *gradient_max_norm, double *step_norm, double *relative_decrease,
+                       double *trust_region_radius, int32_t *step_is_successful);
+
+/* ---- streams, multi-GPU exchange, instrumentation ---------------------------------- */
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream). */
+int ssba_set_stream(ssba_problem *p, void *hip_stream);
+/* Landmark sharding: every rank adds ALL pose blocks and only ITS landmarks and
+ * observations.  The library calls `fn` at the two exchange points of an iteration
+ * with a device buffer of `count` doubles that must be reduced in place over all
+ * ranks (op 0 = sum, 1 = max) on the stream given to ssba_set_stream -- e.g. a
+ * torch.distributed all_reduce over RCCL.  fn == NULL (default) = single GPU. */
+typedef int (*ssba_exchange_fn)(void *ctx, void *device_buffer, uint64_t count, int op);
+int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx);
+/* number of doubles in the per-iteration reduced-system exchange */
+int ssba_exchange_size(ssba_problem *p, uint64_t *count);
+
+/* Kernel timing with HIP events on the library's stream.  mode 0 = off, 1 = time every
+ * kernel class (eager launches).  ssba_kernel_times returns up to `capacity` rows. */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+} ssba_kernel_time;
+int ssba_set_kernel_timing(ssba_problem *p, int mode);
+int ssba_kernel_times(ssba_problem *p, ssba_kernel_time *rows, int32_t capacity, int32_t *num);
+
+/* Problem statistics after ssba_finalize. */
+typedef struct {
+    uint32_t num_poses, num_free_poses, num_points, num_active_points;
+    uint64_t num_observations;
+    uint32_t num_windows;          /* landmark groups sharing a <=12-pose window        */
+    uint32_t num_superblocks;      /* 72x72 super-blocks of the block-tridiagonal S     */
+    uint32_t num_reduced_blocks;   /* non-zero 6x6 blocks of S (upper incl. diagonal)   */
+    uint32_t pose_bandwidth;       /* max free-pose index distance of co-observers      */
+    uint64_t device_bytes;         /* device memory held by the handle                  */
+} ssba_stats;
+int ssba_get_stats(ssba_problem *p, ssba_stats *st);
+
+/* ---- test hooks (parity tests call these through the C ABI) ------------------------ */
+/* Normal-equation blocks at the caller's current parameters, in user index order:
+ * cost, g_p (P*6), g_l (L*3), H_pp (P*36 row-major), H_ll (L*9).  Blocks of constant
+ * poses are zero.  Any output may be NULL. */
+int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, double *H_pp,
+                  double *H_ll);
+/* Dense reduced camera system S (n*n row-major, n = 6*num_free_poses) and rhs (n) for
+ * trust-region radius `radius` at the caller's current parameters (S * delta_p = rhs),
+ * and the step the device solver computes from it: delta_p (P*6), delta_l (L*3) and the
+ * model cost change.  Any output may be NULL. */
+int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S,
+                 double *rhs, double *delta_p, double *delta_l, double *model_cost_change);
+
+const char *ssba_status_string(int status);
+const char *ssba_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSBA_H_ */

@@ -1,0 +1,66 @@
+"""CPU-side checks of the C-ABI library: it builds for gfx950, loads, and exports every
+symbol include/ssba.h declares.  No compute entry point is called here (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from ceres_slam_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_loads():
+    path = build.build_library()
+    assert os.path.exists(path)
+    capi.load()
+
+
+def test_every_header_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "ssba.h")).read()
+    declared = set(re.findall(r"\b(ssba_[a-z_]+)\s*\(", hdr))
+    declared -= {"ssba_exchange_fn"}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    lib = capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_header_sizes():
+    # ssba_options: 8 int32 + 9 double ; ssba_summary: 4 int32 + 4 double
+    assert ctypes.sizeof(capi.Options) == 8 * 4 + 9 * 8
+    assert ctypes.sizeof(capi.Summary) == 4 * 4 + 4 * 8
+    assert ctypes.sizeof(capi.KernelTime) == 48 + 8 + 8
+    assert ctypes.sizeof(capi.Camera) == 40
+
+
+def test_defaults_are_the_ceres_1x_defaults():
+    o = capi.default_options()
+    assert o.max_num_iterations == 50 and o.use_nonmonotonic_steps == 0
+    assert o.initial_trust_region_radius == 1e4 and o.min_relative_decrease == 1e-3
+    assert o.function_tolerance == 1e-6 and o.gradient_tolerance == 1e-10 and o.parameter_tolerance == 1e-8
+    assert o.min_lm_diagonal == 1e-6 and o.max_lm_diagonal == 1e32
+
+
+def test_status_strings_and_no_cpu_fallback():
+    lib = capi.load()
+    assert b"no CPU fallback" in lib.ssba_status_string(-5)
+    import torch
+    if not torch.cuda.is_available():
+        # without a GPU the product path must fail loudly, never compute on the CPU
+        cam = capi.Camera(1, 1, 0, 0, 1)
+        h = ctypes.c_void_p()
+        rc = lib.ssba_create(ctypes.byref(cam), -1, ctypes.byref(h))
+        assert rc == -5
+        with pytest.raises(capi.SsbaError):
+            capi.check(rc, "ssba_create")
+
+
+def test_brief_report_format():
+    s = capi.Summary(0, 11, 8, 3, 799981.7855, 28995.1736, 0.0, 0.0)
+    buf = ctypes.create_string_buffer(256)
+    assert capi.load().ssba_brief_report(ctypes.byref(s), buf, 256) == 0
+    assert buf.value.decode() == ("Ceres Solver Report: Iterations: 11, Initial cost: 7.999818e+05, "
+                                  "Final cost: 2.899517e+04, Termination: CONVERGENCE")
