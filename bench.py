@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Bench harness: Gauss-Newton (Levenberg-Marquardt) iterations/s of the stereo-BA hot path.
+
+Contract (one JSON line on rank 0):
+  * a *step* is one trust-region iteration (linearise -> Schur -> reduced solve ->
+    back-substitute -> candidate evaluation -> accept/reject) on the synthetic stereo-BA
+    problem BASELINE.json quotes the metric on: C2 = 1 000 poses / 100 000 landmarks /
+    ~1.19 M stereo observations, reprojection-only cost, fp64;
+  * all inputs are resident in HBM before the timed region; the timed region runs the real
+    solve repeatedly: whenever the solve has done as many iterations as the converging
+    solve needs (measured in warm-up) the parameters are reset on the device and the
+    solve restarts, so every timed iteration does the full work of a live iteration;
+  * N > 1 (one rank per GPU under torch.distributed.run): weak scaling -- every rank owns
+    one C2-sized segment of an N-times longer trajectory (its landmarks and their
+    observations; poses replicated); the reduced pose system is all-reduced over RCCL
+    every iteration.  `value` = N x joint-problem iterations/s (C2-shard-iterations/s).
+  * `roofline`: the dominant kernel's algorithmic bytes or flops per launch / its average
+    duration measured with HIP events on the library's stream during the timed region;
+  * `cpu_baseline`: the CPU oracle (a port with Ceres-equivalent semantics, NOT Ceres --
+    Ceres/Eigen are not installable here) timed on the host cores on the same problem.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_PEAK_TFLOPS = 78.6        # public MI355X spec, vector = matrix fp64
+
+
+def algorithmic_work(stats):
+    """Per-launch algorithmic bytes / flops of each kernel class."""
+    N, L, P = stats["num_observations"], stats["num_active_points"], stats["num_free_poses"]
+    B, T = stats["num_reduced_blocks"], stats["num_observations"] / max(stats["num_active_points"], 1)
+    return {
+        # 24 B (u,v,d) per observation + landmark in (24) + H_ll,g_l out (72)
+        "k_linearize_landmarks": dict(bytes=24 * N + 96 * L, flops=150 * N),
+        # 24 B obs + 4 B ref + 24 B gathered point per observation, 216 B out per pose
+        "k_linearize_poses": dict(bytes=52 * N + 216 * P, flops=330 * N),
+        # per landmark: T(T+1)/2 pairs x 108 FMA + T half-linearisations (~330 flop)
+        "k_schur_windows": dict(bytes=24 * N + 120 * L, flops=L * (T * (T + 1) / 2 * 216 + T * 330)),
+        "k_backsub_eval": dict(bytes=2 * 24 * N + 120 * L, flops=500 * N),
+        "k_assemble_reduced": dict(bytes=B * 288 * 2, flops=0),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=12)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ceres_slam_amd import capi, synth
+    from ceres_slam_amd.solver import StereoBA
+    from ceres_slam_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the stereo-BA path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    P1, L1 = synth.CONFIGS[args.config]
+    prob = synth.make_problem(P1 * world, L1 * world)
+    if world > 1:
+        shard = sharding.shard_by_landmarks(prob, world, rank)
+    else:
+        shard = sharding.whole(prob)
+    ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
+                  prob.stiffness(), device=local_rank)
+    stream = torch.cuda.current_stream()
+    ba.set_stream(stream.cuda_stream)
+    if world > 1:
+        sharding.attach_torch_exchange(ba, dist)
+    st = ba.stats()
+    stats = {k: int(getattr(st, k)) for k, _ in capi.Stats._fields_}
+
+    opts = capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1)   # tests/dataset_vo.cpp:65-70
+    # ---- warm-up: one real solve to convergence (also gives the restart period) ----------
+    s_conv, log_conv = ba.solve(opts)
+    period = max(int(s_conv.num_iterations) - 1, 1)
+    final_cost = float(s_conv.final_cost)
+    ba.poses[:] = shard.poses_init
+    ba.points[:] = shard.points_init
+
+    def run(n_steps, timing):
+        ba.set_kernel_timing(timing)
+        done = 0
+        while done < n_steps:
+            if done and done % period == 0:
+                ba.restart()
+            ba.step(1)
+            done += 1
+
+    ba.solve_begin(opts, ignore_convergence=True)
+    run(args.warmup, False)
+    ba.synchronize()
+    ba.restart()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, True)
+    ba.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ktimes = ba.kernel_times()
+    ba.solve_end()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        joint_ips = args.steps / dt
+        work = algorithmic_work(stats)
+        per_kernel = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in ktimes.items()}   # avg ms
+        iter_kernel_ms = {k: v[1] / args.steps for k, v in ktimes.items()}
+        dom = max((k for k in iter_kernel_ms if k in work), key=lambda k: iter_kernel_ms[k])
+        w = work[dom]
+        avg_s = per_kernel[dom] * 1e-3
+        ai = w["flops"] / max(w["bytes"], 1)
+        if ai > FP64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+            roof = dict(bound="mfma", achieved=w["flops"] / avg_s / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+        else:
+            roof = dict(bound="hbm", achieved=w["bytes"] / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["kernel"] = dom
+        roof["avg_kernel_ms"] = per_kernel[dom]
+        out = {
+            "metric": "gauss_newton_iters_per_sec",
+            "value": joint_ips * world,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {P1 * world} poses / {L1 * world} landmarks / "
+                                   f"{prob.num_obs} stereo observations, reprojection-only LM (Ceres dataset_vo "
+                                   f"options), {world} shard(s)",
+                       "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
+                       "restart_period_iters": period, "joint_iters_per_sec": joint_ips,
+                       "converged_final_cost": final_cost},
+            "roofline": roof,
+            "kernel_ms_per_iter": {k: round(v, 5) for k, v in iter_kernel_ms.items()},
+            "stats": stats,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(prob, iters, gpu_final_cost):
+    """CPU oracle = port with Ceres-equivalent semantics (kind "port"); bounded sample."""
+    from oracle import oracle as orc
+    cores = min(os.cpu_count() or 1, 16)
+    op = orc.OracleProblem.from_synth(prob)
+    orc.lib()
+    t0 = time.perf_counter()
+    s, log = op.solve(orc.driver_options(num_threads=cores, max_num_iterations=iters))
+    dt = time.perf_counter() - t0
+    n = max(int(s.num_iterations) - 1, 1)
+    return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} trust-region iterations of the same {prob.num_obs}-observation solve "
+                      f"(OpenMP, {cores} threads, analytic Jacobians, Schur + band Cholesky); {dt:.1f} s",
+            "ms_per_iter": 1e3 * dt / n, "cost_after_sample": float(log["cost"][-1]),
+            "gpu_converged_final_cost": gpu_final_cost}
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,7 @@ SYMBOLS = [
     "ssba_add_stereo_observations", "ssba_set_pose_constant", "ssba_set_huber_loss", "ssba_finalize",
     "ssba_default_options", "ssba_solve", "ssba_brief_report", "ssba_solve_begin", "ssba_solve_step",
     "ssba_solve_end", "ssba_solve_restart", "ssba_synchronize", "ssba_iteration_log", "ssba_set_stream",
-    "ssba_set_exchange", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
+    "ssba_set_exchange", "ssba_set_distributed", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_status_string", "ssba_last_error",
 ]
 
@@ -112,6 +112,7 @@ def load():
     L.ssba_iteration_log.argtypes = [H, C.c_int32, _dp, _dp, _dp, _dp, _dp, _dp, _i32p]
     L.ssba_set_stream.argtypes = [H, C.c_void_p]
     L.ssba_set_exchange.argtypes = [H, EXCHANGE_FN, C.c_void_p]
+    L.ssba_set_distributed.argtypes = [H, C.c_int, C.c_int]
     L.ssba_exchange_size.argtypes = [H, C.POINTER(C.c_uint64)]
     L.ssba_set_kernel_timing.argtypes = [H, C.c_int]
     L.ssba_kernel_times.argtypes = [H, C.POINTER(KernelTime), C.c_int32, _i32p]

@@ -58,6 +58,7 @@ struct ssba_problem {
     size_t h_stage_count = 0;
     ssba_exchange_fn xfn = nullptr;
     void *xctx = nullptr;
+    int world_size = 1, rank = 0;
     // solve bookkeeping
     bool began = false;
     ssba_options opt{};
@@ -251,6 +252,14 @@ int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx) {
     return SSBA_OK;
 }
 
+int ssba_set_distributed(ssba_problem *p, int world_size, int rank) {
+    if (!p || world_size < 1 || rank < 0 || rank >= world_size) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    p->world_size = world_size;
+    p->rank = rank;
+    return SSBA_OK;
+}
+
 int ssba_exchange_size(ssba_problem *p, uint64_t *count) {
     if (!p || !count) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
@@ -292,7 +301,7 @@ int ssba_finalize(ssba_problem *p) {
     p->pose_free.assign(P, -1);
     p->free_pose.clear();
     for (uint32_t k = 0; k < P; ++k)
-        if (pose_cnt[k] > 0 && !p->pose_const[k]) {
+        if ((pose_cnt[k] > 0 || p->world_size > 1) && !p->pose_const[k]) {
             p->pose_free[k] = (int)p->free_pose.size();
             p->free_pose.push_back((int)k);
         }

@@ -582,11 +582,13 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
     (void)cost;
     if (threadIdx.x != 0) return;
     if (lin) {
-        const double *sc = d.xv + d.off_scal;
+        double *sc = d.xv + d.off_scal;
         st.x_cost = sc[0];
         st.x_norm = sqrt(sc[1] + xnp);
         st.gmax = fmax(gmp, *d.gmax_l);
         st.just_linearized = 0;
+        sc[0] = 0.0;   // consumed: later all-reduces of the exchange vector add zeros
+        sc[1] = 0.0;
     }
     if (st.iteration == 0) {
         // IterationZero

@@ -14,7 +14,8 @@ from . import capi
 
 class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
-                 stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True):
+                 stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
+                 world_size: int = 1, rank: int = 0):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
         self.points = np.ascontiguousarray(points, dtype=np.float64)
@@ -40,6 +41,8 @@ class StereoBA:
         if huber_a > 0:
             capi.check(self.lib.ssba_set_huber_loss(self.h, float(huber_a)), "ssba_set_huber_loss")
         self._xcb = None
+        if world_size > 1:
+            capi.check(self.lib.ssba_set_distributed(self.h, world_size, rank), "ssba_set_distributed")
         if finalize:
             self.finalize()
 

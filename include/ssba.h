@@ -165,6 +165,10 @@ int ssba_set_stream(ssba_problem *p, void *hip_stream);
  * torch.distributed all_reduce over RCCL.  fn == NULL (default) = single GPU. */
 typedef int (*ssba_exchange_fn)(void *ctx, void *device_buffer, uint64_t count, int op);
 int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx);
+/* Declares (before ssba_finalize) that the landmarks are sharded over `world_size` ranks:
+ * every non-constant pose is then kept in the reduced system even if THIS rank holds no
+ * observation of it, so that all ranks agree on the layout of the exchanged system. */
+int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
 /* number of doubles in the per-iteration reduced-system exchange */
 int ssba_exchange_size(ssba_problem *p, uint64_t *count);
 

@@ -146,7 +146,7 @@ def test_edge_cases_ragged_tracks_unobserved_blocks_and_errors():
     keep[prob.obs_pose == 5] = False
     keep[::7] = False
     args = (prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose[keep], prob.obs_point[keep], prob.obs_uvd[keep], prob.stiffness())
-    ba = StereoBA(cam, *args)
+    ba = StereoBA(cam, args[0].copy(), args[1].copy(), *args[2:])   # StereoBA updates its blocks in place
     s, log = ba.solve(capi.default_options(**DRIVER))
     op = orc.OracleProblem(cam, *args)
     s2, log2 = op.solve(orc.driver_options(num_threads=1))
