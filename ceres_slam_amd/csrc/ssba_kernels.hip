@@ -636,208 +636,6 @@ __global__ void k_best_done(Dev d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d.st->copy_best = 0;
 }
 
-// ---------------------------------------------------- block cyclic reduction ---
-// S is block tridiagonal with BD x BD blocks.  Level l eliminates its odd blocks:
-//   factor  (per odd i):  D_i = G G^T ; YL = G^-1 L_i ; YU = G^-1 L_{i+1}^T ; yr = G^-1 r_i
-//   reduce  (per even e): D' = D_e - YU(e-1)^T YU(e-1) - YL(e+1)^T YL(e+1)
-//                         L' = -YU(e-1)^T YL(e-1) ;  r' likewise
-//   backsub (per odd i):  x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1})
-// The top level (one block) is a plain Cholesky solve.  G, YL, yr overwrite D_i, L_i, r_i.
-constexpr int LDA = BD + 1;    // LDS row stride of the factor (bank spread)
-constexpr int NRHS = 2 * BD + 1;
-constexpr int LDR = NRHS + 1;  // 146
-
-__global__ __launch_bounds__(256) void k_bcr_factor(Dev d, int lev, int top) {
-    State &st = *d.st;
-    if (st.terminated) return;
-    extern __shared__ double lds[];
-    double *A = lds;                // BD x LDA
-    double *R = lds + BD * LDA;     // BD x LDR : [ L_i | L_{i+1}^T | r_i ]
-    const BcrLevel &L = d.lev[lev];
-    const int i = top ? 0 : 2 * blockIdx.x + 1;
-    const bool hasL = !top, hasU = !top && (i + 1 < L.n);
-    double *Dg = L.D + (size_t)i * BD * BD;
-    double *Lg = L.L + (size_t)i * BD * BD;
-    const double *Ug = hasU ? L.L + (size_t)(i + 1) * BD * BD : nullptr;
-    double *rg = L.r + (size_t)i * BD;
-    const int t = threadIdx.x;
-    for (int e = t; e < BD * BD; e += 256) {
-        const int r = e / BD, c = e - r * BD;
-        A[r * LDA + c] = Dg[e];
-        R[r * LDR + c] = hasL ? Lg[e] : 0.0;
-        R[r * LDR + BD + c] = hasU ? Ug[(size_t)c * BD + r] : 0.0;   // transpose of L_{i+1}
-    }
-    if (t < BD) R[t * LDR + 2 * BD] = rg[t];
-    __syncthreads();
-    bool bad = false;
-    for (int k = 0; k < BD; ++k) {
-        const double akk = A[k * LDA + k];
-        if (!(akk > 0.0) || !isfinite(akk)) { bad = true; break; }   // uniform: all threads read the same value
-        const double dk = sqrt(akk), inv = 1.0 / dk;
-        __syncthreads();
-        // scale column k of A (rows > k) and row k of R
-        for (int e = t; e < (BD - 1 - k) + NRHS; e += 256) {
-            if (e < BD - 1 - k) A[(k + 1 + e) * LDA + k] *= inv;
-            else R[k * LDR + (e - (BD - 1 - k))] *= inv;
-        }
-        if (t == 0) A[k * LDA + k] = dk;
-        __syncthreads();
-        // trailing update: A[i][j] -= A[i][k] A[j][k] (k < j <= i) ; R[i][:] -= A[i][k] R[k][:]
-        const int m = BD - 1 - k;            // remaining rows
-        const int wA = m;                    // use full m x m square for simple indexing (lower part only)
-        const int total = m * (wA + NRHS);
-        for (int e = t; e < total; e += 256) {
-            const int ri = e / (wA + NRHS), cj = e - ri * (wA + NRHS);
-            const int row = k + 1 + ri;
-            const double aik = A[row * LDA + k];
-            if (cj < wA) {
-                const int col = k + 1 + cj;
-                if (col <= row) A[row * LDA + col] -= aik * A[col * LDA + k];
-            } else {
-                const int c = cj - wA;
-                R[row * LDR + c] -= aik * R[k * LDR + c];
-            }
-        }
-        __syncthreads();
-    }
-    if (bad) {
-        if (t == 0) st.step_failed = 1;
-        return;
-    }
-    // write back: G (lower) -> D_i, YL -> L_i, YU -> YU slot, yr -> r_i
-    double *YUg = top ? nullptr : L.YU + (size_t)blockIdx.x * BD * BD;
-    for (int e = t; e < BD * BD; e += 256) {
-        const int r = e / BD, c = e - r * BD;
-        Dg[e] = (c <= r) ? A[r * LDA + c] : 0.0;
-        if (hasL) Lg[e] = R[r * LDR + c];
-        if (YUg) YUg[e] = hasU ? R[r * LDR + BD + c] : 0.0;
-    }
-    if (t < BD) rg[t] = R[t * LDR + 2 * BD];
-}
-
-// C = [C0] - A1^T B1 - A2^T B2 for BD x BD operands in global memory (L2 resident),
-// 6x6 register tiles, 144 active lanes of 192.
-__device__ void gemm_tn_sub(double *acc, const double *__restrict__ A, const double *__restrict__ B,
-                            int tr, int tc, double *sA, double *sB) {
-    // stage A and B (BD x BD each) into LDS
-    for (int e = threadIdx.x; e < BD * BD; e += blockDim.x) { sA[e] = A[e]; sB[e] = B[e]; }
-    __syncthreads();
-    if (tr >= 0) {
-        for (int k = 0; k < BD; ++k) {
-            double a[6], b[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) { a[i] = sA[k * BD + tr * 6 + i]; b[i] = sB[k * BD + tc * 6 + i]; }
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[6 * i + j] -= a[i] * b[j];
-        }
-    }
-    __syncthreads();
-}
-
-// grid = (n_next, 2): y = 0 -> D' and r' ; y = 1 -> L'
-__global__ __launch_bounds__(192) void k_bcr_reduce(Dev d, int lev) {
-    const State &st = *d.st;
-    if (st.terminated || st.step_failed) return;
-    extern __shared__ double lds[];
-    double *sA = lds, *sB = lds + BD * BD;
-    const BcrLevel &L = d.lev[lev];
-    const BcrLevel &N = d.lev[lev + 1];
-    const int m = blockIdx.x, e = 2 * m;
-    const int t = threadIdx.x;
-    const int tr = t < 144 ? t / 12 : -1, tc = t < 144 ? t % 12 : 0;
-    const bool hasPrev = e - 1 >= 0, hasNext = e + 1 < L.n;
-    const int tp = (e - 2) / 2, tn = e / 2;     // YU slot of odd block e-1 / e+1
-    double acc[36];
-    if (blockIdx.y == 0) {
-        const double *De = L.D + (size_t)e * BD * BD;
-        if (tr >= 0) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) acc[6 * i + j] = De[(size_t)(tr * 6 + i) * BD + tc * 6 + j];
-        }
-        if (hasPrev) {
-            const double *YU = L.YU + (size_t)tp * BD * BD;
-            gemm_tn_sub(acc, YU, YU, tr, tc, sA, sB);
-        }
-        if (hasNext) {
-            const double *YL = L.L + (size_t)(e + 1) * BD * BD;
-            gemm_tn_sub(acc, YL, YL, tr, tc, sA, sB);
-        }
-        if (tr >= 0) {
-            double *Dn = N.D + (size_t)m * BD * BD;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) Dn[(size_t)(tr * 6 + i) * BD + tc * 6 + j] = acc[6 * i + j];
-        }
-        // r' = r_e - YU(e-1)^T yr(e-1) - YL(e+1)^T yr(e+1)
-        if (t < BD) {
-            double v = L.r[(size_t)e * BD + t];
-            if (hasPrev) {
-                const double *YU = L.YU + (size_t)tp * BD * BD, *yr = L.r + (size_t)(e - 1) * BD;
-                for (int k = 0; k < BD; ++k) v -= YU[(size_t)k * BD + t] * yr[k];
-            }
-            if (hasNext) {
-                const double *YL = L.L + (size_t)(e + 1) * BD * BD, *yr = L.r + (size_t)(e + 1) * BD;
-                for (int k = 0; k < BD; ++k) v -= YL[(size_t)k * BD + t] * yr[k];
-            }
-            N.r[(size_t)m * BD + t] = v;
-        }
-    } else {
-        if (m == 0) return;   // L'[0] unused
-        // L' = -YU(e-1)^T YL(e-1): rows = block e, cols = block e-2
-#pragma unroll
-        for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-        const double *YU = L.YU + (size_t)tp * BD * BD, *YL = L.L + (size_t)(e - 1) * BD * BD;
-        gemm_tn_sub(acc, YU, YL, tr, tc, sA, sB);
-        if (tr >= 0) {
-            double *Ln = N.L + (size_t)m * BD * BD;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) Ln[(size_t)(tr * 6 + i) * BD + tc * 6 + j] = acc[6 * i + j];
-        }
-    }
-}
-
-// x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1}); x lives in d.x0 at level-0 block positions.
-__global__ __launch_bounds__(128) void k_bcr_backsub(Dev d, int lev, int top) {
-    const State &st = *d.st;
-    if (st.terminated || st.step_failed) return;
-    __shared__ double v[BD];
-    const BcrLevel &L = d.lev[lev];
-    const int i = top ? 0 : 2 * blockIdx.x + 1;
-    const int t = threadIdx.x;
-    const double *G = L.D + (size_t)i * BD * BD;
-    double *xi = d.x0 + ((size_t)i << lev) * BD;
-    if (t < BD) {
-        double a = L.r[(size_t)i * BD + t];
-        if (!top) {
-            const double *YL = L.L + (size_t)i * BD * BD;
-            const double *xm = d.x0 + ((size_t)(i - 1) << lev) * BD;
-            for (int k = 0; k < BD; ++k) a -= YL[(size_t)t * BD + k] * xm[k];
-            if (i + 1 < L.n) {
-                const double *YU = L.YU + (size_t)blockIdx.x * BD * BD;
-                const double *xp = d.x0 + ((size_t)(i + 1) << lev) * BD;
-                for (int k = 0; k < BD; ++k) a -= YU[(size_t)t * BD + k] * xp[k];
-            }
-        }
-        v[t] = a;
-    }
-    __syncthreads();
-    // solve G^T x = v (upper triangular, column sweep from the bottom)
-    for (int k = BD - 1; k >= 0; --k) {
-        if (t == 0) v[k] = v[k] / G[(size_t)k * BD + k];
-        __syncthreads();
-        if (t < k) v[t] -= G[(size_t)k * BD + t] * v[k];
-        __syncthreads();
-    }
-    if (t < BD) xi[t] = v[t];
-}
-
 // candidate poses = Plus(x, delta_p)  [Evaluator::Plus with SE3Perturbation]
 __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
     const State &st = *d.st;
@@ -1134,16 +932,6 @@ __global__ void k_reset_state(Dev d, Options opt) {
 }
 
 // ----------------------------------------------------------------- launchers ---
-#define LAUNCH(cls, kern, grid, block, shmem, ...)                               \
-    do {                                                                         \
-        const dim3 _g = (grid);                                                  \
-        if (_g.x > 0 && _g.y > 0) {                                              \
-            L.begin(cls);                                                        \
-            hipLaunchKernelGGL(kern, _g, block, shmem, L.stream, __VA_ARGS__);   \
-            L.end(cls);                                                          \
-        }                                                                        \
-    } while (0)
-
 void launch_reset(Launcher &L, const Dev &d, const Options &o) {
     hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(64), 0, L.stream, d, o);
 }
@@ -1169,21 +957,6 @@ void launch_finish_check(Launcher &L, const Dev &d) {
     hipLaunchKernelGGL(k_best_done, dim3(1), dim3(64), 0, L.stream, d);
 }
 
-void launch_bcr(Launcher &L, const Dev &d) {
-    const size_t sh_factor = (size_t)(BD * LDA + BD * LDR) * sizeof(double);
-    const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
-    const int nl = d.n_levels;
-    for (int l = 0; l + 1 < nl; ++l) {
-        const int n = d.lev[l].n;
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(256), sh_factor, d, l, 0);
-        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(192), sh_reduce, d, l);
-    }
-    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(256), sh_factor, d, nl - 1, 1);
-    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(128), 0, d, nl - 1, 1);
-    for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(128), 0, d, l, 0);
-}
-
 void launch_update_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
@@ -1194,14 +967,6 @@ void launch_decide_commit(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
-}
-
-int configure_kernels() {
-    const int sh_factor = (int)((BD * LDA + BD * LDR) * sizeof(double));
-    const int sh_reduce = (int)(2 * BD * BD * sizeof(double));
-    if (hipFuncSetAttribute((const void *)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, sh_factor) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void *)k_bcr_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, sh_reduce) != hipSuccess) return -1;
-    return 0;
 }
 
 }  // namespace ssba

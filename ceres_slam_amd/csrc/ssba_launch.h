@@ -75,7 +75,18 @@ struct Launcher {
     }
 };
 
+#define LAUNCH(cls, kern, grid, block, shmem, ...)                               \
+    do {                                                                         \
+        const dim3 _g = (grid);                                                  \
+        if (_g.x > 0 && _g.y > 0) {                                              \
+            L.begin(cls);                                                        \
+            hipLaunchKernelGGL(kern, _g, block, shmem, L.stream, __VA_ARGS__);   \
+            L.end(cls);                                                          \
+        }                                                                        \
+    } while (0)
+
 int upload_pair_table(hipStream_t s);
+int upload_bcr_tables(hipStream_t s);
 int configure_kernels();
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 void launch_linearize(Launcher &L, const Dev &d);
