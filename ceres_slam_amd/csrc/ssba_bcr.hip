@@ -53,27 +53,43 @@ int upload_bcr_tables(hipStream_t s) {
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
 
-// 1/sqrt(a) to fp64 accuracy: hardware estimate + two Newton steps (no IEEE sqrt/div chain)
+// 1/sqrt(a) and 1/a to fp64 accuracy: hardware estimate + Newton steps.  IEEE sqrt / divide
+// cost ~150 / ~110 dependent cycles on gfx950 (tools/fp64_calib.hip), the estimates ~20.
 __device__ __forceinline__ double rsqrt_nr(double a) {
     double r = __builtin_amdgcn_rsq(a);
     r = r * (1.5 - 0.5 * a * r * r);
     r = r * (1.5 - 0.5 * a * r * r);
     return r;
 }
+__device__ __forceinline__ double rcp_nr(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
 
+constexpr int LDA = BD + 2;            // 74: LDS row stride of D / G (16-byte aligned rows)
+constexpr int RCOLS = NCB * NB;        // 150 right-hand-side columns incl. padding
+constexpr int LDR = RCOLS + 2;         // 152
+constexpr int FACT_LDS_DOUBLES = BD * LDA + BD * LDR;
+
+// One workgroup per odd block.  Everything is staged into LDS with one coalesced sweep,
+// each lane then owns one 6x6 tile of [D | L | U^T | r] in registers for the whole
+// factorisation; finished tiles go back to LDS (they are the operands of later updates and
+// the kernel's output), and one coalesced sweep writes G, YL, YU, yr.
 __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int top) {
     State &st = *d.st;
     if (st.terminated || st.step_failed) return;
-    __shared__ double sM[24];               // L^-1 of the current diagonal tile (21 used)
-    __shared__ double sPA[NBLK * 36];       // current block column of G, one tile per block row
-    __shared__ double sPY[NCB * 36];        // current block row of Y, tiles stored transposed
+    extern __shared__ double lds[];
+    double *A = lds;                 // BD x LDA
+    double *R = lds + BD * LDA;      // BD x LDR : [ L_i (72) | L_{i+1}^T (72) | r_i | pad ]
     __shared__ int sBad;
     const BcrLevel &L = d.lev[lev];
     const int blk = top ? 0 : 2 * blockIdx.x + 1;
     const bool hasL = !top, hasU = !top && (blk + 1 < L.n);
     double *Dg = L.D + (size_t)blk * BD * BD;
     double *Lg = L.L + (size_t)blk * BD * BD;
-    const double *Ug = hasU ? L.L + (size_t)(blk + 1) * BD * BD : nullptr;
+    const double *Ug = L.L + (size_t)(hasU ? blk + 1 : blk) * BD * BD;
     double *YUg = top ? nullptr : L.YU + (size_t)blockIdx.x * BD * BD;
     double *rg = L.r + (size_t)blk * BD;
     const int t = threadIdx.x;
@@ -82,132 +98,131 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     const int rb = has_tile ? c_tile_rb[t] : 0, cb = has_tile ? c_tile_cb[t] : 0;
     if (t == 0) sBad = 0;
 
+    // ---- bulk load (all global reads issued back to back) --------------------------
+    {
+        const double2 *D2 = reinterpret_cast<const double2 *>(Dg);
+        const double2 *L2 = reinterpret_cast<const double2 *>(Lg);
+        const double2 *U2 = reinterpret_cast<const double2 *>(Ug);
+        for (int e = t; e < BD * BD / 2; e += FACT_THREADS) {
+            const int r = (2 * e) / BD, c = 2 * e - r * BD;
+            const double2 dv = D2[e];
+            double2 lv = make_double2(0.0, 0.0), uv = make_double2(0.0, 0.0);
+            if (hasL) lv = L2[e];
+            if (hasU) uv = U2[e];
+            A[r * LDA + c] = dv.x; A[r * LDA + c + 1] = dv.y;
+            R[r * LDR + c] = lv.x; R[r * LDR + c + 1] = lv.y;
+            // L_{i+1}^T: element (row r of U, col c) goes to R[c][72 + r]
+            R[c * LDR + BD + r] = uv.x; R[(c + 1) * LDR + BD + r] = uv.y;
+        }
+        if (t < BD) {
+            R[t * LDR + 2 * BD] = rg[t];
+#pragma unroll
+            for (int c = 2 * BD + 1; c < LDR; ++c) R[t * LDR + c] = 0.0;
+        }
+    }
+    __syncthreads();
+
     double acc[36];
     if (type == 0) {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] = Dg[(size_t)(rb * 6 + i) * BD + cb * 6 + j];
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] = A[(rb * 6 + i) * LDA + cb * 6 + j];
     } else if (type == 1) {
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int c = cb * 6 + j, r = rb * 6 + i;
-                double v = 0.0;
-                if (c < BD) v = hasL ? Lg[(size_t)r * BD + c] : 0.0;
-                else if (c < 2 * BD) v = hasU ? Ug[(size_t)(c - BD) * BD + r] : 0.0;   // L_{i+1}^T
-                else if (c == 2 * BD) v = rg[r];
-                acc[6 * i + j] = v;
-            }
+            for (int j = 0; j < 6; ++j) acc[6 * i + j] = R[(rb * 6 + i) * LDR + cb * 6 + j];
     }
-    __syncthreads();
 
     for (int kb = 0; kb < NBLK; ++kb) {
-        // (1) owner of the diagonal tile: 6x6 Cholesky and its inverse
+        // (1) owner of the diagonal tile: 6x6 Cholesky.  The pivot chain runs on reciprocals
+        //     (a_ic -= a_ij a_cj / s_j); the square roots only scale the outputs.
         if (type == 0 && rb == kb && cb == kb) {
-            double l[6][6], m[6][6];
+            double a[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) a[i][j] = acc[6 * i + j];
             bool bad = false;
+            double rs[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                double s = acc[6 * j + j];
-#pragma unroll
-                for (int q = 0; q < j; ++q) s -= l[j][q] * l[j][q];
+                double s = a[j][j];
                 if (!(s > 0.0) || !isfinite(s)) { bad = true; s = 1.0; }
-                const double r = rsqrt_nr(s);
-                l[j][j] = s * r;
-                m[j][j] = r;
+                const double rc = rcp_nr(s);
+                rs[j] = rsqrt_nr(s);
 #pragma unroll
-                for (int i = j + 1; i < 6; ++i) {
-                    double v = acc[6 * i + j];
+                for (int c = j + 1; c < 6; ++c) {
+                    const double w = a[c][j] * rc;
 #pragma unroll
-                    for (int q = 0; q < j; ++q) v -= l[i][q] * l[j][q];
-                    l[i][j] = v * r;
+                    for (int i = c; i < 6; ++i) a[i][c] -= a[i][j] * w;
                 }
             }
-            // M = L^-1 (lower)
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int i = j + 1; i < 6; ++i) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int q = j; q < i; ++q) v -= l[i][q] * m[q][j];
-                    m[i][j] = v * m[i][i];
-                }
-            int n = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j) sM[n++] = m[i][j];
             if (bad) sBad = 1;
-            // G tile: L below the diagonal, 1/L_kk ON the diagonal (back-substitution multiplies)
+            // G tile: L below the diagonal, 1/L_jj ON the diagonal (consumers multiply)
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    Dg[(size_t)(kb * 6 + i) * BD + kb * 6 + j] = (j < i) ? l[i][j] : (j == i ? m[i][i] : 0.0);
+                for (int j = 0; j <= i; ++j)
+                    A[(kb * 6 + i) * LDA + kb * 6 + j] = (j < i) ? a[i][j] * rs[j] : rs[j];
         }
         __syncthreads();
         if (sBad) {
             if (t == 0) st.step_failed = 1;
             return;
         }
-        // (2) block column kb of G and block row kb of Y become final
-        if (type == 0 && cb == kb && rb > kb) {
-            double M[21];
-#pragma unroll
-            for (int i = 0; i < 21; ++i) M[i] = sM[i];
-            double x[36];
+        // (2) block column kb of G and block row kb of Y become final (forward substitution
+        //     against the diagonal tile; 6 independent rows / columns per lane)
+        if ((type == 0 && cb == kb && rb > kb) || (type == 1 && rb == kb)) {
+            double l[6][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {   // X' = X M^T : x'[i][c] = sum_{q<=c} x[i][q] M[c][q]
-                    double v = 0.0;
+                for (int j = 0; j <= i; ++j) l[i][j] = A[(kb * 6 + i) * LDA + kb * 6 + j];
+            if (type == 0) {
 #pragma unroll
-                    for (int q = 0; q <= c; ++q) v += acc[6 * i + q] * M[c * (c + 1) / 2 + q];
-                    x[6 * i + c] = v;
+                for (int i = 0; i < 6; ++i) {   // x' L^T = x
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v = acc[6 * i + c];
+#pragma unroll
+                        for (int q = 0; q < c; ++q) v -= acc[6 * i + q] * l[c][q];
+                        acc[6 * i + c] = v * l[c][c];
+                    }
                 }
 #pragma unroll
-            for (int i = 0; i < 36; ++i) { acc[i] = x[i]; sPA[rb * 36 + i] = x[i]; }
+                for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+                    for (int c = 0; c < 6; ++c) A[(rb * 6 + i) * LDA + kb * 6 + c] = acc[6 * i + c];
+            } else {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) Dg[(size_t)(rb * 6 + i) * BD + kb * 6 + c] = x[6 * i + c];
-        } else if (type == 1 && rb == kb) {
-            double M[21];
+                for (int j = 0; j < 6; ++j) {   // L y' = y
 #pragma unroll
-            for (int i = 0; i < 21; ++i) M[i] = sM[i];
-            double y[36];
+                    for (int r = 0; r < 6; ++r) {
+                        double v = acc[6 * r + j];
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {   // Y' = M Y : y'[r][j] = sum_{q<=r} M[r][q] y[q][j]
-                    double v = 0.0;
-#pragma unroll
-                    for (int q = 0; q <= r; ++q) v += M[r * (r + 1) / 2 + q] * acc[6 * q + j];
-                    y[6 * r + j] = v;
+                        for (int q = 0; q < r; ++q) v -= l[r][q] * acc[6 * q + j];
+                        acc[6 * r + j] = v * l[r][r];
+                    }
                 }
 #pragma unroll
-            for (int r = 0; r < 6; ++r)
+                for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    sPY[cb * 36 + j * 6 + r] = y[6 * r + j];      // transposed for the update below
-                    const int c = cb * 6 + j, row = kb * 6 + r;
-                    if (c < BD) { if (hasL) Lg[(size_t)row * BD + c] = y[6 * r + j]; }
-                    else if (c < 2 * BD) { if (YUg) YUg[(size_t)row * BD + (c - BD)] = y[6 * r + j]; }
-                    else if (c == 2 * BD) rg[row] = y[6 * r + j];
-                }
+                    for (int j = 0; j < 6; ++j) R[(kb * 6 + r) * LDR + cb * 6 + j] = acc[6 * r + j];
+            }
         }
         __syncthreads();
-        // (3) trailing update: acc -= G[rb][kb] * B^T with B = G[cb][kb] (D tiles) or Y[kb][cb]^T
-        const bool upd = (type == 0 && cb > kb) || (type == 1 && rb > kb);
-        if (upd) {
-            const double *a = sPA + rb * 36;
-            const double *b = (type == 0) ? sPA + cb * 36 : sPY + cb * 36;
+        // (3) trailing update: acc -= G[rb][kb] * B with B = G[cb][kb]^T (D tiles) or Y[kb][cb]
+        if (type == 0 && cb > kb) {
             double av[36], bv[36];
 #pragma unroll
-            for (int i = 0; i < 36; ++i) { av[i] = a[i]; bv[i] = b[i]; }
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    av[6 * i + q] = A[(rb * 6 + i) * LDA + kb * 6 + q];
+                    bv[6 * i + q] = A[(cb * 6 + i) * LDA + kb * 6 + q];
+                }
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -217,9 +232,40 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
                     for (int q = 0; q < 6; ++q) v -= av[6 * i + q] * bv[6 * j + q];
                     acc[6 * i + j] = v;
                 }
+        } else if (type == 1 && rb > kb) {
+            double av[36], yv[36];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    av[6 * i + q] = A[(rb * 6 + i) * LDA + kb * 6 + q];
+                    yv[6 * i + q] = R[(kb * 6 + i) * LDR + cb * 6 + q];
+                }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    double v = acc[6 * i + j];
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) v -= av[6 * i + q] * yv[6 * q + j];
+                    acc[6 * i + j] = v;
+                }
         }
-        // no barrier here: the next step's first barrier orders these LDS reads before the
-        // next panel writes; sM is only rewritten after every reader passed barrier (2)
+        // the next step's first barrier orders these LDS reads before the next panel writes
+    }
+    __syncthreads();
+    // ---- bulk store ----------------------------------------------------------------
+    {
+        double2 *D2 = reinterpret_cast<double2 *>(Dg);
+        double2 *L2 = reinterpret_cast<double2 *>(Lg);
+        double2 *U2 = reinterpret_cast<double2 *>(YUg);
+        for (int e = t; e < BD * BD / 2; e += FACT_THREADS) {
+            const int r = (2 * e) / BD, c = 2 * e - r * BD;
+            D2[e] = make_double2(A[r * LDA + c], A[r * LDA + c + 1]);
+            if (hasL) L2[e] = make_double2(R[r * LDR + c], R[r * LDR + c + 1]);
+            if (YUg) U2[e] = make_double2(R[r * LDR + BD + c], R[r * LDR + BD + c + 1]);
+        }
+        if (t < BD) rg[t] = R[t * LDR + 2 * BD];
     }
 }
 
@@ -229,10 +275,10 @@ constexpr int RED_THREADS = 448;
 constexpr int KSPLIT = 3;
 constexpr int KCH = BD / KSPLIT;   // 24
 
-__device__ __forceinline__ void stage_block(double *dst, const double *__restrict__ src) {
+__device__ __forceinline__ void stage_block(double *dst, const double *__restrict__ src, int nthreads) {
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
     double2 *d2 = reinterpret_cast<double2 *>(dst);
-    for (int e = threadIdx.x; e < BD * BD / 2; e += RED_THREADS) d2[e] = s2[e];
+    for (int e = threadIdx.x; e < BD * BD / 2; e += nthreads) d2[e] = s2[e];
 }
 
 __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const double *sB, int g, int tr, int tc) {
@@ -247,12 +293,14 @@ __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const do
     }
 }
 
-// grid = (n_next, 2): y = 0 -> D' and r' ; y = 1 -> L'
+// grid = (n_next, 2): y = 0 -> D' and r' ; y = 1 -> L'.  Both operand blocks are staged
+// into LDS up front (one global round trip), r' is computed from the staged copies.
 __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed) return;
     extern __shared__ double lds[];
     double *sA = lds, *sB = lds + BD * BD;
+    __shared__ double sya[BD], syb[BD];
     const BcrLevel &L = d.lev[lev];
     const BcrLevel &N = d.lev[lev + 1];
     const int m = blockIdx.x, e = 2 * m;
@@ -260,49 +308,47 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
     const bool act = t < KSPLIT * 144;
     const int g = t / 144, tt = t - g * 144;
     const int tr = tt / 12, tc = tt - tr * 12;
-    const bool hasPrev = e >= 2 || e - 1 >= 0, hasNext = e + 1 < L.n;
+    const bool hasPrev = e - 1 >= 0, hasNext = e + 1 < L.n;
     const int tp = (e - 2) / 2;     // YU slot of odd block e-1
     double acc[36];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
     double *out;
+    const double *base = nullptr;
+    double rbase = 0.0;
     if (blockIdx.y == 0) {
         out = N.D + (size_t)m * BD * BD;
-        if (e - 1 >= 0) {
-            stage_block(sA, L.YU + (size_t)tp * BD * BD);
-            __syncthreads();
-            if (act) tile_mac(acc, sA, sA, g, tr, tc);
-            __syncthreads();
-        }
-        if (hasNext) {
-            stage_block(sA, L.L + (size_t)(e + 1) * BD * BD);
-            __syncthreads();
-            if (act) tile_mac(acc, sA, sA, g, tr, tc);
-            __syncthreads();
-        }
-        // r' (72 lanes, operands straight from L2)
+        base = L.D + (size_t)e * BD * BD;
+        if (hasPrev) stage_block(sA, L.YU + (size_t)tp * BD * BD, RED_THREADS);
+        if (hasNext) stage_block(sB, L.L + (size_t)(e + 1) * BD * BD, RED_THREADS);
         if (t < BD) {
-            double v = L.r[(size_t)e * BD + t];
-            if (e - 1 >= 0) {
-                const double *YU = L.YU + (size_t)tp * BD * BD, *yr = L.r + (size_t)(e - 1) * BD;
-                for (int k = 0; k < BD; ++k) v -= YU[(size_t)k * BD + t] * yr[k];
-            }
-            if (hasNext) {
-                const double *YL = L.L + (size_t)(e + 1) * BD * BD, *yr = L.r + (size_t)(e + 1) * BD;
-                for (int k = 0; k < BD; ++k) v -= YL[(size_t)k * BD + t] * yr[k];
-            }
-            N.r[(size_t)m * BD + t] = v;
+            sya[t] = hasPrev ? L.r[(size_t)(e - 1) * BD + t] : 0.0;
+            syb[t] = hasNext ? L.r[(size_t)(e + 1) * BD + t] : 0.0;
+            rbase = L.r[(size_t)e * BD + t];
         }
+        __syncthreads();
+        if (act) {
+            if (hasPrev) tile_mac(acc, sA, sA, g, tr, tc);
+            if (hasNext) tile_mac(acc, sB, sB, g, tr, tc);
+        } else if (t - KSPLIT * 144 < 0) {
+        }
+        // r' = r_e - YU(e-1)^T yr(e-1) - YL(e+1)^T yr(e+1) on the spare lanes' time: lanes 0..71
+        if (t < BD) {
+            double v0 = 0.0, v1 = 0.0;
+            if (hasPrev) for (int k = 0; k < BD; ++k) v0 += sA[k * BD + t] * sya[k];
+            if (hasNext) for (int k = 0; k < BD; ++k) v1 += sB[k * BD + t] * syb[k];
+            N.r[(size_t)m * BD + t] = rbase - v0 - v1;
+        }
+        __syncthreads();
     } else {
         if (m == 0) return;   // L'[0] does not exist
         out = N.L + (size_t)m * BD * BD;
-        stage_block(sA, L.YU + (size_t)tp * BD * BD);
-        stage_block(sB, L.L + (size_t)(e - 1) * BD * BD);
+        stage_block(sA, L.YU + (size_t)tp * BD * BD, RED_THREADS);
+        stage_block(sB, L.L + (size_t)(e - 1) * BD * BD, RED_THREADS);
         __syncthreads();
         if (act) tile_mac(acc, sA, sB, g, tr, tc);
         __syncthreads();
     }
-    (void)hasPrev;
     // combine the k-split partials in LDS (fixed order), then out = base - sum
     double *part = lds;   // 2 x 144 x 36 doubles = 82,944 B: fits the operand area exactly
     if (act && g > 0) {
@@ -311,7 +357,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
     }
     __syncthreads();
     if (act && g == 0) {
-        const double *base = (blockIdx.y == 0) ? L.D + (size_t)e * BD * BD : nullptr;
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -330,44 +375,42 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 }
 
 // x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1}); x lives in d.x0 at level-0 block positions.
-__global__ __launch_bounds__(256) void k_bcr_backsub(Dev d, int lev, int top) {
+// G, YL, YU are staged into LDS with one coalesced sweep.
+constexpr int BS_THREADS = 512;
+__global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int top) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed) return;
-    __shared__ double sG[BD * BD];
-    __shared__ double sv[BD];
-    __shared__ double sxm[BD], sxp[BD];
+    extern __shared__ double lds[];
+    double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
+    __shared__ double sv[BD], sxm[BD], sxp[BD];
     const BcrLevel &L = d.lev[lev];
     const int blk = top ? 0 : 2 * blockIdx.x + 1;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const double *G = L.D + (size_t)blk * BD * BD;
-    double *xi = d.x0 + ((size_t)blk << lev) * BD;
     const bool hasU = !top && (blk + 1 < L.n);
-    {
-        const double2 *s2 = reinterpret_cast<const double2 *>(G);
-        double2 *d2 = reinterpret_cast<double2 *>(sG);
-        for (int e = t; e < BD * BD / 2; e += 256) d2[e] = s2[e];
-    }
+    double *xi = d.x0 + ((size_t)blk << lev) * BD;
+    stage_block(sG, L.D + (size_t)blk * BD * BD, BS_THREADS);
+    if (!top) stage_block(sL, L.L + (size_t)blk * BD * BD, BS_THREADS);
+    if (hasU) stage_block(sU, L.YU + (size_t)blockIdx.x * BD * BD, BS_THREADS);
     if (t < BD) {
         sxm[t] = top ? 0.0 : d.x0[((size_t)(blk - 1) << lev) * BD + t];
         sxp[t] = hasU ? d.x0[((size_t)(blk + 1) << lev) * BD + t] : 0.0;
+        sv[t] = L.r[(size_t)blk * BD + t];
     }
     __syncthreads();
-    // v = yr - YL x_{i-1} - YU x_{i+1}: each wave owns 18 rows, lanes stride the row
-    const double *YL = L.L + (size_t)blk * BD * BD;
-    const double *YU = top ? nullptr : L.YU + (size_t)blockIdx.x * BD * BD;
-    for (int r = w * 18; r < w * 18 + 18; ++r) {
+    // v = yr - YL x_{i-1} - YU x_{i+1}: 8 waves x 9 rows, lanes stride the row
+    for (int r = w * 9; r < w * 9 + 9; ++r) {
         double p = 0.0;
         if (!top) {
-            p += YL[(size_t)r * BD + lane] * sxm[lane];
-            if (lane < BD - 64) p += YL[(size_t)r * BD + 64 + lane] * sxm[64 + lane];
+            p += sL[r * BD + lane] * sxm[lane];
+            if (lane < BD - 64) p += sL[r * BD + 64 + lane] * sxm[64 + lane];
             if (hasU) {
-                p += YU[(size_t)r * BD + lane] * sxp[lane];
-                if (lane < BD - 64) p += YU[(size_t)r * BD + 64 + lane] * sxp[64 + lane];
+                p += sU[r * BD + lane] * sxp[lane];
+                if (lane < BD - 64) p += sU[r * BD + 64 + lane] * sxp[64 + lane];
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o, 64);
-        if (lane == 0) sv[r] = L.r[(size_t)blk * BD + r] - p;
+        if (lane == 0) sv[r] -= p;
     }
     __syncthreads();
     if (w != 0) return;
@@ -394,21 +437,25 @@ __global__ __launch_bounds__(256) void k_bcr_backsub(Dev d, int lev, int top) {
 
 void launch_bcr(Launcher &L, const Dev &d) {
     const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
+    const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
+    const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
     for (int l = 0; l + 1 < nl; ++l) {
         const int n = d.lev[l].n;
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), 0, d, l, 0);
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), sh_factor, d, l, 0);
         LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l);
     }
-    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), 0, d, nl - 1, 1);
-    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(256), 0, d, nl - 1, 1);
+    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), sh_factor, d, nl - 1, 1);
+    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, nl - 1, 1);
     for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(256), 0, d, l, 0);
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0);
 }
 
 int configure_kernels() {
     const int sh_reduce = (int)(2 * BD * BD * sizeof(double));
     if (hipFuncSetAttribute((const void *)k_bcr_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, sh_reduce) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FACT_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * BD * BD * sizeof(double))) != hipSuccess) return -1;
     return 0;
 }
 

@@ -1,0 +1,112 @@
+// Calibration microbenchmarks for fp64 on gfx950 (not part of the product path):
+// FMA throughput at 1/2/4 waves per SIMD, dependent-chain latency, rsq/rcp/sqrt/div latency,
+// LDS b128 read rate, trivial-kernel duration.   hipcc --offload-arch=gfx950 -O3 fp64_calib.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+__global__ void k_empty(double *o) { if (o == nullptr) o[0] = 1; }
+
+template <int NACC>
+__global__ void k_fma_tp(double *out, int iters, double a, double b) {
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = fma(acc[i], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// one wave: cycles per dependent op
+template <int OP>
+__global__ void k_chain(double *out, long long *cyc, int iters, double a, double b) {
+    double x = 1.0 + threadIdx.x * 1e-3;
+    long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+        if (OP == 0) x = fma(x, a, b);
+        if (OP == 1) x = __builtin_amdgcn_rsq(x) + b;
+        if (OP == 2) x = __builtin_amdgcn_rcp(x) + b;
+        if (OP == 3) x = sqrt(x) + b;
+        if (OP == 4) x = b / x + a;
+        if (OP == 5) x = __shfl(x, (threadIdx.x + 1) & 63, 64) + b;
+    }
+    long long t1 = clock64();
+    out[threadIdx.x] = x;
+    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+__global__ void k_lds_read(double *out, int iters) {
+    __shared__ double s[8192];
+    for (int i = threadIdx.x; i < 8192; i += blockDim.x) s[i] = i;
+    __syncthreads();
+    double acc0 = 0, acc1 = 0;
+    const double2 *s2 = reinterpret_cast<const double2 *>(s);
+    int idx = threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double2 v = s2[(idx + j * 256) & 4095];
+            acc0 += v.x; acc1 += v.y;
+        }
+        idx = (idx + 1) & 4095;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc0 + acc1;
+}
+
+template <class F> float time_ms(F f, int reps) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a); for (int i = 0; i < reps; ++i) f(); hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b); return ms / reps;
+}
+
+int main() {
+    double *out; long long *cyc;
+    CHK(hipMalloc(&out, 1 << 26)); CHK(hipMalloc(&cyc, 64));
+    hipDeviceProp_t p; CHK(hipGetDeviceProperties(&p, 0));
+    printf("device %s CUs %d clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+    printf("empty kernel (back-to-back, event avg): %.2f us\n", 1e3 * time_ms([&] { hipLaunchKernelGGL(k_empty, 1, 64, 0, 0, out); }, 200));
+    const int iters = 20000;
+    for (int wps : {1, 2, 4}) {
+        int threads = 256 * wps, blocks = 256;   // one block per CU, wps waves per SIMD
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_fma_tp<8>, blocks, threads, 0, 0, out, iters, 1.0000001, 1e-9); }, 3);
+        double fl = 2.0 * 8 * iters * (double)threads * blocks;
+        printf("fp64 FMA throughput, %d wave(s)/SIMD, 8 indep acc: %.1f TFLOP/s (%.3f ms)\n", wps, fl / ms / 1e9, ms);
+    }
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_fma_tp<8>, 1, 64, 0, 0, out, iters, 1.0000001, 1e-9); }, 3);
+        printf("one wave, 8 indep FMA chains: %.2f ns per wave-FMA\n", ms * 1e6 / (8.0 * iters));
+        ms = time_ms([&] { hipLaunchKernelGGL(k_fma_tp<1>, 1, 64, 0, 0, out, iters, 1.0000001, 1e-9); }, 3);
+        printf("one wave, 1 dependent FMA chain: %.2f ns per FMA\n", ms * 1e6 / (1.0 * iters));
+    }
+    const char *names[] = {"fma", "rsq+add", "rcp+add", "sqrt+add", "div+add", "shfl+add"};
+    long long h;
+    auto run_chain = [&](int op) {
+        switch (op) {
+            case 0: hipLaunchKernelGGL(k_chain<0>, 1, 64, 0, 0, out, cyc, 4000, 1.0000001, 1e-9); break;
+            case 1: hipLaunchKernelGGL(k_chain<1>, 1, 64, 0, 0, out, cyc, 4000, 1.0000001, 1.5); break;
+            case 2: hipLaunchKernelGGL(k_chain<2>, 1, 64, 0, 0, out, cyc, 4000, 1.0000001, 1.5); break;
+            case 3: hipLaunchKernelGGL(k_chain<3>, 1, 64, 0, 0, out, cyc, 4000, 1.0000001, 1.5); break;
+            case 4: hipLaunchKernelGGL(k_chain<4>, 1, 64, 0, 0, out, cyc, 4000, 1.0000001, 1.5); break;
+            case 5: hipLaunchKernelGGL(k_chain<5>, 1, 64, 0, 0, out, cyc, 4000, 1.0000001, 1.5); break;
+        }
+    };
+    for (int op = 0; op < 6; ++op) {
+        float ms = time_ms([&] { run_chain(op); }, 3);
+        hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+        printf("dependent %-9s: %.1f clock64 ticks/op, %.1f ns/op\n", names[op], (double)h / 4000, ms * 1e6 / 4000);
+    }
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_lds_read, 256, 256, 0, 0, out, 4000); }, 3);
+        double bytes = 256.0 * 256 * 4000 * 8 * 16;
+        printf("LDS ds_read_b128: %.1f TB/s chip (%.1f B/clk/CU at 2.4 GHz)\n", bytes / ms / 1e9, bytes / ms / 1e9 * 1e12 / 256 / 2.4e9);
+    }
+    return 0;
+}
