@@ -267,6 +267,14 @@ int ssba_exchange_size(ssba_problem *p, uint64_t *count) {
     return SSBA_OK;
 }
 
+// diagnostic: raw in-kernel stamp buffer (only filled by -DSSBA_STAMPS builds); not in ssba.h
+int ssba_debug_stamps(ssba_problem *p, unsigned long long *out, int n) {
+    if (!p || !p->finalized || n > 8192) return SSBA_ERR_INVALID_ARGUMENT;
+    HIPCHECK(hipStreamSynchronize(p->launcher.stream));
+    HIPCHECK(hipMemcpy(out, p->d.dbg, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return SSBA_OK;
+}
+
 int ssba_get_stats(ssba_problem *p, ssba_stats *st) {
     if (!p || !st) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
@@ -558,6 +566,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));
     TRY(dzero(p, &d.st, (size_t)1));
+    TRY(dzero(p, &d.dbg, (size_t)8192));
     HIPCHECK(hipHostMalloc((void **)&p->h_state, sizeof(State), hipHostMallocDefault));
     p->h_stage_count = std::max<size_t>((size_t)P * 12, (size_t)Lpad * 3);
     HIPCHECK(hipHostMalloc((void **)&p->h_stage, std::max<size_t>(p->h_stage_count, 1) * sizeof(double), hipHostMallocDefault));

@@ -68,6 +68,12 @@ __device__ __forceinline__ double rcp_nr(double a) {
     return r;
 }
 
+#ifdef SSBA_STAMPS
+#define STAMP(base, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) d.dbg[(base) + (i)] = clock64(); } while (0)
+#else
+#define STAMP(base, i) do { } while (0)
+#endif
+
 constexpr int LDA = BD + 2;            // 74: LDS row stride of D / G (16-byte aligned rows)
 constexpr int RCOLS = NCB * NB;        // 150 right-hand-side columns incl. padding
 constexpr int LDR = RCOLS + 2;         // 152
@@ -80,7 +86,7 @@ constexpr int FACT_LDS_DOUBLES = BD * LDA + BD * LDR;
 __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int top) {
     State &st = *d.st;
     if (st.terminated || st.step_failed) return;
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *A = lds;                 // BD x LDA
     double *R = lds + BD * LDA;      // BD x LDR : [ L_i (72) | L_{i+1}^T (72) | r_i | pad ]
     __shared__ int sBad;
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     const int type = has_tile ? c_tile_type[t] : 2;
     const int rb = has_tile ? c_tile_rb[t] : 0, cb = has_tile ? c_tile_cb[t] : 0;
     if (t == 0) sBad = 0;
+    STAMP(lev * 64, 0);
 
     // ---- bulk load (all global reads issued back to back) --------------------------
     {
@@ -121,24 +128,34 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
         }
     }
     __syncthreads();
+    STAMP(lev * 64, 1);
 
+    // Per-lane view of the tile so that D tiles and right-hand-side tiles run ONE code path
+    // (no divergence inside a wave): the register tile T[x][z] is the D tile itself
+    // (x = row, z = column) or the TRANSPOSE of the right-hand-side tile (x = column, z = row).
+    //   own tile:        T[x][z]  <->  own[x*osx + z*osz]
+    //   panel operand P: P[x][q]  (type 0: G[rb][kb] rows;      type 1: Y[kb][cb] columns)
+    //   panel operand Q: Q[z][q]  (type 0: G[cb][kb] rows;      type 1: G[rb][kb] rows)
+    //   update:          T[x][z] -= sum_q P[x][q] Q[z][q]
+    //   finalisation:    T[x][:] <- solve against the diagonal tile, identical recurrence
+    double *own;
+    int osx, osz;
+    if (type == 1) { own = R + (rb * 6) * LDR + cb * 6; osx = 1; osz = LDR; }
+    else { own = A + (rb * 6) * LDA + cb * 6; osx = LDA; osz = 1; }
+    const int fin = (type == 1) ? rb : cb;          // step at which this tile becomes final
+    const bool is_diag = (type == 0) && rb == cb;
     double acc[36];
-    if (type == 0) {
+    if (has_tile) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int x = 0; x < 6; ++x)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] = A[(rb * 6 + i) * LDA + cb * 6 + j];
-    } else if (type == 1) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[6 * i + j] = R[(rb * 6 + i) * LDR + cb * 6 + j];
+            for (int z = 0; z < 6; ++z) acc[6 * x + z] = own[x * osx + z * osz];
     }
 
     for (int kb = 0; kb < NBLK; ++kb) {
         // (1) owner of the diagonal tile: 6x6 Cholesky.  The pivot chain runs on reciprocals
         //     (a_ic -= a_ij a_cj / s_j); the square roots only scale the outputs.
-        if (type == 0 && rb == kb && cb == kb) {
+        if (is_diag && rb == kb) {
             double a[6][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -168,92 +185,66 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
                     A[(kb * 6 + i) * LDA + kb * 6 + j] = (j < i) ? a[i][j] * rs[j] : rs[j];
         }
         __syncthreads();
+        STAMP(lev * 64, 2 + 3 * kb);
         if (sBad) {
             if (t == 0) st.step_failed = 1;
             return;
         }
-        // (2) block column kb of G and block row kb of Y become final (forward substitution
-        //     against the diagonal tile; 6 independent rows / columns per lane)
-        if ((type == 0 && cb == kb && rb > kb) || (type == 1 && rb == kb)) {
+        // (2) block column kb of G and block row kb of Y become final: forward substitution of
+        //     each line T[x][:] against the diagonal tile (right-looking, 6 independent lines)
+        if (has_tile && fin == kb && !is_diag) {
             double l[6][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
                 for (int j = 0; j <= i; ++j) l[i][j] = A[(kb * 6 + i) * LDA + kb * 6 + j];
-            if (type == 0) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {   // x' L^T = x
+            for (int c = 0; c < 6; ++c) {
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        double v = acc[6 * i + c];
+                for (int x = 0; x < 6; ++x) {
+                    const double v = acc[6 * x + c] * l[c][c];
+                    acc[6 * x + c] = v;
 #pragma unroll
-                        for (int q = 0; q < c; ++q) v -= acc[6 * i + q] * l[c][q];
-                        acc[6 * i + c] = v * l[c][c];
-                    }
+                    for (int c2 = c + 1; c2 < 6; ++c2) acc[6 * x + c2] -= v * l[c2][c];
                 }
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) A[(rb * 6 + i) * LDA + kb * 6 + c] = acc[6 * i + c];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {   // L y' = y
-#pragma unroll
-                    for (int r = 0; r < 6; ++r) {
-                        double v = acc[6 * r + j];
-#pragma unroll
-                        for (int q = 0; q < r; ++q) v -= l[r][q] * acc[6 * q + j];
-                        acc[6 * r + j] = v * l[r][r];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) R[(kb * 6 + r) * LDR + cb * 6 + j] = acc[6 * r + j];
             }
+#pragma unroll
+            for (int x = 0; x < 6; ++x)
+#pragma unroll
+                for (int z = 0; z < 6; ++z) own[x * osx + z * osz] = acc[6 * x + z];
         }
         __syncthreads();
-        // (3) trailing update: acc -= G[rb][kb] * B with B = G[cb][kb]^T (D tiles) or Y[kb][cb]
-        if (type == 0 && cb > kb) {
-            double av[36], bv[36];
+        STAMP(lev * 64, 3 + 3 * kb);
+        // (3) trailing update of every tile that is not final yet
+        if (has_tile && fin > kb) {
+            const double *Pp, *Qp;
+            int psx, psq;
+            if (type == 1) { Pp = R + (kb * 6) * LDR + cb * 6; psx = 1; psq = LDR; }
+            else { Pp = A + (rb * 6) * LDA + kb * 6; psx = LDA; psq = 1; }
+            Qp = A + ((type == 1 ? rb : cb) * 6) * LDA + kb * 6;
+            double pv[36], qv[36];
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    av[6 * i + q] = A[(rb * 6 + i) * LDA + kb * 6 + q];
-                    bv[6 * i + q] = A[(cb * 6 + i) * LDA + kb * 6 + q];
-                }
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    double v = acc[6 * i + j];
-#pragma unroll
-                    for (int q = 0; q < 6; ++q) v -= av[6 * i + q] * bv[6 * j + q];
-                    acc[6 * i + j] = v;
-                }
-        } else if (type == 1 && rb > kb) {
-            double av[36], yv[36];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int x = 0; x < 6; ++x)
 #pragma unroll
                 for (int q = 0; q < 6; ++q) {
-                    av[6 * i + q] = A[(rb * 6 + i) * LDA + kb * 6 + q];
-                    yv[6 * i + q] = R[(kb * 6 + i) * LDR + cb * 6 + q];
+                    pv[6 * x + q] = Pp[x * psx + q * psq];
+                    qv[6 * x + q] = Qp[x * LDA + q];
                 }
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int x = 0; x < 6; ++x)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    double v = acc[6 * i + j];
+                for (int z = 0; z < 6; ++z) {
+                    double v = acc[6 * x + z];
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) v -= av[6 * i + q] * yv[6 * q + j];
-                    acc[6 * i + j] = v;
+                    for (int q = 0; q < 6; ++q) v -= pv[6 * x + q] * qv[6 * z + q];
+                    acc[6 * x + z] = v;
                 }
         }
         // the next step's first barrier orders these LDS reads before the next panel writes
+        STAMP(lev * 64, 4 + 3 * kb);
     }
     __syncthreads();
+    STAMP(lev * 64, 40);
     // ---- bulk store ----------------------------------------------------------------
     {
         double2 *D2 = reinterpret_cast<double2 *>(Dg);
@@ -267,6 +258,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
         }
         if (t < BD) rg[t] = R[t * LDR + 2 * BD];
     }
+    STAMP(lev * 64, 41);
 }
 
 // C -= A^T B for BD x BD operands: 3-way split over k (432 lanes = 3 x 144 tiles of 6x6),
@@ -284,8 +276,14 @@ __device__ __forceinline__ void stage_block(double *dst, const double *__restric
 __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const double *sB, int g, int tr, int tc) {
     for (int k = g * KCH; k < (g + 1) * KCH; ++k) {
         double a[6], b[6];
+        const double2 *pa = reinterpret_cast<const double2 *>(sA + k * BD + tr * 6);   // 16-byte aligned
+        const double2 *pb = reinterpret_cast<const double2 *>(sB + k * BD + tc * 6);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { a[i] = sA[k * BD + tr * 6 + i]; b[i] = sB[k * BD + tc * 6 + i]; }
+        for (int i = 0; i < 3; ++i) {
+            const double2 va = pa[i], vb = pb[i];
+            a[2 * i] = va.x; a[2 * i + 1] = va.y;
+            b[2 * i] = vb.x; b[2 * i + 1] = vb.y;
+        }
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -298,7 +296,7 @@ __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const do
 __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed) return;
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sB = lds + BD * BD;
     __shared__ double sya[BD], syb[BD];
     const BcrLevel &L = d.lev[lev];
@@ -380,7 +378,7 @@ constexpr int BS_THREADS = 512;
 __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int top) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed) return;
-    extern __shared__ double lds[];
+    extern __shared__ __align__(16) double lds[];
     double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
     __shared__ double sv[BD], sxm[BD], sxp[BD];
     const BcrLevel &L = d.lev[lev];

@@ -118,6 +118,7 @@ struct Dev {
     int n_pose_blocks;
     State *st;
     IterLog log;
+    unsigned long long *dbg;         // in-kernel stamps (diagnostic builds only, -DSSBA_STAMPS)
 };
 
 }  // namespace ssba
