@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,10 @@ struct ssba_problem {
     ssba_exchange_fn xfn = nullptr;
     void *xctx = nullptr;
     int world_size = 1, rank = 0;
+    // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    bool use_graph = true;
     // solve bookkeeping
     bool began = false;
     ssba_options opt{};
@@ -97,7 +102,13 @@ static int dzero(ssba_problem *p, T **out, size_t n) {
     return SSBA_OK;
 }
 
+static void drop_graph(ssba_problem *p) {
+    if (p->gexec) { hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+}
+
 static void free_device(ssba_problem *p) {
+    drop_graph(p);
     for (void *a : p->allocs) hipFree(a);
     p->allocs.clear();
     p->dev_bytes = 0;
@@ -164,6 +175,7 @@ int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
         return SSBA_ERR_HIP;
     }
     p->launcher.stream = p->own_stream;
+    if (const char *e = getenv("SSBA_NO_GRAPH")) p->use_graph = !(e[0] == '1');
     hipEventCreate(&p->ev_begin);
     hipEventCreate(&p->ev_end);
     *out = p;
@@ -234,7 +246,7 @@ int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant) {
 int ssba_set_huber_loss(ssba_problem *p, double a) {
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     p->huber_a = a > 0.0 ? a : 0.0;
-    if (p->finalized) p->d.huber_a = p->huber_a;
+    if (p->finalized) { p->d.huber_a = p->huber_a; drop_graph(p); }   // kernel arguments are baked into the graph
     return SSBA_OK;
 }
 
@@ -657,7 +669,28 @@ static int ensure_log(ssba_problem *p, int capacity) {
 }
 
 // one trust-region iteration, enqueue only
+static int enqueue_kernels(ssba_problem *p);
+
 static int enqueue_iteration(ssba_problem *p) {
+    // The kernel sequence of an iteration is fixed (all control flow is on the device), so on
+    // the plain single-GPU path it is captured once and replayed: ~45 launches become one.
+    if (p->use_graph && !p->xfn && !p->launcher.timing) {
+        hipStream_t s = p->launcher.stream;
+        if (!p->gexec) {
+            HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            int rc = enqueue_kernels(p);
+            hipError_t e = hipStreamEndCapture(s, &p->graph);
+            if (rc) return rc;
+            if (e != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+            HIPCHECK(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
+        }
+        HIPCHECK(hipGraphLaunch(p->gexec, s));
+        return SSBA_OK;
+    }
+    return enqueue_kernels(p);
+}
+
+static int enqueue_kernels(ssba_problem *p) {
     Dev &d = p->d;
     Launcher &L = p->launcher;
     launch_linearize(L, d);
@@ -981,8 +1014,11 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
                     const int I = i / BD, J = j / BD;
                     double v = 0.0;
                     if (I == J) v = D[(size_t)I * blk + (size_t)(i % BD) * BD + (j % BD)];
-                    else if (I == J + 1) v = Lb[(size_t)I * blk + (size_t)(i % BD) * BD + (j % BD)];
-                    else if (J == I + 1) v = Lb[(size_t)J * blk + (size_t)(j % BD) * BD + (i % BD)];
+                    // even-indexed coupling blocks are stored transposed
+                    else if (I == J + 1) v = (I & 1) ? Lb[(size_t)I * blk + (size_t)(i % BD) * BD + (j % BD)]
+                                                     : Lb[(size_t)I * blk + (size_t)(j % BD) * BD + (i % BD)];
+                    else if (J == I + 1) v = (J & 1) ? Lb[(size_t)J * blk + (size_t)(j % BD) * BD + (i % BD)]
+                                                     : Lb[(size_t)J * blk + (size_t)(i % BD) * BD + (j % BD)];
                     S[(size_t)i * n + j] = v;
                 }
         }

@@ -8,6 +8,9 @@
 //   k_bcr_backsub (odd i):  x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1})      (top-down)
 // and recurses on the even blocks; the last level (one block) is a plain Cholesky solve.
 // G (with 1/G_kk on its diagonal), YL and yr overwrite D_i, L_i and r_i in place.
+// Coupling blocks with an EVEN index are only ever consumed transposed (as L_{i+1}^T of the
+// odd block before them), so they are stored transposed at every level: the factor kernel
+// then stages all three operands with plain row-major copies (no LDS transpose).
 //
 // The factor kernel is latency bound (72 dependent pivots); it keeps every 6x6 tile of
 // [D | L | U^T | r] in the registers of one lane for the whole factorisation ("owner
@@ -61,9 +64,10 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
     r = r * (1.5 - 0.5 * a * r * r);
     return r;
 }
+// one Newton step: the hardware estimate is good to ~2^-26, so this reaches ~2^-50, plenty
+// for elimination multipliers (the outputs are scaled by the two-step rsqrt above)
 __device__ __forceinline__ double rcp_nr(double a) {
     double r = __builtin_amdgcn_rcp(a);
-    r = fma(fma(-a, r, 1.0), r, r);
     r = fma(fma(-a, r, 1.0), r, r);
     return r;
 }
@@ -118,8 +122,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             if (hasU) uv = U2[e];
             A[r * LDA + c] = dv.x; A[r * LDA + c + 1] = dv.y;
             R[r * LDR + c] = lv.x; R[r * LDR + c + 1] = lv.y;
-            // L_{i+1}^T: element (row r of U, col c) goes to R[c][72 + r]
-            R[c * LDR + BD + r] = uv.x; R[(c + 1) * LDR + BD + r] = uv.y;
+            R[r * LDR + BD + c] = uv.x; R[r * LDR + BD + c + 1] = uv.y;   // even block: stored as L^T
         }
         if (t < BD) {
             R[t * LDR + 2 * BD] = rg[t];
@@ -361,7 +364,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
             for (int j = 0; j < 6; ++j) {
                 const double s = (acc[6 * i + j] + part[tt * 36 + 6 * i + j]) + part[(144 + tt) * 36 + 6 * i + j];
                 const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
-                out[o] = (base ? base[o] : 0.0) - s;
+                // an even-indexed coupling block of the next level is stored transposed
+                const size_t ow = (blockIdx.y == 1 && (m & 1) == 0) ? (size_t)(tc * 6 + j) * BD + tr * 6 + i : o;
+                out[ow] = (base ? base[o] : 0.0) - s;
             }
     }
 }

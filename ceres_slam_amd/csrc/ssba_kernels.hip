@@ -501,8 +501,10 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
         if (Ia == Ib) {
             D0[(size_t)Ia * BD * BD + (size_t)row * BD + col] = v;
             if (fa != fb) D0[(size_t)Ia * BD * BD + (size_t)col * BD + row] = v;
-        } else {   // Ib == Ia + 1: entry (row in block Ia, col in block Ib) = L[Ib]^T
-            L0[(size_t)Ib * BD * BD + (size_t)col * BD + row] = v;
+        } else {   // Ib == Ia + 1: entry (row in block Ia, col in block Ib) = L[Ib]^T;
+                   // even-indexed coupling blocks are stored transposed (ssba_bcr.hip)
+            if (Ib & 1u) L0[(size_t)Ib * BD * BD + (size_t)col * BD + row] = v;
+            else L0[(size_t)Ib * BD * BD + (size_t)row * BD + col] = v;
         }
     } else if (gid < n_el + (size_t)d.nfree * 6) {
         const size_t i = gid - n_el;
