@@ -52,5 +52,22 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_examples() -> str:
+    """C++ driver written against the Ceres-shaped shim (include/ceres_slam_amd/ceres_shim.hpp)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "examples", "dataset_vo_gpu.cpp")
+    out = os.path.join(root, "examples", "dataset_vo_gpu")
+    build_library()
+    deps = [src, os.path.join(root, "include", "ssba.h"), os.path.join(root, "include", "ceres_slam_amd", "ceres_shim.hpp"), LIB]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-I" + os.path.join(root, "include"), src, "-o", out,
+           "-L" + HERE, "-lssba", "-Wl,-rpath,$ORIGIN/../ceres_slam_amd", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("g++ failed:\n" + r.stdout.decode(errors="replace"))
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))

@@ -240,3 +240,43 @@ def make_problem(num_poses: int, num_points: int, *, track_len: int = 12, seed: 
 def make_config(name: str, **kw) -> StereoBAProblem:
     P, L = CONFIGS[name]
     return make_problem(P, L, **kw)
+
+
+# ------------------------------------------------------------------ file I/O ---
+def _T44_rows(poses12: np.ndarray) -> np.ndarray:
+    t, R = pose_unpack(poses12)
+    T = np.zeros(poses12.shape[:-1] + (4, 4))
+    T[..., :3, :3], T[..., :3, 3], T[..., 3, 3] = R, t, 1.0
+    return T.reshape(poses12.shape[:-1] + (16,))
+
+
+def write_reference_csv(prob: StereoBAProblem, dataset_path: str) -> tuple:
+    """Writes the problem in the reference's on-disk formats: the 5-column dataset CSV of
+    src/ceres_slam/dataset_problem.cpp:16-83 and the initial guess as the `_poses.csv` /
+    `_map.csv` pair its write_csv emits (:121-165), at full double precision.
+    Returns (dataset_path, init_poses_path, init_map_path)."""
+    base = dataset_path[: dataset_path.rfind(".")] if "." in dataset_path else dataset_path
+    c = prob.camera
+    with open(dataset_path, "w") as f:
+        f.write(f"{prob.num_poses},{prob.num_points}\n")
+        f.write(",".join(repr(float(c[k])) for k in ("fu", "fv", "cu", "cv", "b")) + "\n")
+        f.write(",".join(repr(float(v)) for v in prob.stereo_obs_var) + "\n")
+        f.write(",".join(repr(float(v)) for v in _T44_rows(prob.poses_gt[0])) + "\n")
+        for k, j, (u, v, d) in zip(prob.obs_pose, prob.obs_point, prob.obs_uvd):
+            f.write(f"{int(k)},{int(j)},{float(u)!r},{float(v)!r},{float(d)!r}\n")
+    poses_path, map_path = base + "_init_poses.csv", base + "_init_map.csv"
+    with open(poses_path, "w") as f:
+        f.write("T_00, T_01, T_02, T_03,T_10, T_11, T_12, T_13,T_20, T_21, T_22, T_23,T_30, T_31, T_32, T_33\n")
+        for row in _T44_rows(prob.poses_init):
+            f.write(",".join(repr(float(v)) for v in row) + "\n")
+    with open(map_path, "w") as f:
+        f.write("point_id, x, y, z\n")
+        for j, p in enumerate(prob.points_init):
+            f.write(f"{j}," + ",".join(repr(float(v)) for v in p) + "\n")
+    return dataset_path, poses_path, map_path
+
+
+def read_pose_csv(path: str) -> np.ndarray:
+    rows = [l for l in open(path).read().splitlines()[1:] if l.strip()]
+    T = np.array([[float(x) for x in r.split(",")] for r in rows]).reshape(-1, 4, 4)
+    return pose_pack(T[:, :3, 3], T[:, :3, :3])

@@ -1,0 +1,252 @@
+// ceres_shim.hpp -- header-only C++11 shim that reproduces, on top of the C ABI in
+// include/ssba.h, the call shapes the ceres-slam stereo drivers use against Ceres
+// (/root/reference tests/dataset_vo.cpp:22-85):
+//
+//     ceres::Problem problem;
+//     ceres::LocalParameterization *se3 = ceres_slam::SE3Perturbation::Create();
+//     ceres::CostFunction *cost = ceres_slam::StereoReprojectionErrorAutomatic::Create(camera, obs, stiffness);
+//     problem.AddResidualBlock(cost, NULL, pose_k, point_j);
+//     problem.SetParameterization(pose_k, se3);
+//     problem.SetParameterBlockConstant(pose_0);
+//     ceres::Solver::Options options;  options.max_num_iterations = 1000; ...
+//     ceres::Solver::Summary summary;  ceres::Solve(options, &problem, &summary);
+//     std::cout << summary.BriefReport();
+//
+// The shim recognises the typed cost functions of this path and lowers them to observation
+// tables; it does NOT run arbitrary user functors on the GPU -- any other CostFunction is
+// rejected at AddResidualBlock with std::invalid_argument (Ceres would accept it: that is the
+// documented limit of the drop-in).  Parameter blocks stay caller-owned; identity = address.
+// Eigen is not needed: observations and stiffness are plain arrays.
+#ifndef CERES_SLAM_AMD_CERES_SHIM_HPP_
+#define CERES_SLAM_AMD_CERES_SHIM_HPP_
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../ssba.h"
+
+namespace ceres {
+
+class CostFunction { public: virtual ~CostFunction() {} };
+class LocalParameterization { public: virtual ~LocalParameterization() {} };
+class LossFunction { public: virtual ~LossFunction() {} };
+class HuberLoss : public LossFunction {
+ public:
+    explicit HuberLoss(double a) : a_(a) {}
+    double a() const { return a_; }
+ private:
+    double a_;
+};
+
+enum TerminationType { CONVERGENCE = 0, NO_CONVERGENCE = 1, FAILURE = 2 };
+enum LinearSolverType { SPARSE_NORMAL_CHOLESKY, SPARSE_SCHUR, DENSE_SCHUR };
+enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
+enum DoglegType { TRADITIONAL_DOGLEG, SUBSPACE_DOGLEG };
+
+}  // namespace ceres
+
+namespace ceres_slam {
+
+// include/ceres_slam/stereo_camera.hpp:159-163
+struct StereoCamera {
+    double fu, fv, cu, cv, b;
+    StereoCamera(double fu_, double fv_, double cu_, double cv_, double b_) : fu(fu_), fv(fv_), cu(cu_), cv(cv_), b(b_) {}
+};
+
+// include/ceres_slam/stereo_reprojection_error.hpp:59-69
+class StereoReprojectionErrorAutomatic : public ceres::CostFunction {
+ public:
+    static ceres::CostFunction *Create(const std::shared_ptr<const StereoCamera> &camera, const double observation[3],
+                                       const double stiffness[9]) {
+        StereoReprojectionErrorAutomatic *c = new StereoReprojectionErrorAutomatic;
+        c->camera = camera;
+        std::memcpy(c->observation, observation, sizeof c->observation);
+        std::memcpy(c->stiffness, stiffness, sizeof c->stiffness);
+        return c;
+    }
+    std::shared_ptr<const StereoCamera> camera;
+    double observation[3];
+    double stiffness[9];
+};
+
+// include/ceres_slam/perturbations.hpp:69-75
+class SE3Perturbation : public ceres::LocalParameterization {
+ public:
+    static ceres::LocalParameterization *Create() { return new SE3Perturbation; }
+};
+
+}  // namespace ceres_slam
+
+namespace ceres {
+
+class Problem;
+
+class Solver {
+ public:
+    // the Options fields the drivers set (tests/dataset_vo.cpp:65-74), Ceres 1.x defaults
+    struct Options {
+        bool minimizer_progress_to_stdout = false;
+        int num_threads = 1;
+        int num_linear_solver_threads = 1;
+        int max_num_iterations = 50;
+        bool use_nonmonotonic_steps = false;
+        TrustRegionStrategyType trust_region_strategy_type = LEVENBERG_MARQUARDT;
+        DoglegType dogleg_type = TRADITIONAL_DOGLEG;
+        LinearSolverType linear_solver_type = SPARSE_SCHUR;
+        double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+        double initial_trust_region_radius = 1e4;
+    };
+    struct Summary {
+        TerminationType termination_type = NO_CONVERGENCE;
+        int num_successful_steps = 0, num_unsuccessful_steps = 0;
+        double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0;
+        std::string message;
+        bool IsSolutionUsable() const { return termination_type == CONVERGENCE || termination_type == NO_CONVERGENCE; }
+        std::string BriefReport() const {
+            ssba_summary s;
+            std::memset(&s, 0, sizeof s);
+            s.termination_type = termination_type;
+            s.num_successful_steps = num_successful_steps;
+            s.num_unsuccessful_steps = num_unsuccessful_steps;
+            s.initial_cost = initial_cost;
+            s.final_cost = final_cost;
+            char buf[256];
+            ssba_brief_report(&s, buf, sizeof buf);
+            return buf;
+        }
+    };
+};
+
+class Problem {
+ public:
+    Problem() {}
+    ~Problem() {   // Ceres default: the problem owns cost functions, losses, parameterisations
+        for (auto c : owned_costs_) delete c;
+        for (auto &kv : owned_losses_) delete kv.first;
+        for (auto &kv : owned_params_) delete kv.first;
+    }
+    Problem(const Problem &) = delete;
+    Problem &operator=(const Problem &) = delete;
+
+    void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *point_block) {
+        auto *s = dynamic_cast<ceres_slam::StereoReprojectionErrorAutomatic *>(cost);
+        if (!s) throw std::invalid_argument("ceres_shim: only StereoReprojectionErrorAutomatic residual blocks run on the GPU path");
+        const HuberLoss *h = nullptr;
+        if (loss) {
+            h = dynamic_cast<HuberLoss *>(loss);
+            if (!h) throw std::invalid_argument("ceres_shim: loss must be NULL or ceres::HuberLoss");
+            owned_losses_[loss] = 1;
+        }
+        const double a = h ? h->a() : 0.0;
+        if (obs_pose_.empty()) {
+            camera_ = s->camera;
+            std::memcpy(stiffness_, s->stiffness, sizeof stiffness_);
+            huber_a_ = a;
+        } else if (std::memcmp(stiffness_, s->stiffness, sizeof stiffness_) != 0 || a != huber_a_ ||
+                   (s->camera != camera_ && std::memcmp(s->camera.get(), camera_.get(), sizeof(ceres_slam::StereoCamera)) != 0)) {
+            throw std::invalid_argument("ceres_shim: all residual blocks must share camera, stiffness and loss");
+        }
+        obs_pose_.push_back(block_index(pose_index_, pose_blocks_, pose_block));
+        obs_point_.push_back(block_index(point_index_, point_blocks_, point_block));
+        obs_uvd_.insert(obs_uvd_.end(), s->observation, s->observation + 3);
+        owned_costs_.push_back(cost);
+    }
+    void SetParameterization(double *block, LocalParameterization *lp) {
+        if (!dynamic_cast<ceres_slam::SE3Perturbation *>(lp)) throw std::invalid_argument("ceres_shim: only SE3Perturbation is supported");
+        if (!pose_index_.count(block)) throw std::invalid_argument("ceres_shim: parameter block not found");
+        parameterized_[block] = 1;
+        owned_params_[lp] = 1;
+    }
+    void SetParameterBlockConstant(double *block) {
+        if (!pose_index_.count(block)) throw std::invalid_argument("ceres_shim: only pose blocks can be held constant");
+        constant_[block] = 1;
+    }
+    void SetParameterBlockVariable(double *block) { constant_.erase(block); }
+    int NumResidualBlocks() const { return (int)obs_pose_.size(); }
+
+ private:
+    friend void Solve(const Solver::Options &, Problem *, Solver::Summary *);
+    static uint32_t block_index(std::map<double *, uint32_t> &idx, std::vector<double *> &blocks, double *b) {
+        auto it = idx.find(b);
+        if (it != idx.end()) return it->second;
+        const uint32_t i = (uint32_t)blocks.size();
+        idx[b] = i;
+        blocks.push_back(b);
+        return i;
+    }
+    std::shared_ptr<const ceres_slam::StereoCamera> camera_;
+    double stiffness_[9];
+    double huber_a_ = 0.0;
+    std::map<double *, uint32_t> pose_index_, point_index_;
+    std::vector<double *> pose_blocks_, point_blocks_;
+    std::vector<uint32_t> obs_pose_, obs_point_;
+    std::vector<double> obs_uvd_;
+    std::map<double *, int> parameterized_, constant_;
+    std::vector<CostFunction *> owned_costs_;
+    std::map<LossFunction *, int> owned_losses_;
+    std::map<LocalParameterization *, int> owned_params_;
+};
+
+// ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81).  Never throws for
+// solver outcomes: the result is in `summary` (as with Ceres); API misuse throws.
+inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
+    Problem &P = *problem;
+    *summary = Solver::Summary();
+    if (P.obs_pose_.empty()) { summary->termination_type = CONVERGENCE; summary->message = "no residual blocks"; return; }
+    for (double *b : P.pose_blocks_)
+        if (!P.parameterized_.count(b)) throw std::invalid_argument("ceres_shim: pose block without SE3Perturbation");
+    // the C ABI takes contiguous block tables: gather the caller's blocks, scatter back after
+    std::vector<double> poses(P.pose_blocks_.size() * 12), points(P.point_blocks_.size() * 3);
+    for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(&poses[12 * i], P.pose_blocks_[i], 12 * sizeof(double));
+    for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(&points[3 * i], P.point_blocks_[i], 3 * sizeof(double));
+    ssba_camera cam = {P.camera_->fu, P.camera_->fv, P.camera_->cu, P.camera_->cv, P.camera_->b};
+    ssba_problem *h = nullptr;
+    int rc = ssba_create(&cam, -1, &h);
+    auto fail = [&](const char *where) {
+        summary->termination_type = FAILURE;
+        summary->message = std::string(where) + ": " + ssba_status_string(rc) + " (" + ssba_last_error() + ")";
+        if (h) ssba_destroy(h);
+    };
+    if (rc) return fail("ssba_create");
+    if ((rc = ssba_add_pose_blocks(h, poses.data(), (uint32_t)P.pose_blocks_.size()))) return fail("ssba_add_pose_blocks");
+    if ((rc = ssba_add_point_blocks(h, points.data(), (uint32_t)P.point_blocks_.size()))) return fail("ssba_add_point_blocks");
+    if ((rc = ssba_add_stereo_observations(h, P.obs_pose_.data(), P.obs_point_.data(), P.obs_uvd_.data(), P.obs_pose_.size(), P.stiffness_)))
+        return fail("ssba_add_stereo_observations");
+    for (auto &kv : P.constant_)
+        if ((rc = ssba_set_pose_constant(h, P.pose_index_[kv.first], 1))) return fail("ssba_set_pose_constant");
+    if (P.huber_a_ > 0 && (rc = ssba_set_huber_loss(h, P.huber_a_))) return fail("ssba_set_huber_loss");
+    if ((rc = ssba_finalize(h))) return fail("ssba_finalize");
+    ssba_options o;
+    ssba_default_options(&o);
+    o.max_num_iterations = options.max_num_iterations;
+    o.use_nonmonotonic_steps = options.use_nonmonotonic_steps ? 1 : 0;
+    o.minimizer_progress_to_stdout = options.minimizer_progress_to_stdout ? 1 : 0;
+    o.num_threads = options.num_threads;
+    o.num_linear_solver_threads = options.num_linear_solver_threads;
+    o.function_tolerance = options.function_tolerance;
+    o.gradient_tolerance = options.gradient_tolerance;
+    o.parameter_tolerance = options.parameter_tolerance;
+    o.initial_trust_region_radius = options.initial_trust_region_radius;
+    ssba_summary s;
+    rc = ssba_solve(h, &o, &s);
+    if (rc && rc != SSBA_ERR_NUMERICAL_FAILURE) return fail("ssba_solve");
+    summary->termination_type = (TerminationType)s.termination_type;
+    summary->num_successful_steps = s.num_successful_steps;
+    summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
+    summary->initial_cost = s.initial_cost;
+    summary->final_cost = s.final_cost;
+    summary->total_time_in_seconds = s.total_time_s;
+    ssba_destroy(h);
+    if (summary->IsSolutionUsable()) {
+        for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(P.pose_blocks_[i], &poses[12 * i], 12 * sizeof(double));
+        for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(P.point_blocks_[i], &points[3 * i], 3 * sizeof(double));
+    }
+}
+
+}  // namespace ceres
+#endif

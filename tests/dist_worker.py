@@ -1,0 +1,59 @@
+"""Worker for the multi-process tests (one process per rank; RANK / WORLD_SIZE / MASTER_* in env).
+
+mode "cpu": gloo on CPU tensors -- the sharding logic + the all-reduce of the shard-local
+            normal-equation sums, with the CPU oracle as the compute (no GPU needed);
+mode "gpu": every rank drives the HIP library on its landmark shard (all ranks on cuda:0 when
+            only one GPU exists) and the exchange points go through torch.distributed.
+Each rank writes a JSON result file: <out>.<rank>.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, out = sys.argv[1], sys.argv[2]
+    import torch
+    import torch.distributed as dist
+    from ceres_slam_amd import sharding, synth
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = synth.make_problem(16, 400, track_len=6, seed=21)
+    shard = sharding.shard_by_landmarks(prob, world, rank)
+    res = {"rank": rank, "num_local_obs": int(shard.obs_pose.shape[0]), "num_local_points": int(shard.points.shape[0])}
+    if mode == "cpu":
+        from oracle import oracle as orc     # checker as compute: this is a test of the host logic
+        op = orc.OracleProblem(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point,
+                               shard.obs_uvd, prob.stiffness())
+        cost, g_p, g_l, H_pp, H_ll = op.linearize()
+        buf = torch.from_numpy(np.concatenate([[cost], g_p.ravel(), H_pp.ravel()]))
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        gmax = torch.tensor([np.abs(g_l).max()], dtype=torch.float64)
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+        res.update(cost=float(buf[0]), g_p=buf[1:1 + g_p.size].tolist(), H_pp_trace=float(np.trace(buf[1 + g_p.size:].numpy().reshape(-1, 6, 6).sum(0))),
+                   gmax_l=float(gmax[0]))
+    else:
+        from ceres_slam_amd import capi
+        from ceres_slam_amd.solver import StereoBA
+        torch.cuda.set_device(0)
+        ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
+                      prob.stiffness(), device=0, world_size=world, rank=rank)
+        ba.set_stream(torch.cuda.current_stream().cuda_stream)
+        sharding.attach_torch_exchange(ba, dist)
+        s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+        res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
+                   final_cost=float(s.final_cost), initial_cost=float(s.initial_cost), cost=log["cost"].tolist(),
+                   poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist())
+    with open(f"{out}.{rank}.json", "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

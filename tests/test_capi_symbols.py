@@ -64,3 +64,8 @@ def test_brief_report_format():
     assert capi.load().ssba_brief_report(ctypes.byref(s), buf, 256) == 0
     assert buf.value.decode() == ("Ceres Solver Report: Iterations: 11, Initial cost: 7.999818e+05, "
                                   "Final cost: 2.899517e+04, Termination: CONVERGENCE")
+
+
+def test_reference_style_cpp_driver_compiles_against_the_shim():
+    exe = build.build_examples()
+    assert os.path.exists(exe)

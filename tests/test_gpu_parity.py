@@ -180,3 +180,22 @@ def test_stepwise_api_and_restart_reproduce_the_blocking_solve(c1_problem):
     ba3 = StereoBA.from_synth(c1_problem)
     s3, log3 = ba3.solve(o)
     assert np.array_equal(log3["cost"], log["cost"]) and np.array_equal(ba3.poses, ba.poses)
+
+
+def test_cpp_driver_through_ceres_shim_matches_oracle(tmp_path):
+    """examples/dataset_vo_gpu.cpp = the reference's solveWindow written against the C++ shim,
+    fed through the reference's own CSV formats."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples()
+    prob = synth.make_problem(12, 150, track_len=6, seed=9)
+    ds, ip, im = synth.write_reference_csv(prob, str(tmp_path / "sim.csv"))
+    r = subprocess.run([exe, ds, ip, im], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    op = orc.OracleProblem.from_synth(prob)
+    s2, _ = op.solve(orc.driver_options(num_threads=2))
+    report = r.stdout.strip().splitlines()[0]
+    assert report.startswith("Ceres Solver Report: Iterations: %d," % s2.num_iterations), report
+    assert "Termination: CONVERGENCE" in report
+    poses = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(poses - op.poses).max() < 1e-6

@@ -1,0 +1,82 @@
+"""Multi-rank path: landmark sharding + exchange of the pose system.
+CPU part: world_size-2 gloo processes, oracle as compute.  GPU part (marked gpu): two ranks
+drive the HIP library on one device and exchange through torch.distributed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from ceres_slam_amd import sharding, synth
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(mode, out, world=2, timeout=300):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=timeout)[0].decode(errors="replace") for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return [json.load(open(f"{out}.{r}.json")) for r in range(world)]
+
+
+def test_landmark_ranges_partition_and_balance():
+    prob = synth.make_problem(40, 3000, track_len=8, seed=2)
+    for world in (1, 2, 3, 8):
+        ranges = sharding.landmark_ranges(prob.obs_point, prob.num_points, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == prob.num_points
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+        counts = [int(((prob.obs_point >= b) & (prob.obs_point < e)).sum()) for b, e in ranges]
+        assert sum(counts) == prob.num_obs
+        assert max(counts) - min(counts) <= 0.02 * prob.num_obs + 16      # balanced by observations
+    # every observation lands in exactly one shard, indices remapped consistently
+    shards = [sharding.shard_by_landmarks(prob, 3, r) for r in range(3)]
+    assert sum(s.obs_pose.shape[0] for s in shards) == prob.num_obs
+    for s in shards:
+        np.testing.assert_array_equal(s.points, prob.points_init[s.point_ids])
+        assert s.obs_point.max() < s.points.shape[0]
+
+
+def test_two_rank_gloo_sum_of_shard_systems_equals_unsharded(tmp_path):
+    res = _run_ranks("cpu", str(tmp_path / "cpu"))
+    prob = synth.make_problem(16, 400, track_len=6, seed=21)
+    op = orc.OracleProblem.from_synth(prob)
+    cost, g_p, g_l, H_pp, H_ll = op.linearize()
+    for r in res:      # every rank holds the same all-reduced sums
+        assert r["cost"] == pytest.approx(cost, rel=1e-12)
+        np.testing.assert_allclose(np.array(r["g_p"]).reshape(-1, 6), g_p, rtol=1e-10, atol=1e-8)
+        assert r["H_pp_trace"] == pytest.approx(np.trace(H_pp.sum(0)), rel=1e-12)
+        assert r["gmax_l"] == pytest.approx(np.abs(g_l).max(), rel=1e-12)
+    assert sum(r["num_local_obs"] for r in res) == prob.num_obs
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_gpu_solve_matches_unsharded_oracle(tmp_path):
+    res = _run_ranks("gpu", str(tmp_path / "gpu"))
+    prob = synth.make_problem(16, 400, track_len=6, seed=21)
+    op = orc.OracleProblem.from_synth(prob)
+    s, log = op.solve(orc.driver_options(num_threads=2))
+    for r in res:
+        assert r["termination"] == 0
+        assert r["num_iterations"] == s.num_iterations
+        np.testing.assert_allclose(r["cost"], log["cost"], rtol=1e-9)
+        assert r["final_cost"] == pytest.approx(s.final_cost, rel=1e-6)
+        assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-6          # poses replicated
+        assert np.abs(np.array(r["points"]) - op.points[r["point_ids"]]).max() < 1e-5
+    np.testing.assert_array_equal(res[0]["poses"], res[1]["poses"])          # ranks agree bit for bit
