@@ -31,7 +31,7 @@ SYMBOLS = [
     "ssba_default_options", "ssba_solve", "ssba_brief_report", "ssba_solve_begin", "ssba_solve_step",
     "ssba_solve_end", "ssba_solve_restart", "ssba_synchronize", "ssba_iteration_log", "ssba_set_stream",
     "ssba_set_exchange", "ssba_set_distributed", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
-    "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_status_string", "ssba_last_error",
+    "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
 ]
 
 
@@ -119,6 +119,8 @@ def load():
     L.ssba_get_stats.argtypes = [H, C.POINTER(Stats)]
     L.ssba_evaluate.argtypes = [H, _dp, _dp, _dp, _dp, _dp]
     L.ssba_lm_step.argtypes = [H, C.POINTER(Options), C.c_double, _dp, _dp, _dp, _dp, _dp]
+    L.ssba_phong_evaluate.argtypes = [C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp,
+                                      _dp, _dp, _dp, _dp, _dp]
     L.ssba_status_string.argtypes = [C.c_int]
     L.ssba_status_string.restype = C.c_char_p
     L.ssba_last_error.restype = C.c_char_p
@@ -144,3 +146,17 @@ def default_options(**kw) -> Options:
 
 def dptr(a: np.ndarray):
     return a.ctypes.data_as(_dp)
+
+
+def phong_evaluate(light_type, poses, points, normals, phong, texture, light, colour, stiffness, normal_obs,
+                   normal_stiffness, device: int = -1):
+    """Batch evaluation of the intensity + normal residual blocks on the GPU (ssba_phong_evaluate)."""
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (poses, points, normals, phong, texture, light, colour,
+                                                              normal_obs, np.asarray(normal_stiffness).reshape(9))]
+    n = a[0].shape[0]
+    r_int, J_int = np.zeros(n), np.zeros((n, 19))
+    r_nrm, J_np, J_nn = np.zeros((n, 3)), np.zeros((n, 3, 6)), np.zeros((n, 3, 3))
+    check(load().ssba_phong_evaluate(device, light_type, n, dptr(a[0]), dptr(a[1]), dptr(a[2]), dptr(a[3]), dptr(a[4]),
+                                     dptr(a[5]), dptr(a[6]), float(stiffness), dptr(a[7]), dptr(a[8]), dptr(r_int),
+                                     dptr(J_int), dptr(r_nrm), dptr(J_np), dptr(J_nn)), "ssba_phong_evaluate")
+    return r_int, J_int, r_nrm, J_np, J_nn

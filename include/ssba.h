@@ -207,6 +207,28 @@ int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, doubl
 int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S,
                  double *rhs, double *delta_p, double *delta_l, double *model_cost_change);
 
+/* ---- Phong-lighting rows: batch evaluation on the device ------ */
+/* replaces, for each of n residual-block instances, the evaluation Ceres performs on
+ *   IntensityErrorPointLightAutomatic / IntensityErrorDirectionalLightAutomatic
+ *     (include/ceres_slam/intensity_error_point_light.hpp:24-112,
+ *      intensity_error_directional_light.hpp:24-113; blocks 12,3,3,3,1,3 -> 1 residual)
+ *   NormalErrorAutomatic (include/ceres_slam/normal_error.hpp:22-54; blocks 12,3 -> 3)
+ * with SE3Perturbation on the pose and UnitVectorPerturbation on the normal (and on the light
+ * direction when light_type = 1) (perturbations.hpp:45-113; tests/dataset_ba_phong.cpp:102-204).
+ * Per instance i: pose i (12), point i (3), normal i (3), phong i (ka,ks,alpha), texture i (kd),
+ * observed colour i, observed normal i (3); shared: the light (position, light_type 0, or
+ * direction, 1), the intensity stiffness 1/sqrt(int_var) and the 3x3 normal stiffness.
+ * Outputs: r_int (n), J_int (n x 19 = [pose 6 | point 3 | normal 3 | phong 3 | texture 1 |
+ * light 3], local coordinates), r_nrm (n x 3), J_nrm_pose (n x 18), J_nrm_n (n x 9).
+ * This is the arithmetic of BASELINE config 3; its solver integration (6-D landmark blocks,
+ * shared light/material border, bounds) is the next row. */
+int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *poses,
+                        const double *points, const double *normals, const double *phong,
+                        const double *texture, const double light[3], const double *colour,
+                        double stiffness, const double *normal_obs, const double normal_stiffness[9],
+                        double *r_int, double *J_int, double *r_nrm, double *J_nrm_pose,
+                        double *J_nrm_n);
+
 const char *ssba_status_string(int status);
 const char *ssba_last_error(void);
 

@@ -251,3 +251,58 @@ def huber(a: float, s: float):
     rho = np.zeros(3)
     lib().orc_huber(a, s, _p(rho))
     return rho
+
+
+# ---- Phong lighting rows -----------------------------------------
+POINT_LIGHT, DIRECTIONAL_LIGHT = 0, 1
+
+
+def _phong_setup():
+    L = lib()
+    if getattr(L, "_phong_ready", False):
+        return L
+    L.orc_phong_shade.argtypes = [_dp, _dp, _dp, C.c_double, C.c_double, C.c_double]
+    L.orc_phong_shade.restype = C.c_double
+    L.orc_light_shade.argtypes = [C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double]
+    L.orc_light_shade.restype = C.c_double
+    L.orc_unit_vector_plus.argtypes = [_dp, _dp, _dp]
+    L.orc_intensity_residual.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_double, _dp, C.c_double, C.c_double, _dp, _dp]
+    L.orc_normal_residual.argtypes = [_dp, _dp, _dp, _dp, _dp, _dp, _dp]
+    L._phong_ready = True
+    return L
+
+
+def _a(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def light_shade(light_type, p, n, light, kd, ks, alpha) -> float:
+    p, n, light = _a(p), _a(n), _a(light)
+    return _phong_setup().orc_light_shade(light_type, _p(p), _p(n), _p(light), kd, ks, alpha)
+
+
+def phong_shade(n, ldir, cdir, kd, ks, alpha) -> float:
+    n, ldir, cdir = _a(n), _a(ldir), _a(cdir)
+    return _phong_setup().orc_phong_shade(_p(n), _p(ldir), _p(cdir), kd, ks, alpha)
+
+
+def unit_vector_plus(x, delta):
+    x, delta, out = _a(x), _a(delta), np.zeros(3)
+    _phong_setup().orc_unit_vector_plus(_p(x), _p(delta), _p(out))
+    return out
+
+
+def intensity_residual(light_type, T, p, n, phong, kd, light, colour, stiffness, jac=False):
+    T, p, n, phong, light = _a(T), _a(p), _a(n), _a(phong), _a(light)
+    r, J = C.c_double(), np.zeros(19)
+    _phong_setup().orc_intensity_residual(light_type, _p(T), _p(p), _p(n), _p(phong), kd, _p(light), colour,
+                                          stiffness, C.byref(r), _p(J) if jac else None)
+    return (r.value, J) if jac else r.value
+
+
+def normal_residual(T, n, n_obs, S, jac=False):
+    T, n, n_obs, S = _a(T), _a(n), _a(n_obs), _a(np.asarray(S).reshape(9))
+    r, Jp, Jn = np.zeros(3), np.zeros(18), np.zeros(9)
+    _phong_setup().orc_normal_residual(_p(T), _p(n), _p(n_obs), _p(S), _p(r), _p(Jp) if jac else None,
+                                       _p(Jn) if jac else None)
+    return (r, Jp.reshape(3, 6), Jn.reshape(3, 3)) if jac else r

@@ -1014,3 +1014,211 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     s->total_time_s = now_s() - t_start;
     return 0;
 }
+
+
+/* ------------------------------------------------------------------------ */
+/* Phong lighting rows                                 */
+/* ------------------------------------------------------------------------ */
+
+static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* Forward value and, optionally, the gradients of the clamped Phong intensity w.r.t. the
+ * camera-frame normal nc, UNIT light direction ell and UNIT camera direction cd, plus the
+ * partials w.r.t. (kd, ks, alpha).  lighting/phong.hpp:25-51 (shade: ambient = 0),
+ * :59-74 (diffuse guard ldn <= 0), :77-104 (mirror direction, guards |m|^2 <= 0 and
+ * s <= 0, ks * pow(s, alpha)), :136-139 + utils/utils.hpp:16-25 (clamp through the templated
+ * fmax/fmin: at the clamp the whole Jet is replaced by a constant => zero derivatives). */
+static double phong_core(const double nc[3], const double ell[3], const double cd[3], double kd,
+                         double ks, double alpha, double g_nc[3], double g_ell[3], double g_cd[3],
+                         double g_mat[3] /* d/dkd, d/dks, d/dalpha */) {
+    double diffuse = 0.0, specular = 0.0;
+    int want = g_nc != NULL;
+    if (want) {
+        for (int i = 0; i < 3; ++i) g_nc[i] = g_ell[i] = g_cd[i] = g_mat[i] = 0.0;
+    }
+    const int finite = isfinite(ell[0]) && isfinite(ell[1]) && isfinite(ell[2]);
+    const double ldn = dot3(ell, nc);
+    const int diff_on = finite && !(ldn <= 0.0);
+    if (diff_on) {
+        diffuse = kd * ldn;
+        if (want) {
+            for (int i = 0; i < 3; ++i) { g_ell[i] += kd * nc[i]; g_nc[i] += kd * ell[i]; }
+            g_mat[0] = ldn;
+        }
+    }
+    /* mirror direction m~ = 2 (n.l) n - l */
+    double mt[3];
+    for (int i = 0; i < 3; ++i) mt[i] = 2.0 * ldn * nc[i] - ell[i];
+    const double mu2 = dot3(mt, mt);
+    if (!(mu2 <= 0.0)) {
+        const double mu = sqrt(mu2);
+        double m[3] = {mt[0] / mu, mt[1] / mu, mt[2] / mu};
+        const double s = dot3(m, cd);
+        if (!(s <= 0.0)) {
+            const double sa = pow(s, alpha);
+            specular = ks * sa;
+            if (want) {
+                const double gs = ks * alpha * pow(s, alpha - 1.0);
+                /* w = (I - m m^T) cd / mu = d s / d m~ */
+                double w[3];
+                for (int i = 0; i < 3; ++i) w[i] = (cd[i] - m[i] * s) / mu;
+                const double nw = dot3(nc, w);
+                for (int i = 0; i < 3; ++i) {
+                    g_ell[i] += gs * (2.0 * nc[i] * nw - w[i]);
+                    g_nc[i] += gs * 2.0 * (ldn * w[i] + ell[i] * nw);
+                    g_cd[i] += gs * m[i];
+                }
+                g_mat[1] = sa;
+                g_mat[2] = ks * sa * log(s);
+            }
+        }
+    }
+    double col = 1.0 * (0.0 + diffuse + specular);
+    int clamped = 0;
+    if (0.0 >= col) { col = 0.0; clamped = 1; }     /* fmax(Colour(0), col) */
+    if (1.0 <= col) { col = 1.0; clamped = 1; }     /* fmin(Colour(1), col) */
+    if (clamped && want)
+        for (int i = 0; i < 3; ++i) g_nc[i] = g_ell[i] = g_cd[i] = g_mat[i] = 0.0;
+    return col;
+}
+
+double orc_phong_shade(const double n[3], const double ldir[3], const double cdir[3], double kd,
+                       double ks, double alpha) {
+    return phong_core(n, ldir, cdir, kd, ks, alpha, NULL, NULL, NULL, NULL);
+}
+
+/* Intensity of a camera-frame vertex (q, nc) under a light given in the camera frame
+ * (position lc, or un-normalised direction dc), camera at the origin; gradients w.r.t. q, nc
+ * and the light vector.  point_light.hpp:76-90, directional_light.hpp:32-35,82-91. */
+static double light_core(int light_type, const double q[3], const double nc[3], const double lv[3],
+                         double kd, double ks, double alpha, double g_q[3], double g_nc[3],
+                         double g_l[3], double g_mat[3]) {
+    double ell[3], cd[3], rho;
+    if (light_type == ORC_POINT_LIGHT) {
+        double v[3] = {lv[0] - q[0], lv[1] - q[1], lv[2] - q[2]};
+        rho = sqrt(dot3(v, v));
+        for (int i = 0; i < 3; ++i) ell[i] = v[i] / rho;
+    } else {
+        rho = sqrt(dot3(lv, lv));
+        for (int i = 0; i < 3; ++i) ell[i] = lv[i] / rho;
+    }
+    const double qn = sqrt(dot3(q, q));
+    for (int i = 0; i < 3; ++i) cd[i] = -q[i] / qn;
+    if (!g_q) return phong_core(nc, ell, cd, kd, ks, alpha, NULL, NULL, NULL, NULL);
+    double g_ell[3], g_cd[3];
+    const double col = phong_core(nc, ell, cd, kd, ks, alpha, g_nc, g_ell, g_cd, g_mat);
+    /* d ell / d v = (I - ell ell^T)/rho ; d cd / d q = -(I - cd cd^T)/|q| */
+    const double le = dot3(ell, g_ell), ce = dot3(cd, g_cd);
+    for (int i = 0; i < 3; ++i) {
+        const double gv = (g_ell[i] - ell[i] * le) / rho;
+        const double gc = -(g_cd[i] - cd[i] * ce) / qn;
+        g_l[i] = gv;
+        g_q[i] = gc - (light_type == ORC_POINT_LIGHT ? gv : 0.0);
+    }
+    return col;
+}
+
+double orc_light_shade(int light_type, const double p[3], const double n[3], const double light[3],
+                       double kd, double ks, double alpha) {
+    return light_core(light_type, p, n, light, kd, ks, alpha, NULL, NULL, NULL, NULL);
+}
+
+void orc_unit_vector_plus(const double x[3], const double delta[3], double out[3]) {
+    const double s = dot3(delta, x) / dot3(x, x);
+    double y[3] = {x[0] + delta[0] - s * x[0], x[1] + delta[1] - s * x[1], x[2] + delta[2] - s * x[2]};
+    const double nrm = sqrt(dot3(y, y));
+    for (int i = 0; i < 3; ++i) out[i] = y[i] / nrm;
+}
+
+/* plus-Jacobian of UnitVectorPerturbation at delta = 0: (I - x^ x^^T)/|x| (x^ = x/|x|) */
+static void unit_plus_jacobian(const double x[3], double P[9]) {
+    const double n2 = dot3(x, x), nrm = sqrt(n2);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) P[3 * i + j] = ((i == j ? 1.0 : 0.0) - x[i] * x[j] / n2) / nrm;
+}
+
+static void rot_vec(const double T[12], const double v[3], double out[3]) {   /* se3group.hpp:242-244 */
+    const double *R = T + 3;
+    for (int i = 0; i < 3; ++i) out[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+/* row-vector g (1x3) times [ I | -a^ ]  ->  (g, g x (-a)^...) : returns the 3 rotational entries
+ * of g^T [-a^] = (a x g)^T... explicitly: g^T (-a^) = ( -g1 a2 + g2 a1,  g0 a2 - g2 a0, -g0 a1 + g1 a0 ) */
+static void row_times_neg_skew(const double g[3], const double a[3], double out[3]) {
+    out[0] = -g[1] * a[2] + g[2] * a[1];
+    out[1] = g[0] * a[2] - g[2] * a[0];
+    out[2] = -g[0] * a[1] + g[1] * a[0];
+}
+
+void orc_intensity_residual(int light_type, const double T[12], const double p[3],
+                            const double n[3], const double phong[3], double kd,
+                            const double light[3], double colour, double stiffness, double *r,
+                            double *J19) {
+    double q[3], nc[3], lc[3];
+    orc_se3_transform(T, p, q);
+    rot_vec(T, n, nc);
+    if (light_type == ORC_POINT_LIGHT) orc_se3_transform(T, light, lc);
+    else rot_vec(T, light, lc);
+    if (!J19) {
+        *r = stiffness * (light_core(light_type, q, nc, lc, kd, phong[1], phong[2], NULL, NULL, NULL, NULL) - colour);
+        return;
+    }
+    double g_q[3], g_nc[3], g_l[3], g_mat[3];
+    const double col = light_core(light_type, q, nc, lc, kd, phong[1], phong[2], g_q, g_nc, g_l, g_mat);
+    *r = stiffness * (col - colour);
+    const double *R = T + 3;
+    /* pose: dq/deps = [I | -q^], dnc/deps = [0 | -nc^], dlc/deps = [I | -lc^] (point) or [0 | -lc^] */
+    double rq[3], rn[3], rl[3];
+    row_times_neg_skew(g_q, q, rq);
+    row_times_neg_skew(g_nc, nc, rn);
+    row_times_neg_skew(g_l, lc, rl);
+    for (int i = 0; i < 3; ++i) {
+        J19[i] = stiffness * (g_q[i] + (light_type == ORC_POINT_LIGHT ? g_l[i] : 0.0));
+        J19[3 + i] = stiffness * (rq[i] + rn[i] + rl[i]);
+    }
+    /* point: g_q^T R */
+    for (int j = 0; j < 3; ++j) J19[6 + j] = stiffness * (g_q[0] * R[j] + g_q[1] * R[3 + j] + g_q[2] * R[6 + j]);
+    /* normal: g_nc^T R P(n) */
+    double gR[3], P[9];
+    for (int j = 0; j < 3; ++j) gR[j] = g_nc[0] * R[j] + g_nc[1] * R[3 + j] + g_nc[2] * R[6 + j];
+    unit_plus_jacobian(n, P);
+    for (int j = 0; j < 3; ++j) J19[9 + j] = stiffness * (gR[0] * P[j] + gR[1] * P[3 + j] + gR[2] * P[6 + j]);
+    /* phong params (ka, ks, alpha): ambient is disabled (phong.hpp:33) => d/dka = 0 */
+    J19[12] = 0.0;
+    J19[13] = stiffness * g_mat[1];
+    J19[14] = stiffness * g_mat[2];
+    /* texture kd */
+    J19[15] = stiffness * g_mat[0];
+    /* light: g_l^T R, through the unit-vector plus-Jacobian when directional */
+    for (int j = 0; j < 3; ++j) gR[j] = g_l[0] * R[j] + g_l[1] * R[3 + j] + g_l[2] * R[6 + j];
+    if (light_type == ORC_POINT_LIGHT) {
+        for (int j = 0; j < 3; ++j) J19[16 + j] = stiffness * gR[j];
+    } else {
+        unit_plus_jacobian(light, P);
+        for (int j = 0; j < 3; ++j) J19[16 + j] = stiffness * (gR[0] * P[j] + gR[1] * P[3 + j] + gR[2] * P[6 + j]);
+    }
+}
+
+void orc_normal_residual(const double T[12], const double n[3], const double n_obs[3],
+                         const double S[9], double r[3], double *Jpose, double *Jn) {
+    double nc[3];
+    rot_vec(T, n, nc);
+    const double e[3] = {nc[0] - n_obs[0], nc[1] - n_obs[1], nc[2] - n_obs[2]};
+    for (int i = 0; i < 3; ++i) r[i] = S[3 * i] * e[0] + S[3 * i + 1] * e[1] + S[3 * i + 2] * e[2];
+    if (Jpose) {
+        for (int i = 0; i < 3; ++i) {
+            double rr[3];
+            row_times_neg_skew(S + 3 * i, nc, rr);
+            Jpose[6 * i] = Jpose[6 * i + 1] = Jpose[6 * i + 2] = 0.0;
+            Jpose[6 * i + 3] = rr[0]; Jpose[6 * i + 4] = rr[1]; Jpose[6 * i + 5] = rr[2];
+        }
+    }
+    if (Jn) {
+        const double *R = T + 3;
+        double P[9], SR[9];
+        unit_plus_jacobian(n, P);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) SR[3 * i + j] = S[3 * i] * R[j] + S[3 * i + 1] * R[3 + j] + S[3 * i + 2] * R[6 + j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) Jn[3 * i + j] = SR[3 * i] * P[j] + SR[3 * i + 1] * P[3 + j] + SR[3 * i + 2] * P[6 + j];
+    }
+}

@@ -127,6 +127,37 @@ int orc_lm_step(const orc_problem *p, double radius, const orc_options *o,
 /* Full solve with Ceres 1.13/1.14 trust-region semantics (see header comment). */
 int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteration_log *log);
 
+/* ---- Phong lighting rows ------------------------- */
+enum { ORC_POINT_LIGHT = 0, ORC_DIRECTIONAL_LIGHT = 1 };
+
+/* PhongModel::shade with ambient forced to 0, the <= 0 guards and the [0,1] clamp
+ * (include/ceres_slam/lighting/phong.hpp:25-51,59-104,136-139), all vectors in one frame:
+ * normal n, unit light direction ldir, unit camera direction cdir. */
+double orc_phong_shade(const double n[3], const double ldir[3], const double cdir[3],
+                       double kd, double ks, double alpha);
+/* PointLight::shade / DirectionalLight::shade of a vertex at p with normal n, camera at the
+ * origin (point_light.hpp:76-90, directional_light.hpp:82-91).  light = position or direction. */
+double orc_light_shade(int light_type, const double p[3], const double n[3], const double light[3],
+                       double kd, double ks, double alpha);
+/* UnitVectorPerturbation::operator() (include/ceres_slam/perturbations.hpp:87-103) */
+void orc_unit_vector_plus(const double x[3], const double delta[3], double out[3]);
+/* IntensityErrorPointLightAutomatic / ...DirectionalLightAutomatic::operator()
+ * (intensity_error_point_light.hpp:24-96, intensity_error_directional_light.hpp:24-96):
+ *   r = stiffness * (shade(T p, R n, T l | R l) - colour).
+ * Optional LOCAL Jacobians (what Ceres forms with SE3Perturbation on the pose and
+ * UnitVectorPerturbation on the normal -- and on the light when directional,
+ * tests/dataset_ba_phong.cpp:193-204): J = [ pose(6) | point(3) | normal(3) | phong(3) |
+ * texture(1) | light(3) ] = 19 entries. */
+void orc_intensity_residual(int light_type, const double T[12], const double p[3],
+                            const double n[3], const double phong[3], double kd,
+                            const double light[3], double colour, double stiffness,
+                            double *r, double *J19);
+/* NormalErrorAutomatic::operator() (include/ceres_slam/normal_error.hpp:22-42):
+ * r = S_n (R n - n_obs); local Jacobians Jpose (3x6) and Jn (3x3, through the unit-vector
+ * plus-Jacobian). */
+void orc_normal_residual(const double T[12], const double n[3], const double n_obs[3],
+                         const double S[9], double r[3], double *Jpose, double *Jn);
+
 #ifdef __cplusplus
 }
 #endif

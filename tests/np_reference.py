@@ -237,3 +237,75 @@ class NumpyBA:
                 dec *= 2
                 log.append((c_cost, False))
         return x_p, x_l, log
+
+
+# ---- Phong lighting rows: forward formulas only (complex-step differentiable) ----------------
+def _fmax0(col):      # utils/utils.hpp:16-19 with a = 0
+    return 0.0 * col if 0.0 >= col.real else col
+
+
+def _fmin1(col):      # utils/utils.hpp:22-25 with a = 1
+    return 1.0 + 0.0 * col if 1.0 <= col.real else col
+
+
+def phong_shade(nc, ell, cd, kd, ks, alpha):
+    """lighting/phong.hpp:25-51,59-104,136-139 (ambient = 0)."""
+    nc, ell, cd = (np.asarray(v, dtype=complex) for v in (nc, ell, cd))
+    diffuse = 0.0
+    ldn = ell @ nc
+    if np.all(np.isfinite(ell)) and not (ldn.real <= 0):
+        diffuse = kd * ldn
+    specular = 0.0
+    mt = 2 * ldn * nc - ell
+    if not ((mt @ mt).real <= 0):
+        m = mt / np.sqrt(mt @ mt)
+        s = m @ cd
+        if not (s.real <= 0):
+            specular = ks * s ** alpha
+    col = 1.0 * (0.0 + diffuse + specular) + 0j
+    return _fmin1(_fmax0(col))
+
+
+def unit_vector_plus(x, delta):
+    """perturbations.hpp:98-102"""
+    y = x + delta - (delta @ x) / (x @ x) * x
+    return y / np.sqrt(y @ y)
+
+
+def intensity_residual(light_type, T, p, n, phong, kd, light, colour, stiffness):
+    """intensity_error_point_light.hpp:24-96 / intensity_error_directional_light.hpp:24-96"""
+    t, R = T[:3], T[3:].reshape(3, 3)
+    q, nc = R @ p + t, R @ n
+    if light_type == 0:
+        v = (R @ light + t) - q                       # point_light.hpp:79-81
+        ell = v / np.sqrt(v @ v)
+    else:
+        d = R @ light                                 # directional_light.hpp:32-35 normalises
+        ell = d / np.sqrt(d @ d)
+    cd = -q / np.sqrt(q @ q)
+    return stiffness * (phong_shade(nc, ell, cd, kd, phong[1], phong[2]) - colour)
+
+
+def intensity_jacobian_complex_step(light_type, T, p, n, phong, kd, light, colour, stiffness, h=1e-30):
+    """[pose(6) | point(3) | normal(3) | phong(3) | texture(1) | light(3)] local Jacobian the way
+    Ceres forms it: through SE3Perturbation / UnitVectorPerturbation Plus at delta = 0."""
+    J = np.zeros(19)
+    c = lambda a: np.asarray(a, dtype=complex)
+    T, p, n, phong, light = c(T), c(p), c(n), c(phong), c(light)
+    base = dict(light_type=light_type, T=T, p=p, n=n, phong=phong, kd=kd + 0j, light=light, colour=colour, stiffness=stiffness)
+
+    def f(**kw):
+        a = dict(base)
+        a.update(kw)
+        return intensity_residual(**a).imag / h
+    for k in range(6):
+        e = np.zeros(6, dtype=complex); e[k] = 1j * h
+        J[k] = f(T=se3_plus(T, e))
+    for k in range(3):
+        e = np.zeros(3, dtype=complex); e[k] = 1j * h
+        J[6 + k] = f(p=p + e)
+        J[9 + k] = f(n=unit_vector_plus(n, e))
+        J[12 + k] = f(phong=phong + e)
+        J[16 + k] = f(light=(light + e) if light_type == 0 else unit_vector_plus(light, e))
+    J[15] = f(kd=kd + 1j * h)
+    return J

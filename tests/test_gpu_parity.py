@@ -199,3 +199,36 @@ def test_cpp_driver_through_ceres_shim_matches_oracle(tmp_path):
     assert "Termination: CONVERGENCE" in report
     poses = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
     assert np.abs(poses - op.poses).max() < 1e-6
+
+
+@pytest.mark.parametrize("light_type", [0, 1])
+def test_phong_rows_match_oracle(light_type):
+    """intensity (point / directional light) and normal residual blocks with
+    their local Jacobians, evaluated on the GPU through the C ABI, against the oracle."""
+    from test_oracle_phong import _random_scene, V28, V245, LIGHT, KA, KS, ALPHA, KD
+    rng = np.random.default_rng(100 + light_type)
+    scenes = [_random_scene(rng, light_type) for _ in range(500)]
+    T = np.array([s[0] for s in scenes]); p = np.array([s[1] for s in scenes]); n = np.array([s[2] for s in scenes])
+    ph = np.array([s[3] for s in scenes]); kd = np.array([s[4] for s in scenes])
+    light = scenes[0][5]                                      # one shared light, as in the reference driver
+    colour = rng.uniform(0, 1, len(scenes))
+    nobs = np.einsum("nij,nj->ni", T[:, 3:].reshape(-1, 3, 3), n) + rng.normal(size=(len(scenes), 3)) * 0.01
+    Sn = np.eye(3) * 100.0
+    r_int, J_int, r_nrm, J_np, J_nn = capi.phong_evaluate(light_type, T, p, n, ph, kd, light, colour, 100.0, nobs, Sn)
+    nz = 0
+    for i in range(len(scenes)):
+        r, J = orc.intensity_residual(light_type, T[i], p[i], n[i], ph[i], kd[i], light, colour[i], 100.0, jac=True)
+        assert r_int[i] == pytest.approx(r, rel=1e-12, abs=1e-11)
+        np.testing.assert_allclose(J_int[i], J, rtol=1e-10, atol=1e-9)
+        rn, Jp, Jn = orc.normal_residual(T[i], n[i], nobs[i], Sn, jac=True)
+        np.testing.assert_allclose(r_nrm[i], rn, rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(J_np[i], Jp, rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(J_nn[i], Jn, rtol=1e-12, atol=1e-10)
+        nz += int(np.abs(J).max() > 0)
+    assert nz > 300
+    if light_type == 0:   # the reference's own light_test scene (tests/light_test.cpp:26-50), identity pose
+        I = synth.pose_pack(np.zeros(3), np.eye(3))
+        P2 = np.array([V28[0], V245[0]]); N2 = np.array([V28[1], V245[1]])
+        r2 = capi.phong_evaluate(0, np.array([I, I]), P2, N2, np.array([[KA, KS, ALPHA]] * 2), np.array([KD, KD]), LIGHT,
+                                 np.zeros(2), 1.0, N2, np.eye(3))[0]
+        np.testing.assert_allclose(r2, [0.27697118, 0.48917229], atol=5e-9)
