@@ -31,9 +31,10 @@ namespace ssba {
 constexpr int NB = 6;                       // tile edge
 constexpr int NBLK = BD / NB;               // 12 block rows
 constexpr int NCB = (2 * BD + 1 + NB - 1) / NB;   // 25 column blocks of the right-hand sides
-constexpr int NT_A = NBLK * (NBLK + 1) / 2; // 78 lower tiles of D
-constexpr int NT = NT_A + NBLK * NCB;       // 378 tiles in all
-constexpr int FACT_THREADS = 384;
+constexpr int NT_A = NBLK * (NBLK - 1) / 2; // 66 strictly-lower tiles of D (diagonal tiles: see below)
+constexpr int NT = NT_A + NBLK * NCB;       // 366 register-resident tiles
+constexpr int TILE_THREADS = 384;           // waves 0..5 own tiles
+constexpr int FACT_THREADS = 448;           // wave 6 factors the diagonal tiles one step ahead
 
 // tile table, sorted by the step in which a tile becomes final so that whole waves retire early
 __constant__ uint8_t c_tile_type[NT];   // 0 = tile of D (rb >= cb), 1 = tile of the right-hand sides
@@ -44,7 +45,7 @@ int upload_bcr_tables(hipStream_t s) {
     struct T { int fin, type, rb, cb; };
     std::vector<T> v;
     for (int rb = 0; rb < NBLK; ++rb)
-        for (int cb = 0; cb <= rb; ++cb) v.push_back({cb, 0, rb, cb});
+        for (int cb = 0; cb < rb; ++cb) v.push_back({cb, 0, rb, cb});
     for (int rb = 0; rb < NBLK; ++rb)
         for (int cb = 0; cb < NCB; ++cb) v.push_back({rb, 1, rb, cb});
     std::stable_sort(v.begin(), v.end(), [](const T &a, const T &b) { return a.fin < b.fin; });
@@ -74,8 +75,10 @@ __device__ __forceinline__ double rcp_nr(double a) {
 
 #ifdef SSBA_STAMPS
 #define STAMP(base, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) d.dbg[(base) + (i)] = clock64(); } while (0)
+#define STAMPT(tid, base, i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == (tid)) d.dbg[(base) + (i)] = clock64(); } while (0)
 #else
 #define STAMP(base, i) do { } while (0)
+#define STAMPT(tid, base, i) do { } while (0)
 #endif
 
 constexpr int LDA = BD + 2;            // 74: LDS row stride of D / G (16-byte aligned rows)
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     double *A = lds;                 // BD x LDA
     double *R = lds + BD * LDA;      // BD x LDR : [ L_i (72) | L_{i+1}^T (72) | r_i | pad ]
     __shared__ int sBad;
+    __shared__ double sDiag[36];
     const BcrLevel &L = d.lev[lev];
     const int blk = top ? 0 : 2 * blockIdx.x + 1;
     const bool hasL = !top, hasU = !top && (blk + 1 < L.n);
@@ -146,7 +150,6 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     if (type == 1) { own = R + (rb * 6) * LDR + cb * 6; osx = 1; osz = LDR; }
     else { own = A + (rb * 6) * LDA + cb * 6; osx = LDA; osz = 1; }
     const int fin = (type == 1) ? rb : cb;          // step at which this tile becomes final
-    const bool is_diag = (type == 0) && rb == cb;
     double acc[36];
     if (has_tile) {
 #pragma unroll
@@ -154,24 +157,42 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
 #pragma unroll
             for (int z = 0; z < 6; ++z) acc[6 * x + z] = own[x * osx + z * osz];
     }
-
-    for (int kb = 0; kb < NBLK; ++kb) {
-        // (1) owner of the diagonal tile: 6x6 Cholesky.  The pivot chain runs on reciprocals
-        //     (a_ic -= a_ij a_cj / s_j); the square roots only scale the outputs.
-        if (is_diag && rb == kb) {
+    // Diagonal tiles have no owner: wave 6 rebuilds tile (kd,kd) left-looking from the finished
+    // panels of block row kd (they live in LDS), factors it (6 dependent pivots on reciprocals,
+    // square roots only scale the outputs) and stores L with 1/L_jj on the diagonal.  It does so
+    // for step kb+1 while waves 0..5 run the trailing update of step kb, which takes the
+    // ~1.2k-cycle pivot chain off the critical path.
+    auto diag_step = [&](int kd) {
+        const int e = t - TILE_THREADS;
+        if (e < 36) {
+            const int i = e / 6, j = e - i * 6;
+            const double *ri = A + (kd * 6 + i) * LDA, *rj = A + (kd * 6 + j) * LDA;
+            double v0 = ri[kd * 6 + j], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            for (int c = 0; c + 4 <= kd * 6; c += 4) {
+                const double2 a0 = *reinterpret_cast<const double2 *>(ri + c), a1 = *reinterpret_cast<const double2 *>(ri + c + 2);
+                const double2 b0 = *reinterpret_cast<const double2 *>(rj + c), b1 = *reinterpret_cast<const double2 *>(rj + c + 2);
+                v0 -= a0.x * b0.x; v1 -= a0.y * b0.y; v2 -= a1.x * b1.x; v3 -= a1.y * b1.y;
+            }
+            if ((kd * 6) & 2) {   // 6*kd is even: a remainder of two columns when kd is odd
+                const int c = kd * 6 - 2;
+                v0 -= ri[c] * rj[c]; v1 -= ri[c + 1] * rj[c + 1];
+            }
+            sDiag[e] = (v0 + v1) + (v2 + v3);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (e == 0) {
             double a[6][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) a[i][j] = acc[6 * i + j];
+                for (int j = 0; j <= i; ++j) a[i][j] = sDiag[6 * i + j];
             bool bad = false;
-            double rs[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
-                double s = a[j][j];
-                if (!(s > 0.0) || !isfinite(s)) { bad = true; s = 1.0; }
-                const double rc = rcp_nr(s);
-                rs[j] = rsqrt_nr(s);
+                double sv = a[j][j];
+                if (!(sv > 0.0) || !isfinite(sv)) { bad = true; sv = 1.0; a[j][j] = 1.0; }
+                const double rc = rcp_nr(sv);
 #pragma unroll
                 for (int c = j + 1; c < 6; ++c) {
                     const double w = a[c][j] * rc;
@@ -180,14 +201,27 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
                 }
             }
             if (bad) sBad = 1;
-            // G tile: L below the diagonal, 1/L_jj ON the diagonal (consumers multiply)
+            // unscaled columns (L D^1/2 form): the 36 lanes scale them in parallel below
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j)
-                    A[(kb * 6 + i) * LDA + kb * 6 + j] = (j < i) ? a[i][j] * rs[j] : rs[j];
+                for (int j = 0; j <= i; ++j) sDiag[6 * i + j] = a[i][j];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (e < 36) {
+            const int i = e / 6, j = e - i * 6;
+            if (j <= i) {
+                // G tile: L = (unscaled column j) / sqrt(pivot j) below the diagonal, 1/L_jj ON it
+                const double rs = rsqrt_nr(sDiag[7 * j]);
+                A[(kd * 6 + i) * LDA + kd * 6 + j] = (j < i) ? sDiag[6 * i + j] * rs : rs;
+            }
+        }
+    };
+    if (t >= TILE_THREADS) diag_step(0);
+
+    for (int kb = 0; kb < NBLK; ++kb) {
+        __syncthreads();                      // (1) L(kb) is in LDS
         STAMP(lev * 64, 2 + 3 * kb);
         if (sBad) {
             if (t == 0) st.step_failed = 1;
@@ -195,7 +229,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
         }
         // (2) block column kb of G and block row kb of Y become final: forward substitution of
         //     each line T[x][:] against the diagonal tile (right-looking, 6 independent lines)
-        if (has_tile && fin == kb && !is_diag) {
+        if (has_tile && fin == kb) {
             double l[6][6];
 #pragma unroll
             for (int i = 0; i < 6; ++i)
@@ -219,6 +253,8 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
         __syncthreads();
         STAMP(lev * 64, 3 + 3 * kb);
         // (3) trailing update of every tile that is not final yet
+        STAMPT(340, 1024 + lev * 64, 2 * kb);
+        STAMPT(384, 2048 + lev * 64, 2 * kb);
         if (has_tile && fin > kb) {
             const double *Pp, *Qp;
             int psx, psq;
@@ -243,6 +279,9 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
                     acc[6 * x + z] = v;
                 }
         }
+        else if (t >= TILE_THREADS && kb + 1 < NBLK) diag_step(kb + 1);
+        STAMPT(340, 1024 + lev * 64, 2 * kb + 1);
+        STAMPT(384, 2048 + lev * 64, 2 * kb + 1);
         // the next step's first barrier orders these LDS reads before the next panel writes
         STAMP(lev * 64, 4 + 3 * kb);
     }
