@@ -61,9 +61,11 @@ def algorithmic_work(stats):
         # 24 B obs + 4 B ref + 24 B gathered point per observation, 216 B out per pose
         "k_linearize_poses": dict(bytes=52 * N + 216 * P, flops=330 * N),
         # per landmark: T(T+1)/2 pairs x 108 FMA + T half-linearisations (~330 flop)
-        "k_schur_windows": dict(bytes=24 * N + 120 * L, flops=L * (T * (T + 1) / 2 * 216 + T * 330)),
+        # + one 23 KB slab (78 blocks + 12 rhs) written per window
+        "k_schur_windows": dict(bytes=24 * N + 120 * L + 23040 * stats["num_windows"], flops=L * (T * (T + 1) / 2 * 216 + T * 330)),
         "k_backsub_eval": dict(bytes=2 * 24 * N + 120 * L, flops=500 * N),
-        "k_assemble_reduced": dict(bytes=B * 288 * 2, flops=0),
+        # slabs in (23 KB per window) + S blocks out
+        "k_assemble_reduced": dict(bytes=23040 * stats["num_windows"] + B * 288 * 2, flops=0),
         # per block: Cholesky bd^3/3 + two triangular solves with 2*bd+1 right-hand sides; 3 blocks in, 3 out
         "k_bcr_factor": dict(bytes=6 * blk * sum(odd) / len(odd), flops=(bd ** 3 / 3 + bd * bd * (2 * bd + 1)) * sum(odd) / len(odd)),
         # per new block: three bd^3 products (2 flop per FMA), 3 blocks in, 2 out
@@ -71,6 +73,15 @@ def algorithmic_work(stats):
         # per block: two mat-vecs + one triangular solve; 3 blocks in
         "k_bcr_backsub": dict(bytes=3 * blk * sum(odd) / len(odd), flops=(4 * bd * bd + bd * bd) * sum(odd) / len(odd)),
     }
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (bench.py
+    cannot collect PMC counters itself); tools/pmc_summarize.py documents the correction."""
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config.lower()}.json")
+    if not os.path.exists(path):
+        return {}
+    return {k: v["traffic_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
 
 
 def roofline_of(work, avg_ms):
@@ -197,6 +208,12 @@ def main():
         roof = roofline_of(work[dom], per_kernel[dom])
         roof["kernel"] = dom
         roof_all = {k: roofline_of(work[k], per_kernel[k]) for k in work if per_kernel.get(k)}
+        traffic = pmc_traffic(args.config) if world == 1 else {}
+        for k, r in roof_all.items():
+            r["traffic"] = traffic.get(k)
+            r["algorithmic_bytes"] = work[k]["bytes"]
+        roof["traffic"] = traffic.get(dom)
+        roof["algorithmic_bytes"] = work[dom]["bytes"]
         out = {
             "metric": "gauss_newton_iters_per_sec",
             "value": joint_ips * world,
