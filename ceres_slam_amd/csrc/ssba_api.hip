@@ -584,6 +584,7 @@ int ssba_finalize(ssba_problem *p) {
     HIPCHECK(hipHostMalloc((void **)&p->h_stage, std::max<size_t>(p->h_stage_count, 1) * sizeof(double), hipHostMallocDefault));
     if (upload_pair_table(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
     if (upload_bcr_tables(p->launcher.stream)) { set_error("BCR tile table upload failed"); return SSBA_ERR_HIP; }
+    if (configure_schur()) { set_error("hipFuncSetAttribute(k_schur_windows) failed"); return SSBA_ERR_HIP; }
     if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
 #undef TRY
     p->stats.num_poses = P; p->stats.num_free_poses = (uint32_t)nfree;

@@ -342,38 +342,84 @@ __global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
     }
 }
 
-// Schur complement contributions, output-stationary: one block per work item (a window
-// or a slice of it), lanes = the 78 pose pairs (sa <= sb) of the window, each lane keeps
-// its 6x6 block  sum_j (W_aj C_j^-1) W_bj^T  in registers while the block streams over the
-// landmarks; batches of SCHUR_BATCH landmarks are half-linearised by (landmark, slot)
-// lanes and staged through LDS.  W = J_p^T J_l is recomputed from the observation, never
-// stored in HBM.  Result: one slab (78 blocks + 12 rhs vectors) per work item.
-constexpr int SCHUR_BATCH = 10;   // 10 landmarks x 12 slots = 120 of 128 lanes
-constexpr int WY_STRIDE = 38;     // 36 doubles + 2 pad (bank spread for ds_read_b128)
+// Schur complement contributions, output-stationary: one 256-thread block per work item (a
+// window or a slice of it).  Batches of 21 landmarks are half-linearised by 252 (landmark, slot)
+// producer lanes -- W = J_p^T J_l and Y = W C^-1 are recomputed from the observation, never
+// stored in HBM -- and staged through LDS; the consumers are the 78 pose pairs (sa <= sb) of the
+// window times a 3-way split of the batch (234 lanes), each lane keeping its 6x6 partial of
+// sum_j Y_aj W_bj^T in registers for the whole item.  The three partials are combined in a fixed
+// order at the end: one slab (78 blocks + 12 rhs vectors) per item, no float atomics.
+constexpr int SCHUR_THREADS = 256;
+constexpr int SCHUR_BATCH = 21;   // 21 landmarks x 12 slots = 252 producer lanes
+constexpr int SCHUR_SPLIT = 3;    // 78 pairs x 3 = 234 consumer lanes, 7 landmarks each per batch
+constexpr int WY_STRIDE = 38;     // 36 doubles + 2 pad: 304 B, keeps 16-byte alignment
+constexpr int SCHUR_LDS_DOUBLES = SCHUR_BATCH * TW * WY_STRIDE + SCHUR_BATCH * 4;
 
-__global__ __launch_bounds__(128) void k_schur_windows(Dev d) {
+// 1/x and 1/sqrt(x) from the hardware estimates + Newton steps (IEEE divide / sqrt cost ~110 / ~150
+// dependent cycles on gfx950, tools/fp64_calib.hip); relative error ~1e-16
+__device__ __forceinline__ double fast_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double a) {
+    double r = __builtin_amdgcn_rsq(a);
+    r = r * (1.5 - 0.5 * a * r * r);
+    r = r * (1.5 - 0.5 * a * r * r);
+    return r;
+}
+// inverse of the damped 3x3 landmark block, Cholesky based, reciprocal square roots only
+__device__ __forceinline__ bool inv3_spd_fast(const double h[6], const double dmp[3], double Ci[6]) {
+    const double c00 = h[0] + dmp[0], c11 = h[3] + dmp[1], c22 = h[5] + dmp[2];
+    if (!(c00 > 0.0)) return false;
+    const double m00 = fast_rsqrt(c00);
+    const double l10 = h[1] * m00, l20 = h[2] * m00;
+    const double d1 = c11 - l10 * l10;
+    if (!(d1 > 0.0)) return false;
+    const double m11 = fast_rsqrt(d1);
+    const double l21 = (h[4] - l20 * l10) * m11;
+    const double d2 = c22 - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return false;
+    const double m22 = fast_rsqrt(d2);
+    const double m10 = -l10 * m00 * m11;
+    const double m21 = -l21 * m11 * m22;
+    const double m20 = -(l20 * m00 + l21 * m10) * m22;
+    Ci[0] = m00 * m00 + m10 * m10 + m20 * m20;
+    Ci[1] = m10 * m11 + m20 * m21;
+    Ci[2] = m20 * m22;
+    Ci[3] = m11 * m11 + m21 * m21;
+    Ci[4] = m21 * m22;
+    Ci[5] = m22 * m22;
+    return true;
+}
+
+__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_windows(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
-    __shared__ double sWY[SCHUR_BATCH * TW * WY_STRIDE];   // [li][slot][ W(18) | Y(18) ]
-    __shared__ double sGL[SCHUR_BATCH * 4];
+    extern __shared__ __align__(16) double schur_lds[];
+    double *sWY = schur_lds;                                   // [li][slot][ W(18) | Y(18) | pad ]
+    double *sGL = schur_lds + SCHUR_BATCH * TW * WY_STRIDE;    // [li][4]
     const int item = blockIdx.x;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
     const int t = threadIdx.x;
-    const int li = t / TW, s = t - li * TW;           // producer role (t < 120)
-    const int pa = t < NPAIR ? c_pair_a[t] : 0;       // consumer role (t < 78)
-    const int pb = t < NPAIR ? c_pair_b[t] : 0;
+    const bool producer = t < SCHUR_BATCH * TW;
+    const int li = t / TW, s = t - li * TW;
+    const bool consumer = t < NPAIR * SCHUR_SPLIT;
+    const int grp = t / NPAIR, pr = t - grp * NPAIR;          // landmark residue class, pair
+    const int pa = consumer ? c_pair_a[pr] : 0;
+    const int pb = consumer ? c_pair_b[pr] : 0;
     double acc[36], racc[6];
 #pragma unroll
     for (int i = 0; i < 36; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) racc[i] = 0.0;
 
-    uint32_t k = 0xFFFFFFFFu;
     bool pose_ok = false;
     double T[12];
-    if (t < SCHUR_BATCH * TW) {
-        k = d.win_pose[win * TW + s];
+    if (producer) {
+        const uint32_t k = d.win_pose[win * TW + s];
         pose_ok = (k != 0xFFFFFFFFu) && d.pose_free[k] >= 0;
         if (pose_ok) {
 #pragma unroll
@@ -382,7 +428,7 @@ __global__ __launch_bounds__(128) void k_schur_windows(Dev d) {
     }
 
     for (int l0 = lb; l0 < le; l0 += SCHUR_BATCH) {
-        if (t < SCHUR_BATCH * TW) {
+        if (producer) {
             const int l = l0 + li;
             double *dst = sWY + (li * TW + s) * WY_STRIDE;
             bool live = false;
@@ -399,7 +445,7 @@ __global__ __launch_bounds__(128) void k_schur_windows(Dev d) {
 #pragma unroll
                     for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
                     landmark_damping(d, st, l, h, dmp);
-                    if (!inv3_spd(h, dmp, Ci)) {
+                    if (!inv3_spd_fast(h, dmp, Ci)) {
                         d.st->step_failed = 1;
 #pragma unroll
                         for (int c = 0; c < 6; ++c) Ci[c] = 0.0;
@@ -434,14 +480,18 @@ __global__ __launch_bounds__(128) void k_schur_windows(Dev d) {
             }
         }
         __syncthreads();
-        if (t < NPAIR) {
+        if (consumer) {
             const int nb = min(SCHUR_BATCH, le - l0);
-            for (int j = 0; j < nb; ++j) {
-                const double *Y = sWY + (j * TW + pa) * WY_STRIDE + 18;
-                const double *W = sWY + (j * TW + pb) * WY_STRIDE;
+            for (int j = grp; j < nb; j += SCHUR_SPLIT) {
+                const double2 *Y2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pa) * WY_STRIDE + 18);
+                const double2 *W2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pb) * WY_STRIDE);
                 double y[18], w[18];
 #pragma unroll
-                for (int i = 0; i < 18; ++i) { y[i] = Y[i]; w[i] = W[i]; }
+                for (int i = 0; i < 9; ++i) {
+                    const double2 a = Y2[i], b = W2[i];
+                    y[2 * i] = a.x; y[2 * i + 1] = a.y;
+                    w[2 * i] = b.x; w[2 * i + 1] = b.y;
+                }
 #pragma unroll
                 for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -456,14 +506,25 @@ __global__ __launch_bounds__(128) void k_schur_windows(Dev d) {
         }
         __syncthreads();
     }
-    if (t < NPAIR) {
-        double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)t * 36;
+    // combine the three landmark classes in a fixed order: ((g0 + g1) + g2)
+    double *part = schur_lds;    // 2 x 78 x 42 doubles = 52 KB <= staging area
+    if (consumer && grp > 0) {
+        double *o = part + ((grp - 1) * NPAIR + pr) * 42;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) out[i] = acc[i];
+        for (int i = 0; i < 36; ++i) o[i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) o[36 + i] = racc[i];
+    }
+    __syncthreads();
+    if (consumer && grp == 0) {
+        const double *p1 = part + pr * 42, *p2 = part + (NPAIR + pr) * 42;
+        double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)pr * 36;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) out[i] = (acc[i] + p1[i]) + p2[i];
         if (pa == pb) {
             double *ro = d.slab + (size_t)item * SLAB_DOUBLES + NPAIR * 36 + pa * 6;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) ro[a] = racc[a];
+            for (int a = 0; a < 6; ++a) ro[a] = (racc[a] + p1[36 + a]) + p2[36 + a];
         }
     }
 }
@@ -934,6 +995,11 @@ __global__ void k_reset_state(Dev d, Options opt) {
 }
 
 // ----------------------------------------------------------------- launchers ---
+int configure_schur() {
+    return hipFuncSetAttribute((const void *)k_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(SCHUR_LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
+}
+
 void launch_reset(Launcher &L, const Dev &d, const Options &o) {
     hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(64), 0, L.stream, d, o);
 }
@@ -945,7 +1011,7 @@ void launch_linearize(Launcher &L, const Dev &d) {
 }
 
 void launch_schur(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(128), 0, d);
+    LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d);
     hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)d.nfree * 6;
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);

@@ -88,6 +88,7 @@ struct Launcher {
 int upload_pair_table(hipStream_t s);
 int upload_bcr_tables(hipStream_t s);
 int configure_kernels();
+int configure_schur();
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 void launch_linearize(Launcher &L, const Dev &d);
 void launch_schur(Launcher &L, const Dev &d);
