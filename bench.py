@@ -123,9 +123,16 @@ def main():
         raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the stereo-BA path is HIP-only (no CPU fallback)")
+    # one rank per GPU; SSBA_BENCH_BACKEND=gloo + fewer devices than ranks is a rehearsal mode for
+    # boxes with a single GPU (all ranks share cuda:0, collectives staged through the host)
+    backend = os.environ.get("SSBA_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     P1, L1 = synth.CONFIGS[args.config]
     prob = synth.make_problem(P1 * world, L1 * world)
@@ -134,7 +141,7 @@ def main():
     else:
         shard = sharding.whole(prob)
     ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                  prob.stiffness(), device=local_rank)
+                  prob.stiffness(), device=local_rank, world_size=world, rank=rank)
     stream = torch.cuda.current_stream()
     ba.set_stream(stream.cuda_stream)
     if world > 1:

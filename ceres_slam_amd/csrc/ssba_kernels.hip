@@ -394,7 +394,7 @@ __device__ __forceinline__ bool inv3_spd_fast(const double h[6], const double dm
     return true;
 }
 
-__global__ __launch_bounds__(SCHUR_THREADS) void k_schur_windows(Dev d) {
+__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     extern __shared__ __align__(16) double schur_lds[];
@@ -427,52 +427,71 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_windows(Dev d) {
         }
     }
 
+    // Raw inputs of this lane's (landmark, slot) for the NEXT batch are fetched from HBM while the
+    // consumers work on the current one (the loads stay in flight across the barrier and are only
+    // waited for at the top of the next producer phase).
+    struct Raw { double u, v, dd, h[6], sc[3], p[3], g[3]; uint32_t mask; bool in_range; } raw;
+    auto prefetch = [&](int l0) {
+        const int l = l0 + li;
+        raw.in_range = producer && l < le;
+        raw.mask = 0;
+        if (raw.in_range) {
+            raw.mask = d.lm_mask[l];
+            const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+            raw.u = d.ou[oi]; raw.v = d.ov[oi]; raw.dd = d.od[oi];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) raw.h[c] = d.hll[(size_t)c * d.Lpad + l];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                raw.sc[c] = d.sl[(size_t)c * d.Lpad + l];
+                raw.p[c] = d.pts[(size_t)c * d.Lpad + l];
+                raw.g[c] = d.gl[(size_t)c * d.Lpad + l];
+            }
+        }
+    };
+    prefetch(lb);
+
     for (int l0 = lb; l0 < le; l0 += SCHUR_BATCH) {
         if (producer) {
-            const int l = l0 + li;
             double *dst = sWY + (li * TW + s) * WY_STRIDE;
             bool live = false;
-            if (l < le) {
-                const uint32_t mask = d.lm_mask[l];
-                if (s == 0) {
-                    sGL[li * 4 + 0] = d.gl[l];
-                    sGL[li * 4 + 1] = d.gl[(size_t)d.Lpad + l];
-                    sGL[li * 4 + 2] = d.gl[2 * (size_t)d.Lpad + l];
+            if (s == 0) {
+                sGL[li * 4 + 0] = raw.in_range ? raw.g[0] : 0.0;
+                sGL[li * 4 + 1] = raw.in_range ? raw.g[1] : 0.0;
+                sGL[li * 4 + 2] = raw.in_range ? raw.g[2] : 0.0;
+            }
+            if (raw.in_range && pose_ok && ((raw.mask >> s) & 1u)) {
+                live = true;
+                double dmp[3], Ci[6];
+                const double hd[3] = {raw.h[0], raw.h[3], raw.h[5]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
+                    const double s2 = raw.sc[c] * raw.sc[c];
+                    dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(st.radius * s2);
                 }
-                if (pose_ok && ((mask >> s) & 1u)) {
-                    live = true;
-                    double h[6], dmp[3], Ci[6];
+                if (!inv3_spd_fast(raw.h, dmp, Ci)) {
+                    d.st->step_failed = 1;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
-                    landmark_damping(d, st, l, h, dmp);
-                    if (!inv3_spd_fast(h, dmp, Ci)) {
-                        d.st->step_failed = 1;
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) Ci[c] = 0.0;
-                    }
-                    const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
-                    ObsLin o;
-                    obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l],
-                                  d.ou[oi], d.ov[oi], d.od[oi], o);
-                    double Jp[18], Jl[9];
-                    jac_pose(o, Jp);
-                    jac_point(o, T, Jl);
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        double w[3];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c)
-                            w[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
-                        dst[3 * a + 0] = w[0];
-                        dst[3 * a + 1] = w[1];
-                        dst[3 * a + 2] = w[2];
-                        dst[18 + 3 * a + 0] = w[0] * Ci[0] + w[1] * Ci[1] + w[2] * Ci[2];
-                        dst[18 + 3 * a + 1] = w[0] * Ci[1] + w[1] * Ci[3] + w[2] * Ci[4];
-                        dst[18 + 3 * a + 2] = w[0] * Ci[2] + w[1] * Ci[4] + w[2] * Ci[5];
-                    }
+                    for (int c = 0; c < 6; ++c) Ci[c] = 0.0;
                 }
-            } else if (s == 0) {
-                sGL[li * 4 + 0] = 0.0; sGL[li * 4 + 1] = 0.0; sGL[li * 4 + 2] = 0.0;
+                ObsLin o;
+                obs_linearize(d, T, raw.p[0], raw.p[1], raw.p[2], raw.u, raw.v, raw.dd, o);
+                double Jp[18], Jl[9];
+                jac_pose(o, Jp);
+                jac_point(o, T, Jl);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double w[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        w[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
+                    dst[3 * a + 0] = w[0];
+                    dst[3 * a + 1] = w[1];
+                    dst[3 * a + 2] = w[2];
+                    dst[18 + 3 * a + 0] = w[0] * Ci[0] + w[1] * Ci[1] + w[2] * Ci[2];
+                    dst[18 + 3 * a + 1] = w[0] * Ci[1] + w[1] * Ci[3] + w[2] * Ci[4];
+                    dst[18 + 3 * a + 2] = w[0] * Ci[2] + w[1] * Ci[4] + w[2] * Ci[5];
+                }
             }
             if (!live) {
 #pragma unroll
@@ -480,27 +499,43 @@ __global__ __launch_bounds__(SCHUR_THREADS) void k_schur_windows(Dev d) {
             }
         }
         __syncthreads();
+        prefetch(l0 + SCHUR_BATCH);
         if (consumer) {
             const int nb = min(SCHUR_BATCH, le - l0);
             for (int j = grp; j < nb; j += SCHUR_SPLIT) {
                 const double2 *Y2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pa) * WY_STRIDE + 18);
                 const double2 *W2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pb) * WY_STRIDE);
-                double y[18], w[18];
+                double y[18];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
-                    const double2 a = Y2[i], b = W2[i];
-                    y[2 * i] = a.x; y[2 * i + 1] = a.y;
-                    w[2 * i] = b.x; w[2 * i + 1] = b.y;
+                    const double2 av = Y2[i];
+                    y[2 * i] = av.x; y[2 * i + 1] = av.y;
                 }
+                // W in two halves (3 columns of the block each) to keep the register footprint below
+                // the 2-waves-per-SIMD limit; three chained FMAs per output (the compiler does not
+                // re-associate `acc += a*b + c*d + e*f`, which costs a mul and an add per output)
 #pragma unroll
-                for (int a = 0; a < 6; ++a)
+                for (int hc = 0; hc < 2; ++hc) {
+                    double w[10];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c)
-                        acc[6 * a + c] += y[3 * a] * w[3 * c] + y[3 * a + 1] * w[3 * c + 1] + y[3 * a + 2] * w[3 * c + 2];
+                    for (int i = 0; i < 5; ++i) {   // doubles 9*hc-1 .. : read 5 aligned pairs covering w[9*hc .. 9*hc+8]
+                        const double2 bv = W2[(9 * hc) / 2 + i];
+                        w[2 * i] = bv.x; w[2 * i + 1] = bv.y;
+                    }
+                    const int off = (9 * hc) & 1;   // 0 for the first half, 1 for the second (9 is odd)
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int cc = 3 * hc + c;
+                            acc[6 * a + cc] = fma(y[3 * a + 2], w[off + 3 * c + 2],
+                                                  fma(y[3 * a + 1], w[off + 3 * c + 1], fma(y[3 * a], w[off + 3 * c], acc[6 * a + cc])));
+                        }
+                }
                 if (pa == pb) {
                     const double g0 = sGL[j * 4], g1 = sGL[j * 4 + 1], g2 = sGL[j * 4 + 2];
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) racc[a] += y[3 * a] * g0 + y[3 * a + 1] * g1 + y[3 * a + 2] * g2;
+                    for (int a = 0; a < 6; ++a) racc[a] = fma(y[3 * a + 2], g2, fma(y[3 * a + 1], g1, fma(y[3 * a], g0, racc[a])));
                 }
             }
         }
