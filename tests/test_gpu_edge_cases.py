@@ -1,0 +1,117 @@
+"""More GPU parity cases through the C ABI: option variations, block-count edge cases of the
+block-cyclic-reduction solver, full 3x3 stiffness, several constant poses, failure handling."""
+import numpy as np
+import pytest
+
+from ceres_slam_amd import capi, synth
+from ceres_slam_amd.solver import StereoBA
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+DRIVER = dict(max_num_iterations=1000, use_nonmonotonic_steps=1)
+
+
+def _solve_both(prob, gpu_kw=None, orc_kw=None, opts=None, stiffness=None, pose_const=None, huber_a=0.0):
+    S = prob.stiffness() if stiffness is None else stiffness
+    o = dict(DRIVER)
+    o.update(opts or {})
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, S,
+                  pose_const=pose_const, huber_a=huber_a)
+    s, log = ba.solve(capi.default_options(**o))
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, S,
+                           pose_const=pose_const, huber_a=huber_a)
+    s2, log2 = op.solve(orc.default_options(num_threads=2, **o))
+    return ba, s, log, op, s2, log2
+
+
+def _assert_same_solve(ba, s, log, op, s2, log2, pose_tol=1e-6):
+    assert s.termination_type == s2.termination_type
+    assert s.num_iterations == s2.num_iterations
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-8)
+    assert abs(s.final_cost - s2.final_cost) <= 1e-6 * max(s2.final_cost, 1e-300)
+    assert np.abs(ba.poses - op.poses).max() < pose_tol
+
+
+@pytest.mark.parametrize("num_poses", [2, 3, 12, 13, 14, 25, 26, 37, 49, 61, 97, 150])
+def test_bcr_block_count_edges(num_poses):
+    """1, 2, 3, ... super-blocks incl. padded last blocks and odd/even level sizes."""
+    prob = synth.make_problem(num_poses, 40 * num_poses, track_len=12, seed=num_poses)
+    _assert_same_solve(*_solve_both(prob))
+
+
+def test_full_3x3_stiffness_matrix():
+    # the sun driver builds full covariances (tests/dataset_vo_sun.cpp:57-59); the stereo functor
+    # takes any 3x3 stiffness (stereo_reprojection_error.hpp:49-50)
+    prob = synth.make_problem(20, 600, track_len=8, seed=4)
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(3, 3))
+    cov = A @ A.T + 3 * np.eye(3)
+    w, V = np.linalg.eigh(cov)
+    S = V @ np.diag(w ** -0.5) @ V.T
+    _assert_same_solve(*_solve_both(prob, stiffness=S))
+
+
+def test_several_constant_poses_and_nothing_free():
+    prob = synth.make_problem(15, 500, track_len=6, seed=5)
+    const = np.zeros(15, bool)
+    const[[0, 7, 14]] = True
+    ba, s, log, op, s2, log2 = _solve_both(prob, pose_const=const)
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    for k in (0, 7, 14):
+        assert np.array_equal(ba.poses[k], prob.poses_init[k])
+    # all poses constant: pure triangulation refinement, the reduced system is empty
+    ba, s, log, op, s2, log2 = _solve_both(prob, pose_const=np.ones(15, bool))
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    assert np.array_equal(ba.poses, prob.poses_init)
+
+
+@pytest.mark.parametrize("opts", [dict(use_nonmonotonic_steps=0), dict(jacobi_scaling=0), dict(initial_trust_region_radius=1.0),
+                                  dict(max_num_iterations=3), dict(max_num_iterations=0), dict(function_tolerance=1e-12),
+                                  dict(min_relative_decrease=0.5)])
+def test_option_variations(opts):
+    prob = synth.make_problem(16, 500, track_len=8, seed=6)
+    ba, s, log, op, s2, log2 = _solve_both(prob, opts=opts)
+    _assert_same_solve(ba, s, log, op, s2, log2, pose_tol=1e-5)
+    if opts.get("max_num_iterations") == 0:
+        assert s.termination_type == 1 and s.num_iterations == 1      # NO_CONVERGENCE after iteration 0
+        assert np.array_equal(ba.poses, prob.poses_init)
+
+
+def test_huber_medium_scale():
+    prob = synth.make_problem(120, 8000, track_len=12, seed=8, outlier_fraction=0.3)
+    ba, s, log, op, s2, log2 = _solve_both(prob, huber_a=1.345)
+    n = min(len(log["cost"]), len(log2["cost"]), 20)
+    np.testing.assert_allclose(log["cost"][:n], log2["cost"][:n], rtol=1e-8)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)
+
+
+def test_point_behind_camera_gives_rejected_steps_not_garbage():
+    # the reference does not guard z <= 0 (stereo_camera.hpp:79): inf/NaN must end in rejected or
+    # invalid steps / FAILURE, never in a silently accepted non-finite state
+    prob = synth.make_problem(6, 60, track_len=4, seed=9)
+    pts = prob.points_init.copy()
+    pts[3] = prob.points_init[3] * 0 + np.array([0.0, 0.0, -1e3])     # far behind every camera
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), pts, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness())
+    s, log = ba.solve(capi.default_options(max_num_iterations=30, use_nonmonotonic_steps=1))
+    assert np.all(np.isfinite(ba.poses)) and np.all(np.isfinite(ba.points))
+    assert np.all(np.isfinite(log["cost"][log["step_is_successful"] == 1]))
+
+
+def test_handle_reuse_solve_twice_and_set_huber_after_finalize():
+    prob = synth.make_problem(14, 400, track_len=6, seed=10)
+    ba = StereoBA.from_synth(prob)
+    s1, _ = ba.solve(capi.default_options(**DRIVER))
+    # second solve starts from the optimum: converges immediately, parameters barely move
+    before = ba.poses.copy()
+    s2, _ = ba.solve(capi.default_options(**DRIVER))
+    assert s2.num_iterations <= 3 and np.abs(ba.poses - before).max() < 1e-6
+    assert s2.initial_cost == pytest.approx(s1.final_cost, rel=1e-9)
+    # changing the loss on a finalized handle takes effect (and invalidates the captured graph)
+    ba.poses[:] = prob.poses_init
+    ba.points[:] = prob.points_init
+    capi.check(ba.lib.ssba_set_huber_loss(ba.h, 1.345), "ssba_set_huber_loss")
+    s3, _ = ba.solve(capi.default_options(**DRIVER))
+    op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
+    s4, _ = op.solve(orc.driver_options(num_threads=2))
+    assert s3.final_cost == pytest.approx(s4.final_cost, rel=1e-6)
