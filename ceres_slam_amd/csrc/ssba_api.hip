@@ -153,6 +153,8 @@ void ssba_default_options(ssba_options *o) {
     o->function_tolerance = 1e-6;
     o->gradient_tolerance = 1e-10;
     o->parameter_tolerance = 1e-8;
+    o->trust_region_strategy_type = 0;
+    o->reserved = 0;
 }
 
 int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
@@ -551,6 +553,7 @@ int ssba_finalize(ssba_problem *p) {
     d.xv_count = d.off_scal + NSCAL;
     TRY(dzero(p, &d.xv, d.xv_count));
     TRY(dzero(p, &d.x0, (size_t)d.nf_pad * 6));
+    TRY(dzero(p, &d.vp, (size_t)P * 6)); TRY(dzero(p, &d.vl, (size_t)Lpad * 3)); TRY(dzero(p, &d.dl_gn, (size_t)Lpad * 3));
     // BCR level plan
     {
         int n = d.Nsb, lev = 0;
@@ -575,6 +578,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_pose, (size_t)d.n_pose_blocks * 2));
+    TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks) * 4));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));
     TRY(dzero(p, &d.st, (size_t)1));
@@ -641,6 +645,7 @@ static Options to_device_options(const ssba_options *o, int ignore_convergence) 
     d.jacobi_scaling = o->jacobi_scaling;
     d.max_invalid = o->max_num_consecutive_invalid_steps;
     d.ignore_convergence = ignore_convergence;
+    d.strategy = o->trust_region_strategy_type == 1 ? 1 : 0;
     d.initial_radius = o->initial_trust_region_radius;
     d.max_radius = o->max_trust_region_radius;
     d.min_radius = o->min_trust_region_radius;
@@ -702,7 +707,8 @@ static int enqueue_kernels(ssba_problem *p) {
     }
     launch_finish_check(L, d);
     launch_bcr(L, d);
-    launch_update_eval(L, d);
+    if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
+    else launch_update_eval(L, d);
     if (p->xfn) {
         if (p->xfn(p->xctx, d.scal2, NSCAL, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
     }
@@ -729,6 +735,12 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (!p || !o) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
     if (o->max_num_iterations < 0 || !(o->initial_trust_region_radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (o->trust_region_strategy_type != 0 && o->trust_region_strategy_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
+    if (o->trust_region_strategy_type == 1 && p->xfn) {
+        set_error("DOGLEG is not available with landmark sharding yet (its norms need one more exchange point)");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    if (p->gexec && p->opt.trust_region_strategy_type != o->trust_region_strategy_type) drop_graph(p);   // other kernel sequence
     HIPCHECK(hipSetDevice(p->device));
     p->opt = *o;
     p->ignore_convergence = ignore_convergence;

@@ -92,7 +92,7 @@ constexpr int FACT_LDS_DOUBLES = BD * LDA + BD * LDR;
 // the kernel's output), and one coalesced sweep writes G, YL, YU, yr.
 __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int top) {
     State &st = *d.st;
-    if (st.terminated || st.step_failed) return;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *A = lds;                 // BD x LDA
     double *R = lds + BD * LDA;      // BD x LDR : [ L_i (72) | L_{i+1}^T (72) | r_i | pad ]
@@ -337,7 +337,7 @@ __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const do
 // into LDS up front (one global round trip), r' is computed from the staged copies.
 __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
     const State &st = *d.st;
-    if (st.terminated || st.step_failed) return;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sB = lds + BD * BD;
     __shared__ double sya[BD], syb[BD];
@@ -421,7 +421,7 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 constexpr int BS_THREADS = 512;
 __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int top) {
     const State &st = *d.st;
-    if (st.terminated || st.step_failed) return;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
     __shared__ double sv[BD], sxm[BD], sxp[BD];

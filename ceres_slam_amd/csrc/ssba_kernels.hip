@@ -217,6 +217,10 @@ __device__ __forceinline__ bool inv3_spd(const double h[6], const double dmp[3],
     return true;
 }
 
+// radius that scales the LM-type diagonal: the trust-region radius for Levenberg-Marquardt, 1/mu for
+// the regularised Gauss-Newton solve of the dogleg strategy [dogleg_strategy.cc ComputeGaussNewtonStep]
+__device__ __forceinline__ double damp_radius(const State &st) { return st.opt.strategy ? 1.0 / st.mu : st.radius; }
+
 // LM diagonal of a landmark in unscaled coordinates:
 //   D^2 = clamp(s^2 h, min, max) / (radius s^2)   [levenberg_marquardt_strategy.cc on the
 //   Jacobi-scaled Jacobian, mapped back through delta = s .* step]
@@ -227,7 +231,7 @@ __device__ __forceinline__ void landmark_damping(const Dev &d, const State &st, 
     for (int c = 0; c < 3; ++c) {
         const double s = d.sl[(size_t)c * d.Lpad + l];
         const double s2 = s * s;
-        dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (st.radius * s2);
+        dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
     }
 }
 
@@ -396,7 +400,7 @@ __device__ __forceinline__ bool inv3_spd_fast(const double h[6], const double dm
 
 __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
     const State &st = *d.st;
-    if (st.terminated) return;
+    if (st.terminated || st.dl_reuse) return;
     extern __shared__ __align__(16) double schur_lds[];
     double *sWY = schur_lds;                                   // [li][slot][ W(18) | Y(18) | pad ]
     double *sGL = schur_lds + SCHUR_BATCH * TW * WY_STRIDE;    // [li][4]
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
                     const double s2 = raw.sc[c] * raw.sc[c];
-                    dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(st.radius * s2);
+                    dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
                 }
                 if (!inv3_spd_fast(raw.h, dmp, Ci)) {
                     d.st->step_failed = 1;
@@ -573,7 +577,7 @@ __device__ __forceinline__ int tri21(int r, int c) {   // packed upper index, r 
 // S = H_pp - sum slabs (pose damping is added after the exchange, in k_finish_reduced).
 __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
     const State &st = *d.st;
-    if (st.terminated) return;
+    if (st.terminated || st.dl_reuse) return;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n_el = (size_t)d.n_sblk * 36;
     double *D0 = d.xv + d.off_D, *L0 = d.xv + d.off_L;
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
 // on the diagonal, rhs = -reduced gradient, identity rows for the padding.
 __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
     const State &st = *d.st;
-    if (st.terminated) return;
+    if (st.terminated || st.dl_reuse) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.nf_pad * 6) return;
     const int f = i / 6, c = i - f * 6;
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
         const double h = d.xv[d.off_hdiag + i];
         if (st.iteration == 0) d.sp[i] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
         const double s = d.sp[i], s2 = s * s;
-        *Dd += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (st.radius * s2);
+        *Dd += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
         d.xv[d.off_rhs + i] = -d.xv[d.off_rhs + i];
     } else {
         *Dd = 1.0;
@@ -749,7 +753,8 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
             double eps[6], Tn[12];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                eps[c] = d.x0[(size_t)f * 6 + c];
+                eps[c] = st.opt.strategy ? st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c]
+                                         : d.x0[(size_t)f * 6 + c];
                 if (!isfinite(eps[c])) nonfinite = 1.0;
             }
             se3_plus(T, eps, Tn);
@@ -865,6 +870,232 @@ __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
     }
 }
 
+
+// ------------------------------------------------------------------- dogleg ---
+// TRADITIONAL_DOGLEG [Ceres 1.x dogleg_strategy.cc] in unscaled coordinates.  With the Jacobi
+// scale s and D^2 = clamp(s^2 diag(J^T J)):  gradient_ = s g / D,  Gauss-Newton step (D-scaled) =
+// D delta_gn / s,  Cauchy step length alpha = |gradient_|^2 / |J v|^2 with v = s^2 g / D^2, and the
+// step returned to the minimiser is  delta = beta * delta_gn + gamma * v.
+
+// per pose: v_p and the pose parts of |gradient_|^2, |gn|^2, gradient_.gn
+__global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    __shared__ double sm[4];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    double gsq = 0.0, nsq = 0.0, dot = 0.0;
+    if (k < d.P) {
+        const int f = d.pose_free[k];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double v = 0.0;
+            if (f >= 0) {
+                const double s = d.sp[(size_t)f * 6 + c], g = d.xv[d.off_gp + (size_t)f * 6 + c];
+                const double h = d.xv[d.off_hdiag + (size_t)f * 6 + c], gn = d.x0[(size_t)f * 6 + c];
+                const double s2 = s * s, D2 = fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
+                v = s2 * g / D2;
+                gsq += s2 * g * g / D2;
+                nsq += D2 * gn * gn / s2;
+                dot += g * gn;
+            }
+            d.vp[(size_t)k * 6 + c] = v;
+        }
+    }
+    const double a = block_sum(gsq, sm), b = block_sum(nsq, sm), c = block_sum(dot, sm);
+    if (threadIdx.x == 0) {
+        double *o = d.part_dl + (size_t)(d.n_lm_blocks + blockIdx.x) * 4;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = 0.0;
+    }
+}
+
+// per landmark: Gauss-Newton back-substitution delta_l = -C^-1 (g_l + sum W^T delta_p), v_l, the
+// landmark parts of the norms, and |J v|^2 over the landmark's observations
+__global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double gsq = 0.0, nsq = 0.0, dot = 0.0, jv2 = 0.0;
+    double dl[3] = {0, 0, 0}, vl[3] = {0, 0, 0};
+    if (mask && !st.step_failed) {
+        const uint32_t win = d.lm_win[l];
+        const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const double gl[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
+        double tt[3] = {gl[0], gl[1], gl[2]};
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            if (f < 0) continue;
+            const double *T = d.poses + (size_t)k * 12;
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            double Jp[18], Jl[9], jd[3];
+            jac_pose(o, Jp);
+            jac_point(o, T, Jl);
+            const double *dp = d.x0 + (size_t)f * 6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                jd[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tt[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+        }
+        double h[6], dmp[3], Ci[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
+        landmark_damping(d, st, l, h, dmp);
+        if (inv3_spd(h, dmp, Ci)) {
+            dl[0] = -(Ci[0] * tt[0] + Ci[1] * tt[1] + Ci[2] * tt[2]);
+            dl[1] = -(Ci[1] * tt[0] + Ci[3] * tt[1] + Ci[4] * tt[2]);
+            dl[2] = -(Ci[2] * tt[0] + Ci[4] * tt[1] + Ci[5] * tt[2]);
+        } else {
+            d.st->step_failed = 1;
+        }
+        const double hd[3] = {h[0], h[3], h[5]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double s = d.sl[(size_t)c * d.Lpad + l], s2 = s * s;
+            const double D2 = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
+            vl[c] = s2 * gl[c] / D2;
+            gsq += s2 * gl[c] * gl[c] / D2;
+            nsq += D2 * dl[c] * dl[c] / s2;
+            dot += gl[c] * dl[c];
+        }
+        for (int s = 0; s < TW; ++s) {   // |J v|^2
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            const double *T = d.poses + (size_t)k * 12;
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            double Jl[9], jv[3];
+            jac_point(o, T, Jl);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) jv[i] = Jl[3 * i] * vl[0] + Jl[3 * i + 1] * vl[1] + Jl[3 * i + 2] * vl[2];
+            if (f >= 0) {
+                double Jp[18];
+                jac_pose(o, Jp);
+                const double *vp = d.vp + (size_t)k * 6;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) jv[i] += Jp[6 * i + c] * vp[c];
+            }
+            jv2 += jv[0] * jv[0] + jv[1] * jv[1] + jv[2] * jv[2];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d.dl_gn[(size_t)c * d.Lpad + l] = dl[c];
+        d.vl[(size_t)c * d.Lpad + l] = vl[c];
+    }
+    const double a = block_sum(gsq, sm), b = block_sum(nsq, sm), c = block_sum(dot, sm), e = block_sum(jv2, sm);
+    if (threadIdx.x == 0) {
+        double *o = d.part_dl + (size_t)blockIdx.x * 4;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+    }
+}
+
+// ComputeTraditionalDoglegStep: beta, gamma, |step| from the norms and the current radius (1 block)
+__global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
+    if (!st.dl_reuse) {
+        for (int i = threadIdx.x; i < d.n_lm_blocks + d.n_pose_blocks; i += 256) {
+            a += d.part_dl[(size_t)i * 4]; b += d.part_dl[(size_t)i * 4 + 1];
+            c += d.part_dl[(size_t)i * 4 + 2]; e += d.part_dl[(size_t)i * 4 + 3];
+        }
+    }
+    a = block_sum(a, sm); b = block_sum(b, sm); c = block_sum(c, sm); e = block_sum(e, sm);
+    if (threadIdx.x != 0) return;
+    if (!st.dl_reuse) {
+        st.grad_norm = sqrt(a); st.gn_norm = sqrt(b); st.g_dot_gn = c;
+        st.alpha = a / e;             // ComputeCauchyPoint
+        st.dl_reuse = 1;              // reuse_ = true until the next accepted / invalid step
+    }
+    const double r = st.radius;
+    if (st.gn_norm <= r) {                              // Gauss-Newton step inside the region
+        st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
+    } else if (st.grad_norm * st.alpha >= r) {          // Cauchy point outside: scaled steepest descent
+        st.beta = 0.0; st.gamma = -r / st.grad_norm; st.dl_step_norm = r;
+    } else {                                            // on the dogleg
+        const double b_dot_a = -st.alpha * st.g_dot_gn;
+        const double a_sq = (st.alpha * st.grad_norm) * (st.alpha * st.grad_norm);
+        const double bma = a_sq - 2.0 * b_dot_a + st.gn_norm * st.gn_norm;
+        const double cc = b_dot_a - a_sq;
+        const double dd = sqrt(cc * cc + bma * (r * r - a_sq));
+        const double bt = (cc <= 0.0) ? (dd - cc) / bma : (r * r - a_sq) / (dd + cc);
+        st.beta = bt; st.gamma = -st.alpha * (1.0 - bt);
+        st.dl_step_norm = sqrt(st.gamma * st.gamma * st.grad_norm * st.grad_norm + 2.0 * st.gamma * st.beta * st.g_dot_gn +
+                               st.beta * st.beta * st.gn_norm * st.gn_norm);
+    }
+}
+
+// per landmark: delta_l = beta * gn + gamma * v, candidate point, model cost change, candidate cost
+__global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
+    const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+    double nx = px, ny = py, nz = pz;
+    if (mask && !st.step_failed) {
+        const uint32_t win = d.lm_win[l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        double dl[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dl[c] = st.beta * d.dl_gn[(size_t)c * d.Lpad + l] + st.gamma * d.vl[(size_t)c * d.Lpad + l];
+        if (!isfinite(dl[0]) || !isfinite(dl[1]) || !isfinite(dl[2])) nonfinite = 1.0;
+        nx = px + dl[0]; ny = py + dl[1]; nz = pz + dl[2];
+        dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            const double *T = d.poses + (size_t)k * 12;
+            const double u = d.ou[obase + s * LMG], v = d.ov[obase + s * LMG], dd = d.od[obase + s * LMG];
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, u, v, dd, o);
+            double Jl[9], jd[3];
+            jac_point(o, T, Jl);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) jd[i] = Jl[3 * i] * dl[0] + Jl[3 * i + 1] * dl[1] + Jl[3 * i + 2] * dl[2];
+            if (f >= 0) {
+                double Jp[18];
+                jac_pose(o, Jp);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const double dpc = st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) jd[i] += Jp[6 * i + c] * dpc;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) mcc -= jd[i] * (o.r[i] + 0.5 * jd[i]);
+            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, u, v, dd);
+        }
+    }
+    d.cand_pts[l] = nx;
+    d.cand_pts[(size_t)d.Lpad + l] = ny;
+    d.cand_pts[2 * (size_t)d.Lpad + l] = nz;
+    const double a = block_sum(ccost, sm), b = block_sum(mcc, sm), c = block_sum(dn, sm), e = block_sum(nonfinite, sm);
+    if (threadIdx.x == 0) {
+        d.part_eval[blockIdx.x * 4 + 0] = a;
+        d.part_eval[blockIdx.x * 4 + 1] = b;
+        d.part_eval[blockIdx.x * 4 + 2] = c;
+        d.part_eval[blockIdx.x * 4 + 3] = e;
+    }
+}
+
 // Sums the per-block partials of the linearisation into the exchange scalars
 // scal[0] = cost, scal[1] = |x_points|^2 and gmax_l (fixed order, one block).
 __global__ __launch_bounds__(256) void k_reduce_lin(Dev d) {
@@ -940,8 +1171,12 @@ __global__ __launch_bounds__(256) void k_decide(Dev d) {
         if (++st.num_invalid >= o.max_invalid && !o.ignore_convergence) {
             st.terminated = 1; st.termination_type = 2;   // FAILURE
         }
-        st.radius /= st.decrease_factor;
-        st.decrease_factor *= 2.0;
+        if (o.strategy) {            // DoglegStrategy::StepIsInvalid
+            st.mu *= 10.0; st.dl_reuse = 0;
+        } else {
+            st.radius /= st.decrease_factor;
+            st.decrease_factor *= 2.0;
+        }
         ++st.num_unsuccessful;
         log_push(d, st, st.x_cost, 0.0, 0.0, 0.0, 0);
         return;
@@ -972,11 +1207,19 @@ __global__ __launch_bounds__(256) void k_decide(Dev d) {
         st.last_successful = 1;
         st.need_linearize = 1;
         ++st.num_successful;
-        // LevenbergMarquardtStrategy::StepAccepted
-        const double tq = 2.0 * rd - 1.0;
-        st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
-        st.radius = fmin(o.max_radius, st.radius);
-        st.decrease_factor = 2.0;
+        if (o.strategy) {
+            // DoglegStrategy::StepAccepted
+            if (rd < 0.25) st.radius *= 0.5;
+            if (rd > 0.75) st.radius = fmax(st.radius, 3.0 * st.dl_step_norm);
+            st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+            st.dl_reuse = 0;
+        } else {
+            // LevenbergMarquardtStrategy::StepAccepted
+            const double tq = 2.0 * rd - 1.0;
+            st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
+            st.radius = fmin(o.max_radius, st.radius);
+            st.decrease_factor = 2.0;
+        }
         // TrustRegionStepEvaluator::StepAccepted
         st.se_current = candidate_cost;
         st.se_acc_cand += mcc;
@@ -998,9 +1241,13 @@ __global__ __launch_bounds__(256) void k_decide(Dev d) {
             st.se_acc_ref = st.se_acc_cand;
         }
     } else {
-        // HandleUnsuccessfulStep: LevenbergMarquardtStrategy::StepRejected
-        st.radius /= st.decrease_factor;
-        st.decrease_factor *= 2.0;
+        // HandleUnsuccessfulStep: StepRejected
+        if (o.strategy) {
+            st.radius *= 0.5; st.dl_reuse = 1;
+        } else {
+            st.radius /= st.decrease_factor;
+            st.decrease_factor *= 2.0;
+        }
         ++st.num_unsuccessful;
         log_push(d, st, candidate_cost, st.cost_change, step_norm, rd, 0);
     }
@@ -1027,6 +1274,8 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.x_cost = 0.0; st.x_norm = 0.0; st.gmax = 0.0; st.minimum_cost = 0.0;
     st.candidate_cost = 0.0; st.model_cost_change = 0.0; st.step_norm = 0.0;
     st.relative_decrease = 0.0; st.cost_change = 0.0; st.initial_cost = 0.0;
+    st.dl_reuse = 0; st.mu = 1e-8; st.alpha = 0.0; st.dl_step_norm = 0.0; st.grad_norm = 0.0; st.gn_norm = 0.0;
+    st.g_dot_gn = 0.0; st.beta = 1.0; st.gamma = 0.0;
 }
 
 // ----------------------------------------------------------------- launchers ---
@@ -1063,6 +1312,15 @@ void launch_finish_check(Launcher &L, const Dev &d) {
 void launch_update_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
+}
+
+void launch_dogleg_eval(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks), dim3(256), 0, d);
+    LAUNCH(KC_DOGLEG, k_dogleg_gn, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
+    LAUNCH(KC_DOGLEG, k_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
 }
 

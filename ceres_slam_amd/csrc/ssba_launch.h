@@ -17,6 +17,7 @@ enum KernelClass {
     KC_BCR_REDUCE,
     KC_BCR_BACKSUB,
     KC_BACKSUB_EVAL,
+    KC_DOGLEG,
     KC_COPY,
     KC_SMALL,
     KC_COUNT
@@ -24,7 +25,7 @@ enum KernelClass {
 
 static const char *const kKernelClassName[KC_COUNT] = {
     "k_linearize_landmarks", "k_linearize_poses", "k_schur_windows", "k_assemble_reduced",
-    "k_bcr_factor", "k_bcr_reduce", "k_bcr_backsub", "k_backsub_eval", "copy(k_best,k_commit)",
+    "k_bcr_factor", "k_bcr_reduce", "k_bcr_backsub", "k_backsub_eval", "k_dogleg_gn+k_dogleg_eval", "copy(k_best,k_commit)",
     "small(control,reductions)"};
 
 // Stream + optional per-kernel-class HIP-event timing (events are recorded on the
@@ -95,6 +96,7 @@ void launch_schur(Launcher &L, const Dev &d);
 void launch_finish_check(Launcher &L, const Dev &d);
 void launch_bcr(Launcher &L, const Dev &d);
 void launch_update_eval(Launcher &L, const Dev &d);
+void launch_dogleg_eval(Launcher &L, const Dev &d);
 void launch_decide_commit(Launcher &L, const Dev &d);
 
 }  // namespace ssba

@@ -32,7 +32,7 @@ constexpr int MAX_LEVELS = 24;
 constexpr int NSCAL = 16;
 
 struct Options {   // device copy of ssba_options
-    int max_num_iterations, max_nonmono, jacobi_scaling, max_invalid, ignore_convergence;
+    int max_num_iterations, max_nonmono, jacobi_scaling, max_invalid, ignore_convergence, strategy;
     double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diag,
         max_lm_diag, function_tolerance, gradient_tolerance, parameter_tolerance;
 };
@@ -56,8 +56,10 @@ struct State {
     // TrustRegionStepEvaluator
     double se_minimum, se_current, se_reference, se_candidate, se_acc_ref, se_acc_cand;
     int se_num_nonmono;
-    int pad0;
+    int dl_reuse;             // dogleg: Gauss-Newton step and gradient of this point are still valid
     double initial_cost;
+    // DoglegStrategy [Ceres dogleg_strategy.cc]
+    double mu, alpha, dl_step_norm, grad_norm, gn_norm, g_dot_gn, beta, gamma;
 };
 
 struct IterLog {   // device arrays, capacity entries
@@ -106,7 +108,9 @@ struct Dev {
     // reduced system (exchange vector) and solution
     double *xv;                      // [D0 | L0 | rhs | gpx | hdiag | scal]
     uint64_t off_D, off_L, off_rhs, off_gp, off_hdiag, off_scal, xv_count;
-    double *x0;                      // nf_pad*6 pose step
+    double *x0;                      // nf_pad*6 pose step (LM step / dogleg Gauss-Newton step)
+    double *vp, *vl, *dl_gn;         // dogleg: s^2 g / D^2 of poses (P*6) and landmarks (3*Lpad), GN landmark step
+    double *part_dl;                 // dogleg partial sums: n_lm_blocks*4 + n_pose_blocks*4
     int n_levels;
     BcrLevel lev[MAX_LEVELS];
     // reductions

@@ -77,6 +77,12 @@ typedef struct {
     double function_tolerance;                  /* 1e-6                                */
     double gradient_tolerance;                  /* 1e-10                               */
     double parameter_tolerance;                 /* 1e-8                                */
+    int32_t trust_region_strategy_type;         /* 0 = LEVENBERG_MARQUARDT (Ceres default, what
+                                                   tests/dataset_vo.cpp runs); 1 = DOGLEG with
+                                                   TRADITIONAL_DOGLEG (tests/dataset_ba_phong.cpp:85
+                                                   selects DOGLEG; its SUBSPACE_DOGLEG variant is not
+                                                   implemented)                                   */
+    int32_t reserved;
 } ssba_options;
 
 /* ceres::TerminationType values the path can produce */

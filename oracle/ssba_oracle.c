@@ -224,6 +224,8 @@ void orc_default_options(orc_options *o) {
     o->function_tolerance = 1e-6;
     o->gradient_tolerance = 1e-10;
     o->parameter_tolerance = 1e-8;
+    o->trust_region_strategy_type = 0;
+    o->reserved = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -712,6 +714,105 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
     return 0;
 }
 
+/* -(J d)^T (r + J d / 2) for an arbitrary step (dp: P*6, dl: L*3), and |J d|^2 */
+static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w, const double *dp,
+                          const double *dl, double *mcc_out, double *jd_sq_out) {
+    double mcc = 0.0, sq = 0.0;
+#pragma omp parallel for reduction(+ : mcc, sq) schedule(static)
+    for (int64_t i = 0; i < g->N; ++i) {
+        const double *a = w->Jp + 18 * i, *b = w->Jl + 9 * i, *r = w->r + 3 * i;
+        const double *d6 = dp + 6 * (size_t)p->obs_pose[i], *d3 = dl + 3 * (size_t)p->obs_point[i];
+        for (int m = 0; m < 3; ++m) {
+            double jd = b[3 * m] * d3[0] + b[3 * m + 1] * d3[1] + b[3 * m + 2] * d3[2];
+            if (g->free_idx[p->obs_pose[i]] >= 0)
+                for (int c = 0; c < 6; ++c) jd += a[6 * m + c] * d6[c];
+            mcc -= jd * (r[m] + 0.5 * jd);
+            sq += jd * jd;
+        }
+    }
+    if (mcc_out) *mcc_out = mcc;
+    if (jd_sq_out) *jd_sq_out = sq;
+}
+
+/* [Ceres 1.x dogleg_strategy.cc, TRADITIONAL_DOGLEG] state kept between iterations */
+typedef struct {
+    double radius, mu, alpha, dogleg_step_norm, gradient_norm, gn_norm, g_dot_gn;
+    int reuse;
+    double *gn_p, *gn_l;   /* Gauss-Newton step, unscaled (P*6, L*3)                     */
+    double *v_p, *v_l;     /* s^2 g / D^2: the unscaled image of the scaled gradient / D */
+} dogleg_t;
+
+/* One dogleg step.  In Ceres the strategy sees the Jacobi-scaled Jacobian J_s = J diag(s):
+ *   D^2 = clamp(diag(J_s^T J_s)), gradient_ = J_s^T r ./ D, alpha = |gradient_|^2 / |J_s (gradient_ ./ D)|^2,
+ *   Gauss-Newton: (J_s^T J_s + mu D^2) y = J_s^T r, gauss_newton_step_ = -D .* y,
+ *   step = interpolation in the D-scaled space, ./ D, then .* s by the minimiser.
+ * In unscaled coordinates: delta = beta * delta_gn + gamma * v with v = s^2 g / D^2. */
+static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, const double *sp,
+                       const double *sl, const orc_options *o, dogleg_t *dg, double *dp, double *dl,
+                       double *mcc, double *t_schur, double *t_solve) {
+    const int nf = g->nfree, L = g->L;
+    if (!dg->reuse) {
+        dg->reuse = 1;
+        /* Gauss-Newton step with the regulariser mu * D^2: same damped system as LM with 1/radius = mu */
+        double mcc_gn;
+        if (lm_step(p, g, w, sp, sl, 1.0 / dg->mu, o, dg->gn_p, dg->gn_l, &mcc_gn, t_schur, t_solve)) return -1;
+        double gsq = 0.0, nsq = 0.0, dot = 0.0;
+        memset(dg->v_p, 0, (size_t)g->P * 6 * sizeof(double));
+        for (int f = 0; f < nf; ++f)
+            for (int c = 0; c < 6; ++c) {
+                const int k = g->free_pose[f];
+                const double s = sp[6 * f + c], gq = w->g_p[6 * f + c], gn = dg->gn_p[6 * k + c];
+                const double D2 = fmin(fmax(w->sq_p[6 * f + c] * s * s, o->min_lm_diagonal), o->max_lm_diagonal);
+                gsq += s * s * gq * gq / D2;
+                nsq += D2 * gn * gn / (s * s);
+                dot += gq * gn;
+                dg->v_p[6 * k + c] = s * s * gq / D2;
+            }
+        for (int j = 0; j < L; ++j)
+            for (int c = 0; c < 3; ++c) {
+                const double s = sl[3 * j + c], gq = w->g_l[3 * j + c], gn = dg->gn_l[3 * j + c];
+                const double D2 = fmin(fmax(w->sq_l[3 * j + c] * s * s, o->min_lm_diagonal), o->max_lm_diagonal);
+                if (!g->pt_active[j]) { dg->v_l[3 * j + c] = 0.0; continue; }
+                gsq += s * s * gq * gq / D2;
+                nsq += D2 * gn * gn / (s * s);
+                dot += gq * gn;
+                dg->v_l[3 * j + c] = s * s * gq / D2;
+            }
+        double jv_sq;
+        step_products(p, g, w, dg->v_p, dg->v_l, NULL, &jv_sq);
+        dg->gradient_norm = sqrt(gsq);
+        dg->gn_norm = sqrt(nsq);
+        dg->g_dot_gn = dot;           /* gradient_ . gauss_newton_step_ */
+        dg->alpha = gsq / jv_sq;      /* ComputeCauchyPoint */
+    }
+    /* ComputeTraditionalDoglegStep */
+    double beta, gamma;
+    const double r = dg->radius;
+    if (dg->gn_norm <= r) {                               /* case 1: GN step inside the region */
+        beta = 1.0; gamma = 0.0;
+        dg->dogleg_step_norm = dg->gn_norm;
+    } else if (dg->gradient_norm * dg->alpha >= r) {      /* case 2: Cauchy point outside */
+        beta = 0.0; gamma = -r / dg->gradient_norm;
+        dg->dogleg_step_norm = r;
+    } else {                                              /* case 3: on the dogleg */
+        const double b_dot_a = -dg->alpha * dg->g_dot_gn;
+        const double a_sq = pow(dg->alpha * dg->gradient_norm, 2.0);
+        const double bma_sq = a_sq - 2.0 * b_dot_a + pow(dg->gn_norm, 2.0);
+        const double cc = b_dot_a - a_sq;
+        const double dd = sqrt(cc * cc + bma_sq * (r * r - a_sq));
+        const double bt = (cc <= 0.0) ? (dd - cc) / bma_sq : (r * r - a_sq) / (dd + cc);
+        beta = bt; gamma = -dg->alpha * (1.0 - bt);
+        /* |step|^2 in the D-scaled space */
+        const double a = gamma, b = beta;
+        dg->dogleg_step_norm = sqrt(a * a * dg->gradient_norm * dg->gradient_norm + 2.0 * a * b * dg->g_dot_gn +
+                                    b * b * dg->gn_norm * dg->gn_norm);
+    }
+    for (int i = 0; i < g->P * 6; ++i) dp[i] = beta * dg->gn_p[i] + gamma * dg->v_p[i];
+    for (int i = 0; i < L * 3; ++i) dl[i] = beta * dg->gn_l[i] + gamma * dg->v_l[i];
+    step_products(p, g, w, dp, dl, mcc, NULL);
+    return 0;
+}
+
 int orc_lm_step(const orc_problem *p, double radius, const orc_options *o, double *delta_p,
                 double *delta_l, double *model_cost_change) {
     set_threads(o->num_threads);
@@ -901,6 +1002,14 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     } while (0)
     GRADIENT_MAX_NORM();
     double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
+    const int dogleg = o->trust_region_strategy_type == 1;
+    dogleg_t dg;
+    memset(&dg, 0, sizeof dg);
+    dg.radius = radius; dg.mu = 1e-8;      /* DoglegStrategy: mu_ = min_mu_ = 1e-8, max 1.0, factor 10 */
+    if (dogleg) {
+        dg.gn_p = calloc(szP * 6, sizeof(double)); dg.gn_l = calloc(szL * 3, sizeof(double));
+        dg.v_p = calloc(szP * 6, sizeof(double)); dg.v_l = calloc(szL * 3, sizeof(double));
+    }
     step_eval_t se;
     se_init(&se, x_cost, o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0);
     int iteration = 0, num_invalid = 0;
@@ -926,7 +1035,8 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
 
         /* ---- ComputeTrustRegionStep ---- */
         double mcc = 0.0;
-        int rc = lm_step(p, &g, &w, sp, sl, radius, o, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s);
+        int rc = dogleg ? dogleg_step(p, &g, &w, sp, sl, o, &dg, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s)
+                        : lm_step(p, &g, &w, sp, sl, radius, o, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s);
         int step_is_valid = (rc == 0) && (mcc > 0.0);
         if (!step_is_valid) {
             /* HandleInvalidStep */
@@ -936,8 +1046,12 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
                 ++s->num_unsuccessful_steps;
                 break;
             }
-            radius /= decrease_factor;  /* strategy_->StepIsInvalid() == StepRejected */
-            decrease_factor *= 2.0;
+            if (dogleg) {               /* DoglegStrategy::StepIsInvalid */
+                dg.mu *= 10.0; dg.reuse = 0;
+            } else {
+                radius /= decrease_factor;  /* LM: StepIsInvalid() == StepRejected */
+                decrease_factor *= 2.0;
+            }
             log_push(log, s, x_cost, 0.0, gmax, 0.0, 0.0, radius, 0);
             ++s->num_unsuccessful_steps;
             continue;
@@ -975,18 +1089,31 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
             s->linearize_time_s += now_s() - t0;
             x_cost = w.cost;
             GRADIENT_MAX_NORM();
-            /* LevenbergMarquardtStrategy::StepAccepted */
-            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rd - 1.0, 3));
-            radius = fmin(o->max_trust_region_radius, radius);
-            decrease_factor = 2.0;
+            if (dogleg) {
+                /* DoglegStrategy::StepAccepted */
+                if (rd < 0.25) dg.radius *= 0.5;
+                if (rd > 0.75) dg.radius = fmax(dg.radius, 3.0 * dg.dogleg_step_norm);
+                dg.mu = fmax(1e-8, 2.0 * dg.mu / 10.0);
+                dg.reuse = 0;
+                radius = dg.radius;
+            } else {
+                /* LevenbergMarquardtStrategy::StepAccepted */
+                radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rd - 1.0, 3));
+                radius = fmin(o->max_trust_region_radius, radius);
+                decrease_factor = 2.0;
+            }
             se_accepted(&se, candidate_cost, mcc);
             last_successful = 1;
             ++s->num_successful_steps;
             log_push(log, s, x_cost, cost_change, gmax, step_norm, rd, radius, 1);
         } else {
             /* HandleUnsuccessfulStep: StepRejected */
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
+            if (dogleg) {
+                dg.radius *= 0.5; dg.reuse = 1; radius = dg.radius;
+            } else {
+                radius /= decrease_factor;
+                decrease_factor *= 2.0;
+            }
             ++s->num_unsuccessful_steps;
             log_push(log, s, candidate_cost, cost_change, gmax, step_norm, rd, radius, 0);
         }
@@ -1009,6 +1136,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     }
     free(x_pose); free(x_pt); free(c_pose); free(c_pt); free(best_pose); free(best_pt);
     free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl);
+    free(dg.gn_p); free(dg.gn_l); free(dg.v_p); free(dg.v_l);
     lin_free(&w);
     graph_free(&g);
     s->total_time_s = now_s() - t_start;

@@ -77,6 +77,9 @@ typedef struct {
     double function_tolerance;                 /* 1e-6                            */
     double gradient_tolerance;                 /* 1e-10                           */
     double parameter_tolerance;                /* 1e-8                            */
+    int32_t trust_region_strategy_type;        /* 0 = LEVENBERG_MARQUARDT (default), 1 = DOGLEG
+                                                  (TRADITIONAL_DOGLEG; tests/dataset_ba_phong.cpp:85) */
+    int32_t reserved;
 } orc_options;
 
 enum { ORC_CONVERGENCE = 0, ORC_NO_CONVERGENCE = 1, ORC_FAILURE = 2 };

@@ -309,3 +309,102 @@ def intensity_jacobian_complex_step(light_type, T, p, n, phong, kd, light, colou
         J[16 + k] = f(light=(light + e) if light_type == 0 else unit_vector_plus(light, e))
     J[15] = f(kd=kd + 1j * h)
     return J
+
+
+# ---- traditional dogleg [Ceres 1.x dogleg_strategy.cc], written directly in the Jacobi-scaled
+# ---- space the way Ceres does (the C oracle works in unscaled coordinates)
+def dogleg_solve(ba: "NumpyBA", max_iter=1000, nonmonotonic=True, f_tol=1e-6, p_tol=1e-8, min_rd=1e-3,
+                 min_diag=1e-6, max_diag=1e32):
+    x_p, x_l = ba.poses.copy(), ba.points.copy()
+    radius, mu, reuse = 1e4, 1e-8, False
+    scale = None
+    max_nm = 5 if nonmonotonic else 0
+    x_cost, _ = ba.residuals(x_p, x_l)
+    minimum = current = reference = candidate = x_cost
+    acc_ref = acc_cand = 0.0
+    n_nm = 0
+    log = [(x_cost, False)]
+    nf, L = ba.nf, x_l.shape[0]
+    keep = np.concatenate([np.ones(6 * nf, bool), np.repeat(ba.active, 3)])
+    xs = np.concatenate([x_p[ba.free].ravel(), x_l[ba.active].ravel()])
+    x_norm = np.linalg.norm(xs)
+    state = {}
+    for it in range(1, max_iter + 1):
+        if not reuse:
+            reuse = True
+            cost, r, Jp, Jl = ba.residuals(x_p, x_l, jac=True)
+            J = ba.sparse_jacobian(Jp, Jl)[:, keep]
+            if scale is None:
+                scale = 1.0 / (1.0 + np.sqrt(np.asarray(J.multiply(J).sum(0)).ravel()))
+            Js = J @ sp.diags(scale)
+            rv = r.reshape(-1)
+            D = np.sqrt(np.clip(np.asarray(Js.multiply(Js).sum(0)).ravel(), min_diag, max_diag))
+            grad = (Js.T @ rv) / D                                   # ComputeGradient
+            Jg = Js @ (grad / D)
+            alpha = (grad @ grad) / (Jg @ Jg)                        # ComputeCauchyPoint
+            H = (Js.T @ Js + sp.diags(mu * D * D)).tocsc()           # ComputeGaussNewtonStep
+            gn = -D * spla.spsolve(H, Js.T @ rv)
+            state = dict(Js=Js, rv=rv, D=D, grad=grad, alpha=alpha, gn=gn)
+        D, grad, alpha, gn, Js, rv = (state[k] for k in ("D", "grad", "alpha", "gn", "Js", "rv"))
+        gnorm, nnorm = np.linalg.norm(grad), np.linalg.norm(gn)
+        if nnorm <= radius:
+            step = gn.copy()
+        elif gnorm * alpha >= radius:
+            step = -(radius / gnorm) * grad
+        else:
+            b_dot_a = -alpha * (grad @ gn)
+            a_sq = (alpha * gnorm) ** 2
+            bma = a_sq - 2 * b_dot_a + nnorm ** 2
+            c = b_dot_a - a_sq
+            d = np.sqrt(c * c + bma * (radius ** 2 - a_sq))
+            beta = (d - c) / bma if c <= 0 else (radius ** 2 - a_sq) / (d + c)
+            step = (-alpha * (1 - beta)) * grad + beta * gn
+        step_norm_scaled = np.linalg.norm(step)
+        step_js = step / D
+        model = Js @ step_js
+        mcc = -model @ (rv + 0.5 * model)
+        if not (mcc > 0):
+            mu *= 10.0
+            reuse = False
+            log.append((x_cost, False))
+            continue
+        delta = np.zeros(6 * nf + 3 * L)
+        delta[keep] = step_js * scale
+        dp = np.zeros((x_p.shape[0], 6))
+        dp[ba.free] = delta[: 6 * nf].reshape(nf, 6)
+        dl = delta[6 * nf:].reshape(L, 3)
+        c_p, c_l = ba.plus(x_p, x_l, dp, dl)
+        c_cost, _ = ba.residuals(c_p, c_l)
+        stepn = np.sqrt(((c_p[ba.free] - x_p[ba.free]) ** 2).sum() + ((c_l[ba.active] - x_l[ba.active]) ** 2).sum())
+        if stepn <= p_tol * (x_norm + p_tol):
+            break
+        if abs(x_cost - c_cost) <= f_tol * x_cost:
+            break
+        rd = max((current - c_cost) / mcc, (reference - c_cost) / (acc_ref + mcc))
+        if rd > min_rd:
+            x_p, x_l, x_cost = c_p, c_l, c_cost
+            xs = np.concatenate([x_p[ba.free].ravel(), x_l[ba.active].ravel()])
+            x_norm = np.linalg.norm(xs)
+            if rd < 0.25:
+                radius *= 0.5
+            if rd > 0.75:
+                radius = max(radius, 3.0 * step_norm_scaled)
+            mu = max(1e-8, 2.0 * mu / 10.0)
+            reuse = False
+            current = c_cost
+            acc_cand += mcc
+            acc_ref += mcc
+            if current < minimum:
+                minimum, n_nm, candidate, acc_cand = current, 0, current, 0.0
+            else:
+                n_nm += 1
+                if current > candidate:
+                    candidate, acc_cand = current, 0.0
+            if n_nm == max_nm:
+                reference, acc_ref = candidate, acc_cand
+            log.append((x_cost, True))
+        else:
+            radius *= 0.5
+            reuse = True
+            log.append((c_cost, False))
+    return x_p, x_l, log

@@ -115,3 +115,16 @@ def test_handle_reuse_solve_twice_and_set_huber_after_finalize():
     op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
     s4, _ = op.solve(orc.driver_options(num_threads=2))
     assert s3.final_cost == pytest.approx(s4.final_cost, rel=1e-6)
+
+
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+@pytest.mark.parametrize("size", [(16, 500, 8), (50, 2000, 12)])
+def test_dogleg_strategy_matches_oracle(size, huber_a):
+    """trust_region_strategy_type = DOGLEG (TRADITIONAL_DOGLEG)."""
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=12)
+    ba, s, log, op, s2, log2 = _solve_both(prob, opts=dict(trust_region_strategy_type=1), huber_a=huber_a)
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    np.testing.assert_allclose(log["trust_region_radius"], log2["trust_region_radius"], rtol=1e-6)
+    # and it reaches the Levenberg-Marquardt minimum in fewer iterations
+    ba_lm, s_lm, *_ = _solve_both(prob, huber_a=huber_a)
+    assert s.final_cost == pytest.approx(s_lm.final_cost, rel=1e-4)

@@ -147,3 +147,29 @@ def test_empty_and_degenerate_inputs():
     s, log = op.solve()
     assert s.final_cost < 1e-12 * max(s.initial_cost, 1.0)
     np.testing.assert_allclose(op.points[0], [0.3, -0.2, 9.0], atol=1e-6)
+
+
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+def test_dogleg_strategy_matches_independent_scaled_space_loop(tiny_problem, huber_a):
+    """TRADITIONAL_DOGLEG.  The oracle works in unscaled coordinates, the numpy
+    loop in Ceres's Jacobi-scaled space with a sparse direct Gauss-Newton solve."""
+    prob = tiny_problem
+    op = orc.OracleProblem.from_synth(prob, huber_a=huber_a)
+    s, log = op.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1))
+    ref = _np_ba(prob, huber_a)
+    x_p, x_l, rlog = npr.dogleg_solve(ref)
+    assert s.termination_type == 0
+    assert len(rlog) == s.num_iterations
+    np.testing.assert_allclose(log["cost"], [c for c, _ in rlog], rtol=1e-8)
+    assert log["step_is_successful"].tolist() == [int(ok) for _, ok in rlog]
+    np.testing.assert_allclose(op.poses, x_p, atol=1e-7)
+
+
+def test_dogleg_and_lm_reach_the_same_minimum(c1_problem):
+    a = orc.OracleProblem.from_synth(c1_problem)
+    b = orc.OracleProblem.from_synth(c1_problem)
+    sa, _ = a.solve(orc.driver_options(num_threads=4))
+    sb, lb = b.solve(orc.driver_options(num_threads=4, trust_region_strategy_type=1))
+    assert sb.termination_type == 0 and sb.num_iterations < sa.num_iterations
+    assert sb.final_cost == pytest.approx(sa.final_cost, rel=1e-5)
+    assert np.abs(a.poses - b.poses).max() < 1e-3
