@@ -280,3 +280,93 @@ def read_pose_csv(path: str) -> np.ndarray:
     rows = [l for l in open(path).read().splitlines()[1:] if l.strip()]
     T = np.array([[float(x) for x in r.split(",")] for r in rows]).reshape(-1, 4, 4)
     return pose_pack(T[:, :3, 3], T[:, :3, :3])
+
+
+# ------------------------------------------------------------- Phong lighting ---
+@dataclass
+class PhongData:
+    """Lighting side of a config-3 problem (dataset_problem_phong.hpp:34-81 data model)."""
+    normals_gt: np.ndarray         # (L,3) unit
+    normals_init: np.ndarray       # (L,3) unit
+    material_of_point: np.ndarray  # (L,) uint32
+    phong: np.ndarray              # (M,3) ka, ks, alpha
+    texture: np.ndarray            # (M,)  kd
+    light: np.ndarray              # (3,) position (light_type 0) or direction (1), global frame
+    light_type: int
+    intensity: np.ndarray          # (N,) observed intensities
+    normal_obs: np.ndarray         # (N,3) observed normals, camera frame
+    int_var: float
+    normal_obs_var: np.ndarray     # (3,)
+
+    @property
+    def int_stiffness(self) -> float:
+        return 1.0 / np.sqrt(self.int_var)                       # tests/dataset_ba_phong.cpp:44
+
+    def normal_stiffness(self) -> np.ndarray:
+        return np.diag(1.0 / np.sqrt(self.normal_obs_var))       # tests/dataset_ba_phong.cpp:39-42
+
+    def as_oracle_dict(self) -> dict:
+        return dict(normals=self.normals_init, intensity=self.intensity, normal_obs=self.normal_obs, phong=self.phong,
+                    texture=self.texture, material_of_point=self.material_of_point, light=self.light,
+                    light_type=self.light_type, int_stiffness=self.int_stiffness, normal_stiffness=self.normal_stiffness())
+
+
+def _shade(n_c, ell, cd, kd, ks, alpha):
+    """lighting/phong.hpp:25-51 vectorised (ambient = 0, guards, clamp)."""
+    ldn = (ell * n_c).sum(1)
+    diffuse = np.where(ldn > 0, kd * ldn, 0.0)
+    mt = 2 * ldn[:, None] * n_c - ell
+    mu = np.linalg.norm(mt, axis=1)
+    m = mt / np.where(mu > 0, mu, 1.0)[:, None]
+    s = (m * cd).sum(1)
+    spec = np.where((mu > 0) & (s > 0), ks * np.power(np.where(s > 0, s, 1.0), alpha), 0.0)
+    return np.clip(diffuse + spec, 0.0, 1.0)
+
+
+def make_phong_problem(num_poses: int, num_points: int, *, num_materials: int = 4, light_type: int = 0,
+                       int_var: float = 1e-4, normal_var: float = 1e-4, seed: int = 42, **kw):
+    """Config 3: the stereo problem of `make_problem` plus unit normals, one
+    light, `num_materials` Phong materials (ks in [0,0.5], alpha in [1,20]) with textures kd in
+    [0.2,0.9], intensities from the Phong model + N(0, int_var) and normal observations + N(0, var).
+    Returns (StereoBAProblem, PhongData)."""
+    prob = make_problem(num_poses, num_points, seed=seed, **kw)
+    rng = np.random.Generator(np.random.PCG64(seed + 1000003))
+    P, L = prob.num_poses, prob.num_points
+    t_gt, R_gt = pose_unpack(prob.poses_gt)
+    centers = -np.einsum("kji,kj->ki", R_gt, t_gt)
+    anchor = (np.arange(L, dtype=np.int64) * P) // L
+    if light_type == 0:
+        light = centers.mean(0) + np.array([0.0, -25.0, 0.0])          # above the loop (y points down)
+        to_l = light[None] - prob.points_gt
+    else:
+        light = np.array([0.3, -0.8, 0.52])
+        light /= np.linalg.norm(light)
+        to_l = np.tile(light, (L, 1))
+    to_c = centers[anchor] - prob.points_gt
+    bis = to_c / np.linalg.norm(to_c, axis=1)[:, None] + to_l / np.linalg.norm(to_l, axis=1)[:, None]
+    n = bis / np.linalg.norm(bis, axis=1)[:, None] + 0.25 * rng.standard_normal((L, 3))
+    normals_gt = n / np.linalg.norm(n, axis=1)[:, None]
+    mat = rng.integers(0, num_materials, L).astype(np.uint32)
+    phong = np.stack([np.zeros(num_materials), rng.uniform(0.0, 0.5, num_materials), rng.uniform(1.0, 20.0, num_materials)], 1)
+    texture = rng.uniform(0.2, 0.9, num_materials)
+    k, j = prob.obs_pose.astype(np.int64), prob.obs_point.astype(np.int64)
+    q = np.einsum("nij,nj->ni", R_gt[k], prob.points_gt[j]) + t_gt[k]
+    n_c = np.einsum("nij,nj->ni", R_gt[k], normals_gt[j])
+    if light_type == 0:
+        l_c = np.einsum("nij,j->ni", R_gt[k], light) + t_gt[k]
+        v = l_c - q
+    else:
+        v = np.einsum("nij,j->ni", R_gt[k], light)
+    ell = v / np.linalg.norm(v, axis=1)[:, None]
+    cd = -q / np.linalg.norm(q, axis=1)[:, None]
+    inten = _shade(n_c, ell, cd, texture[mat[j]], phong[mat[j], 1], phong[mat[j], 2])
+    intensity = inten + rng.standard_normal(inten.shape) * np.sqrt(int_var)
+    normal_obs = n_c + rng.standard_normal(n_c.shape) * np.sqrt(normal_var)
+    # initial normals: first observation mapped through the initial pose of that state, normalised
+    t_i, R_i = pose_unpack(prob.poses_init)
+    normals_init = normals_gt.copy()
+    jj, idx = np.unique(j, return_index=True)
+    n0 = np.einsum("nji,nj->ni", R_i[k[idx]], normal_obs[idx])
+    normals_init[jj] = n0 / np.linalg.norm(n0, axis=1)[:, None]
+    return prob, PhongData(normals_gt, normals_init, mat, phong, texture, light, light_type, intensity, normal_obs,
+                           int_var, np.full(3, normal_var))

@@ -29,7 +29,10 @@ class Problem(C.Structure):
     _fields_ = [("cam", Camera), ("num_poses", C.c_int32), ("num_points", C.c_int32),
                 ("num_obs", C.c_int64), ("poses", _dp), ("points", _dp),
                 ("obs_pose", _u32p), ("obs_point", _u32p), ("obs_uvd", _dp),
-                ("stiffness", C.c_double * 9), ("pose_const", _u8p), ("huber_a", C.c_double)]
+                ("stiffness", C.c_double * 9), ("pose_const", _u8p), ("huber_a", C.c_double),
+                ("normals", _dp), ("intensity", _dp), ("normal_obs", _dp), ("phong", _dp), ("texture", _dp),
+                ("material_of_point", _u32p), ("light", C.c_double * 3), ("light_type", C.c_int32),
+                ("reserved", C.c_int32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9)]
 
 
 class Options(C.Structure):
@@ -121,7 +124,7 @@ class OracleProblem:
     """Owns numpy copies of a problem and the ctypes view the C oracle reads."""
 
     def __init__(self, camera: dict, poses, points, obs_pose, obs_point, obs_uvd, stiffness,
-                 pose_const=None, huber_a: float = 0.0):
+                 pose_const=None, huber_a: float = 0.0, lighting=None):
         self.poses = np.ascontiguousarray(poses, dtype=np.float64).copy()
         self.points = np.ascontiguousarray(points, dtype=np.float64).copy()
         self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
@@ -144,6 +147,21 @@ class OracleProblem:
         self.c.stiffness = (C.c_double * 9)(*np.asarray(stiffness, dtype=np.float64).reshape(9))
         self.c.pose_const = self.pose_const.ctypes.data_as(_u8p)
         self.c.huber_a = float(huber_a)
+        self.ld = 3
+        self.normals = None
+        if lighting is not None:       # dict: normals, intensity, normal_obs, phong, texture, material_of_point, light, light_type, int_stiffness, normal_stiffness
+            self.ld = 6
+            self.normals = np.ascontiguousarray(lighting["normals"], dtype=np.float64).copy()
+            self._lt = {k: np.ascontiguousarray(lighting[k], dtype=np.float64) for k in ("intensity", "normal_obs", "phong", "texture")}
+            self._mat = np.ascontiguousarray(lighting["material_of_point"], dtype=np.uint32)
+            self.c.normals = _p(self.normals)
+            self.c.intensity, self.c.normal_obs = _p(self._lt["intensity"]), _p(self._lt["normal_obs"])
+            self.c.phong, self.c.texture = _p(self._lt["phong"]), _p(self._lt["texture"])
+            self.c.material_of_point = self._mat.ctypes.data_as(_u32p)
+            self.c.light = (C.c_double * 3)(*np.asarray(lighting["light"], dtype=np.float64))
+            self.c.light_type = int(lighting["light_type"])
+            self.c.int_stiffness = float(lighting["int_stiffness"])
+            self.c.normal_stiffness = (C.c_double * 9)(*np.asarray(lighting["normal_stiffness"], dtype=np.float64).reshape(9))
 
     @classmethod
     def from_synth(cls, prob, huber_a: float = 0.0, pose_const=None):
@@ -155,9 +173,9 @@ class OracleProblem:
         return lib().orc_cost(C.byref(self.c), num_threads)
 
     def linearize(self, num_threads: int = 1):
-        P, L = self.c.num_poses, self.c.num_points
-        g_p, g_l = np.zeros((P, 6)), np.zeros((L, 3))
-        H_pp, H_ll = np.zeros((P, 6, 6)), np.zeros((L, 3, 3))
+        P, L, ld = self.c.num_poses, self.c.num_points, self.ld
+        g_p, g_l = np.zeros((P, 6)), np.zeros((L, ld))
+        H_pp, H_ll = np.zeros((P, 6, 6)), np.zeros((L, ld, ld))
         cost = lib().orc_linearize(C.byref(self.c), _p(g_p), _p(g_l), _p(H_pp), _p(H_ll), num_threads)
         return cost, g_p, g_l, H_pp, H_ll
 
@@ -176,7 +194,7 @@ class OracleProblem:
 
     def lm_step(self, radius: float, options: Options = None):
         o = options or default_options()
-        dp, dl = np.zeros((self.c.num_poses, 6)), np.zeros((self.c.num_points, 3))
+        dp, dl = np.zeros((self.c.num_poses, 6)), np.zeros((self.c.num_points, self.ld))
         mcc = C.c_double(0.0)
         rc = lib().orc_lm_step(C.byref(self.c), radius, C.byref(o), _p(dp), _p(dl), C.byref(mcc))
         if rc:

@@ -231,6 +231,16 @@ void orc_default_options(orc_options *o) {
 /* ------------------------------------------------------------------------ */
 /* evaluation                                                                 */
 /* ------------------------------------------------------------------------ */
+/* Two problem shapes share the code below:
+ *   stereo only (tests/dataset_vo.cpp):            NR = 3 residuals per observation, LD = 3
+ *   stereo + Phong lighting (dataset_ba_phong.cpp): NR = 7 (stereo 3 | intensity 1 | normal 3),
+ *     landmark block LD = 6 = [position | normal], the normal through UnitVectorPerturbation;
+ *     the shared light / material / texture blocks are held constant in this build.
+ * Residual-block order inside an observation follows the driver: stereo, intensity, normal. */
+
+static int is_phong(const orc_problem *p) { return p->intensity != NULL; }
+static int dim_nr(const orc_problem *p) { return is_phong(p) ? 7 : 3; }
+static int dim_ld(const orc_problem *p) { return is_phong(p) ? 6 : 3; }
 
 static void set_threads(int n) {
 #ifdef _OPENMP
@@ -240,33 +250,65 @@ static void set_threads(int n) {
 #endif
 }
 
-/* Evaluate all residual blocks.  r (N*3), Jp (N*18), Jl (N*9) may be NULL.
+/* Evaluate all residual blocks.  r (N*NR), Jp (N*NR*6), Jl (N*NR*LD) may be NULL.
  * Returns cost = 1/2 sum rho(|r|^2); r/J are the loss-CORRECTED quantities, as
  * Ceres's ResidualBlock::Evaluate hands them to the minimiser. */
 static double evaluate(const orc_problem *p, const double *poses, const double *points,
-                       double *r_out, double *Jp_out, double *Jl_out) {
+                       const double *normals, double *r_out, double *Jp_out, double *Jl_out) {
     const int64_t N = p->num_obs;
+    const int nr = dim_nr(p), ld = dim_ld(p), ph = is_phong(p);
     double cost = 0.0;
 #pragma omp parallel for reduction(+ : cost) schedule(static)
     for (int64_t i = 0; i < N; ++i) {
-        double r[3], Jp[18], Jl[9];
-        int wantJ = (Jp_out != NULL);
-        orc_stereo_residual(&p->cam, poses + 12 * (int64_t)p->obs_pose[i],
-                            points + 3 * (int64_t)p->obs_point[i], p->obs_uvd + 3 * i,
-                            p->stiffness, r, wantJ ? Jp : NULL, wantJ ? Jl : NULL);
-        double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        double r[7], Jp[42], Jl[42];
+        const int wantJ = (Jp_out != NULL);
+        const double *T = poses + 12 * (int64_t)p->obs_pose[i];
+        const int64_t j = (int64_t)p->obs_point[i];
+        double r3[3], Jp3[18], Jl3[9];
+        orc_stereo_residual(&p->cam, T, points + 3 * j, p->obs_uvd + 3 * i, p->stiffness, r3,
+                            wantJ ? Jp3 : NULL, wantJ ? Jl3 : NULL);
+        double sq = r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2];
         if (p->huber_a > 0.0) {
             double rho[3];
             orc_huber(p->huber_a, sq, rho);
             cost += 0.5 * rho[0];
-            corrector(rho, sq, r, wantJ ? Jp : NULL, wantJ ? Jl : NULL);
+            corrector(rho, sq, r3, wantJ ? Jp3 : NULL, wantJ ? Jl3 : NULL);
         } else {
             cost += 0.5 * sq;
         }
-        if (r_out) memcpy(r_out + 3 * i, r, sizeof r);
+        memcpy(r, r3, sizeof r3);
         if (wantJ) {
-            memcpy(Jp_out + 18 * i, Jp, sizeof Jp);
-            memcpy(Jl_out + 9 * i, Jl, sizeof Jl);
+            memset(Jp, 0, sizeof Jp);
+            memset(Jl, 0, sizeof Jl);
+            for (int m = 0; m < 3; ++m) {
+                for (int c = 0; c < 6; ++c) Jp[6 * m + c] = Jp3[6 * m + c];
+                for (int c = 0; c < 3; ++c) Jl[ld * m + c] = Jl3[3 * m + c];
+            }
+        }
+        if (ph) {
+            const uint32_t mat = p->material_of_point[j];
+            double ri, J19[19], rn[3], Jnp[18], Jnn[9];
+            orc_intensity_residual(p->light_type, T, points + 3 * j, normals + 3 * j, p->phong + 3 * mat,
+                                   p->texture[mat], p->light, p->intensity[i], p->int_stiffness, &ri,
+                                   wantJ ? J19 : NULL);
+            orc_normal_residual(T, normals + 3 * j, p->normal_obs + 3 * i, p->normal_stiffness, rn,
+                                wantJ ? Jnp : NULL, wantJ ? Jnn : NULL);
+            r[3] = ri;
+            r[4] = rn[0]; r[5] = rn[1]; r[6] = rn[2];
+            cost += 0.5 * (ri * ri + rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2]);
+            if (wantJ) {
+                for (int c = 0; c < 6; ++c) Jp[6 * 3 + c] = J19[c];
+                for (int c = 0; c < 6; ++c) Jl[6 * 3 + c] = J19[6 + c];      /* [point 3 | normal 3] */
+                for (int m = 0; m < 3; ++m) {
+                    for (int c = 0; c < 6; ++c) Jp[6 * (4 + m) + c] = Jnp[6 * m + c];
+                    for (int c = 0; c < 3; ++c) Jl[6 * (4 + m) + 3 + c] = Jnn[3 * m + c];
+                }
+            }
+        }
+        if (r_out) memcpy(r_out + nr * i, r, (size_t)nr * sizeof(double));
+        if (wantJ) {
+            memcpy(Jp_out + (size_t)nr * 6 * i, Jp, (size_t)nr * 6 * sizeof(double));
+            memcpy(Jl_out + (size_t)nr * ld * i, Jl, (size_t)nr * ld * sizeof(double));
         }
     }
     return cost;
@@ -274,7 +316,7 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
 
 double orc_cost(const orc_problem *p, int num_threads) {
     set_threads(num_threads);
-    return evaluate(p, p->poses, p->points, NULL, NULL, NULL);
+    return evaluate(p, p->poses, p->points, p->normals, NULL, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -282,7 +324,7 @@ double orc_cost(const orc_problem *p, int num_threads) {
 /* ------------------------------------------------------------------------ */
 
 typedef struct {
-    int P, L, nfree;
+    int P, L, nfree, nr, ld;
     int64_t N;
     int *free_idx;       /* P: index among free poses or -1 (constant / unobserved) */
     int *free_pose;      /* nfree -> pose id                                      */
@@ -304,6 +346,7 @@ static void graph_build(const orc_problem *p, graph_t *g) {
     int P = p->num_poses, L = p->num_points;
     int64_t N = p->num_obs;
     g->P = P; g->L = L; g->N = N;
+    g->nr = dim_nr(p); g->ld = dim_ld(p);
     g->pose_start = calloc((size_t)P + 1, sizeof(int64_t));
     g->pt_start = calloc((size_t)L + 1, sizeof(int64_t));
     g->pose_obs = malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
@@ -314,7 +357,7 @@ static void graph_build(const orc_problem *p, graph_t *g) {
     }
     for (int k = 0; k < P; ++k) g->pose_start[k + 1] += g->pose_start[k];
     for (int j = 0; j < L; ++j) g->pt_start[j + 1] += g->pt_start[j];
-    int64_t *pc = malloc((size_t)P * sizeof(int64_t)), *lc = malloc((size_t)L * sizeof(int64_t));
+    int64_t *pc = malloc((size_t)(P > 0 ? P : 1) * sizeof(int64_t)), *lc = malloc((size_t)(L > 0 ? L : 1) * sizeof(int64_t));
     memcpy(pc, g->pose_start, (size_t)P * sizeof(int64_t));
     memcpy(lc, g->pt_start, (size_t)L * sizeof(int64_t));
     for (int64_t i = 0; i < N; ++i) { /* stable: keeps the reference's file order */
@@ -322,7 +365,7 @@ static void graph_build(const orc_problem *p, graph_t *g) {
         g->pt_obs[lc[p->obs_point[i]]++] = i;
     }
     free(pc); free(lc);
-    g->free_idx = malloc((size_t)P * sizeof(int));
+    g->free_idx = malloc((size_t)(P > 0 ? P : 1) * sizeof(int));
     g->free_pose = malloc((size_t)(P > 0 ? P : 1) * sizeof(int));
     g->pt_active = malloc((size_t)(L > 0 ? L : 1));
     int nf = 0;
@@ -352,32 +395,35 @@ static void graph_build(const orc_problem *p, graph_t *g) {
 /* small dense helpers                                                        */
 /* ------------------------------------------------------------------------ */
 
-/* inverse of a 3x3 SPD matrix through its Cholesky factor
+/* inverse of an n x n (n <= 6) SPD matrix through its Cholesky factor
  * [Ceres: InvertPSDMatrix -> LLT solve for fixed-size blocks] */
-static int inv3_spd(const double C[9], double Ci[9]) {
-    double l00 = C[0];
-    if (!(l00 > 0.0)) return -1;
-    l00 = sqrt(l00);
-    double l10 = C[3] / l00, l20 = C[6] / l00;
-    double d1 = C[4] - l10 * l10;
-    if (!(d1 > 0.0)) return -1;
-    double l11 = sqrt(d1);
-    double l21 = (C[7] - l20 * l10) / l11;
-    double d2 = C[8] - l20 * l20 - l21 * l21;
-    if (!(d2 > 0.0)) return -1;
-    double l22 = sqrt(d2);
-    /* M = L^-1 (lower) */
-    double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
-    double m10 = -l10 * m00 * m11;
-    double m21 = -l21 * m11 * m22;
-    double m20 = -(l20 * m00 + l21 * m10) * m22;
-    /* C^-1 = M^T M */
-    Ci[0] = m00 * m00 + m10 * m10 + m20 * m20;
-    Ci[1] = Ci[3] = m10 * m11 + m20 * m21;
-    Ci[2] = Ci[6] = m20 * m22;
-    Ci[4] = m11 * m11 + m21 * m21;
-    Ci[5] = Ci[7] = m21 * m22;
-    Ci[8] = m22 * m22;
+static int inv_spd(int n, const double *C, double *Ci) {
+    double Lm[36] = {0}, M[36] = {0};
+    for (int j = 0; j < n; ++j) {
+        double d = C[n * j + j];
+        for (int k = 0; k < j; ++k) d -= Lm[n * j + k] * Lm[n * j + k];
+        if (!(d > 0.0) || !isfinite(d)) return -1;
+        Lm[n * j + j] = sqrt(d);
+        for (int i = j + 1; i < n; ++i) {
+            double s = C[n * i + j];
+            for (int k = 0; k < j; ++k) s -= Lm[n * i + k] * Lm[n * j + k];
+            Lm[n * i + j] = s / Lm[n * j + j];
+        }
+    }
+    for (int j = 0; j < n; ++j) {   /* M = L^-1 */
+        M[n * j + j] = 1.0 / Lm[n * j + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s -= Lm[n * i + k] * M[n * k + j];
+            M[n * i + j] = s / Lm[n * i + i];
+        }
+    }
+    for (int a = 0; a < n; ++a)     /* C^-1 = M^T M */
+        for (int b = 0; b < n; ++b) {
+            double s = 0.0;
+            for (int k = (a > b ? a : b); k < n; ++k) s += M[n * k + a] * M[n * k + b];
+            Ci[n * a + b] = s;
+        }
     return 0;
 }
 
@@ -429,26 +475,26 @@ static void band_solve(const double *A, int n, int bw, double *x) {
 /* ------------------------------------------------------------------------ */
 
 typedef struct {
-    double *r;       /* N*3  corrected residuals                     */
-    double *Jp;      /* N*18 corrected, unscaled                     */
-    double *Jl;      /* N*9                                          */
-    double *g_p;     /* nfree*6 unscaled gradient J^T r              */
-    double *g_l;     /* L*3                                          */
-    double *sq_p;    /* nfree*6 squared column norms of unscaled J   */
-    double *sq_l;    /* L*3                                          */
+    double *r;       /* N*NR     corrected residuals                 */
+    double *Jp;      /* N*NR*6   corrected, unscaled                 */
+    double *Jl;      /* N*NR*LD                                      */
+    double *g_p;     /* nfree*6  unscaled gradient J^T r             */
+    double *g_l;     /* L*LD                                         */
+    double *sq_p;    /* nfree*6  squared column norms of unscaled J  */
+    double *sq_l;    /* L*LD                                         */
     double cost;
 } lin_t;
 
 static void lin_alloc(lin_t *w, const graph_t *g) {
     size_t N = (size_t)(g->N > 0 ? g->N : 1), nf = (size_t)(g->nfree > 0 ? g->nfree : 1),
            L = (size_t)(g->L > 0 ? g->L : 1);
-    w->r = malloc(N * 3 * sizeof(double));
-    w->Jp = malloc(N * 18 * sizeof(double));
-    w->Jl = malloc(N * 9 * sizeof(double));
+    w->r = malloc(N * g->nr * sizeof(double));
+    w->Jp = malloc(N * g->nr * 6 * sizeof(double));
+    w->Jl = malloc(N * g->nr * g->ld * sizeof(double));
     w->g_p = malloc(nf * 6 * sizeof(double));
-    w->g_l = malloc(L * 3 * sizeof(double));
+    w->g_l = malloc(L * g->ld * sizeof(double));
     w->sq_p = malloc(nf * 6 * sizeof(double));
-    w->sq_l = malloc(L * 3 * sizeof(double));
+    w->sq_l = malloc(L * g->ld * sizeof(double));
 }
 static void lin_free(lin_t *w) {
     free(w->r); free(w->Jp); free(w->Jl); free(w->g_p); free(w->g_l); free(w->sq_p); free(w->sq_l);
@@ -456,36 +502,39 @@ static void lin_free(lin_t *w) {
 
 /* [Ceres evaluator: residuals, cost, Jacobian, gradient = J^T r at x] */
 static void linearize(const orc_problem *p, const graph_t *g, const double *poses,
-                      const double *points, lin_t *w) {
-    w->cost = evaluate(p, poses, points, w->r, w->Jp, w->Jl);
+                      const double *points, const double *normals, lin_t *w) {
+    const int nr = g->nr, ld = g->ld;
+    w->cost = evaluate(p, poses, points, normals, w->r, w->Jp, w->Jl);
 #pragma omp parallel for schedule(static)
     for (int f = 0; f < g->nfree; ++f) {
         int k = g->free_pose[f];
         double gp[6] = {0}, sq[6] = {0};
         for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
             int64_t i = g->pose_obs[e];
-            const double *J = w->Jp + 18 * i, *r = w->r + 3 * i;
-            for (int c = 0; c < 6; ++c) {
-                gp[c] += J[c] * r[0] + J[6 + c] * r[1] + J[12 + c] * r[2];
-                sq[c] += J[c] * J[c] + J[6 + c] * J[6 + c] + J[12 + c] * J[12 + c];
-            }
+            const double *J = w->Jp + (size_t)nr * 6 * i, *r = w->r + (size_t)nr * i;
+            for (int m = 0; m < nr; ++m)
+                for (int c = 0; c < 6; ++c) {
+                    gp[c] += J[6 * m + c] * r[m];
+                    sq[c] += J[6 * m + c] * J[6 * m + c];
+                }
         }
         memcpy(w->g_p + 6 * f, gp, sizeof gp);
         memcpy(w->sq_p + 6 * f, sq, sizeof sq);
     }
 #pragma omp parallel for schedule(static)
     for (int j = 0; j < g->L; ++j) {
-        double gl[3] = {0}, sq[3] = {0};
+        double gl[6] = {0}, sq[6] = {0};
         for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
             int64_t i = g->pt_obs[e];
-            const double *J = w->Jl + 9 * i, *r = w->r + 3 * i;
-            for (int c = 0; c < 3; ++c) {
-                gl[c] += J[c] * r[0] + J[3 + c] * r[1] + J[6 + c] * r[2];
-                sq[c] += J[c] * J[c] + J[3 + c] * J[3 + c] + J[6 + c] * J[6 + c];
-            }
+            const double *J = w->Jl + (size_t)nr * ld * i, *r = w->r + (size_t)nr * i;
+            for (int m = 0; m < nr; ++m)
+                for (int c = 0; c < ld; ++c) {
+                    gl[c] += J[ld * m + c] * r[m];
+                    sq[c] += J[ld * m + c] * J[ld * m + c];
+                }
         }
-        memcpy(w->g_l + 3 * j, gl, sizeof gl);
-        memcpy(w->sq_l + 3 * j, sq, sizeof sq);
+        memcpy(w->g_l + (size_t)ld * j, gl, (size_t)ld * sizeof(double));
+        memcpy(w->sq_l + (size_t)ld * j, sq, (size_t)ld * sizeof(double));
     }
 }
 
@@ -493,27 +542,28 @@ double orc_linearize(const orc_problem *p, double *g_p, double *g_l, double *H_p
                      double *H_ll, int num_threads) {
     set_threads(num_threads);
     const int64_t N = p->num_obs;
+    const int nr = dim_nr(p), ld = dim_ld(p);
     size_t n = (size_t)(N > 0 ? N : 1);
-    double *r = malloc(n * 3 * sizeof(double)), *Jp = malloc(n * 18 * sizeof(double)),
-           *Jl = malloc(n * 9 * sizeof(double));
-    double cost = evaluate(p, p->poses, p->points, r, Jp, Jl);
+    double *r = malloc(n * nr * sizeof(double)), *Jp = malloc(n * nr * 6 * sizeof(double)),
+           *Jl = malloc(n * nr * ld * sizeof(double));
+    double cost = evaluate(p, p->poses, p->points, p->normals, r, Jp, Jl);
     memset(g_p, 0, (size_t)p->num_poses * 6 * sizeof(double));
-    memset(g_l, 0, (size_t)p->num_points * 3 * sizeof(double));
+    memset(g_l, 0, (size_t)p->num_points * ld * sizeof(double));
     memset(H_pp, 0, (size_t)p->num_poses * 36 * sizeof(double));
-    memset(H_ll, 0, (size_t)p->num_points * 9 * sizeof(double));
+    memset(H_ll, 0, (size_t)p->num_points * ld * ld * sizeof(double));
     for (int64_t i = 0; i < N; ++i) { /* serial, reference residual-block order */
-        const double *a = Jp + 18 * i, *b = Jl + 9 * i, *ri = r + 3 * i;
-        double *gp = g_p + 6 * (size_t)p->obs_pose[i], *gl = g_l + 3 * (size_t)p->obs_point[i];
-        double *hp = H_pp + 36 * (size_t)p->obs_pose[i], *hl = H_ll + 9 * (size_t)p->obs_point[i];
-        for (int c = 0; c < 6; ++c) {
-            gp[c] += a[c] * ri[0] + a[6 + c] * ri[1] + a[12 + c] * ri[2];
-            for (int d = 0; d < 6; ++d)
-                hp[6 * c + d] += a[c] * a[d] + a[6 + c] * a[6 + d] + a[12 + c] * a[12 + d];
-        }
-        for (int c = 0; c < 3; ++c) {
-            gl[c] += b[c] * ri[0] + b[3 + c] * ri[1] + b[6 + c] * ri[2];
-            for (int d = 0; d < 3; ++d)
-                hl[3 * c + d] += b[c] * b[d] + b[3 + c] * b[3 + d] + b[6 + c] * b[6 + d];
+        const double *a = Jp + (size_t)nr * 6 * i, *b = Jl + (size_t)nr * ld * i, *ri = r + (size_t)nr * i;
+        double *gp = g_p + 6 * (size_t)p->obs_pose[i], *gl = g_l + (size_t)ld * p->obs_point[i];
+        double *hp = H_pp + 36 * (size_t)p->obs_pose[i], *hl = H_ll + (size_t)ld * ld * p->obs_point[i];
+        for (int m = 0; m < nr; ++m) {
+            for (int c = 0; c < 6; ++c) {
+                gp[c] += a[6 * m + c] * ri[m];
+                for (int d = 0; d < 6; ++d) hp[6 * c + d] += a[6 * m + c] * a[6 * m + d];
+            }
+            for (int c = 0; c < ld; ++c) {
+                gl[c] += b[ld * m + c] * ri[m];
+                for (int d = 0; d < ld; ++d) hl[ld * c + d] += b[ld * m + c] * b[ld * m + d];
+            }
         }
     }
     free(r); free(Jp); free(Jl);
@@ -524,15 +574,15 @@ double orc_linearize(const orc_problem *p, double *g_p, double *g_l, double *H_p
  *   scale = 1 / (1 + sqrt(squared column norm)) computed once at iteration 0 */
 static void jacobi_scale(const graph_t *g, const lin_t *w, int enabled, double *sp, double *sl) {
     for (int i = 0; i < g->nfree * 6; ++i) sp[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_p[i])) : 1.0;
-    for (int i = 0; i < g->L * 3; ++i) sl[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_l[i])) : 1.0;
+    for (int i = 0; i < g->L * g->ld; ++i) sl[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_l[i])) : 1.0;
 }
 
 typedef struct {
     double *S;    /* band storage n x (bw+1)                               */
     double *rhs;  /* n                                                     */
-    double *Ci;   /* L*9   inverse of damped landmark blocks (scaled)       */
-    double *W;    /* N*18  Jp_s^T Jl_s (6x3)                                */
-    double *gl_s; /* L*3   scaled landmark gradient                         */
+    double *Ci;   /* L*LD*LD inverse of damped landmark blocks (scaled)     */
+    double *W;    /* N*6*LD  Jp_s^T Jl_s                                    */
+    double *gl_s; /* L*LD    scaled landmark gradient                       */
     int n, bw;
     double t_schur, t_solve;
 } schur_t;
@@ -543,53 +593,56 @@ typedef struct {
 static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
                          const double *sp, const double *sl, double radius,
                          const orc_options *o, schur_t *sc) {
-    const int nf = g->nfree, L = g->L;
+    const int nf = g->nfree, L = g->L, nr = g->nr, ld = g->ld;
     const int n = 6 * nf;
     int bw = 6 * (g->bw_poses + 1) - 1;
     if (bw > n - 1) bw = n - 1;
     if (bw < 0) bw = 0;
     sc->n = n; sc->bw = bw;
-    const int ld = bw + 1;
-    sc->S = calloc((size_t)(n > 0 ? n : 1) * ld, sizeof(double));
+    const int lds = bw + 1;
+    sc->S = calloc((size_t)(n > 0 ? n : 1) * lds, sizeof(double));
     sc->rhs = calloc((size_t)(n > 0 ? n : 1), sizeof(double));
-    sc->Ci = malloc((size_t)(L > 0 ? L : 1) * 9 * sizeof(double));
-    sc->W = malloc((size_t)(g->N > 0 ? g->N : 1) * 18 * sizeof(double));
-    sc->gl_s = malloc((size_t)(L > 0 ? L : 1) * 3 * sizeof(double));
+    sc->Ci = malloc((size_t)(L > 0 ? L : 1) * ld * ld * sizeof(double));
+    sc->W = malloc((size_t)(g->N > 0 ? g->N : 1) * 6 * ld * sizeof(double));
+    sc->gl_s = malloc((size_t)(L > 0 ? L : 1) * ld * sizeof(double));
     int bad = 0;
 
     /* landmark blocks C_j = sum Jl_s^T Jl_s + D_l^2 and their inverses */
 #pragma omp parallel for schedule(static) reduction(| : bad)
     for (int j = 0; j < L; ++j) {
-        double C[9] = {0};
-        const double *s = sl + 3 * j;
+        double C[36] = {0};
+        const double *s = sl + (size_t)ld * j;
         for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
-            const double *J = w->Jl + 9 * g->pt_obs[e];
-            for (int a = 0; a < 3; ++a)
-                for (int b = 0; b < 3; ++b)
-                    C[3 * a + b] += (J[a] * J[b] + J[3 + a] * J[3 + b] + J[6 + a] * J[6 + b]) * s[a] * s[b];
+            const double *J = w->Jl + (size_t)nr * ld * g->pt_obs[e];
+            for (int m = 0; m < nr; ++m)
+                for (int a = 0; a < ld; ++a)
+                    for (int b = 0; b < ld; ++b) C[ld * a + b] += J[ld * m + a] * J[ld * m + b] * s[a] * s[b];
         }
-        for (int a = 0; a < 3; ++a) {
-            double d = w->sq_l[3 * j + a] * s[a] * s[a];
+        for (int a = 0; a < ld; ++a) {
+            double d = w->sq_l[(size_t)ld * j + a] * s[a] * s[a];
             d = fmin(fmax(d, o->min_lm_diagonal), o->max_lm_diagonal);
-            C[4 * a] += d / radius;
-            sc->gl_s[3 * j + a] = w->g_l[3 * j + a] * s[a];
+            C[(ld + 1) * a] += d / radius;
+            sc->gl_s[(size_t)ld * j + a] = w->g_l[(size_t)ld * j + a] * s[a];
         }
-        if (!g->pt_active[j]) { memset(sc->Ci + 9 * j, 0, 9 * sizeof(double)); continue; }
-        if (inv3_spd(C, sc->Ci + 9 * j)) bad |= 1;
+        if (!g->pt_active[j]) { memset(sc->Ci + (size_t)ld * ld * j, 0, (size_t)ld * ld * sizeof(double)); continue; }
+        if (inv_spd(ld, C, sc->Ci + (size_t)ld * ld * j)) bad |= 1;
     }
     if (bad) return -1;
 
-    /* W_i = Jp_s^T Jl_s for observations of free poses */
+    /* W_i = Jp_s^T Jl_s (6 x LD) for observations of free poses */
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < g->N; ++i) {
         int f = g->free_idx[p->obs_pose[i]];
-        double *Wi = sc->W + 18 * i;
-        if (f < 0) { memset(Wi, 0, 18 * sizeof(double)); continue; }
-        const double *a = w->Jp + 18 * i, *b = w->Jl + 9 * i;
-        const double *s6 = sp + 6 * f, *s3 = sl + 3 * (size_t)p->obs_point[i];
+        double *Wi = sc->W + (size_t)6 * ld * i;
+        if (f < 0) { memset(Wi, 0, (size_t)6 * ld * sizeof(double)); continue; }
+        const double *a = w->Jp + (size_t)nr * 6 * i, *b = w->Jl + (size_t)nr * ld * i;
+        const double *s6 = sp + 6 * f, *sL = sl + (size_t)ld * p->obs_point[i];
         for (int c = 0; c < 6; ++c)
-            for (int d = 0; d < 3; ++d)
-                Wi[3 * c + d] = (a[c] * b[d] + a[6 + c] * b[3 + d] + a[12 + c] * b[6 + d]) * s6[c] * s3[d];
+            for (int d = 0; d < ld; ++d) {
+                double v = 0.0;
+                for (int m = 0; m < nr; ++m) v += a[6 * m + c] * b[ld * m + d];
+                Wi[ld * c + d] = v * s6[c] * sL[d];
+            }
     }
 
     /* block-rows of S: each free pose owns its row (lower band) */
@@ -601,10 +654,10 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
         for (int c = 0; c < 6; ++c) gr[c] = w->g_p[6 * f + c] * s6[c];
         for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
             int64_t i = g->pose_obs[e];
-            const double *J = w->Jp + 18 * i;
-            for (int c = 0; c < 6; ++c)
-                for (int d = 0; d <= c; ++d)
-                    B[6 * c + d] += (J[c] * J[d] + J[6 + c] * J[6 + d] + J[12 + c] * J[12 + d]) * s6[c] * s6[d];
+            const double *J = w->Jp + (size_t)nr * 6 * i;
+            for (int m = 0; m < nr; ++m)
+                for (int c = 0; c < 6; ++c)
+                    for (int d = 0; d <= c; ++d) B[6 * c + d] += J[6 * m + c] * J[6 * m + d] * s6[c] * s6[d];
         }
         for (int c = 0; c < 6; ++c) {
             double d = w->sq_p[6 * f + c] * s6[c] * s6[c];
@@ -613,27 +666,31 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
         }
         for (int c = 0; c < 6; ++c)
             for (int d = 0; d <= c; ++d)
-                sc->S[(size_t)(6 * f + c) * ld + (d - c + bw)] += B[6 * c + d];
+                sc->S[(size_t)(6 * f + c) * lds + (d - c + bw)] += B[6 * c + d];
         for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
             int64_t i = g->pose_obs[e];
             int j = (int)p->obs_point[i];
-            const double *Wi = sc->W + 18 * i, *Ci = sc->Ci + 9 * j;
-            double Y[18]; /* W_i C^-1 */
+            const double *Wi = sc->W + (size_t)6 * ld * i, *Ci = sc->Ci + (size_t)ld * ld * j;
+            double Y[36]; /* W_i C^-1 (6 x LD) */
             for (int c = 0; c < 6; ++c)
-                for (int d = 0; d < 3; ++d)
-                    Y[3 * c + d] = Wi[3 * c] * Ci[d] + Wi[3 * c + 1] * Ci[3 + d] + Wi[3 * c + 2] * Ci[6 + d];
+                for (int d = 0; d < ld; ++d) {
+                    double v = 0.0;
+                    for (int q = 0; q < ld; ++q) v += Wi[ld * c + q] * Ci[ld * q + d];
+                    Y[ld * c + d] = v;
+                }
             for (int c = 0; c < 6; ++c)
-                gr[c] -= Y[3 * c] * sc->gl_s[3 * j] + Y[3 * c + 1] * sc->gl_s[3 * j + 1] + Y[3 * c + 2] * sc->gl_s[3 * j + 2];
+                for (int q = 0; q < ld; ++q) gr[c] -= Y[ld * c + q] * sc->gl_s[(size_t)ld * j + q];
             for (int64_t e2 = g->pt_start[j]; e2 < g->pt_start[j + 1]; ++e2) {
                 int64_t i2 = g->pt_obs[e2];
                 int f2 = g->free_idx[p->obs_pose[i2]];
                 if (f2 < 0 || f2 > f) continue;
-                const double *W2 = sc->W + 18 * i2;
+                const double *W2 = sc->W + (size_t)6 * ld * i2;
                 for (int c = 0; c < 6; ++c) {
                     int dmax = (f2 == f) ? c : 5;
                     for (int d = 0; d <= dmax; ++d) {
-                        double v = Y[3 * c] * W2[3 * d] + Y[3 * c + 1] * W2[3 * d + 1] + Y[3 * c + 2] * W2[3 * d + 2];
-                        sc->S[(size_t)(6 * f + c) * ld + ((6 * f2 + d) - (6 * f + c) + bw)] -= v;
+                        double v = 0.0;
+                        for (int q = 0; q < ld; ++q) v += Y[ld * c + q] * W2[ld * d + q];
+                        sc->S[(size_t)(6 * f + c) * lds + ((6 * f2 + d) - (6 * f + c) + bw)] -= v;
                     }
                 }
             }
@@ -647,12 +704,36 @@ static void schur_free(schur_t *sc) {
     free(sc->S); free(sc->rhs); free(sc->Ci); free(sc->W); free(sc->gl_s);
 }
 
+/* -(J d)^T (r + J d / 2) for an arbitrary step (dp: P*6, dl: L*LD), and |J d|^2 */
+static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w, const double *dp,
+                          const double *dl, double *mcc_out, double *jd_sq_out) {
+    const int nr = g->nr, ld = g->ld;
+    double mcc = 0.0, sq = 0.0;
+#pragma omp parallel for reduction(+ : mcc, sq) schedule(static)
+    for (int64_t i = 0; i < g->N; ++i) {
+        const double *a = w->Jp + (size_t)nr * 6 * i, *b = w->Jl + (size_t)nr * ld * i, *r = w->r + (size_t)nr * i;
+        const double *d6 = dp + 6 * (size_t)p->obs_pose[i], *dL = dl + (size_t)ld * p->obs_point[i];
+        const int fr = g->free_idx[p->obs_pose[i]] >= 0;
+        for (int m = 0; m < nr; ++m) {
+            double jd = 0.0;
+            for (int c = 0; c < ld; ++c) jd += b[ld * m + c] * dL[c];
+            if (fr)
+                for (int c = 0; c < 6; ++c) jd += a[6 * m + c] * d6[c];
+            mcc -= jd * (r[m] + 0.5 * jd);
+            sq += jd * jd;
+        }
+    }
+    if (mcc_out) *mcc_out = mcc;
+    if (jd_sq_out) *jd_sq_out = sq;
+}
+
 /* One LM step [Ceres LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver].
  * Outputs the UNSCALED step (delta = scale .* step_scaled) and the model cost
  * change  -(J d)^T (r + J d / 2)  [TrustRegionMinimizer::ComputeTrustRegionStep]. */
 static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const double *sp,
                    const double *sl, double radius, const orc_options *o, double *dp,
                    double *dl, double *model_cost_change, double *t_schur, double *t_solve) {
+    const int ld = g->ld;
     schur_t sc;
     memset(&sc, 0, sizeof sc);
     double t0 = now_s();
@@ -671,22 +752,24 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
     int ok = 1;
 #pragma omp parallel for schedule(static) reduction(& : ok)
     for (int j = 0; j < g->L; ++j) {
-        double t[3] = {sc.gl_s[3 * j], sc.gl_s[3 * j + 1], sc.gl_s[3 * j + 2]};
+        double t[6];
+        for (int d = 0; d < ld; ++d) t[d] = sc.gl_s[(size_t)ld * j + d];
         for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
             int64_t i = g->pt_obs[e];
             int f = g->free_idx[p->obs_pose[i]];
             if (f < 0) continue;
-            const double *Wi = sc.W + 18 * i, *y = yp + 6 * f;
-            for (int d = 0; d < 3; ++d)
-                for (int c = 0; c < 6; ++c) t[d] -= Wi[3 * c + d] * y[c];
+            const double *Wi = sc.W + (size_t)6 * ld * i, *y = yp + 6 * f;
+            for (int d = 0; d < ld; ++d)
+                for (int c = 0; c < 6; ++c) t[d] -= Wi[ld * c + d] * y[c];
         }
-        const double *Ci = sc.Ci + 9 * j;
-        for (int a = 0; a < 3; ++a) {
-            double y = Ci[3 * a] * t[0] + Ci[3 * a + 1] * t[1] + Ci[3 * a + 2] * t[2];
-            double v = -y * sl[3 * j + a];
+        const double *Ci = sc.Ci + (size_t)ld * ld * j;
+        for (int a = 0; a < ld; ++a) {
+            double y = 0.0;
+            for (int q = 0; q < ld; ++q) y += Ci[ld * a + q] * t[q];
+            double v = -y * sl[(size_t)ld * j + a];
             if (!g->pt_active[j]) v = 0.0;
             if (!isfinite(v)) ok = 0;
-            dl[3 * j + a] = v;
+            dl[(size_t)ld * j + a] = v;
         }
     }
     memset(dp, 0, (size_t)g->P * 6 * sizeof(double));
@@ -698,47 +781,15 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
         }
     schur_free(&sc);
     if (!ok) return -1;
-    double mcc = 0.0;
-#pragma omp parallel for reduction(+ : mcc) schedule(static)
-    for (int64_t i = 0; i < g->N; ++i) {
-        const double *a = w->Jp + 18 * i, *b = w->Jl + 9 * i, *r = w->r + 3 * i;
-        const double *d6 = dp + 6 * (size_t)p->obs_pose[i], *d3 = dl + 3 * (size_t)p->obs_point[i];
-        for (int m = 0; m < 3; ++m) {
-            double jd = b[3 * m] * d3[0] + b[3 * m + 1] * d3[1] + b[3 * m + 2] * d3[2];
-            if (g->free_idx[p->obs_pose[i]] >= 0)
-                for (int c = 0; c < 6; ++c) jd += a[6 * m + c] * d6[c];
-            mcc -= jd * (r[m] + 0.5 * jd);
-        }
-    }
-    *model_cost_change = mcc;
+    step_products(p, g, w, dp, dl, model_cost_change, NULL);
     return 0;
-}
-
-/* -(J d)^T (r + J d / 2) for an arbitrary step (dp: P*6, dl: L*3), and |J d|^2 */
-static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w, const double *dp,
-                          const double *dl, double *mcc_out, double *jd_sq_out) {
-    double mcc = 0.0, sq = 0.0;
-#pragma omp parallel for reduction(+ : mcc, sq) schedule(static)
-    for (int64_t i = 0; i < g->N; ++i) {
-        const double *a = w->Jp + 18 * i, *b = w->Jl + 9 * i, *r = w->r + 3 * i;
-        const double *d6 = dp + 6 * (size_t)p->obs_pose[i], *d3 = dl + 3 * (size_t)p->obs_point[i];
-        for (int m = 0; m < 3; ++m) {
-            double jd = b[3 * m] * d3[0] + b[3 * m + 1] * d3[1] + b[3 * m + 2] * d3[2];
-            if (g->free_idx[p->obs_pose[i]] >= 0)
-                for (int c = 0; c < 6; ++c) jd += a[6 * m + c] * d6[c];
-            mcc -= jd * (r[m] + 0.5 * jd);
-            sq += jd * jd;
-        }
-    }
-    if (mcc_out) *mcc_out = mcc;
-    if (jd_sq_out) *jd_sq_out = sq;
 }
 
 /* [Ceres 1.x dogleg_strategy.cc, TRADITIONAL_DOGLEG] state kept between iterations */
 typedef struct {
     double radius, mu, alpha, dogleg_step_norm, gradient_norm, gn_norm, g_dot_gn;
     int reuse;
-    double *gn_p, *gn_l;   /* Gauss-Newton step, unscaled (P*6, L*3)                     */
+    double *gn_p, *gn_l;   /* Gauss-Newton step, unscaled (P*6, L*LD)                    */
     double *v_p, *v_l;     /* s^2 g / D^2: the unscaled image of the scaled gradient / D */
 } dogleg_t;
 
@@ -750,7 +801,7 @@ typedef struct {
 static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, const double *sp,
                        const double *sl, const orc_options *o, dogleg_t *dg, double *dp, double *dl,
                        double *mcc, double *t_schur, double *t_solve) {
-    const int nf = g->nfree, L = g->L;
+    const int nf = g->nfree, L = g->L, ld = g->ld;
     if (!dg->reuse) {
         dg->reuse = 1;
         /* Gauss-Newton step with the regulariser mu * D^2: same damped system as LM with 1/radius = mu */
@@ -769,14 +820,15 @@ static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, c
                 dg->v_p[6 * k + c] = s * s * gq / D2;
             }
         for (int j = 0; j < L; ++j)
-            for (int c = 0; c < 3; ++c) {
-                const double s = sl[3 * j + c], gq = w->g_l[3 * j + c], gn = dg->gn_l[3 * j + c];
-                const double D2 = fmin(fmax(w->sq_l[3 * j + c] * s * s, o->min_lm_diagonal), o->max_lm_diagonal);
-                if (!g->pt_active[j]) { dg->v_l[3 * j + c] = 0.0; continue; }
+            for (int c = 0; c < ld; ++c) {
+                const size_t ix = (size_t)ld * j + c;
+                const double s = sl[ix], gq = w->g_l[ix], gn = dg->gn_l[ix];
+                const double D2 = fmin(fmax(w->sq_l[ix] * s * s, o->min_lm_diagonal), o->max_lm_diagonal);
+                if (!g->pt_active[j]) { dg->v_l[ix] = 0.0; continue; }
                 gsq += s * s * gq * gq / D2;
                 nsq += D2 * gn * gn / (s * s);
                 dot += gq * gn;
-                dg->v_l[3 * j + c] = s * s * gq / D2;
+                dg->v_l[ix] = s * s * gq / D2;
             }
         double jv_sq;
         step_products(p, g, w, dg->v_p, dg->v_l, NULL, &jv_sq);
@@ -802,13 +854,12 @@ static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, c
         const double dd = sqrt(cc * cc + bma_sq * (r * r - a_sq));
         const double bt = (cc <= 0.0) ? (dd - cc) / bma_sq : (r * r - a_sq) / (dd + cc);
         beta = bt; gamma = -dg->alpha * (1.0 - bt);
-        /* |step|^2 in the D-scaled space */
         const double a = gamma, b = beta;
         dg->dogleg_step_norm = sqrt(a * a * dg->gradient_norm * dg->gradient_norm + 2.0 * a * b * dg->g_dot_gn +
                                     b * b * dg->gn_norm * dg->gn_norm);
     }
     for (int i = 0; i < g->P * 6; ++i) dp[i] = beta * dg->gn_p[i] + gamma * dg->v_p[i];
-    for (int i = 0; i < L * 3; ++i) dl[i] = beta * dg->gn_l[i] + gamma * dg->v_l[i];
+    for (int i = 0; i < L * ld; ++i) dl[i] = beta * dg->gn_l[i] + gamma * dg->v_l[i];
     step_products(p, g, w, dp, dl, mcc, NULL);
     return 0;
 }
@@ -820,9 +871,9 @@ int orc_lm_step(const orc_problem *p, double radius, const orc_options *o, doubl
     graph_build(p, &g);
     lin_t w;
     lin_alloc(&w, &g);
-    linearize(p, &g, p->poses, p->points, &w);
+    linearize(p, &g, p->poses, p->points, p->normals, &w);
     double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
-    double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * 3 * sizeof(double));
+    double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * g.ld * sizeof(double));
     jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
     int rc = lm_step(p, &g, &w, sp, sl, radius, o, delta_p, delta_l, model_cost_change, NULL, NULL);
     free(sp); free(sl);
@@ -838,9 +889,9 @@ int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o
     graph_build(p, &g);
     lin_t w;
     lin_alloc(&w, &g);
-    linearize(p, &g, p->poses, p->points, &w);
+    linearize(p, &g, p->poses, p->points, p->normals, &w);
     double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
-    double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * 3 * sizeof(double));
+    double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * g.ld * sizeof(double));
     jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
     schur_t sc;
     memset(&sc, 0, sizeof sc);
@@ -874,23 +925,32 @@ int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o
 /* trust-region minimiser [Ceres 1.13/1.14 trust_region_minimizer.cc]         */
 /* ------------------------------------------------------------------------ */
 
-/* Evaluator::Plus: SE3Perturbation on free poses, Euclidean on active points */
-static void plus_all(const graph_t *g, const double *poses, const double *points,
-                     const double *dp, const double *dl, double *poses_out, double *points_out) {
+/* Evaluator::Plus: SE3Perturbation on free poses, Euclidean on the active points,
+ * UnitVectorPerturbation on their normals (perturbations.hpp:87-103).  The landmark step is
+ * LD wide: [d position | d normal]. */
+static void plus_all(const graph_t *g, const double *poses, const double *points, const double *normals,
+                     const double *dp, const double *dl, double *poses_out, double *points_out,
+                     double *normals_out) {
+    const int ld = g->ld;
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < g->P; ++k) {
         if (g->free_idx[k] >= 0) orc_se3_plus(poses + 12 * k, dp + 6 * k, poses_out + 12 * k);
         else memcpy(poses_out + 12 * k, poses + 12 * k, 12 * sizeof(double));
     }
 #pragma omp parallel for schedule(static)
-    for (int j = 0; j < g->L; ++j)
+    for (int j = 0; j < g->L; ++j) {
         for (int a = 0; a < 3; ++a)
-            points_out[3 * j + a] = g->pt_active[j] ? points[3 * j + a] + dl[3 * j + a] : points[3 * j + a];
+            points_out[3 * j + a] = g->pt_active[j] ? points[3 * j + a] + dl[(size_t)ld * j + a] : points[3 * j + a];
+        if (ld == 6) {
+            if (g->pt_active[j]) orc_unit_vector_plus(normals + 3 * j, dl + (size_t)ld * j + 3, normals_out + 3 * j);
+            else memcpy(normals_out + 3 * j, normals + 3 * j, 3 * sizeof(double));
+        }
+    }
 }
 
 /* ambient-space norms over the reduced program's parameter blocks */
-static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, const double *pb,
-                        const double *qb, double *max_abs) {
+static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, const double *na,
+                        const double *pb, const double *qb, const double *nb, double *max_abs) {
     double s = 0.0, m = 0.0;
     for (int f = 0; f < g->nfree; ++f) {
         int k = g->free_pose[f];
@@ -907,6 +967,12 @@ static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, co
             s += d * d;
             if (fabs(d) > m) m = fabs(d);
         }
+        if (g->ld == 6)
+            for (int c = 0; c < 3; ++c) {
+                double d = na[3 * j + c] - (nb ? nb[3 * j + c] : 0.0);
+                s += d * d;
+                if (fabs(d) > m) m = fabs(d);
+            }
     }
     if (max_abs) *max_abs = m;
     return s;
@@ -966,29 +1032,32 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     double t_start = now_s();
     graph_t g;
     graph_build(p, &g);
-    const int P = g.P, L = g.L;
+    const int P = g.P, L = g.L, ld = g.ld, ph = (ld == 6);
     lin_t w;
     lin_alloc(&w, &g);
     size_t szP = (size_t)(P > 0 ? P : 1), szL = (size_t)(L > 0 ? L : 1);
-    double *x_pose = malloc(szP * 12 * sizeof(double)), *x_pt = malloc(szL * 3 * sizeof(double));
-    double *c_pose = malloc(szP * 12 * sizeof(double)), *c_pt = malloc(szL * 3 * sizeof(double));
-    double *best_pose = malloc(szP * 12 * sizeof(double)), *best_pt = malloc(szL * 3 * sizeof(double));
-    double *dp = calloc(szP * 6, sizeof(double)), *dl = calloc(szL * 3, sizeof(double));
-    double *ngp = calloc(szP * 6, sizeof(double)), *ngl = calloc(szL * 3, sizeof(double));
+    double *x_pose = malloc(szP * 12 * sizeof(double)), *x_pt = malloc(szL * 3 * sizeof(double)), *x_n = malloc(szL * 3 * sizeof(double));
+    double *c_pose = malloc(szP * 12 * sizeof(double)), *c_pt = malloc(szL * 3 * sizeof(double)), *c_n = malloc(szL * 3 * sizeof(double));
+    double *best_pose = malloc(szP * 12 * sizeof(double)), *best_pt = malloc(szL * 3 * sizeof(double)), *best_n = malloc(szL * 3 * sizeof(double));
+    double *dp = calloc(szP * 6, sizeof(double)), *dl = calloc(szL * ld, sizeof(double));
+    double *ngp = calloc(szP * 6, sizeof(double)), *ngl = calloc(szL * ld, sizeof(double));
     double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
-    double *sl = malloc(szL * 3 * sizeof(double));
+    double *sl = malloc(szL * ld * sizeof(double));
     memcpy(x_pose, p->poses, (size_t)P * 12 * sizeof(double));
     memcpy(x_pt, p->points, (size_t)L * 3 * sizeof(double));
+    if (ph) memcpy(x_n, p->normals, (size_t)L * 3 * sizeof(double));
+    else memset(x_n, 0, szL * 3 * sizeof(double));
     memcpy(best_pose, x_pose, (size_t)P * 12 * sizeof(double));
     memcpy(best_pt, x_pt, (size_t)L * 3 * sizeof(double));
+    memcpy(best_n, x_n, szL * 3 * sizeof(double));
 
     /* ---- IterationZero ---- */
     double t0 = now_s();
-    linearize(p, &g, x_pose, x_pt, &w);
+    linearize(p, &g, x_pose, x_pt, x_n, &w);
     s->linearize_time_s += now_s() - t0;
     jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
     double x_cost = w.cost, minimum_cost = x_cost;
-    double x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, NULL, NULL, NULL));
+    double x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, NULL, NULL, NULL, NULL));
     s->initial_cost = x_cost;
     /* projected gradient: |x - Plus(x, -g)|_inf [EvaluateGradientAndJacobian] */
     double gmax;
@@ -996,9 +1065,9 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     do {                                                                                 \
         for (int f = 0; f < g.nfree; ++f)                                                \
             for (int c = 0; c < 6; ++c) ngp[6 * g.free_pose[f] + c] = -w.g_p[6 * f + c]; \
-        for (int i = 0; i < 3 * L; ++i) ngl[i] = -w.g_l[i];                              \
-        plus_all(&g, x_pose, x_pt, ngp, ngl, c_pose, c_pt);                              \
-        x_sq_diff(&g, x_pose, x_pt, c_pose, c_pt, &gmax);                                \
+        for (int i = 0; i < ld * L; ++i) ngl[i] = -w.g_l[i];                             \
+        plus_all(&g, x_pose, x_pt, x_n, ngp, ngl, c_pose, c_pt, c_n);                    \
+        x_sq_diff(&g, x_pose, x_pt, x_n, c_pose, c_pt, c_n, &gmax);                      \
     } while (0)
     GRADIENT_MAX_NORM();
     double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
@@ -1007,8 +1076,8 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     memset(&dg, 0, sizeof dg);
     dg.radius = radius; dg.mu = 1e-8;      /* DoglegStrategy: mu_ = min_mu_ = 1e-8, max 1.0, factor 10 */
     if (dogleg) {
-        dg.gn_p = calloc(szP * 6, sizeof(double)); dg.gn_l = calloc(szL * 3, sizeof(double));
-        dg.v_p = calloc(szP * 6, sizeof(double)); dg.v_l = calloc(szL * 3, sizeof(double));
+        dg.gn_p = calloc(szP * 6, sizeof(double)); dg.gn_l = calloc(szL * ld, sizeof(double));
+        dg.v_p = calloc(szP * 6, sizeof(double)); dg.v_l = calloc(szL * ld, sizeof(double));
     }
     step_eval_t se;
     se_init(&se, x_cost, o->use_nonmonotonic_steps ? o->max_consecutive_nonmonotonic_steps : 0);
@@ -1026,6 +1095,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
             minimum_cost = x_cost;
             memcpy(best_pose, x_pose, (size_t)P * 12 * sizeof(double));
             memcpy(best_pt, x_pt, (size_t)L * 3 * sizeof(double));
+            memcpy(best_n, x_n, (size_t)L * 3 * sizeof(double));
         }
         if (iteration >= o->max_num_iterations) { term = ORC_NO_CONVERGENCE; break; }
         if (gmax <= o->gradient_tolerance) { term = ORC_CONVERGENCE; break; }
@@ -1060,13 +1130,13 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
 
         /* ---- ComputeCandidatePointAndEvaluateCost ---- */
         t0 = now_s();
-        plus_all(&g, x_pose, x_pt, dp, dl, c_pose, c_pt);
-        double candidate_cost = evaluate(p, c_pose, c_pt, NULL, NULL, NULL);
+        plus_all(&g, x_pose, x_pt, x_n, dp, dl, c_pose, c_pt, c_n);
+        double candidate_cost = evaluate(p, c_pose, c_pt, c_n, NULL, NULL, NULL);
         if (!isfinite(candidate_cost)) candidate_cost = DBL_MAX;
         s->update_time_s += now_s() - t0;
 
         /* ---- ParameterToleranceReached ---- */
-        double step_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, c_pose, c_pt, NULL));
+        double step_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, c_pose, c_pt, c_n, NULL));
         if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) {
             term = ORC_CONVERGENCE;
             break;
@@ -1083,9 +1153,10 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
             /* HandleSuccessfulStep */
             memcpy(x_pose, c_pose, (size_t)P * 12 * sizeof(double));
             memcpy(x_pt, c_pt, (size_t)L * 3 * sizeof(double));
-            x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, NULL, NULL, NULL));
+            if (ph) memcpy(x_n, c_n, (size_t)L * 3 * sizeof(double));
+            x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, NULL, NULL, NULL, NULL));
             t0 = now_s();
-            linearize(p, &g, x_pose, x_pt, &w);
+            linearize(p, &g, x_pose, x_pt, x_n, &w);
             s->linearize_time_s += now_s() - t0;
             x_cost = w.cost;
             GRADIENT_MAX_NORM();
@@ -1133,8 +1204,10 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     if (term != ORC_FAILURE) {
         memcpy(p->poses, best_pose, (size_t)P * 12 * sizeof(double));
         memcpy(p->points, best_pt, (size_t)L * 3 * sizeof(double));
+        if (ph) memcpy(p->normals, best_n, (size_t)L * 3 * sizeof(double));
     }
-    free(x_pose); free(x_pt); free(c_pose); free(c_pt); free(best_pose); free(best_pt);
+    free(x_pose); free(x_pt); free(x_n); free(c_pose); free(c_pt); free(c_n);
+    free(best_pose); free(best_pt); free(best_n);
     free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl);
     free(dg.gn_p); free(dg.gn_l); free(dg.v_p); free(dg.v_l);
     lin_free(&w);
@@ -1142,7 +1215,6 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     s->total_time_s = now_s() - t_start;
     return 0;
 }
-
 
 /* ------------------------------------------------------------------------ */
 /* Phong lighting rows                                 */

@@ -59,6 +59,20 @@ typedef struct {
     double stiffness[9];      /* row-major, shared by all observations          */
     const uint8_t *pose_const;/* num_poses, 1 = SetParameterBlockConstant       */
     double huber_a;           /* <= 0: NULL loss                                */
+    /* Phong lighting terms (tests/dataset_ba_phong.cpp:102-195, BASELINE config 3); intensity ==
+     * NULL means a stereo-only problem.  One intensity and one normal residual block per
+     * observation; landmark block = [position | normal]; light / materials / textures constant. */
+    double *normals;                   /* num_points*3, updated in place (UnitVectorPerturbation) */
+    const double *intensity;           /* num_obs                                                 */
+    const double *normal_obs;          /* num_obs*3                                               */
+    const double *phong;               /* num_materials*3: ka, ks, alpha                          */
+    const double *texture;             /* num_materials: kd                                       */
+    const uint32_t *material_of_point; /* num_points                                              */
+    double light[3];
+    int32_t light_type;                /* ORC_POINT_LIGHT / ORC_DIRECTIONAL_LIGHT                 */
+    int32_t reserved;
+    double int_stiffness;              /* 1/sqrt(int_var)  (dataset_ba_phong.cpp:44)              */
+    double normal_stiffness[9];
 } orc_problem;
 
 typedef struct {
@@ -107,7 +121,8 @@ void orc_default_options(orc_options *o);
 double orc_cost(const orc_problem *p, int num_threads);
 
 /* Normal-equation blocks at the current parameters, UNSCALED local coordinates.
- * g_p: P*6, g_l: L*3, H_pp: P*36 (full 6x6 row-major), H_ll: L*9.  Constant poses
+ * g_p: P*6, g_l: L*LD, H_pp: P*36 (full 6x6 row-major), H_ll: L*LD*LD with LD = 3 (stereo only)
+ * or 6 (Phong terms present: [position | normal]).  Constant poses
  * still get their blocks (callers mask them).  Returns cost. */
 double orc_linearize(const orc_problem *p, double *g_p, double *g_l, double *H_pp,
                      double *H_ll, int num_threads);

@@ -408,3 +408,73 @@ def dogleg_solve(ba: "NumpyBA", max_iter=1000, nonmonotonic=True, f_tol=1e-6, p_
             reuse = True
             log.append((c_cost, False))
     return x_p, x_l, log
+
+
+# ---- config 3 (stereo + intensity + normal residual blocks, landmark block = [position | normal]) ----
+def phong_lm_step(cam, poses, points, normals, obs_pose, obs_point, obs_uvd, S, ph, radius, pose_const=None,
+                  min_diag=1e-6, max_diag=1e32):
+    """One Ceres LM step of the config-3 problem with a dense/sparse direct solve and complex-step
+    Jacobians through the reference's Plus operators (slow: small problems only).
+    Returns dp (P,6), dl (L,6), model_cost_change, cost."""
+    P, L, N = poses.shape[0], points.shape[0], obs_pose.shape[0]
+    if pose_const is None:
+        pose_const = np.zeros(P, bool)
+        pose_const[0] = True
+    seen = np.bincount(obs_pose, minlength=P) > 0
+    free = (~pose_const) & seen
+    fidx = np.full(P, -1)
+    fidx[free] = np.arange(free.sum())
+    active = np.bincount(obs_point, minlength=L) > 0
+    nf = int(free.sum())
+    ncol = 6 * nf + 6 * L
+    rows, cols, vals, r = [], [], [], np.zeros(7 * N)
+    Sn = np.asarray(ph["normal_stiffness"]).reshape(3, 3)
+    h = 1e-30
+    for i in range(N):
+        k, j = int(obs_pose[i]), int(obs_point[i])
+        T, p, n = poses[k], points[j], normals[j]
+        m = int(ph["material_of_point"][j])
+        r[7 * i: 7 * i + 3] = residual_global(cam, T, p, obs_uvd[i], S)
+        Jp3, Jl3 = jacobians_complex_step(cam, T, p, obs_uvd[i], S)
+        r[7 * i + 3] = intensity_residual(ph["light_type"], T, p, n, ph["phong"][m], ph["texture"][m], ph["light"],
+                                          ph["intensity"][i], ph["int_stiffness"]).real
+        J19 = intensity_jacobian_complex_step(ph["light_type"], T, p, n, ph["phong"][m], ph["texture"][m], ph["light"],
+                                              ph["intensity"][i], ph["int_stiffness"])
+        R = T[3:].reshape(3, 3)
+        r[7 * i + 4: 7 * i + 7] = Sn @ (R @ n - ph["normal_obs"][i])
+        Jnp, Jnn = np.zeros((3, 6)), np.zeros((3, 3))
+        for c in range(6):
+            e = np.zeros(6, dtype=complex); e[c] = 1j * h
+            Tn = se3_plus(T.astype(complex), e)
+            Jnp[:, c] = (Sn @ (Tn[3:].reshape(3, 3) @ n - ph["normal_obs"][i])).imag / h
+        for c in range(3):
+            e = np.zeros(3, dtype=complex); e[c] = 1j * h
+            Jnn[:, c] = (Sn @ (R @ unit_vector_plus(n.astype(complex), e) - ph["normal_obs"][i])).imag / h
+        Jp = np.vstack([Jp3, J19[None, :6], Jnp])                       # 7 x 6
+        Jl = np.zeros((7, 6))
+        Jl[:3, :3] = Jl3
+        Jl[3, :] = J19[6:12]
+        Jl[4:, 3:] = Jnn
+        for a in range(7):
+            if fidx[k] >= 0:
+                for c in range(6):
+                    rows.append(7 * i + a); cols.append(6 * fidx[k] + c); vals.append(Jp[a, c])
+            for c in range(6):
+                rows.append(7 * i + a); cols.append(6 * nf + 6 * j + c); vals.append(Jl[a, c])
+    J = sp.csr_matrix((vals, (rows, cols)), shape=(7 * N, ncol))
+    keep = np.concatenate([np.ones(6 * nf, bool), np.repeat(active, 6)])
+    J = J[:, keep]
+    colsq = np.asarray(J.multiply(J).sum(0)).ravel()
+    scale = 1.0 / (1.0 + np.sqrt(colsq))
+    Js = J @ sp.diags(scale)
+    diag = np.clip(np.asarray(Js.multiply(Js).sum(0)).ravel(), min_diag, max_diag)
+    H = (Js.T @ Js + sp.diags(diag / radius)).tocsc()
+    y = spla.spsolve(H, Js.T @ r)
+    delta = -y * scale
+    Jd = J @ delta
+    mcc = -Jd @ (r + 0.5 * Jd)
+    full = np.zeros(ncol)
+    full[keep] = delta
+    dp = np.zeros((P, 6))
+    dp[free] = full[: 6 * nf].reshape(nf, 6)
+    return dp, full[6 * nf:].reshape(L, 6), mcc, 0.5 * r @ r
