@@ -32,6 +32,7 @@ SYMBOLS = [
     "ssba_solve_end", "ssba_solve_restart", "ssba_synchronize", "ssba_iteration_log", "ssba_set_stream",
     "ssba_set_exchange", "ssba_set_distributed", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
+    "ssba_add_normal_blocks", "ssba_set_materials", "ssba_set_light", "ssba_add_lighting_observations",
 ]
 
 
@@ -125,6 +126,10 @@ def load():
     L.ssba_lm_step.argtypes = [H, C.POINTER(Options), C.c_double, _dp, _dp, _dp, _dp, _dp]
     L.ssba_phong_evaluate.argtypes = [C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp,
                                       _dp, _dp, _dp, _dp, _dp]
+    L.ssba_add_normal_blocks.argtypes = [H, _dp, C.c_uint32]
+    L.ssba_set_materials.argtypes = [H, _dp, _dp, C.c_uint32, _u32p, C.c_uint32]
+    L.ssba_set_light.argtypes = [H, _dp, C.c_int]
+    L.ssba_add_lighting_observations.argtypes = [H, _dp, C.c_double, _dp, _dp, C.c_uint64]
     L.ssba_status_string.argtypes = [C.c_int]
     L.ssba_status_string.restype = C.c_char_p
     L.ssba_last_error.restype = C.c_char_p

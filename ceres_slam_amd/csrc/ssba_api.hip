@@ -44,6 +44,17 @@ struct ssba_problem {
     std::vector<uint8_t> pose_const;
     double huber_a = 0.0;
     bool finalized = false;
+    // config 3: lighting terms
+    double *user_normals = nullptr;
+    uint32_t num_normals = 0;
+    std::vector<double> ph_mat;            // M*4: ka, ks, alpha, kd
+    std::vector<uint32_t> ph_mat_of_point;
+    double ph_light[3] = {0, 0, 0};
+    int ph_light_type = 0;
+    bool have_light = false;
+    std::vector<double> ph_intensity, ph_nobs;
+    double ph_int_stiff = 0.0, ph_Sn[9] = {0};
+    bool lighting() const { return !ph_intensity.empty(); }
     // host structure
     std::vector<int> pose_free, free_pose;
     std::vector<uint32_t> user_of_dev;   // Lpad -> user landmark or 0xFFFFFFFF
@@ -238,6 +249,59 @@ int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index, co
     return SSBA_OK;
 }
 
+int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num) {
+    if (!p || (!normals && num)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    p->user_normals = normals;
+    p->num_normals = num;
+    return SSBA_OK;
+}
+
+int ssba_set_materials(ssba_problem *p, const double *phong, const double *texture, uint32_t num_materials,
+                       const uint32_t *material_of_point, uint32_t num_points) {
+    if (!p || !phong || !texture || !material_of_point || num_materials == 0) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    for (uint32_t j = 0; j < num_points; ++j)
+        if (material_of_point[j] >= num_materials) return SSBA_ERR_INVALID_ARGUMENT;
+    p->ph_mat.resize((size_t)num_materials * 4);
+    for (uint32_t m = 0; m < num_materials; ++m) {
+        for (int c = 0; c < 3; ++c) p->ph_mat[4 * (size_t)m + c] = phong[3 * (size_t)m + c];
+        p->ph_mat[4 * (size_t)m + 3] = texture[m];
+    }
+    p->ph_mat_of_point.assign(material_of_point, material_of_point + num_points);
+    return SSBA_OK;
+}
+
+int ssba_set_light(ssba_problem *p, const double light[3], int light_type) {
+    if (!p || !light || (light_type != 0 && light_type != 1)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    memcpy(p->ph_light, light, sizeof p->ph_light);
+    p->ph_light_type = light_type;
+    p->have_light = true;
+    return SSBA_OK;
+}
+
+int ssba_add_lighting_observations(ssba_problem *p, const double *intensity, double intensity_stiffness,
+                                   const double *normal_obs, const double normal_stiffness[9], uint64_t num) {
+    if (!p || !normal_stiffness || (num && (!intensity || !normal_obs))) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    if (!p->ph_intensity.empty() &&
+        (p->ph_int_stiff != intensity_stiffness || memcmp(p->ph_Sn, normal_stiffness, sizeof p->ph_Sn) != 0)) {
+        set_error("all lighting residual blocks must share their stiffness (as the reference driver does)");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    for (uint64_t i = 0; i < num; ++i) {
+        if (!std::isfinite(intensity[i])) return SSBA_ERR_INVALID_ARGUMENT;
+        for (int c = 0; c < 3; ++c)
+            if (!std::isfinite(normal_obs[3 * i + c])) return SSBA_ERR_INVALID_ARGUMENT;
+    }
+    p->ph_int_stiff = intensity_stiffness;
+    memcpy(p->ph_Sn, normal_stiffness, sizeof p->ph_Sn);
+    p->ph_intensity.insert(p->ph_intensity.end(), intensity, intensity + num);
+    p->ph_nobs.insert(p->ph_nobs.end(), normal_obs, normal_obs + 3 * num);
+    return SSBA_OK;
+}
+
 int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant) {
     if (!p || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->finalized) return SSBA_ERR_STATE;   // the reduced-system structure depends on it
@@ -307,6 +371,21 @@ int ssba_finalize(ssba_problem *p) {
     HIPCHECK(hipSetDevice(p->device));
     const uint32_t P = p->P, L = p->L;
     const uint64_t N = p->obs_pose.size();
+    const bool ph = p->lighting();
+    if (ph) {
+        if (p->ph_intensity.size() != N) {
+            set_error("lighting observations must pair one-to-one with the stereo observations");
+            return SSBA_ERR_INVALID_ARGUMENT;
+        }
+        if (p->num_normals != L || p->ph_mat_of_point.size() != L || !p->have_light) {
+            set_error("lighting terms need a normal and a material for every point, and the light");
+            return SSBA_ERR_INVALID_ARGUMENT;
+        }
+        if (p->world_size > 1) {
+            set_error("lighting terms are not available with landmark sharding yet");
+            return SSBA_ERR_UNSUPPORTED;
+        }
+    }
     if (N >= (1ull << 28) || L >= (1u << 27)) {
         set_error("problem too large for the 32-bit observation references of this build");
         return SSBA_ERR_UNSUPPORTED;
@@ -391,11 +470,18 @@ int ssba_finalize(ssba_problem *p) {
     const uint32_t n_groups = Lpad / LMG;
     std::vector<double> ou((size_t)n_groups * TW * LMG, 0.0), ov(ou.size(), 0.0), od(ou.size(), 1.0);
     std::vector<uint32_t> lm_mask(Lpad, 0);
+    std::vector<double> oint, onx, ony, onz;
+    std::vector<uint32_t> lm_mat;
+    if (ph) {
+        oint.assign(ou.size(), 0.0); onx.assign(ou.size(), 0.0); ony.assign(ou.size(), 0.0); onz.assign(ou.size(), 1.0);
+        lm_mat.assign(Lpad, 0);
+    }
     p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
     std::vector<std::vector<uint32_t>> pose_refs(P);
     for (uint32_t l = 0; l < Lact; ++l) {
         const uint32_t j = order[l].j, w = lm_win[l];
         p->user_of_dev[l] = j;
+        if (ph) lm_mat[l] = p->ph_mat_of_point[j];
         for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
             const uint32_t i = lm_obs[e], k = p->obs_pose[i];
             const uint32_t *wp = &win_pose[(size_t)w * TW];
@@ -404,6 +490,12 @@ int ssba_finalize(ssba_problem *p) {
             ou[oi] = p->obs_uvd[3 * (size_t)i];
             ov[oi] = p->obs_uvd[3 * (size_t)i + 1];
             od[oi] = p->obs_uvd[3 * (size_t)i + 2];
+            if (ph) {
+                oint[oi] = p->ph_intensity[i];
+                onx[oi] = p->ph_nobs[3 * (size_t)i];
+                ony[oi] = p->ph_nobs[3 * (size_t)i + 1];
+                onz[oi] = p->ph_nobs[3 * (size_t)i + 2];
+            }
             lm_mask[l] |= 1u << s;
             pose_refs[k].push_back(l * 16u + (uint32_t)s);
         }
@@ -532,8 +624,20 @@ int ssba_finalize(ssba_problem *p) {
     if (win_pose.empty()) win_pose.assign(TW, 0xFFFFFFFFu);
     TRY(dupload(p, &d.win_pose, win_pose));
     TRY(dupload(p, &d.pose_obs_start, pose_obs_start)); TRY(dupload(p, &d.pose_obs_ref, pose_obs_ref));
-    TRY(dzero(p, &d.hll, (size_t)Lpad * 6)); TRY(dzero(p, &d.gl, (size_t)Lpad * 3));
-    TRY(dzero(p, &d.sl, (size_t)Lpad * 3));
+    TRY(dzero(p, &d.hll, (size_t)Lpad * (ph ? 21 : 6))); TRY(dzero(p, &d.gl, (size_t)Lpad * (ph ? 6 : 3)));
+    TRY(dzero(p, &d.sl, (size_t)Lpad * (ph ? 6 : 3)));
+    if (ph) {
+        d.phong = 1;
+        d.light_type = p->ph_light_type;
+        memcpy(d.light, p->ph_light, sizeof d.light);
+        d.int_stiff = p->ph_int_stiff;
+        memcpy(d.Sn, p->ph_Sn, sizeof d.Sn);
+        TRY(dzero(p, &d.nrm, (size_t)Lpad * 3)); TRY(dzero(p, &d.cand_nrm, (size_t)Lpad * 3));
+        TRY(dzero(p, &d.best_nrm, (size_t)Lpad * 3)); TRY(dzero(p, &d.init_nrm, (size_t)Lpad * 3));
+        TRY(dupload(p, &d.oi, oint)); TRY(dupload(p, &d.onx, onx)); TRY(dupload(p, &d.ony, ony)); TRY(dupload(p, &d.onz, onz));
+        TRY(dupload(p, &d.lm_mat, lm_mat)); TRY(dupload(p, &d.mat, p->ph_mat));
+        TRY(dzero(p, &d.cinv, (size_t)Lpad * 21)); TRY(dzero(p, &d.dlm, (size_t)Lpad * 6));
+    }
     TRY(dzero(p, &d.hpp, (size_t)P * 21)); TRY(dzero(p, &d.gp, (size_t)P * 6));
     TRY(dzero(p, &d.sp, (size_t)d.nf_pad * 6));
     TRY(dupload(p, &d.slab_win, slab_win)); TRY(dupload(p, &d.slab_lm_begin, slab_b));
@@ -590,6 +694,10 @@ int ssba_finalize(ssba_problem *p) {
     if (upload_bcr_tables(p->launcher.stream)) { set_error("BCR tile table upload failed"); return SSBA_ERR_HIP; }
     if (configure_schur()) { set_error("hipFuncSetAttribute(k_schur_windows) failed"); return SSBA_ERR_HIP; }
     if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
+    if (ph) {
+        if (upload_phong_tables(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
+        if (configure_phong()) { set_error("hipFuncSetAttribute(k_ph_schur_windows) failed"); return SSBA_ERR_HIP; }
+    }
 #undef TRY
     p->stats.num_poses = P; p->stats.num_free_poses = (uint32_t)nfree;
     p->stats.num_points = L; p->stats.num_active_points = Lact;
@@ -616,10 +724,18 @@ static int upload_params(ssba_problem *p) {
     HIPCHECK(hipStreamSynchronize(s));   // poses copied from pageable memory
     HIPCHECK(hipMemcpyAsync(d.pts, st, Lp * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHECK(hipStreamSynchronize(s));
+    if (d.phong) {
+        for (size_t l = 0; l < Lp; ++l) {
+            const uint32_t j = p->user_of_dev[l];
+            for (int c = 0; c < 3; ++c) st[c * Lp + l] = (j == 0xFFFFFFFFu) ? (c == 2 ? 1.0 : 0.0) : p->user_normals[3 * (size_t)j + c];
+        }
+        HIPCHECK(hipMemcpyAsync(d.nrm, st, Lp * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHECK(hipStreamSynchronize(s));
+    }
     return SSBA_OK;
 }
 
-static int download_params(ssba_problem *p, const double *dev_poses, const double *dev_pts) {
+static int download_params(ssba_problem *p, const double *dev_poses, const double *dev_pts, const double *dev_nrm) {
     Dev &d = p->d;
     hipStream_t s = p->launcher.stream;
     const size_t Lp = (size_t)d.Lpad;
@@ -629,6 +745,15 @@ static int download_params(ssba_problem *p, const double *dev_poses, const doubl
         const uint32_t j = p->user_of_dev[l];
         if (j == 0xFFFFFFFFu) continue;
         for (int c = 0; c < 3; ++c) p->user_points[3 * (size_t)j + c] = p->h_stage[c * Lp + l];
+    }
+    if (d.phong) {
+        HIPCHECK(hipMemcpyAsync(p->h_stage, dev_nrm, Lp * 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHECK(hipStreamSynchronize(s));
+        for (size_t l = 0; l < Lp; ++l) {
+            const uint32_t j = p->user_of_dev[l];
+            if (j == 0xFFFFFFFFu) continue;
+            for (int c = 0; c < 3; ++c) p->user_normals[3 * (size_t)j + c] = p->h_stage[c * Lp + l];
+        }
     }
     if (p->P) {
         // constant / unobserved poses are never touched on the device, so a plain copy is exact
@@ -727,6 +852,12 @@ static int reset_solver(ssba_problem *p) {
     HIPCHECK(hipMemcpyAsync(d.best_pts, d.init_pts, (size_t)d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(d.cand_poses, d.init_poses, (size_t)d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(d.cand_pts, d.init_pts, (size_t)d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (d.phong) {
+        const size_t nb = (size_t)d.Lpad * 3 * sizeof(double);
+        HIPCHECK(hipMemcpyAsync(d.nrm, d.init_nrm, nb, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(d.best_nrm, d.init_nrm, nb, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(d.cand_nrm, d.init_nrm, nb, hipMemcpyDeviceToDevice, s));
+    }
     launch_reset(p->launcher, d, to_device_options(&p->opt, p->ignore_convergence));
     return SSBA_OK;
 }
@@ -738,6 +869,10 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (o->trust_region_strategy_type != 0 && o->trust_region_strategy_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
     if (o->trust_region_strategy_type == 1 && p->xfn) {
         set_error("DOGLEG is not available with landmark sharding yet (its norms need one more exchange point)");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    if (p->d.phong && (o->trust_region_strategy_type == 1 || p->huber_a > 0.0 || p->xfn)) {
+        set_error("lighting terms: DOGLEG, Huber loss and landmark sharding are not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     if (p->gexec && p->opt.trust_region_strategy_type != o->trust_region_strategy_type) drop_graph(p);   // other kernel sequence
@@ -755,6 +890,7 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     hipStream_t s = p->launcher.stream;
     HIPCHECK(hipMemcpyAsync(p->d.init_poses, p->d.poses, (size_t)p->d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d.init_pts, p->d.pts, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (p->d.phong) HIPCHECK(hipMemcpyAsync(p->d.init_nrm, p->d.nrm, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     rc = reset_solver(p);
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_begin, s));
@@ -815,7 +951,7 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
     const int term = S.terminated ? S.termination_type : SSBA_NO_CONVERGENCE;
     // the solution is usable unless the minimiser failed: write the lowest-cost iterate back
     if (term != SSBA_FAILURE) {
-        rc = download_params(p, p->d.best_poses, p->d.best_pts);
+        rc = download_params(p, p->d.best_poses, p->d.best_pts, p->d.best_nrm);
         if (rc) return rc;
     }
     if (s) {
@@ -937,6 +1073,10 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     ssba_options opt;
     if (o) opt = *o; else ssba_default_options(&opt);
     if (radius > 0.0) opt.initial_trust_region_radius = radius;
+    if (p->d.phong && (opt.trust_region_strategy_type == 1 || p->huber_a > 0.0 || p->xfn)) {
+        set_error("lighting terms: DOGLEG, Huber loss and landmark sharding are not available yet");
+        return SSBA_ERR_UNSUPPORTED;
+    }
     p->opt = opt;
     p->ignore_convergence = 1;
     p->d.huber_a = p->huber_a;
@@ -947,6 +1087,7 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     hipStream_t s = p->launcher.stream;
     HIPCHECK(hipMemcpyAsync(p->d.init_poses, p->d.poses, (size_t)p->d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d.init_pts, p->d.pts, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (p->d.phong) HIPCHECK(hipMemcpyAsync(p->d.init_nrm, p->d.nrm, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
     return reset_solver(p);
 }
 
@@ -981,21 +1122,24 @@ int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, doubl
         }
     }
     if (g_l || H_ll) {
-        std::vector<double> gl(Lp * 3), hl(Lp * 6);
+        const int ld = d.phong ? 6 : 3, nh = ld * (ld + 1) / 2;
+        std::vector<double> gl(Lp * ld), hl(Lp * nh);
         HIPCHECK(hipMemcpy(gl.data(), d.gl, gl.size() * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHECK(hipMemcpy(hl.data(), d.hll, hl.size() * sizeof(double), hipMemcpyDeviceToHost));
-        if (g_l) memset(g_l, 0, (size_t)p->L * 3 * sizeof(double));
-        if (H_ll) memset(H_ll, 0, (size_t)p->L * 9 * sizeof(double));
-        static const int map6[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+        if (g_l) memset(g_l, 0, (size_t)p->L * ld * sizeof(double));
+        if (H_ll) memset(H_ll, 0, (size_t)p->L * ld * ld * sizeof(double));
         for (size_t l = 0; l < Lp; ++l) {
             const uint32_t j = p->user_of_dev[l];
             if (j == 0xFFFFFFFFu) continue;
-            if (g_l) for (int c = 0; c < 3; ++c) g_l[3 * (size_t)j + c] = gl[c * Lp + l];
-            if (H_ll)
-                for (int c = 0; c < 6; ++c) {
-                    H_ll[9 * (size_t)j + 3 * map6[c][0] + map6[c][1]] = hl[c * Lp + l];
-                    H_ll[9 * (size_t)j + 3 * map6[c][1] + map6[c][0]] = hl[c * Lp + l];
-                }
+            if (g_l) for (int c = 0; c < ld; ++c) g_l[ld * (size_t)j + c] = gl[c * Lp + l];
+            if (H_ll) {
+                int c = 0;   // packed upper triangle, row-major
+                for (int a = 0; a < ld; ++a)
+                    for (int b = a; b < ld; ++b, ++c) {
+                        H_ll[(size_t)ld * ld * j + ld * a + b] = hl[c * Lp + l];
+                        H_ll[(size_t)ld * ld * j + ld * b + a] = hl[c * Lp + l];
+                    }
+            }
         }
     }
     return SSBA_OK;
@@ -1054,7 +1198,17 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
         for (int f = 0; f < nf; ++f)
             for (int c = 0; c < 6; ++c) delta_p[6 * (size_t)p->free_pose[f] + c] = x[6 * (size_t)f + c];
     }
-    if (delta_l) {
+    if (delta_l && d.phong) {
+        const size_t Lp = (size_t)d.Lpad;
+        std::vector<double> a(Lp * 6);
+        HIPCHECK(hipMemcpy(a.data(), d.dlm, a.size() * sizeof(double), hipMemcpyDeviceToHost));
+        memset(delta_l, 0, (size_t)p->L * 6 * sizeof(double));
+        for (size_t l = 0; l < Lp; ++l) {
+            const uint32_t j = p->user_of_dev[l];
+            if (j == 0xFFFFFFFFu) continue;
+            for (int c = 0; c < 6; ++c) delta_l[6 * (size_t)j + c] = a[c * Lp + l];
+        }
+    } else if (delta_l) {
         const size_t Lp = (size_t)d.Lpad;
         std::vector<double> a(Lp * 3), b(Lp * 3);
         HIPCHECK(hipMemcpy(a.data(), d.cand_pts, a.size() * sizeof(double), hipMemcpyDeviceToHost));

@@ -24,6 +24,7 @@
 
 #include "ssba_types.h"
 #include "ssba_launch.h"
+#include "ssba_device.h"
 
 namespace ssba {
 
@@ -38,201 +39,6 @@ int upload_pair_table(hipStream_t s) {
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pair_a), a, NPAIR, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_pair_b), b, NPAIR, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
-}
-
-// ------------------------------------------------------------------ helpers ---
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
-}
-// Deterministic block sum; result valid on thread 0.  sm needs blockDim/64 doubles.
-__device__ __forceinline__ double block_sum(double v, double *sm) {
-    v = wave_sum(v);
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[w] = v;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x == 0)
-        for (int i = 0; i < nw; ++i) t += sm[i];
-    return t;
-}
-__device__ __forceinline__ double block_max(double v, double *sm) {
-    v = wave_max(v);
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[w] = v;
-    __syncthreads();
-    double t = 0.0;
-    if (threadIdx.x == 0)
-        for (int i = 0; i < nw; ++i) t = fmax(t, sm[i]);
-    return t;
-}
-
-struct ObsLin {
-    double r[3];     // loss-corrected residual
-    double A[9];     // sqrt(rho') * S * J_pi(q)
-    double q[3];     // point in the camera frame
-    double half_rho; // 1/2 rho(|r|^2)
-};
-
-// stereo_reprojection_error.hpp:38-50, stereo_camera.hpp:77-104, Huber corrector
-// [Ceres corrector.cc with rho'' <= 0].  T is the 12-double pose block.
-__device__ __forceinline__ void obs_linearize(const Dev &d, const double *__restrict__ T,
-                                              double px, double py, double pz, double u, double v,
-                                              double dd, ObsLin &o) {
-    const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
-    const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
-    const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
-    const double iz = 1.0 / q2;
-    const double e0 = d.fu * q0 * iz + d.cu - u;
-    const double e1 = d.fv * q1 * iz + d.cv - v;
-    const double e2 = d.fu * d.b * iz - dd;
-    const double j00 = d.fu * iz, j11 = d.fv * iz;
-    const double iz2 = iz * iz;
-    const double j02 = -d.fu * q0 * iz2, j12 = -d.fv * q1 * iz2, j22 = -d.fu * d.b * iz2;
-    double sq = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double s0 = d.S[3 * i], s1 = d.S[3 * i + 1], s2 = d.S[3 * i + 2];
-        o.r[i] = s0 * e0 + s1 * e1 + s2 * e2;
-        o.A[3 * i] = s0 * j00;
-        o.A[3 * i + 1] = s1 * j11;
-        o.A[3 * i + 2] = s0 * j02 + s1 * j12 + s2 * j22;
-        sq += o.r[i] * o.r[i];
-    }
-    o.q[0] = q0; o.q[1] = q1; o.q[2] = q2;
-    o.half_rho = 0.5 * sq;
-    if (d.huber_a > 0.0 && sq > d.huber_a * d.huber_a) {
-        const double rs = sqrt(sq);
-        const double rho1 = fmax(DBL_MIN, d.huber_a / rs);
-        const double sc = sqrt(rho1);
-        o.half_rho = 0.5 * (2.0 * d.huber_a * rs - d.huber_a * d.huber_a);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) o.r[i] *= sc;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) o.A[i] *= sc;
-    }
-}
-
-// 1/2 rho(|r|^2) only (candidate evaluation)
-__device__ __forceinline__ double obs_cost(const Dev &d, const double *__restrict__ T, double px,
-                                           double py, double pz, double u, double v, double dd) {
-    const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
-    const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
-    const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
-    const double iz = 1.0 / q2;
-    const double e0 = d.fu * q0 * iz + d.cu - u;
-    const double e1 = d.fv * q1 * iz + d.cv - v;
-    const double e2 = d.fu * d.b * iz - dd;
-    double sq = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double r = d.S[3 * i] * e0 + d.S[3 * i + 1] * e1 + d.S[3 * i + 2] * e2;
-        sq += r * r;
-    }
-    if (d.huber_a > 0.0 && sq > d.huber_a * d.huber_a)
-        return 0.5 * (2.0 * d.huber_a * sqrt(sq) - d.huber_a * d.huber_a);
-    return 0.5 * sq;
-}
-
-// J_l = A R (3x3)   [dq/dp = R]
-__device__ __forceinline__ void jac_point(const ObsLin &o, const double *__restrict__ T, double Jl[9]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            Jl[3 * i + j] = o.A[3 * i] * T[3 + j] + o.A[3 * i + 1] * T[6 + j] + o.A[3 * i + 2] * T[9 + j];
-}
-// J_p = A [I | -q^] (3x6)   [dq/deps at eps = 0: perturbations.hpp:61-62, so3group.hpp:277-280]
-__device__ __forceinline__ void jac_pose(const ObsLin &o, double Jp[18]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double a0 = o.A[3 * i], a1 = o.A[3 * i + 1], a2 = o.A[3 * i + 2];
-        Jp[6 * i + 0] = a0;
-        Jp[6 * i + 1] = a1;
-        Jp[6 * i + 2] = a2;
-        Jp[6 * i + 3] = -a1 * o.q[2] + a2 * o.q[1];
-        Jp[6 * i + 4] = a0 * o.q[2] - a2 * o.q[0];
-        Jp[6 * i + 5] = -a0 * o.q[1] + a1 * o.q[0];
-    }
-}
-
-// so3group.hpp:273-291 ; perturbations.hpp:61-62 with se3group.hpp:176-183,323-325
-__device__ __forceinline__ void se3_plus(const double *__restrict__ T, const double *__restrict__ eps,
-                                         double *__restrict__ out) {
-    const double p0 = eps[3], p1 = eps[4], p2 = eps[5];
-    const double angle = sqrt(p0 * p0 + p1 * p1 + p2 * p2);
-    double E[9];
-    if (angle <= DBL_EPSILON) {
-        E[0] = 1.0; E[1] = -p2; E[2] = p1;
-        E[3] = p2;  E[4] = 1.0; E[5] = -p0;
-        E[6] = -p1; E[7] = p0;  E[8] = 1.0;
-    } else {
-        const double a0 = p0 / angle, a1 = p1 / angle, a2 = p2 / angle;
-        const double cp = cos(angle), sn = sin(angle), omc = 1.0 - cp;
-        E[0] = cp + omc * a0 * a0;      E[1] = omc * a0 * a1 - sn * a2; E[2] = omc * a0 * a2 + sn * a1;
-        E[3] = omc * a1 * a0 + sn * a2; E[4] = cp + omc * a1 * a1;      E[5] = omc * a1 * a2 - sn * a0;
-        E[6] = omc * a2 * a0 - sn * a1; E[7] = omc * a2 * a1 + sn * a0; E[8] = cp + omc * a2 * a2;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        out[i] = E[3 * i] * T[0] + E[3 * i + 1] * T[1] + E[3 * i + 2] * T[2] + eps[i];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-            out[3 + 3 * i + j] = E[3 * i] * T[3 + j] + E[3 * i + 1] * T[6 + j] + E[3 * i + 2] * T[9 + j];
-    }
-}
-
-// inverse of the damped 3x3 landmark block through its Cholesky factor.
-// h = (h00,h01,h02,h11,h12,h22), dmp = LM diagonal.  Returns false on breakdown.
-__device__ __forceinline__ bool inv3_spd(const double h[6], const double dmp[3], double Ci[6]) {
-    const double c00 = h[0] + dmp[0], c11 = h[3] + dmp[1], c22 = h[5] + dmp[2];
-    if (!(c00 > 0.0)) return false;
-    const double l00 = sqrt(c00);
-    const double l10 = h[1] / l00, l20 = h[2] / l00;
-    const double d1 = c11 - l10 * l10;
-    if (!(d1 > 0.0)) return false;
-    const double l11 = sqrt(d1);
-    const double l21 = (h[4] - l20 * l10) / l11;
-    const double d2 = c22 - l20 * l20 - l21 * l21;
-    if (!(d2 > 0.0)) return false;
-    const double l22 = sqrt(d2);
-    const double m00 = 1.0 / l00, m11 = 1.0 / l11, m22 = 1.0 / l22;
-    const double m10 = -l10 * m00 * m11;
-    const double m21 = -l21 * m11 * m22;
-    const double m20 = -(l20 * m00 + l21 * m10) * m22;
-    Ci[0] = m00 * m00 + m10 * m10 + m20 * m20;
-    Ci[1] = m10 * m11 + m20 * m21;
-    Ci[2] = m20 * m22;
-    Ci[3] = m11 * m11 + m21 * m21;
-    Ci[4] = m21 * m22;
-    Ci[5] = m22 * m22;
-    return true;
-}
-
-// radius that scales the LM-type diagonal: the trust-region radius for Levenberg-Marquardt, 1/mu for
-// the regularised Gauss-Newton solve of the dogleg strategy [dogleg_strategy.cc ComputeGaussNewtonStep]
-__device__ __forceinline__ double damp_radius(const State &st) { return st.opt.strategy ? 1.0 / st.mu : st.radius; }
-
-// LM diagonal of a landmark in unscaled coordinates:
-//   D^2 = clamp(s^2 h, min, max) / (radius s^2)   [levenberg_marquardt_strategy.cc on the
-//   Jacobi-scaled Jacobian, mapped back through delta = s .* step]
-__device__ __forceinline__ void landmark_damping(const Dev &d, const State &st, int l, const double h[6],
-                                                 double dmp[3]) {
-    const double hd[3] = {h[0], h[3], h[5]};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double s = d.sl[(size_t)c * d.Lpad + l];
-        const double s2 = s * s;
-        dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
-    }
 }
 
 // ------------------------------------------------------------------ kernels ---
@@ -358,45 +164,6 @@ constexpr int SCHUR_BATCH = 21;   // 21 landmarks x 12 slots = 252 producer lane
 constexpr int SCHUR_SPLIT = 3;    // 78 pairs x 3 = 234 consumer lanes, 7 landmarks each per batch
 constexpr int WY_STRIDE = 38;     // 36 doubles + 2 pad: 304 B, keeps 16-byte alignment
 constexpr int SCHUR_LDS_DOUBLES = SCHUR_BATCH * TW * WY_STRIDE + SCHUR_BATCH * 4;
-
-// 1/x and 1/sqrt(x) from the hardware estimates + Newton steps (IEEE divide / sqrt cost ~110 / ~150
-// dependent cycles on gfx950, tools/fp64_calib.hip); relative error ~1e-16
-__device__ __forceinline__ double fast_rcp(double a) {
-    double r = __builtin_amdgcn_rcp(a);
-    r = fma(fma(-a, r, 1.0), r, r);
-    r = fma(fma(-a, r, 1.0), r, r);
-    return r;
-}
-__device__ __forceinline__ double fast_rsqrt(double a) {
-    double r = __builtin_amdgcn_rsq(a);
-    r = r * (1.5 - 0.5 * a * r * r);
-    r = r * (1.5 - 0.5 * a * r * r);
-    return r;
-}
-// inverse of the damped 3x3 landmark block, Cholesky based, reciprocal square roots only
-__device__ __forceinline__ bool inv3_spd_fast(const double h[6], const double dmp[3], double Ci[6]) {
-    const double c00 = h[0] + dmp[0], c11 = h[3] + dmp[1], c22 = h[5] + dmp[2];
-    if (!(c00 > 0.0)) return false;
-    const double m00 = fast_rsqrt(c00);
-    const double l10 = h[1] * m00, l20 = h[2] * m00;
-    const double d1 = c11 - l10 * l10;
-    if (!(d1 > 0.0)) return false;
-    const double m11 = fast_rsqrt(d1);
-    const double l21 = (h[4] - l20 * l10) * m11;
-    const double d2 = c22 - l20 * l20 - l21 * l21;
-    if (!(d2 > 0.0)) return false;
-    const double m22 = fast_rsqrt(d2);
-    const double m10 = -l10 * m00 * m11;
-    const double m21 = -l21 * m11 * m22;
-    const double m20 = -(l20 * m00 + l21 * m10) * m22;
-    Ci[0] = m00 * m00 + m10 * m10 + m20 * m20;
-    Ci[1] = m10 * m11 + m20 * m21;
-    Ci[2] = m20 * m22;
-    Ci[3] = m11 * m11 + m21 * m21;
-    Ci[4] = m21 * m22;
-    Ci[5] = m22 * m22;
-    return true;
-}
 
 __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
     const State &st = *d.st;
@@ -732,7 +499,10 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
     if (!st.copy_best) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (size_t)d.P * 12) d.best_poses[i] = d.poses[i];
-    if (i < (size_t)d.Lpad * 3) d.best_pts[i] = d.pts[i];
+    if (i < (size_t)d.Lpad * 3) {
+        d.best_pts[i] = d.pts[i];
+        if (d.phong) d.best_nrm[i] = d.nrm[i];
+    }
 }
 __global__ void k_best_done(Dev d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d.st->copy_best = 0;
@@ -1258,7 +1028,10 @@ __global__ __launch_bounds__(256) void k_commit(Dev d) {
     if (st.terminated || !st.accepted) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (size_t)d.P * 12) d.poses[i] = d.cand_poses[i];
-    if (i < (size_t)d.Lpad * 3) d.pts[i] = d.cand_pts[i];
+    if (i < (size_t)d.Lpad * 3) {
+        d.pts[i] = d.cand_pts[i];
+        if (d.phong) d.nrm[i] = d.cand_nrm[i];
+    }
 }
 
 // (re)start of a solve: reset the trust-region state on the device
@@ -1289,13 +1062,18 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
 }
 
 void launch_linearize(Launcher &L, const Dev &d) {
-    LAUNCH(KC_LIN_LM, k_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_LIN_POSE, k_linearize_poses, dim3(d.P), dim3(256), 0, d);
+    if (d.phong) {
+        launch_ph_linearize(L, d);
+    } else {
+        LAUNCH(KC_LIN_LM, k_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
+        LAUNCH(KC_LIN_POSE, k_linearize_poses, dim3(d.P), dim3(256), 0, d);
+    }
     LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d);
 }
 
 void launch_schur(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d);
+    if (d.phong) launch_ph_schur(L, d);
+    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d);
     hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)d.nfree * 6;
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
@@ -1311,7 +1089,8 @@ void launch_finish_check(Launcher &L, const Dev &d) {
 
 void launch_update_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
-    LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    if (d.phong) launch_ph_backsub_eval(L, d);
+    else LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
 }
 

@@ -98,5 +98,11 @@ void launch_bcr(Launcher &L, const Dev &d);
 void launch_update_eval(Launcher &L, const Dev &d);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
 void launch_decide_commit(Launcher &L, const Dev &d);
+// config 3 (ssba_phong_solver.hip)
+int upload_phong_tables(hipStream_t s);
+int configure_phong();
+void launch_ph_linearize(Launcher &L, const Dev &d);
+void launch_ph_schur(Launcher &L, const Dev &d);
+void launch_ph_backsub_eval(Launcher &L, const Dev &d);
 
 }  // namespace ssba

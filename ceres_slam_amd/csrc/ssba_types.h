@@ -97,7 +97,7 @@ struct Dev {
     const uint32_t *pose_obs_start;  // P+1
     const uint32_t *pose_obs_ref;    // n_obs: landmark*16 + slot
     // linearisation
-    double *hll, *gl, *sl;           // 6*Lpad, 3*Lpad, 3*Lpad (component-major)
+    double *hll, *gl, *sl;           // 6*Lpad, 3*Lpad, 3*Lpad (component-major); config 3: 21 / 6 / 6 rows
     double *hpp, *gp;                // P*21 (upper, row-major packed), P*6
     double *sp;                      // nf_pad*6 Jacobi scale of free poses
     // Schur
@@ -123,6 +123,15 @@ struct Dev {
     State *st;
     IterLog log;
     unsigned long long *dbg;         // in-kernel stamps (diagnostic builds only, -DSSBA_STAMPS)
+    // config 3 (stereo + Phong intensity + normal blocks; landmark block = [position | normal])
+    int phong, light_type;
+    double light[3], int_stiff, Sn[9];
+    double *nrm, *cand_nrm, *best_nrm, *init_nrm;   // 3*Lpad, component-major
+    const double *oi, *onx, *ony, *onz;             // ELL: observed intensity and normal
+    const uint32_t *lm_mat;                         // Lpad -> material
+    const double *mat;                              // M*4: ka, ks, alpha, kd (texture)
+    double *cinv;                                   // 21*Lpad damped landmark block inverse
+    double *dlm;                                    // 6*Lpad landmark step (local coordinates)
 };
 
 }  // namespace ssba

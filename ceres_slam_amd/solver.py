@@ -15,7 +15,7 @@ from . import capi
 class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
                  stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
-                 world_size: int = 1, rank: int = 0):
+                 world_size: int = 1, rank: int = 0, lighting: dict = None):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
         self.points = np.ascontiguousarray(points, dtype=np.float64)
@@ -41,10 +41,33 @@ class StereoBA:
         if huber_a > 0:
             capi.check(self.lib.ssba_set_huber_loss(self.h, float(huber_a)), "ssba_set_huber_loss")
         self._xcb = None
+        self.normals = None
+        if lighting is not None:
+            self._add_lighting(lighting)
         if world_size > 1:
             capi.check(self.lib.ssba_set_distributed(self.h, world_size, rank), "ssba_set_distributed")
         if finalize:
             self.finalize()
+
+    def _add_lighting(self, lt: dict):
+        """Config-3 terms (include/ssba.h "config 3"); `lt` has the keys of synth.PhongData.as_oracle_dict()."""
+        L, N = self.points.shape[0], self._obs_pose.shape[0]
+        self.normals = np.ascontiguousarray(lt["normals"], dtype=np.float64).copy()   # caller-owned block, updated in place
+        self._phong = np.ascontiguousarray(lt["phong"], dtype=np.float64)
+        self._texture = np.ascontiguousarray(lt["texture"], dtype=np.float64)
+        self._mat = np.ascontiguousarray(lt["material_of_point"], dtype=np.uint32)
+        self._light = np.ascontiguousarray(lt["light"], dtype=np.float64)
+        self._int = np.ascontiguousarray(lt["intensity"], dtype=np.float64)
+        self._nobs = np.ascontiguousarray(lt["normal_obs"], dtype=np.float64)
+        self._Sn = np.ascontiguousarray(np.asarray(lt["normal_stiffness"], dtype=np.float64).reshape(9))
+        assert self.normals.shape == (L, 3) and self._int.shape == (N,) and self._nobs.shape == (N, 3)
+        capi.check(self.lib.ssba_add_normal_blocks(self.h, capi.dptr(self.normals), L), "ssba_add_normal_blocks")
+        capi.check(self.lib.ssba_set_materials(self.h, capi.dptr(self._phong), capi.dptr(self._texture), self._texture.shape[0],
+                                               self._mat.ctypes.data_as(capi._u32p), L), "ssba_set_materials")
+        capi.check(self.lib.ssba_set_light(self.h, capi.dptr(self._light), int(lt["light_type"])), "ssba_set_light")
+        capi.check(self.lib.ssba_add_lighting_observations(self.h, capi.dptr(self._int), float(lt["int_stiffness"]),
+                                                           capi.dptr(self._nobs), capi.dptr(self._Sn), N),
+                   "ssba_add_lighting_observations")
 
     @classmethod
     def from_synth(cls, prob, **kw):
@@ -154,8 +177,9 @@ class StereoBA:
     def evaluate(self):
         P, L = self.poses.shape[0], self.points.shape[0]
         cost = C.c_double()
-        g_p, g_l = np.zeros((P, 6)), np.zeros((L, 3))
-        H_pp, H_ll = np.zeros((P, 6, 6)), np.zeros((L, 3, 3))
+        ld = 6 if self.normals is not None else 3
+        g_p, g_l = np.zeros((P, 6)), np.zeros((L, ld))
+        H_pp, H_ll = np.zeros((P, 6, 6)), np.zeros((L, ld, ld))
         capi.check(self.lib.ssba_evaluate(self.h, C.byref(cost), capi.dptr(g_p), capi.dptr(g_l), capi.dptr(H_pp),
                                           capi.dptr(H_ll)), "ssba_evaluate")
         return cost.value, g_p, g_l, H_pp, H_ll
@@ -165,7 +189,7 @@ class StereoBA:
         n = 6 * self.stats().num_free_poses
         S = np.zeros((n, n)) if want_S else None
         rhs = np.zeros(n)
-        dp, dl = np.zeros((P, 6)), np.zeros((L, 3))
+        dp, dl = np.zeros((P, 6)), np.zeros((L, 6 if self.normals is not None else 3))
         mcc = C.c_double()
         o = options or capi.default_options()
         capi.check(self.lib.ssba_lm_step(self.h, C.byref(o), radius, capi.dptr(S) if want_S else None, capi.dptr(rhs),

@@ -213,6 +213,38 @@ int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, doubl
 int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S,
                  double *rhs, double *delta_p, double *delta_l, double *model_cost_change);
 
+/* ---- config 3: lighting terms on the same graph (tests/dataset_ba_phong.cpp:101-204) ---- */
+/* The Phong driver adds, for every stereo observation (pose k, vertex j), an intensity residual
+ * block (pose, position, normal, material Phong parameters, texture, light; :108-139) and a normal
+ * residual block (pose, normal; :181-188), with UnitVectorPerturbation on the normal (:191-193).
+ * This build optimises poses, positions and normals (landmark block = [position | normal], 6-D
+ * local step) and holds the shared blocks constant -- the state the driver's commented
+ * SetParameterBlockConstant lines (:166-172, :205-206) select: material parameters, textures and
+ * the light.  (Free shared blocks add a dense border to the reduced system; that and the
+ * parameter bounds (:142-180) are the next row, see DESIGN.md.)
+ *
+ * ssba_add_normal_blocks   : replaces AddParameterBlock/SetParameterization of
+ *                            map_vertices[j].normal() ; normals (num*3) caller-owned, updated in
+ *                            place by ssba_solve like the points; num must equal the point count.
+ * ssba_set_materials       : phong (M*3: ka, ks, alpha), texture (M: kd) and the material of each
+ *                            point (num_points entries); copied.
+ * ssba_set_light           : light position (light_type 0) or direction (1); copied.
+ * ssba_add_lighting_observations : intensity (num) and observed normal (num*3) of the i-th stereo
+ *                            observation already added (same order), 1/sqrt(int_var) and the 3x3
+ *                            normal stiffness; num must equal the stereo observation count at
+ *                            ssba_finalize.
+ * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
+ * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  Huber loss, DOGLEG and landmark
+ * sharding are not available together with lighting terms yet (SSBA_ERR_UNSUPPORTED). */
+int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);
+int ssba_set_materials(ssba_problem *p, const double *phong, const double *texture,
+                       uint32_t num_materials, const uint32_t *material_of_point,
+                       uint32_t num_points);
+int ssba_set_light(ssba_problem *p, const double light[3], int light_type);
+int ssba_add_lighting_observations(ssba_problem *p, const double *intensity,
+                                   double intensity_stiffness, const double *normal_obs,
+                                   const double normal_stiffness[9], uint64_t num);
+
 /* ---- Phong-lighting rows: batch evaluation on the device ------ */
 /* replaces, for each of n residual-block instances, the evaluation Ceres performs on
  *   IntensityErrorPointLightAutomatic / IntensityErrorDirectionalLightAutomatic

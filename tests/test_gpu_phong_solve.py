@@ -1,0 +1,103 @@
+"""Config 3 on the GPU (stereo + Phong intensity + normal residual blocks, landmark block =
+[position | normal], tests/dataset_ba_phong.cpp:101-204 with the shared light / material / texture
+blocks held constant), called through the C ABI and compared with the CPU oracle on the same seeded
+inputs.  fp64; block-level quantities <= 1e-10 relative, whole solves: the same accept / reject
+sequence and final cost <= 1e-6 relative."""
+import numpy as np
+import pytest
+
+from ceres_slam_amd import capi, synth
+from ceres_slam_amd.solver import StereoBA
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _pair(prob, ph):
+    ba = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict())
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=ph.as_oracle_dict())
+    return ba, op
+
+
+@pytest.mark.parametrize("light_type", [0, 1])
+def test_phong_normal_equation_blocks_match_oracle(light_type):
+    prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7, light_type=light_type)
+    ba, op = _pair(prob, ph)
+    cost, g_p, g_l, H_pp, H_ll = ba.evaluate()
+    c2, gp2, gl2, Hp2, Hl2 = op.linearize()
+    gp2[0] = 0
+    Hp2[0] = 0
+    assert g_l.shape == (60, 6) and H_ll.shape == (60, 6, 6)
+    assert cost == pytest.approx(c2, rel=1e-12)
+    assert _rel(g_p, gp2) < 1e-10 and _rel(g_l, gl2) < 1e-10
+    assert _rel(H_pp, Hp2) < 1e-10 and _rel(H_ll, Hl2) < 1e-10
+
+
+@pytest.mark.parametrize("light_type", [0, 1])
+@pytest.mark.parametrize("radius", [1e4, 5.0])
+def test_phong_reduced_system_and_step_match_oracle(light_type, radius):
+    prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7, light_type=light_type)
+    ba, op = _pair(prob, ph)
+    S, rhs, dp, dl, mcc = ba.lm_step(radius)
+    S2, rhs2, _ = op.reduced_system(radius)
+    dp2, dl2, mcc2 = op.lm_step(radius)
+    assert _rel(S, S2) < 1e-9 and _rel(rhs, rhs2) < 1e-9
+    assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7
+    assert mcc == pytest.approx(mcc2, rel=1e-8)
+
+
+@pytest.mark.parametrize("light_type", [0, 1])
+def test_phong_solve_matches_oracle(light_type):
+    prob, ph = synth.make_phong_problem(50, 2000, light_type=light_type)
+    ba, op = _pair(prob, ph)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4))
+    assert s.termination_type == s2.termination_type == 0
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-8)
+    np.testing.assert_allclose(log["trust_region_radius"], log2["trust_region_radius"], rtol=1e-5)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+    assert np.abs(ba.poses - op.poses).max() < 1e-6
+    assert np.abs(ba.points - op.points).max() < 1e-5
+    assert np.abs(ba.normals - op.normals).max() < 1e-6
+    assert np.abs(np.linalg.norm(ba.normals, axis=1) - 1).max() < 1e-12     # UnitVectorPerturbation keeps |n| = 1
+    assert np.array_equal(ba.poses[0], prob.poses_init[0])
+
+
+def test_phong_ragged_tracks_and_long_window():
+    # ragged masks, several Schur work items per window, more than one super-block
+    prob, ph = synth.make_phong_problem(30, 3000, seed=11)
+    keep = np.ones(prob.num_obs, dtype=bool)
+    keep[::7] = False
+    d = ph.as_oracle_dict()
+    d["intensity"] = d["intensity"][keep]
+    d["normal_obs"] = d["normal_obs"][keep]
+    args = (prob.camera, prob.poses_init, prob.points_init, prob.obs_pose[keep], prob.obs_point[keep], prob.obs_uvd[keep],
+            prob.stiffness())
+    ba = StereoBA(args[0], args[1].copy(), args[2].copy(), *args[3:], lighting=d)
+    op = orc.OracleProblem(*args, lighting=d)
+    S, rhs, dp, dl, mcc = ba.lm_step(1e3)
+    dp2, dl2, mcc2 = op.lm_step(1e3)
+    assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7
+    assert mcc == pytest.approx(mcc2, rel=1e-8)
+
+
+def test_phong_unsupported_combinations_fail_loudly():
+    prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7)
+    ba = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict())
+    with pytest.raises(capi.SsbaError):
+        ba.solve(capi.default_options(trust_region_strategy_type=1))
+    ba2 = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict(), huber_a=1.0)
+    with pytest.raises(capi.SsbaError):
+        ba2.solve(capi.default_options())
+    # lighting observations must pair with the stereo observations
+    d = ph.as_oracle_dict()
+    d["intensity"] = d["intensity"][:-1]
+    d["normal_obs"] = d["normal_obs"][:-1]
+    with pytest.raises((capi.SsbaError, AssertionError)):
+        StereoBA.from_synth(prob, lighting=d)
