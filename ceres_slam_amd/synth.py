@@ -297,6 +297,12 @@ class PhongData:
     normal_obs: np.ndarray         # (N,3) observed normals, camera frame
     int_var: float
     normal_obs_var: np.ndarray     # (3,)
+    # initial guesses of the shared blocks when they are optimised (ssba_set_shared_blocks_free)
+    phong_init: np.ndarray = None    # (M,3) perturbed truth, interior to the driver's bounds
+    texture_init: np.ndarray = None  # (M,)
+    light_init: np.ndarray = None    # (3,)
+    phong_ref_init: np.ndarray = None    # (M,3) = (0,0,1): dataset_problem_phong.cpp:266-267
+    texture_ref_init: np.ndarray = None  # (M,) median observed intensity of the material: :269-277
 
     @property
     def int_stiffness(self) -> float:
@@ -305,9 +311,16 @@ class PhongData:
     def normal_stiffness(self) -> np.ndarray:
         return np.diag(1.0 / np.sqrt(self.normal_obs_var))       # tests/dataset_ba_phong.cpp:39-42
 
-    def as_oracle_dict(self) -> dict:
-        return dict(normals=self.normals_init, intensity=self.intensity, normal_obs=self.normal_obs, phong=self.phong,
-                    texture=self.texture, material_of_point=self.material_of_point, light=self.light,
+    def as_oracle_dict(self, shared: str = "truth") -> dict:
+        """shared = "truth" (the constant-block configuration), "perturbed" (interior initial guess) or
+        "reference" (the reference's compute_initial_guess values; the light stays "perturbed")."""
+        phong, texture, light = self.phong, self.texture, self.light
+        if shared == "perturbed":
+            phong, texture, light = self.phong_init, self.texture_init, self.light_init
+        elif shared == "reference":
+            phong, texture, light = self.phong_ref_init, self.texture_ref_init, self.light_init
+        return dict(normals=self.normals_init, intensity=self.intensity, normal_obs=self.normal_obs, phong=phong.copy(),
+                    texture=texture.copy(), material_of_point=self.material_of_point, light=light.copy(),
                     light_type=self.light_type, int_stiffness=self.int_stiffness, normal_stiffness=self.normal_stiffness())
 
 
@@ -368,5 +381,21 @@ def make_phong_problem(num_poses: int, num_points: int, *, num_materials: int = 
     jj, idx = np.unique(j, return_index=True)
     n0 = np.einsum("nji,nj->ni", R_i[k[idx]], normal_obs[idx])
     normals_init[jj] = n0 / np.linalg.norm(n0, axis=1)[:, None]
+    # shared-block initial guesses (drawn last so that the data above do not depend on them)
+    phong_init = phong * np.array([1.0, 1.0, 1.0]) + np.stack([np.zeros(num_materials), 0.05 * rng.standard_normal(num_materials),
+                                                              1.0 * rng.standard_normal(num_materials)], 1)
+    phong_init[:, 1] = np.clip(phong_init[:, 1], 0.02, 0.98)
+    phong_init[:, 2] = np.maximum(phong_init[:, 2], 1.2)
+    texture_init = np.clip(texture + 0.05 * rng.standard_normal(num_materials), 0.05, 0.95)
+    if light_type == 0:
+        light_init = light + 0.5 * rng.standard_normal(3)
+    else:
+        light_init = light + 0.05 * rng.standard_normal(3)
+        light_init /= np.linalg.norm(light_init)
+    texture_ref = np.zeros(num_materials)
+    for m in range(num_materials):
+        ints = np.sort(intensity[mat[j] == m])
+        texture_ref[m] = ints[len(ints) // 2] if len(ints) else 0.5       # std::nth_element(begin + size/2)
+    phong_ref = np.tile(np.array([0.0, 0.0, 1.0]), (num_materials, 1))
     return prob, PhongData(normals_gt, normals_init, mat, phong, texture, light, light_type, intensity, normal_obs,
-                           int_var, np.full(3, normal_var))
+                           int_var, np.full(3, normal_var), phong_init, texture_init, light_init, phong_ref, texture_ref)

@@ -32,7 +32,8 @@ class Problem(C.Structure):
                 ("stiffness", C.c_double * 9), ("pose_const", _u8p), ("huber_a", C.c_double),
                 ("normals", _dp), ("intensity", _dp), ("normal_obs", _dp), ("phong", _dp), ("texture", _dp),
                 ("material_of_point", _u32p), ("light", C.c_double * 3), ("light_type", C.c_int32),
-                ("reserved", C.c_int32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9)]
+                ("shared_free", C.c_uint32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9),
+                ("num_materials", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class Options(C.Structure):
@@ -94,6 +95,8 @@ def lib():
         L.orc_linearize.restype = C.c_double
         L.orc_reduced_system.argtypes = [C.POINTER(Problem), C.c_double, C.POINTER(Options), _dp, _dp, _i32p]
         L.orc_lm_step.argtypes = [C.POINTER(Problem), C.c_double, C.POINTER(Options), _dp, _dp, _dp]
+        L.orc_lm_step_border.argtypes = [C.POINTER(Problem), C.c_double, C.POINTER(Options), _dp, _dp, _dp, _dp]
+        L.orc_border_size.argtypes = [C.POINTER(Problem)]
         L.orc_solve.argtypes = [C.POINTER(Problem), C.POINTER(Options), C.POINTER(Summary), C.POINTER(IterationLog)]
         _lib = L
     return _lib
@@ -124,7 +127,7 @@ class OracleProblem:
     """Owns numpy copies of a problem and the ctypes view the C oracle reads."""
 
     def __init__(self, camera: dict, poses, points, obs_pose, obs_point, obs_uvd, stiffness,
-                 pose_const=None, huber_a: float = 0.0, lighting=None):
+                 pose_const=None, huber_a: float = 0.0, lighting=None, shared_free: int = 0):
         self.poses = np.ascontiguousarray(poses, dtype=np.float64).copy()
         self.points = np.ascontiguousarray(points, dtype=np.float64).copy()
         self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
@@ -152,7 +155,13 @@ class OracleProblem:
         if lighting is not None:       # dict: normals, intensity, normal_obs, phong, texture, material_of_point, light, light_type, int_stiffness, normal_stiffness
             self.ld = 6
             self.normals = np.ascontiguousarray(lighting["normals"], dtype=np.float64).copy()
-            self._lt = {k: np.ascontiguousarray(lighting[k], dtype=np.float64) for k in ("intensity", "normal_obs", "phong", "texture")}
+            self._lt = {k: np.ascontiguousarray(lighting[k], dtype=np.float64) for k in ("intensity", "normal_obs")}
+            # shared blocks: updated in place when freed (bit 0 light, bit 1 Phong parameters, bit 2 textures)
+            self.phong = np.ascontiguousarray(lighting["phong"], dtype=np.float64).copy()
+            self.texture = np.ascontiguousarray(lighting["texture"], dtype=np.float64).copy()
+            self._lt["phong"], self._lt["texture"] = self.phong, self.texture
+            self.c.num_materials = self.texture.shape[0]
+            self.c.shared_free = int(shared_free)
             self._mat = np.ascontiguousarray(lighting["material_of_point"], dtype=np.uint32)
             self.c.normals = _p(self.normals)
             self.c.intensity, self.c.normal_obs = _p(self._lt["intensity"]), _p(self._lt["normal_obs"])
@@ -182,23 +191,34 @@ class OracleProblem:
     def reduced_system(self, radius: float, options: Options = None):
         o = options or default_options()
         P = self.c.num_poses
-        nmax = 6 * P
+        nb = self.border_size()
+        nmax = 6 * P + nb
         S, rhs = np.zeros((nmax, nmax)), np.zeros(nmax)
         free_idx = np.zeros(P, dtype=np.int32)
         rc = lib().orc_reduced_system(C.byref(self.c), radius, C.byref(o), _p(S), _p(rhs),
                                       free_idx.ctypes.data_as(_i32p))
         if rc:
             raise RuntimeError("orc_reduced_system failed")
-        n = 6 * int((free_idx >= 0).sum())
+        n = 6 * int((free_idx >= 0).sum()) + nb     # with free shared blocks: the (poses + border) arrowhead
         return S.reshape(-1)[: n * n].reshape(n, n).copy(), rhs[:n].copy(), free_idx
 
-    def lm_step(self, radius: float, options: Options = None):
+    @property
+    def light(self) -> np.ndarray:
+        return np.array(list(self.c.light))
+
+    def border_size(self) -> int:
+        return int(lib().orc_border_size(C.byref(self.c))) if self.ld == 6 else 0
+
+    def lm_step(self, radius: float, options: Options = None, want_border: bool = False):
         o = options or default_options()
         dp, dl = np.zeros((self.c.num_poses, 6)), np.zeros((self.c.num_points, self.ld))
+        db = np.zeros(max(self.border_size(), 1))
         mcc = C.c_double(0.0)
-        rc = lib().orc_lm_step(C.byref(self.c), radius, C.byref(o), _p(dp), _p(dl), C.byref(mcc))
+        rc = lib().orc_lm_step_border(C.byref(self.c), radius, C.byref(o), _p(dp), _p(dl), _p(db), C.byref(mcc))
         if rc:
             raise RuntimeError("orc_lm_step failed")
+        if want_border:
+            return dp, dl, db[: self.border_size()], mcc.value
         return dp, dl, mcc.value
 
     def solve(self, options: Options = None, log_capacity: int = 1024):

@@ -235,8 +235,19 @@ void orc_default_options(orc_options *o) {
  *   stereo only (tests/dataset_vo.cpp):            NR = 3 residuals per observation, LD = 3
  *   stereo + Phong lighting (dataset_ba_phong.cpp): NR = 7 (stereo 3 | intensity 1 | normal 3),
  *     landmark block LD = 6 = [position | normal], the normal through UnitVectorPerturbation;
- *     the shared light / material / texture blocks are held constant in this build.
+ *     the shared light / material / texture blocks (dataset_ba_phong.cpp:108-139) are free
+ *     when `shared_free` says so: they form a dense "border" of local size
+ *     nb = 3 [light] + 3 M [ka, ks, alpha per material] + M [kd per material].
  * Residual-block order inside an observation follows the driver: stereo, intensity, normal. */
+
+/* packed ambient state of the shared blocks: [light 3 | phong 3M | texture M] */
+static int shared_size(const orc_problem *p) { return 3 + 4 * (int)p->num_materials; }
+static void shared_pack(const orc_problem *p, double *sh) {
+    const int M = (int)p->num_materials;
+    memcpy(sh, p->light, 3 * sizeof(double));
+    memcpy(sh + 3, p->phong, (size_t)3 * M * sizeof(double));
+    memcpy(sh + 3 + 3 * M, p->texture, (size_t)M * sizeof(double));
+}
 
 static int is_phong(const orc_problem *p) { return p->intensity != NULL; }
 static int dim_nr(const orc_problem *p) { return is_phong(p) ? 7 : 3; }
@@ -254,7 +265,10 @@ static void set_threads(int n) {
  * Returns cost = 1/2 sum rho(|r|^2); r/J are the loss-CORRECTED quantities, as
  * Ceres's ResidualBlock::Evaluate hands them to the minimiser. */
 static double evaluate(const orc_problem *p, const double *poses, const double *points,
-                       const double *normals, double *r_out, double *Jp_out, double *Jl_out) {
+                       const double *normals, const double *sh, double *r_out, double *Jp_out, double *Jl_out,
+                       double *Jb_out) {
+    const int Mm = (int)p->num_materials;
+    const double *light = sh ? sh : p->light, *phong = sh ? sh + 3 : p->phong, *texture = sh ? sh + 3 + 3 * Mm : p->texture;
     const int64_t N = p->num_obs;
     const int nr = dim_nr(p), ld = dim_ld(p), ph = is_phong(p);
     double cost = 0.0;
@@ -288,9 +302,10 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
         if (ph) {
             const uint32_t mat = p->material_of_point[j];
             double ri, J19[19], rn[3], Jnp[18], Jnn[9];
-            orc_intensity_residual(p->light_type, T, points + 3 * j, normals + 3 * j, p->phong + 3 * mat,
-                                   p->texture[mat], p->light, p->intensity[i], p->int_stiffness, &ri,
+            orc_intensity_residual(p->light_type, T, points + 3 * j, normals + 3 * j, phong + 3 * mat,
+                                   texture[mat], light, p->intensity[i], p->int_stiffness, &ri,
                                    wantJ ? J19 : NULL);
+            if (wantJ && Jb_out) memcpy(Jb_out + 7 * i, J19 + 12, 7 * sizeof(double));   /* [phong 3 | kd | light 3] */
             orc_normal_residual(T, normals + 3 * j, p->normal_obs + 3 * i, p->normal_stiffness, rn,
                                 wantJ ? Jnp : NULL, wantJ ? Jnn : NULL);
             r[3] = ri;
@@ -316,7 +331,7 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
 
 double orc_cost(const orc_problem *p, int num_threads) {
     set_threads(num_threads);
-    return evaluate(p, p->poses, p->points, p->normals, NULL, NULL, NULL);
+    return evaluate(p, p->poses, p->points, p->normals, NULL, NULL, NULL, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------ */
@@ -334,7 +349,16 @@ typedef struct {
     int64_t *pt_start;   /* L+1 CSR (landmark-major)                              */
     int64_t *pt_obs;     /* N                                                     */
     int bw_poses;        /* max |free_idx(a)-free_idx(b)| over co-observing poses */
+    /* free shared blocks ("border"): column offsets in the local border vector, -1 = constant */
+    int M, nb, b_light, b_phong, b_tex;
 } graph_t;
+
+/* border column of entry q of the per-observation border Jacobian [phong 3 | kd | light 3] */
+static int bcol(const graph_t *g, uint32_t mat, int q) {
+    if (q < 3) return g->b_phong < 0 ? -1 : g->b_phong + 3 * (int)mat + q;
+    if (q == 3) return g->b_tex < 0 ? -1 : g->b_tex + (int)mat;
+    return g->b_light < 0 ? -1 : g->b_light + (q - 4);
+}
 
 static void graph_free(graph_t *g) {
     free(g->free_idx); free(g->free_pose); free(g->pt_active);
@@ -347,6 +371,13 @@ static void graph_build(const orc_problem *p, graph_t *g) {
     int64_t N = p->num_obs;
     g->P = P; g->L = L; g->N = N;
     g->nr = dim_nr(p); g->ld = dim_ld(p);
+    g->M = is_phong(p) ? (int)p->num_materials : 0;
+    g->b_light = g->b_phong = g->b_tex = -1;
+    if (is_phong(p)) {
+        if (p->shared_free & 1u) { g->b_light = g->nb; g->nb += 3; }
+        if (p->shared_free & 2u) { g->b_phong = g->nb; g->nb += 3 * g->M; }
+        if (p->shared_free & 4u) { g->b_tex = g->nb; g->nb += g->M; }
+    }
     g->pose_start = calloc((size_t)P + 1, sizeof(int64_t));
     g->pt_start = calloc((size_t)L + 1, sizeof(int64_t));
     g->pose_obs = malloc((size_t)(N > 0 ? N : 1) * sizeof(int64_t));
@@ -482,6 +513,8 @@ typedef struct {
     double *g_l;     /* L*LD                                         */
     double *sq_p;    /* nfree*6  squared column norms of unscaled J  */
     double *sq_l;    /* L*LD                                         */
+    double *Jb;      /* N*7 border entries of the intensity row, or NULL */
+    double *g_b, *sq_b;   /* nb                                      */
     double cost;
 } lin_t;
 
@@ -495,16 +528,35 @@ static void lin_alloc(lin_t *w, const graph_t *g) {
     w->g_l = malloc(L * g->ld * sizeof(double));
     w->sq_p = malloc(nf * 6 * sizeof(double));
     w->sq_l = malloc(L * g->ld * sizeof(double));
+    w->Jb = g->nb ? malloc(N * 7 * sizeof(double)) : NULL;
+    w->g_b = calloc((size_t)g->nb + 1, sizeof(double));
+    w->sq_b = calloc((size_t)g->nb + 1, sizeof(double));
 }
 static void lin_free(lin_t *w) {
     free(w->r); free(w->Jp); free(w->Jl); free(w->g_p); free(w->g_l); free(w->sq_p); free(w->sq_l);
+    free(w->Jb); free(w->g_b); free(w->sq_b);
 }
 
 /* [Ceres evaluator: residuals, cost, Jacobian, gradient = J^T r at x] */
 static void linearize(const orc_problem *p, const graph_t *g, const double *poses,
-                      const double *points, const double *normals, lin_t *w) {
+                      const double *points, const double *normals, const double *sh, lin_t *w) {
     const int nr = g->nr, ld = g->ld;
-    w->cost = evaluate(p, poses, points, normals, w->r, w->Jp, w->Jl);
+    w->cost = evaluate(p, poses, points, normals, sh, w->r, w->Jp, w->Jl, w->Jb);
+    if (g->nb) {   /* border gradient and squared column norms: only the intensity row (3) touches it */
+        memset(w->g_b, 0, (size_t)g->nb * sizeof(double));
+        memset(w->sq_b, 0, (size_t)g->nb * sizeof(double));
+        for (int64_t i = 0; i < g->N; ++i) {
+            const uint32_t mat = p->material_of_point[p->obs_point[i]];
+            const double ri = w->r[(size_t)nr * i + 3];
+            for (int q = 0; q < 7; ++q) {
+                const int c = bcol(g, mat, q);
+                if (c < 0) continue;
+                const double v = w->Jb[7 * i + q];
+                w->g_b[c] += v * ri;
+                w->sq_b[c] += v * v;
+            }
+        }
+    }
 #pragma omp parallel for schedule(static)
     for (int f = 0; f < g->nfree; ++f) {
         int k = g->free_pose[f];
@@ -546,7 +598,7 @@ double orc_linearize(const orc_problem *p, double *g_p, double *g_l, double *H_p
     size_t n = (size_t)(N > 0 ? N : 1);
     double *r = malloc(n * nr * sizeof(double)), *Jp = malloc(n * nr * 6 * sizeof(double)),
            *Jl = malloc(n * nr * ld * sizeof(double));
-    double cost = evaluate(p, p->poses, p->points, p->normals, r, Jp, Jl);
+    double cost = evaluate(p, p->poses, p->points, p->normals, NULL, r, Jp, Jl, NULL);
     memset(g_p, 0, (size_t)p->num_poses * 6 * sizeof(double));
     memset(g_l, 0, (size_t)p->num_points * ld * sizeof(double));
     memset(H_pp, 0, (size_t)p->num_poses * 36 * sizeof(double));
@@ -572,9 +624,10 @@ double orc_linearize(const orc_problem *p, double *g_p, double *g_l, double *H_p
 
 /* Jacobi scaling [Ceres trust_region_minimizer.cc IterationZero]:
  *   scale = 1 / (1 + sqrt(squared column norm)) computed once at iteration 0 */
-static void jacobi_scale(const graph_t *g, const lin_t *w, int enabled, double *sp, double *sl) {
+static void jacobi_scale(const graph_t *g, const lin_t *w, int enabled, double *sp, double *sl, double *sb) {
     for (int i = 0; i < g->nfree * 6; ++i) sp[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_p[i])) : 1.0;
     for (int i = 0; i < g->L * g->ld; ++i) sl[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_l[i])) : 1.0;
+    for (int i = 0; i < g->nb; ++i) sb[i] = enabled ? 1.0 / (1.0 + sqrt(w->sq_b[i])) : 1.0;
 }
 
 typedef struct {
@@ -585,15 +638,21 @@ typedef struct {
     double *gl_s; /* L*LD    scaled landmark gradient                       */
     int n, bw;
     double t_schur, t_solve;
+    /* border (free shared blocks), scaled coordinates */
+    int nb;
+    double *Spb;  /* n x nb   S_pb = H_pb - sum W C^-1 V                    */
+    double *Sbb;  /* nb x nb  H_bb + D_b^2 - sum V^T C^-1 V                 */
+    double *rhs_b;/* nb       g_b - sum V^T C^-1 g_l                        */
+    double *V;    /* L*LD*7   H_lb of landmark j: columns [phong 3 | kd | light 3] of its material */
 } schur_t;
 
 /* Build the Schur-complemented reduced camera system in SCALED coordinates
  * [Ceres schur_eliminator_impl.h restated; LM diagonal of
  * levenberg_marquardt_strategy.cc: D^2 = clamp(diag(J_s^T J_s), min, max)/radius]. */
 static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
-                         const double *sp, const double *sl, double radius,
+                         const double *sp, const double *sl, const double *sb, double radius,
                          const orc_options *o, schur_t *sc) {
-    const int nf = g->nfree, L = g->L, nr = g->nr, ld = g->ld;
+    const int nf = g->nfree, L = g->L, nr = g->nr, ld = g->ld, nb = g->nb;
     const int n = 6 * nf;
     int bw = 6 * (g->bw_poses + 1) - 1;
     if (bw > n - 1) bw = n - 1;
@@ -605,6 +664,13 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
     sc->Ci = malloc((size_t)(L > 0 ? L : 1) * ld * ld * sizeof(double));
     sc->W = malloc((size_t)(g->N > 0 ? g->N : 1) * 6 * ld * sizeof(double));
     sc->gl_s = malloc((size_t)(L > 0 ? L : 1) * ld * sizeof(double));
+    sc->nb = nb;
+    if (nb) {
+        sc->Spb = calloc((size_t)(n > 0 ? n : 1) * nb, sizeof(double));
+        sc->Sbb = calloc((size_t)nb * nb, sizeof(double));
+        sc->rhs_b = calloc((size_t)nb, sizeof(double));
+        sc->V = calloc((size_t)(L > 0 ? L : 1) * ld * 7, sizeof(double));
+    }
     int bad = 0;
 
     /* landmark blocks C_j = sum Jl_s^T Jl_s + D_l^2 and their inverses */
@@ -628,6 +694,74 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
         if (inv_spd(ld, C, sc->Ci + (size_t)ld * ld * j)) bad |= 1;
     }
     if (bad) return -1;
+
+    if (nb) {
+        /* H_bb + D_b^2 and g_b (serial: reference residual-block order), V_j = H_lb of each landmark */
+        for (int64_t i = 0; i < g->N; ++i) {
+            const uint32_t mat = p->material_of_point[p->obs_point[i]];
+            const double *jb = w->Jb + 7 * i;
+            for (int q = 0; q < 7; ++q) {
+                const int c = bcol(g, mat, q);
+                if (c < 0) continue;
+                for (int q2 = 0; q2 < 7; ++q2) {
+                    const int c2 = bcol(g, mat, q2);
+                    if (c2 >= 0) sc->Sbb[(size_t)c * nb + c2] += jb[q] * sb[c] * jb[q2] * sb[c2];
+                }
+            }
+        }
+        for (int c = 0; c < nb; ++c) {
+            double d = w->sq_b[c] * sb[c] * sb[c];
+            d = fmin(fmax(d, o->min_lm_diagonal), o->max_lm_diagonal);
+            sc->Sbb[(size_t)c * nb + c] += d / radius;
+            sc->rhs_b[c] = w->g_b[c] * sb[c];
+        }
+#pragma omp parallel for schedule(static)
+        for (int j = 0; j < L; ++j) {
+            if (!g->pt_active[j]) continue;
+            const uint32_t mat = p->material_of_point[j];
+            double *V = sc->V + (size_t)ld * 7 * j;
+            for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
+                const int64_t i = g->pt_obs[e];
+                const double *Jl3 = w->Jl + (size_t)nr * ld * i + (size_t)ld * 3;   /* intensity row */
+                for (int a = 0; a < ld; ++a)
+                    for (int q = 0; q < 7; ++q) {
+                        const int c = bcol(g, mat, q);
+                        if (c >= 0) V[7 * a + q] += Jl3[a] * sl[(size_t)ld * j + a] * w->Jb[7 * i + q] * sb[c];
+                    }
+            }
+        }
+        /* S_bb -= sum_j V^T C^-1 V ; rhs_b -= sum_j V^T C^-1 g_l   (serial over landmarks) */
+        for (int j = 0; j < L; ++j) {
+            if (!g->pt_active[j]) continue;
+            const uint32_t mat = p->material_of_point[j];
+            const double *V = sc->V + (size_t)ld * 7 * j, *Ci = sc->Ci + (size_t)ld * ld * j;
+            double CV[42], Cg[6];
+            for (int a = 0; a < ld; ++a) {
+                for (int q = 0; q < 7; ++q) {
+                    double v = 0.0;
+                    for (int b = 0; b < ld; ++b) v += Ci[ld * a + b] * V[7 * b + q];
+                    CV[7 * a + q] = v;
+                }
+                double v = 0.0;
+                for (int b = 0; b < ld; ++b) v += Ci[ld * a + b] * sc->gl_s[(size_t)ld * j + b];
+                Cg[a] = v;
+            }
+            for (int q = 0; q < 7; ++q) {
+                const int c = bcol(g, mat, q);
+                if (c < 0) continue;
+                double vg = 0.0;
+                for (int a = 0; a < ld; ++a) vg += V[7 * a + q] * Cg[a];
+                sc->rhs_b[c] -= vg;
+                for (int q2 = 0; q2 < 7; ++q2) {
+                    const int c2 = bcol(g, mat, q2);
+                    if (c2 < 0) continue;
+                    double v = 0.0;
+                    for (int a = 0; a < ld; ++a) v += V[7 * a + q] * CV[7 * a + q2];
+                    sc->Sbb[(size_t)c * nb + c2] -= v;
+                }
+            }
+        }
+    }
 
     /* W_i = Jp_s^T Jl_s (6 x LD) for observations of free poses */
 #pragma omp parallel for schedule(static)
@@ -680,6 +814,19 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
                 }
             for (int c = 0; c < 6; ++c)
                 for (int q = 0; q < ld; ++q) gr[c] -= Y[ld * c + q] * sc->gl_s[(size_t)ld * j + q];
+            if (nb) {   /* S_pb rows of this pose: J_p^T J_b (intensity row) - Y V_j */
+                const uint32_t mat = p->material_of_point[j];
+                const double *Jp3 = w->Jp + (size_t)nr * 6 * i + 18, *V = sc->V + (size_t)ld * 7 * j;
+                for (int q = 0; q < 7; ++q) {
+                    const int cb = bcol(g, mat, q);
+                    if (cb < 0) continue;
+                    for (int c = 0; c < 6; ++c) {
+                        double v = Jp3[c] * s6[c] * w->Jb[7 * i + q] * sb[cb];
+                        for (int a = 0; a < ld; ++a) v -= Y[ld * c + a] * V[7 * a + q];
+                        sc->Spb[(size_t)(6 * f + c) * nb + cb] += v;
+                    }
+                }
+            }
             for (int64_t e2 = g->pt_start[j]; e2 < g->pt_start[j + 1]; ++e2) {
                 int64_t i2 = g->pt_obs[e2];
                 int f2 = g->free_idx[p->obs_pose[i2]];
@@ -702,11 +849,12 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
 
 static void schur_free(schur_t *sc) {
     free(sc->S); free(sc->rhs); free(sc->Ci); free(sc->W); free(sc->gl_s);
+    free(sc->Spb); free(sc->Sbb); free(sc->rhs_b); free(sc->V);
 }
 
 /* -(J d)^T (r + J d / 2) for an arbitrary step (dp: P*6, dl: L*LD), and |J d|^2 */
 static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w, const double *dp,
-                          const double *dl, double *mcc_out, double *jd_sq_out) {
+                          const double *dl, const double *db, double *mcc_out, double *jd_sq_out) {
     const int nr = g->nr, ld = g->ld;
     double mcc = 0.0, sq = 0.0;
 #pragma omp parallel for reduction(+ : mcc, sq) schedule(static)
@@ -719,6 +867,13 @@ static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w
             for (int c = 0; c < ld; ++c) jd += b[ld * m + c] * dL[c];
             if (fr)
                 for (int c = 0; c < 6; ++c) jd += a[6 * m + c] * d6[c];
+            if (m == 3 && g->nb && db) {
+                const uint32_t mat = p->material_of_point[p->obs_point[i]];
+                for (int q = 0; q < 7; ++q) {
+                    const int c = bcol(g, mat, q);
+                    if (c >= 0) jd += w->Jb[7 * i + q] * db[c];
+                }
+            }
             mcc -= jd * (r[m] + 0.5 * jd);
             sq += jd * jd;
         }
@@ -730,20 +885,78 @@ static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w
 /* One LM step [Ceres LevenbergMarquardtStrategy::ComputeStep + SchurComplementSolver].
  * Outputs the UNSCALED step (delta = scale .* step_scaled) and the model cost
  * change  -(J d)^T (r + J d / 2)  [TrustRegionMinimizer::ComputeTrustRegionStep]. */
+/* dense Cholesky solve A x = b in place (A n x n row-major, destroyed); -1 on breakdown */
+static int dense_spd_solve(double *A, int n, double *b) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+        if (!(d > 0.0) || !isfinite(d)) return -1;
+        d = sqrt(d);
+        A[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = A[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+            A[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * b[k];
+        b[i] = s / A[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * b[k];
+        b[i] = s / A[(size_t)i * n + i];
+    }
+    return 0;
+}
+
 static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const double *sp,
-                   const double *sl, double radius, const orc_options *o, double *dp,
-                   double *dl, double *model_cost_change, double *t_schur, double *t_solve) {
-    const int ld = g->ld;
+                   const double *sl, const double *sb, double radius, const orc_options *o, double *dp,
+                   double *dl, double *db, double *model_cost_change, double *t_schur, double *t_solve) {
+    const int ld = g->ld, nb = g->nb;
     schur_t sc;
     memset(&sc, 0, sizeof sc);
     double t0 = now_s();
-    int rc = build_reduced(p, g, w, sp, sl, radius, o, &sc);
+    int rc = build_reduced(p, g, w, sp, sl, sb, radius, o, &sc);
     double t1 = now_s();
     if (t_schur) *t_schur += t1 - t0;
     if (rc) { schur_free(&sc); return -1; }
     if (sc.n > 0) {
         if (band_cholesky(sc.S, sc.n, sc.bw)) { schur_free(&sc); return -1; }
         band_solve(sc.S, sc.n, sc.bw, sc.rhs);
+    }
+    double *yb = calloc((size_t)nb + 1, sizeof(double));
+    if (nb) {
+        /* arrowhead system [S_pp S_pb; S_pb^T S_bb]: Z = S_pp^-1 S_pb, border Schur complement, then
+         * y_p = S_pp^-1 rhs_p - Z y_b */
+        const int n = sc.n;
+        double *Z = malloc((size_t)(n > 0 ? n : 1) * nb * sizeof(double)), *col = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+        for (int c = 0; c < nb; ++c) {
+            for (int i = 0; i < n; ++i) col[i] = sc.Spb[(size_t)i * nb + c];
+            if (n > 0) band_solve(sc.S, n, sc.bw, col);
+            for (int i = 0; i < n; ++i) Z[(size_t)i * nb + c] = col[i];
+        }
+        double *T = malloc((size_t)nb * nb * sizeof(double));
+        for (int a = 0; a < nb; ++a) {
+            for (int c = 0; c < nb; ++c) {
+                double v = sc.Sbb[(size_t)a * nb + c];
+                for (int i = 0; i < n; ++i) v -= sc.Spb[(size_t)i * nb + a] * Z[(size_t)i * nb + c];
+                T[(size_t)a * nb + c] = v;
+            }
+            double v = sc.rhs_b[a];
+            for (int i = 0; i < n; ++i) v -= sc.Spb[(size_t)i * nb + a] * sc.rhs[i];
+            yb[a] = v;
+        }
+        for (int a = 0; a < nb; ++a)       /* symmetrise against rounding */
+            for (int c = 0; c < a; ++c) T[(size_t)a * nb + c] = T[(size_t)c * nb + a] = 0.5 * (T[(size_t)a * nb + c] + T[(size_t)c * nb + a]);
+        int bad = dense_spd_solve(T, nb, yb);
+        if (!bad)
+            for (int i = 0; i < n; ++i)
+                for (int c = 0; c < nb; ++c) sc.rhs[i] -= Z[(size_t)i * nb + c] * yb[c];
+        free(Z); free(col); free(T);
+        if (bad) { free(yb); schur_free(&sc); return -1; }
     }
     double t2 = now_s();
     if (t_solve) *t_solve += t2 - t1;
@@ -762,6 +975,15 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
             for (int d = 0; d < ld; ++d)
                 for (int c = 0; c < 6; ++c) t[d] -= Wi[ld * c + d] * y[c];
         }
+        if (nb && g->pt_active[j]) {
+            const uint32_t mat = p->material_of_point[j];
+            const double *V = sc.V + (size_t)ld * 7 * j;
+            for (int q = 0; q < 7; ++q) {
+                const int c = bcol(g, mat, q);
+                if (c < 0) continue;
+                for (int d = 0; d < ld; ++d) t[d] -= V[7 * d + q] * yb[c];
+            }
+        }
         const double *Ci = sc.Ci + (size_t)ld * ld * j;
         for (int a = 0; a < ld; ++a) {
             double y = 0.0;
@@ -779,9 +1001,18 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
             if (!isfinite(v)) ok = 0;
             dp[6 * g->free_pose[f] + c] = v;
         }
+    double dbl[64 + 1];   /* local copy when the caller does not want the border step */
+    double *dbo = db ? db : dbl;
+    if (nb > 64) ok = 0;
+    for (int c = 0; c < nb && c < 64; ++c) {
+        double v = -yb[c] * sb[c];
+        if (!isfinite(v)) ok = 0;
+        dbo[c] = v;
+    }
+    free(yb);
     schur_free(&sc);
     if (!ok) return -1;
-    step_products(p, g, w, dp, dl, model_cost_change, NULL);
+    step_products(p, g, w, dp, dl, nb ? dbo : NULL, model_cost_change, NULL);
     return 0;
 }
 
@@ -802,11 +1033,12 @@ static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, c
                        const double *sl, const orc_options *o, dogleg_t *dg, double *dp, double *dl,
                        double *mcc, double *t_schur, double *t_solve) {
     const int nf = g->nfree, L = g->L, ld = g->ld;
+    if (g->nb) return -1;   /* free shared blocks: Levenberg-Marquardt only in this build */
     if (!dg->reuse) {
         dg->reuse = 1;
         /* Gauss-Newton step with the regulariser mu * D^2: same damped system as LM with 1/radius = mu */
         double mcc_gn;
-        if (lm_step(p, g, w, sp, sl, 1.0 / dg->mu, o, dg->gn_p, dg->gn_l, &mcc_gn, t_schur, t_solve)) return -1;
+        if (lm_step(p, g, w, sp, sl, NULL, 1.0 / dg->mu, o, dg->gn_p, dg->gn_l, NULL, &mcc_gn, t_schur, t_solve)) return -1;
         double gsq = 0.0, nsq = 0.0, dot = 0.0;
         memset(dg->v_p, 0, (size_t)g->P * 6 * sizeof(double));
         for (int f = 0; f < nf; ++f)
@@ -831,7 +1063,7 @@ static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, c
                 dg->v_l[ix] = s * s * gq / D2;
             }
         double jv_sq;
-        step_products(p, g, w, dg->v_p, dg->v_l, NULL, &jv_sq);
+        step_products(p, g, w, dg->v_p, dg->v_l, NULL, NULL, &jv_sq);
         dg->gradient_norm = sqrt(gsq);
         dg->gn_norm = sqrt(nsq);
         dg->g_dot_gn = dot;           /* gradient_ . gauss_newton_step_ */
@@ -860,22 +1092,37 @@ static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, c
     }
     for (int i = 0; i < g->P * 6; ++i) dp[i] = beta * dg->gn_p[i] + gamma * dg->v_p[i];
     for (int i = 0; i < L * ld; ++i) dl[i] = beta * dg->gn_l[i] + gamma * dg->v_l[i];
-    step_products(p, g, w, dp, dl, mcc, NULL);
+    step_products(p, g, w, dp, dl, NULL, mcc, NULL);
     return 0;
+}
+
+int orc_border_size(const orc_problem *p) {
+    graph_t g;
+    graph_build(p, &g);
+    int nb = g.nb;
+    graph_free(&g);
+    return nb;
 }
 
 int orc_lm_step(const orc_problem *p, double radius, const orc_options *o, double *delta_p,
                 double *delta_l, double *model_cost_change) {
+    return orc_lm_step_border(p, radius, o, delta_p, delta_l, NULL, model_cost_change);
+}
+
+int orc_lm_step_border(const orc_problem *p, double radius, const orc_options *o, double *delta_p,
+                       double *delta_l, double *delta_b, double *model_cost_change) {
     set_threads(o->num_threads);
     graph_t g;
     graph_build(p, &g);
     lin_t w;
     lin_alloc(&w, &g);
-    linearize(p, &g, p->poses, p->points, p->normals, &w);
+    linearize(p, &g, p->poses, p->points, p->normals, NULL, &w);
     double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
     double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * g.ld * sizeof(double));
-    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
-    int rc = lm_step(p, &g, &w, sp, sl, radius, o, delta_p, delta_l, model_cost_change, NULL, NULL);
+    double sb[64 + 1];
+    if (g.nb > 64) { lin_free(&w); graph_free(&g); free(sp); free(sl); return -1; }
+    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl, sb);
+    int rc = lm_step(p, &g, &w, sp, sl, sb, radius, o, delta_p, delta_l, delta_b, model_cost_change, NULL, NULL);
     free(sp); free(sl);
     lin_free(&w);
     graph_free(&g);
@@ -889,28 +1136,39 @@ int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o
     graph_build(p, &g);
     lin_t w;
     lin_alloc(&w, &g);
-    linearize(p, &g, p->poses, p->points, p->normals, &w);
+    linearize(p, &g, p->poses, p->points, p->normals, NULL, &w);
     double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
     double *sl = malloc((size_t)(g.L > 0 ? g.L : 1) * g.ld * sizeof(double));
-    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
+    double sb[64 + 1];
+    if (g.nb > 64) { lin_free(&w); graph_free(&g); free(sp); free(sl); return -1; }
+    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl, sb);
     schur_t sc;
     memset(&sc, 0, sizeof sc);
-    int rc = build_reduced(p, &g, &w, sp, sl, radius, o, &sc);
+    int rc = build_reduced(p, &g, &w, sp, sl, sb, radius, o, &sc);
     if (!rc) {
         /* un-scale: S_unscaled = diag(1/s) S_s diag(1/s), rhs_unscaled = -(1/s) rhs_s
-         * so that S_unscaled * delta_p = rhs_unscaled (delta = -s .* y). */
-        int n = sc.n, ld = sc.bw + 1;
-        for (int i = 0; i < n; ++i) {
-            for (int j = 0; j < n; ++j) S[(size_t)i * n + j] = 0.0;
-            rhs[i] = -sc.rhs[i] / sp[i];
-        }
+         * so that S_unscaled * delta = rhs_unscaled (delta = -s .* y).  With free shared blocks the
+         * system is the (n + nb) arrowhead [S_pp S_pb; S_pb^T S_bb], leading dimension n + nb. */
+        int n = sc.n, ld = sc.bw + 1, nb = sc.nb, nt = n + nb;
+        for (int i = 0; i < nt; ++i)
+            for (int j = 0; j < nt; ++j) S[(size_t)i * nt + j] = 0.0;
+        for (int i = 0; i < n; ++i) rhs[i] = -sc.rhs[i] / sp[i];
         for (int i = 0; i < n; ++i) {
             int j0 = i - sc.bw < 0 ? 0 : i - sc.bw;
             for (int j = j0; j <= i; ++j) {
                 double v = sc.S[(size_t)i * ld + (j - i + sc.bw)] / (sp[i] * sp[j]);
-                S[(size_t)i * n + j] = v;
-                S[(size_t)j * n + i] = v;
+                S[(size_t)i * nt + j] = v;
+                S[(size_t)j * nt + i] = v;
             }
+        }
+        for (int c = 0; c < nb; ++c) {
+            rhs[n + c] = -sc.rhs_b[c] / sb[c];
+            for (int i = 0; i < n; ++i) {
+                double v = sc.Spb[(size_t)i * nb + c] / (sp[i] * sb[c]);
+                S[(size_t)i * nt + n + c] = v;
+                S[(size_t)(n + c) * nt + i] = v;
+            }
+            for (int c2 = 0; c2 < nb; ++c2) S[(size_t)(n + c) * nt + n + c2] = sc.Sbb[(size_t)c * nb + c2] / (sb[c] * sb[c2]);
         }
         for (int k = 0; k < g.P; ++k) free_pose_index[k] = g.free_idx[k];
     }
@@ -928,10 +1186,22 @@ int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o
 /* Evaluator::Plus: SE3Perturbation on free poses, Euclidean on the active points,
  * UnitVectorPerturbation on their normals (perturbations.hpp:87-103).  The landmark step is
  * LD wide: [d position | d normal]. */
-static void plus_all(const graph_t *g, const double *poses, const double *points, const double *normals,
-                     const double *dp, const double *dl, double *poses_out, double *points_out,
-                     double *normals_out) {
+static void plus_all(const orc_problem *p, const graph_t *g, const double *poses, const double *points, const double *normals,
+                     const double *sh, const double *dp, const double *dl, const double *db, double *poses_out,
+                     double *points_out, double *normals_out, double *sh_out) {
     const int ld = g->ld;
+    if (sh_out) {
+        /* shared blocks: Euclidean Plus, UnitVectorPerturbation on a directional light
+         * (dataset_ba_phong.cpp:201-204) */
+        const int M = g->M;
+        memcpy(sh_out, sh, (size_t)(3 + 4 * M) * sizeof(double));
+        if (g->b_light >= 0) {
+            if (p->light_type == ORC_DIRECTIONAL_LIGHT) orc_unit_vector_plus(sh, db + g->b_light, sh_out);
+            else for (int c = 0; c < 3; ++c) sh_out[c] = sh[c] + db[g->b_light + c];
+        }
+        if (g->b_phong >= 0) for (int c = 0; c < 3 * M; ++c) sh_out[3 + c] = sh[3 + c] + db[g->b_phong + c];
+        if (g->b_tex >= 0) for (int c = 0; c < M; ++c) sh_out[3 + 3 * M + c] = sh[3 + 3 * M + c] + db[g->b_tex + c];
+    }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < g->P; ++k) {
         if (g->free_idx[k] >= 0) orc_se3_plus(poses + 12 * k, dp + 6 * k, poses_out + 12 * k);
@@ -949,9 +1219,20 @@ static void plus_all(const graph_t *g, const double *poses, const double *points
 }
 
 /* ambient-space norms over the reduced program's parameter blocks */
-static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, const double *na,
-                        const double *pb, const double *qb, const double *nb, double *max_abs) {
+static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, const double *na, const double *sa,
+                        const double *pb, const double *qb, const double *nb, const double *sbb, double *max_abs) {
     double s = 0.0, m = 0.0;
+    if (g->nb) {
+        const int M = g->M;
+        const int lo[3] = {0, 3, 3 + 3 * M}, hi[3] = {3, 3 + 3 * M, 3 + 4 * M}, on[3] = {g->b_light >= 0, g->b_phong >= 0, g->b_tex >= 0};
+        for (int b = 0; b < 3; ++b)
+            if (on[b])
+                for (int c = lo[b]; c < hi[b]; ++c) {
+                    double d = sa[c] - (sbb ? sbb[c] : 0.0);
+                    s += d * d;
+                    if (fabs(d) > m) m = fabs(d);
+                }
+    }
     for (int f = 0; f < g->nfree; ++f) {
         int k = g->free_pose[f];
         for (int c = 0; c < 12; ++c) {
@@ -1043,6 +1324,18 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     double *ngp = calloc(szP * 6, sizeof(double)), *ngl = calloc(szL * ld, sizeof(double));
     double *sp = malloc((size_t)(g.nfree > 0 ? g.nfree : 1) * 6 * sizeof(double));
     double *sl = malloc(szL * ld * sizeof(double));
+    /* shared blocks (light / materials / textures): packed ambient state, border step, scale */
+    const int nb = g.nb, nsh = ph ? shared_size(p) : 1;
+    double *x_sh = calloc((size_t)nsh, sizeof(double)), *c_sh = calloc((size_t)nsh, sizeof(double)), *best_sh = calloc((size_t)nsh, sizeof(double));
+    double db[64 + 1] = {0}, ngb[64 + 1] = {0}, sb[64 + 1];
+    if (nb > 64 || (nb && o->trust_region_strategy_type == 1)) {   /* unsupported here: report FAILURE */
+        s->termination_type = ORC_FAILURE;
+        free(x_pose); free(x_pt); free(x_n); free(c_pose); free(c_pt); free(c_n); free(best_pose); free(best_pt); free(best_n);
+        free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl); free(x_sh); free(c_sh); free(best_sh);
+        lin_free(&w); graph_free(&g);
+        return -1;
+    }
+    if (ph) { shared_pack(p, x_sh); memcpy(c_sh, x_sh, (size_t)nsh * sizeof(double)); memcpy(best_sh, x_sh, (size_t)nsh * sizeof(double)); }
     memcpy(x_pose, p->poses, (size_t)P * 12 * sizeof(double));
     memcpy(x_pt, p->points, (size_t)L * 3 * sizeof(double));
     if (ph) memcpy(x_n, p->normals, (size_t)L * 3 * sizeof(double));
@@ -1053,11 +1346,11 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
 
     /* ---- IterationZero ---- */
     double t0 = now_s();
-    linearize(p, &g, x_pose, x_pt, x_n, &w);
+    linearize(p, &g, x_pose, x_pt, x_n, ph ? x_sh : NULL, &w);
     s->linearize_time_s += now_s() - t0;
-    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl);
+    jacobi_scale(&g, &w, o->jacobi_scaling, sp, sl, sb);
     double x_cost = w.cost, minimum_cost = x_cost;
-    double x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, NULL, NULL, NULL, NULL));
+    double x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, x_sh, NULL, NULL, NULL, NULL, NULL));
     s->initial_cost = x_cost;
     /* projected gradient: |x - Plus(x, -g)|_inf [EvaluateGradientAndJacobian] */
     double gmax;
@@ -1066,8 +1359,9 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
         for (int f = 0; f < g.nfree; ++f)                                                \
             for (int c = 0; c < 6; ++c) ngp[6 * g.free_pose[f] + c] = -w.g_p[6 * f + c]; \
         for (int i = 0; i < ld * L; ++i) ngl[i] = -w.g_l[i];                             \
-        plus_all(&g, x_pose, x_pt, x_n, ngp, ngl, c_pose, c_pt, c_n);                    \
-        x_sq_diff(&g, x_pose, x_pt, x_n, c_pose, c_pt, c_n, &gmax);                      \
+        for (int i = 0; i < nb; ++i) ngb[i] = -w.g_b[i];                                 \
+        plus_all(p, &g, x_pose, x_pt, x_n, x_sh, ngp, ngl, ngb, c_pose, c_pt, c_n, nb ? c_sh : NULL); \
+        x_sq_diff(&g, x_pose, x_pt, x_n, x_sh, c_pose, c_pt, c_n, c_sh, &gmax);          \
     } while (0)
     GRADIENT_MAX_NORM();
     double radius = o->initial_trust_region_radius, decrease_factor = 2.0;
@@ -1096,6 +1390,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
             memcpy(best_pose, x_pose, (size_t)P * 12 * sizeof(double));
             memcpy(best_pt, x_pt, (size_t)L * 3 * sizeof(double));
             memcpy(best_n, x_n, (size_t)L * 3 * sizeof(double));
+            memcpy(best_sh, x_sh, (size_t)nsh * sizeof(double));
         }
         if (iteration >= o->max_num_iterations) { term = ORC_NO_CONVERGENCE; break; }
         if (gmax <= o->gradient_tolerance) { term = ORC_CONVERGENCE; break; }
@@ -1106,7 +1401,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
         /* ---- ComputeTrustRegionStep ---- */
         double mcc = 0.0;
         int rc = dogleg ? dogleg_step(p, &g, &w, sp, sl, o, &dg, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s)
-                        : lm_step(p, &g, &w, sp, sl, radius, o, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s);
+                        : lm_step(p, &g, &w, sp, sl, sb, radius, o, dp, dl, db, &mcc, &s->schur_time_s, &s->solve_time_s);
         int step_is_valid = (rc == 0) && (mcc > 0.0);
         if (!step_is_valid) {
             /* HandleInvalidStep */
@@ -1130,13 +1425,13 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
 
         /* ---- ComputeCandidatePointAndEvaluateCost ---- */
         t0 = now_s();
-        plus_all(&g, x_pose, x_pt, x_n, dp, dl, c_pose, c_pt, c_n);
-        double candidate_cost = evaluate(p, c_pose, c_pt, c_n, NULL, NULL, NULL);
+        plus_all(p, &g, x_pose, x_pt, x_n, x_sh, dp, dl, db, c_pose, c_pt, c_n, nb ? c_sh : NULL);
+        double candidate_cost = evaluate(p, c_pose, c_pt, c_n, ph ? c_sh : NULL, NULL, NULL, NULL, NULL);
         if (!isfinite(candidate_cost)) candidate_cost = DBL_MAX;
         s->update_time_s += now_s() - t0;
 
         /* ---- ParameterToleranceReached ---- */
-        double step_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, c_pose, c_pt, c_n, NULL));
+        double step_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, x_sh, c_pose, c_pt, c_n, c_sh, NULL));
         if (step_norm <= o->parameter_tolerance * (x_norm + o->parameter_tolerance)) {
             term = ORC_CONVERGENCE;
             break;
@@ -1154,9 +1449,10 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
             memcpy(x_pose, c_pose, (size_t)P * 12 * sizeof(double));
             memcpy(x_pt, c_pt, (size_t)L * 3 * sizeof(double));
             if (ph) memcpy(x_n, c_n, (size_t)L * 3 * sizeof(double));
-            x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, NULL, NULL, NULL, NULL));
+            if (nb) memcpy(x_sh, c_sh, (size_t)nsh * sizeof(double));
+            x_norm = sqrt(x_sq_diff(&g, x_pose, x_pt, x_n, x_sh, NULL, NULL, NULL, NULL, NULL));
             t0 = now_s();
-            linearize(p, &g, x_pose, x_pt, x_n, &w);
+            linearize(p, &g, x_pose, x_pt, x_n, ph ? x_sh : NULL, &w);
             s->linearize_time_s += now_s() - t0;
             x_cost = w.cost;
             GRADIENT_MAX_NORM();
@@ -1205,10 +1501,17 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
         memcpy(p->poses, best_pose, (size_t)P * 12 * sizeof(double));
         memcpy(p->points, best_pt, (size_t)L * 3 * sizeof(double));
         if (ph) memcpy(p->normals, best_n, (size_t)L * 3 * sizeof(double));
+        if (nb) {
+            const int M = g.M;
+            if (g.b_light >= 0) memcpy(p->light, best_sh, 3 * sizeof(double));
+            if (g.b_phong >= 0) memcpy(p->phong, best_sh + 3, (size_t)3 * M * sizeof(double));
+            if (g.b_tex >= 0) memcpy(p->texture, best_sh + 3 + 3 * M, (size_t)M * sizeof(double));
+        }
     }
     free(x_pose); free(x_pt); free(x_n); free(c_pose); free(c_pt); free(c_n);
     free(best_pose); free(best_pt); free(best_n);
     free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl);
+    free(x_sh); free(c_sh); free(best_sh);
     free(dg.gn_p); free(dg.gn_l); free(dg.v_p); free(dg.v_l);
     lin_free(&w);
     graph_free(&g);

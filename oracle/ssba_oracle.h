@@ -61,18 +61,23 @@ typedef struct {
     double huber_a;           /* <= 0: NULL loss                                */
     /* Phong lighting terms (tests/dataset_ba_phong.cpp:102-195, BASELINE config 3); intensity ==
      * NULL means a stereo-only problem.  One intensity and one normal residual block per
-     * observation; landmark block = [position | normal]; light / materials / textures constant. */
+     * observation; landmark block = [position | normal].  The shared blocks -- light, the Phong
+     * parameters [ka, ks, alpha] and the texture kd of each material -- are constant unless
+     * `shared_free` frees them (bit 0 light, bit 1 Phong parameters, bit 2 textures); free blocks are
+     * updated in place by orc_solve like every other parameter block. */
     double *normals;                   /* num_points*3, updated in place (UnitVectorPerturbation) */
     const double *intensity;           /* num_obs                                                 */
     const double *normal_obs;          /* num_obs*3                                               */
-    const double *phong;               /* num_materials*3: ka, ks, alpha                          */
-    const double *texture;             /* num_materials: kd                                       */
+    double *phong;                     /* num_materials*3: ka, ks, alpha                          */
+    double *texture;                   /* num_materials: kd                                       */
     const uint32_t *material_of_point; /* num_points                                              */
     double light[3];
     int32_t light_type;                /* ORC_POINT_LIGHT / ORC_DIRECTIONAL_LIGHT                 */
-    int32_t reserved;
+    uint32_t shared_free;              /* bit 0 light, bit 1 Phong parameters, bit 2 textures     */
     double int_stiffness;              /* 1/sqrt(int_var)  (dataset_ba_phong.cpp:44)              */
     double normal_stiffness[9];
+    uint32_t num_materials;
+    uint32_t reserved2;
 } orc_problem;
 
 typedef struct {
@@ -141,6 +146,14 @@ int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o
  * model cost change.  Test hook. */
 int orc_lm_step(const orc_problem *p, double radius, const orc_options *o,
                 double *delta_p, double *delta_l, double *model_cost_change);
+
+/* local size of the border of free shared blocks: 3 [light] + 3 M [Phong] + M [texture] as freed */
+int orc_border_size(const orc_problem *p);
+/* orc_lm_step with the border step delta_b (orc_border_size entries; order light, Phong parameters of
+ * material 0.., textures).  With a border, orc_reduced_system returns the (n + nb) arrowhead system
+ * [S_pp S_pb; S_pb^T S_bb] (leading dimension n + nb) and rhs (n + nb). */
+int orc_lm_step_border(const orc_problem *p, double radius, const orc_options *o, double *delta_p,
+                       double *delta_l, double *delta_b, double *model_cost_change);
 
 /* Full solve with Ceres 1.13/1.14 trust-region semantics (see header comment). */
 int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteration_log *log);

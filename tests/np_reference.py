@@ -412,10 +412,12 @@ def dogleg_solve(ba: "NumpyBA", max_iter=1000, nonmonotonic=True, f_tol=1e-6, p_
 
 # ---- config 3 (stereo + intensity + normal residual blocks, landmark block = [position | normal]) ----
 def phong_lm_step(cam, poses, points, normals, obs_pose, obs_point, obs_uvd, S, ph, radius, pose_const=None,
-                  min_diag=1e-6, max_diag=1e32):
+                  min_diag=1e-6, max_diag=1e32, shared_free=0):
     """One Ceres LM step of the config-3 problem with a dense/sparse direct solve and complex-step
     Jacobians through the reference's Plus operators (slow: small problems only).
-    Returns dp (P,6), dl (L,6), model_cost_change, cost."""
+    `shared_free` frees the shared blocks (bit 0 light, bit 1 Phong parameters, bit 2 textures); their
+    columns follow the landmark columns in the order light, Phong parameters, textures.
+    Returns dp (P,6), dl (L,6), model_cost_change, cost [, db when shared_free]."""
     P, L, N = poses.shape[0], points.shape[0], obs_pose.shape[0]
     if pose_const is None:
         pose_const = np.zeros(P, bool)
@@ -426,7 +428,16 @@ def phong_lm_step(cam, poses, points, normals, obs_pose, obs_point, obs_uvd, S, 
     fidx[free] = np.arange(free.sum())
     active = np.bincount(obs_point, minlength=L) > 0
     nf = int(free.sum())
-    ncol = 6 * nf + 6 * L
+    M = len(ph["texture"])
+    b_light = b_phong = b_tex = -1
+    nb = 0
+    if shared_free & 1:
+        b_light, nb = nb, nb + 3
+    if shared_free & 2:
+        b_phong, nb = nb, nb + 3 * M
+    if shared_free & 4:
+        b_tex, nb = nb, nb + M
+    ncol = 6 * nf + 6 * L + nb
     rows, cols, vals, r = [], [], [], np.zeros(7 * N)
     Sn = np.asarray(ph["normal_stiffness"]).reshape(3, 3)
     h = 1e-30
@@ -461,8 +472,17 @@ def phong_lm_step(cam, poses, points, normals, obs_pose, obs_point, obs_uvd, S, 
                     rows.append(7 * i + a); cols.append(6 * fidx[k] + c); vals.append(Jp[a, c])
             for c in range(6):
                 rows.append(7 * i + a); cols.append(6 * nf + 6 * j + c); vals.append(Jl[a, c])
+        b0 = 6 * nf + 6 * L
+        if b_phong >= 0:
+            for c in range(3):
+                rows.append(7 * i + 3); cols.append(b0 + b_phong + 3 * m + c); vals.append(J19[12 + c])
+        if b_tex >= 0:
+            rows.append(7 * i + 3); cols.append(b0 + b_tex + m); vals.append(J19[15])
+        if b_light >= 0:
+            for c in range(3):
+                rows.append(7 * i + 3); cols.append(b0 + b_light + c); vals.append(J19[16 + c])
     J = sp.csr_matrix((vals, (rows, cols)), shape=(7 * N, ncol))
-    keep = np.concatenate([np.ones(6 * nf, bool), np.repeat(active, 6)])
+    keep = np.concatenate([np.ones(6 * nf, bool), np.repeat(active, 6), np.ones(nb, bool)])
     J = J[:, keep]
     colsq = np.asarray(J.multiply(J).sum(0)).ravel()
     scale = 1.0 / (1.0 + np.sqrt(colsq))
@@ -477,4 +497,6 @@ def phong_lm_step(cam, poses, points, normals, obs_pose, obs_point, obs_uvd, S, 
     full[keep] = delta
     dp = np.zeros((P, 6))
     dp[free] = full[: 6 * nf].reshape(nf, 6)
+    if shared_free:
+        return dp, full[6 * nf: 6 * nf + 6 * L].reshape(L, 6), mcc, 0.5 * r @ r, full[6 * nf + 6 * L:]
     return dp, full[6 * nf:].reshape(L, 6), mcc, 0.5 * r @ r
