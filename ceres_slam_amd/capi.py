@@ -32,7 +32,8 @@ SYMBOLS = [
     "ssba_solve_end", "ssba_solve_restart", "ssba_synchronize", "ssba_iteration_log", "ssba_set_stream",
     "ssba_set_exchange", "ssba_set_distributed", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
-    "ssba_add_normal_blocks", "ssba_set_materials", "ssba_set_light", "ssba_add_lighting_observations",
+    "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
+    "ssba_add_lighting_observations", "ssba_border_system",
 ]
 
 
@@ -127,8 +128,10 @@ def load():
     L.ssba_phong_evaluate.argtypes = [C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp,
                                       _dp, _dp, _dp, _dp, _dp]
     L.ssba_add_normal_blocks.argtypes = [H, _dp, C.c_uint32]
-    L.ssba_set_materials.argtypes = [H, _dp, _dp, C.c_uint32, _u32p, C.c_uint32]
-    L.ssba_set_light.argtypes = [H, _dp, C.c_int]
+    L.ssba_add_material_blocks.argtypes = [H, _dp, _dp, C.c_uint32, _u32p, C.c_uint32]
+    L.ssba_add_light_block.argtypes = [H, _dp, C.c_int]
+    L.ssba_set_shared_block_constant.argtypes = [H, C.c_int, C.c_int]
+    L.ssba_border_system.argtypes = [H, C.POINTER(C.c_uint32), _dp, _dp, _dp, _dp]
     L.ssba_add_lighting_observations.argtypes = [H, _dp, C.c_double, _dp, _dp, C.c_uint64]
     L.ssba_status_string.argtypes = [C.c_int]
     L.ssba_status_string.restype = C.c_char_p

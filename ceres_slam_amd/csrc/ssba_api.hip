@@ -47,11 +47,12 @@ struct ssba_problem {
     // config 3: lighting terms
     double *user_normals = nullptr;
     uint32_t num_normals = 0;
-    std::vector<double> ph_mat;            // M*4: ka, ks, alpha, kd
+    double *user_phong = nullptr, *user_texture = nullptr, *user_light = nullptr;   // caller-owned shared blocks
+    uint32_t M = 0;
     std::vector<uint32_t> ph_mat_of_point;
-    double ph_light[3] = {0, 0, 0};
     int ph_light_type = 0;
-    bool have_light = false;
+    uint32_t shared_const = 0;             // bit 0 light, bit 1 Phong parameters, bit 2 textures
+    std::vector<double> h_sh;              // packed [light 3 | phong 3M | texture M]
     std::vector<double> ph_intensity, ph_nobs;
     double ph_int_stiff = 0.0, ph_Sn[9] = {0};
     bool lighting() const { return !ph_intensity.empty(); }
@@ -257,27 +258,36 @@ int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num) {
     return SSBA_OK;
 }
 
-int ssba_set_materials(ssba_problem *p, const double *phong, const double *texture, uint32_t num_materials,
-                       const uint32_t *material_of_point, uint32_t num_points) {
+int ssba_add_material_blocks(ssba_problem *p, double *phong, double *texture, uint32_t num_materials,
+                             const uint32_t *material_of_point, uint32_t num_points) {
     if (!p || !phong || !texture || !material_of_point || num_materials == 0) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->finalized) return SSBA_ERR_STATE;
+    if (num_materials > SSBA_MAX_MATERIALS) {
+        set_error("more than SSBA_MAX_MATERIALS materials");
+        return SSBA_ERR_UNSUPPORTED;
+    }
     for (uint32_t j = 0; j < num_points; ++j)
         if (material_of_point[j] >= num_materials) return SSBA_ERR_INVALID_ARGUMENT;
-    p->ph_mat.resize((size_t)num_materials * 4);
-    for (uint32_t m = 0; m < num_materials; ++m) {
-        for (int c = 0; c < 3; ++c) p->ph_mat[4 * (size_t)m + c] = phong[3 * (size_t)m + c];
-        p->ph_mat[4 * (size_t)m + 3] = texture[m];
-    }
+    p->user_phong = phong;
+    p->user_texture = texture;
+    p->M = num_materials;
     p->ph_mat_of_point.assign(material_of_point, material_of_point + num_points);
     return SSBA_OK;
 }
 
-int ssba_set_light(ssba_problem *p, const double light[3], int light_type) {
+int ssba_add_light_block(ssba_problem *p, double *light, int light_type) {
     if (!p || !light || (light_type != 0 && light_type != 1)) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->finalized) return SSBA_ERR_STATE;
-    memcpy(p->ph_light, light, sizeof p->ph_light);
+    p->user_light = light;
     p->ph_light_type = light_type;
-    p->have_light = true;
+    return SSBA_OK;
+}
+
+int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant) {
+    if (!p || which < 0 || which > 2) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;   // the border of the reduced system depends on it
+    if (is_constant) p->shared_const |= (1u << which);
+    else p->shared_const &= ~(1u << which);
     return SSBA_OK;
 }
 
@@ -377,7 +387,7 @@ int ssba_finalize(ssba_problem *p) {
             set_error("lighting observations must pair one-to-one with the stereo observations");
             return SSBA_ERR_INVALID_ARGUMENT;
         }
-        if (p->num_normals != L || p->ph_mat_of_point.size() != L || !p->have_light) {
+        if (p->num_normals != L || p->ph_mat_of_point.size() != L || !p->user_light) {
             set_error("lighting terms need a normal and a material for every point, and the light");
             return SSBA_ERR_INVALID_ARGUMENT;
         }
@@ -502,8 +512,23 @@ int ssba_finalize(ssba_problem *p) {
     }
     std::vector<uint32_t> pose_obs_start(P + 1, 0), pose_obs_ref;
     pose_obs_ref.reserve(N);
+    std::vector<uint32_t> pose_mat_start;   // config 3: references of a pose sorted by material, P*(M+1) offsets
+    const uint32_t Mm = ph ? p->M : 0;
     for (uint32_t k = 0; k < P; ++k) {
-        std::sort(pose_refs[k].begin(), pose_refs[k].end());
+        if (ph)
+            std::sort(pose_refs[k].begin(), pose_refs[k].end(), [&](uint32_t x, uint32_t y) {
+                const uint32_t mx = lm_mat[x >> 4], my = lm_mat[y >> 4];
+                return mx != my ? mx < my : x < y;
+            });
+        else
+            std::sort(pose_refs[k].begin(), pose_refs[k].end());
+        if (ph) {
+            size_t q = 0;
+            for (uint32_t m = 0; m <= Mm; ++m) {
+                while (q < pose_refs[k].size() && lm_mat[pose_refs[k][q] >> 4] < m) ++q;
+                pose_mat_start.push_back((uint32_t)(pose_obs_ref.size() + q));
+            }
+        }
         pose_obs_ref.insert(pose_obs_ref.end(), pose_refs[k].begin(), pose_refs[k].end());
         pose_obs_start[k + 1] = (uint32_t)pose_obs_ref.size();
     }
@@ -629,14 +654,31 @@ int ssba_finalize(ssba_problem *p) {
     if (ph) {
         d.phong = 1;
         d.light_type = p->ph_light_type;
-        memcpy(d.light, p->ph_light, sizeof d.light);
+        d.M = (int)p->M;
+        d.nsh = 3 + 4 * (int)p->M;
+        d.b_light = d.b_phong = d.b_tex = -1;
+        if (!(p->shared_const & 1u)) { d.b_light = d.nb; d.nb += 3; }
+        if (!(p->shared_const & 2u)) { d.b_phong = d.nb; d.nb += 3 * d.M; }
+        if (!(p->shared_const & 4u)) { d.b_tex = d.nb; d.nb += d.M; }
+        if (d.nb > NBP) { set_error("border of free shared blocks wider than this build supports"); return SSBA_ERR_UNSUPPORTED; }
         d.int_stiff = p->ph_int_stiff;
         memcpy(d.Sn, p->ph_Sn, sizeof d.Sn);
         TRY(dzero(p, &d.nrm, (size_t)Lpad * 3)); TRY(dzero(p, &d.cand_nrm, (size_t)Lpad * 3));
         TRY(dzero(p, &d.best_nrm, (size_t)Lpad * 3)); TRY(dzero(p, &d.init_nrm, (size_t)Lpad * 3));
         TRY(dupload(p, &d.oi, oint)); TRY(dupload(p, &d.onx, onx)); TRY(dupload(p, &d.ony, ony)); TRY(dupload(p, &d.onz, onz));
-        TRY(dupload(p, &d.lm_mat, lm_mat)); TRY(dupload(p, &d.mat, p->ph_mat));
+        TRY(dupload(p, &d.lm_mat, lm_mat));
+        TRY(dzero(p, &d.sh, (size_t)d.nsh)); TRY(dzero(p, &d.cand_sh, (size_t)d.nsh));
+        TRY(dzero(p, &d.best_sh, (size_t)d.nsh)); TRY(dzero(p, &d.init_sh, (size_t)d.nsh));
+        p->h_sh.assign((size_t)d.nsh, 0.0);
         TRY(dzero(p, &d.cinv, (size_t)Lpad * 21)); TRY(dzero(p, &d.dlm, (size_t)Lpad * 6));
+        TRY(dupload(p, &d.pose_mat_start, pose_mat_start));
+        if (d.nb) {
+            TRY(dzero(p, &d.lmV, (size_t)Lpad * 42)); TRY(dzero(p, &d.lmH, (size_t)Lpad * 28)); TRY(dzero(p, &d.lmG, (size_t)Lpad * 7));
+            TRY(dzero(p, &d.part_b, (size_t)(Lpad / 256) * d.M * NBV));
+            TRY(dzero(p, &d.bsys, (size_t)BS_COUNT));
+            d.n_gram = 64;
+            TRY(dzero(p, &d.part_g, (size_t)d.n_gram * (NBP * NBP + NBP)));
+        }
     }
     TRY(dzero(p, &d.hpp, (size_t)P * 21)); TRY(dzero(p, &d.gp, (size_t)P * 6));
     TRY(dzero(p, &d.sp, (size_t)d.nf_pad * 6));
@@ -657,6 +699,10 @@ int ssba_finalize(ssba_problem *p) {
     d.xv_count = d.off_scal + NSCAL;
     TRY(dzero(p, &d.xv, d.xv_count));
     TRY(dzero(p, &d.x0, (size_t)d.nf_pad * 6));
+    if (d.nb) {
+        TRY(dzero(p, &d.Spb, (size_t)d.nf_pad * 6 * NBP));
+        TRY(dzero(p, &d.Zb, (size_t)d.nf_pad * 6 * NBP));
+    }
     TRY(dzero(p, &d.vp, (size_t)P * 6)); TRY(dzero(p, &d.vl, (size_t)Lpad * 3)); TRY(dzero(p, &d.dl_gn, (size_t)Lpad * 3));
     // BCR level plan
     {
@@ -666,6 +712,7 @@ int ssba_finalize(ssba_problem *p) {
         d.lev[0].L = d.xv + d.off_L;
         d.lev[0].r = d.xv + d.off_rhs;
         for (;;) {
+            if (d.nb) TRY(dzero(p, &d.lev[lev].B, (size_t)n * BD * NBP));
             TRY(dzero(p, &d.lev[lev].YU, (size_t)std::max(1, n / 2) * blk));
             if (n == 1) break;
             const int n2 = (n + 1) / 2;
@@ -681,7 +728,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
-    TRY(dzero(p, &d.part_pose, (size_t)d.n_pose_blocks * 2));
+    TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * 2));   // + one entry for the border of shared blocks
     TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks) * 4));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));
@@ -697,6 +744,7 @@ int ssba_finalize(ssba_problem *p) {
     if (ph) {
         if (upload_phong_tables(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
         if (configure_phong()) { set_error("hipFuncSetAttribute(k_ph_schur_windows) failed"); return SSBA_ERR_HIP; }
+        if (configure_border()) { set_error("hipFuncSetAttribute(border kernels) failed"); return SSBA_ERR_HIP; }
     }
 #undef TRY
     p->stats.num_poses = P; p->stats.num_free_poses = (uint32_t)nfree;
@@ -731,11 +779,17 @@ static int upload_params(ssba_problem *p) {
         }
         HIPCHECK(hipMemcpyAsync(d.nrm, st, Lp * 3 * sizeof(double), hipMemcpyHostToDevice, s));
         HIPCHECK(hipStreamSynchronize(s));
+        const size_t M = p->M;
+        memcpy(p->h_sh.data(), p->user_light, 3 * sizeof(double));
+        memcpy(p->h_sh.data() + 3, p->user_phong, 3 * M * sizeof(double));
+        memcpy(p->h_sh.data() + 3 + 3 * M, p->user_texture, M * sizeof(double));
+        HIPCHECK(hipMemcpy(d.sh, p->h_sh.data(), (size_t)d.nsh * sizeof(double), hipMemcpyHostToDevice));
     }
     return SSBA_OK;
 }
 
-static int download_params(ssba_problem *p, const double *dev_poses, const double *dev_pts, const double *dev_nrm) {
+static int download_params(ssba_problem *p, const double *dev_poses, const double *dev_pts, const double *dev_nrm,
+                           const double *dev_sh) {
     Dev &d = p->d;
     hipStream_t s = p->launcher.stream;
     const size_t Lp = (size_t)d.Lpad;
@@ -753,6 +807,13 @@ static int download_params(ssba_problem *p, const double *dev_poses, const doubl
             const uint32_t j = p->user_of_dev[l];
             if (j == 0xFFFFFFFFu) continue;
             for (int c = 0; c < 3; ++c) p->user_normals[3 * (size_t)j + c] = p->h_stage[c * Lp + l];
+        }
+        if (d.nb) {   // free shared blocks are written back like every other parameter block
+            const size_t M = p->M;
+            HIPCHECK(hipMemcpy(p->h_sh.data(), dev_sh, (size_t)d.nsh * sizeof(double), hipMemcpyDeviceToHost));
+            if (d.b_light >= 0) memcpy(p->user_light, p->h_sh.data(), 3 * sizeof(double));
+            if (d.b_phong >= 0) memcpy(p->user_phong, p->h_sh.data() + 3, 3 * M * sizeof(double));
+            if (d.b_tex >= 0) memcpy(p->user_texture, p->h_sh.data() + 3 + 3 * M, M * sizeof(double));
         }
     }
     if (p->P) {
@@ -832,6 +893,7 @@ static int enqueue_kernels(ssba_problem *p) {
     }
     launch_finish_check(L, d);
     launch_bcr(L, d);
+    if (d.nb) launch_border_solve(L, d);
     if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
     else launch_update_eval(L, d);
     if (p->xfn) {
@@ -857,6 +919,10 @@ static int reset_solver(ssba_problem *p) {
         HIPCHECK(hipMemcpyAsync(d.nrm, d.init_nrm, nb, hipMemcpyDeviceToDevice, s));
         HIPCHECK(hipMemcpyAsync(d.best_nrm, d.init_nrm, nb, hipMemcpyDeviceToDevice, s));
         HIPCHECK(hipMemcpyAsync(d.cand_nrm, d.init_nrm, nb, hipMemcpyDeviceToDevice, s));
+        const size_t ns = (size_t)d.nsh * sizeof(double);
+        HIPCHECK(hipMemcpyAsync(d.sh, d.init_sh, ns, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(d.best_sh, d.init_sh, ns, hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(d.cand_sh, d.init_sh, ns, hipMemcpyDeviceToDevice, s));
     }
     launch_reset(p->launcher, d, to_device_options(&p->opt, p->ignore_convergence));
     return SSBA_OK;
@@ -890,7 +956,10 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     hipStream_t s = p->launcher.stream;
     HIPCHECK(hipMemcpyAsync(p->d.init_poses, p->d.poses, (size_t)p->d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d.init_pts, p->d.pts, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (p->d.phong) HIPCHECK(hipMemcpyAsync(p->d.init_nrm, p->d.nrm, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (p->d.phong) {
+        HIPCHECK(hipMemcpyAsync(p->d.init_nrm, p->d.nrm, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(p->d.init_sh, p->d.sh, (size_t)p->d.nsh * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     rc = reset_solver(p);
     if (rc) return rc;
     HIPCHECK(hipEventRecord(p->ev_begin, s));
@@ -951,7 +1020,7 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
     const int term = S.terminated ? S.termination_type : SSBA_NO_CONVERGENCE;
     // the solution is usable unless the minimiser failed: write the lowest-cost iterate back
     if (term != SSBA_FAILURE) {
-        rc = download_params(p, p->d.best_poses, p->d.best_pts, p->d.best_nrm);
+        rc = download_params(p, p->d.best_poses, p->d.best_pts, p->d.best_nrm, p->d.best_sh);
         if (rc) return rc;
     }
     if (s) {
@@ -1087,7 +1156,10 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     hipStream_t s = p->launcher.stream;
     HIPCHECK(hipMemcpyAsync(p->d.init_poses, p->d.poses, (size_t)p->d.P * 12 * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHECK(hipMemcpyAsync(p->d.init_pts, p->d.pts, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (p->d.phong) HIPCHECK(hipMemcpyAsync(p->d.init_nrm, p->d.nrm, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (p->d.phong) {
+        HIPCHECK(hipMemcpyAsync(p->d.init_nrm, p->d.nrm, (size_t)p->d.Lpad * 3 * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHECK(hipMemcpyAsync(p->d.init_sh, p->d.sh, (size_t)p->d.nsh * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     return reset_solver(p);
 }
 
@@ -1182,6 +1254,7 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
         if (rhs) for (int i = 0; i < n; ++i) rhs[i] = r[i];
     }
     launch_bcr(L, d);
+    if (d.nb) launch_border_solve(L, d);
     launch_update_eval(L, d);
     HIPCHECK(hipStreamSynchronize(L.stream));
     HIPCHECK(hipGetLastError());
@@ -1219,6 +1292,41 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
             if (j == 0xFFFFFFFFu) continue;
             for (int c = 0; c < 3; ++c) delta_l[3 * (size_t)j + c] = a[c * Lp + l] - b[c * Lp + l];
         }
+    }
+    return SSBA_OK;
+}
+
+int ssba_border_system(ssba_problem *p, uint32_t *nb_out, double *S_pb, double *S_bb, double *rhs_b, double *delta_b) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    Dev &d = p->d;
+    if (nb_out) *nb_out = (uint32_t)d.nb;
+    if (!d.nb) return SSBA_OK;
+    HIPCHECK(hipStreamSynchronize(p->launcher.stream));
+    const int nb = d.nb, nf = d.nfree;
+    std::vector<double> bs((size_t)BS_COUNT);
+    HIPCHECK(hipMemcpy(bs.data(), d.bsys, bs.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(p->h_state, d.st, sizeof(State), hipMemcpyDeviceToHost));
+    if (S_pb) {
+        std::vector<double> sp((size_t)d.nf_pad * 6 * NBP);
+        HIPCHECK(hipMemcpy(sp.data(), d.Spb, sp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 6 * nf; ++i)
+            for (int c = 0; c < nb; ++c) S_pb[(size_t)i * nb + c] = sp[(size_t)i * NBP + c];
+    }
+    const State &S = *p->h_state;
+    const double radius = S.opt.strategy ? 1.0 / S.mu : S.radius;
+    for (int a = 0; a < nb; ++a) {
+        if (rhs_b) rhs_b[a] = -bs[BS_RHS + a];
+        if (delta_b) delta_b[a] = bs[BS_DB + a];
+        if (S_bb)
+            for (int c = 0; c < nb; ++c) {
+                double v = bs[BS_SBB + a * NBP + c];
+                if (a == c) {
+                    const double s2 = bs[BS_S + a] * bs[BS_S + a];
+                    v += std::min(std::max(bs[BS_H + a] * s2, S.opt.min_lm_diag), S.opt.max_lm_diag) / (radius * s2);
+                }
+                S_bb[(size_t)a * nb + c] = v;
+            }
     }
     return SSBA_OK;
 }

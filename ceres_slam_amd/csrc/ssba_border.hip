@@ -1,0 +1,311 @@
+// Arrowhead solve for the border of free shared blocks (config 3: light, Phong parameters, textures).
+//
+//   [S_pp S_pb; S_pb^T S_bb] [dp; db] = [-g_p^; -g_b^]
+//
+// S_pp is the block-tridiagonal reduced camera system that ssba_bcr.hip has just factored level by
+// level (G in D, YL = G^-1 L in L, YU = G^-1 L_{i+1}^T) while solving x0 = S_pp^-1 (-g_p^).  The kernels
+// here push the nb <= NBP columns of S_pb through the SAME factors (forward: yb = G^-1 B on odd blocks,
+// B' = B_e - YU^T yb - YL^T yb on even blocks; backward: X_i = G^-T (yb - YL X_{i-1} - YU X_{i+1})),
+// giving Zb = S_pp^-1 S_pb, then form and solve the small border system
+//   (S_bb + D_b^2 - S_pb^T Zb) db = -g_b^ - S_pb^T x0 ,   dp = x0 - Zb db .
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssba_launch.h"
+#include "ssba_types.h"
+
+namespace ssba {
+
+constexpr int LDT = BD + 1;            // padded LDS stride: column and row sweeps both stay conflict-light
+constexpr int MR_THREADS = 1024;       // 16 waves x 2 columns = NBP
+constexpr int UPD_THREADS = 576;       // 72 rows x 8 column groups of 4
+
+static __device__ __forceinline__ double bcast(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+static __device__ __forceinline__ void stage_pad(double *dst, const double *__restrict__ src, bool transpose) {
+    for (int e = threadIdx.x; e < BD * BD; e += blockDim.x) {
+        const int r = e / BD, c = e - r * BD;
+        dst[transpose ? c * LDT + r : r * LDT + c] = src[e];
+    }
+}
+static __device__ __forceinline__ void stage_flat(double *dst, const double *__restrict__ src, int n) {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = src[e];
+}
+
+// odd blocks: yb = G^-1 B in place (forward substitution, column sweep; lanes = rows, a wave = 2 columns)
+__global__ __launch_bounds__(MR_THREADS) void k_bcrm_fwd(Dev d, int lev, int top) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    extern __shared__ __align__(16) double lds[];
+    double *Gt = lds;   // Gt[k][i] = G[i][k]
+    const BcrLevel &L = d.lev[lev];
+    const int blk = top ? 0 : 2 * blockIdx.x + 1;
+    stage_pad(Gt, L.D + (size_t)blk * BD * BD, true);
+    double *B = L.B + (size_t)blk * BD * NBP;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
+    const bool hiRow = lane < BD - 64;
+    double lo0 = B[lane * NBP + c0], lo1 = B[lane * NBP + c1];
+    double hi0 = hiRow ? B[(64 + lane) * NBP + c0] : 0.0, hi1 = hiRow ? B[(64 + lane) * NBP + c1] : 0.0;
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 64; ++k) {
+        const double ginv = Gt[k * LDT + k];
+        const double x0 = bcast(lo0, k) * ginv, x1 = bcast(lo1, k) * ginv;
+        const double gl = (lane > k) ? Gt[k * LDT + lane] : 0.0;
+        const double gh = hiRow ? Gt[k * LDT + 64 + lane] : 0.0;
+        lo0 = (lane == k) ? x0 : lo0 - gl * x0;
+        lo1 = (lane == k) ? x1 : lo1 - gl * x1;
+        hi0 -= gh * x0;
+        hi1 -= gh * x1;
+    }
+#pragma unroll
+    for (int k = 64; k < BD; ++k) {
+        const int kk = k - 64;
+        const double ginv = Gt[k * LDT + k];
+        const double x0 = bcast(hi0, kk) * ginv, x1 = bcast(hi1, kk) * ginv;
+        const double gh = (hiRow && lane > kk) ? Gt[k * LDT + 64 + lane] : 0.0;
+        hi0 = (lane == kk) ? x0 : hi0 - gh * x0;
+        hi1 = (lane == kk) ? x1 : hi1 - gh * x1;
+    }
+    B[lane * NBP + c0] = lo0;
+    B[lane * NBP + c1] = lo1;
+    if (hiRow) { B[(64 + lane) * NBP + c0] = hi0; B[(64 + lane) * NBP + c1] = hi1; }
+}
+
+// even blocks: B'(m) = B(e) - YU(e-1)^T yb(e-1) - YL(e+1)^T yb(e+1), e = 2m
+__global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    extern __shared__ __align__(16) double lds[];
+    double *sA = lds, *sB = lds + BD * BD, *ya = lds + 2 * BD * BD, *yb = ya + BD * NBP;
+    const BcrLevel &L = d.lev[lev];
+    const BcrLevel &N = d.lev[lev + 1];
+    const int m = blockIdx.x, e = 2 * m;
+    const bool hasPrev = e >= 1, hasNext = e + 1 < L.n;
+    if (hasPrev) {
+        stage_flat(sA, L.YU + (size_t)(m - 1) * BD * BD, BD * BD);
+        stage_flat(ya, L.B + (size_t)(e - 1) * BD * NBP, BD * NBP);
+    }
+    if (hasNext) {
+        stage_flat(sB, L.L + (size_t)(e + 1) * BD * BD, BD * BD);
+        stage_flat(yb, L.B + (size_t)(e + 1) * BD * NBP, BD * NBP);
+    }
+    __syncthreads();
+    const int t = threadIdx.x, r = t % BD, cg = (t / BD) * 4;
+    double acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = L.B[((size_t)e * BD + r) * NBP + cg + c];
+    if (hasPrev)
+        for (int k = 0; k < BD; ++k) {
+            const double a = sA[k * BD + r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] -= a * ya[k * NBP + cg + c];
+        }
+    if (hasNext)
+        for (int k = 0; k < BD; ++k) {
+            const double a = sB[k * BD + r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] -= a * yb[k * NBP + cg + c];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) N.B[((size_t)m * BD + r) * NBP + cg + c] = acc[c];
+}
+
+// odd blocks, top-down: X_i = G^-T (yb_i - YL_i X_{i-1} - YU_i X_{i+1}); X lives in d.Zb at level-0 positions
+__global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    extern __shared__ __align__(16) double lds[];
+    double *sL = lds, *sU = lds + BD * LDT, *xm = lds + 2 * BD * LDT, *xp = xm + BD * NBP;
+    const BcrLevel &L = d.lev[lev];
+    const int blk = top ? 0 : 2 * blockIdx.x + 1;
+    const bool hasU = !top && (blk + 1 < L.n);
+    if (!top) {
+        stage_pad(sL, L.L + (size_t)blk * BD * BD, false);
+        stage_flat(xm, d.Zb + (((size_t)(blk - 1) << lev) * BD) * NBP, BD * NBP);
+    }
+    if (hasU) {
+        stage_pad(sU, L.YU + (size_t)blockIdx.x * BD * BD, false);
+        stage_flat(xp, d.Zb + (((size_t)(blk + 1) << lev) * BD) * NBP, BD * NBP);
+    }
+    const double *B = L.B + (size_t)blk * BD * NBP;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
+    const bool hiRow = lane < BD - 64;
+    double lo0 = B[lane * NBP + c0], lo1 = B[lane * NBP + c1];
+    double hi0 = hiRow ? B[(64 + lane) * NBP + c0] : 0.0, hi1 = hiRow ? B[(64 + lane) * NBP + c1] : 0.0;
+    __syncthreads();
+    if (!top) {
+        for (int k = 0; k < BD; ++k) {
+            const double a = sL[lane * LDT + k], ah = hiRow ? sL[(64 + lane) * LDT + k] : 0.0;
+            const double v0 = xm[k * NBP + c0], v1 = xm[k * NBP + c1];
+            lo0 -= a * v0; lo1 -= a * v1; hi0 -= ah * v0; hi1 -= ah * v1;
+        }
+        if (hasU)
+            for (int k = 0; k < BD; ++k) {
+                const double a = sU[lane * LDT + k], ah = hiRow ? sU[(64 + lane) * LDT + k] : 0.0;
+                const double v0 = xp[k * NBP + c0], v1 = xp[k * NBP + c1];
+                lo0 -= a * v0; lo1 -= a * v1; hi0 -= ah * v0; hi1 -= ah * v1;
+            }
+    }
+    __syncthreads();
+    double *sG = lds;   // rows of G over the YL staging area
+    stage_pad(sG, L.D + (size_t)blk * BD * BD, false);
+    __syncthreads();
+#pragma unroll
+    for (int k = BD - 1; k >= 64; --k) {
+        const int kk = k - 64;
+        const double ginv = sG[k * LDT + k];
+        const double x0 = bcast(hi0, kk) * ginv, x1 = bcast(hi1, kk) * ginv;
+        const double gl = sG[k * LDT + lane];
+        const double gh = (lane < kk) ? sG[k * LDT + 64 + lane] : 0.0;
+        lo0 -= gl * x0; lo1 -= gl * x1;
+        hi0 = (lane == kk) ? x0 : hi0 - gh * x0;
+        hi1 = (lane == kk) ? x1 : hi1 - gh * x1;
+    }
+#pragma unroll 4
+    for (int k = 63; k >= 0; --k) {
+        const double ginv = sG[k * LDT + k];
+        const double x0 = bcast(lo0, k) * ginv, x1 = bcast(lo1, k) * ginv;
+        const double gl = (lane < k) ? sG[k * LDT + lane] : 0.0;
+        lo0 = (lane == k) ? x0 : lo0 - gl * x0;
+        lo1 = (lane == k) ? x1 : lo1 - gl * x1;
+    }
+    double *X = d.Zb + (((size_t)blk << lev) * BD) * NBP;
+    X[lane * NBP + c0] = lo0;
+    X[lane * NBP + c1] = lo1;
+    if (hiRow) { X[(64 + lane) * NBP + c0] = hi0; X[(64 + lane) * NBP + c1] = hi1; }
+}
+
+// partial sums of S_pb^T [Zb | x0] over a slice of pose rows: thread (a, b) of the NBP x NBP result
+__global__ __launch_bounds__(1024) void k_border_gram(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    const int t = threadIdx.x, a = t / NBP, b = t - a * NBP;
+    const int rows = d.nf_pad * 6, per = (rows + d.n_gram - 1) / d.n_gram;
+    const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+    double acc = 0.0, av = 0.0;
+    for (int i = r0; i < r1; ++i) {
+        const double s = d.Spb[(size_t)i * NBP + a];
+        acc += s * d.Zb[(size_t)i * NBP + b];
+        if (b == 0) av += s * d.x0[i];
+    }
+    double *out = d.part_g + (size_t)blockIdx.x * (NBP * NBP + NBP);
+    out[t] = acc;
+    if (b == 0) out[NBP * NBP + a] = av;
+}
+
+// border system: T = S_bb + D_b^2 - S_pb^T Zb, rb = -g_b^ - S_pb^T x0, Cholesky solve -> delta_b (one wave
+// does the factorisation out of LDS)
+__global__ __launch_bounds__(1024) void k_border_solve(Dev d) {
+    State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    __shared__ double T[NBP * (NBP + 1)];
+    __shared__ double rb[NBP];
+    __shared__ int sBad;
+    const int t = threadIdx.x, a = t / NBP, b = t - a * NBP, nb = d.nb;
+    if (t == 0) sBad = 0;
+    {
+        double g = 0.0, gt = 0.0;
+        for (int q = 0; q < d.n_gram; ++q) {
+            const double *pg = d.part_g + (size_t)q * (NBP * NBP + NBP);
+            g += pg[a * NBP + b];
+            gt += pg[b * NBP + a];
+        }
+        // symmetrised against rounding (only the lower triangle is read below)
+        double v = 0.5 * ((d.bsys[BS_SBB + a * NBP + b] - g) + (d.bsys[BS_SBB + b * NBP + a] - gt));
+        if (a == b) {
+            if (a < nb) {
+                const double s = d.bsys[BS_S + a], s2 = s * s;
+                const double radius = st.opt.strategy ? 1.0 / st.mu : st.radius;
+                v += fmin(fmax(d.bsys[BS_H + a] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (radius * s2);
+            } else {
+                v = 1.0;
+            }
+        } else if (a >= nb || b >= nb) {
+            v = 0.0;
+        }
+        T[a * (NBP + 1) + b] = v;
+        if (b == 0) {
+            double gv = 0.0;
+            for (int q = 0; q < d.n_gram; ++q) gv += d.part_g[(size_t)q * (NBP * NBP + NBP) + NBP * NBP + a];
+            rb[a] = a < nb ? -d.bsys[BS_RHS + a] - gv : 0.0;
+        }
+    }
+    __syncthreads();
+    if (t >= 64) return;
+    const int i = t;   // lane = row (lanes >= NBP idle)
+    for (int j = 0; j < NBP; ++j) {
+        const double piv = T[j * (NBP + 1) + j];
+        if (!(piv > 0.0) || !isfinite(piv)) { if (i == 0) sBad = 1; break; }
+        const double rs = 1.0 / sqrt(piv);
+        double lij = 0.0;
+        if (i < NBP && i >= j) { lij = T[i * (NBP + 1) + j] * rs; T[i * (NBP + 1) + j] = lij; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (i < NBP && i > j)
+            for (int c = j + 1; c <= i; ++c) T[i * (NBP + 1) + c] -= lij * T[c * (NBP + 1) + j];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (sBad) { if (i == 0) st.step_failed = 1; return; }
+    // forward and backward substitution (lane i owns rb[i])
+    double v = i < NBP ? rb[i] : 0.0;
+    for (int j = 0; j < NBP; ++j) {
+        const double yj = bcast(v, j) / T[j * (NBP + 1) + j];
+        if (i == j) v = yj;
+        else if (i > j && i < NBP) v -= T[i * (NBP + 1) + j] * yj;
+    }
+    for (int j = NBP - 1; j >= 0; --j) {
+        const double xj = bcast(v, j) / T[j * (NBP + 1) + j];
+        if (i == j) v = xj;
+        else if (i < j) v -= T[j * (NBP + 1) + i] * xj;
+    }
+    if (i < NBP) d.bsys[BS_DB + i] = i < nb ? v : 0.0;
+}
+
+// dp = x0 - Zb db
+__global__ __launch_bounds__(256) void k_border_apply(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nf_pad * 6) return;
+    double v = d.x0[i];
+    for (int c = 0; c < d.nb; ++c) v -= d.Zb[(size_t)i * NBP + c] * d.bsys[BS_DB + c];
+    d.x0[i] = v;
+}
+
+static constexpr size_t SH_FWD = (size_t)BD * LDT * sizeof(double);
+static constexpr size_t SH_UPD = (size_t)(2 * BD * BD + 2 * BD * NBP) * sizeof(double);
+static constexpr size_t SH_BWD = (size_t)(2 * BD * LDT + 2 * BD * NBP) * sizeof(double);
+
+int configure_border() {
+    if (hipFuncSetAttribute((const void *)k_bcrm_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_FWD) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcrm_upd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_UPD) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcrm_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH_BWD) != hipSuccess) return -1;
+    return 0;
+}
+
+// after launch_bcr: x0 = S_pp^-1 (-g_p^) and the level factors are in place
+void launch_border_solve(Launcher &L, const Dev &d) {
+    const int nl = d.n_levels;
+    hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
+    for (int l = 0; l + 1 < nl; ++l) {
+        const int n = d.lev[l].n;
+        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0);
+        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l);
+    }
+    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1);
+    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1);
+    for (int l = nl - 2; l >= 0; --l)
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0);
+    LAUNCH(KC_BORDER, k_border_gram, dim3(d.n_gram), dim3(1024), 0, d);
+    LAUNCH(KC_SMALL, k_border_solve, dim3(1), dim3(1024), 0, d);
+    LAUNCH(KC_SMALL, k_border_apply, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
+}
+
+}  // namespace ssba

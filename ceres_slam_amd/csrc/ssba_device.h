@@ -245,4 +245,13 @@ static __device__ __forceinline__ bool inv3_spd_fast(const double h[6], const do
 }
 
 
+// UnitVectorPerturbation::operator() (perturbations.hpp:98-102)
+static __device__ __forceinline__ void unit_plus(const double x[3], const double dl[3], double out[3]) {
+    const double s = (dl[0] * x[0] + dl[1] * x[1] + dl[2] * x[2]) / (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    const double y0 = x[0] + dl[0] - s * x[0], y1 = x[1] + dl[1] - s * x[1], y2 = x[2] + dl[2] - s * x[2];
+    const double nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
+    out[0] = y0 / nrm; out[1] = y1 / nrm; out[2] = y2 / nrm;
+}
+
+
 }  // namespace ssba

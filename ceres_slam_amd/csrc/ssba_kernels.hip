@@ -453,8 +453,25 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
     if (lin) {
         double *sc = d.xv + d.off_scal;
         st.x_cost = sc[0];
-        st.x_norm = sqrt(sc[1] + xnp);
-        st.gmax = fmax(gmp, *d.gmax_l);
+        double xnb = 0.0, gmb = 0.0;
+        if (d.nb) {   // free shared blocks: |x_b|^2 and |x_b - Plus(x_b, -g_b)|_inf
+            const double *gb = d.bsys + BS_G;
+            if (d.b_light >= 0) {
+                double ng[3] = {-gb[d.b_light], -gb[d.b_light + 1], -gb[d.b_light + 2]}, nl[3];
+                if (d.light_type == 1) unit_plus(d.sh, ng, nl);
+                else for (int c = 0; c < 3; ++c) nl[c] = d.sh[c] + ng[c];
+                for (int c = 0; c < 3; ++c) { xnb += d.sh[c] * d.sh[c]; gmb = fmax(gmb, fabs(nl[c] - d.sh[c])); }
+            }
+            if (d.b_phong >= 0)
+                for (int c = 0; c < 3 * d.M; ++c) { xnb += d.sh[3 + c] * d.sh[3 + c]; gmb = fmax(gmb, fabs(gb[d.b_phong + c])); }
+            if (d.b_tex >= 0)
+                for (int c = 0; c < d.M; ++c) {
+                    const double v = d.sh[3 + 3 * d.M + c];
+                    xnb += v * v; gmb = fmax(gmb, fabs(gb[d.b_tex + c]));
+                }
+        }
+        st.x_norm = sqrt(sc[1] + xnp + xnb);
+        st.gmax = fmax(fmax(gmp, *d.gmax_l), gmb);
         st.just_linearized = 0;
         sc[0] = 0.0;   // consumed: later all-reduces of the exchange vector add zeros
         sc[1] = 0.0;
@@ -503,6 +520,7 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
         d.best_pts[i] = d.pts[i];
         if (d.phong) d.best_nrm[i] = d.nrm[i];
     }
+    if (d.phong && i < (size_t)d.nsh) d.best_sh[i] = d.sh[i];
 }
 __global__ void k_best_done(Dev d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d.st->copy_best = 0;
@@ -920,7 +938,7 @@ __global__ __launch_bounds__(256) void k_decide(Dev d) {
     if (st.terminated) return;
     __shared__ double sm[4];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) {
+    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) {   // last entry: border of shared blocks
         a += d.part_pose[i * 2];
         b += d.part_pose[i * 2 + 1];
     }
@@ -1032,6 +1050,7 @@ __global__ __launch_bounds__(256) void k_commit(Dev d) {
         d.pts[i] = d.cand_pts[i];
         if (d.phong) d.nrm[i] = d.cand_nrm[i];
     }
+    if (d.phong && i < (size_t)d.nsh) d.sh[i] = d.cand_sh[i];
 }
 
 // (re)start of a solve: reset the trust-region state on the device

@@ -18,6 +18,7 @@ enum KernelClass {
     KC_BCR_BACKSUB,
     KC_BACKSUB_EVAL,
     KC_DOGLEG,
+    KC_BORDER,
     KC_COPY,
     KC_SMALL,
     KC_COUNT
@@ -25,7 +26,7 @@ enum KernelClass {
 
 static const char *const kKernelClassName[KC_COUNT] = {
     "k_linearize_landmarks", "k_linearize_poses", "k_schur_windows", "k_assemble_reduced",
-    "k_bcr_factor", "k_bcr_reduce", "k_bcr_backsub", "k_backsub_eval", "k_dogleg_gn+k_dogleg_eval", "copy(k_best,k_commit)",
+    "k_bcr_factor", "k_bcr_reduce", "k_bcr_backsub", "k_backsub_eval", "k_dogleg_gn+k_dogleg_eval", "border(shared blocks)", "copy(k_best,k_commit)",
     "small(control,reductions)"};
 
 // Stream + optional per-kernel-class HIP-event timing (events are recorded on the
@@ -104,5 +105,8 @@ int configure_phong();
 void launch_ph_linearize(Launcher &L, const Dev &d);
 void launch_ph_schur(Launcher &L, const Dev &d);
 void launch_ph_backsub_eval(Launcher &L, const Dev &d);
+// border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
+int configure_border();
+void launch_border_solve(Launcher &L, const Dev &d);
 
 }  // namespace ssba

@@ -42,8 +42,23 @@ struct ObsPh {
     double r[7];
     double Jp[42];   // 7 x 6
     double Jl[42];   // 7 x 6
+    double jb[NBQ];  // intensity row w.r.t. the shared blocks: [phong 3 | kd | light 3]
     double half_sq;  // 1/2 |r|^2
 };
+
+// shared blocks of one observation out of the packed state [light 3 | phong 3M | texture M]
+struct Shared { double light[3], ph3[3], kd; };
+static __device__ __forceinline__ void load_shared(const Dev &d, const double *__restrict__ sh, uint32_t mat, Shared &x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x.light[c] = sh[c]; x.ph3[c] = sh[3 + 3 * mat + c]; }
+    x.kd = sh[3 + 3 * d.M + mat];
+}
+// border column of entry q of jb for material `mat`, -1 when that block is constant
+static __device__ __forceinline__ int bcol(const Dev &d, uint32_t mat, int q) {
+    if (q < 3) return d.b_phong < 0 ? -1 : d.b_phong + 3 * (int)mat + q;
+    if (q == 3) return d.b_tex < 0 ? -1 : d.b_tex + (int)mat;
+    return d.b_light < 0 ? -1 : d.b_light + (q - 4);
+}
 
 static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const double *__restrict__ T, const double p[3],
                                                         const double n[3], uint32_t mat, double u, double v, double dd,
@@ -66,9 +81,12 @@ static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const doub
 #pragma unroll
         for (int i = 0; i < 18; ++i) o.Jp[i] = Jp3[i];
     }
-    const double ph3[3] = {d.mat[4 * mat], d.mat[4 * mat + 1], d.mat[4 * mat + 2]};
+    Shared sx;
+    load_shared(d, d.sh, mat, sx);
     double ri, J19[19], rn[3], Jnp[18], Jnn[9];
-    intensity_residual(d.light_type, T, p, n, ph3, d.mat[4 * mat + 3], d.light, inten, d.int_stiff, &ri, J19);
+    intensity_residual(d.light_type, T, p, n, sx.ph3, sx.kd, sx.light, inten, d.int_stiff, &ri, J19);
+#pragma unroll
+    for (int q = 0; q < NBQ; ++q) o.jb[q] = J19[12 + q];
     normal_residual(T, n, nobs, d.Sn, rn, Jnp, Jnn);
     o.r[3] = ri;
 #pragma unroll
@@ -89,22 +107,15 @@ static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const doub
 }
 
 // residuals only (candidate evaluation)
-static __device__ __forceinline__ double obs_ph_cost(const Dev &d, const double *__restrict__ T, const double p[3],
-                                                     const double n[3], uint32_t mat, double u, double v, double dd,
-                                                     double inten, const double nobs[3]) {
-    const double ph3[3] = {d.mat[4 * mat], d.mat[4 * mat + 1], d.mat[4 * mat + 2]};
+static __device__ __forceinline__ double obs_ph_cost(const Dev &d, const double *__restrict__ sh, const double *__restrict__ T,
+                                                     const double p[3], const double n[3], uint32_t mat, double u, double v,
+                                                     double dd, double inten, const double nobs[3]) {
+    Shared sx;
+    load_shared(d, sh, mat, sx);
     double ri, rn[3];
-    intensity_residual(d.light_type, T, p, n, ph3, d.mat[4 * mat + 3], d.light, inten, d.int_stiff, &ri, nullptr);
+    intensity_residual(d.light_type, T, p, n, sx.ph3, sx.kd, sx.light, inten, d.int_stiff, &ri, nullptr);
     normal_residual(T, n, nobs, d.Sn, rn, nullptr, nullptr);
     return obs_cost(d, T, p[0], p[1], p[2], u, v, dd) + 0.5 * (ri * ri + rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2]);
-}
-
-// UnitVectorPerturbation::operator() (perturbations.hpp:98-102)
-static __device__ __forceinline__ void unit_plus(const double x[3], const double dl[3], double out[3]) {
-    const double s = (dl[0] * x[0] + dl[1] * x[1] + dl[2] * x[2]) / (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-    const double y0 = x[0] + dl[0] - s * x[0], y1 = x[1] + dl[1] - s * x[1], y2 = x[2] + dl[2] - s * x[2];
-    const double nrm = sqrt(y0 * y0 + y1 * y1 + y2 * y2);
-    out[0] = y0 / nrm; out[1] = y1 / nrm; out[2] = y2 / nrm;
 }
 
 __device__ __forceinline__ int tri6(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
@@ -475,6 +486,20 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
                 for (int c = 0; c < 6; ++c) tt[c] += o.Jl[6 * m + c] * jd;
             }
         }
+        double dbq[NBQ];   // border step seen by this landmark's material
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) dbq[q] = 0.0;
+        if (d.nb) {
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                const int c = bcol(d, x.mat, q);
+                dbq[q] = c >= 0 ? d.bsys[BS_DB + c] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) tt[a] += d.lmV[(size_t)(a * NBQ + q) * d.Lpad + l] * dbq[q];
+        }
         double Ci[21];
 #pragma unroll
         for (int c = 0; c < 21; ++c) Ci[c] = d.cinv[(size_t)c * d.Lpad + l];
@@ -511,9 +536,13 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
 #pragma unroll
                     for (int c = 0; c < 6; ++c) jd += o.Jp[6 * m + c] * dp[c];
                 }
+                if (m == 3) {
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) jd += o.jb[q] * dbq[q];
+                }
                 mcc -= jd * (o.r[m] + 0.5 * jd);
             }
-            ccost += obs_ph_cost(d, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, u, v, dd, inten, nobs);
+            ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, u, v, dd, inten, nobs);
         }
     }
 #pragma unroll
@@ -532,15 +561,290 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
     }
 }
 
+// ------------------------------------------------------------------ border ---
+// Free shared blocks (light, Phong parameters and texture of each material: the blocks every
+// intensity residual of dataset_ba_phong.cpp:108-139 touches) are a dense border of the system:
+//   [S_pp S_pb; S_pb^T S_bb] [dp; db] = -[g_p^; g_b^]
+// with S_pb = H_pb - sum_j W_j C_j^-1 V_j,  S_bb = H_bb + D_b^2 - sum_j V_j^T C_j^-1 V_j,
+// g_b^ = g_b - sum_j V_j^T C_j^-1 g_l,j  and V_j = H_lb of landmark j (6 x 7: only the columns of its
+// material and of the light are non-zero).  The kernels below build V_j / H_bb / g_b (on
+// linearisation), the Schur-complemented border blocks (every iteration) and the pose rows of S_pb;
+// ssba_border.hip solves the arrowhead system on top of the block-cyclic-reduction factors.
+
+__device__ __forceinline__ int tri7(int r, int c) { return r * 7 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
+
+// one lane per landmark, on linearisation: V_j (42), H_bb,j (28 unique), g_b,j (7)
+__global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double V[42], H[28], G[7];
+#pragma unroll
+    for (int i = 0; i < 42; ++i) V[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 28; ++i) H[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) G[i] = 0.0;
+    if (mask) {
+        const uint32_t win = d.lm_win[l];
+        LmIn x;
+        load_lm(d, l, x);
+        Shared sx;
+        load_shared(d, d.sh, x.mat, sx);
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            double ri, J19[19];
+            intensity_residual(d.light_type, d.poses + (size_t)k * 12, x.p, x.n, sx.ph3, sx.kd, sx.light,
+                               d.oi[obase + (size_t)s * LMG], d.int_stiff, &ri, J19);
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                G[q] += J19[12 + q] * ri;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) V[a * NBQ + q] += J19[6 + a] * J19[12 + q];
+#pragma unroll
+                for (int q2 = q; q2 < NBQ; ++q2) H[c++] += J19[12 + q] * J19[12 + q2];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 42; ++i) d.lmV[(size_t)i * d.Lpad + l] = V[i];
+#pragma unroll
+    for (int i = 0; i < 28; ++i) d.lmH[(size_t)i * d.Lpad + l] = H[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) d.lmG[(size_t)i * d.Lpad + l] = G[i];
+}
+
+// one lane per landmark, every iteration (after k_ph_invert): the landmark's contribution to
+// S_bb, g_b^, diag(H_bb) and g_b, summed per material over the block of 256 landmarks (fixed order).
+constexpr int BSP = 17;   // components per LDS pass (3 passes cover NBV = 49)
+__global__ __launch_bounds__(256) void k_ph_border_schur(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    __shared__ double sv[256 * BSP];
+    __shared__ uint8_t smat[256];
+    const int t = threadIdx.x, l = blockIdx.x * 256 + t;
+    const uint32_t mask = d.lm_mask[l];
+    double val[NBV + 2];
+#pragma unroll
+    for (int i = 0; i < NBV + 2; ++i) val[i] = 0.0;
+    if (mask) {
+        double V[42], Ci[21], CV[42], Cg[6], g[6];
+#pragma unroll
+        for (int i = 0; i < 42; ++i) V[i] = d.lmV[(size_t)i * d.Lpad + l];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Ci[i] = d.cinv[(size_t)i * d.Lpad + l];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = d.gl[(size_t)i * d.Lpad + l];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double cg = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) cg += Ci[a <= b ? tri6(a, b) : tri6(b, a)] * g[b];
+            Cg[a] = cg;
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) v += Ci[a <= b ? tri6(a, b) : tri6(b, a)] * V[b * NBQ + q];
+                CV[a * NBQ + q] = v;
+            }
+        }
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+#pragma unroll
+            for (int q2 = q; q2 < NBQ; ++q2) {
+                double v = d.lmH[(size_t)c * d.Lpad + l];
+                if (q2 == q) val[35 + q] = v;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) v -= V[a * NBQ + q] * CV[a * NBQ + q2];
+                val[c++] = v;
+            }
+            const double gq = d.lmG[(size_t)q * d.Lpad + l];
+            double v = gq;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v -= V[a * NBQ + q] * Cg[a];
+            val[28 + q] = v;
+            val[42 + q] = gq;
+        }
+    }
+    smat[t] = mask ? (uint8_t)d.lm_mat[l] : (uint8_t)0xFF;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < BSP; ++c) sv[t * BSP + c] = val[p * BSP + c];
+        __syncthreads();
+        const int cnt = (NBV - p * BSP) < BSP ? (NBV - p * BSP) : BSP;
+        if (t < cnt * d.M) {
+            const int comp = t / d.M, m = t - comp * d.M;
+            double acc = 0.0;
+            for (int i = 0; i < 256; ++i)
+                if (smat[i] == m) acc += sv[i * BSP + comp];
+            d.part_b[((size_t)blockIdx.x * d.M + m) * NBV + p * BSP + comp] = acc;
+        }
+    }
+}
+
+// sums the per-block partials and scatters them into the border system (one block)
+__global__ __launch_bounds__(256) void k_ph_border_reduce(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    __shared__ double tot[8 * NBV];
+    const int t = threadIdx.x;
+    for (int idx = t; idx < d.M * NBV; idx += 256) {
+        double a = 0.0;
+        for (int b = 0; b < d.n_lm_blocks; ++b) a += d.part_b[(size_t)b * d.M * NBV + idx];
+        tot[idx] = a;
+    }
+    for (int i = t; i < BS_S; i += 256) d.bsys[i] = 0.0;     // Sbb | rhsb | gb | hb
+    __syncthreads();
+    if (t != 0) return;
+    double *S = d.bsys + BS_SBB;
+    for (int m = 0; m < d.M; ++m) {
+        const double *tm = tot + m * NBV;
+        for (int q = 0; q < NBQ; ++q) {
+            const int c = bcol(d, (uint32_t)m, q);
+            if (c < 0) continue;
+            d.bsys[BS_RHS + c] += tm[28 + q];
+            d.bsys[BS_H + c] += tm[35 + q];
+            d.bsys[BS_G + c] += tm[42 + q];
+            for (int q2 = q; q2 < NBQ; ++q2) {
+                const int c2 = bcol(d, (uint32_t)m, q2);
+                if (c2 < 0) continue;
+                const double v = tm[tri7(q, q2)];
+                S[c * NBP + c2] += v;
+                if (c2 != c) S[c2 * NBP + c] += v;
+            }
+        }
+    }
+    if (st.iteration == 0)
+        for (int c = 0; c < d.nb; ++c) d.bsys[BS_S + c] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(d.bsys[BS_H + c])) : 1.0;
+}
+
+// one block per free pose, every iteration: its six rows of S_pb = H_pb - sum_j Y_j V_j.  The pose's
+// observation references are sorted by material, so a thread accumulates one material's four columns
+// at a time (plus the three light columns throughout) and the block reduces them in a fixed order.
+__global__ __launch_bounds__(256) void k_ph_border_poses(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    const int k = blockIdx.x, f = d.pose_free[k];
+    if (f < 0) return;
+    __shared__ double sm[4][24];
+    const int t = threadIdx.x;
+    const double *T = d.poses + (size_t)k * 12;
+    double accL[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) accL[i] = 0.0;
+    for (int m = 0; m <= d.M; ++m) {
+        double accM[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) accM[i] = 0.0;
+        if (m < d.M) {
+            const uint32_t b = d.pose_mat_start[(size_t)k * (d.M + 1) + m], e = d.pose_mat_start[(size_t)k * (d.M + 1) + m + 1];
+            for (uint32_t i = b + t; i < e; i += 256) {
+                const uint32_t ref = d.pose_obs_ref[i];
+                const int l = (int)(ref >> 4), s = (int)(ref & 15u);
+                const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+                LmIn x;
+                load_lm(d, l, x);
+                const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
+                ObsPh o;
+                obs_ph_linearize(d, T, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+                double Ci[21];
+#pragma unroll
+                for (int c = 0; c < 21; ++c) Ci[c] = d.cinv[(size_t)c * d.Lpad + l];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double w[6], y[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int r = 0; r < 7; ++r) v += o.Jp[6 * r + a] * o.Jl[6 * r + c];
+                        w[c] = v;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int q = 0; q < 6; ++q) v += w[q] * Ci[q <= c ? tri6(q, c) : tri6(c, q)];
+                        y[c] = v;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) {
+                        double v = o.Jp[18 + a] * o.jb[q];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) v -= y[c] * d.lmV[(size_t)(c * NBQ + q) * d.Lpad + l];
+                        if (q < 4) accM[a * 4 + q] += v;
+                        else accL[a * 3 + (q - 4)] += v;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 18; ++i) accM[i] = accL[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const double v = wave_sum(accM[i]);
+            if ((t & 63) == 0) sm[t >> 6][i] = v;
+        }
+        __syncthreads();
+        if (t < 24) {
+            const double v = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+            int a, col;
+            if (m < d.M) { a = t / 4; col = bcol(d, (uint32_t)m, t - a * 4); }
+            else { a = t / 3; col = (t < 18) ? bcol(d, 0u, 4 + (t - a * 3)) : -1; }
+            if (col >= 0) d.Spb[((size_t)f * 6 + a) * NBP + col] = v;
+        }
+    }
+}
+
+// candidate shared blocks = Plus(x_b, delta_b): Euclidean, UnitVectorPerturbation on a directional
+// light (dataset_ba_phong.cpp:201-204); its |dx|^2 and non-finite flag join the pose partials
+__global__ void k_ph_border_update(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || threadIdx.x != 0 || blockIdx.x != 0) return;
+    double dn = 0.0, bad = 0.0;
+    for (int i = 0; i < d.nsh; ++i) d.cand_sh[i] = d.sh[i];
+    if (!st.step_failed && d.nb) {
+        const double *db = d.bsys + BS_DB;
+        for (int c = 0; c < d.nb; ++c)
+            if (!isfinite(db[c])) bad = 1.0;
+        if (d.b_light >= 0) {
+            if (d.light_type == 1) unit_plus(d.sh, db + d.b_light, d.cand_sh);
+            else for (int c = 0; c < 3; ++c) d.cand_sh[c] = d.sh[c] + db[d.b_light + c];
+        }
+        if (d.b_phong >= 0) for (int c = 0; c < 3 * d.M; ++c) d.cand_sh[3 + c] = d.sh[3 + c] + db[d.b_phong + c];
+        if (d.b_tex >= 0) for (int c = 0; c < d.M; ++c) d.cand_sh[3 + 3 * d.M + c] = d.sh[3 + 3 * d.M + c] + db[d.b_tex + c];
+        for (int i = 0; i < d.nsh; ++i) { const double df = d.cand_sh[i] - d.sh[i]; dn += df * df; }
+    }
+    d.part_pose[d.n_pose_blocks * 2] = dn;
+    d.part_pose[d.n_pose_blocks * 2 + 1] = bad;
+}
+
 void launch_ph_linearize(Launcher &L, const Dev &d) {
     LAUNCH(KC_LIN_LM, k_ph_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_LIN_POSE, k_ph_linearize_poses, dim3(d.P), dim3(256), 0, d);
+    if (d.nb) LAUNCH(KC_BORDER, k_ph_border_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 void launch_ph_schur(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SCHUR, k_ph_schur_windows, dim3(d.n_slabs), dim3(PH_THREADS), PH_LDS_DOUBLES * sizeof(double), d);
+    if (d.nb) {
+        LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
+        LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
+        LAUNCH(KC_BORDER, k_ph_border_poses, dim3(d.P), dim3(256), 0, d);
+    }
 }
 void launch_ph_backsub_eval(Launcher &L, const Dev &d) {
+    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
     LAUNCH(KC_BACKSUB_EVAL, k_ph_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 int configure_phong() {

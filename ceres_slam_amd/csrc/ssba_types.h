@@ -30,6 +30,9 @@ constexpr int LMG = 64;                 // landmarks per ELL group (= wavefront)
 constexpr int SLAB_DOUBLES = NPAIR * 36 + TW * 6;   // per Schur work item
 constexpr int MAX_LEVELS = 24;
 constexpr int NSCAL = 16;
+constexpr int NBP = 32;                 // padded width of the border of free shared blocks (nb <= NBP)
+constexpr int NBQ = 7;                  // border entries one intensity row touches: [phong 3 | kd | light 3]
+constexpr int NBV = 49;                 // per-landmark border sums: S_bb part 28 | rhs_b 7 | diag H_bb 7 | g_b 7
 
 struct Options {   // device copy of ssba_options
     int max_num_iterations, max_nonmono, jacobi_scaling, max_invalid, ignore_convergence, strategy;
@@ -72,6 +75,7 @@ struct BcrLevel {
     int n;            // blocks at this level
     double *D, *L, *r;  // n blocks each (L[0] unused)
     double *YU;       // n/2 blocks: G^-1 L[i+1]^T for odd i
+    double *B;        // n x BD x NBP extra right-hand sides (border columns), or nullptr
 };
 
 struct Dev {
@@ -125,13 +129,28 @@ struct Dev {
     unsigned long long *dbg;         // in-kernel stamps (diagnostic builds only, -DSSBA_STAMPS)
     // config 3 (stereo + Phong intensity + normal blocks; landmark block = [position | normal])
     int phong, light_type;
-    double light[3], int_stiff, Sn[9];
+    double int_stiff, Sn[9];
     double *nrm, *cand_nrm, *best_nrm, *init_nrm;   // 3*Lpad, component-major
     const double *oi, *onx, *ony, *onz;             // ELL: observed intensity and normal
     const uint32_t *lm_mat;                         // Lpad -> material
-    const double *mat;                              // M*4: ka, ks, alpha, kd (texture)
+    // shared blocks, packed ambient state [light 3 | phong 3M (ka,ks,alpha) | texture M (kd)]
+    int M, nsh;
+    double *sh, *cand_sh, *best_sh, *init_sh;
     double *cinv;                                   // 21*Lpad damped landmark block inverse
     double *dlm;                                    // 6*Lpad landmark step (local coordinates)
+    // free shared blocks = dense border of the reduced system (nb columns; offsets, -1 = constant)
+    int nb, b_light, b_phong, b_tex;
+    const uint32_t *pose_mat_start;                 // P*(M+1): pose_obs_ref is sorted by material inside a pose
+    double *lmV, *lmH, *lmG;                        // per landmark: H_lb 42, H_bb 28, g_b 7 (component-major)
+    double *part_b;                                 // n_lm_blocks * M * NBV
+    double *Spb;                                    // nf_pad*6 x NBP   S_pb (rows of free poses)
+    double *Zb;                                     // nf_pad*6 x NBP   S_pp^-1 S_pb
+    double *part_g;                                 // gram partials: n_gram x (NBP*NBP + NBP)
+    int n_gram;
+    // border system, NBP-strided: Sbb (NBP*NBP) | rhsb | gb | hb | sb | db
+    double *bsys;
 };
+constexpr int BS_SBB = 0, BS_RHS = NBP * NBP, BS_G = BS_RHS + NBP, BS_H = BS_G + NBP, BS_S = BS_H + NBP,
+              BS_DB = BS_S + NBP, BS_COUNT = BS_DB + NBP;
 
 }  // namespace ssba

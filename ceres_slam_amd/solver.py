@@ -15,7 +15,7 @@ from . import capi
 class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
                  stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
-                 world_size: int = 1, rank: int = 0, lighting: dict = None):
+                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
         self.points = np.ascontiguousarray(points, dtype=np.float64)
@@ -42,6 +42,7 @@ class StereoBA:
             capi.check(self.lib.ssba_set_huber_loss(self.h, float(huber_a)), "ssba_set_huber_loss")
         self._xcb = None
         self.normals = None
+        self.shared_free = int(shared_free)
         if lighting is not None:
             self._add_lighting(lighting)
         if world_size > 1:
@@ -53,18 +54,22 @@ class StereoBA:
         """Config-3 terms (include/ssba.h "config 3"); `lt` has the keys of synth.PhongData.as_oracle_dict()."""
         L, N = self.points.shape[0], self._obs_pose.shape[0]
         self.normals = np.ascontiguousarray(lt["normals"], dtype=np.float64).copy()   # caller-owned block, updated in place
-        self._phong = np.ascontiguousarray(lt["phong"], dtype=np.float64)
-        self._texture = np.ascontiguousarray(lt["texture"], dtype=np.float64)
+        # shared blocks: caller-owned, updated in place when free (shared_free: bit 0 light, 1 Phong, 2 texture)
+        self.phong = np.ascontiguousarray(lt["phong"], dtype=np.float64).copy()
+        self.texture = np.ascontiguousarray(lt["texture"], dtype=np.float64).copy()
+        self.light = np.ascontiguousarray(lt["light"], dtype=np.float64).copy()
         self._mat = np.ascontiguousarray(lt["material_of_point"], dtype=np.uint32)
-        self._light = np.ascontiguousarray(lt["light"], dtype=np.float64)
         self._int = np.ascontiguousarray(lt["intensity"], dtype=np.float64)
         self._nobs = np.ascontiguousarray(lt["normal_obs"], dtype=np.float64)
         self._Sn = np.ascontiguousarray(np.asarray(lt["normal_stiffness"], dtype=np.float64).reshape(9))
         assert self.normals.shape == (L, 3) and self._int.shape == (N,) and self._nobs.shape == (N, 3)
         capi.check(self.lib.ssba_add_normal_blocks(self.h, capi.dptr(self.normals), L), "ssba_add_normal_blocks")
-        capi.check(self.lib.ssba_set_materials(self.h, capi.dptr(self._phong), capi.dptr(self._texture), self._texture.shape[0],
-                                               self._mat.ctypes.data_as(capi._u32p), L), "ssba_set_materials")
-        capi.check(self.lib.ssba_set_light(self.h, capi.dptr(self._light), int(lt["light_type"])), "ssba_set_light")
+        capi.check(self.lib.ssba_add_material_blocks(self.h, capi.dptr(self.phong), capi.dptr(self.texture), self.texture.shape[0],
+                                                     self._mat.ctypes.data_as(capi._u32p), L), "ssba_add_material_blocks")
+        capi.check(self.lib.ssba_add_light_block(self.h, capi.dptr(self.light), int(lt["light_type"])), "ssba_add_light_block")
+        for which in range(3):
+            capi.check(self.lib.ssba_set_shared_block_constant(self.h, which, 0 if (self.shared_free >> which) & 1 else 1),
+                       "ssba_set_shared_block_constant")
         capi.check(self.lib.ssba_add_lighting_observations(self.h, capi.dptr(self._int), float(lt["int_stiffness"]),
                                                            capi.dptr(self._nobs), capi.dptr(self._Sn), N),
                    "ssba_add_lighting_observations")
@@ -183,6 +188,18 @@ class StereoBA:
         capi.check(self.lib.ssba_evaluate(self.h, C.byref(cost), capi.dptr(g_p), capi.dptr(g_l), capi.dptr(H_pp),
                                           capi.dptr(H_ll)), "ssba_evaluate")
         return cost.value, g_p, g_l, H_pp, H_ll
+
+    def border_system(self):
+        """Border blocks of the last lm_step (free shared blocks): S_pb, S_bb (damped), rhs_b, delta_b."""
+        nb = C.c_uint32()
+        capi.check(self.lib.ssba_border_system(self.h, C.byref(nb), None, None, None, None), "ssba_border_system")
+        nb = int(nb.value)
+        n = 6 * self.stats().num_free_poses
+        S_pb, S_bb, rhs_b, db = np.zeros((n, max(nb, 1))), np.zeros((max(nb, 1), max(nb, 1))), np.zeros(max(nb, 1)), np.zeros(max(nb, 1))
+        if nb:
+            capi.check(self.lib.ssba_border_system(self.h, None, capi.dptr(S_pb), capi.dptr(S_bb), capi.dptr(rhs_b), capi.dptr(db)),
+                       "ssba_border_system")
+        return S_pb[:, :nb], S_bb[:nb, :nb], rhs_b[:nb], db[:nb]
 
     def lm_step(self, radius: float, options: capi.Options = None, want_S: bool = True):
         P, L = self.poses.shape[0], self.points.shape[0]

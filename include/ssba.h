@@ -215,35 +215,49 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
 
 /* ---- config 3: lighting terms on the same graph (tests/dataset_ba_phong.cpp:101-204) ---- */
 /* The Phong driver adds, for every stereo observation (pose k, vertex j), an intensity residual
- * block (pose, position, normal, material Phong parameters, texture, light; :108-139) and a normal
- * residual block (pose, normal; :181-188), with UnitVectorPerturbation on the normal (:191-193).
- * This build optimises poses, positions and normals (landmark block = [position | normal], 6-D
- * local step) and holds the shared blocks constant -- the state the driver's commented
- * SetParameterBlockConstant lines (:166-172, :205-206) select: material parameters, textures and
- * the light.  (Free shared blocks add a dense border to the reduced system; that and the
- * parameter bounds (:142-180) are the next row, see DESIGN.md.)
+ * block over (pose, position, normal, material Phong parameters, texture, light) (:108-139) and a
+ * normal residual block over (pose, normal) (:181-188), with UnitVectorPerturbation on the normal
+ * (:191-193) and on a directional light (:201-204).  Landmark blocks become [position | normal]
+ * (6-D local step); the shared blocks -- the light, and the Phong parameters [ka, ks, alpha] and the
+ * texture kd of each material -- are a dense border of the reduced camera system, solved together
+ * with the poses.
  *
- * ssba_add_normal_blocks   : replaces AddParameterBlock/SetParameterization of
- *                            map_vertices[j].normal() ; normals (num*3) caller-owned, updated in
- *                            place by ssba_solve like the points; num must equal the point count.
- * ssba_set_materials       : phong (M*3: ka, ks, alpha), texture (M: kd) and the material of each
- *                            point (num_points entries); copied.
- * ssba_set_light           : light position (light_type 0) or direction (1); copied.
+ * ssba_add_normal_blocks    : replaces AddParameterBlock / SetParameterization of
+ *                             map_vertices[j].normal(); normals (num*3) caller-owned, updated in
+ *                             place by ssba_solve like the points; num must equal the point count.
+ * ssba_add_material_blocks  : material()->phong_params().data() (M*3) and texture()->data() (M),
+ *                             caller-owned and updated in place when free; material_of_point maps
+ *                             each point to its material (copied).  M <= SSBA_MAX_MATERIALS.
+ * ssba_add_light_block      : dataset.light_pos.data() (light_type 0) or light_dir.data() (1),
+ *                             caller-owned, updated in place when free.
+ * ssba_set_shared_block_constant : SetParameterBlockConstant on ALL blocks of one kind
+ *                             (:166-172, :205-206 -- the driver's "DEBUG: hold ... constant" lines and
+ *                             its --multistage stages): which = SSBA_BLOCK_LIGHT / _PHONG / _TEXTURE.
+ *                             Shared blocks are free by default, as in the driver.
  * ssba_add_lighting_observations : intensity (num) and observed normal (num*3) of the i-th stereo
- *                            observation already added (same order), 1/sqrt(int_var) and the 3x3
- *                            normal stiffness; num must equal the stereo observation count at
- *                            ssba_finalize.
+ *                             observation already added (same order), 1/sqrt(int_var) and the 3x3
+ *                             normal stiffness; num must equal the stereo observation count at
+ *                             ssba_finalize.
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
- * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  Huber loss, DOGLEG and landmark
- * sharding are not available together with lighting terms yet (SSBA_ERR_UNSUPPORTED). */
+ * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  Not available together with lighting
+ * terms yet (SSBA_ERR_UNSUPPORTED): Huber loss, DOGLEG, landmark sharding, parameter bounds
+ * (:142-180). */
+#define SSBA_MAX_MATERIALS 7
+enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };
 int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);
-int ssba_set_materials(ssba_problem *p, const double *phong, const double *texture,
-                       uint32_t num_materials, const uint32_t *material_of_point,
-                       uint32_t num_points);
-int ssba_set_light(ssba_problem *p, const double light[3], int light_type);
+int ssba_add_material_blocks(ssba_problem *p, double *phong, double *texture, uint32_t num_materials,
+                             const uint32_t *material_of_point, uint32_t num_points);
+int ssba_add_light_block(ssba_problem *p, double *light, int light_type);
+int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant);
 int ssba_add_lighting_observations(ssba_problem *p, const double *intensity,
                                    double intensity_stiffness, const double *normal_obs,
                                    const double normal_stiffness[9], uint64_t num);
+/* test hook: the border of the last ssba_lm_step -- nb = 3 [light] + 3M [Phong] + M [texture] as
+ * freed (that column order), S_pb (6*num_free_poses x nb), S_bb (nb x nb, damped), rhs_b (nb) of
+ *   [S S_pb; S_pb^T S_bb] [delta_p; delta_b] = [rhs; rhs_b]
+ * and the border step delta_b (nb).  Any output may be NULL. */
+int ssba_border_system(ssba_problem *p, uint32_t *nb, double *S_pb, double *S_bb, double *rhs_b,
+                       double *delta_b);
 
 /* ---- Phong-lighting rows: batch evaluation on the device ------ */
 /* replaces, for each of n residual-block instances, the evaluation Ceres performs on

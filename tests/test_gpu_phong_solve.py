@@ -17,10 +17,11 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def _pair(prob, ph):
-    ba = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict())
+def _pair(prob, ph, shared_free=0):
+    d = ph.as_oracle_dict("perturbed" if shared_free else "truth")
+    ba = StereoBA.from_synth(prob, lighting=d, shared_free=shared_free)
     op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
-                           prob.stiffness(), lighting=ph.as_oracle_dict())
+                           prob.stiffness(), lighting=d, shared_free=shared_free)
     return ba, op
 
 
@@ -85,6 +86,63 @@ def test_phong_ragged_tracks_and_long_window():
     dp2, dl2, mcc2 = op.lm_step(1e3)
     assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7
     assert mcc == pytest.approx(mcc2, rel=1e-8)
+
+
+# ---- free shared blocks: light, Phong parameters, textures (the border of the reduced system) ----
+@pytest.mark.parametrize("light_type", [0, 1])
+@pytest.mark.parametrize("shared_free,nb", [(7, 19), (1, 3), (6, 16), (4, 4)])
+def test_border_system_and_step_match_oracle(light_type, shared_free, nb):
+    prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7, light_type=light_type)
+    for radius in (1e4, 5.0):
+        ba, op = _pair(prob, ph, shared_free)
+        S, rhs, dp, dl, mcc = ba.lm_step(radius)
+        S_pb, S_bb, rhs_b, db = ba.border_system()
+        assert S_pb.shape[1] == nb == op.border_size()
+        A, b, _ = op.reduced_system(radius)
+        n = A.shape[0] - nb
+        assert _rel(S, A[:n, :n]) < 1e-9 and _rel(rhs, b[:n]) < 1e-9
+        assert _rel(S_pb, A[:n, n:]) < 1e-9
+        assert _rel(S_bb, A[n:, n:]) < 1e-9 and _rel(rhs_b, b[n:]) < 1e-9
+        dp2, dl2, db2, mcc2 = op.lm_step(radius, want_border=True)
+        assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7 and _rel(db, db2) < 1e-7
+        assert mcc == pytest.approx(mcc2, rel=1e-8)
+        # the multi-right-hand-side block cyclic reduction solves the same arrowhead system
+        x = np.linalg.solve(A, b)
+        assert _rel(dp[1:].ravel(), x[:n]) < 1e-8 and _rel(db, x[n:]) < 1e-8
+
+
+@pytest.mark.parametrize("light_type", [0, 1])
+def test_free_shared_blocks_solve_matches_oracle(light_type):
+    prob, ph = synth.make_phong_problem(50, 2000, light_type=light_type)
+    ba, op = _pair(prob, ph, 7)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4))
+    assert s.termination_type == s2.termination_type == 0
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    ok = np.asarray(log2["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][ok], log2["cost"][ok], rtol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+    assert np.abs(ba.poses - op.poses).max() < 1e-6
+    assert np.abs(ba.normals - op.normals).max() < 1e-6
+    np.testing.assert_allclose(ba.phong, op.phong, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(ba.texture, op.texture, rtol=1e-6)
+    np.testing.assert_allclose(ba.light, op.light, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(ba.texture, ph.texture, atol=5e-3)         # and they are the true values
+    d0 = ph.as_oracle_dict("perturbed")
+    assert not np.array_equal(ba.light, d0["light"])
+
+
+def test_constant_shared_blocks_are_untouched_on_the_device():
+    prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7)
+    ba, op = _pair(prob, ph, 1)            # only the light is free
+    d0 = ph.as_oracle_dict("perturbed")
+    s, _ = ba.solve(capi.default_options(max_num_iterations=200, use_nonmonotonic_steps=1))
+    s2, _ = op.solve(orc.driver_options(num_threads=2, max_num_iterations=200))
+    np.testing.assert_array_equal(ba.phong, d0["phong"])
+    np.testing.assert_array_equal(ba.texture, d0["texture"])
+    np.testing.assert_allclose(ba.light, op.light, rtol=1e-6, atol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
 
 
 def test_phong_unsupported_combinations_fail_loudly():
