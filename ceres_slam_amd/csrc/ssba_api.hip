@@ -166,7 +166,7 @@ void ssba_default_options(ssba_options *o) {
     o->gradient_tolerance = 1e-10;
     o->parameter_tolerance = 1e-8;
     o->trust_region_strategy_type = 0;
-    o->reserved = 0;
+    o->dogleg_type = 0;
 }
 
 int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
@@ -703,7 +703,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dzero(p, &d.Spb, (size_t)d.nf_pad * 6 * NBP));
         TRY(dzero(p, &d.Zb, (size_t)d.nf_pad * 6 * NBP));
     }
-    TRY(dzero(p, &d.vp, (size_t)P * 6)); TRY(dzero(p, &d.vl, (size_t)Lpad * 3)); TRY(dzero(p, &d.dl_gn, (size_t)Lpad * 3));
+    TRY(dzero(p, &d.vp, (size_t)P * 6)); TRY(dzero(p, &d.vl, (size_t)Lpad * (ph ? 6 : 3))); TRY(dzero(p, &d.dl_gn, (size_t)Lpad * (ph ? 6 : 3)));
     // BCR level plan
     {
         int n = d.Nsb, lev = 0;
@@ -729,7 +729,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * 2));   // + one entry for the border of shared blocks
-    TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks) * 4));
+    TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks + 1) * NDL));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));
     TRY(dzero(p, &d.st, (size_t)1));
@@ -832,6 +832,7 @@ static Options to_device_options(const ssba_options *o, int ignore_convergence) 
     d.max_invalid = o->max_num_consecutive_invalid_steps;
     d.ignore_convergence = ignore_convergence;
     d.strategy = o->trust_region_strategy_type == 1 ? 1 : 0;
+    d.dogleg_type = o->dogleg_type == 1 ? 1 : 0;
     d.initial_radius = o->initial_trust_region_radius;
     d.max_radius = o->max_trust_region_radius;
     d.min_radius = o->min_trust_region_radius;
@@ -937,8 +938,9 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         set_error("DOGLEG is not available with landmark sharding yet (its norms need one more exchange point)");
         return SSBA_ERR_UNSUPPORTED;
     }
-    if (p->d.phong && (o->trust_region_strategy_type == 1 || p->huber_a > 0.0 || p->xfn)) {
-        set_error("lighting terms: DOGLEG, Huber loss and landmark sharding are not available yet");
+    if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->d.phong && (p->huber_a > 0.0 || p->xfn)) {
+        set_error("lighting terms: Huber loss and landmark sharding are not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     if (p->gexec && p->opt.trust_region_strategy_type != o->trust_region_strategy_type) drop_graph(p);   // other kernel sequence
@@ -1142,8 +1144,8 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     ssba_options opt;
     if (o) opt = *o; else ssba_default_options(&opt);
     if (radius > 0.0) opt.initial_trust_region_radius = radius;
-    if (p->d.phong && (opt.trust_region_strategy_type == 1 || p->huber_a > 0.0 || p->xfn)) {
-        set_error("lighting terms: DOGLEG, Huber loss and landmark sharding are not available yet");
+    if (p->d.phong && (p->huber_a > 0.0 || p->xfn)) {
+        set_error("lighting terms: Huber loss and landmark sharding are not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     p->opt = opt;

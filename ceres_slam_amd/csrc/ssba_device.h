@@ -245,6 +245,78 @@ static __device__ __forceinline__ bool inv3_spd_fast(const double h[6], const do
 }
 
 
+// ------------------------------------------------------------------ dogleg scalars ---
+// Real parts of all roots of a polynomial of degree <= 4 (coefficients highest degree first), as
+// Ceres's FindPolynomialRoots(p, &real, NULL) hands them to DoglegStrategy [polynomial.cc]: leading
+// zeros removed, closed forms for degree 1 and 2, otherwise Aberth-Ehrlich iteration (Ceres takes the
+// eigenvalues of the companion matrix: the same roots).  Returns the number of roots, -1 on failure.
+static __device__ int poly_roots_real(const double *coef_in, int ncoef, double *re) {
+    int lead = 0;
+    while (lead < ncoef - 1 && coef_in[lead] == 0.0) ++lead;
+    const double *c = coef_in + lead;
+    const int deg = ncoef - lead - 1;
+    if (deg < 0) return -1;
+    if (deg == 0) return 0;
+    if (deg == 1) { re[0] = -c[1] / c[0]; return 1; }
+    if (deg == 2) {
+        const double a = c[0], b = c[1], cc = c[2];
+        const double D = b * b - 4 * a * cc, sq = sqrt(fabs(D));
+        if (D >= 0) {
+            if (b >= 0) { re[0] = (-b - sq) / (2.0 * a); re[1] = (2.0 * cc) / (-b - sq); }
+            else { re[0] = (2.0 * cc) / (-b + sq); re[1] = (-b + sq) / (2.0 * a); }
+        } else {
+            re[0] = re[1] = -b / (2.0 * a);
+        }
+        return 2;
+    }
+    if (deg > 4) return -1;
+    double m[5], bound = 0.0;
+    for (int i = 0; i <= deg; ++i) {
+        m[i] = c[i] / c[0];
+        if (!isfinite(m[i])) return -1;
+        if (i && fabs(m[i]) > bound) bound = fabs(m[i]);
+    }
+    double zr[4], zi[4];
+    for (int i = 0; i < deg; ++i) {
+        const double ang = 2.0 * 3.14159265358979323846 * i / deg + 0.4;
+        zr[i] = (1.0 + bound) * cos(ang); zi[i] = (1.0 + bound) * sin(ang);
+    }
+    for (int it = 0; it < 500; ++it) {
+        double worst = 0.0;
+        for (int i = 0; i < deg; ++i) {
+            double pr = m[0], pi = 0.0, dr = 0.0, di = 0.0;     // Horner: value and derivative
+            for (int k = 1; k <= deg; ++k) {
+                const double ndr = dr * zr[i] - di * zi[i] + pr, ndi = dr * zi[i] + di * zr[i] + pi;
+                dr = ndr; di = ndi;
+                const double npr = pr * zr[i] - pi * zi[i] + m[k], npi = pr * zi[i] + pi * zr[i];
+                pr = npr; pi = npi;
+            }
+            if (pr == 0.0 && pi == 0.0) continue;
+            double rr, ri;                                        // ratio = p / p'
+            const double dn = dr * dr + di * di;
+            if (dn == 0.0) { rr = 1e-3 * (1.0 + sqrt(zr[i] * zr[i] + zi[i] * zi[i])); ri = 0.0; }
+            else { rr = (pr * dr + pi * di) / dn; ri = (pi * dr - pr * di) / dn; }
+            double sr = 0.0, si = 0.0;                            // sum 1 / (z_i - z_k)
+            for (int k = 0; k < deg; ++k)
+                if (k != i) {
+                    const double er = zr[i] - zr[k], ei = zi[i] - zi[k], en = er * er + ei * ei;
+                    sr += er / en; si -= ei / en;
+                }
+            const double qr = 1.0 - (rr * sr - ri * si), qi = -(rr * si + ri * sr), qn = qr * qr + qi * qi;
+            const double stepr = (rr * qr + ri * qi) / qn, stepi = (ri * qr - rr * qi) / qn;
+            zr[i] -= stepr; zi[i] -= stepi;
+            const double rel = sqrt(stepr * stepr + stepi * stepi) / (1.0 + sqrt(zr[i] * zr[i] + zi[i] * zi[i]));
+            if (rel > worst) worst = rel;
+        }
+        if (worst < 1e-16) break;
+    }
+    for (int i = 0; i < deg; ++i) {
+        if (!isfinite(zr[i])) return -1;
+        re[i] = zr[i];
+    }
+    return deg;
+}
+
 // UnitVectorPerturbation::operator() (perturbations.hpp:98-102)
 static __device__ __forceinline__ void unit_plus(const double x[3], const double dl[3], double out[3]) {
     const double s = (dl[0] * x[0] + dl[1] * x[1] + dl[2] * x[2]) / (x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);

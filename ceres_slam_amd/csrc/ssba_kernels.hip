@@ -691,8 +691,8 @@ __global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
     }
     const double a = block_sum(gsq, sm), b = block_sum(nsq, sm), c = block_sum(dot, sm);
     if (threadIdx.x == 0) {
-        double *o = d.part_dl + (size_t)(d.n_lm_blocks + blockIdx.x) * 4;
-        o[0] = a; o[1] = b; o[2] = c; o[3] = 0.0;
+        double *o = d.part_dl + (size_t)(d.n_lm_blocks + blockIdx.x) * NDL;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0;
     }
 }
 
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
     __shared__ double sm[4];
     const int l = blockIdx.x * 256 + threadIdx.x;
     const uint32_t mask = d.lm_mask[l];
-    double gsq = 0.0, nsq = 0.0, dot = 0.0, jv2 = 0.0;
+    double gsq = 0.0, nsq = 0.0, dot = 0.0, jv2 = 0.0, jg2 = 0.0, jvg = 0.0;
     double dl[3] = {0, 0, 0}, vl[3] = {0, 0, 0};
     if (mask && !st.step_failed) {
         const uint32_t win = d.lm_win[l];
@@ -754,27 +754,32 @@ __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
             nsq += D2 * dl[c] * dl[c] / s2;
             dot += gl[c] * dl[c];
         }
-        for (int s = 0; s < TW; ++s) {   // |J v|^2
+        for (int s = 0; s < TW; ++s) {   // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn)
             if (!((mask >> s) & 1u)) continue;
             const uint32_t k = d.win_pose[win * TW + s];
             const int f = d.pose_free[k];
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
             obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
-            double Jl[9], jv[3];
+            double Jl[9], jv[3], jg[3];
             jac_point(o, T, Jl);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) jv[i] = Jl[3 * i] * vl[0] + Jl[3 * i + 1] * vl[1] + Jl[3 * i + 2] * vl[2];
+            for (int i = 0; i < 3; ++i) {
+                jv[i] = Jl[3 * i] * vl[0] + Jl[3 * i + 1] * vl[1] + Jl[3 * i + 2] * vl[2];
+                jg[i] = Jl[3 * i] * dl[0] + Jl[3 * i + 1] * dl[1] + Jl[3 * i + 2] * dl[2];
+            }
             if (f >= 0) {
                 double Jp[18];
                 jac_pose(o, Jp);
-                const double *vp = d.vp + (size_t)k * 6;
+                const double *vp = d.vp + (size_t)k * 6, *gp = d.x0 + (size_t)f * 6;
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) jv[i] += Jp[6 * i + c] * vp[c];
+                    for (int c = 0; c < 6; ++c) { jv[i] += Jp[6 * i + c] * vp[c]; jg[i] += Jp[6 * i + c] * gp[c]; }
             }
             jv2 += jv[0] * jv[0] + jv[1] * jv[1] + jv[2] * jv[2];
+            jg2 += jg[0] * jg[0] + jg[1] * jg[1] + jg[2] * jg[2];
+            jvg += jv[0] * jg[0] + jv[1] * jg[1] + jv[2] * jg[2];
         }
     }
 #pragma unroll
@@ -783,31 +788,15 @@ __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
         d.vl[(size_t)c * d.Lpad + l] = vl[c];
     }
     const double a = block_sum(gsq, sm), b = block_sum(nsq, sm), c = block_sum(dot, sm), e = block_sum(jv2, sm);
+    const double e2 = block_sum(jg2, sm), e3 = block_sum(jvg, sm);
     if (threadIdx.x == 0) {
-        double *o = d.part_dl + (size_t)blockIdx.x * 4;
-        o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+        double *o = d.part_dl + (size_t)blockIdx.x * NDL;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = e; o[4] = e2; o[5] = e3;
     }
 }
 
-// ComputeTraditionalDoglegStep: beta, gamma, |step| from the norms and the current radius (1 block)
-__global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
-    State &st = *d.st;
-    if (st.terminated) return;
-    __shared__ double sm[4];
-    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
-    if (!st.dl_reuse) {
-        for (int i = threadIdx.x; i < d.n_lm_blocks + d.n_pose_blocks; i += 256) {
-            a += d.part_dl[(size_t)i * 4]; b += d.part_dl[(size_t)i * 4 + 1];
-            c += d.part_dl[(size_t)i * 4 + 2]; e += d.part_dl[(size_t)i * 4 + 3];
-        }
-    }
-    a = block_sum(a, sm); b = block_sum(b, sm); c = block_sum(c, sm); e = block_sum(e, sm);
-    if (threadIdx.x != 0) return;
-    if (!st.dl_reuse) {
-        st.grad_norm = sqrt(a); st.gn_norm = sqrt(b); st.g_dot_gn = c;
-        st.alpha = a / e;             // ComputeCauchyPoint
-        st.dl_reuse = 1;              // reuse_ = true until the next accepted / invalid step
-    }
+// DoglegStrategy::ComputeTraditionalDoglegStep
+__device__ void traditional_dogleg(State &st) {
     const double r = st.radius;
     if (st.gn_norm <= r) {                              // Gauss-Newton step inside the region
         st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
@@ -823,6 +812,113 @@ __global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
         st.beta = bt; st.gamma = -st.alpha * (1.0 - bt);
         st.dl_step_norm = sqrt(st.gamma * st.gamma * st.grad_norm * st.grad_norm + 2.0 * st.gamma * st.beta * st.g_dot_gn +
                                st.beta * st.beta * st.gn_norm * st.gn_norm);
+    }
+}
+
+// DoglegStrategy::ComputeSubspaceModel from the Gram matrices of (gradient_, gauss_newton_step_) in the
+// D-scaled space (pn2, qn2, pq) and of their Jacobian images (jj = |Jv|^2, |J gn|^2, Jv.Jgn).
+// ColPivHouseholderQR pivots the longer column first; rank threshold epsilon * min(rows, cols).
+__device__ bool subspace_model(State &st, double pn2, double qn2, double pq, const double jj[3]) {
+    const bool a_is_p = pn2 >= qn2;
+    const double an2 = a_is_p ? pn2 : qn2, bn2 = a_is_p ? qn2 : pn2;
+    if (!(an2 > 0.0)) return false;
+    const double an = sqrt(an2), proj = pq / an;
+    double wn2 = bn2 - proj * proj;
+    if (wn2 < 0.0) wn2 = 0.0;
+    const double wn = sqrt(wn2);
+    const int ia = a_is_p ? 0 : 1, ib = 1 - ia;
+    st.sub_e[0][ia] = 1.0 / an; st.sub_e[0][ib] = 0.0;
+    st.sub_one_dim = wn <= 2.0 * DBL_EPSILON * an;
+    if (st.sub_one_dim) return true;
+    st.sub_e[1][ia] = -proj / (an * wn); st.sub_e[1][ib] = 1.0 / wn;
+    for (int i = 0; i < 2; ++i) st.sub_g[i] = st.sub_e[i][0] * pn2 + st.sub_e[i][1] * pq;
+    int n = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = i; j < 2; ++j)
+            st.sub_B[n++] = st.sub_e[i][0] * st.sub_e[j][0] * jj[0] +
+                            (st.sub_e[i][0] * st.sub_e[j][1] + st.sub_e[i][1] * st.sub_e[j][0]) * jj[2] +
+                            st.sub_e[i][1] * st.sub_e[j][1] * jj[1];
+    return true;
+}
+
+// DoglegStrategy::FindMinimumOnTrustRegionBoundary
+__device__ bool subspace_boundary_minimum(const State &st, double mo[2]) {
+    const double B00 = st.sub_B[0], B01 = st.sub_B[1], B11 = st.sub_B[2], g0 = st.sub_g[0], g1 = st.sub_g[1];
+    const double detB = B00 * B11 - B01 * B01, trB = B00 + B11, r2 = st.radius * st.radius;
+    const double ag0 = B11 * g0 - B01 * g1, ag1 = -B01 * g0 + B00 * g1;     // B_adj g
+    double poly[5];
+    poly[0] = r2;
+    poly[1] = 2.0 * r2 * trB;
+    poly[2] = r2 * (trB * trB + 2.0 * detB) - (g0 * g0 + g1 * g1);
+    poly[3] = -2.0 * ((g0 * ag0 + g1 * ag1) - r2 * detB * trB);
+    poly[4] = r2 * detB * detB - (ag0 * ag0 + ag1 * ag1);
+    double roots[4];
+    const int nroots = poly_roots_real(poly, 5, roots);
+    mo[0] = mo[1] = 0.0;
+    if (nroots < 0) return false;
+    double best = DBL_MAX;
+    bool found = false;
+    for (int i = 0; i < nroots; ++i) {
+        // x = -(B + y I)^-1 g through a partial-pivot LU of the 2x2
+        double a = B00 + roots[i], b = B01, c = B01, dd = B11 + roots[i], r0 = g0, r1 = g1;
+        if (fabs(c) > fabs(a)) { double t; t = a; a = c; c = t; t = b; b = dd; dd = t; t = r0; r0 = r1; r1 = t; }
+        const double l = c / a, u = dd - l * b;
+        const double x1 = (r1 - l * r0) / u, x0 = (r0 - b * x1) / a;
+        const double x[2] = {-x0, -x1};
+        const double nx = sqrt(x[0] * x[0] + x[1] * x[1]);
+        if (nx > 0) {
+            const double sx[2] = {st.radius / nx * x[0], st.radius / nx * x[1]};
+            const double f = 0.5 * (sx[0] * (B00 * sx[0] + B01 * sx[1]) + sx[1] * (B01 * sx[0] + B11 * sx[1])) + g0 * sx[0] + g1 * sx[1];
+            found = true;
+            if (f < best) { best = f; mo[0] = x[0]; mo[1] = x[1]; }
+        }
+    }
+    return found;
+}
+
+// The scalar part of DoglegStrategy::ComputeStep: norms, Cauchy point, subspace model (when the point
+// is new) and beta, gamma, |step| of delta = beta * delta_gn + gamma * v for the current radius (1 block)
+__global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double acc[NDL];
+#pragma unroll
+    for (int q = 0; q < NDL; ++q) acc[q] = 0.0;
+    if (!st.dl_reuse) {
+        const int n = d.n_lm_blocks + d.n_pose_blocks + (d.nb ? 1 : 0);   // last entry: border of shared blocks
+        for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+            for (int q = 0; q < NDL; ++q) acc[q] += d.part_dl[(size_t)i * NDL + q];
+    }
+#pragma unroll
+    for (int q = 0; q < NDL; ++q) acc[q] = block_sum(acc[q], sm);
+    if (threadIdx.x != 0) return;
+    if (!st.dl_reuse) {
+        st.grad_norm = sqrt(acc[0]); st.gn_norm = sqrt(acc[1]); st.g_dot_gn = acc[2];
+        st.alpha = acc[0] / acc[3];   // ComputeCauchyPoint
+        st.dl_reuse = 1;              // reuse_ = true until the next accepted / invalid step
+        if (st.opt.dogleg_type == 1) {
+            const double jj[3] = {acc[3], acc[4], acc[5]};
+            if (!subspace_model(st, acc[0], acc[1], acc[2], jj)) st.step_failed = 1;   // LINEAR_SOLVER_FAILURE
+        }
+    }
+    if (st.opt.dogleg_type != 1) {
+        traditional_dogleg(st);
+        return;
+    }
+    // ComputeSubspaceDoglegStep
+    double m2[2];
+    if (st.gn_norm <= st.radius) {
+        st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
+    } else if (st.sub_one_dim) {
+        st.beta = 0.0; st.gamma = -st.radius / st.grad_norm; st.dl_step_norm = st.radius;
+    } else if (!subspace_boundary_minimum(st, m2)) {
+        traditional_dogleg(st);           // "Taking traditional dogleg step instead."
+    } else {
+        st.gamma = m2[0] * st.sub_e[0][0] + m2[1] * st.sub_e[1][0];    // coefficient of gradient_ -> v
+        st.beta = m2[0] * st.sub_e[0][1] + m2[1] * st.sub_e[1][1];     // coefficient of gauss_newton_step_
+        st.dl_step_norm = st.radius;
     }
 }
 
@@ -1068,6 +1164,8 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.relative_decrease = 0.0; st.cost_change = 0.0; st.initial_cost = 0.0;
     st.dl_reuse = 0; st.mu = 1e-8; st.alpha = 0.0; st.dl_step_norm = 0.0; st.grad_norm = 0.0; st.gn_norm = 0.0;
     st.g_dot_gn = 0.0; st.beta = 1.0; st.gamma = 0.0;
+    st.sub_one_dim = 0; st.sub_g[0] = st.sub_g[1] = 0.0; st.sub_B[0] = st.sub_B[1] = st.sub_B[2] = 0.0;
+    st.sub_e[0][0] = st.sub_e[0][1] = st.sub_e[1][0] = st.sub_e[1][1] = 0.0;
 }
 
 // ----------------------------------------------------------------- launchers ---
@@ -1115,10 +1213,12 @@ void launch_update_eval(Launcher &L, const Dev &d) {
 
 void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks), dim3(256), 0, d);
-    LAUNCH(KC_DOGLEG, k_dogleg_gn, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    if (d.phong) launch_ph_dogleg_gn(L, d);
+    else LAUNCH(KC_DOGLEG, k_dogleg_gn, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
-    LAUNCH(KC_DOGLEG, k_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    if (d.phong) launch_ph_dogleg_eval(L, d);
+    else LAUNCH(KC_DOGLEG, k_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
 }
 

@@ -105,6 +105,8 @@ int configure_phong();
 void launch_ph_linearize(Launcher &L, const Dev &d);
 void launch_ph_schur(Launcher &L, const Dev &d);
 void launch_ph_backsub_eval(Launcher &L, const Dev &d);
+void launch_ph_dogleg_gn(Launcher &L, const Dev &d);
+void launch_ph_dogleg_eval(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();
 void launch_border_solve(Launcher &L, const Dev &d);

@@ -814,9 +814,11 @@ __global__ void k_ph_border_update(Dev d) {
     double dn = 0.0, bad = 0.0;
     for (int i = 0; i < d.nsh; ++i) d.cand_sh[i] = d.sh[i];
     if (!st.step_failed && d.nb) {
-        const double *db = d.bsys + BS_DB;
-        for (int c = 0; c < d.nb; ++c)
+        double db[NBP];   // LM: beta = 1, gamma = 0; dogleg: beta * delta_gn + gamma * v
+        for (int c = 0; c < d.nb; ++c) {
+            db[c] = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
             if (!isfinite(db[c])) bad = 1.0;
+        }
         if (d.b_light >= 0) {
             if (d.light_type == 1) unit_plus(d.sh, db + d.b_light, d.cand_sh);
             else for (int c = 0; c < 3; ++c) d.cand_sh[c] = d.sh[c] + db[d.b_light + c];
@@ -827,6 +829,207 @@ __global__ void k_ph_border_update(Dev d) {
     }
     d.part_pose[d.n_pose_blocks * 2] = dn;
     d.part_pose[d.n_pose_blocks * 2 + 1] = bad;
+}
+
+// ------------------------------------------------------------------ dogleg (config 3) ---
+// border part of the dogleg vectors: v_b = s^2 g / D^2 and its share of |gradient_|^2, |gn|^2, gradient_.gn
+__global__ void k_ph_dogleg_border(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse || threadIdx.x != 0 || blockIdx.x != 0) return;
+    double gsq = 0.0, nsq = 0.0, dot = 0.0;
+    for (int c = 0; c < d.nb; ++c) {
+        const double s = d.bsys[BS_S + c], s2 = s * s, g = d.bsys[BS_G + c], gn = d.bsys[BS_DB + c];
+        const double D2 = fmin(fmax(d.bsys[BS_H + c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
+        d.bsys[BS_VB + c] = s2 * g / D2;
+        gsq += s2 * g * g / D2;
+        nsq += D2 * gn * gn / s2;
+        dot += g * gn;
+    }
+    double *o = d.part_dl + (size_t)(d.n_lm_blocks + d.n_pose_blocks) * NDL;
+    o[0] = gsq; o[1] = nsq; o[2] = dot; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0;
+}
+
+// per landmark: Gauss-Newton back-substitution, v_l, the landmark parts of the norms and the products
+// |J v|^2, |J delta_gn|^2, (J v).(J delta_gn) over the landmark's observations
+__global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double sums[NDL];
+#pragma unroll
+    for (int q = 0; q < NDL; ++q) sums[q] = 0.0;
+    double dl[6] = {0, 0, 0, 0, 0, 0}, vl[6] = {0, 0, 0, 0, 0, 0};
+    if (mask && !st.step_failed) {
+        const uint32_t win = d.lm_win[l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        LmIn x;
+        load_lm(d, l, x);
+        double gl[6], tt[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { gl[c] = d.gl[(size_t)c * d.Lpad + l]; tt[c] = gl[c]; }
+        double gbq[NBQ], vbq[NBQ];   // border Gauss-Newton step and v seen by this landmark's material
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            const int c = d.nb ? bcol(d, x.mat, q) : -1;
+            gbq[q] = c >= 0 ? d.bsys[BS_DB + c] : 0.0;
+            vbq[q] = c >= 0 ? d.bsys[BS_VB + c] : 0.0;
+        }
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            if (f < 0) continue;
+            const size_t oi = obase + (size_t)s * LMG;
+            const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
+            ObsPh o;
+            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+            const double *dp = d.x0 + (size_t)f * 6;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                double jd = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) jd += o.Jp[6 * m + c] * dp[c];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) tt[c] += o.Jl[6 * m + c] * jd;
+            }
+        }
+        if (d.nb) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) tt[a] += d.lmV[(size_t)(a * NBQ + q) * d.Lpad + l] * gbq[q];
+        }
+        double Ci[21];
+#pragma unroll
+        for (int c = 0; c < 21; ++c) Ci[c] = d.cinv[(size_t)c * d.Lpad + l];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v += Ci[q <= a ? tri6(q, a) : tri6(a, q)] * tt[q];
+            dl[a] = -v;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double s = d.sl[(size_t)c * d.Lpad + l], s2 = s * s;
+            const double D2 = fmin(fmax(d.hll[(size_t)tri6(c, c) * d.Lpad + l] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
+            vl[c] = s2 * gl[c] / D2;
+            sums[0] += s2 * gl[c] * gl[c] / D2;
+            sums[1] += D2 * dl[c] * dl[c] / s2;
+            sums[2] += gl[c] * dl[c];
+        }
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            const size_t oi = obase + (size_t)s * LMG;
+            const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
+            ObsPh o;
+            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                double jv = 0.0, jg = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) { jv += o.Jl[6 * m + c] * vl[c]; jg += o.Jl[6 * m + c] * dl[c]; }
+                if (f >= 0) {
+                    const double *vp = d.vp + (size_t)k * 6, *gp = d.x0 + (size_t)f * 6;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) { jv += o.Jp[6 * m + c] * vp[c]; jg += o.Jp[6 * m + c] * gp[c]; }
+                }
+                if (m == 3) {
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) { jv += o.jb[q] * vbq[q]; jg += o.jb[q] * gbq[q]; }
+                }
+                sums[3] += jv * jv; sums[4] += jg * jg; sums[5] += jv * jg;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        d.dl_gn[(size_t)c * d.Lpad + l] = dl[c];
+        d.vl[(size_t)c * d.Lpad + l] = vl[c];
+    }
+#pragma unroll
+    for (int q = 0; q < NDL; ++q) {
+        const double v = block_sum(sums[q], sm);
+        if (threadIdx.x == 0) d.part_dl[(size_t)blockIdx.x * NDL + q] = v;
+    }
+}
+
+// per landmark: delta_l = beta * gn + gamma * v, candidate point / normal, model cost change, candidate cost
+__global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
+    LmIn x;
+    load_lm(d, l, x);
+    double np_[3] = {x.p[0], x.p[1], x.p[2]}, nn[3] = {x.n[0], x.n[1], x.n[2]};
+    double dl[6] = {0, 0, 0, 0, 0, 0};
+    if (mask && !st.step_failed) {
+        const uint32_t win = d.lm_win[l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            dl[c] = st.beta * d.dl_gn[(size_t)c * d.Lpad + l] + st.gamma * d.vl[(size_t)c * d.Lpad + l];
+            if (!isfinite(dl[c])) nonfinite = 1.0;
+        }
+        double dbq[NBQ];
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            const int c = d.nb ? bcol(d, x.mat, q) : -1;
+            dbq[q] = c >= 0 ? st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c] : 0.0;
+        }
+        np_[0] = x.p[0] + dl[0]; np_[1] = x.p[1] + dl[1]; np_[2] = x.p[2] + dl[2];
+        unit_plus(x.n, dl + 3, nn);
+        dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
+             (nn[1] - x.n[1]) * (nn[1] - x.n[1]) + (nn[2] - x.n[2]) * (nn[2] - x.n[2]);
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            const size_t oi = obase + (size_t)s * LMG;
+            const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
+            const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
+            ObsPh o;
+            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                double jd = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) jd += o.Jl[6 * m + c] * dl[c];
+                if (f >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c)
+                        jd += o.Jp[6 * m + c] * (st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c]);
+                }
+                if (m == 3) {
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) jd += o.jb[q] * dbq[q];
+                }
+                mcc -= jd * (o.r[m] + 0.5 * jd);
+            }
+            ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, u, v, dd, inten, nobs);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d.cand_pts[(size_t)c * d.Lpad + l] = np_[c];
+        d.cand_nrm[(size_t)c * d.Lpad + l] = nn[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) d.dlm[(size_t)c * d.Lpad + l] = dl[c];
+    const double a = block_sum(ccost, sm), b = block_sum(mcc, sm), c = block_sum(dn, sm), e = block_sum(nonfinite, sm);
+    if (threadIdx.x == 0) {
+        d.part_eval[blockIdx.x * 4 + 0] = a;
+        d.part_eval[blockIdx.x * 4 + 1] = b;
+        d.part_eval[blockIdx.x * 4 + 2] = c;
+        d.part_eval[blockIdx.x * 4 + 3] = e;
+    }
 }
 
 void launch_ph_linearize(Launcher &L, const Dev &d) {
@@ -846,6 +1049,14 @@ void launch_ph_schur(Launcher &L, const Dev &d) {
 void launch_ph_backsub_eval(Launcher &L, const Dev &d) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
     LAUNCH(KC_BACKSUB_EVAL, k_ph_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+}
+void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
+    if (d.nb) LAUNCH(KC_SMALL, k_ph_dogleg_border, dim3(1), dim3(64), 0, d);
+    LAUNCH(KC_DOGLEG, k_ph_dogleg_gn, dim3(d.n_lm_blocks), dim3(256), 0, d);
+}
+void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {
+    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
+    LAUNCH(KC_DOGLEG, k_ph_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 int configure_phong() {
     return hipFuncSetAttribute((const void *)k_ph_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,

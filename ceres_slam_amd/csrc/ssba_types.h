@@ -32,10 +32,12 @@ constexpr int MAX_LEVELS = 24;
 constexpr int NSCAL = 16;
 constexpr int NBP = 32;                 // padded width of the border of free shared blocks (nb <= NBP)
 constexpr int NBQ = 7;                  // border entries one intensity row touches: [phong 3 | kd | light 3]
+constexpr int NDL = 6;                  // dogleg partials: |gradient_|^2, |gn|^2, gradient_.gn, |J v|^2, |J gn|^2, Jv.Jgn
 constexpr int NBV = 49;                 // per-landmark border sums: S_bb part 28 | rhs_b 7 | diag H_bb 7 | g_b 7
 
 struct Options {   // device copy of ssba_options
     int max_num_iterations, max_nonmono, jacobi_scaling, max_invalid, ignore_convergence, strategy;
+    int dogleg_type, pad_;    // 0 TRADITIONAL_DOGLEG, 1 SUBSPACE_DOGLEG
     double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diag,
         max_lm_diag, function_tolerance, gradient_tolerance, parameter_tolerance;
 };
@@ -63,6 +65,9 @@ struct State {
     double initial_cost;
     // DoglegStrategy [Ceres dogleg_strategy.cc]
     double mu, alpha, dl_step_norm, grad_norm, gn_norm, g_dot_gn, beta, gamma;
+    // SUBSPACE_DOGLEG model: u_i = sub_e[i][0] * gradient_ + sub_e[i][1] * gauss_newton_step_
+    int sub_one_dim, sub_pad_;
+    double sub_e[2][2], sub_g[2], sub_B[3];
 };
 
 struct IterLog {   // device arrays, capacity entries
@@ -114,7 +119,7 @@ struct Dev {
     uint64_t off_D, off_L, off_rhs, off_gp, off_hdiag, off_scal, xv_count;
     double *x0;                      // nf_pad*6 pose step (LM step / dogleg Gauss-Newton step)
     double *vp, *vl, *dl_gn;         // dogleg: s^2 g / D^2 of poses (P*6) and landmarks (3*Lpad), GN landmark step
-    double *part_dl;                 // dogleg partial sums: n_lm_blocks*4 + n_pose_blocks*4
+    double *part_dl;                 // dogleg partial sums: (n_lm_blocks + n_pose_blocks + 1 [border]) * NDL
     int n_levels;
     BcrLevel lev[MAX_LEVELS];
     // reductions
@@ -147,10 +152,10 @@ struct Dev {
     double *Zb;                                     // nf_pad*6 x NBP   S_pp^-1 S_pb
     double *part_g;                                 // gram partials: n_gram x (NBP*NBP + NBP)
     int n_gram;
-    // border system, NBP-strided: Sbb (NBP*NBP) | rhsb | gb | hb | sb | db
+    // border system, NBP-strided: Sbb (NBP*NBP) | rhsb | gb | hb | sb | db | vb
     double *bsys;
 };
 constexpr int BS_SBB = 0, BS_RHS = NBP * NBP, BS_G = BS_RHS + NBP, BS_H = BS_G + NBP, BS_S = BS_H + NBP,
-              BS_DB = BS_S + NBP, BS_COUNT = BS_DB + NBP;
+              BS_DB = BS_S + NBP, BS_VB = BS_DB + NBP, BS_COUNT = BS_VB + NBP;   // VB: dogleg v_b = s^2 g / D^2
 
 }  // namespace ssba

@@ -232,7 +232,8 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
     o.gradient_tolerance = options.gradient_tolerance;
     o.parameter_tolerance = options.parameter_tolerance;
     o.initial_trust_region_radius = options.initial_trust_region_radius;
-    o.trust_region_strategy_type = options.trust_region_strategy_type == DOGLEG ? 1 : 0;   // TRADITIONAL_DOGLEG only
+    o.trust_region_strategy_type = options.trust_region_strategy_type == DOGLEG ? 1 : 0;
+    o.dogleg_type = options.dogleg_type == SUBSPACE_DOGLEG ? 1 : 0;
     ssba_summary s;
     rc = ssba_solve(h, &o, &s);
     if (rc && rc != SSBA_ERR_NUMERICAL_FAILURE) return fail("ssba_solve");

@@ -78,11 +78,11 @@ typedef struct {
     double gradient_tolerance;                  /* 1e-10                               */
     double parameter_tolerance;                 /* 1e-8                                */
     int32_t trust_region_strategy_type;         /* 0 = LEVENBERG_MARQUARDT (Ceres default, what
-                                                   tests/dataset_vo.cpp runs); 1 = DOGLEG with
-                                                   TRADITIONAL_DOGLEG (tests/dataset_ba_phong.cpp:85
-                                                   selects DOGLEG; its SUBSPACE_DOGLEG variant is not
-                                                   implemented)                                   */
-    int32_t reserved;
+                                                   tests/dataset_vo.cpp runs); 1 = DOGLEG
+                                                   (tests/dataset_ba_phong.cpp:85)                */
+    int32_t dogleg_type;                        /* 0 = TRADITIONAL_DOGLEG (Ceres default); 1 =
+                                                   SUBSPACE_DOGLEG (tests/dataset_ba_phong.cpp:86,
+                                                   tests/dataset_vo_sun.cpp:143)                  */
 } ssba_options;
 
 /* ceres::TerminationType values the path can produce */
@@ -240,7 +240,7 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
  *                             ssba_finalize.
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
  * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  Not available together with lighting
- * terms yet (SSBA_ERR_UNSUPPORTED): Huber loss, DOGLEG, landmark sharding, parameter bounds
+ * terms yet (SSBA_ERR_UNSUPPORTED): Huber loss, landmark sharding, parameter bounds
  * (:142-180). */
 #define SSBA_MAX_MATERIALS 7
 enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };

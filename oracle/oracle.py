@@ -45,7 +45,7 @@ class Options(C.Structure):
                 ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double), ("trust_region_strategy_type", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("dogleg_type", C.c_int32)]
 
 
 class Summary(C.Structure):

@@ -7,6 +7,7 @@
  */
 #include "ssba_oracle.h"
 
+#include <complex.h>
 #include <float.h>
 #include <math.h>
 #include <stdio.h>
@@ -225,7 +226,7 @@ void orc_default_options(orc_options *o) {
     o->gradient_tolerance = 1e-10;
     o->parameter_tolerance = 1e-8;
     o->trust_region_strategy_type = 0;
-    o->reserved = 0;
+    o->dogleg_type = 0;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -1016,29 +1017,207 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
     return 0;
 }
 
-/* [Ceres 1.x dogleg_strategy.cc, TRADITIONAL_DOGLEG] state kept between iterations */
+/* |J d1|^2, |J d2|^2 and (J d1).(J d2) for two arbitrary steps (dp: P*6, dl: L*LD, db: nb or NULL) */
+static void jd_products(const orc_problem *p, const graph_t *g, const lin_t *w, const double *dp1, const double *dl1,
+                        const double *db1, const double *dp2, const double *dl2, const double *db2, double out[3]) {
+    const int nr = g->nr, ld = g->ld;
+    double s11 = 0.0, s22 = 0.0, s12 = 0.0;
+#pragma omp parallel for reduction(+ : s11, s22, s12) schedule(static)
+    for (int64_t i = 0; i < g->N; ++i) {
+        const double *a = w->Jp + (size_t)nr * 6 * i, *b = w->Jl + (size_t)nr * ld * i;
+        const size_t k = p->obs_pose[i], j = p->obs_point[i];
+        const int fr = g->free_idx[k] >= 0;
+        for (int m = 0; m < nr; ++m) {
+            double j1 = 0.0, j2 = 0.0;
+            for (int c = 0; c < ld; ++c) { j1 += b[ld * m + c] * dl1[ld * j + c]; j2 += b[ld * m + c] * dl2[ld * j + c]; }
+            if (fr)
+                for (int c = 0; c < 6; ++c) { j1 += a[6 * m + c] * dp1[6 * k + c]; j2 += a[6 * m + c] * dp2[6 * k + c]; }
+            if (m == 3 && g->nb) {
+                const uint32_t mat = p->material_of_point[j];
+                for (int q = 0; q < 7; ++q) {
+                    const int c = bcol(g, mat, q);
+                    if (c >= 0) { j1 += w->Jb[7 * i + q] * db1[c]; j2 += w->Jb[7 * i + q] * db2[c]; }
+                }
+            }
+            s11 += j1 * j1; s22 += j2 * j2; s12 += j1 * j2;
+        }
+    }
+    out[0] = s11; out[1] = s22; out[2] = s12;
+}
+
+/* Real parts of ALL roots of a polynomial (coefficients highest degree first), as Ceres's
+ * FindPolynomialRoots(polynomial, &real, NULL) hands them to its callers [polynomial.cc]: leading zeros
+ * removed, closed forms for degree 1 and 2 (the numerically stable quadratic formula), otherwise the
+ * eigenvalues of the companion matrix -- restated here with the Aberth-Ehrlich iteration, which
+ * converges to the same roots.  Returns the number of roots or -1. */
+static int poly_roots_real(const double *coef_in, int ncoef, double *re) {
+    int lead = 0;
+    while (lead < ncoef - 1 && coef_in[lead] == 0.0) ++lead;
+    const double *c = coef_in + lead;
+    const int deg = ncoef - lead - 1;
+    if (deg < 0) return -1;
+    if (deg == 0) return 0;
+    if (deg == 1) { re[0] = -c[1] / c[0]; return 1; }
+    if (deg == 2) {
+        const double a = c[0], b = c[1], cc = c[2];
+        const double D = b * b - 4 * a * cc, sq = sqrt(fabs(D));
+        if (D >= 0) {
+            if (b >= 0) { re[0] = (-b - sq) / (2.0 * a); re[1] = (2.0 * cc) / (-b - sq); }
+            else { re[0] = (2.0 * cc) / (-b + sq); re[1] = (-b + sq) / (2.0 * a); }
+        } else {
+            re[0] = re[1] = -b / (2.0 * a);
+        }
+        return 2;
+    }
+    if (deg > 8) return -1;
+    double m[9], bound = 0.0;
+    for (int i = 0; i <= deg; ++i) {
+        m[i] = c[i] / c[0];
+        if (!isfinite(m[i])) return -1;
+        if (i && fabs(m[i]) > bound) bound = fabs(m[i]);
+    }
+    double complex z[8];
+    for (int i = 0; i < deg; ++i) z[i] = (1.0 + bound) * cexp(I * (2.0 * 3.14159265358979323846 * i / deg + 0.4));
+    for (int it = 0; it < 500; ++it) {
+        double worst = 0.0;
+        for (int i = 0; i < deg; ++i) {
+            double complex pv = m[0], dv = 0.0;
+            for (int k = 1; k <= deg; ++k) { dv = dv * z[i] + pv; pv = pv * z[i] + m[k]; }
+            if (cabs(pv) == 0.0) continue;
+            double complex ratio = pv / dv, sum = 0.0;
+            if (cabs(dv) == 0.0) ratio = 1e-3 * (1.0 + cabs(z[i]));
+            for (int k = 0; k < deg; ++k)
+                if (k != i) sum += 1.0 / (z[i] - z[k]);
+            const double complex step = ratio / (1.0 - ratio * sum);
+            z[i] -= step;
+            const double rel = cabs(step) / (1.0 + cabs(z[i]));
+            if (rel > worst) worst = rel;
+        }
+        if (worst < 1e-16) break;
+    }
+    for (int i = 0; i < deg; ++i) {
+        if (!isfinite(creal(z[i]))) return -1;
+        re[i] = creal(z[i]);
+    }
+    return deg;
+}
+
+/* [Ceres 1.x dogleg_strategy.cc] state kept between iterations */
 typedef struct {
     double radius, mu, alpha, dogleg_step_norm, gradient_norm, gn_norm, g_dot_gn;
     int reuse;
     double *gn_p, *gn_l;   /* Gauss-Newton step, unscaled (P*6, L*LD)                    */
     double *v_p, *v_l;     /* s^2 g / D^2: the unscaled image of the scaled gradient / D */
+    double gn_b[64 + 1], v_b[64 + 1];   /* the same for the border of free shared blocks */
+    /* SUBSPACE_DOGLEG: orthonormal basis of span{gradient_, gauss_newton_step_} expressed in those two
+     * vectors (u_i = e[i][0] * gradient_ + e[i][1] * gauss_newton_step_), model g and B */
+    int one_dim;
+    double e[2][2], sub_g[2], sub_B[3];
 } dogleg_t;
+
+/* DoglegStrategy::ComputeTraditionalDoglegStep: coefficients of delta = beta * delta_gn + gamma * v */
+static void traditional_dogleg(dogleg_t *dg, double *beta_out, double *gamma_out) {
+    double beta, gamma;
+    const double r = dg->radius;
+    if (dg->gn_norm <= r) {                               /* case 1: GN step inside the region */
+        beta = 1.0; gamma = 0.0;
+        dg->dogleg_step_norm = dg->gn_norm;
+    } else if (dg->gradient_norm * dg->alpha >= r) {      /* case 2: Cauchy point outside */
+        beta = 0.0; gamma = -r / dg->gradient_norm;
+        dg->dogleg_step_norm = r;
+    } else {                                              /* case 3: on the dogleg */
+        const double b_dot_a = -dg->alpha * dg->g_dot_gn;
+        const double a_sq = pow(dg->alpha * dg->gradient_norm, 2.0);
+        const double bma_sq = a_sq - 2.0 * b_dot_a + pow(dg->gn_norm, 2.0);
+        const double cc = b_dot_a - a_sq;
+        const double dd = sqrt(cc * cc + bma_sq * (r * r - a_sq));
+        const double bt = (cc <= 0.0) ? (dd - cc) / bma_sq : (r * r - a_sq) / (dd + cc);
+        beta = bt; gamma = -dg->alpha * (1.0 - bt);
+        const double a = gamma, b = beta;
+        dg->dogleg_step_norm = sqrt(a * a * dg->gradient_norm * dg->gradient_norm + 2.0 * a * b * dg->g_dot_gn +
+                                    b * b * dg->gn_norm * dg->gn_norm);
+    }
+    *beta_out = beta; *gamma_out = gamma;
+}
+
+/* DoglegStrategy::ComputeSubspaceModel from the Gram matrices of (gradient_, gauss_newton_step_):
+ * inner products in the D-scaled space (pn2, qn2, pq) and of their Jacobian images (jj = |Jv|^2,
+ * |J dgn|^2, Jv.J dgn).  ColPivHouseholderQR pivots the longer column first; rank threshold
+ * epsilon * min(rows, cols).  Returns 0 if the rank is 0. */
+static int subspace_model(dogleg_t *dg, double pn2, double qn2, double pq, const double jj[3]) {
+    const int a_is_p = pn2 >= qn2;
+    const double an2 = a_is_p ? pn2 : qn2, bn2 = a_is_p ? qn2 : pn2;
+    if (!(an2 > 0.0)) return 0;
+    const double an = sqrt(an2), proj = pq / an;
+    double wn2 = bn2 - proj * proj;
+    if (wn2 < 0.0) wn2 = 0.0;
+    const double wn = sqrt(wn2);
+    const int ia = a_is_p ? 0 : 1, ib = 1 - ia;
+    dg->e[0][ia] = 1.0 / an; dg->e[0][ib] = 0.0;
+    dg->one_dim = wn <= 2.0 * DBL_EPSILON * an;
+    if (dg->one_dim) return 1;
+    dg->e[1][ia] = -proj / (an * wn); dg->e[1][ib] = 1.0 / wn;
+    for (int i = 0; i < 2; ++i) dg->sub_g[i] = dg->e[i][0] * pn2 + dg->e[i][1] * pq;      /* u_i . gradient_ */
+    int n = 0;
+    for (int i = 0; i < 2; ++i)
+        for (int j = i; j < 2; ++j)
+            dg->sub_B[n++] = dg->e[i][0] * dg->e[j][0] * jj[0] + (dg->e[i][0] * dg->e[j][1] + dg->e[i][1] * dg->e[j][0]) * jj[2] +
+                             dg->e[i][1] * dg->e[j][1] * jj[1];
+    return 1;
+}
+
+/* DoglegStrategy::FindMinimumOnTrustRegionBoundary */
+static int subspace_boundary_minimum(const dogleg_t *dg, double min_out[2]) {
+    const double B00 = dg->sub_B[0], B01 = dg->sub_B[1], B11 = dg->sub_B[2], g0 = dg->sub_g[0], g1 = dg->sub_g[1];
+    const double detB = B00 * B11 - B01 * B01, trB = B00 + B11, r2 = dg->radius * dg->radius;
+    /* B_adj = [B11 -B01; -B01 B00] */
+    const double ag0 = B11 * g0 - B01 * g1, ag1 = -B01 * g0 + B00 * g1;
+    double poly[5];
+    poly[0] = r2;
+    poly[1] = 2.0 * r2 * trB;
+    poly[2] = r2 * (trB * trB + 2.0 * detB) - (g0 * g0 + g1 * g1);
+    poly[3] = -2.0 * ((g0 * ag0 + g1 * ag1) - r2 * detB * trB);
+    poly[4] = r2 * detB * detB - (ag0 * ag0 + ag1 * ag1);
+    double roots[8];
+    const int nroots = poly_roots_real(poly, 5, roots);
+    min_out[0] = min_out[1] = 0.0;
+    if (nroots < 0) return 0;
+    double best = DBL_MAX;
+    int found = 0;
+    for (int i = 0; i < nroots; ++i) {
+        /* x = -(B + y I)^-1 g, partial-pivot LU of the 2x2 */
+        double a = B00 + roots[i], b = B01, c = B01, d = B11 + roots[i], r0 = g0, r1 = g1;
+        if (fabs(c) > fabs(a)) { double t; t = a; a = c; c = t; t = b; b = d; d = t; t = r0; r0 = r1; r1 = t; }
+        const double l = c / a, u = d - l * b;
+        const double x1 = (r1 - l * r0) / u, x0 = (r0 - b * x1) / a;
+        const double x[2] = {-x0, -x1};
+        const double nx = sqrt(x[0] * x[0] + x[1] * x[1]);
+        if (nx > 0) {
+            const double sx[2] = {dg->radius / nx * x[0], dg->radius / nx * x[1]};
+            const double f = 0.5 * (sx[0] * (B00 * sx[0] + B01 * sx[1]) + sx[1] * (B01 * sx[0] + B11 * sx[1])) + g0 * sx[0] + g1 * sx[1];
+            found = 1;
+            if (f < best) { best = f; min_out[0] = x[0]; min_out[1] = x[1]; }
+        }
+    }
+    return found;
+}
 
 /* One dogleg step.  In Ceres the strategy sees the Jacobi-scaled Jacobian J_s = J diag(s):
  *   D^2 = clamp(diag(J_s^T J_s)), gradient_ = J_s^T r ./ D, alpha = |gradient_|^2 / |J_s (gradient_ ./ D)|^2,
  *   Gauss-Newton: (J_s^T J_s + mu D^2) y = J_s^T r, gauss_newton_step_ = -D .* y,
  *   step = interpolation in the D-scaled space, ./ D, then .* s by the minimiser.
- * In unscaled coordinates: delta = beta * delta_gn + gamma * v with v = s^2 g / D^2. */
+ * In unscaled coordinates: delta = beta * delta_gn + gamma * v with v = s^2 g / D^2, for the traditional
+ * and for the subspace dogleg (its basis vectors are combinations of gradient_ and gauss_newton_step_). */
 static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, const double *sp,
-                       const double *sl, const orc_options *o, dogleg_t *dg, double *dp, double *dl,
-                       double *mcc, double *t_schur, double *t_solve) {
-    const int nf = g->nfree, L = g->L, ld = g->ld;
-    if (g->nb) return -1;   /* free shared blocks: Levenberg-Marquardt only in this build */
+                       const double *sl, const double *sb, const orc_options *o, dogleg_t *dg, double *dp, double *dl,
+                       double *db, double *mcc, double *t_schur, double *t_solve) {
+    const int nf = g->nfree, L = g->L, ld = g->ld, nb = g->nb;
+    const int subspace = o->dogleg_type == 1;
     if (!dg->reuse) {
         dg->reuse = 1;
         /* Gauss-Newton step with the regulariser mu * D^2: same damped system as LM with 1/radius = mu */
         double mcc_gn;
-        if (lm_step(p, g, w, sp, sl, NULL, 1.0 / dg->mu, o, dg->gn_p, dg->gn_l, NULL, &mcc_gn, t_schur, t_solve)) return -1;
+        if (lm_step(p, g, w, sp, sl, sb, 1.0 / dg->mu, o, dg->gn_p, dg->gn_l, dg->gn_b, &mcc_gn, t_schur, t_solve)) return -1;
         double gsq = 0.0, nsq = 0.0, dot = 0.0;
         memset(dg->v_p, 0, (size_t)g->P * 6 * sizeof(double));
         for (int f = 0; f < nf; ++f)
@@ -1062,37 +1241,46 @@ static int dogleg_step(const orc_problem *p, const graph_t *g, const lin_t *w, c
                 dot += gq * gn;
                 dg->v_l[ix] = s * s * gq / D2;
             }
-        double jv_sq;
-        step_products(p, g, w, dg->v_p, dg->v_l, NULL, NULL, &jv_sq);
+        for (int c = 0; c < nb; ++c) {
+            const double s = sb[c], gq = w->g_b[c], gn = dg->gn_b[c];
+            const double D2 = fmin(fmax(w->sq_b[c] * s * s, o->min_lm_diagonal), o->max_lm_diagonal);
+            gsq += s * s * gq * gq / D2;
+            nsq += D2 * gn * gn / (s * s);
+            dot += gq * gn;
+            dg->v_b[c] = s * s * gq / D2;
+        }
+        double jj[3];
+        jd_products(p, g, w, dg->v_p, dg->v_l, dg->v_b, dg->gn_p, dg->gn_l, dg->gn_b, jj);
         dg->gradient_norm = sqrt(gsq);
         dg->gn_norm = sqrt(nsq);
         dg->g_dot_gn = dot;           /* gradient_ . gauss_newton_step_ */
-        dg->alpha = gsq / jv_sq;      /* ComputeCauchyPoint */
+        dg->alpha = gsq / jj[0];      /* ComputeCauchyPoint */
+        if (subspace && !subspace_model(dg, gsq, nsq, dot, jj)) return -1;   /* ComputeSubspaceModel */
     }
-    /* ComputeTraditionalDoglegStep */
     double beta, gamma;
-    const double r = dg->radius;
-    if (dg->gn_norm <= r) {                               /* case 1: GN step inside the region */
-        beta = 1.0; gamma = 0.0;
-        dg->dogleg_step_norm = dg->gn_norm;
-    } else if (dg->gradient_norm * dg->alpha >= r) {      /* case 2: Cauchy point outside */
-        beta = 0.0; gamma = -r / dg->gradient_norm;
-        dg->dogleg_step_norm = r;
-    } else {                                              /* case 3: on the dogleg */
-        const double b_dot_a = -dg->alpha * dg->g_dot_gn;
-        const double a_sq = pow(dg->alpha * dg->gradient_norm, 2.0);
-        const double bma_sq = a_sq - 2.0 * b_dot_a + pow(dg->gn_norm, 2.0);
-        const double cc = b_dot_a - a_sq;
-        const double dd = sqrt(cc * cc + bma_sq * (r * r - a_sq));
-        const double bt = (cc <= 0.0) ? (dd - cc) / bma_sq : (r * r - a_sq) / (dd + cc);
-        beta = bt; gamma = -dg->alpha * (1.0 - bt);
-        const double a = gamma, b = beta;
-        dg->dogleg_step_norm = sqrt(a * a * dg->gradient_norm * dg->gradient_norm + 2.0 * a * b * dg->g_dot_gn +
-                                    b * b * dg->gn_norm * dg->gn_norm);
+    if (!subspace) {
+        traditional_dogleg(dg, &beta, &gamma);
+    } else {
+        /* ComputeSubspaceDoglegStep */
+        double m2[2];
+        if (dg->gn_norm <= dg->radius) {
+            beta = 1.0; gamma = 0.0;
+            dg->dogleg_step_norm = dg->gn_norm;
+        } else if (dg->one_dim) {
+            beta = 0.0; gamma = -dg->radius / dg->gradient_norm;
+            dg->dogleg_step_norm = dg->radius;
+        } else if (!subspace_boundary_minimum(dg, m2)) {
+            traditional_dogleg(dg, &beta, &gamma);   /* "Taking traditional dogleg step instead" */
+        } else {
+            gamma = m2[0] * dg->e[0][0] + m2[1] * dg->e[1][0];   /* coefficient of gradient_ -> v */
+            beta = m2[0] * dg->e[0][1] + m2[1] * dg->e[1][1];    /* coefficient of gauss_newton_step_ */
+            dg->dogleg_step_norm = dg->radius;
+        }
     }
     for (int i = 0; i < g->P * 6; ++i) dp[i] = beta * dg->gn_p[i] + gamma * dg->v_p[i];
     for (int i = 0; i < L * ld; ++i) dl[i] = beta * dg->gn_l[i] + gamma * dg->v_l[i];
-    step_products(p, g, w, dp, dl, NULL, mcc, NULL);
+    for (int c = 0; c < nb; ++c) db[c] = beta * dg->gn_b[c] + gamma * dg->v_b[c];
+    step_products(p, g, w, dp, dl, nb ? db : NULL, mcc, NULL);
     return 0;
 }
 
@@ -1328,7 +1516,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     const int nb = g.nb, nsh = ph ? shared_size(p) : 1;
     double *x_sh = calloc((size_t)nsh, sizeof(double)), *c_sh = calloc((size_t)nsh, sizeof(double)), *best_sh = calloc((size_t)nsh, sizeof(double));
     double db[64 + 1] = {0}, ngb[64 + 1] = {0}, sb[64 + 1];
-    if (nb > 64 || (nb && o->trust_region_strategy_type == 1)) {   /* unsupported here: report FAILURE */
+    if (nb > 64) {   /* unsupported here: report FAILURE */
         s->termination_type = ORC_FAILURE;
         free(x_pose); free(x_pt); free(x_n); free(c_pose); free(c_pt); free(c_n); free(best_pose); free(best_pt); free(best_n);
         free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl); free(x_sh); free(c_sh); free(best_sh);
@@ -1400,7 +1588,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
 
         /* ---- ComputeTrustRegionStep ---- */
         double mcc = 0.0;
-        int rc = dogleg ? dogleg_step(p, &g, &w, sp, sl, o, &dg, dp, dl, &mcc, &s->schur_time_s, &s->solve_time_s)
+        int rc = dogleg ? dogleg_step(p, &g, &w, sp, sl, sb, o, &dg, dp, dl, db, &mcc, &s->schur_time_s, &s->solve_time_s)
                         : lm_step(p, &g, &w, sp, sl, sb, radius, o, dp, dl, db, &mcc, &s->schur_time_s, &s->solve_time_s);
         int step_is_valid = (rc == 0) && (mcc > 0.0);
         if (!step_is_valid) {

@@ -97,8 +97,9 @@ typedef struct {
     double gradient_tolerance;                 /* 1e-10                           */
     double parameter_tolerance;                /* 1e-8                            */
     int32_t trust_region_strategy_type;        /* 0 = LEVENBERG_MARQUARDT (default), 1 = DOGLEG
-                                                  (TRADITIONAL_DOGLEG; tests/dataset_ba_phong.cpp:85) */
-    int32_t reserved;
+                                                  (tests/dataset_ba_phong.cpp:85) */
+    int32_t dogleg_type;                       /* 0 = TRADITIONAL_DOGLEG (Ceres default), 1 = SUBSPACE_DOGLEG
+                                                  (tests/dataset_ba_phong.cpp:86, dataset_vo_sun.cpp:143) */
 } orc_options;
 
 enum { ORC_CONVERGENCE = 0, ORC_NO_CONVERGENCE = 1, ORC_FAILURE = 2 };

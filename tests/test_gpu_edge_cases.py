@@ -121,12 +121,14 @@ def test_handle_reuse_solve_twice_and_set_huber_after_finalize():
     assert s3.final_cost == pytest.approx(s4.final_cost, rel=1e-6)
 
 
+@pytest.mark.parametrize("dogleg_type", [0, 1])
 @pytest.mark.parametrize("huber_a", [0.0, 1.345])
 @pytest.mark.parametrize("size", [(16, 500, 8), (50, 2000, 12)])
-def test_dogleg_strategy_matches_oracle(size, huber_a):
-    """trust_region_strategy_type = DOGLEG (TRADITIONAL_DOGLEG)."""
+def test_dogleg_strategy_matches_oracle(size, huber_a, dogleg_type):
+    """trust_region_strategy_type = DOGLEG, TRADITIONAL_DOGLEG and SUBSPACE_DOGLEG
+    (tests/dataset_vo_sun.cpp:142-143)."""
     prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=12)
-    ba, s, log, op, s2, log2 = _solve_both(prob, opts=dict(trust_region_strategy_type=1), huber_a=huber_a)
+    ba, s, log, op, s2, log2 = _solve_both(prob, opts=dict(trust_region_strategy_type=1, dogleg_type=dogleg_type), huber_a=huber_a)
     _assert_same_solve(ba, s, log, op, s2, log2)
     np.testing.assert_allclose(log["trust_region_radius"], log2["trust_region_radius"], rtol=1e-6)
     if huber_a == 0.0:   # same minimum as Levenberg-Marquardt (the robustified runs stop on different flat tails)
