@@ -33,7 +33,7 @@ class Problem(C.Structure):
                 ("normals", _dp), ("intensity", _dp), ("normal_obs", _dp), ("phong", _dp), ("texture", _dp),
                 ("material_of_point", _u32p), ("light", C.c_double * 3), ("light_type", C.c_int32),
                 ("shared_free", C.c_uint32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9),
-                ("num_materials", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("num_materials", C.c_uint32), ("use_bounds", C.c_uint32)]
 
 
 class Options(C.Structure):
@@ -54,7 +54,7 @@ class Summary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("total_time_s", C.c_double), ("linearize_time_s", C.c_double),
                 ("schur_time_s", C.c_double), ("solve_time_s", C.c_double),
-                ("update_time_s", C.c_double)]
+                ("update_time_s", C.c_double), ("num_line_search_steps", C.c_int32), ("reserved", C.c_int32)]
 
 
 class IterationLog(C.Structure):
@@ -127,7 +127,7 @@ class OracleProblem:
     """Owns numpy copies of a problem and the ctypes view the C oracle reads."""
 
     def __init__(self, camera: dict, poses, points, obs_pose, obs_point, obs_uvd, stiffness,
-                 pose_const=None, huber_a: float = 0.0, lighting=None, shared_free: int = 0):
+                 pose_const=None, huber_a: float = 0.0, lighting=None, shared_free: int = 0, use_bounds: bool = False):
         self.poses = np.ascontiguousarray(poses, dtype=np.float64).copy()
         self.points = np.ascontiguousarray(points, dtype=np.float64).copy()
         self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
@@ -162,6 +162,7 @@ class OracleProblem:
             self._lt["phong"], self._lt["texture"] = self.phong, self.texture
             self.c.num_materials = self.texture.shape[0]
             self.c.shared_free = int(shared_free)
+            self.c.use_bounds = 1 if use_bounds else 0
             self._mat = np.ascontiguousarray(lighting["material_of_point"], dtype=np.uint32)
             self.c.normals = _p(self.normals)
             self.c.intensity, self.c.normal_obs = _p(self._lt["intensity"]), _p(self._lt["normal_obs"])

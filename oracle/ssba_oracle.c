@@ -1102,6 +1102,8 @@ static int poly_roots_real(const double *coef_in, int ncoef, double *re) {
     return deg;
 }
 
+int orc_poly_roots_real(const double *coef, int ncoef, double *re) { return poly_roots_real(coef, ncoef, re); }
+
 /* [Ceres 1.x dogleg_strategy.cc] state kept between iterations */
 typedef struct {
     double radius, mu, alpha, dogleg_step_norm, gradient_norm, gn_norm, g_dot_gn;
@@ -1389,6 +1391,19 @@ static void plus_all(const orc_problem *p, const graph_t *g, const double *poses
         }
         if (g->b_phong >= 0) for (int c = 0; c < 3 * M; ++c) sh_out[3 + c] = sh[3 + c] + db[g->b_phong + c];
         if (g->b_tex >= 0) for (int c = 0; c < M; ++c) sh_out[3 + 3 * M + c] = sh[3 + 3 * M + c] + db[g->b_tex + c];
+        if (p->use_bounds) {
+            /* ParameterBlock::Plus projects onto the box [Ceres parameter_block.h]; the driver's bounds:
+             * ka, ks in [0,1], alpha >= 1, kd in [0,1] (dataset_ba_phong.cpp:143-181) */
+            if (g->b_phong >= 0)
+                for (int m = 0; m < M; ++m) {
+                    double *q = sh_out + 3 + 3 * m;
+                    q[0] = fmin(fmax(q[0], 0.0), 1.0);
+                    q[1] = fmin(fmax(q[1], 0.0), 1.0);
+                    q[2] = fmax(q[2], 1.0);
+                }
+            if (g->b_tex >= 0)
+                for (int m = 0; m < M; ++m) sh_out[3 + 3 * M + m] = fmin(fmax(sh_out[3 + 3 * M + m], 0.0), 1.0);
+        }
     }
 #pragma omp parallel for schedule(static)
     for (int k = 0; k < g->P; ++k) {
@@ -1495,6 +1510,148 @@ static void log_push(orc_iteration_log *log, orc_summary *s, double cost, double
     log->trust_region_radius[i] = radius; log->step_is_successful[i] = ok;
 }
 
+/* ---- projected Armijo line search of the bounds-constrained trust-region loop ----------------
+ * [Ceres 1.13 TrustRegionMinimizer::DoLineSearch -> ArmijoLineSearch::DoSearch with the Solver::Options
+ * defaults: CUBIC interpolation, sufficient decrease 1e-4, step contraction in [1e-3, 0.6], 20
+ * iterations, min step size 1e-9; line_search.cc, polynomial.cc] */
+typedef struct { double x, value, gradient; int value_ok, gradient_ok; } ls_sample_t;
+
+static double poly_eval(const double *c, int n, double x) {
+    double v = 0.0;
+    for (int i = 0; i < n; ++i) v = v * x + c[i];
+    return v;
+}
+
+/* FindInterpolatingPolynomial: full-pivot elimination of the Vandermonde-type system */
+static int ls_fit(const ls_sample_t *smp, int ns, double *coef) {
+    int nc = 0;
+    for (int i = 0; i < ns; ++i) nc += smp[i].value_ok + smp[i].gradient_ok;
+    const int deg = nc - 1;
+    double A[6][7];
+    int row = 0;
+    for (int i = 0; i < ns; ++i) {
+        if (smp[i].value_ok) {
+            for (int j = 0; j <= deg; ++j) A[row][j] = pow(smp[i].x, deg - j);
+            A[row][nc] = smp[i].value;
+            ++row;
+        }
+        if (smp[i].gradient_ok) {
+            for (int j = 0; j <= deg; ++j) A[row][j] = j < deg ? (deg - j) * pow(smp[i].x, deg - j - 1) : 0.0;
+            A[row][nc] = smp[i].gradient;
+            ++row;
+        }
+    }
+    int perm[6];
+    for (int i = 0; i < nc; ++i) perm[i] = i;
+    for (int k = 0; k < nc; ++k) {
+        int pr = k, pc = k;
+        double best = -1.0;
+        for (int i = k; i < nc; ++i)
+            for (int j = k; j < nc; ++j)
+                if (fabs(A[i][j]) > best) { best = fabs(A[i][j]); pr = i; pc = j; }
+        if (!(best > 0.0)) { for (int i = k; i < nc; ++i) A[i][nc] = 0.0; break; }
+        for (int j = 0; j <= nc; ++j) { double t = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = t; }
+        for (int i = 0; i < nc; ++i) { double t = A[i][k]; A[i][k] = A[i][pc]; A[i][pc] = t; }
+        { int t = perm[k]; perm[k] = perm[pc]; perm[pc] = t; }
+        for (int i = k + 1; i < nc; ++i) {
+            const double f = A[i][k] / A[k][k];
+            for (int j = k; j <= nc; ++j) A[i][j] -= f * A[k][j];
+        }
+    }
+    double y[6];
+    for (int i = nc - 1; i >= 0; --i) {
+        double v = A[i][nc];
+        for (int j = i + 1; j < nc; ++j) v -= A[i][j] * y[j];
+        y[i] = A[i][i] != 0.0 ? v / A[i][i] : 0.0;
+    }
+    for (int i = 0; i < nc; ++i) coef[perm[i]] = y[i];
+    return nc;
+}
+
+/* MinimizeInterpolatingPolynomial */
+static double ls_minimize(const ls_sample_t *smp, int ns, double x_min, double x_max) {
+    double coef[6];
+    const int nc = ls_fit(smp, ns, coef);
+    double best_x = 0.5 * (x_min + x_max), best_v = poly_eval(coef, nc, best_x), v;
+    if ((v = poly_eval(coef, nc, x_min)) < best_v) { best_v = v; best_x = x_min; }
+    if ((v = poly_eval(coef, nc, x_max)) < best_v) { best_v = v; best_x = x_max; }
+    if (nc > 2) {
+        double der[6], roots[8];
+        for (int i = 0; i < nc - 1; ++i) der[i] = (nc - 1 - i) * coef[i];
+        const int nr = poly_roots_real(der, nc - 1, roots);
+        for (int i = 0; i < nr; ++i) {
+            if (roots[i] < x_min || roots[i] > x_max) continue;
+            if ((v = poly_eval(coef, nc, roots[i])) < best_v) { best_v = v; best_x = roots[i]; }
+        }
+    }
+    for (int i = 0; i < ns; ++i)
+        if (smp[i].value_ok && smp[i].x >= x_min && smp[i].x <= x_max && smp[i].value < best_v) { best_v = smp[i].value; best_x = smp[i].x; }
+    return best_x;
+}
+
+/* LineSearch::InterpolatingPolynomialMinimizingStepSize, CUBIC */
+static double ls_next_step(const ls_sample_t *lower, const ls_sample_t *prev, const ls_sample_t *cur, double min_step, double max_step) {
+    if (!cur->value_ok) return fmin(fmax(cur->x * 0.5, min_step), max_step);
+    ls_sample_t smp[3];
+    int ns = 0;
+    smp[ns++] = *lower;
+    smp[ns++] = *cur;
+    if (prev->value_ok) smp[ns++] = *prev;
+    return ls_minimize(smp, ns, min_step, max_step);
+}
+
+/* ArmijoLineSearch::DoSearch as a resumable state machine: the caller evaluates phi(x) = cost(Plus(x0,
+ * x * delta)) and phi'(x) = delta . gradient(x) at the requested step and feeds the sample back. */
+typedef struct {
+    ls_sample_t initial, previous, current;
+    double dir_max_norm;
+    int num_iterations, done, success;
+    double optimal_step;
+} armijo_t;
+
+static void armijo_begin(armijo_t *a, double initial_cost, double initial_gradient, double dir_max_norm) {
+    memset(a, 0, sizeof *a);
+    a->initial.x = 0.0; a->initial.value = initial_cost; a->initial.gradient = initial_gradient;
+    a->initial.value_ok = a->initial.gradient_ok = 1;
+    a->current.x = 1.0;                 /* step_size_estimate = 1.0 */
+    a->dir_max_norm = dir_max_norm;
+}
+/* feed the evaluation of a->current.x; afterwards either a->done or a->current.x is the next request */
+static void armijo_feed(armijo_t *a, double value, double gradient) {
+    const double sufficient_decrease = 1e-4, max_step_contraction = 1e-3, min_step_contraction = 0.6, min_step_size = 1e-9;
+    const int max_num_iterations = 20;
+    a->current.value = value; a->current.gradient = gradient;
+    a->current.value_ok = isfinite(value);
+    a->current.gradient_ok = a->current.value_ok && isfinite(gradient);
+    if (a->current.value_ok && !(a->current.value > a->initial.value + sufficient_decrease * a->initial.gradient * a->current.x)) {
+        a->optimal_step = a->current.x; a->success = 1; a->done = 1;
+        return;
+    }
+    ++a->num_iterations;
+    if (a->num_iterations >= max_num_iterations) { a->done = 1; return; }
+    const double step = ls_next_step(&a->initial, &a->previous, &a->current, max_step_contraction * a->current.x,
+                                     min_step_contraction * a->current.x);
+    if (step * a->dir_max_norm < min_step_size) { a->done = 1; return; }
+    a->previous = a->current;
+    a->current.x = step;
+    a->current.value_ok = a->current.gradient_ok = 0;
+}
+
+int orc_armijo_trace(const double *values, const double *gradients, int n, double initial_cost, double initial_gradient,
+                     double dir_max_norm, double *steps_out, double *optimal_step) {
+    /* test hook: replays the state machine on a given sequence of evaluations; returns #requests made */
+    armijo_t a;
+    armijo_begin(&a, initial_cost, initial_gradient, dir_max_norm);
+    int k = 0;
+    while (!a.done && k < n) {
+        steps_out[k] = a.current.x;
+        armijo_feed(&a, values[k], gradients[k]);
+        ++k;
+    }
+    *optimal_step = a.success ? a.optimal_step : -1.0;
+    return k;
+}
+
 int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteration_log *log) {
     set_threads(o->num_threads);
     memset(s, 0, sizeof *s);
@@ -1533,6 +1690,20 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     memcpy(best_n, x_n, szL * 3 * sizeof(double));
 
     /* ---- IterationZero ---- */
+    const int constrained = ph && p->use_bounds && (g.b_phong >= 0 || g.b_tex >= 0);
+    lin_t w2;                 /* line-search evaluations keep the linearisation at x intact */
+    memset(&w2, 0, sizeof w2);
+    double *ls_pose = NULL, *ls_pt = NULL, *ls_n = NULL, *ls_sh = NULL, *sdp = NULL, *sdl = NULL;
+    if (constrained) {
+        lin_alloc(&w2, &g);
+        ls_pose = malloc(szP * 12 * sizeof(double)); ls_pt = malloc(szL * 3 * sizeof(double)); ls_n = malloc(szL * 3 * sizeof(double));
+        ls_sh = calloc((size_t)nsh, sizeof(double));
+        sdp = calloc(szP * 6, sizeof(double)); sdl = calloc(szL * ld, sizeof(double));
+        /* "x = Plus(x, 0)": project the initial point onto the feasible set */
+        plus_all(p, &g, x_pose, x_pt, x_n, x_sh, dp, dl, db, c_pose, c_pt, c_n, c_sh);
+        memcpy(x_sh, c_sh, (size_t)nsh * sizeof(double));
+        memcpy(best_sh, x_sh, (size_t)nsh * sizeof(double));
+    }
     double t0 = now_s();
     linearize(p, &g, x_pose, x_pt, x_n, ph ? x_sh : NULL, &w);
     s->linearize_time_s += now_s() - t0;
@@ -1610,6 +1781,50 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
             continue;
         }
         num_invalid = 0;
+
+        if (constrained) {
+            /* ---- DoLineSearch(x, gradient, cost, &delta): projected Armijo search along delta ---- */
+            double g0 = 0.0, dmax = 0.0;
+            for (int f = 0; f < g.nfree; ++f)
+                for (int c = 0; c < 6; ++c) {
+                    const double dv = dp[6 * g.free_pose[f] + c];
+                    g0 += w.g_p[6 * f + c] * dv;
+                    if (fabs(dv) > dmax) dmax = fabs(dv);
+                }
+            for (int j = 0; j < L; ++j) {
+                if (!g.pt_active[j]) continue;
+                for (int c = 0; c < ld; ++c) {
+                    g0 += w.g_l[(size_t)ld * j + c] * dl[(size_t)ld * j + c];
+                    if (fabs(dl[(size_t)ld * j + c]) > dmax) dmax = fabs(dl[(size_t)ld * j + c]);
+                }
+            }
+            for (int c = 0; c < nb; ++c) { g0 += w.g_b[c] * db[c]; if (fabs(db[c]) > dmax) dmax = fabs(db[c]); }
+            armijo_t arm;
+            armijo_begin(&arm, x_cost, g0, dmax);
+            while (!arm.done) {
+                const double a = arm.current.x;
+                double sdb[64 + 1];
+                for (int i = 0; i < P * 6; ++i) sdp[i] = a * dp[i];
+                for (int i = 0; i < L * ld; ++i) sdl[i] = a * dl[i];
+                for (int c = 0; c < nb; ++c) sdb[c] = a * db[c];
+                plus_all(p, &g, x_pose, x_pt, x_n, x_sh, sdp, sdl, sdb, ls_pose, ls_pt, ls_n, ls_sh);
+                linearize(p, &g, ls_pose, ls_pt, ls_n, ls_sh, &w2);
+                double gd = 0.0;      /* direction . gradient at the trial point (its own tangent space) */
+                for (int f = 0; f < g.nfree; ++f)
+                    for (int c = 0; c < 6; ++c) gd += w2.g_p[6 * f + c] * dp[6 * g.free_pose[f] + c];
+                for (int j = 0; j < L; ++j)
+                    if (g.pt_active[j])
+                        for (int c = 0; c < ld; ++c) gd += w2.g_l[(size_t)ld * j + c] * dl[(size_t)ld * j + c];
+                for (int c = 0; c < nb; ++c) gd += w2.g_b[c] * db[c];
+                armijo_feed(&arm, w2.cost, gd);
+                ++s->num_line_search_steps;
+            }
+            if (arm.success) {
+                for (int i = 0; i < P * 6; ++i) dp[i] *= arm.optimal_step;
+                for (int i = 0; i < L * ld; ++i) dl[i] *= arm.optimal_step;
+                for (int c = 0; c < nb; ++c) db[c] *= arm.optimal_step;
+            }
+        }
 
         /* ---- ComputeCandidatePointAndEvaluateCost ---- */
         t0 = now_s();
@@ -1700,6 +1915,7 @@ int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteratio
     free(best_pose); free(best_pt); free(best_n);
     free(dp); free(dl); free(ngp); free(ngl); free(sp); free(sl);
     free(x_sh); free(c_sh); free(best_sh);
+    if (constrained) { lin_free(&w2); free(ls_pose); free(ls_pt); free(ls_n); free(ls_sh); free(sdp); free(sdl); }
     free(dg.gn_p); free(dg.gn_l); free(dg.v_p); free(dg.v_l);
     lin_free(&w);
     graph_free(&g);

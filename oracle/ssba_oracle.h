@@ -77,7 +77,9 @@ typedef struct {
     double int_stiffness;              /* 1/sqrt(int_var)  (dataset_ba_phong.cpp:44)              */
     double normal_stiffness[9];
     uint32_t num_materials;
-    uint32_t reserved2;
+    uint32_t use_bounds;               /* 1: the driver's SetParameterLower/UpperBound calls on the free Phong
+                                          and texture blocks (dataset_ba_phong.cpp:143-181): ka, ks, kd in
+                                          [0,1], alpha >= 1 -> projected Plus + Armijo line search        */
 } orc_problem;
 
 typedef struct {
@@ -111,6 +113,8 @@ typedef struct {
     int32_t num_unsuccessful_steps;
     double initial_cost, final_cost;
     double total_time_s, linearize_time_s, schur_time_s, solve_time_s, update_time_s;
+    int32_t num_line_search_steps;   /* function evaluations of the projected line search (bounds) */
+    int32_t reserved;
 } orc_summary;
 
 /* one row per recorded iteration; arrays have capacity log_capacity */
@@ -155,6 +159,14 @@ int orc_border_size(const orc_problem *p);
  * [S_pp S_pb; S_pb^T S_bb] (leading dimension n + nb) and rhs (n + nb). */
 int orc_lm_step_border(const orc_problem *p, double radius, const orc_options *o, double *delta_p,
                        double *delta_l, double *delta_b, double *model_cost_change);
+
+/* real parts of all roots of a polynomial (coefficients highest degree first, degree <= 8), the
+ * contract of Ceres's FindPolynomialRoots(p, &real, NULL); returns the root count or -1 */
+int orc_poly_roots_real(const double *coef, int ncoef, double *re);
+
+/* test hook: replays ArmijoLineSearch::DoSearch on a given sequence of (value, gradient) evaluations */
+int orc_armijo_trace(const double *values, const double *gradients, int n, double initial_cost, double initial_gradient,
+                     double dir_max_norm, double *steps_out, double *optimal_step);
 
 /* Full solve with Ceres 1.13/1.14 trust-region semantics (see header comment). */
 int orc_solve(orc_problem *p, const orc_options *o, orc_summary *s, orc_iteration_log *log);

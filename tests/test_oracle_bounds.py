@@ -1,0 +1,126 @@
+"""Bounds on the Phong / texture blocks (tests/dataset_ba_phong.cpp:143-181): projected Plus and the
+Armijo line search Ceres 1.x runs inside its trust-region loop when the problem is constrained.
+The oracle's state machine is checked against an independent numpy restatement of
+ArmijoLineSearch::DoSearch + cubic/quintic interpolation.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ceres_slam_amd import synth
+from oracle import oracle as orc
+
+
+def _np_armijo(phi, dphi, dir_max_norm=1.0, c1=1e-4, max_contr=1e-3, min_contr=0.6, min_step=1e-9, max_it=20):
+    """line_search.cc ArmijoLineSearch::DoSearch, CUBIC interpolation, with numpy linear algebra."""
+    f0, g0 = phi(0.0), dphi(0.0)
+    init = (0.0, f0, g0)
+    prev, cur_x, steps = None, 1.0, []
+    it = 0
+    while True:
+        steps.append(cur_x)
+        cur = (cur_x, phi(cur_x), dphi(cur_x))
+        if cur[1] <= f0 + c1 * g0 * cur_x:
+            return steps, cur_x
+        it += 1
+        if it >= max_it:
+            return steps, -1.0
+        lo, hi = max_contr * cur_x, min_contr * cur_x
+        smp = [init, cur] + ([prev] if prev is not None else [])
+        n = 2 * len(smp)
+        A, b = np.zeros((n, n)), np.zeros(n)
+        for i, (x, v, g) in enumerate(smp):
+            A[2 * i] = [x ** (n - 1 - j) for j in range(n)]
+            A[2 * i + 1] = [(n - 1 - j) * x ** (n - 2 - j) if j < n - 1 else 0.0 for j in range(n)]
+            b[2 * i], b[2 * i + 1] = v, g
+        coef = np.linalg.solve(A, b)
+        cand = [0.5 * (lo + hi), lo, hi] + [r for r in np.roots(np.polyder(coef)).real if lo <= r <= hi]
+        vals = [np.polyval(coef, x) for x in cand]
+        best_x, best_v = cand[0], vals[0]
+        for x, v in zip(cand[1:], vals[1:]):
+            if v < best_v:
+                best_x, best_v = x, v
+        for x, v, g in smp:
+            if lo <= x <= hi and v < best_v:
+                best_x, best_v = x, v
+        if best_x * dir_max_norm < min_step:
+            return steps, -1.0
+        prev, cur_x = cur, best_x
+
+
+@pytest.mark.parametrize("case", ["quadratic_overshoot", "quartic", "exp_wall", "accept_at_one"])
+def test_armijo_state_machine_matches_numpy_restatement(case):
+    fns = {
+        "quadratic_overshoot": (lambda a: (a - 0.05) ** 2, lambda a: 2 * (a - 0.05)),
+        "quartic": (lambda a: (a - 0.02) ** 2 * (1 + 40 * a * a) + 1.0, None),
+        "exp_wall": (lambda a: np.exp(9 * a) - 12 * a, lambda a: 9 * np.exp(9 * a) - 12),
+        "accept_at_one": (lambda a: (a - 2.0) ** 2, lambda a: 2 * (a - 2.0)),
+    }
+    phi, dphi = fns[case]
+    if dphi is None:
+        dphi = lambda a: (phi(a + 1e-7) - phi(a - 1e-7)) / 2e-7
+    steps, opt = _np_armijo(phi, dphi)
+    lib = orc.lib()
+    dp = C.POINTER(C.c_double)
+    lib.orc_armijo_trace.argtypes = [dp, dp, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]
+    vals = np.array([phi(x) for x in steps])
+    grads = np.array([dphi(x) for x in steps])
+    out, optimal = np.zeros(len(steps) + 2), C.c_double()
+    n = lib.orc_armijo_trace(vals.ctypes.data_as(dp), grads.ctypes.data_as(dp), len(steps), phi(0.0), dphi(0.0), 1.0,
+                             out.ctypes.data_as(dp), C.byref(optimal))
+    assert n == len(steps)
+    np.testing.assert_allclose(out[:n], steps, rtol=1e-9)
+    assert optimal.value == pytest.approx(opt, rel=1e-9)
+    if case == "accept_at_one":
+        assert steps == [1.0]
+    else:
+        assert len(steps) >= 2            # the interpolation was exercised
+
+
+def _oracle(prob, ph, init, **kw):
+    return orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                             prob.stiffness(), lighting=ph.as_oracle_dict(init), shared_free=7, **kw)
+
+
+@pytest.mark.parametrize("light_type", [0, 1])
+def test_bounded_solve_from_the_reference_initial_guess(light_type):
+    # the reference starts every material at (ka, ks, alpha) = (0, 0, 1): ON the lower bounds
+    prob, ph = synth.make_phong_problem(50, 2000, light_type=light_type)
+    op = _oracle(prob, ph, "reference", use_bounds=True)
+    s, log = op.solve(orc.driver_options(num_threads=4))
+    assert s.termination_type == 0 and s.num_line_search_steps >= s.num_iterations - 2
+    assert np.all(op.phong[:, :2] >= 0) and np.all(op.phong[:, :2] <= 1) and np.all(op.phong[:, 2] >= 1)
+    assert np.all(op.texture >= 0) and np.all(op.texture <= 1)
+    assert s.final_cost < 0.2 * s.initial_cost
+    np.testing.assert_allclose(op.texture, ph.texture, atol=0.02)
+
+
+def test_infeasible_start_is_projected_and_bounds_stay_active():
+    prob, ph = synth.make_phong_problem(20, 600, track_len=8, seed=2)
+    d = ph.as_oracle_dict("perturbed")
+    d["phong"][:, 1] = -0.2            # ks below its lower bound
+    d["phong"][0, 2] = 0.5             # alpha below 1
+    d["texture"][1] = 1.4              # kd above its upper bound
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s, log = op.solve(orc.driver_options(num_threads=4, max_num_iterations=1))
+    # iteration 0 evaluates the PROJECTED point: same cost as starting from the clipped values
+    d2 = ph.as_oracle_dict("perturbed")
+    d2["phong"][:, 1] = 0.0
+    d2["phong"][0, 2] = 1.0
+    d2["texture"][1] = 1.0
+    op2 = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                            prob.stiffness(), lighting=d2, shared_free=7)
+    assert s.initial_cost == pytest.approx(op2.cost(), rel=1e-13)
+    s, log = op.solve(orc.driver_options(num_threads=4))
+    assert np.all(op.phong[:, 1] >= 0) and np.all(op.phong[:, 2] >= 1) and np.all(op.texture <= 1)
+
+
+def test_without_bounds_nothing_changes():
+    prob, ph = synth.make_phong_problem(20, 600, track_len=8, seed=2)
+    a = _oracle(prob, ph, "perturbed")
+    b = _oracle(prob, ph, "perturbed", use_bounds=False)
+    sa, la = a.solve(orc.driver_options(num_threads=2))
+    sb, lb = b.solve(orc.driver_options(num_threads=2))
+    assert sa.num_line_search_steps == 0
+    np.testing.assert_array_equal(la["cost"], lb["cost"])

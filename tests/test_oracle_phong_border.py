@@ -69,8 +69,56 @@ def test_constant_blocks_are_untouched():
     np.testing.assert_array_equal(op.phong, d["phong"])
     np.testing.assert_array_equal(op.texture, d["texture"])
     assert not np.array_equal(op.light, d["light"])
-    # DOGLEG with a border is rejected loudly by the oracle as well
-    with pytest.raises(Exception):
-        op2 = _oracle(prob, ph, 7)
-        s2, _ = op2.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1))
-        assert s2.termination_type != 2
+
+
+def test_polynomial_roots_match_numpy():
+    """The quartic of DoglegStrategy::FindMinimumOnTrustRegionBoundary is solved by Aberth iteration in
+    the oracle (Ceres: companion-matrix eigenvalues); the real parts of all roots must agree with numpy."""
+    import ctypes as C
+    lib = orc.lib()
+    lib.orc_poly_roots_real.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+    rng = np.random.default_rng(3)
+    for deg in (1, 2, 3, 4):
+        for _ in range(50):
+            c = rng.normal(size=deg + 1) * 10.0 ** rng.integers(-3, 4, deg + 1)
+            out = np.zeros(8)
+            n = lib.orc_poly_roots_real(c.ctypes.data_as(C.POINTER(C.c_double)), deg + 1, out.ctypes.data_as(C.POINTER(C.c_double)))
+            assert n == deg
+            ref = np.sort(np.roots(c).real)
+            np.testing.assert_allclose(np.sort(out[:n]), ref, rtol=1e-8, atol=1e-9 * np.abs(ref).max())
+    # leading zeros are dropped first
+    c = np.array([0.0, 0.0, 2.0, -6.0, 4.0])
+    out = np.zeros(8)
+    assert lib.orc_poly_roots_real(c.ctypes.data_as(C.POINTER(C.c_double)), 5, out.ctypes.data_as(C.POINTER(C.c_double))) == 2
+    np.testing.assert_allclose(np.sort(out[:2]), [1.0, 2.0], rtol=1e-14)
+
+
+@pytest.mark.parametrize("dogleg_type", [0, 1])
+@pytest.mark.parametrize("shared_free", [0, 7])
+def test_dogleg_reaches_the_levenberg_marquardt_minimum(dogleg_type, shared_free):
+    prob, ph = synth.make_phong_problem(50, 2000)
+    init = "perturbed" if shared_free else "truth"
+    kw = dict(num_threads=4, use_nonmonotonic_steps=0)
+    s_lm, _ = _oracle(prob, ph, shared_free, init).solve(orc.driver_options(**kw))
+    op = _oracle(prob, ph, shared_free, init)
+    s, log = op.solve(orc.driver_options(trust_region_strategy_type=1, dogleg_type=dogleg_type, **kw))
+    assert s.termination_type == 0
+    assert s.final_cost == pytest.approx(s_lm.final_cost, rel=1e-4)
+    # the trust region only ever halves on a rejected step and the radius sequence starts at 1e4
+    assert log["trust_region_radius"][0] == 1e4
+    assert np.abs(np.linalg.norm(op.normals, axis=1) - 1).max() < 1e-12
+
+
+def test_subspace_dogleg_step_is_never_worse_than_the_traditional_one():
+    """On the trust-region boundary the 2-D subspace minimiser contains the dogleg path, so its model
+    decrease is at least the traditional one; inside the region both take the Gauss-Newton step."""
+    prob, ph = synth.make_phong_problem(12, 200, track_len=6, seed=5)
+    for radius in (1e4, 30.0, 3.0, 0.3):
+        costs = []
+        for dt in (0, 1):
+            op = _oracle(prob, ph, 7)
+            s, log = op.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1, dogleg_type=dt, max_num_iterations=1,
+                                                 initial_trust_region_radius=radius, use_nonmonotonic_steps=0))
+            costs.append(log["cost"][1] if len(log["cost"]) > 1 else log["cost"][0])
+        if radius >= 1e4:
+            assert costs[0] == pytest.approx(costs[1], rel=1e-12)
