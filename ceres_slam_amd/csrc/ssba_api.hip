@@ -14,7 +14,10 @@
 
 #include "../../include/ssba.h"
 #include "ssba_launch.h"
+#include "ssba_linesearch.h"
 #include "ssba_types.h"
+
+#include <limits>
 
 using namespace ssba;
 
@@ -53,6 +56,12 @@ struct ssba_problem {
     int ph_light_type = 0;
     uint32_t shared_const = 0;             // bit 0 light, bit 1 Phong parameters, bit 2 textures
     std::vector<double> h_sh;              // packed [light 3 | phong 3M | texture M]
+    double blo[4] = {-std::numeric_limits<double>::infinity(), -std::numeric_limits<double>::infinity(),
+                     -std::numeric_limits<double>::infinity(), -std::numeric_limits<double>::infinity()};
+    double bhi[4] = {std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(),
+                     std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity()};
+    double *h_ls = nullptr;                // pinned: line-search scalars + state
+    int num_line_search_steps = 0;
     std::vector<double> ph_intensity, ph_nobs;
     double ph_int_stiff = 0.0, ph_Sn[9] = {0};
     bool lighting() const { return !ph_intensity.empty(); }
@@ -126,6 +135,7 @@ static void free_device(ssba_problem *p) {
     p->dev_bytes = 0;
     if (p->h_state) { hipHostFree(p->h_state); p->h_state = nullptr; }
     if (p->h_stage) { hipHostFree(p->h_stage); p->h_stage = nullptr; }
+    if (p->h_ls) { hipHostFree(p->h_ls); p->h_ls = nullptr; }
     p->finalized = false;
 }
 
@@ -288,6 +298,17 @@ int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant) 
     if (p->finalized) return SSBA_ERR_STATE;   // the border of the reduced system depends on it
     if (is_constant) p->shared_const |= (1u << which);
     else p->shared_const &= ~(1u << which);
+    return SSBA_OK;
+}
+
+int ssba_set_shared_block_bounds(ssba_problem *p, int which, int index, double lower, double upper) {
+    if (!p || (which != SSBA_BLOCK_PHONG && which != SSBA_BLOCK_TEXTURE) || !(lower <= upper)) return SSBA_ERR_INVALID_ARGUMENT;
+    if ((which == SSBA_BLOCK_PHONG && (index < 0 || index > 2)) || (which == SSBA_BLOCK_TEXTURE && index != 0))
+        return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    const int i = which == SSBA_BLOCK_PHONG ? index : 3;
+    p->blo[i] = lower;
+    p->bhi[i] = upper;
     return SSBA_OK;
 }
 
@@ -661,6 +682,12 @@ int ssba_finalize(ssba_problem *p) {
         if (!(p->shared_const & 2u)) { d.b_phong = d.nb; d.nb += 3 * d.M; }
         if (!(p->shared_const & 4u)) { d.b_tex = d.nb; d.nb += d.M; }
         if (d.nb > NBP) { set_error("border of free shared blocks wider than this build supports"); return SSBA_ERR_UNSUPPORTED; }
+        // bounds only matter on free blocks; a constrained problem runs the projected line search
+        for (int i = 0; i < 4; ++i) {
+            d.blo[i] = p->blo[i]; d.bhi[i] = p->bhi[i];
+            const bool is_free = i < 3 ? d.b_phong >= 0 : d.b_tex >= 0;
+            if (is_free && (std::isfinite(p->blo[i]) || std::isfinite(p->bhi[i]))) d.constrained = 1;
+        }
         d.int_stiff = p->ph_int_stiff;
         memcpy(d.Sn, p->ph_Sn, sizeof d.Sn);
         TRY(dzero(p, &d.nrm, (size_t)Lpad * 3)); TRY(dzero(p, &d.cand_nrm, (size_t)Lpad * 3));
@@ -679,6 +706,8 @@ int ssba_finalize(ssba_problem *p) {
             d.n_gram = 64;
             TRY(dzero(p, &d.part_g, (size_t)d.n_gram * (NBP * NBP + NBP)));
         }
+        TRY(dzero(p, &d.part_ls, (size_t)(Lpad / 256) * NLS));
+        TRY(dzero(p, &d.ls_out, (size_t)NLS_OUT));
     }
     TRY(dzero(p, &d.hpp, (size_t)P * 21)); TRY(dzero(p, &d.gp, (size_t)P * 6));
     TRY(dzero(p, &d.sp, (size_t)d.nf_pad * 6));
@@ -735,6 +764,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.st, (size_t)1));
     TRY(dzero(p, &d.dbg, (size_t)8192));
     HIPCHECK(hipHostMalloc((void **)&p->h_state, sizeof(State), hipHostMallocDefault));
+    HIPCHECK(hipHostMalloc((void **)&p->h_ls, NLS_OUT * sizeof(double), hipHostMallocDefault));
     p->h_stage_count = std::max<size_t>((size_t)P * 12, (size_t)Lpad * 3);
     HIPCHECK(hipHostMalloc((void **)&p->h_stage, std::max<size_t>(p->h_stage_count, 1) * sizeof(double), hipHostMallocDefault));
     if (upload_pair_table(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
@@ -783,6 +813,12 @@ static int upload_params(ssba_problem *p) {
         memcpy(p->h_sh.data(), p->user_light, 3 * sizeof(double));
         memcpy(p->h_sh.data() + 3, p->user_phong, 3 * M * sizeof(double));
         memcpy(p->h_sh.data() + 3 + 3 * M, p->user_texture, M * sizeof(double));
+        if (d.constrained) {   // "x = Plus(x, 0)": the minimiser starts from the projection onto the feasible set
+            if (d.b_phong >= 0)
+                for (size_t c = 0; c < 3 * M; ++c) p->h_sh[3 + c] = std::min(std::max(p->h_sh[3 + c], d.blo[c % 3]), d.bhi[c % 3]);
+            if (d.b_tex >= 0)
+                for (size_t c = 0; c < M; ++c) p->h_sh[3 + 3 * M + c] = std::min(std::max(p->h_sh[3 + 3 * M + c], d.blo[3]), d.bhi[3]);
+        }
         HIPCHECK(hipMemcpy(d.sh, p->h_sh.data(), (size_t)d.nsh * sizeof(double), hipMemcpyHostToDevice));
     }
     return SSBA_OK;
@@ -864,7 +900,10 @@ static int ensure_log(ssba_problem *p, int capacity) {
 // one trust-region iteration, enqueue only
 static int enqueue_kernels(ssba_problem *p);
 
+static int enqueue_constrained_iteration(ssba_problem *p);
+
 static int enqueue_iteration(ssba_problem *p) {
+    if (p->d.constrained) return enqueue_constrained_iteration(p);   // host-driven line search: no graph
     // The kernel sequence of an iteration is fixed (all control flow is on the device), so on
     // the plain single-GPU path it is captured once and replayed: ~45 launches become one.
     if (p->use_graph && !p->xfn && !p->launcher.timing) {
@@ -883,7 +922,59 @@ static int enqueue_iteration(ssba_problem *p) {
     return enqueue_kernels(p);
 }
 
+static int enqueue_front(ssba_problem *p);
+
 static int enqueue_kernels(ssba_problem *p) {
+    int rc = enqueue_front(p);
+    if (rc) return rc;
+    launch_decide_commit(p->launcher, p->d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+    return SSBA_OK;
+}
+
+// Bounds-constrained problems [Ceres 1.x trust_region_minimizer.cc]: after the trust-region step the
+// minimiser runs a projected Armijo line search along it.  The device evaluates the line-search function,
+// the host drives the search (one synchronisation per evaluation), then the usual accept / reject logic
+// judges the (possibly shortened) step.
+static int enqueue_constrained_iteration(ssba_problem *p) {
+    Dev &d = p->d;
+    Launcher &L = p->launcher;
+    int rc = enqueue_front(p);
+    if (rc) return rc;
+    auto fetch = [&]() -> int {
+        HIPCHECK(hipMemcpyAsync(p->h_ls, d.ls_out, NLS_OUT * sizeof(double), hipMemcpyDeviceToHost, L.stream));
+        HIPCHECK(hipMemcpyAsync(p->h_state, d.st, sizeof(State), hipMemcpyDeviceToHost, L.stream));
+        HIPCHECK(hipStreamSynchronize(L.stream));
+        return SSBA_OK;
+    };
+    // first evaluation at step 1: the candidate of the update kernels is that trial point
+    launch_ph_ls_probe(L, d, -1.0, 0);
+    if ((rc = fetch())) return rc;
+    if (!p->h_state->terminated && p->h_ls[6] != 0.0) {
+        Armijo a;
+        a.begin(p->h_ls[7], p->h_ls[5], p->h_ls[4]);
+        double at = 1.0;
+        a.feed(p->h_ls[0], p->h_ls[1]);
+        ++p->num_line_search_steps;
+        while (!a.done) {
+            at = a.current.x;
+            launch_ph_ls_probe(L, d, at, 1);
+            if ((rc = fetch())) return rc;
+            a.feed(p->h_ls[0], p->h_ls[1]);
+            ++p->num_line_search_steps;
+        }
+        const double want = a.success ? a.optimal_step : 1.0;    // a failed search leaves delta alone
+        if (want != at) launch_ph_ls_probe(L, d, want, 1);
+        if (want != 1.0 || at != 1.0) launch_ph_ls_accept(L, d);
+    }
+    launch_decide_commit(L, d);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+    return SSBA_OK;
+}
+
+static int enqueue_front(ssba_problem *p) {
     Dev &d = p->d;
     Launcher &L = p->launcher;
     launch_linearize(L, d);
@@ -900,9 +991,6 @@ static int enqueue_kernels(ssba_problem *p) {
     if (p->xfn) {
         if (p->xfn(p->xctx, d.scal2, NSCAL, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
     }
-    launch_decide_commit(L, d);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
 }
 
@@ -953,6 +1041,7 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     int rc = ensure_log(p, cap);
     if (rc) return rc;
     p->t_begin = std::chrono::steady_clock::now();
+    p->num_line_search_steps = 0;
     rc = upload_params(p);
     if (rc) return rc;
     hipStream_t s = p->launcher.stream;

@@ -462,12 +462,20 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
                 else for (int c = 0; c < 3; ++c) nl[c] = d.sh[c] + ng[c];
                 for (int c = 0; c < 3; ++c) { xnb += d.sh[c] * d.sh[c]; gmb = fmax(gmb, fabs(nl[c] - d.sh[c])); }
             }
+            // Plus projects onto the bounds [Ceres ParameterBlock::Plus], so the projected gradient does too
             if (d.b_phong >= 0)
-                for (int c = 0; c < 3 * d.M; ++c) { xnb += d.sh[3 + c] * d.sh[3 + c]; gmb = fmax(gmb, fabs(gb[d.b_phong + c])); }
+                for (int c = 0; c < 3 * d.M; ++c) {
+                    const double v = d.sh[3 + c];
+                    double nv = v - gb[d.b_phong + c];
+                    if (d.constrained) nv = fmin(fmax(nv, d.blo[c % 3]), d.bhi[c % 3]);
+                    xnb += v * v; gmb = fmax(gmb, fabs(nv - v));
+                }
             if (d.b_tex >= 0)
                 for (int c = 0; c < d.M; ++c) {
                     const double v = d.sh[3 + 3 * d.M + c];
-                    xnb += v * v; gmb = fmax(gmb, fabs(gb[d.b_tex + c]));
+                    double nv = v - gb[d.b_tex + c];
+                    if (d.constrained) nv = fmin(fmax(nv, d.blo[3]), d.bhi[3]);
+                    xnb += v * v; gmb = fmax(gmb, fabs(nv - v));
                 }
         }
         st.x_norm = sqrt(sc[1] + xnp + xnb);
@@ -508,6 +516,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
     ++st.iteration;
     st.last_successful = 0;
     st.accepted = 0;
+    st.ls_alpha = 1.0;
     // step_failed may already carry a landmark-block breakdown from k_schur_windows
 }
 
@@ -543,6 +552,7 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
             for (int c = 0; c < 6; ++c) {
                 eps[c] = st.opt.strategy ? st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c]
                                          : d.x0[(size_t)f * 6 + c];
+                eps[c] *= st.ls_alpha;      // 1 except inside the projected line search (bounds)
                 if (!isfinite(eps[c])) nonfinite = 1.0;
             }
             se3_plus(T, eps, Tn);
@@ -1164,6 +1174,7 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.relative_decrease = 0.0; st.cost_change = 0.0; st.initial_cost = 0.0;
     st.dl_reuse = 0; st.mu = 1e-8; st.alpha = 0.0; st.dl_step_norm = 0.0; st.grad_norm = 0.0; st.gn_norm = 0.0;
     st.g_dot_gn = 0.0; st.beta = 1.0; st.gamma = 0.0;
+    st.ls_alpha = 1.0;
     st.sub_one_dim = 0; st.sub_g[0] = st.sub_g[1] = 0.0; st.sub_B[0] = st.sub_B[1] = st.sub_B[2] = 0.0;
     st.sub_e[0][0] = st.sub_e[0][1] = st.sub_e[1][0] = st.sub_e[1][1] = 0.0;
 }
@@ -1209,6 +1220,10 @@ void launch_update_eval(Launcher &L, const Dev &d) {
     if (d.phong) launch_ph_backsub_eval(L, d);
     else LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
+}
+
+void launch_pose_update(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
 }
 
 void launch_dogleg_eval(Launcher &L, const Dev &d) {

@@ -60,7 +60,7 @@ static __device__ __forceinline__ int bcol(const Dev &d, uint32_t mat, int q) {
     return d.b_light < 0 ? -1 : d.b_light + (q - 4);
 }
 
-static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const double *__restrict__ T, const double p[3],
+static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const double *__restrict__ sh, const double *__restrict__ T, const double p[3],
                                                         const double n[3], uint32_t mat, double u, double v, double dd,
                                                         double inten, const double nobs[3], bool want_pose, ObsPh &o) {
     ObsLin s;
@@ -82,7 +82,7 @@ static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const doub
         for (int i = 0; i < 18; ++i) o.Jp[i] = Jp3[i];
     }
     Shared sx;
-    load_shared(d, d.sh, mat, sx);
+    load_shared(d, sh, mat, sx);
     double ri, J19[19], rn[3], Jnp[18], Jnn[9];
     intensity_residual(d.light_type, T, p, n, sx.ph3, sx.kd, sx.light, inten, d.int_stiff, &ri, J19);
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
             const size_t oi = obase + (size_t)s * LMG;
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
-            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, false, o);
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, false, o);
             cost += o.half_sq;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_ph_linearize_poses(Dev d) {
         load_lm(d, l, x);
         const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
         ObsPh o;
-        obs_ph_linearize(d, T, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+        obs_ph_linearize(d, d.sh, T, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
             int n = 0;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
                 const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
                 const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
                 ObsPh o;
-                obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+                obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
                 const double *Ci = sLM + li * 28;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
             const size_t oi = obase + (size_t)s * LMG;
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
-            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
             const double *dp = d.x0 + (size_t)f * 6;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
             ObsPh o;
-            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 double jd = 0.0;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_ph_border_poses(Dev d) {
                 load_lm(d, l, x);
                 const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
                 ObsPh o;
-                obs_ph_linearize(d, T, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+                obs_ph_linearize(d, d.sh, T, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
                 double Ci[21];
 #pragma unroll
                 for (int c = 0; c < 21; ++c) Ci[c] = d.cinv[(size_t)c * d.Lpad + l];
@@ -816,7 +816,7 @@ __global__ void k_ph_border_update(Dev d) {
     if (!st.step_failed && d.nb) {
         double db[NBP];   // LM: beta = 1, gamma = 0; dogleg: beta * delta_gn + gamma * v
         for (int c = 0; c < d.nb; ++c) {
-            db[c] = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
+            db[c] = st.ls_alpha * (st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c]);
             if (!isfinite(db[c])) bad = 1.0;
         }
         if (d.b_light >= 0) {
@@ -825,6 +825,12 @@ __global__ void k_ph_border_update(Dev d) {
         }
         if (d.b_phong >= 0) for (int c = 0; c < 3 * d.M; ++c) d.cand_sh[3 + c] = d.sh[3 + c] + db[d.b_phong + c];
         if (d.b_tex >= 0) for (int c = 0; c < d.M; ++c) d.cand_sh[3 + 3 * d.M + c] = d.sh[3 + 3 * d.M + c] + db[d.b_tex + c];
+        if (d.constrained) {   // ParameterBlock::Plus projects onto the box constraints
+            if (d.b_phong >= 0)
+                for (int c = 0; c < 3 * d.M; ++c) d.cand_sh[3 + c] = fmin(fmax(d.cand_sh[3 + c], d.blo[c % 3]), d.bhi[c % 3]);
+            if (d.b_tex >= 0)
+                for (int c = 0; c < d.M; ++c) d.cand_sh[3 + 3 * d.M + c] = fmin(fmax(d.cand_sh[3 + 3 * d.M + c], d.blo[3]), d.bhi[3]);
+        }
         for (int i = 0; i < d.nsh; ++i) { const double df = d.cand_sh[i] - d.sh[i]; dn += df * df; }
     }
     d.part_pose[d.n_pose_blocks * 2] = dn;
@@ -884,7 +890,7 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
             const size_t oi = obase + (size_t)s * LMG;
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
-            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
             const double *dp = d.x0 + (size_t)f * 6;
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
@@ -927,7 +933,7 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
             const size_t oi = obase + (size_t)s * LMG;
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
-            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 double jv = 0.0, jg = 0.0;
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
             ObsPh o;
-            obs_ph_linearize(d, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 double jd = 0.0;
@@ -1032,6 +1038,138 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
     }
 }
 
+// ------------------------------------------------------------------ projected line search ---
+// [Ceres 1.x TrustRegionMinimizer::DoLineSearch] phi(a) = cost(Plus(x, a * delta)) and
+// phi'(a) = delta . gradient(Plus(x, a * delta)) = sum_obs r . (J delta), r and J evaluated at the
+// trial point; the scalar Armijo logic runs on the host (ssba_linesearch.h).
+__global__ void k_ls_set_alpha(Dev d, double alpha) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) d.st->ls_alpha = alpha;
+}
+
+// per landmark: trial point for st.ls_alpha (candidate poses / shared blocks are already in place),
+// its cost, phi', |dx_l|^2, and the alpha-independent max|delta_l| and g_l . delta_l
+__global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double cost = 0.0, dphi = 0.0, dn = 0.0, nonfinite = 0.0, dmax = 0.0, gd = 0.0;
+    LmIn x;
+    load_lm(d, l, x);
+    double np_[3] = {x.p[0], x.p[1], x.p[2]}, nn[3] = {x.n[0], x.n[1], x.n[2]};
+    if (mask && !st.step_failed) {
+        const uint32_t win = d.lm_win[l];
+        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        double dl[6], sdl[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            dl[c] = d.dlm[(size_t)c * d.Lpad + l];
+            sdl[c] = st.ls_alpha * dl[c];
+            if (!isfinite(dl[c])) nonfinite = 1.0;
+            dmax = fmax(dmax, fabs(dl[c]));
+            gd += d.gl[(size_t)c * d.Lpad + l] * dl[c];
+        }
+        double dbq[NBQ];
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            const int c = d.nb ? bcol(d, x.mat, q) : -1;
+            dbq[q] = c >= 0 ? st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c] : 0.0;
+        }
+        np_[0] = x.p[0] + sdl[0]; np_[1] = x.p[1] + sdl[1]; np_[2] = x.p[2] + sdl[2];
+        unit_plus(x.n, sdl + 3, nn);
+        dn = sdl[0] * sdl[0] + sdl[1] * sdl[1] + sdl[2] * sdl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
+             (nn[1] - x.n[1]) * (nn[1] - x.n[1]) + (nn[2] - x.n[2]) * (nn[2] - x.n[2]);
+        for (int s = 0; s < TW; ++s) {
+            if (!((mask >> s) & 1u)) continue;
+            const uint32_t k = d.win_pose[win * TW + s];
+            const int f = d.pose_free[k];
+            const size_t oi = obase + (size_t)s * LMG;
+            const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
+            ObsPh o;
+            obs_ph_linearize(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi],
+                             nobs, f >= 0, o);
+            cost += o.half_sq;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                double jd = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) jd += o.Jl[6 * m + c] * dl[c];
+                if (f >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        const double dpc = st.opt.strategy ? st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c]
+                                                           : d.x0[(size_t)f * 6 + c];
+                        jd += o.Jp[6 * m + c] * dpc;
+                    }
+                }
+                if (m == 3) {
+#pragma unroll
+                    for (int q = 0; q < NBQ; ++q) jd += o.jb[q] * dbq[q];
+                }
+                dphi += o.r[m] * jd;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d.cand_pts[(size_t)c * d.Lpad + l] = np_[c];
+        d.cand_nrm[(size_t)c * d.Lpad + l] = nn[c];
+    }
+    const double a = block_sum(cost, sm), b = block_sum(dphi, sm), c = block_sum(dn, sm), e = block_sum(nonfinite, sm);
+    const double f2 = block_max(dmax, sm), g2 = block_sum(gd, sm);
+    if (threadIdx.x == 0) {
+        double *o = d.part_ls + (size_t)blockIdx.x * NLS;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = e; o[4] = f2; o[5] = g2;
+    }
+}
+
+// one block: totals of the probe plus the pose / border parts of max|delta| and g . delta, and the
+// validity of the trust-region step (as k_decide will judge it)
+__global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double acc[NLS] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+        const double *o = d.part_ls + (size_t)i * NLS;
+        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; acc[4] = fmax(acc[4], o[4]); acc[5] += o[5];
+    }
+    double pmax = 0.0, pgd = 0.0, pbad = 0.0;
+    for (int i = threadIdx.x; i < d.nfree * 6; i += 256) {
+        const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
+        const double dpc = st.opt.strategy ? st.beta * d.x0[i] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[i];
+        pmax = fmax(pmax, fabs(dpc));
+        pgd += d.xv[d.off_gp + i] * dpc;
+    }
+    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) pbad += d.part_pose[i * 2 + 1];
+    const double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
+    const double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
+    const double qmax = block_max(pmax, sm), qgd = block_sum(pgd, sm), qbad = block_sum(pbad, sm);
+    if (threadIdx.x != 0) return;
+    double bmax = 0.0, bgd = 0.0;
+    for (int c = 0; c < d.nb; ++c) {
+        const double v = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
+        bmax = fmax(bmax, fabs(v));
+        bgd += d.bsys[BS_G + c] * v;
+    }
+    d.ls_out[0] = cost; d.ls_out[1] = dphi; d.ls_out[2] = dn; d.ls_out[3] = bad;
+    d.ls_out[4] = fmax(fmax(lmax, qmax), bmax);
+    d.ls_out[5] = lgd + qgd + bgd;
+    // ComputeTrustRegionStep: valid iff the solve succeeded, the step is finite and model_cost_change > 0
+    d.ls_out[6] = (!st.step_failed && (d.scal2[3] + qbad) == 0.0 && d.scal2[1] > 0.0) ? 1.0 : 0.0;
+    d.ls_out[7] = st.x_cost;
+}
+
+// the accepted trial point becomes the candidate k_decide judges; the model cost change of the
+// unscaled trust-region step stays [trust_region_minimizer.cc: DoLineSearch only rescales delta]
+__global__ void k_ph_ls_accept(Dev d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || d.st->terminated) return;
+    d.scal2[0] = d.ls_out[0];
+    d.scal2[2] = d.ls_out[2];
+    d.scal2[3] = d.ls_out[3];
+}
+
 void launch_ph_linearize(Launcher &L, const Dev &d) {
     LAUNCH(KC_LIN_LM, k_ph_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_LIN_POSE, k_ph_linearize_poses, dim3(d.P), dim3(256), 0, d);
@@ -1057,6 +1195,19 @@ void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
     LAUNCH(KC_DOGLEG, k_ph_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+}
+// one evaluation of the line-search function at step `alpha` (alpha < 0: keep the current one)
+void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
+    if (alpha >= 0.0) hipLaunchKernelGGL(k_ls_set_alpha, dim3(1), dim3(64), 0, L.stream, d, alpha);
+    if (moved) {
+        launch_pose_update(L, d);
+        if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
+    }
+    LAUNCH(KC_BACKSUB_EVAL, k_ph_ls_probe, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d);
+}
+void launch_ph_ls_accept(Launcher &L, const Dev &d) {
+    hipLaunchKernelGGL(k_ph_ls_accept, dim3(1), dim3(64), 0, L.stream, d);
 }
 int configure_phong() {
     return hipFuncSetAttribute((const void *)k_ph_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -68,6 +68,7 @@ struct State {
     // SUBSPACE_DOGLEG model: u_i = sub_e[i][0] * gradient_ + sub_e[i][1] * gauss_newton_step_
     int sub_one_dim, sub_pad_;
     double sub_e[2][2], sub_g[2], sub_B[3];
+    double ls_alpha;          // projected line search (bounds): the candidate is Plus(x, ls_alpha * delta)
 };
 
 struct IterLog {   // device arrays, capacity entries
@@ -154,7 +155,15 @@ struct Dev {
     int n_gram;
     // border system, NBP-strided: Sbb (NBP*NBP) | rhsb | gb | hb | sb | db | vb
     double *bsys;
+    // bounds on the shared blocks (SetParameterLower/UpperBound): [ka, ks, alpha, kd]; projected Plus +
+    // Armijo line search when constrained
+    int constrained, pad2_;
+    double blo[4], bhi[4];
+    double *part_ls;                                // n_lm_blocks * NLS line-search partials
+    double *ls_out;                                 // NLS_OUT scalars the host reads per probe
 };
+constexpr int NLS = 6;        // per block: cost, phi', |dx_l|^2, nonfinite, max|delta_l|, g_l . delta_l
+constexpr int NLS_OUT = 8;    // cost, phi', |dx_l|^2, nonfinite_l, max|delta|, g . delta, valid, x_cost
 constexpr int BS_SBB = 0, BS_RHS = NBP * NBP, BS_G = BS_RHS + NBP, BS_H = BS_G + NBP, BS_S = BS_H + NBP,
               BS_DB = BS_S + NBP, BS_VB = BS_DB + NBP, BS_COUNT = BS_VB + NBP;   // VB: dogleg v_b = s^2 g / D^2
 

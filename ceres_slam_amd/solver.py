@@ -15,7 +15,7 @@ from . import capi
 class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
                  stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
-                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0):
+                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0, use_bounds: bool = False):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
         self.points = np.ascontiguousarray(points, dtype=np.float64)
@@ -43,6 +43,7 @@ class StereoBA:
         self._xcb = None
         self.normals = None
         self.shared_free = int(shared_free)
+        self.use_bounds = bool(use_bounds)
         if lighting is not None:
             self._add_lighting(lighting)
         if world_size > 1:
@@ -70,6 +71,10 @@ class StereoBA:
         for which in range(3):
             capi.check(self.lib.ssba_set_shared_block_constant(self.h, which, 0 if (self.shared_free >> which) & 1 else 1),
                        "ssba_set_shared_block_constant")
+        if self.use_bounds:      # tests/dataset_ba_phong.cpp:142-180
+            inf = float("inf")
+            for which, index, lo, hi in ((1, 0, 0.0, 1.0), (1, 1, 0.0, 1.0), (1, 2, 1.0, inf), (2, 0, 0.0, 1.0)):
+                capi.check(self.lib.ssba_set_shared_block_bounds(self.h, which, index, lo, hi), "ssba_set_shared_block_bounds")
         capi.check(self.lib.ssba_add_lighting_observations(self.h, capi.dptr(self._int), float(lt["int_stiffness"]),
                                                            capi.dptr(self._nobs), capi.dptr(self._Sn), N),
                    "ssba_add_lighting_observations")

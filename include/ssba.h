@@ -238,10 +238,17 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
  *                             observation already added (same order), 1/sqrt(int_var) and the 3x3
  *                             normal stiffness; num must equal the stereo observation count at
  *                             ssba_finalize.
+ * ssba_set_shared_block_bounds : SetParameterLowerBound / SetParameterUpperBound on entry `index`
+ *                             of ALL Phong-parameter (index 0..2 = ka, ks, alpha) or texture (index
+ *                             0 = kd) blocks, as the driver does for every material (:142-180: ka, ks,
+ *                             kd in [0,1], alpha >= 1); +-INFINITY = no bound.  With a bound on a free
+ *                             block the problem is constrained and the minimiser does what Ceres 1.x
+ *                             does: Plus projects onto the box and every trust-region step goes through
+ *                             a projected Armijo line search (host-driven, one synchronisation per
+ *                             evaluation; such solves are not captured in a hipGraph).
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
  * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  Not available together with lighting
- * terms yet (SSBA_ERR_UNSUPPORTED): Huber loss, landmark sharding, parameter bounds
- * (:142-180). */
+ * terms yet (SSBA_ERR_UNSUPPORTED): Huber loss, landmark sharding. */
 #define SSBA_MAX_MATERIALS 7
 enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };
 int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);
@@ -249,6 +256,7 @@ int ssba_add_material_blocks(ssba_problem *p, double *phong, double *texture, ui
                              const uint32_t *material_of_point, uint32_t num_points);
 int ssba_add_light_block(ssba_problem *p, double *light, int light_type);
 int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant);
+int ssba_set_shared_block_bounds(ssba_problem *p, int which, int index, double lower, double upper);
 int ssba_add_lighting_observations(ssba_problem *p, const double *intensity,
                                    double intensity_stiffness, const double *normal_obs,
                                    const double normal_stiffness[9], uint64_t num);

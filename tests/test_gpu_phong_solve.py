@@ -169,6 +169,48 @@ def test_phong_dogleg_solve_matches_oracle(dogleg_type, shared_free, nonmono):
         assert np.abs(ba.normals - op.normals).max() < 1e-5
 
 
+# ---- bounds on the Phong / texture blocks: projected Plus + Armijo line search ----
+@pytest.mark.parametrize("light_type", [0, 1])
+@pytest.mark.parametrize("init", ["perturbed", "reference"])
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 1)])       # LM, and the driver's DOGLEG / SUBSPACE_DOGLEG
+def test_bounded_solve_matches_oracle(light_type, init, strategy):
+    prob, ph = synth.make_phong_problem(50, 2000, light_type=light_type)
+    d = ph.as_oracle_dict(init)
+    ba = StereoBA.from_synth(prob, lighting=d, shared_free=7, use_bounds=True)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    kw = dict(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    s, log = ba.solve(capi.default_options(**kw))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, **kw))
+    assert s.termination_type == s2.termination_type == 0
+    n = min(len(log["cost"]), len(log2["cost"]), 12)
+    assert log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-6)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)
+    assert np.all(ba.phong[:, :2] >= 0) and np.all(ba.phong[:, :2] <= 1) and np.all(ba.phong[:, 2] >= 1)
+    assert np.all(ba.texture >= 0) and np.all(ba.texture <= 1)
+    if len(log["cost"]) == len(log2["cost"]):
+        np.testing.assert_allclose(ba.texture, op.texture, rtol=1e-4, atol=1e-6)
+
+
+def test_infeasible_start_is_projected_on_the_device():
+    prob, ph = synth.make_phong_problem(20, 600, track_len=8, seed=2)
+    d = ph.as_oracle_dict("perturbed")
+    d["phong"][:, 1] = -0.2
+    d["phong"][0, 2] = 0.5
+    d["texture"][1] = 1.4
+    ba = StereoBA.from_synth(prob, lighting=d, shared_free=7, use_bounds=True)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4))
+    assert s.initial_cost == pytest.approx(s2.initial_cost, rel=1e-12)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)
+    assert np.all(ba.phong[:, 1] >= 0) and np.all(ba.phong[:, 2] >= 1) and np.all(ba.texture <= 1)
+
+
 def test_phong_unsupported_combinations_fail_loudly():
     prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7)
     ba2 = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict(), huber_a=1.0)
