@@ -52,11 +52,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_examples() -> str:
-    """C++ driver written against the Ceres-shaped shim (include/ceres_slam_amd/ceres_shim.hpp)."""
+def build_examples(name: str = "dataset_vo_gpu") -> str:
+    """C++ drivers written against the Ceres-shaped shim (include/ceres_slam_amd/ceres_shim.hpp):
+    dataset_vo_gpu (tests/dataset_vo.cpp) and dataset_ba_phong_gpu (tests/dataset_ba_phong.cpp)."""
     root = os.path.dirname(HERE)
-    src = os.path.join(root, "examples", "dataset_vo_gpu.cpp")
-    out = os.path.join(root, "examples", "dataset_vo_gpu")
+    src = os.path.join(root, "examples", name + ".cpp")
+    out = os.path.join(root, "examples", name)
     build_library()
     deps = [src, os.path.join(root, "include", "ssba.h"), os.path.join(root, "include", "ceres_slam_amd", "ceres_shim.hpp"), LIB]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):

@@ -399,3 +399,40 @@ def make_phong_problem(num_poses: int, num_points: int, *, num_materials: int = 
     phong_ref = np.tile(np.array([0.0, 0.0, 1.0]), (num_materials, 1))
     return prob, PhongData(normals_gt, normals_init, mat, phong, texture, light, light_type, intensity, normal_obs,
                            int_var, np.full(3, normal_var), phong_init, texture_init, light_init, phong_ref, texture_ref)
+
+
+def write_reference_phong_csv(prob: StereoBAProblem, ph: PhongData, dataset_path: str, shared: str = "reference") -> tuple:
+    """Config-3 problem in the reference's on-disk formats: the 10-column dataset CSV of
+    src/ceres_slam/dataset_problem_phong.cpp:16-117 (5 header rows, then `t,j,material,u,v,d,I,nx,ny,nz`)
+    and the initial guess as the `_poses.csv` / `_map.csv` / `_lights.csv` triple its write_csv emits
+    (:177-232), at full double precision.  `shared` picks the initial shared blocks as in
+    PhongData.as_oracle_dict.  Returns (dataset, init_poses, init_map, init_lights)."""
+    base = dataset_path[: dataset_path.rfind(".")] if "." in dataset_path else dataset_path
+    d = ph.as_oracle_dict(shared)
+    c = prob.camera
+    mat = ph.material_of_point
+    with open(dataset_path, "w") as f:
+        f.write(f"{prob.num_poses},{prob.num_points},{len(ph.texture)}\n")
+        f.write(",".join(repr(float(c[k])) for k in ("fu", "fv", "cu", "cv", "b")) + "\n")
+        f.write(",".join(repr(float(v)) for v in list(prob.stereo_obs_var) + list(ph.normal_obs_var) + [ph.int_var]) + "\n")
+        f.write(",".join(repr(float(v)) for v in d["light"]) + "\n")
+        f.write(",".join(repr(float(v)) for v in _T44_rows(prob.poses_gt[0])) + "\n")
+        for i in range(prob.num_obs):
+            k, j = int(prob.obs_pose[i]), int(prob.obs_point[i])
+            vals = list(prob.obs_uvd[i]) + [ph.intensity[i]] + list(ph.normal_obs[i])
+            f.write(f"{float(k)!r},{j},{int(mat[j])}," + ",".join(repr(float(v)) for v in vals) + "\n")
+    poses_path, map_path, light_path = base + "_init_poses.csv", base + "_init_map.csv", base + "_init_lights.csv"
+    with open(poses_path, "w") as f:
+        f.write("T_00, T_01, T_02, T_03,T_10, T_11, T_12, T_13,T_20, T_21, T_22, T_23,T_30, T_31, T_32, T_33\n")
+        for row in _T44_rows(prob.poses_init):
+            f.write(",".join(repr(float(v)) for v in row) + "\n")
+    with open(map_path, "w") as f:
+        f.write("point_id, x, y, z, nx, ny, nz, ka, ks, exponent, kd\n")
+        for j in range(prob.num_points):
+            vals = list(prob.points_init[j]) + list(ph.normals_init[j]) + list(d["phong"][mat[j]]) + [d["texture"][mat[j]]]
+            f.write(f"{j}," + ",".join(repr(float(v)) for v in vals) + "\n")
+    with open(light_path, "w") as f:
+        f.write(("i, j, k" if ph.light_type == 1 else "x, y, z") + "\n")
+        f.write(",".join(repr(float(v)) for v in d["light"]) + "\n")
+    return dataset_path, poses_path, map_path, light_path
+

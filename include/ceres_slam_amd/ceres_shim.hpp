@@ -12,6 +12,15 @@
 //     ceres::Solver::Summary summary;  ceres::Solve(options, &problem, &summary);
 //     std::cout << summary.BriefReport();
 //
+// and of the Phong driver (tests/dataset_ba_phong.cpp:26-255):
+//
+//     problem.AddResidualBlock(IntensityErrorPointLightAutomatic::Create(I, int_stiffness), NULL,
+//                              pose_k, position_j, normal_j, phong_m, texture_m, light);
+//     problem.AddResidualBlock(NormalErrorAutomatic::Create(n_obs, normal_stiffness), NULL, pose_k, normal_j);
+//     problem.SetParameterization(normal_j, unit_vector_perturbation);
+//     problem.SetParameterLowerBound(phong_m, 0, 0.);  problem.SetParameterUpperBound(phong_m, 0, 1.); ...
+//     options.trust_region_strategy_type = ceres::DOGLEG;  options.dogleg_type = ceres::SUBSPACE_DOGLEG;
+//
 // The shim recognises the typed cost functions of this path and lowers them to observation
 // tables; it does NOT run arbitrary user functors on the GPU -- any other CostFunction is
 // rejected at AddResidualBlock with std::invalid_argument (Ceres would accept it: that is the
@@ -80,6 +89,49 @@ class SE3Perturbation : public ceres::LocalParameterization {
     static ceres::LocalParameterization *Create() { return new SE3Perturbation; }
 };
 
+// include/ceres_slam/perturbations.hpp:87-113
+class UnitVectorPerturbation : public ceres::LocalParameterization {
+ public:
+    static ceres::LocalParameterization *Create() { return new UnitVectorPerturbation; }
+};
+
+// include/ceres_slam/intensity_error_point_light.hpp:98-112 / intensity_error_directional_light.hpp:98-113:
+// blocks (pose 12, position 3, normal 3, Phong parameters 3, texture 1, light 3) -> 1 residual
+class IntensityErrorAutomaticBase : public ceres::CostFunction {
+ public:
+    double colour = 0.0, stiffness = 0.0;
+    int light_type = 0;      // 0 point light, 1 directional light
+};
+class IntensityErrorPointLightAutomatic : public IntensityErrorAutomaticBase {
+ public:
+    static ceres::CostFunction *Create(double colour, double stiffness) {
+        IntensityErrorPointLightAutomatic *c = new IntensityErrorPointLightAutomatic;
+        c->colour = colour; c->stiffness = stiffness; c->light_type = 0;
+        return c;
+    }
+};
+class IntensityErrorDirectionalLightAutomatic : public IntensityErrorAutomaticBase {
+ public:
+    static ceres::CostFunction *Create(double colour, double stiffness) {
+        IntensityErrorDirectionalLightAutomatic *c = new IntensityErrorDirectionalLightAutomatic;
+        c->colour = colour; c->stiffness = stiffness; c->light_type = 1;
+        return c;
+    }
+};
+
+// include/ceres_slam/normal_error.hpp:46-54: blocks (pose 12, normal 3) -> 3 residuals
+class NormalErrorAutomatic : public ceres::CostFunction {
+ public:
+    static ceres::CostFunction *Create(const double obs[3], const double stiffness[9]) {
+        NormalErrorAutomatic *c = new NormalErrorAutomatic;
+        std::memcpy(c->obs, obs, sizeof c->obs);
+        std::memcpy(c->stiffness, stiffness, sizeof c->stiffness);
+        return c;
+    }
+    double obs[3];
+    double stiffness[9];
+};
+
 }  // namespace ceres_slam
 
 namespace ceres {
@@ -133,7 +185,34 @@ class Problem {
     Problem(const Problem &) = delete;
     Problem &operator=(const Problem &) = delete;
 
+    // intensity residual block (tests/dataset_ba_phong.cpp:108-139)
+    void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *position_block, double *normal_block,
+                          double *phong_block, double *texture_block, double *light_block) {
+        auto *c = dynamic_cast<ceres_slam::IntensityErrorAutomaticBase *>(cost);
+        if (!c) throw std::invalid_argument("ceres_shim: a six-block residual must be an IntensityError*Automatic");
+        if (loss) throw std::invalid_argument("ceres_shim: lighting residual blocks take a NULL loss");
+        if (!intensity_.empty() && (c->stiffness != intensity_[0].stiffness || c->light_type != intensity_[0].light_type ||
+                                    light_block != light_))
+            throw std::invalid_argument("ceres_shim: intensity residual blocks must share stiffness, light type and light block");
+        light_ = light_block;
+        IntensityBlock b;
+        b.pose = pose_block; b.position = position_block; b.normal = normal_block; b.phong = phong_block; b.texture = texture_block;
+        b.colour = c->colour; b.stiffness = c->stiffness; b.light_type = c->light_type;
+        intensity_.push_back(b);
+        owned_costs_.push_back(cost);
+    }
+
     void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *point_block) {
+        if (auto *n = dynamic_cast<ceres_slam::NormalErrorAutomatic *>(cost)) {   // (pose, normal): dataset_ba_phong.cpp:181-188
+            if (loss) throw std::invalid_argument("ceres_shim: lighting residual blocks take a NULL loss");
+            NormalBlock b;
+            b.pose = pose_block; b.normal = point_block;
+            std::memcpy(b.obs, n->obs, sizeof b.obs);
+            std::memcpy(b.stiffness, n->stiffness, sizeof b.stiffness);
+            normals_.push_back(b);
+            owned_costs_.push_back(cost);
+            return;
+        }
         auto *s = dynamic_cast<ceres_slam::StereoReprojectionErrorAutomatic *>(cost);
         if (!s) throw std::invalid_argument("ceres_shim: only StereoReprojectionErrorAutomatic residual blocks run on the GPU path");
         const HuberLoss *h = nullptr;
@@ -157,16 +236,18 @@ class Problem {
         owned_costs_.push_back(cost);
     }
     void SetParameterization(double *block, LocalParameterization *lp) {
-        if (!dynamic_cast<ceres_slam::SE3Perturbation *>(lp)) throw std::invalid_argument("ceres_shim: only SE3Perturbation is supported");
+        owned_params_[lp] = 1;
+        if (dynamic_cast<ceres_slam::UnitVectorPerturbation *>(lp)) { unit_vector_[block] = 1; return; }   // normals, light direction
+        if (!dynamic_cast<ceres_slam::SE3Perturbation *>(lp)) throw std::invalid_argument("ceres_shim: only SE3Perturbation / UnitVectorPerturbation are supported");
         if (!pose_index_.count(block)) throw std::invalid_argument("ceres_shim: parameter block not found");
         parameterized_[block] = 1;
-        owned_params_[lp] = 1;
     }
-    void SetParameterBlockConstant(double *block) {
-        if (!pose_index_.count(block)) throw std::invalid_argument("ceres_shim: only pose blocks can be held constant");
-        constant_[block] = 1;
-    }
+    // poses: per block; shared lighting blocks (light, Phong parameters, textures): checked at Solve, the
+    // GPU path holds ALL blocks of one kind constant or none (what the driver's DEBUG lines do)
+    void SetParameterBlockConstant(double *block) { constant_[block] = 1; }
     void SetParameterBlockVariable(double *block) { constant_.erase(block); }
+    void SetParameterLowerBound(double *block, int index, double v) { lower_[block][index] = v; }
+    void SetParameterUpperBound(double *block, int index, double v) { upper_[block][index] = v; }
     int NumResidualBlocks() const { return (int)obs_pose_.size(); }
 
  private:
@@ -186,7 +267,13 @@ class Problem {
     std::vector<double *> pose_blocks_, point_blocks_;
     std::vector<uint32_t> obs_pose_, obs_point_;
     std::vector<double> obs_uvd_;
-    std::map<double *, int> parameterized_, constant_;
+    std::map<double *, int> parameterized_, constant_, unit_vector_;
+    struct IntensityBlock { double *pose, *position, *normal, *phong, *texture; double colour, stiffness; int light_type; };
+    struct NormalBlock { double *pose, *normal; double obs[3], stiffness[9]; };
+    std::vector<IntensityBlock> intensity_;
+    std::vector<NormalBlock> normals_;
+    double *light_ = nullptr;
+    std::map<double *, std::map<int, double>> lower_, upper_;
     std::vector<CostFunction *> owned_costs_;
     std::map<LossFunction *, int> owned_losses_;
     std::map<LocalParameterization *, int> owned_params_;
@@ -218,7 +305,96 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
     if ((rc = ssba_add_stereo_observations(h, P.obs_pose_.data(), P.obs_point_.data(), P.obs_uvd_.data(), P.obs_pose_.size(), P.stiffness_)))
         return fail("ssba_add_stereo_observations");
     for (auto &kv : P.constant_)
-        if ((rc = ssba_set_pose_constant(h, P.pose_index_[kv.first], 1))) return fail("ssba_set_pose_constant");
+        if (P.pose_index_.count(kv.first) && (rc = ssba_set_pose_constant(h, P.pose_index_[kv.first], 1))) return fail("ssba_set_pose_constant");
+    // ---- lighting terms (tests/dataset_ba_phong.cpp:101-204) -> the config-3 tables of the C ABI ----
+    std::vector<double> normals, phong, texture, intensity, normal_obs;
+    std::vector<double *> normal_blocks(P.point_blocks_.size(), nullptr), phong_blocks, texture_blocks;
+    std::vector<uint32_t> material_of_point(P.point_blocks_.size(), 0);
+    double light[3] = {0, 0, 0};
+    const bool lighting = !P.intensity_.empty();
+    if (lighting) {
+        const size_t N = P.obs_pose_.size();
+        if (P.intensity_.size() != N || P.normals_.size() != N)
+            throw std::invalid_argument("ceres_shim: every stereo observation needs one intensity and one normal residual block");
+        std::map<std::pair<double *, double *>, size_t> obs_of;      // (pose, position) -> stereo observation
+        for (size_t i = 0; i < N; ++i) obs_of[{P.pose_blocks_[P.obs_pose_[i]], P.point_blocks_[P.obs_point_[i]]}] = i;
+        std::map<double *, uint32_t> material_index, point_of_normal;
+        intensity.assign(N, 0.0);
+        normal_obs.assign(3 * N, 0.0);
+        for (auto &b : P.intensity_) {
+            auto it = obs_of.find({b.pose, b.position});
+            if (it == obs_of.end()) throw std::invalid_argument("ceres_shim: intensity residual without a stereo residual on the same (pose, point)");
+            const uint32_t j = P.point_index_[b.position];
+            if (normal_blocks[j] && normal_blocks[j] != b.normal) throw std::invalid_argument("ceres_shim: a vertex has two normal blocks");
+            normal_blocks[j] = b.normal;
+            point_of_normal[b.normal] = j;
+            if (!material_index.count(b.phong)) {
+                material_index[b.phong] = (uint32_t)phong_blocks.size();
+                phong_blocks.push_back(b.phong);
+                texture_blocks.push_back(b.texture);
+            }
+            const uint32_t m = material_index[b.phong];
+            if (texture_blocks[m] != b.texture) throw std::invalid_argument("ceres_shim: Phong parameter and texture blocks must pair one-to-one");
+            material_of_point[j] = m;
+            intensity[it->second] = b.colour;
+        }
+        for (auto &b : P.normals_) {
+            auto pj = point_of_normal.find(b.normal);
+            if (pj == point_of_normal.end()) throw std::invalid_argument("ceres_shim: normal residual on an unknown normal block");
+            auto it = obs_of.find({b.pose, P.point_blocks_[pj->second]});
+            if (it == obs_of.end()) throw std::invalid_argument("ceres_shim: normal residual without a stereo residual on the same (pose, point)");
+            std::memcpy(&normal_obs[3 * it->second], b.obs, 3 * sizeof(double));
+            if (std::memcmp(b.stiffness, P.normals_[0].stiffness, sizeof b.stiffness) != 0)
+                throw std::invalid_argument("ceres_shim: normal residual blocks must share their stiffness");
+        }
+        const size_t M = phong_blocks.size();
+        normals.resize(3 * P.point_blocks_.size());
+        for (size_t j = 0; j < P.point_blocks_.size(); ++j) {
+            if (!normal_blocks[j]) throw std::invalid_argument("ceres_shim: a vertex without lighting terms");
+            if (!P.unit_vector_.count(normal_blocks[j])) throw std::invalid_argument("ceres_shim: normal block without UnitVectorPerturbation");
+            std::memcpy(&normals[3 * j], normal_blocks[j], 3 * sizeof(double));
+        }
+        phong.resize(3 * M); texture.resize(M);
+        for (size_t m = 0; m < M; ++m) { std::memcpy(&phong[3 * m], phong_blocks[m], 3 * sizeof(double)); texture[m] = *texture_blocks[m]; }
+        std::memcpy(light, P.light_, sizeof light);
+        const int light_type = P.intensity_[0].light_type;
+        if (light_type == 1 && !P.unit_vector_.count(P.light_)) throw std::invalid_argument("ceres_shim: light direction without UnitVectorPerturbation");
+        if ((rc = ssba_add_normal_blocks(h, normals.data(), (uint32_t)P.point_blocks_.size()))) return fail("ssba_add_normal_blocks");
+        if ((rc = ssba_add_material_blocks(h, phong.data(), texture.data(), (uint32_t)M, material_of_point.data(), (uint32_t)P.point_blocks_.size())))
+            return fail("ssba_add_material_blocks");
+        if ((rc = ssba_add_light_block(h, light, light_type))) return fail("ssba_add_light_block");
+        if ((rc = ssba_add_lighting_observations(h, intensity.data(), P.intensity_[0].stiffness, normal_obs.data(), P.normals_[0].stiffness, N)))
+            return fail("ssba_add_lighting_observations");
+        // SetParameterBlockConstant / bounds on shared blocks: all blocks of a kind or none
+        auto all_or_none = [&](const std::vector<double *> &blocks, const char *what) {
+            size_t n = 0;
+            for (double *b : blocks) n += P.constant_.count(b);
+            if (n != 0 && n != blocks.size()) throw std::invalid_argument(std::string("ceres_shim: hold all ") + what + " blocks constant or none");
+            return n != 0;
+        };
+        if ((rc = ssba_set_shared_block_constant(h, SSBA_BLOCK_LIGHT, P.constant_.count(P.light_) ? 1 : 0))) return fail("ssba_set_shared_block_constant");
+        if ((rc = ssba_set_shared_block_constant(h, SSBA_BLOCK_PHONG, all_or_none(phong_blocks, "Phong parameter") ? 1 : 0))) return fail("ssba_set_shared_block_constant");
+        if ((rc = ssba_set_shared_block_constant(h, SSBA_BLOCK_TEXTURE, all_or_none(texture_blocks, "texture") ? 1 : 0))) return fail("ssba_set_shared_block_constant");
+        auto bounds = [&](const std::vector<double *> &blocks, int which, int size) -> int {
+            for (int idx = 0; idx < size; ++idx) {
+                auto get = [&](std::map<double *, std::map<int, double>> &tab, double *b, double none) {
+                    auto it = tab.find(b);
+                    if (it == tab.end() || !it->second.count(idx)) return none;
+                    return it->second[idx];
+                };
+                const double inf = 1.0 / 0.0;
+                const double lo = get(P.lower_, blocks[0], -inf), hi = get(P.upper_, blocks[0], inf);
+                for (double *b : blocks)
+                    if (get(P.lower_, b, -inf) != lo || get(P.upper_, b, inf) != hi)
+                        throw std::invalid_argument("ceres_shim: bounds must be the same on all blocks of a kind");
+                if (lo != -inf || hi != inf)
+                    if (int r = ssba_set_shared_block_bounds(h, which, idx, lo, hi)) return r;
+            }
+            return 0;
+        };
+        if ((rc = bounds(phong_blocks, SSBA_BLOCK_PHONG, 3))) return fail("ssba_set_shared_block_bounds");
+        if ((rc = bounds(texture_blocks, SSBA_BLOCK_TEXTURE, 1))) return fail("ssba_set_shared_block_bounds");
+    }
     if (P.huber_a_ > 0 && (rc = ssba_set_huber_loss(h, P.huber_a_))) return fail("ssba_set_huber_loss");
     if ((rc = ssba_finalize(h))) return fail("ssba_finalize");
     ssba_options o;
@@ -247,6 +423,11 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
     if (summary->IsSolutionUsable()) {
         for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(P.pose_blocks_[i], &poses[12 * i], 12 * sizeof(double));
         for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(P.point_blocks_[i], &points[3 * i], 3 * sizeof(double));
+        if (lighting) {   // every lighting block is written back; constant ones come back unchanged
+            for (size_t j = 0; j < P.point_blocks_.size(); ++j) std::memcpy(normal_blocks[j], &normals[3 * j], 3 * sizeof(double));
+            for (size_t m = 0; m < phong_blocks.size(); ++m) { std::memcpy(phong_blocks[m], &phong[3 * m], 3 * sizeof(double)); *texture_blocks[m] = texture[m]; }
+            std::memcpy(P.light_, light, sizeof light);
+        }
     }
 }
 

@@ -211,6 +211,38 @@ def test_infeasible_start_is_projected_on_the_device():
     assert np.all(ba.phong[:, 1] >= 0) and np.all(ba.phong[:, 2] >= 1) and np.all(ba.texture <= 1)
 
 
+@pytest.mark.parametrize("light_type", [0, 1])
+def test_config1_phong_driver_through_the_ceres_shim(tmp_path, light_type):
+    """BASELINE.json configs[0]: dataset_ba_phong on a 50-pose / 2 000-landmark sequence.
+    examples/dataset_ba_phong_gpu.cpp = the reference's solveWindow (tests/dataset_ba_phong.cpp:26-255)
+    written against the C++ shim with the driver's own settings -- DOGLEG / SUBSPACE_DOGLEG, non-monotonic
+    steps, free light / material / texture blocks with their bounds, the reference's initial material
+    values -- fed through the reference's own CSV formats, against the oracle with the same settings."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples("dataset_ba_phong_gpu")
+    prob, ph = synth.make_phong_problem(50, 2000, light_type=light_type)
+    files = synth.write_reference_phong_csv(prob, ph, str(tmp_path / "sim.csv"), shared="reference")
+    r = subprocess.run([exe, *files] + (["--dirlight"] if light_type else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    d = ph.as_oracle_dict("reference")
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s2, _ = op.solve(orc.driver_options(num_threads=4, trust_region_strategy_type=1, dogleg_type=1))
+    report = [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")][0]
+    assert "Termination: CONVERGENCE" in report
+    final = float(report.split("Final cost: ")[1].split(",")[0])
+    assert final == pytest.approx(s2.final_cost, rel=1e-4)
+    poses = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(poses - op.poses).max() < 1e-4
+    m = np.loadtxt(str(tmp_path / "sim_map.csv"), delimiter=",", skiprows=1)
+    assert m.shape == (2000, 11)
+    assert np.abs(np.linalg.norm(m[:, 4:7], axis=1) - 1).max() < 1e-12
+    assert np.all(m[:, 7:9] >= 0) and np.all(m[:, 7:9] <= 1) and np.all(m[:, 9] >= 1) and np.all((m[:, 10] >= 0) & (m[:, 10] <= 1))
+    lights = np.loadtxt(str(tmp_path / "sim_lights.csv"), delimiter=",", skiprows=1)
+    np.testing.assert_allclose(lights, op.light, rtol=1e-4, atol=1e-5)
+
+
 def test_phong_unsupported_combinations_fail_loudly():
     prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7)
     ba2 = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict(), huber_a=1.0)
