@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iteration cap of the CPU-oracle sample (it converges in ~80)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP-event bracketing (use under rocprofv3)")
+    ap.add_argument("--shared-free", type=int, default=0, help="C3 only: free shared blocks (bit 0 light, 1 Phong, 2 texture)")
+    ap.add_argument("--bounds", action="store_true", help="C3 only: the driver's bounds on the Phong / texture blocks")
+    ap.add_argument("--dogleg", type=int, default=-1, help="-1 LM (dataset_vo), 0 TRADITIONAL_DOGLEG, 1 SUBSPACE_DOGLEG")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +159,7 @@ def main():
         if world > 1:
             raise SystemExit("config C3 (lighting terms) is single-GPU in this build")
         prob, ph = synth.make_phong_problem(P1, L1)
-        lighting = ph.as_oracle_dict()
+        lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
         prob = synth.make_problem(P1 * world, L1 * world)
     if world > 1:
@@ -164,7 +167,8 @@ def main():
     else:
         shard = sharding.whole(prob)
     ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                  prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting)
+                  prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting,
+                  shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds))
     stream = torch.cuda.current_stream()
     ba.set_stream(stream.cuda_stream)
     if world > 1:
@@ -173,6 +177,8 @@ def main():
     stats = {k: int(getattr(st, k)) for k, _ in capi.Stats._fields_}
 
     opts = capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1)   # tests/dataset_vo.cpp:65-70
+    if args.dogleg >= 0:
+        opts.trust_region_strategy_type, opts.dogleg_type = 1, args.dogleg
     # ---- warm-up: one real solve to convergence (also gives the restart period) ----------
     s_conv, log_conv = ba.solve(opts)
     period = max(int(s_conv.num_iterations) - 1, 1)
@@ -182,6 +188,7 @@ def main():
     ba.points[:] = shard.points_init
     if phong:
         ba.normals[:] = lighting["normals"]
+        ba.phong[:], ba.texture[:], ba.light[:] = lighting["phong"], lighting["texture"], lighting["light"]
 
     def run(n_steps, timing):
         ba.set_kernel_timing(timing)
@@ -263,7 +270,8 @@ def main():
             "config": {"workload": f"{args.config}: {P1 * world} poses / {L1 * world} landmarks / "
                                    f"{prob.num_obs} stereo observations, "
                                    + ("stereo + Phong intensity + normal residual blocks, 6-D landmark blocks "
-                                      "(position + unit normal), light / materials constant, LM"
+                                      f"(position + unit normal), shared_free={args.shared_free}, bounds={bool(args.bounds)}, "
+                                      f"strategy={'LM' if args.dogleg < 0 else 'DOGLEG/%d' % args.dogleg}"
                                       if phong else "reprojection-only LM (Ceres dataset_vo options)")
                                    + f", {world} shard(s)",
                        "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
@@ -278,14 +286,14 @@ def main():
             "stats": stats,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost, lighting)
+            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost, lighting, args)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(prob, iters, gpu_final_cost, lighting=None):
+def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None):
     """CPU oracle = port with Ceres-equivalent semantics (kind "port"); bounded sample."""
     from oracle import oracle as orc
     cores = min(os.cpu_count() or 1, 16)
@@ -293,10 +301,13 @@ def cpu_baseline(prob, iters, gpu_final_cost, lighting=None):
         op = orc.OracleProblem.from_synth(prob)
     else:
         op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
-                               prob.stiffness(), lighting=lighting)
+                               prob.stiffness(), lighting=lighting, shared_free=args.shared_free, use_bounds=args.bounds)
     orc.lib()
+    kw = dict(num_threads=cores, max_num_iterations=iters)
+    if args is not None and args.dogleg >= 0:
+        kw.update(trust_region_strategy_type=1, dogleg_type=args.dogleg)
     t0 = time.perf_counter()
-    s, log = op.solve(orc.driver_options(num_threads=cores, max_num_iterations=iters))
+    s, log = op.solve(orc.driver_options(**kw))
     dt = time.perf_counter() - t0
     n = max(int(s.num_iterations) - 1, 1)
     return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port",
