@@ -701,7 +701,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.pose_mat_start, pose_mat_start));
         if (d.nb) {
             TRY(dzero(p, &d.lmV, (size_t)Lpad * 42)); TRY(dzero(p, &d.lmH, (size_t)Lpad * 28)); TRY(dzero(p, &d.lmG, (size_t)Lpad * 7));
-            TRY(dzero(p, &d.part_b, (size_t)(Lpad / 256) * d.M * NBV));
+            TRY(dzero(p, &d.part_b, (size_t)(Lpad / 256 + 1) * d.M * NBV));   // + one row of column sums
             TRY(dzero(p, &d.bsys, (size_t)BS_COUNT));
             d.n_gram = 64;
             TRY(dzero(p, &d.part_g, (size_t)d.n_gram * (NBP * NBP + NBP)));

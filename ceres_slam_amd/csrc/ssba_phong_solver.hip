@@ -690,17 +690,24 @@ __global__ __launch_bounds__(256) void k_ph_border_schur(Dev d) {
     }
 }
 
-// sums the per-block partials and scatters them into the border system (one block)
+// column sums of the per-block partials: one wave per (material, component), fixed summation order
+__global__ __launch_bounds__(64) void k_ph_border_colsum(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    const int idx = blockIdx.x, lane = threadIdx.x;
+    double a = 0.0;
+    for (int b = lane; b < d.n_lm_blocks; b += 64) a += d.part_b[(size_t)b * d.M * NBV + idx];
+    a = wave_sum(a);
+    if (lane == 0) d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx] = a;
+}
+
+// scatters the summed partials into the border system (one block)
 __global__ __launch_bounds__(256) void k_ph_border_reduce(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double tot[8 * NBV];
     const int t = threadIdx.x;
-    for (int idx = t; idx < d.M * NBV; idx += 256) {
-        double a = 0.0;
-        for (int b = 0; b < d.n_lm_blocks; ++b) a += d.part_b[(size_t)b * d.M * NBV + idx];
-        tot[idx] = a;
-    }
+    for (int idx = t; idx < d.M * NBV; idx += 256) tot[idx] = d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx];
     for (int i = t; i < BS_S; i += 256) d.bsys[i] = 0.0;     // Sbb | rhsb | gb | hb
     __syncthreads();
     if (t != 0) return;
@@ -1180,6 +1187,7 @@ void launch_ph_schur(Launcher &L, const Dev &d) {
     LAUNCH(KC_SCHUR, k_ph_schur_windows, dim3(d.n_slabs), dim3(PH_THREADS), PH_LDS_DOUBLES * sizeof(double), d);
     if (d.nb) {
         LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
+        LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
         LAUNCH(KC_BORDER, k_ph_border_poses, dim3(d.P), dim3(256), 0, d);
     }
