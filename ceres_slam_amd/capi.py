@@ -34,6 +34,7 @@ SYMBOLS = [
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
     "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds",
+    "ssba_set_partition",
 ]
 
 
@@ -119,6 +120,7 @@ def load():
     L.ssba_set_stream.argtypes = [H, C.c_void_p]
     L.ssba_set_exchange.argtypes = [H, EXCHANGE_FN, C.c_void_p]
     L.ssba_set_distributed.argtypes = [H, C.c_int, C.c_int]
+    L.ssba_set_partition.argtypes = [H, _u32p, C.c_uint32]
     L.ssba_exchange_size.argtypes = [H, C.POINTER(C.c_uint64)]
     L.ssba_set_kernel_timing.argtypes = [H, C.c_int]
     L.ssba_kernel_times.argtypes = [H, C.POINTER(KernelTime), C.c_int32, _i32p]

@@ -81,6 +81,7 @@ struct ssba_problem {
     ssba_exchange_fn xfn = nullptr;
     void *xctx = nullptr;
     int world_size = 1, rank = 0;
+    std::vector<uint32_t> sep_sb;          // partitioned solve: separator super-blocks (world_size + 1 entries)
     // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -366,6 +367,20 @@ int ssba_set_distributed(ssba_problem *p, int world_size, int rank) {
     if (p->finalized) return SSBA_ERR_STATE;
     p->world_size = world_size;
     p->rank = rank;
+    return SSBA_OK;
+}
+
+int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, uint32_t num) {
+    if (!p || (num && !separator_superblocks)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    if (num == 0) { p->sep_sb.clear(); return SSBA_OK; }
+    if ((int)num != p->world_size + 1 || num > (uint32_t)MAX_SEP) {
+        set_error("ssba_set_partition: world_size + 1 separators expected (call ssba_set_distributed first)");
+        return SSBA_ERR_INVALID_ARGUMENT;
+    }
+    for (uint32_t i = 0; i + 1 < num; ++i)
+        if (separator_superblocks[i + 1] <= separator_superblocks[i]) return SSBA_ERR_INVALID_ARGUMENT;
+    p->sep_sb.assign(separator_superblocks, separator_superblocks + num);
     return SSBA_OK;
 }
 
@@ -733,18 +748,47 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dzero(p, &d.Zb, (size_t)d.nf_pad * 6 * NBP));
     }
     TRY(dzero(p, &d.vp, (size_t)P * 6)); TRY(dzero(p, &d.vl, (size_t)Lpad * (ph ? 6 : 3))); TRY(dzero(p, &d.dl_gn, (size_t)Lpad * (ph ? 6 : 3)));
-    // BCR level plan
+    // BCR level plan.  Plain: all super-blocks, odd blocks eliminated level by level down to one block.
+    // Partitioned (ssba_set_partition): this rank's chain [sep[rank], sep[rank+1]] with both ends pinned, down to the
+    // two ends, plus a plain plan for the separator system (one block per chain end).
+    auto upload_pos = [&](const std::vector<int> &pos, const int **out) -> int { return dupload(p, out, pos); };
+    const bool part = !p->sep_sb.empty();
+    if (part) {
+        if (ph) { set_error("lighting terms are not available with landmark sharding yet"); return SSBA_ERR_UNSUPPORTED; }
+        if ((int)p->sep_sb.back() != d.Nsb - 1 || p->sep_sb.front() != 0) {
+            set_error("ssba_set_partition: the separators must start at super-block 0 and end at the last one");
+            return SSBA_ERR_INVALID_ARGUMENT;
+        }
+        d.part = 1; d.rank = p->rank; d.n_sep = (int)p->sep_sb.size();
+        for (int i = 0; i < d.n_sep; ++i) d.sep_sb[i] = (int)p->sep_sb[i];
+        d.chain0 = d.sep_sb[p->rank]; d.chain1 = d.sep_sb[p->rank + 1];
+        // every observation of this rank must fall into its chain (the sharding has to be aligned to super-blocks)
+        for (uint64_t i = 0; i < N; ++i) {
+            const int f = p->pose_free[p->obs_pose[i]];
+            if (f >= 0 && (f / SBP < d.chain0 || f / SBP > d.chain1)) {
+                set_error("ssba_set_partition: an observation of this rank touches a pose outside its chain of super-blocks");
+                return SSBA_ERR_INVALID_ARGUMENT;
+            }
+        }
+    }
     {
-        int n = d.Nsb, lev = 0;
+        int n = part ? d.chain1 - d.chain0 + 1 : d.Nsb, lev = 0;
+        const size_t c0 = part ? (size_t)d.chain0 : 0;
         d.lev[0].n = n;
-        d.lev[0].D = d.xv + d.off_D;
-        d.lev[0].L = d.xv + d.off_L;
-        d.lev[0].r = d.xv + d.off_rhs;
+        d.lev[0].D = d.xv + d.off_D + c0 * blk;
+        d.lev[0].L = d.xv + d.off_L + c0 * blk;
+        d.lev[0].r = d.xv + d.off_rhs + c0 * BD;
+        std::vector<int> pos(n);
+        for (int i = 0; i < n; ++i) pos[i] = i;
         for (;;) {
             if (d.nb) TRY(dzero(p, &d.lev[lev].B, (size_t)n * BD * NBP));
             TRY(dzero(p, &d.lev[lev].YU, (size_t)std::max(1, n / 2) * blk));
-            if (n == 1) break;
-            const int n2 = (n + 1) / 2;
+            TRY(upload_pos(pos, &d.lev[lev].pos));
+            if (part ? n <= 2 : n == 1) break;
+            d.lev[lev].pin = (part && (n % 2 == 0)) ? 1 : 0;
+            const int n2 = d.lev[lev].pin ? n / 2 + 1 : (n + 1) / 2;
+            std::vector<int> pos2(n2);
+            for (int m = 0; m < n2; ++m) pos2[m] = (d.lev[lev].pin && m == n2 - 1) ? pos[n - 1] : pos[2 * m];
             ++lev;
             if (lev >= MAX_LEVELS) return SSBA_ERR_UNSUPPORTED;
             d.lev[lev].n = n2;
@@ -752,8 +796,42 @@ int ssba_finalize(ssba_problem *p) {
             TRY(dzero(p, &d.lev[lev].L, (size_t)n2 * blk));
             TRY(dzero(p, &d.lev[lev].r, (size_t)n2 * BD));
             n = n2;
+            pos.swap(pos2);
         }
         d.n_levels = lev + 1;
+    }
+    if (part) {
+        const uint64_t ns = (uint64_t)d.n_sep;
+        d.soff_D = 0;
+        d.soff_L = d.soff_D + ns * blk;
+        d.soff_rhs = d.soff_L + ns * blk;
+        d.soff_gp = d.soff_rhs + ns * BD;
+        d.soff_hdiag = d.soff_gp + ns * BD;
+        d.soff_scal = d.soff_hdiag + ns * BD;
+        d.sepv_count = d.soff_scal + NSCAL;
+        TRY(dzero(p, &d.sepv, d.sepv_count));
+        TRY(dzero(p, &d.xsep, (size_t)ns * BD));
+        int n = d.n_sep, lev = 0;
+        d.slev[0].n = n;
+        d.slev[0].D = d.sepv + d.soff_D;
+        d.slev[0].L = d.sepv + d.soff_L;
+        d.slev[0].r = d.sepv + d.soff_rhs;
+        for (;;) {
+            TRY(dzero(p, &d.slev[lev].YU, (size_t)std::max(1, n / 2) * blk));
+            std::vector<int> pos(n);
+            for (int i = 0; i < n; ++i) pos[i] = i << lev;
+            TRY(upload_pos(pos, &d.slev[lev].pos));
+            if (n == 1) break;
+            const int n2 = (n + 1) / 2;
+            ++lev;
+            if (lev >= MAX_SLEVELS) return SSBA_ERR_UNSUPPORTED;
+            d.slev[lev].n = n2;
+            TRY(dzero(p, &d.slev[lev].D, (size_t)n2 * blk));
+            TRY(dzero(p, &d.slev[lev].L, (size_t)n2 * blk));
+            TRY(dzero(p, &d.slev[lev].r, (size_t)n2 * BD));
+            n = n2;
+        }
+        d.ns_levels = lev + 1;
     }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
@@ -979,6 +1057,22 @@ static int enqueue_front(ssba_problem *p) {
     Launcher &L = p->launcher;
     launch_linearize(L, d);
     launch_schur(L, d);
+    if (d.part) {
+        // partitioned reduced solve: eliminate this rank's chain interior, sum the chain ends (the separator
+        // system: ~1 MB instead of the whole reduced system) over the ranks, solve it everywhere, back-substitute
+        if (!p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
+        launch_finish_local(L, d);
+        launch_bcr(L, d);
+        launch_sep_pack(L, d);
+        if (p->xfn(p->xctx, d.sepv, d.sepv_count, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        if (p->xfn(p->xctx, d.gmax_l, 1, 1)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        launch_sep_finish_check(L, d);
+        launch_bcr_separators(L, d);
+        launch_update_eval(L, d);
+        launch_eval_add_pose(L, d);
+        if (p->xfn(p->xctx, d.scal2, NSCAL, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        return SSBA_OK;
+    }
     if (p->xfn) {
         if (p->xfn(p->xctx, d.xv, d.xv_count, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
         if (p->xfn(p->xctx, d.gmax_l, 1, 1)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
@@ -1022,6 +1116,7 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
     if (o->max_num_iterations < 0 || !(o->initial_trust_region_radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
     if (o->trust_region_strategy_type != 0 && o->trust_region_strategy_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->d.part && !p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
     if (o->trust_region_strategy_type == 1 && p->xfn) {
         set_error("DOGLEG is not available with landmark sharding yet (its norms need one more exchange point)");
         return SSBA_ERR_UNSUPPORTED;
@@ -1111,6 +1206,11 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
     const int term = S.terminated ? S.termination_type : SSBA_NO_CONVERGENCE;
     // the solution is usable unless the minimiser failed: write the lowest-cost iterate back
     if (term != SSBA_FAILURE) {
+        if (p->d.part) {   // every rank holds the poses of its own chain: gather them (sum of owner-masked copies)
+            launch_mask_unowned_poses(p->launcher, p->d, p->d.best_poses);
+            if (p->xfn(p->xctx, p->d.best_poses, (uint64_t)p->d.P * 12, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+            HIPCHECK(hipStreamSynchronize(st));
+        }
         rc = download_params(p, p->d.best_poses, p->d.best_pts, p->d.best_nrm, p->d.best_sh);
         if (rc) return rc;
     }
@@ -1228,6 +1328,7 @@ int ssba_kernel_times(ssba_problem *p, ssba_kernel_time *rows, int32_t capacity,
 // ---------------------------------------------------------------------------------
 static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    if (p->d.part) { set_error("test hooks are not available on a partitioned problem"); return SSBA_ERR_UNSUPPORTED; }
     if (p->began) return SSBA_ERR_STATE;
     HIPCHECK(hipSetDevice(p->device));
     ssba_options opt;

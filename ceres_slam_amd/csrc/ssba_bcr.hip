@@ -90,7 +90,7 @@ constexpr int FACT_LDS_DOUBLES = BD * LDA + BD * LDR;
 // each lane then owns one 6x6 tile of [D | L | U^T | r] in registers for the whole
 // factorisation; finished tiles go back to LDS (they are the operands of later updates and
 // the kernel's output), and one coalesced sweep writes G, YL, YU, yr.
-__global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int top) {
+__global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int top, int which) {
     State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     double *R = lds + BD * LDA;      // BD x LDR : [ L_i (72) | L_{i+1}^T (72) | r_i | pad ]
     __shared__ int sBad;
     __shared__ double sDiag[36];
-    const BcrLevel &L = d.lev[lev];
+    const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
     const int blk = top ? 0 : 2 * blockIdx.x + 1;
     const bool hasL = !top, hasU = !top && (blk + 1 < L.n);
     double *Dg = L.D + (size_t)blk * BD * BD;
@@ -335,20 +335,38 @@ __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const do
 
 // grid = (n_next, 2): y = 0 -> D' and r' ; y = 1 -> L'.  Both operand blocks are staged
 // into LDS up front (one global round trip), r' is computed from the staged copies.
-__global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev) {
+__global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int which) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sB = lds + BD * BD;
     __shared__ double sya[BD], syb[BD];
-    const BcrLevel &L = d.lev[lev];
-    const BcrLevel &N = d.lev[lev + 1];
+    const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
+    const BcrLevel &N = which ? d.slev[lev + 1] : d.lev[lev + 1];
     const int m = blockIdx.x, e = 2 * m;
     const int t = threadIdx.x;
+    if (L.pin && m == L.n / 2) {
+        // pinned end of a partitioned chain (old index n-1, odd): carried over unchanged as the new last block;
+        // its coupling to the new block before it is the old L[n-1] (no fill-in: old n-2 is its direct neighbour)
+        const int src = L.n - 1;
+        if (blockIdx.y == 0) {
+            stage_block(N.D + (size_t)m * BD * BD, L.D + (size_t)src * BD * BD, RED_THREADS);
+            if (t < BD) N.r[(size_t)m * BD + t] = L.r[(size_t)src * BD + t];
+        } else {
+            const double *sl = L.L + (size_t)src * BD * BD;    // odd index: stored untransposed
+            double *dl = N.L + (size_t)m * BD * BD;
+            const bool tr = (m & 1) == 0;                        // even-indexed couplings are stored transposed
+            for (int i = t; i < BD * BD; i += RED_THREADS) {
+                const int r = i / BD, c = i - r * BD;
+                dl[tr ? c * BD + r : i] = sl[i];
+            }
+        }
+        return;
+    }
     const bool act = t < KSPLIT * 144;
     const int g = t / 144, tt = t - g * 144;
     const int tr = tt / 12, tc = tt - tr * 12;
-    const bool hasPrev = e - 1 >= 0, hasNext = e + 1 < L.n;
+    const bool hasPrev = e - 1 >= 0, hasNext = e + 1 < L.n && !(L.pin && e + 1 == L.n - 1);   // a pinned end is not eliminated
     const int tp = (e - 2) / 2;     // YU slot of odd block e-1
     double acc[36];
 #pragma unroll
@@ -419,23 +437,24 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 // x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1}); x lives in d.x0 at level-0 block positions.
 // G, YL, YU are staged into LDS with one coalesced sweep.
 constexpr int BS_THREADS = 512;
-__global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int top) {
+__global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int top, int which) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
     __shared__ double sv[BD], sxm[BD], sxp[BD];
-    const BcrLevel &L = d.lev[lev];
+    const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
     const int blk = top ? 0 : 2 * blockIdx.x + 1;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool hasU = !top && (blk + 1 < L.n);
-    double *xi = d.x0 + ((size_t)blk << lev) * BD;
+    double *xb = which ? d.xsep : d.x0 + (size_t)d.chain0 * BD;     // solution at level-0 block positions
+    double *xi = xb + (size_t)L.pos[blk] * BD;
     stage_block(sG, L.D + (size_t)blk * BD * BD, BS_THREADS);
     if (!top) stage_block(sL, L.L + (size_t)blk * BD * BD, BS_THREADS);
     if (hasU) stage_block(sU, L.YU + (size_t)blockIdx.x * BD * BD, BS_THREADS);
     if (t < BD) {
-        sxm[t] = top ? 0.0 : d.x0[((size_t)(blk - 1) << lev) * BD + t];
-        sxp[t] = hasU ? d.x0[((size_t)(blk + 1) << lev) * BD + t] : 0.0;
+        sxm[t] = top ? 0.0 : xb[(size_t)L.pos[blk - 1] * BD + t];
+        sxp[t] = hasU ? xb[(size_t)L.pos[blk + 1] * BD + t] : 0.0;
         sv[t] = L.r[(size_t)blk * BD + t];
     }
     __syncthreads();
@@ -477,20 +496,53 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
     if (lane < BD - 64) xi[64 + lane] = hi;
 }
 
+// blocks eliminated at a level: all odd ones, except the pinned end of a partitioned chain
+static int n_odd(const BcrLevel &lv, bool pinned) { return pinned ? (lv.n - 1) / 2 : lv.n / 2; }
+
 void launch_bcr(Launcher &L, const Dev &d) {
     const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
     const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
-    for (int l = 0; l + 1 < nl; ++l) {
-        const int n = d.lev[l].n;
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), sh_factor, d, l, 0);
-        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l);
+    if (!d.part) {
+        for (int l = 0; l + 1 < nl; ++l) {
+            const int n = d.lev[l].n;
+            LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
+            LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
+        }
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), sh_factor, d, nl - 1, 1, 0);
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, nl - 1, 1, 0);
+        for (int l = nl - 2; l >= 0; --l)
+            LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
+        return;
     }
-    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), sh_factor, d, nl - 1, 1);
-    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, nl - 1, 1);
-    for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0);
+    // Partitioned solve, forward part: eliminate the interior of this rank's chain (both ends pinned) down to the
+    // two ends; launch_bcr_separators() continues after the separator exchange.
+    for (int l = 0; l + 1 < nl; ++l) {
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n_odd(d.lev[l], true)), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
+        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(d.lev[l + 1].n, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
+    }
+}
+
+// separator system (all ranks' chain ends, summed over ranks): plain BCR, replicated on every rank; then the
+// back-substitution of this rank's chain interior
+void launch_bcr_separators(Launcher &L, const Dev &d) {
+    const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
+    const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
+    const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
+    const int ns = d.ns_levels;
+    for (int l = 0; l + 1 < ns; ++l) {
+        const int n = d.slev[l].n;
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), sh_factor, d, l, 0, 1);
+        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l, 1);
+    }
+    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), sh_factor, d, ns - 1, 1, 1);
+    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, ns - 1, 1, 1);
+    for (int l = ns - 2; l >= 0; --l)
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.slev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 1);
+    launch_sep_scatter(L, d);       // x0 at this rank's two chain ends <- separator solution
+    for (int l = d.n_levels - 2; l >= 0; --l)
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n_odd(d.lev[l], true)), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
 }
 
 int configure_kernels() {

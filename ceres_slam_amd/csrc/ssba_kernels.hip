@@ -369,8 +369,9 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
             D0[(size_t)Ia * BD * BD + (size_t)row * BD + col] = v;
             if (fa != fb) D0[(size_t)Ia * BD * BD + (size_t)col * BD + row] = v;
         } else {   // Ib == Ia + 1: entry (row in block Ia, col in block Ib) = L[Ib]^T;
-                   // even-indexed coupling blocks are stored transposed (ssba_bcr.hip)
-            if (Ib & 1u) L0[(size_t)Ib * BD * BD + (size_t)col * BD + row] = v;
+                   // even-indexed coupling blocks are stored transposed (ssba_bcr.hip); in a partitioned
+                   // solve the index is the position in this rank's chain
+            if ((Ib - (uint32_t)d.chain0) & 1u) L0[(size_t)Ib * BD * BD + (size_t)col * BD + row] = v;
             else L0[(size_t)Ib * BD * BD + (size_t)row * BD + col] = v;
         }
     } else if (gid < n_el + (size_t)d.nfree * 6) {
@@ -400,6 +401,15 @@ __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
     const int f = i / 6, c = i - f * 6;
     const int I = f / SBP, row = (f - I * SBP) * 6 + c;
     double *Dd = d.xv + d.off_D + (size_t)I * BD * BD + (size_t)row * BD + row;
+    if (d.part) {
+        if (I < d.chain0 || I > d.chain1) return;
+        if (I == d.chain0 || I == d.chain1) {
+            // a chain end is a separator: other ranks contribute to it too, so it is damped after the exchange
+            // (k_sep_finish); only the sign convention rhs = -gradient is applied here
+            d.xv[d.off_rhs + i] = f < d.nfree ? -d.xv[d.off_rhs + i] : 0.0;
+            return;
+        }
+    }
     if (f < d.nfree) {
         const double h = d.xv[d.off_hdiag + i];
         if (st.iteration == 0) d.sp[i] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
@@ -431,13 +441,24 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
     double gm = 0.0, xn = 0.0, cost = 0.0;
     const bool lin = st.just_linearized != 0;
     if (lin) {
-        // landmark partials (already all-reduced in scal[] when sharded: see host)
-        for (int i = threadIdx.x; i < d.nfree; i += 256) {
+        // landmark partials (already all-reduced in scal[] when sharded: see host).  Partitioned solve: the
+        // interior poses of every rank went into those sums before the exchange (k_sep_pack); what is left
+        // are the separator poses, whose gradient is the sum over ranks held in the separator vector
+        const int npose = d.part ? d.n_sep * SBP : d.nfree;
+        for (int q = threadIdx.x; q < npose; q += 256) {
+            int i = q;
+            const double *gsrc = d.xv + d.off_gp + (size_t)q * 6;
+            if (d.part) {
+                const int s = q / SBP;
+                i = d.sep_sb[s] * SBP + (q - s * SBP);
+                if (i >= d.nfree) continue;
+                gsrc = d.sepv + d.soff_gp + (size_t)q * 6;
+            }
             const int k = d.free_pose[i];
             const double *T = d.poses + (size_t)k * 12;
             double ng[6], Tn[12];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) ng[c] = -d.xv[d.off_gp + (size_t)i * 6 + c];
+            for (int c = 0; c < 6; ++c) ng[c] = -gsrc[c];
             se3_plus(T, ng, Tn);    // projected gradient: |x - Plus(x, -g)|_inf
 #pragma unroll
             for (int c = 0; c < 12; ++c) {
@@ -451,7 +472,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
     (void)cost;
     if (threadIdx.x != 0) return;
     if (lin) {
-        double *sc = d.xv + d.off_scal;
+        double *sc = d.part ? d.sepv + d.soff_scal : d.xv + d.off_scal;
         st.x_cost = sc[0];
         double xnb = 0.0, gmb = 0.0;
         if (d.nb) {   // free shared blocks: |x_b|^2 and |x_b - Plus(x_b, -g_b)|_inf
@@ -556,11 +577,13 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
                 if (!isfinite(eps[c])) nonfinite = 1.0;
             }
             se3_plus(T, eps, Tn);
+            // partitioned solve: the separator poses are updated by both neighbouring ranks, counted once
+            const bool owned = !d.part || (f >= (d.rank == 0 ? d.chain0 : d.chain0 + 1) * SBP && f < (d.chain1 + 1) * SBP);
 #pragma unroll
             for (int c = 0; c < 12; ++c) {
                 C[c] = Tn[c];
                 const double df = Tn[c] - T[c];
-                dn += df * df;
+                if (owned) dn += df * df;
             }
         } else {
 #pragma unroll
@@ -1051,6 +1074,7 @@ __global__ __launch_bounds__(256) void k_decide(Dev d) {
     a = block_sum(a, sm);
     b = block_sum(b, sm);
     if (threadIdx.x != 0) return;
+    if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_eval_add_pose), summed over ranks
     const Options &o = st.opt;
     const double candidate_cost_raw = d.scal2[0];
     const double mcc = d.scal2[1];
@@ -1179,6 +1203,117 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.sub_e[0][0] = st.sub_e[0][1] = st.sub_e[1][0] = st.sub_e[1][1] = 0.0;
 }
 
+// ------------------------------------------------------------------ partitioned solve ---
+// One rank per contiguous chain of super-blocks (landmark sharding).  After the local
+// elimination of the chain interior (ssba_bcr.hip, pinned ends) the two end blocks hold this rank's share of
+// the separator system; k_sep_pack writes them, the ends' gradient / diag(H_pp) and the scalars of the
+// linearisation into the (zeroed) separator vector, which the ranks then sum.
+__global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    const BcrLevel &E = d.lev[d.n_levels - 1];       // two blocks: the chain ends
+    const int t = threadIdx.x, r = d.rank;
+    const size_t blk = (size_t)BD * BD;
+    if (blockIdx.x < 2) {
+        double *dst = d.sepv + d.soff_D + (size_t)(r + blockIdx.x) * blk;
+        const double *src = E.D + (size_t)blockIdx.x * blk;
+        for (int i = t; i < BD * BD; i += 256) dst[i] = src[i];
+    } else if (blockIdx.x == 2) {
+        // coupling of the two ends: local index 1 (odd, untransposed) -> separator index r+1 (even: transposed)
+        double *dst = d.sepv + d.soff_L + (size_t)(r + 1) * blk;
+        const double *src = E.L + blk;
+        const bool tr = ((r + 1) & 1) == 0;
+        for (int i = t; i < BD * BD; i += 256) {
+            const int row = i / BD, col = i - row * BD;
+            dst[tr ? col * BD + row : i] = src[i];
+        }
+    } else {
+        __shared__ double sm[4];
+        for (int e = 0; e < 2; ++e) {
+            const int sb = e ? d.chain1 : d.chain0;
+            if (t < BD) {
+                d.sepv[d.soff_rhs + (size_t)(r + e) * BD + t] = E.r[(size_t)e * BD + t];
+                d.sepv[d.soff_gp + (size_t)(r + e) * BD + t] = d.xv[d.off_gp + (size_t)sb * BD + t];
+                d.sepv[d.soff_hdiag + (size_t)(r + e) * BD + t] = d.xv[d.off_hdiag + (size_t)sb * BD + t];
+            }
+        }
+        // interior poses of this rank: projected gradient and |x|^2 join the landmark sums of the linearisation
+        double gm = 0.0, xn = 0.0;
+        if (st.just_linearized) {
+            for (int i = (d.chain0 + 1) * SBP + t; i < d.chain1 * SBP && i < d.nfree; i += 256) {
+                const int k = d.free_pose[i];
+                const double *T = d.poses + (size_t)k * 12;
+                double ng[6], Tn[12];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) ng[c] = -d.xv[d.off_gp + (size_t)i * 6 + c];
+                se3_plus(T, ng, Tn);
+#pragma unroll
+                for (int c = 0; c < 12; ++c) { gm = fmax(gm, fabs(T[c] - Tn[c])); xn += T[c] * T[c]; }
+            }
+        }
+        const double gmp = block_max(gm, sm), xnp = block_sum(xn, sm);
+        if (t == 0) {
+            double *sc = d.xv + d.off_scal, *ss = d.sepv + d.soff_scal;
+            if (st.just_linearized) {
+                ss[0] = sc[0]; ss[1] = sc[1] + xnp;
+                *d.gmax_l = fmax(*d.gmax_l, gmp);
+                sc[0] = 0.0; sc[1] = 0.0;
+            }
+        }
+    }
+}
+
+// after the exchange: Jacobi scale (iteration 0) and LM damping of the separator diagonals, identity rows for
+// the padding of the last super-block
+__global__ __launch_bounds__(256) void k_sep_finish(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.n_sep * BD) return;
+    const int s = q / BD, row = q - s * BD;
+    const int i = d.sep_sb[s] * BD + row, f = i / 6;
+    double *Dd = d.sepv + d.soff_D + (size_t)s * BD * BD + (size_t)row * BD + row;
+    if (f < d.nfree) {
+        const double h = d.sepv[d.soff_hdiag + q];
+        if (st.iteration == 0) d.sp[i] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+        const double sc = d.sp[i], s2 = sc * sc;
+        *Dd += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
+    } else {
+        *Dd = 1.0;
+        d.sepv[d.soff_rhs + q] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sep_scatter(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed) return;
+    const int t = threadIdx.x;
+    if (t < BD) d.x0[(size_t)d.chain0 * BD + t] = d.xsep[(size_t)d.rank * BD + t];
+    else if (t < 2 * BD) d.x0[(size_t)d.chain1 * BD + (t - BD)] = d.xsep[(size_t)(d.rank + 1) * BD + (t - BD)];
+}
+
+// pose part of |dx|^2 and of the non-finite flag (owned poses only) joins the landmark sums before the exchange
+__global__ __launch_bounds__(256) void k_eval_add_pose(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) { a += d.part_pose[i * 2]; b += d.part_pose[i * 2 + 1]; }
+    a = block_sum(a, sm);
+    b = block_sum(b, sm);
+    if (threadIdx.x == 0) { d.scal2[2] += a; d.scal2[3] += b; }
+}
+
+// zero the poses another rank owns, so that a sum over ranks gathers the solution
+__global__ __launch_bounds__(256) void k_mask_unowned_poses(Dev d, double *poses) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.P) return;
+    const int f = d.pose_free[k];
+    const bool owned = f < 0 ? d.rank == 0 : (f >= (d.rank == 0 ? d.chain0 : d.chain0 + 1) * SBP && f < (d.chain1 + 1) * SBP);
+    if (!owned)
+        for (int c = 0; c < 12; ++c) poses[(size_t)k * 12 + c] = 0.0;
+}
+
 // ----------------------------------------------------------------- launchers ---
 int configure_schur() {
     return hipFuncSetAttribute((const void *)k_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1202,9 +1337,18 @@ void launch_linearize(Launcher &L, const Dev &d) {
 void launch_schur(Launcher &L, const Dev &d) {
     if (d.phong) launch_ph_schur(L, d);
     else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d);
+    if (d.part) {   // only this rank's chain is assembled and eliminated
+        const size_t n = (size_t)(d.chain1 - d.chain0 + 1) * BD * BD * sizeof(double);
+        hipMemsetAsync(d.xv + d.off_D + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
+        hipMemsetAsync(d.xv + d.off_L + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
+    } else
     hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)d.nfree * 6;
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+}
+
+void launch_finish_local(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
 }
 
 void launch_finish_check(Launcher &L, const Dev &d) {
@@ -1220,6 +1364,27 @@ void launch_update_eval(Launcher &L, const Dev &d) {
     if (d.phong) launch_ph_backsub_eval(L, d);
     else LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
+}
+
+void launch_sep_pack(Launcher &L, const Dev &d) {
+    hipMemsetAsync(d.sepv, 0, (size_t)d.sepv_count * sizeof(double), L.stream);
+    LAUNCH(KC_SMALL, k_sep_pack, dim3(4), dim3(256), 0, d);
+}
+void launch_sep_finish_check(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
+    const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
+    LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+    hipLaunchKernelGGL(k_best_done, dim3(1), dim3(64), 0, L.stream, d);
+}
+void launch_sep_scatter(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_sep_scatter, dim3(1), dim3(256), 0, d);
+}
+void launch_eval_add_pose(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_eval_add_pose, dim3(1), dim3(256), 0, d);
+}
+void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses) {
+    LAUNCH(KC_SMALL, k_mask_unowned_poses, dim3((d.P + 255) / 256), dim3(256), 0, d, poses);
 }
 
 void launch_pose_update(Launcher &L, const Dev &d) {

@@ -96,6 +96,15 @@ void launch_linearize(Launcher &L, const Dev &d);
 void launch_schur(Launcher &L, const Dev &d);
 void launch_finish_check(Launcher &L, const Dev &d);
 void launch_bcr(Launcher &L, const Dev &d);
+// partitioned (multi-rank) solve: pack the chain ends into the separator exchange vector; after the exchange:
+// damping + convergence checks, separator BCR, scatter, back-substitution of the chain interior
+void launch_finish_local(Launcher &L, const Dev &d);
+void launch_sep_pack(Launcher &L, const Dev &d);
+void launch_sep_finish_check(Launcher &L, const Dev &d);
+void launch_bcr_separators(Launcher &L, const Dev &d);
+void launch_sep_scatter(Launcher &L, const Dev &d);
+void launch_eval_add_pose(Launcher &L, const Dev &d);
+void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
 void launch_update_eval(Launcher &L, const Dev &d);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
 void launch_decide_commit(Launcher &L, const Dev &d);

@@ -29,6 +29,8 @@ constexpr int BD = 6 * SBP;             // 72 rows per super-block
 constexpr int LMG = 64;                 // landmarks per ELL group (= wavefront)
 constexpr int SLAB_DOUBLES = NPAIR * 36 + TW * 6;   // per Schur work item
 constexpr int MAX_LEVELS = 24;
+constexpr int MAX_SLEVELS = 8;          // levels of the separator system of a partitioned (multi-rank) solve
+constexpr int MAX_SEP = 65;             // separators = ranks + 1
 constexpr int NSCAL = 16;
 constexpr int NBP = 32;                 // padded width of the border of free shared blocks (nb <= NBP)
 constexpr int NBQ = 7;                  // border entries one intensity row touches: [phong 3 | kd | light 3]
@@ -82,6 +84,9 @@ struct BcrLevel {
     double *D, *L, *r;  // n blocks each (L[0] unused)
     double *YU;       // n/2 blocks: G^-1 L[i+1]^T for odd i
     double *B;        // n x BD x NBP extra right-hand sides (border columns), or nullptr
+    int pin;          // chain with pinned ends (partitioned solve) and n even: the last block (odd index) is
+                      // NOT eliminated at this level but carried over as the last block of the next level
+    const int *pos;   // n: level-0 position of each block (i << level for a plain plan)
 };
 
 struct Dev {
@@ -123,6 +128,15 @@ struct Dev {
     double *part_dl;                 // dogleg partial sums: (n_lm_blocks + n_pose_blocks + 1 [border]) * NDL
     int n_levels;
     BcrLevel lev[MAX_LEVELS];
+    // partitioned solve (one rank per contiguous chain of super-blocks): this rank's chain is
+    // super-blocks [chain0, chain1] with both ends pinned; the ends of all ranks form the separator system
+    int part, rank, n_sep, chain0, chain1;
+    int sep_sb[MAX_SEP];             // separator s = super-block sep_sb[s]; rank r owns the chain [sep_sb[r], sep_sb[r+1]]
+    int ns_levels;
+    BcrLevel slev[MAX_SLEVELS];      // plain BCR plan of the separator system (n_sep blocks)
+    double *sepv;                    // [Dsep | Lsep | rhs | gp | hdiag | scal]: the (small) exchange vector
+    uint64_t soff_D, soff_L, soff_rhs, soff_gp, soff_hdiag, soff_scal, sepv_count;
+    double *xsep;                    // n_sep * BD separator solution
     // reductions
     double *part_lin;                // n_lm_blocks*4: cost, |x_pts|^2, max|g_l|, -
     double *part_eval;               // n_lm_blocks*4: cand cost, mcc, |dl|^2, nonfinite

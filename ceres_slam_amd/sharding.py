@@ -39,13 +39,60 @@ def landmark_ranges(obs_point: np.ndarray, num_points: int, world: int):
     return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
 
 
+def aligned_partition(obs_pose: np.ndarray, obs_point: np.ndarray, num_poses: int, num_points: int, world: int, pose_const=None,
+                      sbp: int = 12):
+    """Landmark ranges cut where the co-visibility band crosses a super-block boundary, for the partitioned
+    reduced solve (ssba_set_partition).  Landmarks must be ordered along the trajectory (as the reference's
+    datasets and synth.py are: by first observing state).  Returns (ranges, separator_superblocks) or None if no
+    such cut exists near the balanced one (the caller then uses the plain all-reduce path).
+
+    Free-pose index f = rank of the pose among the non-constant poses; super-block = f // sbp.  Rank r may only
+    touch super-blocks [sep[r], sep[r+1]] and neighbours share exactly the super-block sep[r+1]."""
+    if pose_const is None:
+        pose_const = np.zeros(num_poses, dtype=bool)
+        pose_const[0] = True
+    free_idx = np.full(num_poses, -1, dtype=np.int64)
+    free_idx[~np.asarray(pose_const, dtype=bool)] = np.arange(int((~np.asarray(pose_const, dtype=bool)).sum()))
+    nsb = max(1, (int(free_idx.max()) + 1 + sbp - 1) // sbp)
+    f = free_idx[obs_pose]
+    ok = f >= 0
+    lo = np.full(num_points, np.iinfo(np.int64).max, dtype=np.int64)
+    hi = np.full(num_points, -1, dtype=np.int64)
+    np.minimum.at(lo, obs_point[ok], f[ok] // sbp)
+    np.maximum.at(hi, obs_point[ok], f[ok] // sbp)
+    seen = hi >= 0
+    # running envelopes: a cut before landmark c is valid for separator s iff every landmark < c stays in
+    # super-blocks <= s and every landmark >= c stays in super-blocks >= s
+    hi_prefix = np.maximum.accumulate(np.where(seen, hi, -1))
+    lo_suffix = np.minimum.accumulate(np.where(seen, lo, np.iinfo(np.int64).max)[::-1])[::-1]
+    balanced = landmark_ranges(obs_point, num_points, world)
+    cuts, seps = [0], [0]
+    for r in range(1, world):
+        target = balanced[r][0]
+        best = None
+        for c in sorted(range(max(1, target - 4000), min(num_points, target + 4000)), key=lambda c: abs(c - target)):
+            s = hi_prefix[c - 1]
+            if s >= 0 and lo_suffix[c] >= s and s > seps[-1] and c > cuts[-1]:
+                best = (c, int(s))
+                break
+        if best is None:
+            return None
+        cuts.append(best[0])
+        seps.append(best[1])
+    cuts.append(num_points)
+    seps.append(nsb - 1)
+    if seps[-1] <= seps[-2]:
+        return None
+    return [(cuts[r], cuts[r + 1]) for r in range(world)], np.asarray(seps, dtype=np.uint32)
+
+
 def whole(prob) -> Shard:
     return Shard(prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
                  np.arange(prob.num_points), prob.poses_init.copy(), prob.points_init.copy())
 
 
-def shard_by_landmarks(prob, world: int, rank: int) -> Shard:
-    b, e = landmark_ranges(prob.obs_point, prob.num_points, world)[rank]
+def shard_by_landmarks(prob, world: int, rank: int, ranges=None) -> Shard:
+    b, e = (ranges or landmark_ranges(prob.obs_point, prob.num_points, world))[rank]
     sel = (prob.obs_point >= b) & (prob.obs_point < e)
     pts = prob.points_init[b:e].copy()
     return Shard(prob.poses_init.copy(), pts, prob.obs_pose[sel], (prob.obs_point[sel] - b).astype(np.uint32),

@@ -15,7 +15,8 @@ from . import capi
 class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
                  stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
-                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0, use_bounds: bool = False):
+                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0, use_bounds: bool = False,
+                 partition=None):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
         self.points = np.ascontiguousarray(points, dtype=np.float64)
@@ -48,6 +49,9 @@ class StereoBA:
             self._add_lighting(lighting)
         if world_size > 1:
             capi.check(self.lib.ssba_set_distributed(self.h, world_size, rank), "ssba_set_distributed")
+            if partition is not None:     # separator super-blocks of a super-block-aligned sharding (sharding.aligned_partition)
+                sep = np.ascontiguousarray(partition, dtype=np.uint32)
+                capi.check(self.lib.ssba_set_partition(self.h, sep.ctypes.data_as(capi._u32p), sep.shape[0]), "ssba_set_partition")
         if finalize:
             self.finalize()
 

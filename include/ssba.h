@@ -175,6 +175,18 @@ int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx);
  * every non-constant pose is then kept in the reduced system even if THIS rank holds no
  * observation of it, so that all ranks agree on the layout of the exchanged system. */
 int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
+/* Partitioned reduced solve (after ssba_set_distributed, before ssba_finalize).  The free poses are
+ * grouped into super-blocks of 12 (free-pose index / 12); separator_superblocks (world_size + 1 ascending
+ * entries, first = 0, last = the last super-block) says that rank r's landmarks only observe poses of the
+ * super-blocks [sep[r], sep[r+1]] -- i.e. the landmark ranges are cut where the co-visibility band crosses
+ * a super-block boundary, so that consecutive ranks share exactly one super-block.  Each rank then
+ * eliminates the interior of its own chain of the block-tridiagonal reduced camera system and only the
+ * chain ends (the separator system: (world_size + 1) blocks of 72 x 72) are summed over the ranks and
+ * solved everywhere -- ~1 MB per iteration instead of the whole reduced system, and no redundant solve of
+ * the other ranks' chains.  At the end of the solve the poses are gathered (one more exchange), so every
+ * rank returns the complete trajectory.  Without this call the ranks sum the whole reduced system and
+ * each solves all of it (works for any sharding).  num = 0 clears the partition. */
+int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, uint32_t num);
 /* number of doubles in the per-iteration reduced-system exchange */
 int ssba_exchange_size(ssba_problem *p, uint64_t *count);
 

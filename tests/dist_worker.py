@@ -23,8 +23,14 @@ def main():
     from ceres_slam_amd import sharding, synth
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    prob = synth.make_problem(16, 400, track_len=6, seed=21)
-    shard = sharding.shard_by_landmarks(prob, world, rank)
+    P, Lm, T = [int(v) for v in os.environ.get("SSBA_TEST_SIZE", "16,400,6").split(",")]
+    prob = synth.make_problem(P, Lm, track_len=T, seed=21)
+    partition = None
+    if mode == "gpu_part":      # super-block-aligned landmark ranges + partitioned reduced solve
+        ranges, partition = sharding.aligned_partition(prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
+        shard = sharding.shard_by_landmarks(prob, world, rank, ranges=ranges)
+    else:
+        shard = sharding.shard_by_landmarks(prob, world, rank)
     res = {"rank": rank, "num_local_obs": int(shard.obs_pose.shape[0]), "num_local_points": int(shard.points.shape[0])}
     if mode == "cpu":
         from oracle import oracle as orc     # checker as compute: this is a test of the host logic
@@ -42,13 +48,15 @@ def main():
         from ceres_slam_amd.solver import StereoBA
         torch.cuda.set_device(0)
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                      prob.stiffness(), device=0, world_size=world, rank=rank)
+                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition)
         ba.set_stream(torch.cuda.current_stream().cuda_stream)
         sharding.attach_torch_exchange(ba, dist)
         s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
         res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
                    final_cost=float(s.final_cost), initial_cost=float(s.initial_cost), cost=log["cost"].tolist(),
-                   poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist())
+                   poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist(),
+                   partition=None if partition is None else partition.tolist(), accept=log["step_is_successful"].tolist(),
+                   gmax=log["gradient_max_norm"].tolist(), step_norm=log["step_norm"].tolist())
     with open(f"{out}.{rank}.json", "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -22,12 +22,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(mode, out, world=2, timeout=300):
+def _run_ranks(mode, out, world=2, timeout=300, size=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+        if size:
+            env["SSBA_TEST_SIZE"] = ",".join(str(v) for v in size)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=timeout)[0].decode(errors="replace") for p in procs]
@@ -80,3 +82,43 @@ def test_two_rank_sharded_gpu_solve_matches_unsharded_oracle(tmp_path):
         assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-6          # poses replicated
         assert np.abs(np.array(r["points"]) - op.points[r["point_ids"]]).max() < 1e-5
     np.testing.assert_array_equal(res[0]["poses"], res[1]["poses"])          # ranks agree bit for bit
+
+
+def test_aligned_partition_cuts_at_superblock_boundaries():
+    for P, L, W in ((40, 1600, 2), (60, 2400, 3), (300, 12000, 4)):
+        prob = synth.make_problem(P, L)
+        ranges, seps = sharding.aligned_partition(prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, W)
+        assert ranges[0][0] == 0 and ranges[-1][1] == L and all(ranges[r][1] == ranges[r + 1][0] for r in range(W - 1))
+        assert seps[0] == 0 and seps[-1] == (P - 1 + 11) // 12 - 1 and np.all(np.diff(seps.astype(int)) >= 1)
+        f = prob.obs_pose.astype(int) - 1          # pose 0 is constant
+        for r, (b, e) in enumerate(ranges):
+            sel = (prob.obs_point >= b) & (prob.obs_point < e) & (f >= 0)
+            sb = f[sel] // 12
+            assert sb.min() >= seps[r] and sb.max() <= seps[r + 1]
+    # no aligned cut when every landmark is seen from everywhere
+    rng = np.random.default_rng(0)
+    op, ol = rng.integers(0, 60, 5000), rng.integers(0, 200, 5000)
+    assert sharding.aligned_partition(op, ol, 60, 200, 2) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,size", [(2, (40, 1600, 12)), (3, (100, 4000, 12)), (2, (300, 9000, 12)), (4, (300, 9000, 12))])
+def test_partitioned_gpu_solve_matches_unsharded_oracle(tmp_path, world, size):
+    """Partitioned reduced solve (ssba_set_partition): every rank eliminates its own chain of super-blocks with
+    pinned ends, only the separator system is summed over the ranks.  Same iterates as the unsharded solve."""
+    res = _run_ranks("gpu_part", str(tmp_path / "part"), world, size=size)
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21)
+    op = orc.OracleProblem.from_synth(prob)
+    s2, log2 = op.solve(orc.driver_options(num_threads=2))
+    for r in res:
+        assert r["termination"] == s2.termination_type == 0
+        assert r["accept"] == log2["step_is_successful"].tolist()
+        ok = np.asarray(log2["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log2["cost"][ok], rtol=1e-8)
+        np.testing.assert_allclose(r["gmax"], log2["gradient_max_norm"], rtol=1e-5)
+        np.testing.assert_allclose(r["step_norm"], log2["step_norm"], rtol=1e-5, atol=1e-12)
+        assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
+        assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6              # every rank has the whole trajectory
+        assert np.abs(np.asarray(r["points"]) - op.points[r["point_ids"]]).max() < 1e-5
+    assert res[0]["poses"] == res[1]["poses"]                                      # bit-identical across ranks
