@@ -162,17 +162,24 @@ def main():
         lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
         prob = synth.make_problem(P1 * world, L1 * world)
+    partition = None
     if world > 1:
-        shard = sharding.shard_by_landmarks(prob, world, rank)
+        # landmark ranges cut at super-block boundaries -> partitioned reduced solve (only the separator system is
+        # exchanged); SSBA_NO_PARTITION=1 or an unalignable problem falls back to summing the whole reduced system
+        cut = None if os.environ.get("SSBA_NO_PARTITION") == "1" else sharding.aligned_partition(
+            prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
+        if cut is not None:
+            shard = sharding.shard_by_landmarks(prob, world, rank, ranges=cut[0])
+            partition = cut[1]
+        else:
+            shard = sharding.shard_by_landmarks(prob, world, rank)
     else:
         shard = sharding.whole(prob)
     ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
                   prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting,
-                  shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds))
-    stream = torch.cuda.current_stream()
-    ba.set_stream(stream.cuda_stream)
+                  shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds), partition=partition)
     if world > 1:
-        sharding.attach_torch_exchange(ba, dist)
+        sharding.attach_torch_exchange(ba, dist)      # library kernels + collectives on one dedicated torch stream
     st = ba.stats()
     stats = {k: int(getattr(st, k)) for k, _ in capi.Stats._fields_}
 
@@ -275,6 +282,9 @@ def main():
                                       if phong else "reprojection-only LM (Ceres dataset_vo options)")
                                    + f", {world} shard(s)",
                        "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
+                       "reduced_solve": ("partitioned: chain elimination per rank + separator exchange" if partition is not None
+                                         else ("replicated after an all-reduce of the reduced system" if world > 1 else "single GPU")),
+                       "exchange_doubles_per_iteration": int(ba.exchange_size()) if world > 1 else 0,
                        "restart_period_iters": period, "joint_iters_per_sec": joint_ips,
                        "converged_final_cost": final_cost,
                        # one blocking ssba_solve from host buffers: upload + loop + write-back (PCIe-inclusive)

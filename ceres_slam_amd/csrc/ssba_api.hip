@@ -387,7 +387,7 @@ int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, u
 int ssba_exchange_size(ssba_problem *p, uint64_t *count) {
     if (!p || !count) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
-    *count = p->d.xv_count;
+    *count = p->d.part ? p->d.sepv_count : p->d.xv_count;
     return SSBA_OK;
 }
 

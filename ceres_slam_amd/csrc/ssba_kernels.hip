@@ -1284,12 +1284,15 @@ __global__ __launch_bounds__(256) void k_sep_finish(Dev d) {
     }
 }
 
+// The separator solution is known on every rank: all separator poses are updated everywhere (they enter the
+// convergence checks of every rank), the chain ends among them seed the back-substitution of the interior.
 __global__ __launch_bounds__(256) void k_sep_scatter(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed) return;
-    const int t = threadIdx.x;
-    if (t < BD) d.x0[(size_t)d.chain0 * BD + t] = d.xsep[(size_t)d.rank * BD + t];
-    else if (t < 2 * BD) d.x0[(size_t)d.chain1 * BD + (t - BD)] = d.xsep[(size_t)(d.rank + 1) * BD + (t - BD)];
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.n_sep * BD) return;
+    const int s = q / BD, row = q - s * BD;
+    d.x0[(size_t)d.sep_sb[s] * BD + row] = d.xsep[q];
 }
 
 // pose part of |dx|^2 and of the non-finite flag (owned poses only) joins the landmark sums before the exchange
@@ -1378,7 +1381,7 @@ void launch_sep_finish_check(Launcher &L, const Dev &d) {
     hipLaunchKernelGGL(k_best_done, dim3(1), dim3(64), 0, L.stream, d);
 }
 void launch_sep_scatter(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_sep_scatter, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_sep_scatter, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
 }
 void launch_eval_add_pose(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_eval_add_pose, dim3(1), dim3(256), 0, d);

@@ -107,11 +107,16 @@ class _DevArray:
 
 
 def attach_torch_exchange(ba, dist, group=None):
-    """Route the library's exchange points through torch.distributed (backend "nccl" = RCCL
-    over xGMI on ROCm; "gloo" works for tests).  The library must run on torch's current
-    stream (StereoBA.set_stream) so that the collective is ordered after the kernels that
-    fill the buffer."""
+    """Route the library's exchange points through torch.distributed (backend "nccl" = RCCL over xGMI on ROCm;
+    "gloo" works for tests).  Kernels and collectives must be ordered on ONE stream: a dedicated torch stream
+    is created, handed to the library (ssba_set_stream) and made current around every collective.  (The
+    legacy default stream cannot be used: its handle is NULL, which ssba_set_stream reads as "the library's
+    own non-blocking stream" -- the collectives would then race with the kernels that fill the buffers.)
+    Returns the stream; synchronise it (or call StereoBA.synchronize) before reading results."""
     import torch
+    stream = torch.cuda.Stream()
+    assert stream.cuda_stream != 0
+    ba.set_stream(stream.cuda_stream)
     cache = {}
 
     def exchange(ptr: int, count: int, op: int):
@@ -120,7 +125,9 @@ def attach_torch_exchange(ba, dist, group=None):
         if t is None:
             t = torch.as_tensor(_DevArray(ptr, count), device="cuda")
             cache[key] = t
-        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
+        with torch.cuda.stream(stream):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM, group=group)
 
     ba.set_exchange(exchange)
-    return exchange
+    ba._exchange_stream = stream
+    return stream

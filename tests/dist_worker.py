@@ -49,9 +49,8 @@ def main():
         torch.cuda.set_device(0)
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
                       prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition)
-        ba.set_stream(torch.cuda.current_stream().cuda_stream)
         sharding.attach_torch_exchange(ba, dist)
-        s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+        s, log = ba.solve(capi.default_options(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1))
         res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
                    final_cost=float(s.final_cost), initial_cost=float(s.initial_cost), cost=log["cost"].tolist(),
                    poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist(),
