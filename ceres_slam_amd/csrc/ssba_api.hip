@@ -85,6 +85,9 @@ struct ssba_problem {
     // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
+    // multi-rank: the kernel runs between the exchange points are captured as separate graphs
+    hipGraph_t seg_graph[3] = {nullptr, nullptr, nullptr};
+    hipGraphExec_t seg_exec[3] = {nullptr, nullptr, nullptr};
     bool use_graph = true;
     // solve bookkeeping
     bool began = false;
@@ -127,6 +130,10 @@ static int dzero(ssba_problem *p, T **out, size_t n) {
 static void drop_graph(ssba_problem *p) {
     if (p->gexec) { hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
     if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+    for (int i = 0; i < 3; ++i) {
+        if (p->seg_exec[i]) { hipGraphExecDestroy(p->seg_exec[i]); p->seg_exec[i] = nullptr; }
+        if (p->seg_graph[i]) { hipGraphDestroy(p->seg_graph[i]); p->seg_graph[i] = nullptr; }
+    }
 }
 
 static void free_device(ssba_problem *p) {
@@ -138,6 +145,23 @@ static void free_device(ssba_problem *p) {
     if (p->h_stage) { hipHostFree(p->h_stage); p->h_stage = nullptr; }
     if (p->h_ls) { hipHostFree(p->h_ls); p->h_ls = nullptr; }
     p->finalized = false;
+}
+
+// A run of kernels between two exchange points: captured once as a hipGraph and replayed (the multi-rank
+// path has ~60 launches per iteration; launched eagerly the host, not the GPU, would set the iteration time).
+template <class F>
+static int run_segment(ssba_problem *p, int idx, F body) {
+    hipStream_t s = p->launcher.stream;
+    if (!p->use_graph || p->launcher.timing || idx < 0) { body(); return SSBA_OK; }
+    if (!p->seg_exec[idx]) {
+        HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        body();
+        hipError_t e = hipStreamEndCapture(s, &p->seg_graph[idx]);
+        if (e != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+        HIPCHECK(hipGraphInstantiate(&p->seg_exec[idx], p->seg_graph[idx], nullptr, nullptr, 0));
+    }
+    HIPCHECK(hipGraphLaunch(p->seg_exec[idx], s));
+    return SSBA_OK;
 }
 
 extern "C" {
@@ -1005,7 +1029,7 @@ static int enqueue_front(ssba_problem *p);
 static int enqueue_kernels(ssba_problem *p) {
     int rc = enqueue_front(p);
     if (rc) return rc;
-    launch_decide_commit(p->launcher, p->d);
+    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
@@ -1055,36 +1079,36 @@ static int enqueue_constrained_iteration(ssba_problem *p) {
 static int enqueue_front(ssba_problem *p) {
     Dev &d = p->d;
     Launcher &L = p->launcher;
-    launch_linearize(L, d);
-    launch_schur(L, d);
+    int rc;
+    const bool multi = p->xfn != nullptr && !d.constrained;     // segments only matter (and are only valid) between exchanges
+    auto X = [&](void *buf, uint64_t n, int op) -> int {
+        if (p->xfn(p->xctx, buf, n, op)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        return SSBA_OK;
+    };
     if (d.part) {
         // partitioned reduced solve: eliminate this rank's chain interior, sum the chain ends (the separator
         // system: ~1 MB instead of the whole reduced system) over the ranks, solve it everywhere, back-substitute
         if (!p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
-        launch_finish_local(L, d);
-        launch_bcr(L, d);
-        launch_sep_pack(L, d);
-        if (p->xfn(p->xctx, d.sepv, d.sepv_count, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
-        if (p->xfn(p->xctx, d.gmax_l, 1, 1)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
-        launch_sep_finish_check(L, d);
-        launch_bcr_separators(L, d);
-        launch_update_eval(L, d);
-        launch_eval_add_pose(L, d);
-        if (p->xfn(p->xctx, d.scal2, NSCAL, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        if ((rc = run_segment(p, 0, [&] { launch_linearize(L, d); launch_schur(L, d); launch_finish_local(L, d); launch_bcr(L, d); launch_sep_pack(L, d); }))) return rc;
+        if ((rc = X(d.sepv, d.sepv_count, 0))) return rc;
+        if ((rc = X(d.gmax_l, 1, 1))) return rc;
+        if ((rc = run_segment(p, 1, [&] { launch_sep_finish_check(L, d); launch_bcr_separators(L, d); launch_update_eval(L, d); launch_eval_add_pose(L, d); }))) return rc;
+        if ((rc = X(d.scal2, NSCAL, 0))) return rc;
         return SSBA_OK;
     }
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d); launch_schur(L, d); }))) return rc;
     if (p->xfn) {
-        if (p->xfn(p->xctx, d.xv, d.xv_count, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
-        if (p->xfn(p->xctx, d.gmax_l, 1, 1)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        if ((rc = X(d.xv, d.xv_count, 0))) return rc;
+        if ((rc = X(d.gmax_l, 1, 1))) return rc;
     }
-    launch_finish_check(L, d);
-    launch_bcr(L, d);
-    if (d.nb) launch_border_solve(L, d);
-    if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
-    else launch_update_eval(L, d);
-    if (p->xfn) {
-        if (p->xfn(p->xctx, d.scal2, NSCAL, 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
-    }
+    if ((rc = run_segment(p, multi ? 1 : -1, [&] {
+            launch_finish_check(L, d);
+            launch_bcr(L, d);
+            if (d.nb) launch_border_solve(L, d);
+            if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
+            else launch_update_eval(L, d);
+        }))) return rc;
+    if (p->xfn && (rc = X(d.scal2, NSCAL, 0))) return rc;
     return SSBA_OK;
 }
 
@@ -1126,7 +1150,8 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         set_error("lighting terms: Huber loss and landmark sharding are not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
-    if (p->gexec && p->opt.trust_region_strategy_type != o->trust_region_strategy_type) drop_graph(p);   // other kernel sequence
+    if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
+        drop_graph(p);   // other kernel sequence
     HIPCHECK(hipSetDevice(p->device));
     p->opt = *o;
     p->ignore_convergence = ignore_convergence;
