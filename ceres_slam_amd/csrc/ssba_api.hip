@@ -1146,8 +1146,8 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         return SSBA_ERR_UNSUPPORTED;
     }
     if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
-    if (p->d.phong && (p->huber_a > 0.0 || p->xfn)) {
-        set_error("lighting terms: Huber loss and landmark sharding are not available yet");
+    if (p->d.phong && p->xfn) {
+        set_error("lighting terms: landmark sharding is not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
@@ -1359,8 +1359,8 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     ssba_options opt;
     if (o) opt = *o; else ssba_default_options(&opt);
     if (radius > 0.0) opt.initial_trust_region_radius = radius;
-    if (p->d.phong && (p->huber_a > 0.0 || p->xfn)) {
-        set_error("lighting terms: Huber loss and landmark sharding are not available yet");
+    if (p->d.phong && p->xfn) {
+        set_error("lighting terms: landmark sharding is not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     p->opt = opt;

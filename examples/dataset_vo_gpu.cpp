@@ -3,14 +3,17 @@
 // include/ceres_slam_amd/ceres_shim.hpp, i.e. the same calls the reference makes against
 // Ceres, executed by the MI355X back end.
 //
-// usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A]
+// usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A] [--window N]
 //   dataset.csv   reference format (src/ceres_slam/dataset_problem.cpp:16-83): row 1
 //                 "num_states,num_points", row 2 intrinsics "fu,fv,cu,cv,b", row 3 variances,
 //                 row 4 first pose (4x4 row-major), then "k,j,u,v,d" rows
 //   init_*.csv    initial guess in the format the reference's write_csv emits
 //                 (dataset_problem.cpp:144-159): header + 4x4 row-major poses; "id,x,y,z" points
 // The front end that produces the initial guess (compute_initial_guess: matching + RANSAC)
-// is SURVEY.md section 8(f) row N2 and not part of this path.
+// is SURVEY.md section 8(f) row N2 and not part of this path.  --window N runs the reference's sliding
+// window loop (tests/dataset_vo.cpp:121-127): states [k1, k1+N) per solve, first state of the window
+// constant, poses carried over, points reset between windows (reset_points) to the supplied guess
+// (the reference re-triangulates them in compute_initial_guess(k1, k2)).
 // Output: <dataset>_poses.csv / <dataset>_map.csv at full precision + the brief report.
 #include <cmath>
 #include <fstream>
@@ -31,12 +34,15 @@ static std::vector<double> parse_row(const std::string &line) {
 
 int main(int argc, char **argv) {
     if (argc < 4) {
-        std::cerr << "usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A]" << std::endl;
+        std::cerr << "usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A] [--window N]" << std::endl;
         return EXIT_FAILURE;
     }
     double huber = 0.0;
-    for (int a = 4; a + 1 < argc; ++a)
+    size_t window_size = 0;
+    for (int a = 4; a + 1 < argc; ++a) {
         if (std::string(argv[a]) == "--huber") huber = std::atof(argv[a + 1]);
+        if (std::string(argv[a]) == "--window") window_size = (size_t)std::atoi(argv[a + 1]);
+    }
     std::ifstream f(argv[1]);
     if (!f.is_open()) { std::cerr << "Error: couldn't open " << argv[1] << std::endl; return EXIT_FAILURE; }
     std::string line;
@@ -79,6 +85,12 @@ int main(int argc, char **argv) {
         }
     }
 
+    if (window_size == 0 || window_size > num_states) window_size = num_states;     // 0 = full batch (:117-119)
+    const std::vector<double> points_init(points);
+    ceres::Solver::Summary summary;
+    for (size_t k1 = 0; k1 + window_size <= num_states; ++k1) {                     // :121-127
+    const size_t k2 = k1 + window_size;
+    if (k1 > 0) points = points_init;                                               // reset_points()
     // ---- solveWindow (tests/dataset_vo.cpp:22-85) ------------------------------------------
     ceres::Problem problem;
     const double stiffness[9] = {1.0 / std::sqrt(var[0]), 0, 0, 0, 1.0 / std::sqrt(var[1]), 0, 0, 0, 1.0 / std::sqrt(var[2])};
@@ -87,14 +99,14 @@ int main(int argc, char **argv) {
     std::vector<bool> pose_used(num_states, false);
     for (size_t i = 0; i < state_ids.size(); ++i) {
         const unsigned k = state_ids[i], j = point_ids[i];
-        if (k >= num_states || j >= num_points || !initialized[j]) continue;   // only initialised map points
+        if (k < k1 || k >= k2 || j >= num_points || !initialized[j]) continue;    // states of the window, initialised map points
         ceres::CostFunction *stereo_cost = ceres_slam::StereoReprojectionErrorAutomatic::Create(camera, &obs[3 * i], stiffness);
         problem.AddResidualBlock(stereo_cost, huber > 0 ? new ceres::HuberLoss(huber) : NULL, &poses[12 * k], &points[3 * j]);
         pose_used[k] = true;
     }
     for (size_t k = 0; k < num_states; ++k)
         if (pose_used[k]) problem.SetParameterization(&poses[12 * k], se3_perturbation);
-    problem.SetParameterBlockConstant(&poses[0]);
+    problem.SetParameterBlockConstant(&poses[12 * k1]);                            // :62
 
     ceres::Solver::Options solver_options;
     solver_options.minimizer_progress_to_stdout = false;
@@ -102,10 +114,11 @@ int main(int argc, char **argv) {
     solver_options.num_linear_solver_threads = 8;
     solver_options.max_num_iterations = 1000;
     solver_options.use_nonmonotonic_steps = true;
-    ceres::Solver::Summary summary;
     ceres::Solve(solver_options, &problem, &summary);
     std::cout << summary.BriefReport() << std::endl << std::endl;
     if (!summary.message.empty()) std::cerr << summary.message << std::endl;
+    if (!summary.IsSolutionUsable()) break;
+    }   // windows
 
     // ---- write_csv (dataset_problem.cpp:121-165), full precision ----------------------------
     std::string base(argv[1]);

@@ -259,8 +259,9 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
  *                             a projected Armijo line search (host-driven, one synchronisation per
  *                             evaluation; such solves are not captured in a hipGraph).
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
- * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  Not available together with lighting
- * terms yet (SSBA_ERR_UNSUPPORTED): Huber loss, landmark sharding. */
+ * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  ssba_set_huber_loss keeps its meaning
+ * (the loss sits on the stereo residual blocks; lighting blocks take a NULL loss, :113,186).  Not
+ * available together with lighting terms yet (SSBA_ERR_UNSUPPORTED): landmark sharding. */
 #define SSBA_MAX_MATERIALS 7
 enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };
 int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);

@@ -201,6 +201,33 @@ def test_cpp_driver_through_ceres_shim_matches_oracle(tmp_path):
     assert np.abs(poses - op.poses).max() < 1e-6
 
 
+def test_cpp_driver_sliding_windows(tmp_path):
+    """--window N: the reference's loop over windows of N states (tests/dataset_vo.cpp:121-127), one
+    problem per window through the shim; the oracle runs the same sequence of sub-problems."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples()
+    prob = synth.make_problem(14, 180, track_len=5, seed=4)
+    W = 6
+    ds, ip, im = synth.write_reference_csv(prob, str(tmp_path / "sim.csv"))
+    r = subprocess.run([exe, ds, ip, im, "--window", str(W)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    reports = [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")]
+    assert len(reports) == prob.num_poses - W + 1
+    poses = prob.poses_init.copy()
+    for k1 in range(prob.num_poses - W + 1):
+        sel = (prob.obs_pose >= k1) & (prob.obs_pose < k1 + W)
+        const = np.zeros(prob.num_poses, dtype=np.uint8)
+        const[k1] = 1
+        op = orc.OracleProblem(prob.camera, poses, prob.points_init, prob.obs_pose[sel], prob.obs_point[sel], prob.obs_uvd[sel],
+                               prob.stiffness(), pose_const=const)
+        s2, _ = op.solve(orc.driver_options(num_threads=2))
+        assert ("Iterations: %d," % s2.num_iterations) in reports[k1], (k1, reports[k1], s2.num_iterations)
+        poses = op.poses.copy()
+    out = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(out - poses).max() < 1e-6
+
+
 @pytest.mark.parametrize("light_type", [0, 1])
 def test_phong_rows_match_oracle(light_type):
     """intensity (point / directional light) and normal residual blocks with

@@ -243,11 +243,27 @@ def test_config1_phong_driver_through_the_ceres_shim(tmp_path, light_type):
     np.testing.assert_allclose(lights, op.light, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shared_free", [0, 7])
+def test_phong_with_huber_loss_on_the_stereo_blocks(shared_free):
+    """BASELINE config 5 shape (30 % outlier observations, Huber a = 1.345) on the config-3 graph: the loss
+    sits on the stereo residual blocks only, the lighting blocks keep their NULL loss."""
+    prob, ph = synth.make_phong_problem(50, 2000, outlier_fraction=0.3)
+    d = ph.as_oracle_dict("perturbed" if shared_free else "truth")
+    ba = StereoBA.from_synth(prob, lighting=d, shared_free=shared_free, huber_a=1.345)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=shared_free, huber_a=1.345)
+    S, rhs, dp, dl, mcc = ba.lm_step(1e4)
+    dp2, dl2, mcc2 = op.lm_step(1e4)
+    assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7 and mcc == pytest.approx(mcc2, rel=1e-8)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4))
+    n = min(len(log["cost"]), len(log2["cost"]), 10)
+    np.testing.assert_allclose(log["cost"][:n], log2["cost"][:n], rtol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)
+
+
 def test_phong_unsupported_combinations_fail_loudly():
     prob, ph = synth.make_phong_problem(8, 60, track_len=5, seed=7)
-    ba2 = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict(), huber_a=1.0)
-    with pytest.raises(capi.SsbaError):
-        ba2.solve(capi.default_options())
     # lighting observations must pair with the stereo observations
     d = ph.as_oracle_dict()
     d["intensity"] = d["intensity"][:-1]
