@@ -613,7 +613,12 @@ __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
     if (mask && !st.step_failed) {
         const uint32_t win = d.lm_win[l];
         const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
-        double tt[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
+        const double gl[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
+        double tt[3] = {gl[0], gl[1], gl[2]};
+        // With e = J_p delta_p of an observation the model cost change -(J d)^T (r + J d / 2) of this landmark's
+        // observations is  -(sum e.r + dl.g_l) - (sum e.e + 2 dl.(tt - g_l) + dl^T H_ll dl) / 2 :
+        // one linearisation pass instead of two (H_ll and g_l are those of this linearisation point)
+        double er = 0.0, ee = 0.0;
         for (int s = 0; s < TW; ++s) {
             if (!((mask >> s) & 1u)) continue;
             const uint32_t k = d.win_pose[win * TW + s];
@@ -631,6 +636,8 @@ __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
                 jd[i] = 0.0;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
+                er += jd[i] * o.r[i];
+                ee += jd[i] * jd[i];
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) tt[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
@@ -650,30 +657,18 @@ __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
         if (!isfinite(dl[0]) || !isfinite(dl[1]) || !isfinite(dl[2])) nonfinite = 1.0;
         nx = px + dl[0]; ny = py + dl[1]; nz = pz + dl[2];
         dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
+        {
+            const double hd0 = h[0] * dl[0] + h[1] * dl[1] + h[2] * dl[2], hd1 = h[1] * dl[0] + h[3] * dl[1] + h[4] * dl[2],
+                         hd2 = h[2] * dl[0] + h[4] * dl[1] + h[5] * dl[2];
+            const double dg = dl[0] * gl[0] + dl[1] * gl[1] + dl[2] * gl[2];
+            const double dt = dl[0] * (tt[0] - gl[0]) + dl[1] * (tt[1] - gl[1]) + dl[2] * (tt[2] - gl[2]);
+            mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + (dl[0] * hd0 + dl[1] * hd1 + dl[2] * hd2));
+        }
         for (int s = 0; s < TW; ++s) {
             if (!((mask >> s) & 1u)) continue;
             const uint32_t k = d.win_pose[win * TW + s];
-            const int f = d.pose_free[k];
-            const double *T = d.poses + (size_t)k * 12;
-            const double u = d.ou[obase + s * LMG], v = d.ov[obase + s * LMG], dd = d.od[obase + s * LMG];
-            ObsLin o;
-            obs_linearize(d, T, px, py, pz, u, v, dd, o);
-            double Jl[9], jd[3];
-            jac_point(o, T, Jl);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) jd[i] = Jl[3 * i] * dl[0] + Jl[3 * i + 1] * dl[1] + Jl[3 * i + 2] * dl[2];
-            if (f >= 0) {
-                double Jp[18];
-                jac_pose(o, Jp);
-                const double *dp = d.x0 + (size_t)f * 6;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) mcc -= jd[i] * (o.r[i] + 0.5 * jd[i]);
-            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, u, v, dd);
+            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, d.ou[obase + s * LMG], d.ov[obase + s * LMG],
+                              d.od[obase + s * LMG]);
         }
     }
     d.cand_pts[l] = nx;

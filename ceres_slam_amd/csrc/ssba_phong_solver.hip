@@ -464,41 +464,45 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
     if (mask && !st.step_failed) {
         const uint32_t win = d.lm_win[l];
         const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
-        double tt[6];
+        double gl[6], tt[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) tt[c] = d.gl[(size_t)c * d.Lpad + l];
+        for (int c = 0; c < 6; ++c) { gl[c] = d.gl[(size_t)c * d.Lpad + l]; tt[c] = gl[c]; }
+        double dbq[NBQ];   // border step seen by this landmark's material
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) {
+            const int c = d.nb ? bcol(d, x.mat, q) : -1;
+            dbq[q] = c >= 0 ? d.bsys[BS_DB + c] : 0.0;
+        }
+        // e = J_p delta_p + J_b delta_b of an observation row; tt = g_l + sum J_l^T e, and the model cost change
+        // -(J d)^T (r + J d / 2) of this landmark's rows is
+        //   -(sum e.r + dl.g_l) - (sum e.e + 2 dl.(tt - g_l) + dl^T H_ll dl) / 2 :  one linearisation pass
+        double er = 0.0, ee = 0.0;
         for (int s = 0; s < TW; ++s) {
             if (!((mask >> s) & 1u)) continue;
             const uint32_t k = d.win_pose[win * TW + s];
             const int f = d.pose_free[k];
-            if (f < 0) continue;
+            if (f < 0 && !d.nb) continue;
             const size_t oi = obase + (size_t)s * LMG;
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
-            const double *dp = d.x0 + (size_t)f * 6;
+            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
-                double jd = 0.0;
+                double e = 0.0;
+                if (f >= 0) {
+                    const double *dp = d.x0 + (size_t)f * 6;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) jd += o.Jp[6 * m + c] * dp[c];
+                    for (int c = 0; c < 6; ++c) e += o.Jp[6 * m + c] * dp[c];
+                }
+                if (m == 3) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) tt[c] += o.Jl[6 * m + c] * jd;
+                    for (int q = 0; q < NBQ; ++q) e += o.jb[q] * dbq[q];
+                }
+                er += e * o.r[m];
+                ee += e * e;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) tt[c] += o.Jl[6 * m + c] * e;
             }
-        }
-        double dbq[NBQ];   // border step seen by this landmark's material
-#pragma unroll
-        for (int q = 0; q < NBQ; ++q) dbq[q] = 0.0;
-        if (d.nb) {
-#pragma unroll
-            for (int q = 0; q < NBQ; ++q) {
-                const int c = bcol(d, x.mat, q);
-                dbq[q] = c >= 0 ? d.bsys[BS_DB + c] : 0.0;
-            }
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int q = 0; q < NBQ; ++q) tt[a] += d.lmV[(size_t)(a * NBQ + q) * d.Lpad + l] * dbq[q];
         }
         double Ci[21];
 #pragma unroll
@@ -513,6 +517,19 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
 #pragma unroll
         for (int a = 0; a < 6; ++a)
             if (!isfinite(dl[a])) nonfinite = 1.0;
+        {
+            double dg = 0.0, dt = 0.0, dhd = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                dg += dl[a] * gl[a];
+                dt += dl[a] * (tt[a] - gl[a]);
+                double hd = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) hd += d.hll[(size_t)(q <= a ? tri6(q, a) : tri6(a, q)) * d.Lpad + l] * dl[q];
+                dhd += dl[a] * hd;
+            }
+            mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + dhd);
+        }
         np_[0] = x.p[0] + dl[0]; np_[1] = x.p[1] + dl[1]; np_[2] = x.p[2] + dl[2];
         unit_plus(x.n, dl + 3, nn);
         dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
@@ -520,29 +537,9 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
         for (int s = 0; s < TW; ++s) {
             if (!((mask >> s) & 1u)) continue;
             const uint32_t k = d.win_pose[win * TW + s];
-            const int f = d.pose_free[k];
             const size_t oi = obase + (size_t)s * LMG;
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
-            ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
-#pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                double jd = 0.0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) jd += o.Jl[6 * m + c] * dl[c];
-                if (f >= 0) {
-                    const double *dp = d.x0 + (size_t)f * 6;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) jd += o.Jp[6 * m + c] * dp[c];
-                }
-                if (m == 3) {
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) jd += o.jb[q] * dbq[q];
-                }
-                mcc -= jd * (o.r[m] + 0.5 * jd);
-            }
-            ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, u, v, dd, inten, nobs);
+            ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs);
         }
     }
 #pragma unroll
