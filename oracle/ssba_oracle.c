@@ -2129,3 +2129,184 @@ void orc_normal_residual(const double T[12], const double n[3], const double n_o
             for (int j = 0; j < 3; ++j) Jn[3 * i + j] = SR[3 * i] * P[j] + SR[3 * i + 1] * P[3 + j] + SR[3 * i + 2] * P[6 + j];
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Front end: VO initial guess                        */
+/* ------------------------------------------------------------------------ */
+/* std::mt19937 (the generator of point_cloud_aligner.cpp:71-73, seeded with 42) */
+void orc_mt19937_seed(orc_mt19937 *g, uint32_t seed) {
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+}
+uint32_t orc_mt19937_next(orc_mt19937 *g) {
+    if (g->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            const uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+            g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        g->idx = 0;
+    }
+    uint32_t y = g->mt[g->idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+/* std::uniform_int_distribution<unsigned>(0, n - 1)(rng) -- implementation-defined by the C++ standard; the two
+ * libstdc++ algorithms are restated: variant 1 = GCC >= 11 (Lemire's nearly divisionless method on the 32-bit
+ * generator, bits/uniform_int_dist.h _S_nd), variant 0 = GCC <= 10 (scaling + rejection). */
+uint32_t orc_uniform_uint(orc_mt19937 *g, uint32_t n, int variant) {
+    if (variant == 1) {
+        uint64_t product = (uint64_t)orc_mt19937_next(g) * (uint64_t)n;
+        uint32_t low = (uint32_t)product;
+        if (low < n) {
+            const uint32_t threshold = (uint32_t)(-n) % n;
+            while (low < threshold) {
+                product = (uint64_t)orc_mt19937_next(g) * (uint64_t)n;
+                low = (uint32_t)product;
+            }
+        }
+        return (uint32_t)(product >> 32);
+    }
+    const uint64_t urngrange = 0xFFFFFFFFull, uerange = (uint64_t)n;
+    const uint64_t scaling = urngrange / uerange, past = uerange * scaling;
+    uint64_t ret;
+    do ret = orc_mt19937_next(g); while (ret >= past);
+    return (uint32_t)(ret / scaling);
+}
+
+/* 3 unique indices per RANSAC iteration (point_cloud_aligner.cpp:82-91); the generator is re-seeded with 42 in
+ * every call of compute_transformation_and_inliers (:71-73) */
+void orc_ransac_samples(uint32_t n, uint32_t num_iters, int variant, uint32_t *idx3) {
+    orc_mt19937 g;
+    orc_mt19937_seed(&g, 42u);
+    for (uint32_t it = 0; it < num_iters; ++it) {
+        uint32_t a = orc_uniform_uint(&g, n, variant), b, c;
+        b = orc_uniform_uint(&g, n, variant);
+        while (b == a) b = orc_uniform_uint(&g, n, variant);
+        c = orc_uniform_uint(&g, n, variant);
+        while (c == a || c == b) c = orc_uniform_uint(&g, n, variant);
+        idx3[3 * it] = a; idx3[3 * it + 1] = b; idx3[3 * it + 2] = c;
+    }
+}
+
+/* symmetric 3x3 eigen-decomposition by cyclic Jacobi rotations: A = V diag(w) V^T, eigenvalues descending */
+static void jacobi_eig3(const double A[9], double w[3], double V[9]) {
+    double a[9];
+    memcpy(a, A, sizeof a);
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = a[3 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {        /* A <- A J */
+                    const double akp = a[3 * k + p], akq = a[3 * k + q];
+                    a[3 * k + p] = c * akp - s * akq; a[3 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {        /* A <- J^T A */
+                    const double apk = a[3 * p + k], aqk = a[3 * q + k];
+                    a[3 * p + k] = c * apk - s * aqk; a[3 * q + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                    V[3 * k + p] = c * vkp - s * vkq; V[3 * k + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int ord[3] = {0, 1, 2};
+    double d[3] = {a[0], a[4], a[8]};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (d[ord[j]] > d[ord[i]]) { int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+    double Vs[9];
+    for (int c = 0; c < 3; ++c) { w[c] = d[ord[c]]; for (int r = 0; r < 3; ++r) Vs[3 * r + c] = V[3 * r + ord[c]]; }
+    memcpy(V, Vs, sizeof Vs);
+}
+
+static void cross3(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+/* PointCloudAligner::compute_transformation (point_cloud_aligner.cpp:12-62): centroids, W_1_0 = mean of
+ * (p1 - c1)(p0 - c0)^T, C_1_0 = U diag(1, 1, det U det V) V^T from the SVD of W, r = c1 - C c0.  For the
+ * 3-point samples of the RANSAC loop W has rank <= 2; the product is then fixed by the two leading singular
+ * pairs: C = u1 v1^T + u2 v2^T + (u1 x u2)(v1 x v2)^T, whatever signs / third vectors an SVD routine returns.
+ * Full-rank W (n > 3) goes through the same formula with the det correction.  T = [t | R row-major]. */
+void orc_align_points(const double *pts0, const double *pts1, int n, double T[12]) {
+    double c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) { c0[c] += pts0[3 * i + c]; c1[c] += pts1[3 * i + c]; }
+    for (int c = 0; c < 3; ++c) { c0[c] /= (double)n; c1[c] /= (double)n; }
+    double W[9] = {0};
+    for (int i = 0; i < n; ++i)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) W[3 * r + c] += (pts1[3 * i + r] - c1[r]) * (pts0[3 * i + c] - c0[c]);
+    for (int i = 0; i < 9; ++i) W[i] /= (double)n;
+    double WtW[9], w[3], V[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double v = 0.0;
+            for (int k = 0; k < 3; ++k) v += W[3 * k + r] * W[3 * k + c];
+            WtW[3 * r + c] = v;
+        }
+    jacobi_eig3(WtW, w, V);
+    double v1[3] = {V[0], V[3], V[6]}, v2[3] = {V[1], V[4], V[7]}, v3[3], u1[3], u2[3], u3[3];
+    for (int r = 0; r < 3; ++r) {
+        u1[r] = W[3 * r] * v1[0] + W[3 * r + 1] * v1[1] + W[3 * r + 2] * v1[2];
+        u2[r] = W[3 * r] * v2[0] + W[3 * r + 1] * v2[1] + W[3 * r + 2] * v2[2];
+    }
+    double n1 = sqrt(dot3(u1, u1)), n2;
+    for (int r = 0; r < 3; ++r) u1[r] /= n1;
+    /* re-orthogonalise u2 against u1 (it is orthogonal in exact arithmetic) */
+    const double d12 = dot3(u1, u2);
+    for (int r = 0; r < 3; ++r) u2[r] -= d12 * u1[r];
+    n2 = sqrt(dot3(u2, u2));
+    for (int r = 0; r < 3; ++r) u2[r] /= n2;
+    /* third pair: with V = [v1 v2 v1 x v2] (det +1) and U = [u1 u2 +-(u1 x u2)] the product
+     * diag(1, 1, det U det V) maps the third term to (u1 x u2)(v1 x v2)^T whatever the sign */
+    cross3(v1, v2, v3);
+    cross3(u1, u2, u3);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[3 + 3 * r + c] = u1[r] * v1[c] + u2[r] * v2[c] + u3[r] * v3[c];
+    for (int r = 0; r < 3; ++r) T[r] = c1[r] - (T[3 + 3 * r] * c0[0] + T[4 + 3 * r] * c0[1] + T[5 + 3 * r] * c0[2]);
+}
+
+/* PointCloudAligner::compute_transformation_and_inliers (point_cloud_aligner.cpp:64-136) with the sample
+ * indices given (orc_ransac_samples): returns the number of inliers of the best hypothesis (first maximum),
+ * its transformation and the inlier flags. */
+int orc_ransac_align(const orc_camera *cam, const double *pts0, const double *pts1, int n, const uint32_t *idx3,
+                     int num_iters, double thresh, double T_best[12], uint8_t *inlier) {
+    int best = 0;   /* best_inlier_idx starts empty: a hypothesis needs more than 0 inliers to be taken */
+    memset(T_best, 0, 12 * sizeof(double));
+    T_best[3] = T_best[7] = T_best[11] = 1.0;     /* default-constructed SE3: identity */
+    if (inlier) memset(inlier, 0, (size_t)n);
+    uint8_t *cur = malloc((size_t)(n > 0 ? n : 1));
+    for (int it = 0; it < num_iters; ++it) {
+        double s0[9], s1[9], T[12];
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) { s0[3 * k + c] = pts0[3 * idx3[3 * it + k] + c]; s1[3 * k + c] = pts1[3 * idx3[3 * it + k] + c]; }
+        orc_align_points(s0, s1, 3, T);
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            double q[3], a[3], b[3];
+            orc_se3_transform(T, pts0 + 3 * i, q);
+            orc_project(cam, pts1 + 3 * i, a, NULL);
+            orc_project(cam, q, b, NULL);
+            const double e = (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]);
+            cur[i] = e < thresh;
+            cnt += cur[i];
+        }
+        if (cnt > best) {
+            best = cnt;
+            memcpy(T_best, T, sizeof T);
+            if (inlier) memcpy(inlier, cur, (size_t)n);
+        }
+    }
+    free(cur);
+    return best;
+}

@@ -202,6 +202,19 @@ void orc_intensity_residual(int light_type, const double T[12], const double p[3
 void orc_normal_residual(const double T[12], const double n[3], const double n_obs[3],
                          const double S[9], double r[3], double *Jpose, double *Jn);
 
+/* ---- front end: VO initial guess ------------------------------
+ * src/ceres_slam/point_cloud_aligner.cpp: 3-point RANSAC (400 iterations, std::mt19937 seeded with 42 in
+ * every call, std::uniform_int_distribution) over Horn / SVD alignment, inliers by stereo reprojection error. */
+typedef struct { uint32_t mt[624]; int idx; } orc_mt19937;
+void orc_mt19937_seed(orc_mt19937 *g, uint32_t seed);
+uint32_t orc_mt19937_next(orc_mt19937 *g);
+/* std::uniform_int_distribution<unsigned>(0, n-1): variant 1 = libstdc++ >= 11, 0 = libstdc++ <= 10 */
+uint32_t orc_uniform_uint(orc_mt19937 *g, uint32_t n, int variant);
+void orc_ransac_samples(uint32_t n, uint32_t num_iters, int variant, uint32_t *idx3);
+void orc_align_points(const double *pts0, const double *pts1, int n, double T[12]);
+int orc_ransac_align(const orc_camera *cam, const double *pts0, const double *pts1, int n, const uint32_t *idx3,
+                     int num_iters, double thresh, double T_best[12], uint8_t *inlier);
+
 #ifdef __cplusplus
 }
 #endif
