@@ -302,6 +302,25 @@ int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *po
                         double *r_int, double *J_int, double *r_nrm, double *J_nrm_pose,
                         double *J_nrm_n);
 
+/* ---- front end: the VO initial guess --------------------------------- */
+/* ssba_frontend_ransac replaces, for `num_pairs` pairs of consecutive states at once,
+ *   PointCloudAligner::compute_transformation_and_inliers (src/ceres_slam/point_cloud_aligner.cpp:64-136)
+ * as compute_initial_guess calls it (src/ceres_slam/dataset_problem.cpp:246-249: 400 iterations, threshold 4;
+ * dataset_problem_phong.cpp:346-348: threshold 9).  Pair p owns the matched points
+ * [offset[p], offset[p+1]) of pts0 / pts1 (camera-frame points from StereoCamera::triangulate, 3 doubles each,
+ * paired by position as the reference pairs them); samples = num_pairs * num_iters * 3 indices local to the
+ * pair; thresh bounds the squared stereo reprojection error (:117-124).  Outputs: T (num_pairs * 12,
+ * [t | R row-major] = T_1_0 of the hypothesis with the most inliers, the first one on ties, identity when no
+ * hypothesis has an inlier), inlier flags (one byte per matched point; may be NULL), count (num_pairs; may be
+ * NULL), device_time_s (kernel time; may be NULL).
+ * ssba_ransac_samples (host) restates the reference's draw sequence (:69-91): std::mt19937 re-seeded with 42 in
+ * every call and std::uniform_int_distribution<uint>(0, n-1), three distinct indices per iteration.  The
+ * distribution is implementation-defined; libstdcxx_variant 1 = libstdc++ >= 11, 0 = libstdc++ <= 10. */
+int ssba_ransac_samples(uint32_t n, uint32_t num_iters, int libstdcxx_variant, uint32_t *idx3);
+int ssba_frontend_ransac(const ssba_camera *camera, int device, uint32_t num_pairs, const uint32_t *offset,
+                         const double *pts0, const double *pts1, const uint32_t *samples, uint32_t num_iters,
+                         double thresh, double *T, uint8_t *inlier, uint32_t *count, double *device_time_s);
+
 const char *ssba_status_string(int status);
 const char *ssba_last_error(void);
 

@@ -1,0 +1,99 @@
+"""Front end on the GPU: the batched 3-point RANSAC through the C ABI against the oracle's
+restatement of point_cloud_aligner.cpp pair by pair, the whole compute_initial_guess, and dataset -> initial
+guess -> solve end to end."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from ceres_slam_amd import capi, frontend, synth
+from ceres_slam_amd.solver import StereoBA
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+_u32p = C.POINTER(C.c_uint32)
+_dp = C.POINTER(C.c_double)
+
+
+def _oracle_ransac(camera, pts0_list, pts1_list, num_iters, thresh, variant, device):
+    L = orc.lib()
+    L.orc_ransac_samples.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _u32p]
+    L.orc_ransac_align.argtypes = [C.POINTER(orc.Camera), _dp, _dp, C.c_int, _u32p, C.c_int, C.c_double, _dp, C.POINTER(C.c_uint8)]
+    L.orc_ransac_align.restype = C.c_int
+    cam = orc.Camera(**camera)
+    Ts, masks, counts = [], [], []
+    for p0, p1 in zip(pts0_list, pts1_list):
+        n = len(p0)
+        idx = np.zeros(3 * num_iters, dtype=np.uint32)
+        L.orc_ransac_samples(n, num_iters, variant, idx.ctypes.data_as(_u32p))
+        T, inl = np.zeros(12), np.zeros(n, dtype=np.uint8)
+        p0c, p1c = np.ascontiguousarray(p0), np.ascontiguousarray(p1)
+        c = L.orc_ransac_align(C.byref(cam), p0c.ctypes.data_as(_dp), p1c.ctypes.data_as(_dp), n, idx.ctypes.data_as(_u32p), num_iters,
+                               thresh, T.ctypes.data_as(_dp), inl.ctypes.data_as(C.POINTER(C.c_uint8)))
+        Ts.append(T); masks.append(inl.astype(bool)); counts.append(c)
+    return np.array(Ts), masks, np.array(counts, dtype=np.uint32), 0.0
+
+
+def _problem(P=20, L=1500, **kw):
+    # feature noise of a real tracker (sub-pixel); the generator's default sigma = 2 px is the BA stress setting
+    return synth.make_problem(P, L, obs_var=(0.04, 0.04, 0.04), **kw)
+
+
+def test_sampling_sequence_matches_the_oracle():
+    L = orc.lib()
+    L.orc_ransac_samples.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _u32p]
+    for n in (3, 17, 1187):
+        for variant in (0, 1):
+            want = np.zeros(1200, dtype=np.uint32)
+            L.orc_ransac_samples(n, 400, variant, want.ctypes.data_as(_u32p))
+            assert np.array_equal(frontend.ransac_samples(n, 400, variant).ravel(), want)
+
+
+@pytest.mark.parametrize("outliers", [0.0, 0.25])
+def test_batched_ransac_matches_oracle_pair_by_pair(outliers):
+    prob = _problem(outlier_fraction=outliers)
+    idx_of = [np.nonzero(prob.obs_pose == k)[0] for k in range(prob.num_poses)]
+    p0s, p1s = [], []
+    for k in range(1, prob.num_poses):
+        a, b = frontend.match_states(prob.obs_point[idx_of[k - 1]], prob.obs_point[idx_of[k]])
+        p0s.append(frontend.triangulate(prob.camera, prob.obs_uvd[idx_of[k - 1][a]]))
+        p1s.append(frontend.triangulate(prob.camera, prob.obs_uvd[idx_of[k][b]]))
+    T, masks, counts, secs = frontend.ransac_batch(prob.camera, p0s, p1s, 400, 4.0, 1)
+    T2, masks2, counts2, _ = _oracle_ransac(prob.camera, p0s, p1s, 400, 4.0, 1, -1)
+    assert np.array_equal(counts, counts2)
+    np.testing.assert_allclose(T, T2, rtol=1e-9, atol=1e-10)
+    assert all(np.array_equal(a, b) for a, b in zip(masks, masks2))
+    assert counts.min() > 0.5 * min(len(p) for p in p0s) * (1 - 2 * outliers)
+    assert secs > 0
+
+
+def test_compute_initial_guess_matches_the_oracle_backed_restatement_and_feeds_the_solver():
+    prob = _problem(30, 2400)
+    args = (prob.camera, prob.num_poses, prob.num_points, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.poses_gt[0])
+    poses, points, init, stats = frontend.compute_initial_guess(*args)
+    poses2, points2, init2, _ = frontend.compute_initial_guess(*args, ransac=_oracle_ransac)
+    np.testing.assert_allclose(poses, poses2, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(init, init2)
+    np.testing.assert_allclose(points[init], points2[init], rtol=1e-9, atol=1e-8)
+    assert init.mean() > 0.95 and stats["inliers"] > 0.8 * stats["matches"]
+    # VO drift stays small on this sequence, and the guess is good enough for the bundle adjustment
+    assert np.abs(poses[:, :3] - prob.poses_gt[:, :3]).max() < 1.0
+    sel = init[prob.obs_point]                                  # only initialised map points get residuals (dataset_vo.cpp:45)
+    ba = StereoBA(prob.camera, poses.copy(), points.copy(), prob.obs_pose[sel], prob.obs_point[sel], prob.obs_uvd[sel],
+                  prob.stiffness())
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    assert s.termination_type == 0 and s.final_cost < 0.05 * s.initial_cost
+    assert np.abs(ba.poses[:, :3] - prob.poses_gt[:, :3]).max() < 0.05
+
+
+def test_degenerate_inputs_are_rejected():
+    cam = capi.Camera(**synth.KITTI_CAMERA)
+    lib = capi.load()
+    off = np.array([0, 2], dtype=np.uint32)
+    pts = np.zeros((2, 3)) + 1.0
+    smp = np.zeros(3, dtype=np.uint32)
+    T = np.zeros(12)
+    rc = lib.ssba_frontend_ransac(C.byref(cam), -1, 1, off.ctypes.data_as(_u32p), capi.dptr(pts), capi.dptr(pts),
+                                  np.array([0, 1, 5], dtype=np.uint32).ctypes.data_as(_u32p), 1, 4.0, capi.dptr(T), None, None, None)
+    assert rc == -1            # sample index outside the pair
+    assert lib.ssba_ransac_samples(2, 10, 1, smp.ctypes.data_as(_u32p)) == -1      # three distinct indices need n >= 3
