@@ -87,6 +87,30 @@ def test_compute_initial_guess_matches_the_oracle_backed_restatement_and_feeds_t
     assert np.abs(ba.poses[:, :3] - prob.poses_gt[:, :3]).max() < 0.05
 
 
+def test_cpp_driver_with_its_own_front_end(tmp_path):
+    """examples/dataset_vo_gpu --frontend: read the dataset, compute the initial guess (GPU RANSAC), solve, write --
+    the whole main() of tests/dataset_vo.cpp; same result as the Python mirror of the front end + the oracle."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples()
+    prob = _problem(16, 800, track_len=8, seed=3)
+    ds, _, _ = synth.write_reference_csv(prob, str(tmp_path / "sim.csv"))
+    r = subprocess.run([exe, ds, "--frontend"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    variant = 1 if int(subprocess.run(["g++", "-dumpversion"], capture_output=True, text=True).stdout.split(".")[0]) >= 11 else 0
+    poses0, points0, init, _ = frontend.compute_initial_guess(prob.camera, prob.num_poses, prob.num_points, prob.obs_pose, prob.obs_point,
+                                                               prob.obs_uvd, prob.poses_gt[0], variant=variant, ransac=_oracle_ransac)
+    sel = init[prob.obs_point]
+    op = orc.OracleProblem(prob.camera, poses0, points0, prob.obs_pose[sel], prob.obs_point[sel], prob.obs_uvd[sel], prob.stiffness())
+    s2, _ = op.solve(orc.driver_options(num_threads=2))
+    report = [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")][0]
+    assert "Termination: CONVERGENCE" in report
+    assert float(report.split("Final cost: ")[1].split(",")[0]) == pytest.approx(s2.final_cost, rel=1e-5)
+    out = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(out - op.poses).max() < 1e-5
+    assert np.abs(out[:, :3] - prob.poses_gt[:, :3]).max() < 0.05
+
+
 def test_degenerate_inputs_are_rejected():
     cam = capi.Camera(**synth.KITTI_CAMERA)
     lib = capi.load()
