@@ -109,3 +109,50 @@ def compute_initial_guess(camera: dict, num_states: int, num_points: int, obs_st
         initialized[js[new]] = True
     return poses, points, initialized, dict(pairs=len(pairs), matches=int(sum(len(p[0]) for p in pairs)),
                                             inliers=int(counts.sum()), ransac_device_s=secs)
+
+
+def compute_initial_guess_phong(camera: dict, num_states: int, num_points: int, num_materials: int, obs_state, obs_point, obs_material,
+                                obs_uvd, obs_intensity, obs_normal, first_pose, num_iters: int = 400, thresh: float = 9.0,
+                                variant: int = 1, device: int = -1, ransac=None, reference_material_indexing: bool = True):
+    """DatasetProblemPhong::compute_initial_guess(0, num_states) (src/ceres_slam/dataset_problem_phong.cpp:250-391).
+    On top of the stereo version: materials start at (ka, ks, exponent) = (0, 0, 1) (:266-267), textures at the
+    median observed intensity of the material (std::nth_element at size/2, :269-277); an inlier vertex without a guess
+    gets position poses[k-1]^-1 * p_km1 and normal = poses[k-1]^-1 * observed normal (rotation only, :361-365).
+
+    reference_material_indexing=True keeps the reference's indexing of the vertex's material, `material_ids[i]` with
+    i the position of the match in the pair's list (:369-370) rather than the observation's own material id; False
+    uses the observation's material (what the data say).  Returns poses, positions, normals, initialised flags,
+    material_of_vertex, phong (M,3), texture (M,), stats."""
+    obs_state, obs_point, obs_material = np.asarray(obs_state), np.asarray(obs_point), np.asarray(obs_material)
+    phong = np.tile(np.array([0.0, 0.0, 1.0]), (num_materials, 1))
+    texture = np.zeros(num_materials)
+    for m in range(num_materials):
+        ints = np.sort(np.asarray(obs_intensity)[obs_material == m])
+        if len(ints):
+            texture[m] = ints[len(ints) // 2]
+    idx_of = [np.nonzero(obs_state == k)[0] for k in range(num_states)]
+    pairs = []
+    for k in range(1, num_states):
+        a, b = match_states(obs_point[idx_of[k - 1]], obs_point[idx_of[k]])
+        ia, ib = idx_of[k - 1][a], idx_of[k][b]
+        pairs.append((ia, triangulate(camera, obs_uvd[ia]), triangulate(camera, obs_uvd[ib])))
+    T, masks, counts, secs = (ransac or ransac_batch)(camera, [p[1] for p in pairs], [p[2] for p in pairs], num_iters, thresh, variant, device)
+    poses = np.zeros((num_states, 12))
+    poses[0] = first_pose
+    positions, normals = np.zeros((num_points, 3)), np.zeros((num_points, 3))
+    material_of_vertex = np.zeros(num_points, dtype=np.uint32)
+    initialized = np.zeros(num_points, dtype=bool)
+    for k in range(1, num_states):
+        ia, p_km1, _ = pairs[k - 1]
+        poses[k] = se3_compose(T[k - 1], poses[k - 1])
+        R = poses[k - 1][3:].reshape(3, 3)
+        for i in np.nonzero(masks[k - 1])[0]:           # in list order: "if (!initialized_vertex[j])"
+            j = int(obs_point[ia[i]])
+            if initialized[j]:
+                continue
+            positions[j] = se3_inverse_apply(poses[k - 1], p_km1[i][None])[0]
+            normals[j] = obs_normal[ia[i]] @ R              # R^T n
+            material_of_vertex[j] = obs_material[i] if reference_material_indexing else obs_material[ia[i]]
+            initialized[j] = True
+    return poses, positions, normals, initialized, material_of_vertex, phong, texture, dict(
+        pairs=len(pairs), matches=int(sum(len(p[0]) for p in pairs)), inliers=int(counts.sum()), ransac_device_s=secs)

@@ -111,6 +111,39 @@ def test_cpp_driver_with_its_own_front_end(tmp_path):
     assert np.abs(out[:, :3] - prob.poses_gt[:, :3]).max() < 0.05
 
 
+def test_phong_front_end_and_solve():
+    """DatasetProblemPhong::compute_initial_guess -> the driver's solve (free shared blocks, bounds, SUBSPACE_DOGLEG)."""
+    prob, ph = synth.make_phong_problem(30, 2400, obs_var=(0.04, 0.04, 0.04))
+    mat_obs = ph.material_of_point[prob.obs_point]
+    out = frontend.compute_initial_guess_phong(prob.camera, prob.num_poses, prob.num_points, len(ph.texture), prob.obs_pose, prob.obs_point,
+                                               mat_obs, prob.obs_uvd, ph.intensity, ph.normal_obs, prob.poses_gt[0],
+                                               reference_material_indexing=False)
+    poses, positions, normals, init, mat_v, phong, texture, stats = out
+    assert init.mean() > 0.95 and np.array_equal(mat_v[init], ph.material_of_point[init])
+    np.testing.assert_allclose(texture, ph.texture_ref_init)              # the generator restates the same median
+    assert np.all(phong == np.array([0.0, 0.0, 1.0]))
+    assert np.abs(np.linalg.norm(normals[init], axis=1) - 1).max() < 0.05  # observed normals carry noise, Plus renormalises
+    assert np.abs(poses[:, :3] - prob.poses_gt[:, :3]).max() < 1.0
+    # the reference indexes material_ids by the position in the match list (dataset_problem_phong.cpp:369-370)
+    out_q = frontend.compute_initial_guess_phong(prob.camera, prob.num_poses, prob.num_points, len(ph.texture), prob.obs_pose, prob.obs_point,
+                                                 mat_obs, prob.obs_uvd, ph.intensity, ph.normal_obs, prob.poses_gt[0])
+    assert not np.array_equal(out_q[4][init], ph.material_of_point[init])
+    sel = init[prob.obs_point]
+    keep = np.nonzero(init)[0]
+    remap = np.full(prob.num_points, -1)
+    remap[keep] = np.arange(len(keep))
+    n_unit = normals[keep] / np.linalg.norm(normals[keep], axis=1)[:, None]
+    d = dict(normals=n_unit, intensity=ph.intensity[sel], normal_obs=ph.normal_obs[sel], phong=phong, texture=texture,
+             material_of_point=mat_v[keep], light=ph.light_init, light_type=ph.light_type, int_stiffness=ph.int_stiffness,
+             normal_stiffness=ph.normal_stiffness())
+    ba = StereoBA(prob.camera, poses.copy(), positions[keep].copy(), prob.obs_pose[sel], remap[prob.obs_point[sel]].astype(np.uint32),
+                  prob.obs_uvd[sel], prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1))
+    assert s.termination_type == 0 and s.final_cost < 0.1 * s.initial_cost
+    assert np.abs(ba.poses[:, :3] - prob.poses_gt[:, :3]).max() < 0.05
+    np.testing.assert_allclose(ba.texture, ph.texture, atol=0.02)
+
+
 def test_degenerate_inputs_are_rejected():
     cam = capi.Camera(**synth.KITTI_CAMERA)
     lib = capi.load()
