@@ -33,7 +33,9 @@ class Problem(C.Structure):
                 ("normals", _dp), ("intensity", _dp), ("normal_obs", _dp), ("phong", _dp), ("texture", _dp),
                 ("material_of_point", _u32p), ("light", C.c_double * 3), ("light_type", C.c_int32),
                 ("shared_free", C.c_uint32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9),
-                ("num_materials", C.c_uint32), ("use_bounds", C.c_uint32)]
+                ("num_materials", C.c_uint32), ("use_bounds", C.c_uint32),
+                ("num_pose_factors", C.c_uint32), ("reserved3", C.c_uint32), ("pf_pose", _u32p), ("pf_type", _u32p),
+                ("pf_data", _dp), ("pf_stiffness", _dp), ("pf_huber", _dp)]
 
 
 class Options(C.Structure):
@@ -127,7 +129,8 @@ class OracleProblem:
     """Owns numpy copies of a problem and the ctypes view the C oracle reads."""
 
     def __init__(self, camera: dict, poses, points, obs_pose, obs_point, obs_uvd, stiffness,
-                 pose_const=None, huber_a: float = 0.0, lighting=None, shared_free: int = 0, use_bounds: bool = False):
+                 pose_const=None, huber_a: float = 0.0, lighting=None, shared_free: int = 0, use_bounds: bool = False,
+                 pose_factors=None):
         self.poses = np.ascontiguousarray(poses, dtype=np.float64).copy()
         self.points = np.ascontiguousarray(points, dtype=np.float64).copy()
         self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
@@ -152,6 +155,19 @@ class OracleProblem:
         self.c.huber_a = float(huber_a)
         self.ld = 3
         self.normals = None
+        if pose_factors:        # list of dicts: pose, type (0 prior / 1 sun), data (<= 18), stiffness (36 or 4), huber
+            F = len(pose_factors)
+            self._pf_pose = np.array([f["pose"] for f in pose_factors], dtype=np.uint32)
+            self._pf_type = np.array([f["type"] for f in pose_factors], dtype=np.uint32)
+            self._pf_data, self._pf_S, self._pf_h = np.zeros((F, 18)), np.zeros((F, 36)), np.zeros(F)
+            for i, f in enumerate(pose_factors):
+                dat, S = np.asarray(f["data"], dtype=np.float64).ravel(), np.asarray(f["stiffness"], dtype=np.float64).ravel()
+                self._pf_data[i, :len(dat)] = dat
+                self._pf_S[i, :len(S)] = S
+                self._pf_h[i] = float(f.get("huber", 0.0))
+            self.c.num_pose_factors = F
+            self.c.pf_pose, self.c.pf_type = self._pf_pose.ctypes.data_as(_u32p), self._pf_type.ctypes.data_as(_u32p)
+            self.c.pf_data, self.c.pf_stiffness, self.c.pf_huber = _p(self._pf_data), _p(self._pf_S), _p(self._pf_h)
         if lighting is not None:       # dict: normals, intensity, normal_obs, phong, texture, material_of_point, light, light_type, int_stiffness, normal_stiffness
             self.ld = 6
             self.normals = np.ascontiguousarray(lighting["normals"], dtype=np.float64).copy()

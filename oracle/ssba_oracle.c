@@ -262,6 +262,127 @@ static void set_threads(int n) {
 #endif
 }
 
+static double dot3(const double a[3], const double b[3]);
+static void row_times_neg_skew(const double g[3], const double a[3], double out[3]);
+
+/* ---- unary pose residual blocks ------------------------------------------
+ * type 0: PoseErrorAutomatic (include/ceres_slam/pose_error.hpp:22-55): r = S log(T_ref T^-1) with the
+ *         reference's log = [translation ; SO3::log(rotation)] (se3group.hpp:337-342, so3group.hpp:293-348);
+ * type 1: SunSensorErrorAutomatic (include/ceres_slam/sun_sensor_error.hpp:35-104): azimuth / zenith of the
+ *         expected sun direction R s_g against the observed one, wrap-around, outlier thresholds, 2x2 stiffness.
+ * Local Jacobians (6 columns, SE3Perturbation) in closed form; Huber via the same corrector as the stereo blocks. */
+static void so3_log(const double R[9], double phi[3]) {       /* so3group.hpp:293-348 */
+    double axis[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+    const double sin_angle = 0.5 * sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    const double cos_angle = 0.5 * (R[0] + R[4] + R[8] - 1.0);
+    const double angle = atan2(sin_angle, cos_angle);
+    if (fabs(angle) <= DBL_EPSILON) {                         /* vee(C - I) */
+        phi[0] = 0.5 * (R[7] - R[5]); phi[1] = 0.5 * (R[2] - R[6]); phi[2] = 0.5 * (R[3] - R[1]);
+        return;
+    }
+    for (int i = 0; i < 3; ++i) phi[i] = 0.5 * angle * axis[i] / sin_angle;
+}
+
+/* inverse right Jacobian of SO(3): log(R Exp(d)) ~ log R + Jr^-1(phi) d */
+static void so3_inv_right_jacobian(const double phi[3], double J[9]) {
+    const double th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2], th = sqrt(th2);
+    const double W[9] = {0, -phi[2], phi[1], phi[2], 0, -phi[0], -phi[1], phi[0], 0};
+    double c;
+    if (th < 1e-5) c = 1.0 / 12.0 + th2 / 720.0;
+    else c = 1.0 / th2 - (1.0 + cos(th)) / (2.0 * th * sin(th));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double w2 = 0.0;
+            for (int k = 0; k < 3; ++k) w2 += W[3 * i + k] * W[3 * k + j];
+            J[3 * i + j] = (i == j ? 1.0 : 0.0) + 0.5 * W[3 * i + j] + c * w2;
+        }
+}
+
+void orc_pose_prior_residual(const double T[12], const double T_ref[12], const double S[36], double r[6], double *J) {
+    const double *R = T + 3, *Rr = T_ref + 3;
+    double Rres[9], e[6], Je[36];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rres[3 * i + j] = Rr[3 * i] * R[3 * j] + Rr[3 * i + 1] * R[3 * j + 1] + Rr[3 * i + 2] * R[3 * j + 2];   /* R_ref R^T */
+    for (int i = 0; i < 3; ++i) e[i] = T_ref[i] - (Rres[3 * i] * T[0] + Rres[3 * i + 1] * T[1] + Rres[3 * i + 2] * T[2]);
+    so3_log(Rres, e + 3);
+    for (int i = 0; i < 6; ++i) {
+        double v = 0.0;
+        for (int k = 0; k < 6; ++k) v += S[6 * i + k] * e[k];
+        r[i] = v;
+    }
+    if (!J) return;
+    /* T <- exp(eps) T:  R_res <- R_res Exp(-phi),  t_res <- t_res - R_res Exp(-phi) rho  */
+    double Jr[9];
+    so3_inv_right_jacobian(e + 3, Jr);
+    memset(Je, 0, sizeof Je);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { Je[6 * i + j] = -Rres[3 * i + j]; Je[6 * (3 + i) + 3 + j] = -Jr[3 * i + j]; }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < 6; ++k) v += S[6 * i + k] * Je[6 * k + j];
+            J[6 * i + j] = v;
+        }
+}
+
+void orc_sun_residual(const double T[12], const double obs_c_in[3], const double exp_g_in[3], const double S[4], double az_thresh,
+                      double zen_thresh, double r[2], double *J) {
+    const double pi = 3.14159265358979323846;
+    const double *R = T + 3;
+    double oc[3], eg[3], sc[3];
+    const double no = sqrt(dot3(obs_c_in, obs_c_in)), ne = sqrt(dot3(exp_g_in, exp_g_in));     /* normalised in the constructor (:30-31) */
+    for (int i = 0; i < 3; ++i) { oc[i] = obs_c_in[i] / no; eg[i] = exp_g_in[i] / ne; }
+    for (int i = 0; i < 3; ++i) sc[i] = R[3 * i] * eg[0] + R[3 * i + 1] * eg[1] + R[3 * i + 2] * eg[2];
+    const double ezen = acos(-sc[1]), eaz = atan2(sc[0], sc[2]);
+    const double ozen = acos(-oc[1]), oaz = atan2(oc[0], oc[2]);
+    double raz = eaz - oaz, rzen = ezen - ozen;
+    if (raz > pi) raz -= 2 * pi; else if (raz < -pi) raz += 2 * pi;
+    int kaz = 1, kzen = 1;
+    if (fabs(raz) > az_thresh) { raz = 0.0; kaz = 0; }
+    if (fabs(rzen) > zen_thresh) { rzen = 0.0; kzen = 0; }
+    r[0] = S[0] * raz + S[1] * rzen;
+    r[1] = S[2] * raz + S[3] * rzen;
+    if (!J) return;
+    /* d s_c / d phi = -s_c^ ;  d az / d s_c = [z, 0, -x] / (x^2 + z^2) ;  d zen / d s_c = [0, 1/sqrt(1-y^2), 0] */
+    const double x = sc[0], y = sc[1], z = sc[2], d2 = x * x + z * z;
+    const double gaz[3] = {z / d2, 0.0, -x / d2}, gzen[3] = {0.0, 1.0 / sqrt(1.0 - y * y), 0.0};
+    double jaz[3], jzen[3];
+    row_times_neg_skew(gaz, sc, jaz);
+    row_times_neg_skew(gzen, sc, jzen);
+    for (int c = 0; c < 3; ++c) { if (!kaz) jaz[c] = 0.0; if (!kzen) jzen[c] = 0.0; }
+    for (int i = 0; i < 2; ++i)
+        for (int c = 0; c < 6; ++c) J[6 * i + c] = c < 3 ? 0.0 : S[2 * i] * jaz[c - 3] + S[2 * i + 1] * jzen[c - 3];
+}
+
+/* all unary factors at `poses`: corrected residuals pf_r (6 per factor, unused rows zero) and Jacobians pf_J (36 per
+ * factor) if requested; returns their cost 1/2 sum rho(|r|^2) */
+static double pf_eval(const orc_problem *p, const double *poses, double *pf_r, double *pf_J) {
+    double cost = 0.0;
+    for (uint32_t f = 0; f < p->num_pose_factors; ++f) {
+        const double *T = poses + 12 * (size_t)p->pf_pose[f], *dat = p->pf_data + 18 * (size_t)f, *S = p->pf_stiffness + 36 * (size_t)f;
+        double r[6] = {0}, J[36] = {0};
+        const int dim = p->pf_type[f] == 0 ? 6 : 2;
+        if (p->pf_type[f] == 0) orc_pose_prior_residual(T, dat, S, r, pf_J ? J : NULL);
+        else orc_sun_residual(T, dat, dat + 3, S, dat[6], dat[7], r, pf_J ? J : NULL);
+        double sq = 0.0;
+        for (int i = 0; i < dim; ++i) sq += r[i] * r[i];
+        const double a = p->pf_huber ? p->pf_huber[f] : 0.0;
+        if (a > 0.0) {
+            double rho[3];
+            orc_huber(a, sq, rho);
+            cost += 0.5 * rho[0];
+            const double sc = sqrt(rho[1]);             /* corrector with rho'' <= 0: scale r and J by sqrt(rho') */
+            for (int i = 0; i < dim; ++i) r[i] *= sc;
+            if (pf_J) for (int i = 0; i < 6 * dim; ++i) J[i] *= sc;
+        } else {
+            cost += 0.5 * sq;
+        }
+        if (pf_r) memcpy(pf_r + 6 * (size_t)f, r, sizeof r);
+        if (pf_J) memcpy(pf_J + 36 * (size_t)f, J, sizeof J);
+    }
+    return cost;
+}
+
 /* Evaluate all residual blocks.  r (N*NR), Jp (N*NR*6), Jl (N*NR*LD) may be NULL.
  * Returns cost = 1/2 sum rho(|r|^2); r/J are the loss-CORRECTED quantities, as
  * Ceres's ResidualBlock::Evaluate hands them to the minimiser. */
@@ -327,6 +448,7 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
             memcpy(Jl_out + (size_t)nr * ld * i, Jl, (size_t)nr * ld * sizeof(double));
         }
     }
+    if (p->num_pose_factors) cost += pf_eval(p, poses, NULL, NULL);
     return cost;
 }
 
@@ -352,6 +474,7 @@ typedef struct {
     int bw_poses;        /* max |free_idx(a)-free_idx(b)| over co-observing poses */
     /* free shared blocks ("border"): column offsets in the local border vector, -1 = constant */
     int M, nb, b_light, b_phong, b_tex;
+    int *pf_start, *pf_list;   /* P+1 CSR over the unary pose factors */
 } graph_t;
 
 /* border column of entry q of the per-observation border Jacobian [phong 3 | kd | light 3] */
@@ -364,6 +487,7 @@ static int bcol(const graph_t *g, uint32_t mat, int q) {
 static void graph_free(graph_t *g) {
     free(g->free_idx); free(g->free_pose); free(g->pt_active);
     free(g->pose_start); free(g->pose_obs); free(g->pt_start); free(g->pt_obs);
+    free(g->pf_start); free(g->pf_list);
 }
 
 static void graph_build(const orc_problem *p, graph_t *g) {
@@ -400,9 +524,19 @@ static void graph_build(const orc_problem *p, graph_t *g) {
     g->free_idx = malloc((size_t)(P > 0 ? P : 1) * sizeof(int));
     g->free_pose = malloc((size_t)(P > 0 ? P : 1) * sizeof(int));
     g->pt_active = malloc((size_t)(L > 0 ? L : 1));
+    g->pf_start = calloc((size_t)P + 1, sizeof(int));
+    g->pf_list = malloc((size_t)(p->num_pose_factors > 0 ? p->num_pose_factors : 1) * sizeof(int));
+    for (uint32_t f = 0; f < p->num_pose_factors; ++f) g->pf_start[p->pf_pose[f] + 1]++;
+    for (int k = 0; k < P; ++k) g->pf_start[k + 1] += g->pf_start[k];
+    {
+        int *cur = malloc((size_t)(P > 0 ? P : 1) * sizeof(int));
+        memcpy(cur, g->pf_start, (size_t)P * sizeof(int));
+        for (uint32_t f = 0; f < p->num_pose_factors; ++f) g->pf_list[cur[p->pf_pose[f]]++] = (int)f;
+        free(cur);
+    }
     int nf = 0;
     for (int k = 0; k < P; ++k) {
-        int in_problem = g->pose_start[k + 1] > g->pose_start[k];
+        int in_problem = g->pose_start[k + 1] > g->pose_start[k] || g->pf_start[k + 1] > g->pf_start[k];
         int is_const = p->pose_const && p->pose_const[k];
         if (in_problem && !is_const) { g->free_idx[k] = nf; g->free_pose[nf++] = k; }
         else g->free_idx[k] = -1;
@@ -516,6 +650,7 @@ typedef struct {
     double *sq_l;    /* L*LD                                         */
     double *Jb;      /* N*7 border entries of the intensity row, or NULL */
     double *g_b, *sq_b;   /* nb                                      */
+    double *pf_r, *pf_J;  /* 6 / 36 per unary pose factor             */
     double cost;
 } lin_t;
 
@@ -532,10 +667,12 @@ static void lin_alloc(lin_t *w, const graph_t *g) {
     w->Jb = g->nb ? malloc(N * 7 * sizeof(double)) : NULL;
     w->g_b = calloc((size_t)g->nb + 1, sizeof(double));
     w->sq_b = calloc((size_t)g->nb + 1, sizeof(double));
+    w->pf_r = calloc((size_t)(g->pf_start[g->P] + 1) * 6, sizeof(double));
+    w->pf_J = calloc((size_t)(g->pf_start[g->P] + 1) * 36, sizeof(double));
 }
 static void lin_free(lin_t *w) {
     free(w->r); free(w->Jp); free(w->Jl); free(w->g_p); free(w->g_l); free(w->sq_p); free(w->sq_l);
-    free(w->Jb); free(w->g_b); free(w->sq_b);
+    free(w->Jb); free(w->g_b); free(w->sq_b); free(w->pf_r); free(w->pf_J);
 }
 
 /* [Ceres evaluator: residuals, cost, Jacobian, gradient = J^T r at x] */
@@ -543,6 +680,7 @@ static void linearize(const orc_problem *p, const graph_t *g, const double *pose
                       const double *points, const double *normals, const double *sh, lin_t *w) {
     const int nr = g->nr, ld = g->ld;
     w->cost = evaluate(p, poses, points, normals, sh, w->r, w->Jp, w->Jl, w->Jb);
+    if (p->num_pose_factors) pf_eval(p, poses, w->pf_r, w->pf_J);
     if (g->nb) {   /* border gradient and squared column norms: only the intensity row (3) touches it */
         memset(w->g_b, 0, (size_t)g->nb * sizeof(double));
         memset(w->sq_b, 0, (size_t)g->nb * sizeof(double));
@@ -570,6 +708,11 @@ static void linearize(const orc_problem *p, const graph_t *g, const double *pose
                     gp[c] += J[6 * m + c] * r[m];
                     sq[c] += J[6 * m + c] * J[6 * m + c];
                 }
+        }
+        for (int e = g->pf_start[k]; e < g->pf_start[k + 1]; ++e) {
+            const double *J = w->pf_J + 36 * (size_t)g->pf_list[e], *r = w->pf_r + 6 * (size_t)g->pf_list[e];
+            for (int m = 0; m < 6; ++m)
+                for (int c = 0; c < 6; ++c) { gp[c] += J[6 * m + c] * r[m]; sq[c] += J[6 * m + c] * J[6 * m + c]; }
         }
         memcpy(w->g_p + 6 * f, gp, sizeof gp);
         memcpy(w->sq_p + 6 * f, sq, sizeof sq);
@@ -794,6 +937,12 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
                 for (int c = 0; c < 6; ++c)
                     for (int d = 0; d <= c; ++d) B[6 * c + d] += J[6 * m + c] * J[6 * m + d] * s6[c] * s6[d];
         }
+        for (int e = g->pf_start[k]; e < g->pf_start[k + 1]; ++e) {
+            const double *J = w->pf_J + 36 * (size_t)g->pf_list[e];
+            for (int m = 0; m < 6; ++m)
+                for (int c = 0; c < 6; ++c)
+                    for (int d = 0; d <= c; ++d) B[6 * c + d] += J[6 * m + c] * J[6 * m + d] * s6[c] * s6[d];
+        }
         for (int c = 0; c < 6; ++c) {
             double d = w->sq_p[6 * f + c] * s6[c] * s6[c];
             d = fmin(fmax(d, o->min_lm_diagonal), o->max_lm_diagonal);
@@ -877,6 +1026,18 @@ static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w
             }
             mcc -= jd * (r[m] + 0.5 * jd);
             sq += jd * jd;
+        }
+    }
+    for (int k = 0; k < g->P; ++k) {
+        if (g->free_idx[k] < 0) continue;
+        for (int e = g->pf_start[k]; e < g->pf_start[k + 1]; ++e) {
+            const double *J = w->pf_J + 36 * (size_t)g->pf_list[e], *r = w->pf_r + 6 * (size_t)g->pf_list[e];
+            for (int m = 0; m < 6; ++m) {
+                double jd = 0.0;
+                for (int c = 0; c < 6; ++c) jd += J[6 * m + c] * dp[6 * (size_t)k + c];
+                mcc -= jd * (r[m] + 0.5 * jd);
+                sq += jd * jd;
+            }
         }
     }
     if (mcc_out) *mcc_out = mcc;
@@ -1040,6 +1201,17 @@ static void jd_products(const orc_problem *p, const graph_t *g, const lin_t *w, 
                 }
             }
             s11 += j1 * j1; s22 += j2 * j2; s12 += j1 * j2;
+        }
+    }
+    for (int k = 0; k < g->P; ++k) {
+        if (g->free_idx[k] < 0) continue;
+        for (int e = g->pf_start[k]; e < g->pf_start[k + 1]; ++e) {
+            const double *J = w->pf_J + 36 * (size_t)g->pf_list[e];
+            for (int m = 0; m < 6; ++m) {
+                double j1 = 0.0, j2 = 0.0;
+                for (int c = 0; c < 6; ++c) { j1 += J[6 * m + c] * dp1[6 * (size_t)k + c]; j2 += J[6 * m + c] * dp2[6 * (size_t)k + c]; }
+                s11 += j1 * j1; s22 += j2 * j2; s12 += j1 * j2;
+            }
         }
     }
     out[0] = s11; out[1] = s22; out[2] = s12;

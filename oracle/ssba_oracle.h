@@ -80,6 +80,14 @@ typedef struct {
     uint32_t use_bounds;               /* 1: the driver's SetParameterLower/UpperBound calls on the free Phong
                                           and texture blocks (dataset_ba_phong.cpp:143-181): ka, ks, kd in
                                           [0,1], alpha >= 1 -> projected Plus + Armijo line search        */
+    /* unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124) */
+    uint32_t num_pose_factors, reserved3;
+    const uint32_t *pf_pose;           /* F: pose index                                                   */
+    const uint32_t *pf_type;           /* F: 0 = PoseErrorAutomatic, 1 = SunSensorErrorAutomatic          */
+    const double *pf_data;             /* F*18: type 0: T_ref (12); type 1: observed dir (camera frame, 3),
+                                          expected dir (global, 3), azimuth threshold, zenith threshold  */
+    const double *pf_stiffness;        /* F*36: 6x6 (type 0) or 2x2 in the first 4 entries (type 1)       */
+    const double *pf_huber;            /* F or NULL: HuberLoss parameter of the block, 0 = NULL loss       */
 } orc_problem;
 
 typedef struct {
@@ -201,6 +209,11 @@ void orc_intensity_residual(int light_type, const double T[12], const double p[3
  * plus-Jacobian). */
 void orc_normal_residual(const double T[12], const double n[3], const double n_obs[3],
                          const double S[9], double r[3], double *Jpose, double *Jn);
+
+/* unary pose residuals (row N4): corrected-free residual and local 6-column Jacobian (may be NULL) */
+void orc_pose_prior_residual(const double T[12], const double T_ref[12], const double S[36], double r[6], double *J);
+void orc_sun_residual(const double T[12], const double obs_c[3], const double exp_g[3], const double S[4], double az_thresh,
+                      double zen_thresh, double r[2], double *J);
 
 /* ---- front end: VO initial guess ------------------------------
  * src/ceres_slam/point_cloud_aligner.cpp: 3-point RANSAC (400 iterations, std::mt19937 seeded with 42 in

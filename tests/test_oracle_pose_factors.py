@@ -1,0 +1,192 @@
+"""Row N4: unary pose residual blocks of the sun-aided driver (tests/dataset_vo_sun.cpp:80-124) --
+PoseErrorAutomatic (pose prior, pose_error.hpp:22-55) and SunSensorErrorAutomatic (sun_sensor_error.hpp:35-104).
+The oracle's closed-form Jacobians against complex-step / finite differences of the reference formulas through
+SE3Perturbation, and the LM step of a prior-anchored problem against a dense numpy solve.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import np_reference as npr
+from ceres_slam_amd import synth
+from oracle import oracle as orc
+
+_dp = C.POINTER(C.c_double)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(_dp)
+
+
+def _so3_log(R):
+    """so3group.hpp:293-348 (works on complex matrices for complex-step differentiation)."""
+    axis = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    sin_a = 0.5 * np.sqrt((axis * axis).sum())
+    cos_a = 0.5 * (R[0, 0] + R[1, 1] + R[2, 2] - 1.0)
+    # atan2 for complex arguments: angle + first-order imaginary part
+    ang = np.arctan2(sin_a.real, cos_a.real)
+    d = (cos_a.real * sin_a.imag - sin_a.real * cos_a.imag) / (sin_a.real ** 2 + cos_a.real ** 2) if np.iscomplexobj(R) else 0.0
+    angle = ang + 1j * d if np.iscomplexobj(R) else ang
+    if abs(ang) <= np.finfo(float).eps:         # first-order branch: vee(C - I)
+        return 0.5 * axis
+    return 0.5 * angle * axis / sin_a
+
+
+def _prior_res(T, T_ref, S):
+    R, Rr = T[3:].reshape(3, 3), T_ref[3:].reshape(3, 3)
+    Rres = Rr @ R.T
+    e = np.concatenate([T_ref[:3] - Rres @ T[:3], _so3_log(Rres)])
+    return S @ e
+
+
+def _sun_res(T, oc, eg, S, taz, tzen):
+    R = T[3:].reshape(3, 3)
+    oc, eg = oc / np.linalg.norm(oc), eg / np.linalg.norm(eg)
+    sc = R @ eg
+
+    def azzen(v):
+        y = v[1]
+        zen = np.arccos(-y.real) + (1j * y.imag / np.sqrt(1 - y.real ** 2) if np.iscomplexobj(v) else 0.0)
+        x, z = v[0], v[2]
+        az = np.arctan2(x.real, z.real) + (1j * (z.real * x.imag - x.real * z.imag) / (x.real ** 2 + z.real ** 2) if np.iscomplexobj(v) else 0.0)
+        return az, zen
+    eaz, ezen = azzen(sc)
+    oaz, ozen = azzen(oc)
+    raz, rzen = eaz - oaz, ezen - ozen
+    if raz.real > np.pi:
+        raz -= 2 * np.pi
+    elif raz.real < -np.pi:
+        raz += 2 * np.pi
+    if abs(raz.real) > taz:
+        raz = 0.0
+    if abs(rzen.real) > tzen:
+        rzen = 0.0
+    return S @ np.array([raz, rzen])
+
+
+def _cs_jac(fun, T, h=1e-30):
+    J = []
+    for c in range(6):
+        e = np.zeros(6, dtype=complex)
+        e[c] = 1j * h
+        J.append(fun(npr.se3_plus(T.astype(complex), e)).imag / h)
+    return np.array(J).T
+
+
+def _rand_pose(rng, scale=0.3):
+    return npr.se3_plus(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), np.concatenate([rng.normal(size=3), scale * rng.normal(size=3)]))
+
+
+def test_pose_prior_residual_and_jacobian():
+    L = orc.lib()
+    L.orc_pose_prior_residual.argtypes = [_dp] * 5
+    rng = np.random.default_rng(0)
+    for it in range(100):
+        T_ref = _rand_pose(rng, 1.0)
+        T = npr.se3_plus(T_ref, np.concatenate([0.5 * rng.normal(size=3), (0.3 if it % 2 else 1e-9) * rng.normal(size=3)]))
+        A = rng.normal(size=(6, 6))
+        S = np.linalg.inv(np.linalg.cholesky(A @ A.T + np.eye(6)))
+        r, J = np.zeros(6), np.zeros(36)
+        L.orc_pose_prior_residual(_c(T), _c(T_ref), _c(S), r.ctypes.data_as(_dp), J.ctypes.data_as(_dp))
+        np.testing.assert_allclose(r, _prior_res(T, T_ref, S), rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(J.reshape(6, 6), _cs_jac(lambda X: _prior_res(X, T_ref, S), T), rtol=1e-7, atol=1e-8)
+
+
+def test_sun_sensor_residual_and_jacobian():
+    L = orc.lib()
+    L.orc_sun_residual.argtypes = [_dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp, _dp]
+    rng = np.random.default_rng(1)
+    for it in range(200):
+        T = _rand_pose(rng, 1.0)
+        eg = rng.normal(size=3)
+        oc = T[3:].reshape(3, 3) @ (eg / np.linalg.norm(eg)) + 0.05 * rng.normal(size=3)
+        A = rng.normal(size=(2, 2))
+        S = np.linalg.inv(np.linalg.cholesky(A @ A.T + np.eye(2)))
+        taz, tzen = (1000.0, 1000.0) if it % 3 else (0.03, 0.03)       # dataset_vo_sun.cpp:28-29 defaults / tight
+        r, J = np.zeros(2), np.zeros(12)
+        L.orc_sun_residual(_c(T), _c(oc), _c(eg), _c(S), taz, tzen, r.ctypes.data_as(_dp), J.ctypes.data_as(_dp))
+        np.testing.assert_allclose(r, _sun_res(T, oc, eg, S, taz, tzen), rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(J.reshape(2, 6), _cs_jac(lambda X: _sun_res(X, oc, eg, S, taz, tzen), T), rtol=1e-7, atol=1e-9)
+    # wrap-around of the azimuth difference
+    T = np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0])
+    r = np.zeros(2)
+    L.orc_sun_residual(_c(T), _c([0.02, -0.5, -1.0]), _c([-0.02, -0.5, -1.0]), _c(np.eye(2)), 1000.0, 1000.0, r.ctypes.data_as(_dp), None)
+    assert abs(r[0]) < 0.1
+
+
+def _sun_problem(P=8, L=120, seed=2, huber=0.0):
+    prob = synth.make_problem(P, L, track_len=5, seed=seed)
+    rng = np.random.default_rng(seed)
+    sun_g = np.array([0.3, -0.8, 0.5])
+    factors = [dict(pose=0, type=0, data=prob.poses_init[0], stiffness=np.eye(6) * 1e2)]          # prior on the first pose (:107-124)
+    for k in range(P):
+        if k % 4 == 3:
+            continue                                                                               # state_has_sun_obs
+        obs = prob.poses_gt[k][3:].reshape(3, 3) @ sun_g + 0.01 * rng.normal(size=3)
+        factors.append(dict(pose=k, type=1, data=np.concatenate([obs, sun_g, [1000.0, 1000.0]]), stiffness=np.eye(2).ravel() * 50.0,
+                            huber=huber))
+    return prob, factors
+
+
+@pytest.mark.parametrize("huber", [0.0, 0.5])
+def test_lm_step_with_pose_factors_matches_dense_numpy_solve(huber):
+    prob, factors = _sun_problem(huber=huber)
+    none_const = np.zeros(prob.num_poses, dtype=np.uint8)                                          # no constant pose: the prior anchors
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_const=none_const, pose_factors=factors)
+    radius = 50.0
+    dp, dl, mcc = op.lm_step(radius)
+    # dense restatement with complex-step Jacobians
+    P, Lm = prob.num_poses, prob.num_points
+    rows, r = [], []
+    S = prob.stiffness()
+    for i in range(prob.num_obs):
+        k, j = int(prob.obs_pose[i]), int(prob.obs_point[i])
+        Jp, Jl = npr.jacobians_complex_step(prob.camera, prob.poses_init[k], prob.points_init[j], prob.obs_uvd[i], S)
+        ri = npr.residual_global(prob.camera, prob.poses_init[k], prob.points_init[j], prob.obs_uvd[i], S)
+        for m in range(3):
+            row = np.zeros(6 * P + 3 * Lm)
+            row[6 * k: 6 * k + 6] = Jp[m]
+            row[6 * P + 3 * j: 6 * P + 3 * j + 3] = Jl[m]
+            rows.append(row); r.append(ri[m])
+    for f in factors:
+        k, T = f["pose"], prob.poses_init[f["pose"]]
+        if f["type"] == 0:
+            fun = lambda X: _prior_res(X, np.asarray(f["data"]), np.asarray(f["stiffness"]).reshape(6, 6))
+        else:
+            d = np.asarray(f["data"])
+            fun = lambda X: _sun_res(X, d[:3], d[3:6], np.asarray(f["stiffness"]).reshape(2, 2), d[6], d[7])
+        rf, Jf = fun(T).real, _cs_jac(fun, T)
+        a = f.get("huber", 0.0)
+        sq = rf @ rf
+        if a > 0 and sq > a * a:
+            sc = np.sqrt(a / np.sqrt(sq))
+            rf, Jf = rf * sc, Jf * sc
+        for m in range(len(rf)):
+            row = np.zeros(6 * P + 3 * Lm)
+            row[6 * k: 6 * k + 6] = Jf[m]
+            rows.append(row); r.append(rf[m])
+    J, r = np.array(rows), np.array(r)
+    active = np.concatenate([np.ones(6 * P, bool), np.repeat(np.bincount(prob.obs_point, minlength=Lm) > 0, 3)])
+    J = J[:, active]
+    scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))
+    Js = J * scale
+    D = np.clip((Js * Js).sum(0), 1e-6, 1e32) / radius
+    y = np.linalg.solve(Js.T @ Js + np.diag(D), Js.T @ r)
+    delta = np.zeros(6 * P + 3 * Lm)
+    delta[active] = -y * scale
+    np.testing.assert_allclose(dp.ravel(), delta[:6 * P], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(dl.ravel(), delta[6 * P:], rtol=1e-7, atol=1e-9)
+    Jd = J @ delta[active]
+    assert mcc == pytest.approx(-Jd @ (r + 0.5 * Jd), rel=1e-8)
+
+
+def test_sun_aided_solve_reduces_heading_drift():
+    prob, factors = _sun_problem(P=12, L=300, seed=5)
+    none_const = np.zeros(prob.num_poses, dtype=np.uint8)
+    kw = dict(pose_const=none_const)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_factors=factors, **kw)
+    s, log = op.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1, dogleg_type=1))      # :141-143
+    assert s.termination_type == 0 and s.final_cost < 0.2 * s.initial_cost
+    assert np.abs(op.poses[0] - prob.poses_init[0]).max() < 0.02              # the prior holds the first pose in place
