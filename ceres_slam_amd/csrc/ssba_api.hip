@@ -60,6 +60,9 @@ struct ssba_problem {
                      -std::numeric_limits<double>::infinity(), -std::numeric_limits<double>::infinity()};
     double bhi[4] = {std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(),
                      std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity()};
+    // unary pose residual blocks (pose prior, sun sensor)
+    struct PoseFactor { uint32_t pose; int type; double data[18], S[36], huber; };
+    std::vector<PoseFactor> pose_factors;
     double *h_ls = nullptr;                // pinned: line-search scalars + state
     int num_line_search_steps = 0;
     std::vector<double> ph_intensity, ph_nobs;
@@ -326,6 +329,31 @@ int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant) 
     return SSBA_OK;
 }
 
+int ssba_add_pose_prior(ssba_problem *p, uint32_t pose, const double T_ref[12], const double stiffness[36], double huber_a) {
+    if (!p || !T_ref || !stiffness || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    ssba_problem::PoseFactor f{};
+    f.pose = pose; f.type = 0; f.huber = huber_a > 0.0 ? huber_a : 0.0;
+    memcpy(f.data, T_ref, 12 * sizeof(double));
+    memcpy(f.S, stiffness, 36 * sizeof(double));
+    p->pose_factors.push_back(f);
+    return SSBA_OK;
+}
+
+int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observed_dir_c[3], const double expected_dir_g[3],
+                             const double stiffness[4], double az_err_thresh, double zen_err_thresh, double huber_a) {
+    if (!p || !observed_dir_c || !expected_dir_g || !stiffness || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    ssba_problem::PoseFactor f{};
+    f.pose = pose; f.type = 1; f.huber = huber_a > 0.0 ? huber_a : 0.0;
+    memcpy(f.data, observed_dir_c, 3 * sizeof(double));
+    memcpy(f.data + 3, expected_dir_g, 3 * sizeof(double));
+    f.data[6] = az_err_thresh; f.data[7] = zen_err_thresh;
+    memcpy(f.S, stiffness, 4 * sizeof(double));
+    p->pose_factors.push_back(f);
+    return SSBA_OK;
+}
+
 int ssba_set_shared_block_bounds(ssba_problem *p, int which, int index, double lower, double upper) {
     if (!p || (which != SSBA_BLOCK_PHONG && which != SSBA_BLOCK_TEXTURE) || !(lower <= upper)) return SSBA_ERR_INVALID_ARGUMENT;
     if ((which == SSBA_BLOCK_PHONG && (index < 0 || index > 2)) || (which == SSBA_BLOCK_TEXTURE && index != 0))
@@ -469,10 +497,19 @@ int ssba_finalize(ssba_problem *p) {
     for (uint64_t i = 0; i < N; ++i) lm_obs[cur[p->obs_point[i]]++] = (uint32_t)i;
 
     // free poses: in the problem (observed) and not constant
+    std::vector<uint32_t> pf_cnt(P, 0);
+    for (auto &f : p->pose_factors) {
+        pf_cnt[f.pose]++;
+        if (p->pose_const[f.pose]) { set_error("a unary residual block sits on a constant pose"); return SSBA_ERR_UNSUPPORTED; }
+    }
+    if (!p->pose_factors.empty() && (ph || p->world_size > 1)) {
+        set_error("pose priors / sun observations are not available with lighting terms or landmark sharding yet");
+        return SSBA_ERR_UNSUPPORTED;
+    }
     p->pose_free.assign(P, -1);
     p->free_pose.clear();
     for (uint32_t k = 0; k < P; ++k)
-        if ((pose_cnt[k] > 0 || p->world_size > 1) && !p->pose_const[k]) {
+        if ((pose_cnt[k] > 0 || pf_cnt[k] > 0 || p->world_size > 1) && !p->pose_const[k]) {
             p->pose_free[k] = (int)p->free_pose.size();
             p->free_pose.push_back((int)k);
         }
@@ -857,9 +894,27 @@ int ssba_finalize(ssba_problem *p) {
         }
         d.ns_levels = lev + 1;
     }
+    if (!p->pose_factors.empty()) {
+        std::vector<uint32_t> start(P + 1, 0);
+        for (uint32_t k = 0; k < P; ++k) start[k + 1] = start[k] + pf_cnt[k];
+        std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+        const size_t F = p->pose_factors.size();
+        std::vector<int> type(F);
+        std::vector<double> data(F * 18), S(F * 36), hub(F);
+        for (auto &f : p->pose_factors) {     // stable: keeps the caller's order inside a pose
+            const uint32_t q = cur[f.pose]++;
+            type[q] = f.type; hub[q] = f.huber;
+            memcpy(&data[18 * (size_t)q], f.data, sizeof f.data);
+            memcpy(&S[36 * (size_t)q], f.S, sizeof f.S);
+        }
+        d.n_pf = (int)F;
+        TRY(dupload(p, &d.pf_start, start)); TRY(dupload(p, &d.pf_type, type));
+        TRY(dupload(p, &d.pf_data, data)); TRY(dupload(p, &d.pf_S, S)); TRY(dupload(p, &d.pf_huber, hub));
+        TRY(dzero(p, &d.pf_cost, (size_t)P));
+    }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
-    TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * 2));   // + one entry for the border of shared blocks
+    TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * NPP));   // + one entry for the border of shared blocks
     TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks + 1) * NDL));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));

@@ -25,6 +25,7 @@
 #include "ssba_types.h"
 #include "ssba_launch.h"
 #include "ssba_device.h"
+#include "ssba_posefactor_device.h"
 
 namespace ssba {
 
@@ -145,10 +146,25 @@ __global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][i] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 27) {
-        const double v = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (threadIdx.x < 28) {
+        double v = threadIdx.x < 27 ? sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x] : 0.0;
+        if (d.n_pf) {
+            // unary residual blocks of this pose (pose prior, sun sensor): every one of the 28 lanes evaluates them
+            // and takes its own entry of J^T J (21), J^T r (6) or the cost (lane 27)
+            int a = 0, c = 0;
+            if (threadIdx.x < 21) { int n = threadIdx.x; while (n >= 6 - a) { n -= 6 - a; ++a; } c = a + n; }
+            for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
+                double r[6], J[36];
+                int dim;
+                const double cost = pf_evaluate(d, (int)e, T, r, J, &dim);
+                if (threadIdx.x < 21) { for (int m = 0; m < dim; ++m) v += J[6 * m + a] * J[6 * m + c]; }
+                else if (threadIdx.x < 27) { for (int m = 0; m < dim; ++m) v += J[6 * m + (threadIdx.x - 21)] * r[m]; }
+                else v += cost;
+            }
+        }
         if (threadIdx.x < 21) d.hpp[(size_t)k * 21 + threadIdx.x] = v;
-        else d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
+        else if (threadIdx.x < 27) d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
+        else if (d.n_pf) d.pf_cost[k] = v;
     }
 }
 
@@ -562,7 +578,7 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
     if (st.terminated) return;
     __shared__ double sm[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    double dn = 0.0, nonfinite = 0.0;
+    double dn = 0.0, nonfinite = 0.0, pf_cc = 0.0, pf_mcc = 0.0;
     if (k < d.P) {
         const int f = d.pose_free[k];
         const double *T = d.poses + (size_t)k * 12;
@@ -577,6 +593,18 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
                 if (!isfinite(eps[c])) nonfinite = 1.0;
             }
             se3_plus(T, eps, Tn);
+            if (d.n_pf)     // unary residual blocks: model cost change at x, cost at the candidate
+                for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
+                    double r[6], J[36], rc[6];
+                    int dim;
+                    pf_evaluate(d, (int)e, T, r, J, &dim);
+                    for (int m = 0; m < dim; ++m) {
+                        double jd = 0.0;
+                        for (int c = 0; c < 6; ++c) jd += J[6 * m + c] * eps[c];
+                        pf_mcc -= jd * (r[m] + 0.5 * jd);
+                    }
+                    pf_cc += pf_evaluate(d, (int)e, Tn, rc, nullptr, &dim);
+                }
             // partitioned solve: the separator poses are updated by both neighbouring ranks, counted once
             const bool owned = !d.part || (f >= (d.rank == 0 ? d.chain0 : d.chain0 + 1) * SBP && f < (d.chain1 + 1) * SBP);
 #pragma unroll
@@ -592,9 +620,12 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
     }
     const double a = block_sum(dn, sm);
     const double b = block_sum(nonfinite, sm);
+    const double c2 = block_sum(pf_cc, sm), c3 = block_sum(pf_mcc, sm);
     if (threadIdx.x == 0) {
-        d.part_pose[blockIdx.x * 2] = a;
-        d.part_pose[blockIdx.x * 2 + 1] = b;
+        d.part_pose[blockIdx.x * NPP] = a;
+        d.part_pose[blockIdx.x * NPP + 1] = b;
+        d.part_pose[blockIdx.x * NPP + 2] = c2;
+        d.part_pose[blockIdx.x * NPP + 3] = c3;
     }
 }
 
@@ -699,7 +730,7 @@ __global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
     if (st.terminated || st.dl_reuse) return;
     __shared__ double sm[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
-    double gsq = 0.0, nsq = 0.0, dot = 0.0;
+    double gsq = 0.0, nsq = 0.0, dot = 0.0, pjv = 0.0, pjg = 0.0, pvg = 0.0;
     if (k < d.P) {
         const int f = d.pose_free[k];
 #pragma unroll
@@ -716,11 +747,23 @@ __global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
             }
             d.vp[(size_t)k * 6 + c] = v;
         }
+        if (d.n_pf && f >= 0)      // rows of the unary residual blocks in |J v|^2, |J gn|^2, (J v).(J gn)
+            for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
+                double r[6], J[36];
+                int dim;
+                pf_evaluate(d, (int)e, d.poses + (size_t)k * 12, r, J, &dim);
+                for (int m = 0; m < dim; ++m) {
+                    double jv = 0.0, jg = 0.0;
+                    for (int c = 0; c < 6; ++c) { jv += J[6 * m + c] * d.vp[(size_t)k * 6 + c]; jg += J[6 * m + c] * d.x0[(size_t)f * 6 + c]; }
+                    pjv += jv * jv; pjg += jg * jg; pvg += jv * jg;
+                }
+            }
     }
     const double a = block_sum(gsq, sm), b = block_sum(nsq, sm), c = block_sum(dot, sm);
+    const double e3 = block_sum(pjv, sm), e4 = block_sum(pjg, sm), e5 = block_sum(pvg, sm);
     if (threadIdx.x == 0) {
         double *o = d.part_dl + (size_t)(d.n_lm_blocks + blockIdx.x) * NDL;
-        o[0] = a; o[1] = b; o[2] = c; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = e3; o[4] = e4; o[5] = e5;
     }
 }
 
@@ -1020,6 +1063,8 @@ __global__ __launch_bounds__(256) void k_reduce_lin(Dev d) {
         b += d.part_lin[i * 4 + 1];
         c = fmax(c, d.part_lin[i * 4 + 2]);
     }
+    if (d.n_pf)
+        for (int k = threadIdx.x; k < d.P; k += 256) a += d.pf_cost[k];     // unary pose residual blocks
     a = block_sum(a, sm);
     b = block_sum(b, sm);
     c = block_max(c, sm);
@@ -1061,18 +1106,21 @@ __global__ __launch_bounds__(256) void k_decide(Dev d) {
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
-    double a = 0.0, b = 0.0;
+    double a = 0.0, b = 0.0, pcc = 0.0, pmc = 0.0;
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) {   // last entry: border of shared blocks
-        a += d.part_pose[i * 2];
-        b += d.part_pose[i * 2 + 1];
+        a += d.part_pose[i * NPP];
+        b += d.part_pose[i * NPP + 1];
+        if (d.n_pf && i < d.n_pose_blocks) { pcc += d.part_pose[i * NPP + 2]; pmc += d.part_pose[i * NPP + 3]; }
     }
     a = block_sum(a, sm);
     b = block_sum(b, sm);
+    pcc = block_sum(pcc, sm);
+    pmc = block_sum(pmc, sm);
     if (threadIdx.x != 0) return;
     if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_eval_add_pose), summed over ranks
     const Options &o = st.opt;
-    const double candidate_cost_raw = d.scal2[0];
-    const double mcc = d.scal2[1];
+    const double candidate_cost_raw = d.scal2[0] + pcc;      // + unary pose residual blocks
+    const double mcc = d.scal2[1] + pmc;
     const double step_norm = sqrt(d.scal2[2] + a);
     const bool finite_step = (d.scal2[3] + b) == 0.0 && !st.step_failed;
     st.model_cost_change = mcc;
@@ -1296,7 +1344,7 @@ __global__ __launch_bounds__(256) void k_eval_add_pose(Dev d) {
     if (st.terminated) return;
     __shared__ double sm[4];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) { a += d.part_pose[i * 2]; b += d.part_pose[i * 2 + 1]; }
+    for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) { a += d.part_pose[i * NPP]; b += d.part_pose[i * NPP + 1]; }
     a = block_sum(a, sm);
     b = block_sum(b, sm);
     if (threadIdx.x == 0) { d.scal2[2] += a; d.scal2[3] += b; }

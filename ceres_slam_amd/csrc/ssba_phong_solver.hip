@@ -837,8 +837,8 @@ __global__ void k_ph_border_update(Dev d) {
         }
         for (int i = 0; i < d.nsh; ++i) { const double df = d.cand_sh[i] - d.sh[i]; dn += df * df; }
     }
-    d.part_pose[d.n_pose_blocks * 2] = dn;
-    d.part_pose[d.n_pose_blocks * 2 + 1] = bad;
+    d.part_pose[d.n_pose_blocks * NPP] = dn;
+    d.part_pose[d.n_pose_blocks * NPP + 1] = bad;
 }
 
 // ------------------------------------------------------------------ dogleg (config 3) ---
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d) {
         pmax = fmax(pmax, fabs(dpc));
         pgd += d.xv[d.off_gp + i] * dpc;
     }
-    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) pbad += d.part_pose[i * 2 + 1];
+    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) pbad += d.part_pose[i * NPP + 1];
     const double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
     const double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
     const double qmax = block_max(pmax, sm), qgd = block_sum(pgd, sm), qbad = block_sum(pbad, sm);

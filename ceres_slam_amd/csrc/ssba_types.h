@@ -34,6 +34,7 @@ constexpr int MAX_SEP = 65;             // separators = ranks + 1
 constexpr int NSCAL = 16;
 constexpr int NBP = 32;                 // padded width of the border of free shared blocks (nb <= NBP)
 constexpr int NBQ = 7;                  // border entries one intensity row touches: [phong 3 | kd | light 3]
+constexpr int NPP = 4;                  // pose partials per block: |dx|^2, non-finite, unary-factor candidate cost, unary-factor model change
 constexpr int NDL = 6;                  // dogleg partials: |gradient_|^2, |gn|^2, gradient_.gn, |J v|^2, |J gn|^2, Jv.Jgn
 constexpr int NBV = 49;                 // per-landmark border sums: S_bb part 28 | rhs_b 7 | diag H_bb 7 | g_b 7
 
@@ -175,6 +176,12 @@ struct Dev {
     double blo[4], bhi[4];
     double *part_ls;                                // n_lm_blocks * NLS line-search partials
     double *ls_out;                                 // NLS_OUT scalars the host reads per probe
+    // unary pose residual blocks (pose prior, sun sensor), sorted by pose
+    int n_pf, pad3_;
+    const uint32_t *pf_start;                       // P+1
+    const int *pf_type;                             // F
+    const double *pf_data, *pf_S, *pf_huber;        // F*18, F*36, F
+    double *pf_cost;                                // P: cost of the factors of each pose at the linearisation point
 };
 constexpr int NLS = 6;        // per block: cost, phi', |dx_l|^2, nonfinite, max|delta_l|, g_l . delta_l
 constexpr int NLS_OUT = 8;    // cost, phi', |dx_l|^2, nonfinite_l, max|delta|, g . delta, valid, x_cost

@@ -16,7 +16,7 @@ class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
                  stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
                  world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0, use_bounds: bool = False,
-                 partition=None):
+                 partition=None, pose_factors=None):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
         self.points = np.ascontiguousarray(points, dtype=np.float64)
@@ -41,6 +41,17 @@ class StereoBA:
             capi.check(self.lib.ssba_set_pose_constant(self.h, int(k), 1), "ssba_set_pose_constant")
         if huber_a > 0:
             capi.check(self.lib.ssba_set_huber_loss(self.h, float(huber_a)), "ssba_set_huber_loss")
+        for f in (pose_factors or []):      # dicts as for oracle.OracleProblem: pose, type (0 prior / 1 sun), data, stiffness, huber
+            dat = np.ascontiguousarray(f["data"], dtype=np.float64).ravel()
+            S = np.ascontiguousarray(f["stiffness"], dtype=np.float64).ravel()
+            if f["type"] == 0:
+                capi.check(self.lib.ssba_add_pose_prior(self.h, int(f["pose"]), capi.dptr(dat), capi.dptr(S), float(f.get("huber", 0.0))),
+                           "ssba_add_pose_prior")
+            else:
+                obs, exp = np.ascontiguousarray(dat[:3]), np.ascontiguousarray(dat[3:6])
+                capi.check(self.lib.ssba_add_sun_observation(self.h, int(f["pose"]), capi.dptr(obs), capi.dptr(exp), capi.dptr(S),
+                                                             float(dat[6]), float(dat[7]), float(f.get("huber", 0.0))),
+                           "ssba_add_sun_observation")
         self._xcb = None
         self.normals = None
         self.shared_free = int(shared_free)

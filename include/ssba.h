@@ -302,6 +302,20 @@ int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *po
                         double *r_int, double *J_int, double *r_nrm, double *J_nrm_pose,
                         double *J_nrm_n);
 
+/* ---- unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124) ------- */
+/* ssba_add_pose_prior replaces problem.AddResidualBlock(PoseErrorAutomatic::Create(T_k_0_ref, stiffness), loss,
+ *   pose) (include/ceres_slam/pose_error.hpp:22-55; dataset_vo_sun.cpp:116-118): r = stiffness * log(T_ref T^-1) with
+ *   the reference's log = [translation ; axis-angle] (se3group.hpp:337-342), 6 residuals; stiffness 6x6 row-major.
+ * ssba_add_sun_observation replaces AddResidualBlock(SunSensorErrorAutomatic::Create(observed_dir_c, expected_dir_g,
+ *   stiffness, az_err_thresh, zen_err_thresh), loss, pose) (sun_sensor_error.hpp:35-104; dataset_vo_sun.cpp:80-99):
+ *   azimuth / zenith of R * expected_dir_g against the observation, wrap-around, outlier thresholds; 2 residuals;
+ *   stiffness 2x2 row-major.  huber_a > 0 wraps the block in ceres::HuberLoss(huber_a) (:87-92), 0 = NULL loss.
+ * Both before ssba_finalize; not on constant poses; not together with lighting terms or landmark sharding yet. */
+int ssba_add_pose_prior(ssba_problem *p, uint32_t pose, const double T_ref[12], const double stiffness[36], double huber_a);
+int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observed_dir_c[3],
+                             const double expected_dir_g[3], const double stiffness[4], double az_err_thresh,
+                             double zen_err_thresh, double huber_a);
+
 /* ---- front end: the VO initial guess --------------------------------- */
 /* ssba_frontend_ransac replaces, for `num_pairs` pairs of consecutive states at once,
  *   PointCloudAligner::compute_transformation_and_inliers (src/ceres_slam/point_cloud_aligner.cpp:64-136)

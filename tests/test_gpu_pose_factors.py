@@ -1,0 +1,65 @@
+"""Row N4 on the GPU: unary pose residual blocks (pose prior, sun sensor) of tests/dataset_vo_sun.cpp:80-124 through the
+C ABI against the oracle: LM step, whole solves with the driver's SUBSPACE_DOGLEG setting, Huber on the sun blocks,
+no constant pose (the prior anchors the window)."""
+import numpy as np
+import pytest
+
+from ceres_slam_amd import capi, synth
+from ceres_slam_amd.solver import StereoBA
+from oracle import oracle as orc
+from test_oracle_pose_factors import _sun_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _pair(prob, factors):
+    none_const = np.zeros(prob.num_poses, dtype=np.uint8)
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                  pose_const=none_const, pose_factors=factors)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_const=none_const, pose_factors=factors)
+    return ba, op
+
+
+@pytest.mark.parametrize("huber", [0.0, 0.5])
+@pytest.mark.parametrize("radius", [1e4, 20.0])
+def test_lm_step_with_pose_factors_matches_oracle(huber, radius):
+    prob, factors = _sun_problem(huber=huber)
+    ba, op = _pair(prob, factors)
+    S, rhs, dp, dl, mcc = ba.lm_step(radius)
+    S2, rhs2, _ = op.reduced_system(radius)
+    dp2, dl2, mcc2 = op.lm_step(radius)
+    assert _rel(S, S2) < 1e-9 and _rel(rhs, rhs2) < 1e-9
+    assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7
+    assert mcc == pytest.approx(mcc2, rel=1e-8)
+    assert ba.evaluate()[0] == pytest.approx(op.cost(), rel=1e-12)
+
+
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("huber", [0.0, 0.5])
+def test_sun_aided_solve_matches_oracle(strategy, huber):
+    prob, factors = _sun_problem(P=30, L=1500, seed=5, huber=huber)
+    ba, op = _pair(prob, factors)
+    kw = dict(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    s, log = ba.solve(capi.default_options(**kw))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, **kw))
+    assert s.termination_type == s2.termination_type == 0
+    n = min(len(log["cost"]), len(log2["cost"]), 12)
+    assert log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-5)
+    assert np.abs(ba.poses - op.poses).max() < 1e-4
+    assert np.abs(ba.poses[0] - prob.poses_init[0]).max() < 0.02       # the prior holds the first pose
+
+
+def test_pose_factor_restrictions():
+    prob, factors = _sun_problem()
+    with pytest.raises(capi.SsbaError):           # default pose_const holds pose 0 constant: the prior would sit on it
+        StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                 prob.stiffness(), pose_factors=factors)
