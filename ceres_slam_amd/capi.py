@@ -35,6 +35,7 @@ SYMBOLS = [
     "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation",
+    "ssba_pose_covariance",
 ]
 
 
@@ -138,6 +139,7 @@ def load():
     L.ssba_add_lighting_observations.argtypes = [H, _dp, C.c_double, _dp, _dp, C.c_uint64]
     L.ssba_add_pose_prior.argtypes = [H, C.c_uint32, _dp, _dp, C.c_double]
     L.ssba_add_sun_observation.argtypes = [H, C.c_uint32, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double]
+    L.ssba_pose_covariance.argtypes = [H, C.c_uint32, _dp]
     L.ssba_ransac_samples.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _u32p]
     L.ssba_frontend_ransac.argtypes = [C.POINTER(Camera), C.c_int, C.c_uint32, _u32p, _dp, _dp, _u32p, C.c_uint32, C.c_double, _dp,
                                        C.POINTER(C.c_uint8), _u32p, _dp]

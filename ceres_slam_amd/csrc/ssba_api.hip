@@ -1535,7 +1535,14 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
     double sc[NSCAL];
     HIPCHECK(hipMemcpy(sc, d.scal2, sizeof sc, hipMemcpyDeviceToHost));
     if (p->h_state->step_failed || sc[3] != 0.0) return SSBA_ERR_NUMERICAL_FAILURE;
-    if (model_cost_change) *model_cost_change = sc[1];
+    if (model_cost_change) {
+        *model_cost_change = sc[1];
+        if (d.n_pf) {     // rows of the unary pose residual blocks (summed by k_decide in a solve)
+            std::vector<double> pp((size_t)d.n_pose_blocks * NPP);
+            HIPCHECK(hipMemcpy(pp.data(), d.part_pose, pp.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int i = 0; i < d.n_pose_blocks; ++i) *model_cost_change += pp[(size_t)i * NPP + 3];
+        }
+    }
     if (delta_p) {
         std::vector<double> x((size_t)d.nf_pad * 6);
         HIPCHECK(hipMemcpy(x.data(), d.x0, x.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1565,6 +1572,54 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
             for (int c = 0; c < 3; ++c) delta_l[3 * (size_t)j + c] = a[c * Lp + l] - b[c * Lp + l];
         }
     }
+    return SSBA_OK;
+}
+
+// ceres::Covariance::Compute + GetCovarianceBlockInTangentSpace for one pose block (tests/dataset_vo_sun.cpp:159-183):
+// the pose's 6x6 block of (J^T J)^-1 in local coordinates = the same block of the inverse of the (undamped) reduced
+// camera system.  Six unit right-hand sides go through the block-cyclic-reduction factors of S.
+int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
+    if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    if (p->d.part || p->d.phong) { set_error("covariance: not available on partitioned problems or with lighting terms"); return SSBA_ERR_UNSUPPORTED; }
+    const int f = p->pose_free[pose];
+    if (f < 0) { set_error("covariance of a constant pose"); return SSBA_ERR_INVALID_ARGUMENT; }
+    Dev &d = p->d;
+    int rc;
+    if (!d.Spb) {      // multi-right-hand-side buffers are only allocated with a border: add them now
+        drop_graph(p);
+        if ((rc = dzero(p, &d.Spb, (size_t)d.nf_pad * 6 * NBP))) return rc;
+        if ((rc = dzero(p, &d.Zb, (size_t)d.nf_pad * 6 * NBP))) return rc;
+        for (int l = 0; l < d.n_levels; ++l)
+            if ((rc = dzero(p, &d.lev[l].B, (size_t)d.lev[l].n * BD * NBP))) return rc;
+        if (configure_border()) { set_error("hipFuncSetAttribute(border kernels) failed"); return SSBA_ERR_HIP; }
+    }
+    ssba_options o;
+    ssba_default_options(&o);
+    rc = begin_hook(p, &o, 1e300);        // radius -> infinity: no Levenberg-Marquardt damping in S
+    if (rc) return rc;
+    Launcher &L = p->launcher;
+    launch_linearize(L, d);
+    launch_schur(L, d);
+    launch_finish_check(L, d);
+    launch_bcr(L, d);
+    HIPCHECK(hipMemsetAsync(d.Spb, 0, (size_t)d.nf_pad * 6 * NBP * sizeof(double), L.stream));
+    {
+        std::vector<double> unit((size_t)6 * NBP, 0.0);
+        for (int c = 0; c < 6; ++c) unit[(size_t)c * NBP + c] = 1.0;
+        HIPCHECK(hipMemcpyAsync(d.Spb + (size_t)f * 6 * NBP, unit.data(), unit.size() * sizeof(double), hipMemcpyHostToDevice, L.stream));
+        HIPCHECK(hipStreamSynchronize(L.stream));
+    }
+    launch_bcr_multi_rhs(L, d);
+    HIPCHECK(hipStreamSynchronize(L.stream));
+    HIPCHECK(hipGetLastError());
+    if ((rc = fetch_state(p))) return rc;
+    if (p->h_state->step_failed) { set_error("covariance: the reduced camera system is not positive definite (gauge freedom?)"); return SSBA_ERR_NUMERICAL_FAILURE; }
+    std::vector<double> z((size_t)6 * NBP);
+    HIPCHECK(hipMemcpy(z.data(), d.Zb + (size_t)f * 6 * NBP, z.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) cov[6 * r + c] = z[(size_t)r * NBP + c];
+    HIPCHECK(hipMemsetAsync(d.Spb, 0, (size_t)d.nf_pad * 6 * NBP * sizeof(double), L.stream));
     return SSBA_OK;
 }
 

@@ -290,6 +290,21 @@ int configure_border() {
     return 0;
 }
 
+// Z = S_pp^-1 B for the NBP columns in d.Spb, through the level factors launch_bcr has left in place
+void launch_bcr_multi_rhs(Launcher &L, const Dev &d) {
+    const int nl = d.n_levels;
+    hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
+    for (int l = 0; l + 1 < nl; ++l) {
+        const int n = d.lev[l].n;
+        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0);
+        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l);
+    }
+    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1);
+    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1);
+    for (int l = nl - 2; l >= 0; --l)
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0);
+}
+
 // after launch_bcr: x0 = S_pp^-1 (-g_p^) and the level factors are in place
 void launch_border_solve(Launcher &L, const Dev &d) {
     const int nl = d.n_levels;

@@ -122,5 +122,6 @@ void launch_ph_ls_accept(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();
 void launch_border_solve(Launcher &L, const Dev &d);
+void launch_bcr_multi_rhs(Launcher &L, const Dev &d);
 
 }  // namespace ssba

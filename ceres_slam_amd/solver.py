@@ -209,6 +209,12 @@ class StereoBA:
                                           capi.dptr(H_ll)), "ssba_evaluate")
         return cost.value, g_p, g_l, H_pp, H_ll
 
+    def pose_covariance(self, pose: int) -> np.ndarray:
+        """6x6 block of (J^T J)^-1 of one pose in tangent space (ceres::Covariance, tests/dataset_vo_sun.cpp:159-183)."""
+        cov = np.zeros((6, 6))
+        capi.check(self.lib.ssba_pose_covariance(self.h, int(pose), capi.dptr(cov)), "ssba_pose_covariance")
+        return cov
+
     def border_system(self):
         """Border blocks of the last lm_step (free shared blocks): S_pb, S_bb (damped), rhs_b, delta_b."""
         nb = C.c_uint32()

@@ -316,6 +316,12 @@ int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observ
                              const double expected_dir_g[3], const double stiffness[4], double az_err_thresh,
                              double zen_err_thresh, double huber_a);
 
+/* ssba_pose_covariance replaces ceres::Covariance::Compute + GetCovarianceBlockInTangentSpace for one pose block
+ * (tests/dataset_vo_sun.cpp:159-183): cov (6x6 row-major) = that pose's block of (J^T J)^-1 in local (tangent)
+ * coordinates at the caller's current parameters, i.e. of the inverse of the undamped reduced camera system.
+ * SSBA_ERR_NUMERICAL_FAILURE when the system is rank deficient (Ceres: "Covariance computation failed"). */
+int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]);
+
 /* ---- front end: the VO initial guess --------------------------------- */
 /* ssba_frontend_ransac replaces, for `num_pairs` pairs of consecutive states at once,
  *   PointCloudAligner::compute_transformation_and_inliers (src/ceres_slam/point_cloud_aligner.cpp:64-136)

@@ -58,6 +58,31 @@ def test_sun_aided_solve_matches_oracle(strategy, huber):
     assert np.abs(ba.poses[0] - prob.poses_init[0]).max() < 0.02       # the prior holds the first pose
 
 
+@pytest.mark.parametrize("P", [8, 30])
+def test_pose_covariance_block_matches_dense_inverse(P):
+    """The prior for the next window (dataset_vo_sun.cpp:159-183): covariance of pose k1+1 in tangent space after the solve."""
+    prob, factors = _sun_problem(P=P, L=60 * P, seed=7)
+    ba, op = _pair(prob, factors)
+    ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    op.poses[:], op.points[:] = ba.poses, ba.points
+    S, rhs, free_idx = op.reduced_system(1e300)          # undamped reduced camera system at the solution
+    Sinv = np.linalg.inv(S)
+    for k in (1, P // 2, P - 1):
+        f = int(free_idx[k])
+        cov = ba.pose_covariance(k)
+        ref = Sinv[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]
+        assert _rel(cov, ref) < 1e-7
+        assert np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
+    # without the prior and the sun blocks nothing fixes the gauge: the reduced system is singular
+    ba2 = StereoBA(prob.camera, ba.poses.copy(), ba.points.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                   pose_const=np.zeros(P, dtype=np.uint8))
+    try:
+        c = ba2.pose_covariance(1)
+        assert np.abs(c).max() > 1e6         # numerically singular: enormous variances if the factorisation survives
+    except capi.SsbaError:
+        pass
+
+
 def test_pose_factor_restrictions():
     prob, factors = _sun_problem()
     with pytest.raises(capi.SsbaError):           # default pose_const holds pose 0 constant: the prior would sit on it
