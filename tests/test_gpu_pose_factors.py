@@ -67,11 +67,15 @@ def test_pose_covariance_block_matches_dense_inverse(P):
     op.poses[:], op.points[:] = ba.poses, ba.points
     S, rhs, free_idx = op.reduced_system(1e300)          # undamped reduced camera system at the solution
     Sinv = np.linalg.inv(S)
+    Sg = ba.lm_step(1e300)[0]                             # the device's own assembly of the same system
+    Sginv = np.linalg.inv(Sg)
+    assert _rel(Sg, S) < 1e-9
     for k in (1, P // 2, P - 1):
         f = int(free_idx[k])
         cov = ba.pose_covariance(k)
-        ref = Sinv[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]
-        assert _rel(cov, ref) < 1e-7
+        # the gauge is only held by the prior: cond(S) ~ 1e9, so 1e-12 differences of the two assemblies show at 1e-4
+        assert _rel(cov, Sginv[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]) < 1e-6
+        assert _rel(cov, Sinv[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]) < 1e-3
         assert np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
     # without the prior and the sun blocks nothing fixes the gauge: the reduced system is singular
     ba2 = StereoBA(prob.camera, ba.poses.copy(), ba.points.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
