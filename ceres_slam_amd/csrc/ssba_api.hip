@@ -515,7 +515,9 @@ int ssba_finalize(ssba_problem *p) {
         }
     const int nfree = (int)p->free_pose.size();
 
-    // per-landmark sorted pose sets; envelope checks
+    // per-landmark sorted pose sets; envelope checks.  The windowed layout needs tracks <= TW and a pose co-visibility
+    // span <= SBP (block-tridiagonal reduced system); anything else takes the general path with a dense reduced system.
+    bool dense = false;
     struct LmInfo { uint32_t j, kmin, kmax; };
     std::vector<LmInfo> order;
     order.reserve(L);
@@ -523,10 +525,7 @@ int ssba_finalize(ssba_problem *p) {
     for (uint32_t j = 0; j < L; ++j) {
         const uint32_t n = lm_start[j + 1] - lm_start[j];
         if (n == 0) continue;
-        if (n > (uint32_t)TW) {
-            set_error("a landmark has more than SSBA_MAX_TRACK observations");
-            return SSBA_ERR_UNSUPPORTED;
-        }
+        if (n > (uint32_t)TW) dense = true;     // longer tracks than the window layout holds: general (dense) path
         auto &ks = lm_poses[j];
         for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) ks.push_back(p->obs_pose[lm_obs[e]]);
         std::sort(ks.begin(), ks.end());
@@ -535,7 +534,19 @@ int ssba_finalize(ssba_problem *p) {
             return SSBA_ERR_UNSUPPORTED;
         }
         order.push_back({j, ks.front(), ks.back()});
+        int flo = 1 << 30, fhi = -1;
+        for (uint32_t k : ks) { const int f = p->pose_free[k]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
+        if (fhi - flo > SBP) dense = true;
     }
+    if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
+    if (dense) {
+        if (ph || p->world_size > 1 || 6 * (size_t)nfree > 8192) {
+            set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
+                      "which is limited to stereo-only single-GPU problems with <= 1365 free poses in this build");
+            return SSBA_ERR_UNSUPPORTED;
+        }
+        std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) { return a.j < b.j; });
+    } else
     std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) {
         if (a.kmin != b.kmin) return a.kmin < b.kmin;
         if (a.kmax != b.kmax) return a.kmax < b.kmax;
@@ -557,7 +568,7 @@ int ssba_finalize(ssba_problem *p) {
             for (uint32_t l = begin; l < end; ++l) lm_win[l] = w;
             begin = end;
         };
-        for (uint32_t l = 0; l < Lact; ++l) {
+        for (uint32_t l = 0; l < Lact && !dense; ++l) {
             const auto &ks = lm_poses[order[l].j];
             merged.clear();
             std::set_union(cur_set.begin(), cur_set.end(), ks.begin(), ks.end(), std::back_inserter(merged));
@@ -568,8 +579,9 @@ int ssba_finalize(ssba_problem *p) {
                 cur_set.swap(merged);
             }
         }
-        if (Lact > 0) close(Lact);
-        win_begin.push_back(Lact);
+        if (Lact > 0 && !dense) close(Lact);
+        win_begin.push_back(dense ? 0 : Lact);
+        if (dense) win_begin.assign(1, 0);
     }
     const uint32_t n_windows = (uint32_t)win_begin.size() - 1;
 
@@ -585,7 +597,66 @@ int ssba_finalize(ssba_problem *p) {
     }
     p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
     std::vector<std::vector<uint32_t>> pose_refs(P);
-    for (uint32_t l = 0; l < Lact; ++l) {
+    // general path: landmark-major observation arrays + the pose-major index list into them
+    std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs;
+    std::vector<double> dn_u, dn_v, dn_d;
+    std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b;
+    if (dense) {
+        dn_lm_start.assign(Lpad + 1, 0);
+        for (uint32_t l = 0; l < Lact; ++l) {
+            const uint32_t j = order[l].j;
+            p->user_of_dev[l] = j;
+            lm_mask[l] = 1u;
+            for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
+                const uint32_t i = lm_obs[e];
+                dn_obs_pose.push_back(p->obs_pose[i]);
+                dn_obs_lm.push_back(l);
+                dn_u.push_back(p->obs_uvd[3 * (size_t)i]); dn_v.push_back(p->obs_uvd[3 * (size_t)i + 1]); dn_d.push_back(p->obs_uvd[3 * (size_t)i + 2]);
+            }
+            dn_lm_start[l + 1] = (uint32_t)dn_obs_pose.size();
+        }
+        for (uint32_t l = Lact; l < Lpad; ++l) dn_lm_start[l + 1] = dn_lm_start[Lact];
+        dn_pose_start.assign(P + 1, 0);
+        for (uint32_t q : dn_obs_pose) dn_pose_start[q + 1]++;
+        for (uint32_t k = 0; k < P; ++k) dn_pose_start[k + 1] += dn_pose_start[k];
+        dn_pose_obs.resize(dn_obs_pose.size());
+        std::vector<uint32_t> cur2(dn_pose_start.begin(), dn_pose_start.end() - 1);
+        for (uint32_t i = 0; i < dn_obs_pose.size(); ++i) dn_pose_obs[cur2[dn_obs_pose[i]]++] = i;
+        // blocks (a <= b) of S = H_pp - sum_l Y_l W_l^T and, per block, the observation pairs (ea, eb) of one
+        // landmark that contribute Y_ea W_eb^T; sorted by block so that one wave owns one block (no atomics)
+        struct Pr { uint32_t a, b, ea, eb; };
+        std::vector<Pr> prs;
+        uint64_t npairs = 0;
+        for (uint32_t l = 0; l < Lact; ++l) { const uint64_t n = dn_lm_start[l + 1] - dn_lm_start[l]; npairs += n * (n + 1) / 2; }
+        if (npairs > (1ull << 28)) { set_error("general-structure path: too many co-visibility pairs"); return SSBA_ERR_UNSUPPORTED; }
+        prs.reserve((size_t)npairs + nfree);
+        for (int f = 0; f < nfree; ++f) prs.push_back({(uint32_t)f, (uint32_t)f, 0xFFFFFFFFu, 0xFFFFFFFFu});   // every free pose has its diagonal block
+        for (uint32_t l = 0; l < Lact; ++l)
+            for (uint32_t ea = dn_lm_start[l]; ea < dn_lm_start[l + 1]; ++ea) {
+                const int fa = p->pose_free[dn_obs_pose[ea]];
+                if (fa < 0) continue;
+                for (uint32_t eb = dn_lm_start[l]; eb < dn_lm_start[l + 1]; ++eb) {
+                    const int fb = p->pose_free[dn_obs_pose[eb]];
+                    if (fb < fa) continue;       // fb == fa keeps both orders of a repeated (pose, landmark) pair
+                    prs.push_back({(uint32_t)fa, (uint32_t)fb, ea, eb});
+                }
+            }
+        std::sort(prs.begin(), prs.end(), [](const Pr &x, const Pr &y) {
+            if (x.a != y.a) return x.a < y.a;
+            if (x.b != y.b) return x.b < y.b;
+            if (x.ea != y.ea) return x.ea < y.ea;
+            return x.eb < y.eb;
+        });
+        for (size_t i = 0; i < prs.size(); ++i) {
+            if (i == 0 || prs[i].a != prs[i - 1].a || prs[i].b != prs[i - 1].b) {
+                dn_blk_a.push_back(prs[i].a); dn_blk_b.push_back(prs[i].b);
+                dn_blk_start.push_back((uint32_t)dn_pair_a.size());
+            }
+            if (prs[i].ea != 0xFFFFFFFFu) { dn_pair_a.push_back(prs[i].ea); dn_pair_b.push_back(prs[i].eb); }
+        }
+        dn_blk_start.push_back((uint32_t)dn_pair_a.size());
+    }
+    for (uint32_t l = 0; l < Lact && !dense; ++l) {
         const uint32_t j = order[l].j, w = lm_win[l];
         p->user_of_dev[l] = j;
         if (ph) lm_mat[l] = p->ph_mat_of_point[j];
@@ -677,7 +748,7 @@ int ssba_finalize(ssba_problem *p) {
             if (f >= 0) prow.push_back({(uint32_t)f, it * TW + (uint32_t)s});
         }
     }
-    if (bandwidth > (uint32_t)SBP) {
+    if (bandwidth > (uint32_t)SBP) {      // cannot happen: such problems took the dense path above
         set_error("pose co-visibility bandwidth exceeds the block-tridiagonal envelope of this build");
         return SSBA_ERR_UNSUPPORTED;
     }
@@ -912,6 +983,19 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.pf_data, data)); TRY(dupload(p, &d.pf_S, S)); TRY(dupload(p, &d.pf_huber, hub));
         TRY(dzero(p, &d.pf_cost, (size_t)P));
     }
+    if (dense) {
+        d.dense = 1;
+        d.n_dn = 6 * nfree;
+        d.dn_pad = (d.n_dn + DN_BS - 1) / DN_BS * DN_BS;
+        d.dn_nblk = (int)dn_blk_a.size();
+        TRY(dupload(p, &d.dn_blk_a, dn_blk_a)); TRY(dupload(p, &d.dn_blk_b, dn_blk_b)); TRY(dupload(p, &d.dn_blk_start, dn_blk_start));
+        TRY(dupload(p, &d.dn_pair_a, dn_pair_a)); TRY(dupload(p, &d.dn_pair_b, dn_pair_b));
+        TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
+        TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
+        TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs));
+        TRY(dzero(p, &d.dn_W, dn_obs_pose.size() * 18)); TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * 18));
+        TRY(dzero(p, &d.dn_S, (size_t)(d.dn_pad + DN_BS) * std::max(d.dn_pad, DN_BS)));
+    }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
     TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * NPP));   // + one entry for the border of shared blocks
@@ -939,6 +1023,12 @@ int ssba_finalize(ssba_problem *p) {
     p->stats.num_observations = N; p->stats.num_windows = n_windows;
     p->stats.num_superblocks = (uint32_t)d.Nsb; p->stats.num_reduced_blocks = n_sblk;
     p->stats.pose_bandwidth = bandwidth;
+    p->stats.general_structure = dense ? 1u : 0u;
+    p->stats.reserved = 0;
+    if (dense) {      // the dense reduced system: its non-zero blocks and the real co-visibility span
+        p->stats.num_reduced_blocks = (uint32_t)dn_blk_a.size();
+        for (size_t i = 0; i < dn_blk_a.size(); ++i) p->stats.pose_bandwidth = std::max(p->stats.pose_bandwidth, dn_blk_b[i] - dn_blk_a[i]);
+    }
     p->finalized = true;
     return SSBA_OK;
 }
@@ -1151,14 +1241,14 @@ static int enqueue_front(ssba_problem *p) {
         if ((rc = X(d.scal2, NSCAL, 0))) return rc;
         return SSBA_OK;
     }
-    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d); launch_schur(L, d); }))) return rc;
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d); }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if ((rc = X(d.gmax_l, 1, 1))) return rc;
     }
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
             launch_finish_check(L, d);
-            launch_bcr(L, d);
+            if (d.dense) launch_dense_solve(L, d); else launch_bcr(L, d);
             if (d.nb) launch_border_solve(L, d);
             if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
             else launch_update_eval(L, d);
@@ -1497,12 +1587,19 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
     Dev &d = p->d;
     Launcher &L = p->launcher;
     launch_linearize(L, d);
-    launch_schur(L, d);
+    if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d);
     launch_finish_check(L, d);
     HIPCHECK(hipStreamSynchronize(L.stream));
     HIPCHECK(hipGetLastError());
     const int nf = d.nfree, n = 6 * nf;
-    if (S || rhs) {
+    if ((S || rhs) && d.dense) {      // lower triangle + the right-hand-side row of the dense matrix
+        std::vector<double> M((size_t)(d.dn_pad + 1) * d.dn_pad);
+        if (!M.empty()) HIPCHECK(hipMemcpy(M.data(), d.dn_S, M.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (S)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j <= i; ++j) S[(size_t)i * n + j] = S[(size_t)j * n + i] = M[(size_t)i * d.dn_pad + j];
+        if (rhs) for (int i = 0; i < n; ++i) rhs[i] = M[(size_t)d.dn_pad * d.dn_pad + i];
+    } else if (S || rhs) {
         const size_t blk = (size_t)BD * BD;
         std::vector<double> D((size_t)d.Nsb * blk), Lb((size_t)d.Nsb * blk), r((size_t)d.Nsb * BD);
         HIPCHECK(hipMemcpy(D.data(), d.xv + d.off_D, D.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1525,7 +1622,7 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
         }
         if (rhs) for (int i = 0; i < n; ++i) rhs[i] = r[i];
     }
-    launch_bcr(L, d);
+    if (d.dense) launch_dense_solve(L, d); else launch_bcr(L, d);
     if (d.nb) launch_border_solve(L, d);
     launch_update_eval(L, d);
     HIPCHECK(hipStreamSynchronize(L.stream));
@@ -1581,7 +1678,10 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
 int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
-    if (p->d.part || p->d.phong) { set_error("covariance: not available on partitioned problems or with lighting terms"); return SSBA_ERR_UNSUPPORTED; }
+    if (p->d.part || p->d.phong || p->d.dense) {
+        set_error("covariance: not available on partitioned problems, with lighting terms or on the general-structure path");
+        return SSBA_ERR_UNSUPPORTED;
+    }
     const int f = p->pose_free[pose];
     if (f < 0) { set_error("covariance of a constant pose"); return SSBA_ERR_INVALID_ARGUMENT; }
     Dev &d = p->d;

@@ -42,12 +42,39 @@ int upload_pair_table(hipStream_t s) {
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
 
+// Observations of one landmark.  Windowed layout (DN = false): TW slots of the landmark's window in the
+// transposed ELL arrays, present where the mask bit is set.  General layout (DN = true, ssba_dense.hip):
+// the landmark's contiguous range of the landmark-major observation arrays.
+template <bool DN> struct LmObs;
+template <> struct LmObs<false> {
+    uint32_t mask, win;
+    size_t obase;
+    __device__ __forceinline__ LmObs(const Dev &d, int l, uint32_t m)
+        : mask(m), win(d.lm_win[l]), obase((size_t)(l >> 6) * (TW * LMG) + (l & 63)) {}
+    __device__ __forceinline__ int count() const { return TW; }
+    __device__ __forceinline__ bool has(int s) const { return (mask >> s) & 1u; }
+    __device__ __forceinline__ uint32_t pose(const Dev &d, int s) const { return d.win_pose[win * TW + s]; }
+    __device__ __forceinline__ double u(const Dev &d, int s) const { return d.ou[obase + s * LMG]; }
+    __device__ __forceinline__ double v(const Dev &d, int s) const { return d.ov[obase + s * LMG]; }
+    __device__ __forceinline__ double dd(const Dev &d, int s) const { return d.od[obase + s * LMG]; }
+};
+template <> struct LmObs<true> {
+    uint32_t b, n;
+    __device__ __forceinline__ LmObs(const Dev &d, int l, uint32_t) : b(d.dn_lm_start[l]), n(d.dn_lm_start[l + 1] - d.dn_lm_start[l]) {}
+    __device__ __forceinline__ int count() const { return (int)n; }
+    __device__ __forceinline__ bool has(int) const { return true; }
+    __device__ __forceinline__ uint32_t pose(const Dev &d, int s) const { return d.dn_obs_pose[b + s]; }
+    __device__ __forceinline__ double u(const Dev &d, int s) const { return d.dn_u[b + s]; }
+    __device__ __forceinline__ double v(const Dev &d, int s) const { return d.dn_v[b + s]; }
+    __device__ __forceinline__ double dd(const Dev &d, int s) const { return d.dn_d[b + s]; }
+};
+
 // ------------------------------------------------------------------ kernels ---
 
 // One lane per landmark.  Streams the ELL observation arrays (coalesced), gathers the
 // (few, shared) pose blocks through L1/L2.  Writes H_ll (6), g_l (3) component-major and
 // per-block partials {cost, |x_l|^2, max|g_l|}.  At iteration 0 also the Jacobi scale.
-__global__ __launch_bounds__(256) void k_linearize_landmarks(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_linearize_landmarks(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     __shared__ double sm[4];
@@ -55,16 +82,15 @@ __global__ __launch_bounds__(256) void k_linearize_landmarks(Dev d) {
     const uint32_t mask = d.lm_mask[l];
     double cost = 0.0, xn = 0.0, gm = 0.0;
     if (mask) {
-        const uint32_t win = d.lm_win[l];
+        const LmObs<DN> ob(d, l, mask);
         const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
         double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < ob.count(); ++s) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jl[9];
             jac_point(o, T, Jl);
             cost += o.half_rho;
@@ -107,7 +133,7 @@ __global__ __launch_bounds__(256) void k_linearize_landmarks(Dev d) {
 // One block per pose: gathers that pose's observations through the pose-major
 // reference list, accumulates the 21 unique entries of H_pp and g_p in registers and
 // reduces them across the block in a fixed order (no float atomics).
-__global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     const int k = blockIdx.x;
@@ -119,14 +145,23 @@ __global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-    const uint32_t b = d.pose_obs_start[k], e = d.pose_obs_start[k + 1];
+    const uint32_t b = DN ? d.dn_pose_start[k] : d.pose_obs_start[k], e = DN ? d.dn_pose_start[k + 1] : d.pose_obs_start[k + 1];
     for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-        const uint32_t ref = d.pose_obs_ref[i];
-        const int l = (int)(ref >> 4), s = (int)(ref & 15u);
-        const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+        int l;
+        double ou, ov, od;
+        if (DN) {
+            const uint32_t oi = d.dn_pose_obs[i];
+            l = (int)d.dn_obs_lm[oi];
+            ou = d.dn_u[oi]; ov = d.dn_v[oi]; od = d.dn_d[oi];
+        } else {
+            const uint32_t ref = d.pose_obs_ref[i];
+            l = (int)(ref >> 4);
+            const int s = (int)(ref & 15u);
+            const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+            ou = d.ou[oi]; ov = d.ov[oi]; od = d.od[oi];
+        }
         ObsLin o;
-        obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], d.ou[oi],
-                      d.ov[oi], d.od[oi], o);
+        obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], ou, ov, od, o);
         double Jp[18];
         jac_pose(o, Jp);
         int n = 0;
@@ -632,7 +667,7 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
 // One lane per landmark: back-substitution delta_l = -C^-1 (g_l + sum_s W_s^T delta_p,s),
 // candidate point, model cost change -(J d)^T (r + J d / 2) and candidate cost, all in
 // one pass over the landmark's observations (second sweep hits L1/L2).
-__global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -642,22 +677,21 @@ __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
     const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
     double nx = px, ny = py, nz = pz;
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const LmObs<DN> ob(d, l, mask);
         const double gl[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
         double tt[3] = {gl[0], gl[1], gl[2]};
         // With e = J_p delta_p of an observation the model cost change -(J d)^T (r + J d / 2) of this landmark's
         // observations is  -(sum e.r + dl.g_l) - (sum e.e + 2 dl.(tt - g_l) + dl^T H_ll dl) / 2 :
         // one linearisation pass instead of two (H_ll and g_l are those of this linearisation point)
         double er = 0.0, ee = 0.0;
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < ob.count(); ++s) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
             const int f = d.pose_free[k];
             if (f < 0) continue;
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jp[18], Jl[9], jd[3];
             jac_pose(o, Jp);
             jac_point(o, T, Jl);
@@ -695,11 +729,10 @@ __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) {
             const double dt = dl[0] * (tt[0] - gl[0]) + dl[1] * (tt[1] - gl[1]) + dl[2] * (tt[2] - gl[2]);
             mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + (dl[0] * hd0 + dl[1] * hd1 + dl[2] * hd2));
         }
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
-            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, d.ou[obase + s * LMG], d.ov[obase + s * LMG],
-                              d.od[obase + s * LMG]);
+        for (int s = 0; s < ob.count(); ++s) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
+            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
         }
     }
     d.cand_pts[l] = nx;
@@ -769,7 +802,7 @@ __global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
 
 // per landmark: Gauss-Newton back-substitution delta_l = -C^-1 (g_l + sum W^T delta_p), v_l, the
 // landmark parts of the norms, and |J v|^2 over the landmark's observations
-__global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double sm[4];
@@ -778,19 +811,18 @@ __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
     double gsq = 0.0, nsq = 0.0, dot = 0.0, jv2 = 0.0, jg2 = 0.0, jvg = 0.0;
     double dl[3] = {0, 0, 0}, vl[3] = {0, 0, 0};
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
+        const LmObs<DN> ob(d, l, mask);
         const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
         const double gl[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
         double tt[3] = {gl[0], gl[1], gl[2]};
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < ob.count(); ++s) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
             const int f = d.pose_free[k];
             if (f < 0) continue;
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jp[18], Jl[9], jd[3];
             jac_pose(o, Jp);
             jac_point(o, T, Jl);
@@ -825,13 +857,13 @@ __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
             nsq += D2 * dl[c] * dl[c] / s2;
             dot += gl[c] * dl[c];
         }
-        for (int s = 0; s < TW; ++s) {   // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn)
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < ob.count(); ++s) {   // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn)
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
             const int f = d.pose_free[k];
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, d.ou[obase + s * LMG], d.ov[obase + s * LMG], d.od[obase + s * LMG], o);
+            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jl[9], jv[3], jg[3];
             jac_point(o, T, Jl);
 #pragma unroll
@@ -994,7 +1026,7 @@ __global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
 }
 
 // per landmark: delta_l = beta * gn + gamma * v, candidate point, model cost change, candidate cost
-__global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -1004,20 +1036,19 @@ __global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
     const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
     double nx = px, ny = py, nz = pz;
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const LmObs<DN> ob(d, l, mask);
         double dl[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) dl[c] = st.beta * d.dl_gn[(size_t)c * d.Lpad + l] + st.gamma * d.vl[(size_t)c * d.Lpad + l];
         if (!isfinite(dl[0]) || !isfinite(dl[1]) || !isfinite(dl[2])) nonfinite = 1.0;
         nx = px + dl[0]; ny = py + dl[1]; nz = pz + dl[2];
         dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < ob.count(); ++s) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
             const int f = d.pose_free[k];
             const double *T = d.poses + (size_t)k * 12;
-            const double u = d.ou[obase + s * LMG], v = d.ov[obase + s * LMG], dd = d.od[obase + s * LMG];
+            const double u = ob.u(d, s), v = ob.v(d, s), dd = ob.dd(d, s);
             ObsLin o;
             obs_linearize(d, T, px, py, pz, u, v, dd, o);
             double Jl[9], jd[3];
@@ -1374,8 +1405,8 @@ void launch_linearize(Launcher &L, const Dev &d) {
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        LAUNCH(KC_LIN_LM, k_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
-        LAUNCH(KC_LIN_POSE, k_linearize_poses, dim3(d.P), dim3(256), 0, d);
+        LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
     }
     LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d);
 }
@@ -1398,7 +1429,8 @@ void launch_finish_local(Launcher &L, const Dev &d) {
 }
 
 void launch_finish_check(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
+    if (d.dense) launch_dense_finish(L, d);
+    else LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
@@ -1408,7 +1440,7 @@ void launch_finish_check(Launcher &L, const Dev &d) {
 void launch_update_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_backsub_eval(L, d);
-    else LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
 }
 
@@ -1440,11 +1472,11 @@ void launch_pose_update(Launcher &L, const Dev &d) {
 void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_dogleg_gn(L, d);
-    else LAUNCH(KC_DOGLEG, k_dogleg_gn, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_gn<true> : k_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_dogleg_eval(L, d);
-    else LAUNCH(KC_DOGLEG, k_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_eval<true> : k_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
 }
 

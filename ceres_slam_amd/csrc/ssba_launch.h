@@ -123,5 +123,9 @@ void launch_ph_ls_accept(Launcher &L, const Dev &d);
 int configure_border();
 void launch_border_solve(Launcher &L, const Dev &d);
 void launch_bcr_multi_rhs(Launcher &L, const Dev &d);
+// general structure: dense reduced camera system (ssba_dense.hip)
+void launch_dense_schur(Launcher &L, const Dev &d);
+void launch_dense_finish(Launcher &L, const Dev &d);
+void launch_dense_solve(Launcher &L, const Dev &d);
 
 }  // namespace ssba

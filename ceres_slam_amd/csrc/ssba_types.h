@@ -182,7 +182,21 @@ struct Dev {
     const int *pf_type;                             // F
     const double *pf_data, *pf_S, *pf_huber;        // F*18, F*36, F
     double *pf_cost;                                // P: cost of the factors of each pose at the linearisation point
+    // general structure (tracks longer than TW, loop closures): dense reduced camera system (ssba_dense.hip)
+    int dense, n_dn, dn_pad;                        // n_dn = 6 * nfree, dn_pad = n_dn rounded up to DN_BS (= row stride of dn_S)
+    const uint32_t *dn_lm_start;                    // Lpad+1: observations of a landmark, landmark-major
+    const uint32_t *dn_obs_pose;                    // N
+    const double *dn_u, *dn_v, *dn_d;               // N
+    const uint32_t *dn_pose_start, *dn_pose_obs;    // P+1, N: landmark-major observation indices of a pose
+    const uint32_t *dn_obs_lm;                      // N: landmark of an observation
+    double *dn_W, *dn_Y;                            // N*18: J_p^T J_l and its product with C^-1, per observation
+    // blocks (a <= b) of the reduced system with the observation pairs (of one landmark) that contribute to each
+    int dn_nblk;
+    const uint32_t *dn_blk_a, *dn_blk_b, *dn_blk_start, *dn_pair_a, *dn_pair_b;
+    double *dn_S;                                   // (dn_pad + DN_BS) x dn_pad, row-major, lower triangle; row dn_pad holds the
+                                                    // right-hand side, so the factorisation leaves L^-1 rhs there
 };
+constexpr int DN_BS = 64;                           // block size of the dense Cholesky
 constexpr int NLS = 6;        // per block: cost, phi', |dx_l|^2, nonfinite, max|delta_l|, g_l . delta_l
 constexpr int NLS_OUT = 8;    // cost, phi', |dx_l|^2, nonfinite_l, max|delta|, g . delta, valid, x_cost
 constexpr int BS_SBB = 0, BS_RHS = NBP * NBP, BS_G = BS_RHS + NBP, BS_H = BS_G + NBP, BS_S = BS_H + NBP,

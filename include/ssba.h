@@ -209,6 +209,8 @@ typedef struct {
     uint32_t num_reduced_blocks;   /* non-zero 6x6 blocks of S (upper incl. diagonal)   */
     uint32_t pose_bandwidth;       /* max free-pose index distance of co-observers      */
     uint64_t device_bytes;         /* device memory held by the handle                  */
+    uint32_t general_structure;    /* 1: tracks > SSBA_MAX_TRACK or span > 12 poses -> dense reduced system */
+    uint32_t reserved;
 } ssba_stats;
 int ssba_get_stats(ssba_problem *p, ssba_stats *st);
 

@@ -1,0 +1,172 @@
+"""General problem structure through the C ABI: tracks longer than SSBA_MAX_TRACK observations and pose co-visibility
+that is not banded (loop closures, arbitrary state numbering).  Ceres itself takes any structure
+(tests/dataset_vo.cpp:41-56 adds whatever the dataset file holds), so the drop-in has to as well: such problems run
+the dense reduced-system kernels of ssba_dense.hip, with the same oracle parity bar as the windowed layout."""
+import os
+from contextlib import contextmanager
+
+import numpy as np
+import pytest
+
+from ceres_slam_amd import capi, synth
+from ceres_slam_amd.solver import StereoBA
+from oracle import oracle as orc
+from test_gpu_edge_cases import _assert_same_solve, _solve_both
+
+pytestmark = pytest.mark.gpu
+
+
+@contextmanager
+def _force_dense():
+    os.environ["SSBA_FORCE_DENSE"] = "1"
+    try:
+        yield
+    finally:
+        del os.environ["SSBA_FORCE_DENSE"]
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _permuted(prob, seed):
+    """Same problem with the states renumbered at random (state 0 stays the constant first pose)."""
+    rng = np.random.default_rng(seed)
+    P = prob.num_poses
+    new_of_old = np.concatenate([[0], 1 + rng.permutation(P - 1)])
+    old_of_new = np.argsort(new_of_old)
+    import copy
+    q = copy.copy(prob)
+    q.poses_init = prob.poses_init[old_of_new].copy()
+    q.poses_gt = prob.poses_gt[old_of_new].copy()
+    q.obs_pose = new_of_old[prob.obs_pose].astype(np.uint32)
+    return q, new_of_old
+
+
+def _track_lengths(prob):
+    return np.bincount(prob.obs_point, minlength=prob.num_points)
+
+
+@pytest.mark.parametrize("radius", [1e4, 3.0])
+@pytest.mark.parametrize("size", [(5, 120, 4), (11, 300, 8), (30, 900, 12)])     # n = 24, 60, 174: below / across 64-blocks
+def test_dense_reduced_system_and_step_match_oracle(size, radius):
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=3)
+    with _force_dense():
+        ba = StereoBA.from_synth(prob)
+    assert ba.stats().general_structure == 1
+    op = orc.OracleProblem.from_synth(prob)
+    S, rhs, dp, dl, mcc = ba.lm_step(radius)
+    S2, rhs2, _ = op.reduced_system(radius)
+    dp2, dl2, mcc2 = op.lm_step(radius)
+    assert _rel(S, S2) < 1e-10 and _rel(rhs, rhs2) < 1e-10
+    assert _rel(dp, dp2) < 1e-8 and _rel(dl, dl2) < 1e-8
+    assert mcc == pytest.approx(mcc2, rel=1e-9)
+
+
+def test_forced_dense_solve_equals_windowed_solve():
+    prob = synth.make_problem(40, 1600, track_len=10, seed=21)
+    ba_w = StereoBA.from_synth(prob)
+    s_w, log_w = ba_w.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    with _force_dense():
+        ba_d = StereoBA.from_synth(prob)
+    s_d, log_d = ba_d.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    assert ba_w.stats().general_structure == 0 and ba_d.stats().general_structure == 1
+    assert s_d.num_iterations == s_w.num_iterations
+    assert log_d["step_is_successful"].tolist() == log_w["step_is_successful"].tolist()
+    np.testing.assert_allclose(log_d["cost"], log_w["cost"], rtol=1e-9)
+    assert np.abs(ba_d.poses - ba_w.poses).max() < 1e-8
+
+
+@pytest.mark.parametrize("size", [(30, 1500, 20), (60, 2400, 40), (150, 4000, 16)])
+def test_long_tracks_match_oracle(size):
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=size[2])
+    assert _track_lengths(prob).max() > 12
+    ba, s, log, op, s2, log2 = _solve_both(prob)
+    assert ba.stats().general_structure == 1
+    _assert_same_solve(ba, s, log, op, s2, log2)
+
+
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+def test_renumbered_states_match_oracle(strategy, huber_a):
+    """Random state numbering = co-visibility all over the reduced system (what a loop closure does locally)."""
+    base = synth.make_problem(36, 1400, track_len=8, seed=17, outlier_fraction=0.1 if huber_a else 0.0)
+    prob, new_of_old = _permuted(base, seed=5)
+    opts = dict(trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    ba, s, log, op, s2, log2 = _solve_both(prob, opts=opts, huber_a=huber_a)
+    st = ba.stats()
+    assert st.general_structure == 1 and st.pose_bandwidth > 12
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    if huber_a == 0.0 and strategy == (0, 0):      # and the same minimum as the banded numbering
+        ba0, s0, *_ = _solve_both(base)
+        assert s.final_cost == pytest.approx(s0.final_cost, rel=1e-9)
+        assert np.abs(ba.poses[new_of_old] - ba0.poses).max() < 1e-6
+
+
+def test_loop_closure_observations():
+    """A banded trajectory plus landmarks of the first states seen again from the last ones."""
+    prob = synth.make_problem(40, 1600, track_len=6, seed=9)
+    cam = prob.camera
+    rng = np.random.default_rng(2)
+    first = np.flatnonzero(np.isin(np.arange(prob.num_points), prob.obs_point[prob.obs_pose < 3]))[:60]
+    k_new, j_new, uvd_new = [], [], []
+    for k in (37, 38, 39):
+        t, R = prob.poses_gt[k, :3], prob.poses_gt[k, 3:].reshape(3, 3)
+        q = prob.points_gt[first] @ R.T + t
+        ok = q[:, 2] > 0.5
+        uvd = synth.project(cam, q[ok]) + rng.normal(size=(int(ok.sum()), 3)) * 0.5
+        uvd[:, 2] = np.maximum(uvd[:, 2], 0.25)
+        k_new += [k] * int(ok.sum()); j_new += first[ok].tolist(); uvd_new.append(uvd)
+    assert len(k_new) > 20
+    import copy
+    q = copy.copy(prob)
+    q.obs_pose = np.concatenate([prob.obs_pose, np.asarray(k_new, np.uint32)]).astype(np.uint32)
+    q.obs_point = np.concatenate([prob.obs_point, np.asarray(j_new, np.uint32)]).astype(np.uint32)
+    q.obs_uvd = np.vstack([prob.obs_uvd] + uvd_new)
+    ba, s, log, op, s2, log2 = _solve_both(q, huber_a=1.345)
+    st = ba.stats()
+    assert st.general_structure == 1 and st.pose_bandwidth >= 36
+    _assert_same_solve(ba, s, log, op, s2, log2)
+
+
+def test_constant_states_and_nothing_free_on_the_general_path():
+    prob = synth.make_problem(20, 700, track_len=16, seed=4)
+    const = np.zeros(20, bool)
+    const[[0, 9, 19]] = True
+    ba, s, log, op, s2, log2 = _solve_both(prob, pose_const=const)
+    assert ba.stats().general_structure == 1
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    for k in (0, 9, 19):
+        assert np.array_equal(ba.poses[k], prob.poses_init[k])
+    ba, s, log, op, s2, log2 = _solve_both(prob, pose_const=np.ones(20, bool))
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    assert np.array_equal(ba.poses, prob.poses_init)
+
+
+def test_pose_factors_on_the_general_path():
+    from test_oracle_pose_factors import _sun_problem
+    prob, factors = _sun_problem(P=24, L=900, seed=8, huber=0.5)
+    none_const = np.zeros(prob.num_poses, dtype=np.uint8)
+    kw = dict(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1)
+    with _force_dense():
+        ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                      prob.stiffness(), pose_const=none_const, pose_factors=factors)
+    s, log = ba.solve(capi.default_options(**kw))
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_const=none_const, pose_factors=factors)
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, **kw))
+    n = min(len(log["cost"]), len(log2["cost"]), 12)
+    assert log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-5)
+
+
+def test_structure_beyond_the_general_path_is_rejected_loudly():
+    # lighting terms keep the windowed layout only
+    prob, ph = synth.make_phong_problem(8, 200, seed=1)
+    with _force_dense():
+        with pytest.raises(capi.SsbaError) as e:
+            StereoBA.from_synth(prob, lighting=ph.as_oracle_dict())
+    assert e.value.status == -6      # SSBA_ERR_UNSUPPORTED

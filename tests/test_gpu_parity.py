@@ -155,10 +155,12 @@ def test_edge_cases_ragged_tracks_unobserved_blocks_and_errors():
     assert np.abs(ba.poses - op.poses).max() < 1e-6
     assert np.array_equal(ba.points[5], prob.points_init[5])        # unobserved landmark untouched
     assert np.array_equal(ba.poses[5], prob.poses_init[5])          # unobserved pose untouched
-    # a track longer than SSBA_MAX_TRACK is rejected loudly, not mis-solved
+    # a track longer than SSBA_MAX_TRACK leaves the windowed layout for the general-structure path
+    # (tests/test_gpu_general_structure.py); what that path does not cover is rejected loudly, not mis-solved
     long = synth.make_problem(20, 10, track_len=14, seed=5)
+    assert StereoBA.from_synth(long).stats().general_structure == 1
     with pytest.raises(capi.SsbaError) as e:
-        StereoBA.from_synth(long)
+        StereoBA.from_synth(long, world_size=2, rank=0)
     assert e.value.status == -6
     # out-of-range index
     with pytest.raises(capi.SsbaError):
