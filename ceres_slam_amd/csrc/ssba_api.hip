@@ -540,9 +540,9 @@ int ssba_finalize(ssba_problem *p) {
     }
     if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
     if (dense) {
-        if (ph || p->world_size > 1 || 6 * (size_t)nfree > 8192) {
+        if (ph || p->world_size > 1 || nfree > 4096) {
             set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
-                      "which is limited to stereo-only single-GPU problems with <= 1365 free poses in this build");
+                      "which is limited to stereo-only single-GPU problems with <= 4096 free poses in this build");
             return SSBA_ERR_UNSUPPORTED;
         }
         std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) { return a.j < b.j; });
@@ -601,6 +601,7 @@ int ssba_finalize(ssba_problem *p) {
     std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs;
     std::vector<double> dn_u, dn_v, dn_d;
     std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b;
+    DensePlan dplan;
     if (dense) {
         dn_lm_start.assign(Lpad + 1, 0);
         for (uint32_t l = 0; l < Lact; ++l) {
@@ -655,6 +656,33 @@ int ssba_finalize(ssba_problem *p) {
             if (prs[i].ea != 0xFFFFFFFFu) { dn_pair_a.push_back(prs[i].ea); dn_pair_b.push_back(prs[i].eb); }
         }
         dn_blk_start.push_back((uint32_t)dn_pair_a.size());
+        // symbolic Cholesky at DN_BS-block granularity (natural order): banded problems stay banded, a loop closure
+        // fills the rows between its two ends; block row nbk (the right-hand side) is in every column
+        const int nbk = (6 * nfree + DN_BS - 1) / DN_BS;
+        std::vector<std::vector<uint8_t>> nz(nbk, std::vector<uint8_t>(nbk, 0));
+        for (size_t i = 0; i < dn_blk_a.size(); ++i)
+            for (int r = 0; r < 6; r += 5)
+                for (int c = 0; c < 6; c += 5) nz[(dn_blk_b[i] * 6 + c) / DN_BS][(dn_blk_a[i] * 6 + r) / DN_BS] = 1;
+        dplan.row_start.assign(1, 0); dplan.tile_start.assign(1, 0);
+        for (int j = 0; j < nbk; ++j) {
+            std::vector<uint32_t> R;
+            for (int i = j + 1; i < nbk; ++i) if (nz[i][j]) R.push_back((uint32_t)i);
+            for (size_t x = 0; x < R.size(); ++x)
+                for (size_t y = 0; y <= x; ++y) nz[R[x]][R[y]] = 1;
+            R.push_back((uint32_t)nbk);
+            for (size_t x = 0; x < R.size(); ++x)
+                for (size_t y = 0; y <= x && R[y] < (uint32_t)nbk; ++y) { dplan.ti.push_back(R[x]); dplan.tk.push_back(R[y]); }
+            dplan.rows.insert(dplan.rows.end(), R.begin(), R.end());
+            dplan.row_start.push_back((uint32_t)dplan.rows.size());
+            dplan.tile_start.push_back((uint32_t)dplan.ti.size());
+        }
+        dplan.col_start.assign(1, 0); dplan.upd_last.assign(nbk + 1, 0);
+        for (int i = 0; i <= nbk; ++i) {      // block row i of the factor: its columns j < i - 1 (j = i - 1 is handled by the solving work-group)
+            if (i >= 1 && i < nbk) dplan.upd_last[i] = nz[i][i - 1];
+            for (int j = 0; i < nbk && j + 1 < i; ++j) if (nz[i][j]) dplan.cols.push_back((uint32_t)j);
+            dplan.col_start.push_back((uint32_t)dplan.cols.size());
+        }
+        dplan.nbk = nbk;
     }
     for (uint32_t l = 0; l < Lact && !dense; ++l) {
         const uint32_t j = order[l].j, w = lm_win[l];
@@ -990,6 +1018,9 @@ int ssba_finalize(ssba_problem *p) {
         d.dn_nblk = (int)dn_blk_a.size();
         TRY(dupload(p, &d.dn_blk_a, dn_blk_a)); TRY(dupload(p, &d.dn_blk_b, dn_blk_b)); TRY(dupload(p, &d.dn_blk_start, dn_blk_start));
         TRY(dupload(p, &d.dn_pair_a, dn_pair_a)); TRY(dupload(p, &d.dn_pair_b, dn_pair_b));
+        TRY(dupload(p, &d.dn_rows, dplan.rows)); TRY(dupload(p, &d.dn_ti, dplan.ti)); TRY(dupload(p, &d.dn_tk, dplan.tk));
+        TRY(dupload(p, &d.dn_cols, dplan.cols));
+        p->launcher.dense = dplan;
         TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
         TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs));

@@ -11,6 +11,8 @@
 //   k_dn_potrf / k_dn_trsm / k_dn_syrk   right-looking blocked Cholesky (DN_BS = 64), fp64 FMA bound; the extra
 //                row makes the forward solve part of the factorisation
 //   k_dn_bwd     block back-substitution with L^T -> pose step x0
+// The factorisation skips zero 64x64 blocks: ssba_finalize runs a symbolic Cholesky at block granularity, so a
+// banded problem costs O(n b^2) and a loop closure only fills the block rows between its two ends.
 // What Ceres does here (SPARSE_SCHUR / DENSE_SCHUR on the reduced camera matrix, schur_complement_solver.cc)
 // is the same elimination order: landmarks first, then one Cholesky of S.
 #include <hip/hip_runtime.h>
@@ -64,19 +66,43 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
     }
 }
 
+// One work-group per block.  Every thread takes every 256th observation pair of the block and accumulates the whole
+// 6x6 product Y_a W_b^T in registers (the loads of different pairs are independent: the kernel is bound by the
+// latency of the two gathers per pair, so pairs are spread over as many lanes as possible); the 36 partial sums are
+// then reduced over the wave by shuffles and over the four waves through LDS, both in a fixed order.
 __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
-    const int blk = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (blk >= d.dn_nblk || lane >= 36) return;
+    __shared__ double part[4][36];
+    const int blk = blockIdx.x;
     const uint32_t a = d.dn_blk_a[blk], b = d.dn_blk_b[blk];
-    const int r = lane / 6, c = lane - r * 6;
-    double v = 0.0;
-    for (uint32_t i = d.dn_blk_start[blk]; i < d.dn_blk_start[blk + 1]; ++i) {
-        const double *Y = d.dn_Y + (size_t)d.dn_pair_a[i] * 18 + 3 * r, *W = d.dn_W + (size_t)d.dn_pair_b[i] * 18 + 3 * c;
-        v += Y[0] * W[0] + Y[1] * W[1] + Y[2] * W[2];
+    double acc[36];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+    for (uint32_t i = d.dn_blk_start[blk] + threadIdx.x; i < d.dn_blk_start[blk + 1]; i += 256) {
+        const double2 *Y2 = reinterpret_cast<const double2 *>(d.dn_Y + (size_t)d.dn_pair_a[i] * 18);
+        const double2 *W2 = reinterpret_cast<const double2 *>(d.dn_W + (size_t)d.dn_pair_b[i] * 18);
+        double y[18], w[18];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double2 yv = Y2[q], wv = W2[q];
+            y[2 * q] = yv.x; y[2 * q + 1] = yv.y; w[2 * q] = wv.x; w[2 * q + 1] = wv.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc[6 * r + c] += y[3 * r] * w[3 * c] + y[3 * r + 1] * w[3 * c + 1] + y[3 * r + 2] * w[3 * c + 2];
     }
-    v = -v;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 36; ++q) {
+        const double v = wave_sum(acc[q]);
+        if (lane == 0) part[wv][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 36) return;
+    const int el = threadIdx.x, r = el / 6, c = el - r * 6;
+    double v = -(part[0][el] + part[1][el] + part[2][el] + part[3][el]);
     const size_t lda = (size_t)d.dn_pad;
     if (a == b) {
         if (c < r) return;    // (r, c) with r <= c stands for the symmetric pair; stored at (row 6a+c, col 6a+r)
@@ -131,52 +157,57 @@ __global__ __launch_bounds__(256) void k_dn_finish(Dev d) {
 }
 
 // ---- blocked Cholesky, lower triangle, row-major with stride dn_pad; block row dn_pad / DN_BS is the rhs ------
-__global__ __launch_bounds__(256) void k_dn_potrf(Dev d, int j) {
-    State &st = *d.st;
-    if (st.terminated || st.step_failed || st.dl_reuse) return;
-    __shared__ double t[DN_BS * TP];
-    __shared__ int bad;
-    const size_t lda = (size_t)d.dn_pad;
-    double *A = d.dn_S + ((size_t)j * DN_BS) * lda + (size_t)j * DN_BS;
-    const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
-    for (int m = q; m < DN_BS; m += 4) t[m * TP + r] = A[(size_t)m * lda + r];      // t[row m][col r]
-    if (tid == 0) bad = 0;
-    __syncthreads();
-    for (int c = 0; c < DN_BS; ++c) {
-        const double piv = t[c * TP + c];
-        if (!(piv > 0.0) || !isfinite(piv)) { if (tid == 0) bad = 1; break; }      // uniform: every thread reads the same pivot
-        const double inv = 1.0 / sqrt(piv);
-        __syncthreads();
-        if (tid == c) t[c * TP + c] = sqrt(piv);
-        else if (q == 0 && r > c) t[r * TP + c] *= inv;
-        __syncthreads();
-        // trailing update of the lower triangle: rows r > c, columns c < cc <= r
-        if (r > c)
-            for (int cc = c + 1 + q; cc <= r; cc += 4) t[r * TP + cc] -= t[r * TP + c] * t[cc * TP + c];
-        __syncthreads();
-    }
-    __syncthreads();
-    if (bad) { if (tid == 0) st.step_failed = 1; return; }
-    for (int m = q; m < DN_BS; m += 4) A[(size_t)m * lda + r] = r <= m ? t[m * TP + r] : 0.0;
+static __device__ __forceinline__ double lane_value(double v, int lane) {      // lane is uniform (unrolled loops)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
 }
 
-// rows of the panel below the diagonal block: X = A L_jj^-T, one thread per row, right-looking substitution
-__global__ __launch_bounds__(64) void k_dn_trsm(Dev d, int j) {
+// Diagonal block: one wave, lane r keeps row r of the 64x64 tile in registers; the pivot column travels by
+// readlane (no LDS, no barrier).  The chain of 64 dependent columns is what bounds this kernel.
+__global__ __launch_bounds__(64) void k_dn_potrf(Dev d, int j) {
+    State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    const size_t lda = (size_t)d.dn_pad;
+    const int r = threadIdx.x;
+    double *A = d.dn_S + ((size_t)j * DN_BS + r) * lda + (size_t)j * DN_BS;
+    double a[DN_BS];
+#pragma unroll
+    for (int c = 0; c < DN_BS; ++c) a[c] = A[c];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < DN_BS; ++c) {
+        const double piv = lane_value(a[c], c);
+        bad = bad || !(piv > 0.0) || !isfinite(piv);
+        const double l = a[c] * fast_rsqrt(piv);       // lane c: sqrt(piv); lanes r < c hold nothing of the factor
+        a[c] = l;
+#pragma unroll
+        for (int cc = c + 1; cc < DN_BS; ++cc) a[cc] -= l * lane_value(l, cc);
+    }
+    if (bad) { if (r == 0) st.step_failed = 1; return; }
+#pragma unroll
+    for (int c = 0; c < DN_BS; ++c) A[c] = c <= r ? a[c] : 0.0;
+}
+
+// rows of the panel below the diagonal block: X = A L_jj^-T, one thread per row, right-looking substitution;
+// one work-group per non-zero block row of this block column (rows[])
+__global__ __launch_bounds__(64) void k_dn_trsm(Dev d, int j, const uint32_t *rows) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     __shared__ double Lt[DN_BS * DN_BS];       // read as broadcasts only: no padding needed
+    __shared__ double rd[DN_BS];
     const size_t lda = (size_t)d.dn_pad;
-    const int i = j + 1 + blockIdx.x, tid = threadIdx.x;
+    const int i = (int)rows[blockIdx.x], tid = threadIdx.x;
     const double *Lj = d.dn_S + ((size_t)j * DN_BS) * lda + (size_t)j * DN_BS;
     double *A = d.dn_S + ((size_t)i * DN_BS + tid) * lda + (size_t)j * DN_BS;     // this thread's row: 512 contiguous bytes
     for (int m = 0; m < DN_BS; ++m) Lt[m * DN_BS + tid] = Lj[(size_t)m * lda + tid];
+    rd[tid] = 1.0 / Lj[(size_t)tid * lda + tid];
     double x[DN_BS];
 #pragma unroll
     for (int c = 0; c < DN_BS; ++c) x[c] = A[c];
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < DN_BS; ++c) {
-        x[c] = x[c] / Lt[c * DN_BS + c];
+        x[c] *= rd[c];
 #pragma unroll
         for (int cc = c + 1; cc < DN_BS; ++cc) x[cc] -= x[c] * Lt[cc * DN_BS + c];
     }
@@ -184,12 +215,12 @@ __global__ __launch_bounds__(64) void k_dn_trsm(Dev d, int j) {
     for (int c = 0; c < DN_BS; ++c) A[c] = x[c];
 }
 
-// trailing update A_ik -= L_ij L_kj^T for j < k <= i: one 64x64 tile per work-group, 4x4 outputs per thread
-__global__ __launch_bounds__(256) void k_dn_syrk(Dev d, int j) {
+// trailing update A_ik -= L_ij L_kj^T over the non-zero block rows i >= k of block column j (tile list ti / tk):
+// one 64x64 tile per work-group, 4x4 outputs per thread
+__global__ __launch_bounds__(256) void k_dn_syrk(Dev d, int j, const uint32_t *ti, const uint32_t *tk) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
-    const int k = j + 1 + blockIdx.x, i = j + 1 + blockIdx.y;
-    if (i < k) return;
+    const int i = (int)ti[blockIdx.x], k = (int)tk[blockIdx.x];
     constexpr int KH = DN_BS / 2;
     __shared__ double sA[KH * TP], sB[KH * TP];      // transposed halves of the two panels: s[m][row]
     const size_t lda = (size_t)d.dn_pad;
@@ -227,41 +258,55 @@ __global__ __launch_bounds__(256) void k_dn_syrk(Dev d, int j) {
         for (int b = 0; b < 4; ++b) C[(size_t)(ty + 16 * a) * lda + tx + 16 * b] -= acc[a][b];
 }
 
-// x_i = L_ii^-T (y_i - sum_{j > i} L_ji^T x_j); y and x live in the rhs row
-__global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i) {
+// Back-substitution L^T x = y in the rhs row, right-looking: step i (block row i of L, x_i known) subtracts
+// L_ij^T x_i from y_j for the non-zero blocks j < i (cols[], one work-group each); the last work-group owns
+// j = i - 1, whose y is complete after its own update, and solves x_{i-1} = L_{i-1,i-1}^-T y_{i-1} right away.
+// Step i = nbk (the rhs row itself) has no update and only solves the last block.
+__global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i, const uint32_t *cols, int n_upd, int upd_last) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
-    __shared__ double t[DN_BS * TP], part[4][DN_BS];
+    __shared__ double t[DN_BS * TP], part[4][DN_BS], rd[DN_BS];
     const size_t lda = (size_t)d.dn_pad;
     const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
     double *xrow = d.dn_S + (size_t)d.dn_pad * lda;
-    const double *Lc = d.dn_S + (size_t)i * DN_BS;       // column panel of block column i
+    const bool solver = (int)blockIdx.x == n_upd;
+    const int j = solver ? i - 1 : (int)cols[blockIdx.x];
     double s = 0.0;
-    for (int r = (i + 1) * DN_BS + q; r < d.dn_pad; r += 4) s += Lc[(size_t)r * lda + c] * xrow[r];
+    if (!solver || upd_last) {
+        const double *Lij = d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)j * DN_BS;
+        const double *xi = xrow + (size_t)i * DN_BS;
+#pragma unroll 4
+        for (int r = q; r < DN_BS; r += 4) s += Lij[(size_t)r * lda + c] * xi[r];
+    }
     part[q][c] = s;
-    const double *Li = d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)i * DN_BS;
-    for (int m = q; m < DN_BS; m += 4) t[m * TP + c] = Li[(size_t)m * lda + c];
+    if (solver) {
+        const double *Lj = d.dn_S + ((size_t)j * DN_BS) * lda + (size_t)j * DN_BS;
+        for (int m = q; m < DN_BS; m += 4) t[m * TP + c] = Lj[(size_t)m * lda + c];
+        if (q == 0) rd[c] = 1.0 / Lj[(size_t)c * lda + c];
+    }
     __syncthreads();
     if (q != 0) return;
-    double v = xrow[i * DN_BS + c] - (part[0][c] + part[1][c] + part[2][c] + part[3][c]);
-    // one wave: lane c owns x_c; columns of L^T are rows of L
-    for (int m = DN_BS - 1; m >= 0; --m) {
-        double xm = 0.0;
-        if (c == m) xm = v / t[m * TP + m];
-        xm = __shfl(xm, m, 64);
-        if (c == m) v = xm;
-        else if (c < m) v -= t[m * TP + c] * xm;
+    double v = xrow[j * DN_BS + c] - (part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+    if (solver) {
+        // one wave: lane c owns x_c; columns of L^T are rows of L
+        for (int m = DN_BS - 1; m >= 0; --m) {
+            double xm = 0.0;
+            if (c == m) xm = v * rd[m];
+            xm = __shfl(xm, m, 64);
+            if (c == m) v = xm;
+            else if (c < m) v -= t[m * TP + c] * xm;
+        }
+        const int g = j * DN_BS + c;
+        if (g < d.n_dn) d.x0[g] = v;
     }
-    const int g = i * DN_BS + c;
-    xrow[g] = v;
-    if (g < d.n_dn) d.x0[g] = v;
+    xrow[j * DN_BS + c] = v;
 }
 
 // ----------------------------------------------------------------- launchers ---
 void launch_dense_schur(Launcher &L, const Dev &d) {
     if (d.dn_pad > 0) hipMemsetAsync(d.dn_S, 0, (size_t)(d.dn_pad + DN_BS) * d.dn_pad * sizeof(double), L.stream);
     LAUNCH(KC_SCHUR, k_dn_wy, dim3((d.n_obs + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SCHUR, k_dn_schur, dim3((d.dn_nblk + 3) / 4), dim3(256), 0, d);
+    LAUNCH(KC_SCHUR, k_dn_schur, dim3(d.dn_nblk), dim3(256), 0, d);
     LAUNCH(KC_ASSEMBLE, k_dn_rhs, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
 }
 
@@ -270,13 +315,18 @@ void launch_dense_finish(Launcher &L, const Dev &d) {
 }
 
 void launch_dense_solve(Launcher &L, const Dev &d) {
-    const int nbk = d.dn_pad / DN_BS;
+    const DensePlan &pl = L.dense;
+    const int nbk = pl.nbk;
     for (int j = 0; j < nbk; ++j) {
-        LAUNCH(KC_BCR_FACTOR, k_dn_potrf, dim3(1), dim3(256), 0, d, j);
-        LAUNCH(KC_BCR_FACTOR, k_dn_trsm, dim3(nbk - j), dim3(64), 0, d, j);        // block rows j+1 .. nbk (the rhs row)
-        LAUNCH(KC_BCR_REDUCE, k_dn_syrk, dim3(nbk - 1 - j, nbk - j), dim3(256), 0, d, j);
+        const uint32_t r0 = pl.row_start[j], nr = pl.row_start[j + 1] - r0, t0 = pl.tile_start[j], nt = pl.tile_start[j + 1] - t0;
+        LAUNCH(KC_BCR_FACTOR, k_dn_potrf, dim3(1), dim3(64), 0, d, j);
+        LAUNCH(KC_BCR_FACTOR, k_dn_trsm, dim3(nr), dim3(64), 0, d, j, d.dn_rows + r0);
+        LAUNCH(KC_BCR_REDUCE, k_dn_syrk, dim3(nt), dim3(256), 0, d, j, d.dn_ti + t0, d.dn_tk + t0);
     }
-    for (int i = nbk - 1; i >= 0; --i) LAUNCH(KC_BCR_BACKSUB, k_dn_bwd, dim3(1), dim3(256), 0, d, i);
+    for (int i = nbk; i >= 1; --i) {
+        const uint32_t c0 = pl.col_start[i], nc = pl.col_start[i + 1] - c0;
+        LAUNCH(KC_BCR_BACKSUB, k_dn_bwd, dim3(nc + 1), dim3(256), 0, d, i, d.dn_cols + c0, (int)nc, (int)pl.upd_last[i]);
+    }
 }
 
 }  // namespace ssba

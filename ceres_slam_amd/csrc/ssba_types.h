@@ -193,6 +193,9 @@ struct Dev {
     // blocks (a <= b) of the reduced system with the observation pairs (of one landmark) that contribute to each
     int dn_nblk;
     const uint32_t *dn_blk_a, *dn_blk_b, *dn_blk_start, *dn_pair_a, *dn_pair_b;
+    // block-level (DN_BS) symbolic factorisation: non-zero block rows below the diagonal of every block column
+    // (the rhs row last), the tile pairs of every trailing update, and the non-zero block columns of every block row
+    const uint32_t *dn_rows, *dn_ti, *dn_tk, *dn_cols;
     double *dn_S;                                   // (dn_pad + DN_BS) x dn_pad, row-major, lower triangle; row dn_pad holds the
                                                     // right-hand side, so the factorisation leaves L^-1 rhs there
 };

@@ -237,6 +237,40 @@ def make_problem(num_poses: int, num_points: int, *, track_len: int = 12, seed: 
         outlier_mask=outlier_mask)
 
 
+def add_loop_closure(prob: StereoBAProblem, num_states: int = 3, num_landmarks: int = 60, seed: int = 2,
+                     sigma: float = 0.5) -> StereoBAProblem:
+    """Copy of `prob` in which landmarks first seen from the first three states are observed again from the last
+    `num_states` states (they pass through the ground-truth poses, so the problem stays consistent): the pose
+    co-visibility is no longer banded, which is what a loop closure does to the reduced camera system."""
+    import copy
+    rng = np.random.default_rng(seed)
+    P = prob.num_poses
+    seen_first = np.zeros(prob.num_points, bool)
+    seen_first[prob.obs_point[prob.obs_pose < 3]] = True
+    first = np.flatnonzero(seen_first)[:num_landmarks]
+    k_new, j_new, uvd_new = [], [], []
+    for k in range(P - num_states, P):
+        already = set(prob.obs_point[prob.obs_pose == k].tolist())
+        cand = np.asarray([j for j in first if j not in already], dtype=np.int64)
+        if cand.size == 0:
+            continue
+        t, R = prob.poses_gt[k, :3], prob.poses_gt[k, 3:].reshape(3, 3)
+        q = prob.points_gt[cand] @ R.T + t
+        ok = q[:, 2] > 0.5
+        uvd = project(prob.camera, q[ok]) + rng.normal(size=(int(ok.sum()), 3)) * sigma
+        uvd[:, 2] = np.maximum(uvd[:, 2], 0.25)
+        k_new += [k] * int(ok.sum())
+        j_new += cand[ok].tolist()
+        uvd_new.append(uvd)
+    out = copy.copy(prob)
+    out.obs_pose = np.concatenate([prob.obs_pose, np.asarray(k_new, np.uint32)]).astype(np.uint32)
+    out.obs_point = np.concatenate([prob.obs_point, np.asarray(j_new, np.uint32)]).astype(np.uint32)
+    out.obs_uvd = np.vstack([prob.obs_uvd] + uvd_new)
+    if prob.outlier_mask is not None:
+        out.outlier_mask = np.concatenate([prob.outlier_mask, np.zeros(len(k_new), bool)])
+    return out
+
+
 def make_config(name: str, **kw) -> StereoBAProblem:
     P, L = CONFIGS[name]
     return make_problem(P, L, **kw)

@@ -34,7 +34,8 @@ extern "C" {
 #endif
 
 #define SSBA_VERSION 1
-/* longest landmark track (observations of one landmark) this build accepts */
+/* longest landmark track (observations of one landmark) of the windowed layout; problems with longer tracks, or
+ * with co-observing free poses more than 12 apart, run the general-structure kernels (ssba_stats.general_structure) */
 #define SSBA_MAX_TRACK 12
 
 typedef struct ssba_problem ssba_problem;

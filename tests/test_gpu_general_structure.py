@@ -77,7 +77,7 @@ def test_forced_dense_solve_equals_windowed_solve():
     assert np.abs(ba_d.poses - ba_w.poses).max() < 1e-8
 
 
-@pytest.mark.parametrize("size", [(30, 1500, 20), (60, 2400, 40), (150, 4000, 16)])
+@pytest.mark.parametrize("size", [(30, 1500, 20), (60, 2400, 40), (150, 4000, 16), (1400, 14000, 14)])
 def test_long_tracks_match_oracle(size):
     prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=size[2])
     assert _track_lengths(prob).max() > 12
@@ -106,23 +106,8 @@ def test_renumbered_states_match_oracle(strategy, huber_a):
 def test_loop_closure_observations():
     """A banded trajectory plus landmarks of the first states seen again from the last ones."""
     prob = synth.make_problem(40, 1600, track_len=6, seed=9)
-    cam = prob.camera
-    rng = np.random.default_rng(2)
-    first = np.flatnonzero(np.isin(np.arange(prob.num_points), prob.obs_point[prob.obs_pose < 3]))[:60]
-    k_new, j_new, uvd_new = [], [], []
-    for k in (37, 38, 39):
-        t, R = prob.poses_gt[k, :3], prob.poses_gt[k, 3:].reshape(3, 3)
-        q = prob.points_gt[first] @ R.T + t
-        ok = q[:, 2] > 0.5
-        uvd = synth.project(cam, q[ok]) + rng.normal(size=(int(ok.sum()), 3)) * 0.5
-        uvd[:, 2] = np.maximum(uvd[:, 2], 0.25)
-        k_new += [k] * int(ok.sum()); j_new += first[ok].tolist(); uvd_new.append(uvd)
-    assert len(k_new) > 20
-    import copy
-    q = copy.copy(prob)
-    q.obs_pose = np.concatenate([prob.obs_pose, np.asarray(k_new, np.uint32)]).astype(np.uint32)
-    q.obs_point = np.concatenate([prob.obs_point, np.asarray(j_new, np.uint32)]).astype(np.uint32)
-    q.obs_uvd = np.vstack([prob.obs_uvd] + uvd_new)
+    q = synth.add_loop_closure(prob, num_states=3, num_landmarks=60)
+    assert q.num_obs > prob.num_obs + 20
     ba, s, log, op, s2, log2 = _solve_both(q, huber_a=1.345)
     st = ba.stats()
     assert st.general_structure == 1 and st.pose_bandwidth >= 36

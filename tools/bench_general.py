@@ -1,0 +1,80 @@
+"""Timing of the general-structure path (ssba_dense.hip): solver iterations per second on problems the windowed
+layout cannot hold (long tracks), and on C2 itself forced onto the dense reduced system, next to the windowed path
+on the same problem.  One JSON line per case.
+
+    python tools/bench_general.py [--steps 30]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run_case(name, prob, steps, force_dense):
+    from ceres_slam_amd import capi
+    from ceres_slam_amd.solver import StereoBA
+    if force_dense:
+        os.environ["SSBA_FORCE_DENSE"] = "1"
+    try:
+        ba = StereoBA.from_synth(prob)
+    finally:
+        os.environ.pop("SSBA_FORCE_DENSE", None)
+    st = ba.stats()
+    opts = capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1)
+    s, _ = ba.solve(opts)
+    period = max(int(s.num_iterations) - 1, 1)
+    ba.poses[:] = prob.poses_init
+    ba.points[:] = prob.points_init
+    ba.solve_begin(opts, ignore_convergence=True)
+    ba.step(3)
+    ba.synchronize()
+    ba.restart()
+    def loop():
+        ba.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if i and i % period == 0:
+                ba.restart()
+            ba.step(1)
+        ba.synchronize()
+        return time.perf_counter() - t0
+
+    dt = loop()                       # graph replay, no event bracketing
+    ba.restart()
+    ba.set_kernel_timing(True)        # per-kernel-class HIP events (slower: two events per launch)
+    loop()
+    rows = {k: round(ms / steps, 4) for k, (n, ms) in ba.kernel_times().items() if n}
+    ba.solve_end()
+    print(json.dumps({"case": name, "general_structure": int(st.general_structure), "free_poses": int(st.num_free_poses),
+                      "observations": int(st.num_observations), "reduced_blocks": int(st.num_reduced_blocks),
+                      "solve_iterations": int(s.num_iterations), "final_cost": float(s.final_cost),
+                      "ms_per_iteration": round(1e3 * dt / steps, 4), "iterations_per_s": round(steps / dt, 2),
+                      "kernel_ms_per_iteration": rows}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--case", default="", help="run only the cases whose name contains this")
+    args = ap.parse_args()
+    global run_case
+    _run = run_case
+
+    def run_case(name, make, steps, force):       # problems are built lazily: a filtered-out case costs nothing
+        if args.case in name:
+            _run(name, make(), steps, force)
+
+    from ceres_slam_amd import synth
+    run_case("P200_L20000_track24", lambda: synth.make_problem(200, 20000, track_len=24), args.steps, False)
+    run_case("P600_L60000_track24", lambda: synth.make_problem(600, 60000, track_len=24), args.steps, False)
+    # C2: 1000 states on a circle of 1000 x 0.5 m, so the last states see the landmarks of the first ones
+    run_case("C2_loop_closure", lambda: synth.add_loop_closure(synth.make_config("C2"), num_landmarks=300), args.steps, False)
+    run_case("C2_windowed", lambda: synth.make_config("C2"), args.steps, False)
+    run_case("C2_forced_dense", lambda: synth.make_config("C2"), args.steps, True)
+
+
+if __name__ == "__main__":
+    main()
