@@ -43,7 +43,8 @@ struct ssba_problem {
     std::vector<uint32_t> obs_pose, obs_point;
     std::vector<double> obs_uvd;
     double S[9] = {0};
-    bool have_S = false;
+    bool have_S = false, per_obs_S = false;
+    std::vector<double> obs_S;          // 9 per observation once two stereo blocks differ in stiffness
     std::vector<uint8_t> pose_const;
     double huber_a = 0.0;
     bool finalized = false;
@@ -268,10 +269,8 @@ int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index, co
                                  const double *uvd, uint64_t num, const double stiffness[9]) {
     if (!p || !stiffness || (num && (!pose_index || !point_index || !uvd))) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->finalized) return SSBA_ERR_STATE;
-    if (p->have_S && memcmp(p->S, stiffness, sizeof p->S) != 0) {
-        set_error("all stereo residual blocks must share one stiffness matrix (as the reference drivers do)");
-        return SSBA_ERR_UNSUPPORTED;
-    }
+    for (int c = 0; c < 9; ++c)
+        if (!std::isfinite(stiffness[c])) return SSBA_ERR_INVALID_ARGUMENT;
     for (uint64_t i = 0; i < num; ++i) {
         if (pose_index[i] >= p->P || point_index[i] >= p->L) {
             set_error("observation references a parameter block that was not added");
@@ -280,8 +279,17 @@ int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index, co
         for (int c = 0; c < 3; ++c)
             if (!std::isfinite(uvd[3 * i + c])) return SSBA_ERR_INVALID_ARGUMENT;
     }
-    memcpy(p->S, stiffness, sizeof p->S);
+    // one stiffness for all blocks (every reference driver but one) stays a kernel constant; a second, different
+    // matrix (tests/dataset_vo_sun.cpp:56-65: one per map point) switches to one matrix per residual block
+    if (p->have_S && !p->per_obs_S && memcmp(p->S, stiffness, sizeof p->S) != 0) {
+        p->per_obs_S = true;
+        p->obs_S.resize(9 * p->obs_pose.size());
+        for (size_t i = 0; i < p->obs_pose.size(); ++i) memcpy(&p->obs_S[9 * i], p->S, sizeof p->S);
+    }
+    if (!p->have_S) memcpy(p->S, stiffness, sizeof p->S);
     p->have_S = true;
+    if (p->per_obs_S)
+        for (uint64_t i = 0; i < num; ++i) p->obs_S.insert(p->obs_S.end(), stiffness, stiffness + 9);
     p->obs_pose.insert(p->obs_pose.end(), pose_index, pose_index + num);
     p->obs_point.insert(p->obs_point.end(), point_index, point_index + num);
     p->obs_uvd.insert(p->obs_uvd.end(), uvd, uvd + 3 * num);
@@ -539,6 +547,7 @@ int ssba_finalize(ssba_problem *p) {
         if (fhi - flo > SBP) dense = true;
     }
     if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
+    if (p->per_obs_S) dense = true;     // per-block stiffness lives in the general layout only
     if (dense) {
         if (ph || p->world_size > 1 || nfree > 4096) {
             set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
@@ -599,7 +608,7 @@ int ssba_finalize(ssba_problem *p) {
     std::vector<std::vector<uint32_t>> pose_refs(P);
     // general path: landmark-major observation arrays + the pose-major index list into them
     std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs;
-    std::vector<double> dn_u, dn_v, dn_d;
+    std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
     std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b;
     DensePlan dplan;
     if (dense) {
@@ -613,6 +622,7 @@ int ssba_finalize(ssba_problem *p) {
                 dn_obs_pose.push_back(p->obs_pose[i]);
                 dn_obs_lm.push_back(l);
                 dn_u.push_back(p->obs_uvd[3 * (size_t)i]); dn_v.push_back(p->obs_uvd[3 * (size_t)i + 1]); dn_d.push_back(p->obs_uvd[3 * (size_t)i + 2]);
+                if (p->per_obs_S) dn_Sobs.insert(dn_Sobs.end(), &p->obs_S[9 * (size_t)i], &p->obs_S[9 * (size_t)i] + 9);
             }
             dn_lm_start[l + 1] = (uint32_t)dn_obs_pose.size();
         }
@@ -1023,6 +1033,7 @@ int ssba_finalize(ssba_problem *p) {
         p->launcher.dense = dplan;
         TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
+        if (p->per_obs_S) TRY(dupload(p, &d.dn_Sobs, dn_Sobs));
         TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs));
         TRY(dzero(p, &d.dn_W, dn_obs_pose.size() * 18)); TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * 18));
         TRY(dzero(p, &d.dn_S, (size_t)(d.dn_pad + DN_BS) * std::max(d.dn_pad, DN_BS)));

@@ -49,7 +49,10 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
     }
     const double *T = d.poses + (size_t)k * 12;
     ObsLin o;
-    obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], d.dn_u[e], d.dn_v[e], d.dn_d[e], o);
+    double Sk[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Sk[c] = d.dn_Sobs ? d.dn_Sobs[(size_t)e * 9 + c] : d.S[c];
+    obs_linearize_S(d, Sk, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], d.dn_u[e], d.dn_v[e], d.dn_d[e], o);
     double Jp[18], Jl[9];
     jac_pose(o, Jp);
     jac_point(o, T, Jl);

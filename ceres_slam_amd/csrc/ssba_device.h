@@ -53,9 +53,9 @@ struct ObsLin {
 
 // stereo_reprojection_error.hpp:38-50, stereo_camera.hpp:77-104, Huber corrector
 // [Ceres corrector.cc with rho'' <= 0].  T is the 12-double pose block.
-static __device__ __forceinline__ void obs_linearize(const Dev &d, const double *__restrict__ T,
-                                              double px, double py, double pz, double u, double v,
-                                              double dd, ObsLin &o) {
+static __device__ __forceinline__ void obs_linearize_S(const Dev &d, const double *__restrict__ S, const double *__restrict__ T,
+                                                double px, double py, double pz, double u, double v,
+                                                double dd, ObsLin &o) {
     const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
     const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
     const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
@@ -69,7 +69,7 @@ static __device__ __forceinline__ void obs_linearize(const Dev &d, const double 
     double sq = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double s0 = d.S[3 * i], s1 = d.S[3 * i + 1], s2 = d.S[3 * i + 2];
+        const double s0 = S[3 * i], s1 = S[3 * i + 1], s2 = S[3 * i + 2];
         o.r[i] = s0 * e0 + s1 * e1 + s2 * e2;
         o.A[3 * i] = s0 * j00;
         o.A[3 * i + 1] = s1 * j11;
@@ -90,9 +90,16 @@ static __device__ __forceinline__ void obs_linearize(const Dev &d, const double 
     }
 }
 
+// the stiffness shared by all stereo residual blocks (every reference driver except dataset_vo_sun)
+static __device__ __forceinline__ void obs_linearize(const Dev &d, const double *__restrict__ T,
+                                              double px, double py, double pz, double u, double v,
+                                              double dd, ObsLin &o) {
+    obs_linearize_S(d, d.S, T, px, py, pz, u, v, dd, o);
+}
+
 // 1/2 rho(|r|^2) only (candidate evaluation)
-static __device__ __forceinline__ double obs_cost(const Dev &d, const double *__restrict__ T, double px,
-                                           double py, double pz, double u, double v, double dd) {
+static __device__ __forceinline__ double obs_cost_S(const Dev &d, const double *__restrict__ S, const double *__restrict__ T, double px,
+                                             double py, double pz, double u, double v, double dd) {
     const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
     const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
     const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
@@ -103,12 +110,16 @@ static __device__ __forceinline__ double obs_cost(const Dev &d, const double *__
     double sq = 0.0;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double r = d.S[3 * i] * e0 + d.S[3 * i + 1] * e1 + d.S[3 * i + 2] * e2;
+        const double r = S[3 * i] * e0 + S[3 * i + 1] * e1 + S[3 * i + 2] * e2;
         sq += r * r;
     }
     if (d.huber_a > 0.0 && sq > d.huber_a * d.huber_a)
         return 0.5 * (2.0 * d.huber_a * sqrt(sq) - d.huber_a * d.huber_a);
     return 0.5 * sq;
+}
+static __device__ __forceinline__ double obs_cost(const Dev &d, const double *__restrict__ T, double px,
+                                           double py, double pz, double u, double v, double dd) {
+    return obs_cost_S(d, d.S, T, px, py, pz, u, v, dd);
 }
 
 // J_l = A R (3x3)   [dq/dp = R]

@@ -57,6 +57,10 @@ template <> struct LmObs<false> {
     __device__ __forceinline__ double u(const Dev &d, int s) const { return d.ou[obase + s * LMG]; }
     __device__ __forceinline__ double v(const Dev &d, int s) const { return d.ov[obase + s * LMG]; }
     __device__ __forceinline__ double dd(const Dev &d, int s) const { return d.od[obase + s * LMG]; }
+    __device__ __forceinline__ void stiffness(const Dev &d, int, double S[9]) const {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S[c] = d.S[c];
+    }
 };
 template <> struct LmObs<true> {
     uint32_t b, n;
@@ -67,6 +71,10 @@ template <> struct LmObs<true> {
     __device__ __forceinline__ double u(const Dev &d, int s) const { return d.dn_u[b + s]; }
     __device__ __forceinline__ double v(const Dev &d, int s) const { return d.dn_v[b + s]; }
     __device__ __forceinline__ double dd(const Dev &d, int s) const { return d.dn_d[b + s]; }
+    __device__ __forceinline__ void stiffness(const Dev &d, int s, double S[9]) const {     // per residual block when given
+#pragma unroll
+        for (int c = 0; c < 9; ++c) S[c] = d.dn_Sobs ? d.dn_Sobs[(size_t)(b + s) * 9 + c] : d.S[c];
+    }
 };
 
 // ------------------------------------------------------------------ kernels ---
@@ -90,7 +98,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_landmarks(
             const uint32_t k = ob.pose(d, s);
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jl[9];
             jac_point(o, T, Jl);
             cost += o.half_rho;
@@ -148,11 +158,17 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
     const uint32_t b = DN ? d.dn_pose_start[k] : d.pose_obs_start[k], e = DN ? d.dn_pose_start[k + 1] : d.pose_obs_start[k + 1];
     for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
         int l;
-        double ou, ov, od;
+        double ou, ov, od, Sk[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Sk[c] = d.S[c];
         if (DN) {
             const uint32_t oi = d.dn_pose_obs[i];
             l = (int)d.dn_obs_lm[oi];
             ou = d.dn_u[oi]; ov = d.dn_v[oi]; od = d.dn_d[oi];
+            if (d.dn_Sobs) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) Sk[c] = d.dn_Sobs[(size_t)oi * 9 + c];
+            }
         } else {
             const uint32_t ref = d.pose_obs_ref[i];
             l = (int)(ref >> 4);
@@ -161,7 +177,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
             ou = d.ou[oi]; ov = d.ov[oi]; od = d.od[oi];
         }
         ObsLin o;
-        obs_linearize(d, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], ou, ov, od, o);
+        obs_linearize_S(d, Sk, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], ou, ov, od, o);
         double Jp[18];
         jac_pose(o, Jp);
         int n = 0;
@@ -691,7 +707,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
             if (f < 0) continue;
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jp[18], Jl[9], jd[3];
             jac_pose(o, Jp);
             jac_point(o, T, Jl);
@@ -732,7 +750,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
         for (int s = 0; s < ob.count(); ++s) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
-            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            ccost += obs_cost_S(d, Sk, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
         }
     }
     d.cand_pts[l] = nx;
@@ -822,7 +842,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
             if (f < 0) continue;
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jp[18], Jl[9], jd[3];
             jac_pose(o, Jp);
             jac_point(o, T, Jl);
@@ -863,7 +885,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
             const int f = d.pose_free[k];
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jl[9], jv[3], jg[3];
             jac_point(o, T, Jl);
 #pragma unroll
@@ -1050,7 +1074,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
             const double *T = d.poses + (size_t)k * 12;
             const double u = ob.u(d, s), v = ob.v(d, s), dd = ob.dd(d, s);
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, u, v, dd, o);
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            obs_linearize_S(d, Sk, T, px, py, pz, u, v, dd, o);
             double Jl[9], jd[3];
             jac_point(o, T, Jl);
 #pragma unroll
@@ -1067,7 +1093,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) mcc -= jd[i] * (o.r[i] + 0.5 * jd[i]);
-            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, u, v, dd);
+            ccost += obs_cost_S(d, Sk, d.cand_poses + (size_t)k * 12, nx, ny, nz, u, v, dd);
         }
     }
     d.cand_pts[l] = nx;

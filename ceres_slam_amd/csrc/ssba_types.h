@@ -187,6 +187,7 @@ struct Dev {
     const uint32_t *dn_lm_start;                    // Lpad+1: observations of a landmark, landmark-major
     const uint32_t *dn_obs_pose;                    // N
     const double *dn_u, *dn_v, *dn_d;               // N
+    const double *dn_Sobs;                          // N*9 or null: one stiffness per stereo residual block (dataset_vo_sun.cpp:56-65)
     const uint32_t *dn_pose_start, *dn_pose_obs;    // P+1, N: landmark-major observation indices of a pose
     const uint32_t *dn_obs_lm;                      // N: landmark of an observation
     double *dn_W, *dn_Y;                            // N*18: J_p^T J_l and its product with C^-1, per observation

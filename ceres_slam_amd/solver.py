@@ -23,16 +23,31 @@ class StereoBA:
         self._obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
         self._obs_point = np.ascontiguousarray(obs_point, dtype=np.uint32)
         self._obs_uvd = np.ascontiguousarray(obs_uvd, dtype=np.float64)
-        self._S = np.ascontiguousarray(np.asarray(stiffness, dtype=np.float64).reshape(9))
+        S = np.asarray(stiffness, dtype=np.float64)
+        self._S_obs = None
+        if S.ndim == 3:      # one 3x3 stiffness per residual block (tests/dataset_vo_sun.cpp:56-65)
+            self._S_obs = np.ascontiguousarray(S.reshape(-1, 9))
+            assert self._S_obs.shape[0] == self._obs_pose.shape[0]
+        else:
+            self._S = np.ascontiguousarray(S.reshape(9))
         self.h = C.c_void_p()
         cam = capi.Camera(**camera)
         capi.check(self.lib.ssba_create(C.byref(cam), device, C.byref(self.h)), "ssba_create")
         P, L = self.poses.shape[0], self.points.shape[0]
         capi.check(self.lib.ssba_add_pose_blocks(self.h, capi.dptr(self.poses), P), "ssba_add_pose_blocks")
         capi.check(self.lib.ssba_add_point_blocks(self.h, capi.dptr(self.points), L), "ssba_add_point_blocks")
-        capi.check(self.lib.ssba_add_stereo_observations(
-            self.h, self._obs_pose.ctypes.data_as(capi._u32p), self._obs_point.ctypes.data_as(capi._u32p),
-            capi.dptr(self._obs_uvd), self._obs_pose.shape[0], capi.dptr(self._S)), "ssba_add_stereo_observations")
+        if self._S_obs is None:
+            capi.check(self.lib.ssba_add_stereo_observations(
+                self.h, self._obs_pose.ctypes.data_as(capi._u32p), self._obs_point.ctypes.data_as(capi._u32p),
+                capi.dptr(self._obs_uvd), self._obs_pose.shape[0], capi.dptr(self._S)), "ssba_add_stereo_observations")
+        else:                # runs of equal stiffness go in one call each, as the C++ shim lowers them
+            n = self._obs_pose.shape[0]
+            cut = np.flatnonzero(np.any(self._S_obs[1:] != self._S_obs[:-1], axis=1)) + 1
+            for b, e in zip(np.concatenate([[0], cut]), np.concatenate([cut, [n]])):
+                b, e = int(b), int(e)
+                capi.check(self.lib.ssba_add_stereo_observations(
+                    self.h, self._obs_pose[b:e].ctypes.data_as(capi._u32p), self._obs_point[b:e].ctypes.data_as(capi._u32p),
+                    capi.dptr(self._obs_uvd[b:e]), e - b, capi.dptr(self._S_obs[b])), "ssba_add_stereo_observations")
         if pose_const is None:
             pose_const = np.zeros(P, dtype=bool)
             if P:

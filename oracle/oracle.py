@@ -35,7 +35,7 @@ class Problem(C.Structure):
                 ("shared_free", C.c_uint32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9),
                 ("num_materials", C.c_uint32), ("use_bounds", C.c_uint32),
                 ("num_pose_factors", C.c_uint32), ("reserved3", C.c_uint32), ("pf_pose", _u32p), ("pf_type", _u32p),
-                ("pf_data", _dp), ("pf_stiffness", _dp), ("pf_huber", _dp)]
+                ("pf_data", _dp), ("pf_stiffness", _dp), ("pf_huber", _dp), ("obs_stiffness", _dp)]
 
 
 class Options(C.Structure):
@@ -150,7 +150,13 @@ class OracleProblem:
         self.c.obs_pose = self.obs_pose.ctypes.data_as(_u32p)
         self.c.obs_point = self.obs_point.ctypes.data_as(_u32p)
         self.c.obs_uvd = _p(self.obs_uvd)
-        self.c.stiffness = (C.c_double * 9)(*np.asarray(stiffness, dtype=np.float64).reshape(9))
+        S = np.asarray(stiffness, dtype=np.float64)
+        if S.ndim == 3:     # one 3x3 stiffness per residual block (tests/dataset_vo_sun.cpp:56-65)
+            self._obs_S = np.ascontiguousarray(S.reshape(-1, 9))
+            assert self._obs_S.shape[0] == self.obs_pose.shape[0]
+            self.c.obs_stiffness = _p(self._obs_S)
+            S = S[0] if S.shape[0] else np.eye(3)
+        self.c.stiffness = (C.c_double * 9)(*S.reshape(9))
         self.c.pose_const = self.pose_const.ctypes.data_as(_u8p)
         self.c.huber_a = float(huber_a)
         self.ld = 3

@@ -401,7 +401,8 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
         const double *T = poses + 12 * (int64_t)p->obs_pose[i];
         const int64_t j = (int64_t)p->obs_point[i];
         double r3[3], Jp3[18], Jl3[9];
-        orc_stereo_residual(&p->cam, T, points + 3 * j, p->obs_uvd + 3 * i, p->stiffness, r3,
+        orc_stereo_residual(&p->cam, T, points + 3 * j, p->obs_uvd + 3 * i,
+                            p->obs_stiffness ? p->obs_stiffness + 9 * i : p->stiffness, r3,
                             wantJ ? Jp3 : NULL, wantJ ? Jl3 : NULL);
         double sq = r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2];
         if (p->huber_a > 0.0) {

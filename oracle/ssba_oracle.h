@@ -88,6 +88,9 @@ typedef struct {
                                           expected dir (global, 3), azimuth threshold, zenith threshold  */
     const double *pf_stiffness;        /* F*36: 6x6 (type 0) or 2x2 in the first 4 entries (type 1)       */
     const double *pf_huber;            /* F or NULL: HuberLoss parameter of the block, 0 = NULL loss       */
+    /* per-residual-block stereo stiffness (tests/dataset_vo_sun.cpp:56-65 builds one per map point from
+     * stereo_obs_covars[j]): num_obs*9 row-major, or NULL = `stiffness` for every block */
+    const double *obs_stiffness;
 } orc_problem;
 
 typedef struct {

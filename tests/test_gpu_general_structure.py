@@ -148,6 +148,38 @@ def test_pose_factors_on_the_general_path():
     assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-5)
 
 
+def _per_point_stiffness(prob, seed=0):
+    """One 3x3 inverse square root of a random covariance per map point, expanded to the residual blocks
+    (tests/dataset_vo_sun.cpp:56-59: SelfAdjointEigenSolver(stereo_obs_covars[j]).operatorInverseSqrt())."""
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(prob.num_points, 3, 3))
+    cov = A @ A.transpose(0, 2, 1) + 2.0 * np.eye(3)
+    w, V = np.linalg.eigh(cov)
+    S = np.einsum("nij,nj,nkj->nik", V, w ** -0.5, V)
+    return np.ascontiguousarray(S[prob.obs_point])
+
+
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 1)])
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+def test_per_point_stiffness_matches_oracle(strategy, huber_a):
+    prob = synth.make_problem(24, 900, track_len=8, seed=31)
+    S = _per_point_stiffness(prob)
+    opts = dict(trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    ba, s, log, op, s2, log2 = _solve_both(prob, stiffness=S, opts=opts, huber_a=huber_a)
+    assert ba.stats().general_structure == 1          # per-block stiffness lives in the general layout
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    # and the reduced system of one LM step
+    ba2 = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, S, huber_a=huber_a)
+    op2 = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, S, huber_a=huber_a)
+    Sg, rhs, dp, dl, mcc = ba2.lm_step(50.0)
+    S2, rhs2, _ = op2.reduced_system(50.0)
+    assert _rel(Sg, S2) < 1e-10 and _rel(rhs, rhs2) < 1e-10
+    # the same matrix for every block is the shared-stiffness problem
+    same = np.broadcast_to(prob.stiffness(), (prob.num_obs, 3, 3)).copy()
+    ba3 = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, same)
+    assert ba3.stats().general_structure == 0
+
+
 def test_structure_beyond_the_general_path_is_rejected_loudly():
     # lighting terms keep the windowed layout only
     prob, ph = synth.make_phong_problem(8, 200, seed=1)

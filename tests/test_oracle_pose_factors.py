@@ -190,3 +190,23 @@ def test_sun_aided_solve_reduces_heading_drift():
     s, log = op.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1, dogleg_type=1))      # :141-143
     assert s.termination_type == 0 and s.final_cost < 0.2 * s.initial_cost
     assert np.abs(op.poses[0] - prob.poses_init[0]).max() < 0.02              # the prior holds the first pose in place
+
+
+def test_per_block_stereo_stiffness():
+    """tests/dataset_vo_sun.cpp:56-65 gives every stereo block the stiffness of its map point: with the same matrix
+    everywhere the oracle reproduces the shared-stiffness problem bit for bit, and the cost follows the definition."""
+    prob = synth.make_problem(8, 200, track_len=5, seed=2)
+    same = np.broadcast_to(prob.stiffness(), (prob.num_obs, 3, 3)).copy()
+    a = orc.OracleProblem.from_synth(prob)
+    b = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, same)
+    assert a.cost() == b.cost()
+    sa, _ = a.solve(orc.driver_options(num_threads=1))
+    sb, _ = b.solve(orc.driver_options(num_threads=1))
+    assert sa.final_cost == sb.final_cost and np.array_equal(a.poses, b.poses)
+    rng = np.random.default_rng(0)
+    S = same * rng.uniform(0.5, 2.0, size=(prob.num_obs, 1, 1))
+    c = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, S)
+    q = np.einsum("nij,nj->ni", prob.poses_init[prob.obs_pose, 3:].reshape(-1, 3, 3), prob.points_init[prob.obs_point]) + prob.poses_init[prob.obs_pose, :3]
+    e = synth.project(prob.camera, q) - prob.obs_uvd
+    r = np.einsum("nij,nj->ni", S, e)
+    assert c.cost() == pytest.approx(0.5 * (r * r).sum(), rel=1e-12)
