@@ -1720,14 +1720,41 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
 int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
-    if (p->d.part || p->d.phong || p->d.dense) {
-        set_error("covariance: not available on partitioned problems, with lighting terms or on the general-structure path");
+    if (p->d.part || p->d.phong) {
+        set_error("covariance: not available on partitioned problems or with lighting terms");
         return SSBA_ERR_UNSUPPORTED;
     }
     const int f = p->pose_free[pose];
     if (f < 0) { set_error("covariance of a constant pose"); return SSBA_ERR_INVALID_ARGUMENT; }
     Dev &d = p->d;
     int rc;
+    if (d.dense) {
+        // general layout: the six unit vectors go into rows 0..5 of the right-hand-side block row, the blocked
+        // Cholesky forward-solves them with the factorisation, then one back-substitution sweep per row
+        ssba_options o;
+        ssba_default_options(&o);
+        if ((rc = begin_hook(p, &o, 1e300))) return rc;
+        Launcher &L = p->launcher;
+        launch_linearize(L, d);
+        launch_dense_schur(L, d);
+        const size_t lda = (size_t)d.dn_pad;
+        HIPCHECK(hipMemsetAsync(d.dn_S + lda * lda, 0, (size_t)DN_BS * lda * sizeof(double), L.stream));
+        const double one = 1.0;
+        for (int c = 0; c < 6; ++c)
+            HIPCHECK(hipMemcpyAsync(d.dn_S + (lda + c) * lda + (size_t)f * 6 + c, &one, sizeof one, hipMemcpyHostToDevice, L.stream));
+        launch_finish_check(L, d);
+        launch_dense_solve(L, d, 6);
+        HIPCHECK(hipStreamSynchronize(L.stream));
+        HIPCHECK(hipGetLastError());
+        if ((rc = fetch_state(p))) return rc;
+        if (p->h_state->step_failed) { set_error("covariance: the reduced camera system is not positive definite (gauge freedom?)"); return SSBA_ERR_NUMERICAL_FAILURE; }
+        for (int c = 0; c < 6; ++c) {
+            double col[6];
+            HIPCHECK(hipMemcpy(col, d.dn_S + (lda + c) * lda + (size_t)f * 6, sizeof col, hipMemcpyDeviceToHost));
+            for (int r = 0; r < 6; ++r) cov[6 * r + c] = col[r];
+        }
+        return SSBA_OK;
+    }
     if (!d.Spb) {      // multi-right-hand-side buffers are only allocated with a border: add them now
         drop_graph(p);
         if ((rc = dzero(p, &d.Spb, (size_t)d.nf_pad * 6 * NBP))) return rc;

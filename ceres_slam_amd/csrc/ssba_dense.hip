@@ -265,13 +265,13 @@ __global__ __launch_bounds__(256) void k_dn_syrk(Dev d, int j, const uint32_t *t
 // L_ij^T x_i from y_j for the non-zero blocks j < i (cols[], one work-group each); the last work-group owns
 // j = i - 1, whose y is complete after its own update, and solves x_{i-1} = L_{i-1,i-1}^-T y_{i-1} right away.
 // Step i = nbk (the rhs row itself) has no update and only solves the last block.
-__global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i, const uint32_t *cols, int n_upd, int upd_last) {
+__global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i, const uint32_t *cols, int n_upd, int upd_last, int row) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     __shared__ double t[DN_BS * TP], part[4][DN_BS], rd[DN_BS];
     const size_t lda = (size_t)d.dn_pad;
     const int tid = threadIdx.x, c = tid & 63, q = tid >> 6;
-    double *xrow = d.dn_S + (size_t)d.dn_pad * lda;
+    double *xrow = d.dn_S + (size_t)(d.dn_pad + row) * lda;     // row 0: the solve's right-hand side; rows 1.. : extra ones (covariance)
     const bool solver = (int)blockIdx.x == n_upd;
     const int j = solver ? i - 1 : (int)cols[blockIdx.x];
     double s = 0.0;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i, const uint32_t *co
             else if (c < m) v -= t[m * TP + c] * xm;
         }
         const int g = j * DN_BS + c;
-        if (g < d.n_dn) d.x0[g] = v;
+        if (g < d.n_dn && row == 0) d.x0[g] = v;
     }
     xrow[j * DN_BS + c] = v;
 }
@@ -317,7 +317,7 @@ void launch_dense_finish(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_dn_finish, dim3((d.dn_pad + 255) / 256), dim3(256), 0, d);
 }
 
-void launch_dense_solve(Launcher &L, const Dev &d) {
+void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows) {
     const DensePlan &pl = L.dense;
     const int nbk = pl.nbk;
     for (int j = 0; j < nbk; ++j) {
@@ -326,10 +326,11 @@ void launch_dense_solve(Launcher &L, const Dev &d) {
         LAUNCH(KC_BCR_FACTOR, k_dn_trsm, dim3(nr), dim3(64), 0, d, j, d.dn_rows + r0);
         LAUNCH(KC_BCR_REDUCE, k_dn_syrk, dim3(nt), dim3(256), 0, d, j, d.dn_ti + t0, d.dn_tk + t0);
     }
-    for (int i = nbk; i >= 1; --i) {
-        const uint32_t c0 = pl.col_start[i], nc = pl.col_start[i + 1] - c0;
-        LAUNCH(KC_BCR_BACKSUB, k_dn_bwd, dim3(nc + 1), dim3(256), 0, d, i, d.dn_cols + c0, (int)nc, (int)pl.upd_last[i]);
-    }
+    for (int row = 0; row < n_rhs_rows; ++row)
+        for (int i = nbk; i >= 1; --i) {
+            const uint32_t c0 = pl.col_start[i], nc = pl.col_start[i + 1] - c0;
+            LAUNCH(KC_BCR_BACKSUB, k_dn_bwd, dim3(nc + 1), dim3(256), 0, d, i, d.dn_cols + c0, (int)nc, (int)pl.upd_last[i], row);
+        }
 }
 
 }  // namespace ssba

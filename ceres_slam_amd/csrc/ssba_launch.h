@@ -136,6 +136,6 @@ void launch_bcr_multi_rhs(Launcher &L, const Dev &d);
 // general structure: dense reduced camera system (ssba_dense.hip)
 void launch_dense_schur(Launcher &L, const Dev &d);
 void launch_dense_finish(Launcher &L, const Dev &d);
-void launch_dense_solve(Launcher &L, const Dev &d);
+void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows = 1);   // rows of the rhs block row to back-substitute
 
 }  // namespace ssba

@@ -180,6 +180,31 @@ def test_per_point_stiffness_matches_oracle(strategy, huber_a):
     assert ba3.stats().general_structure == 0
 
 
+@pytest.mark.parametrize("P", [6, 30])
+def test_pose_covariance_on_the_general_path(P):
+    """dataset_vo_sun.cpp:159-183 with the driver's per-point stiffness: the covariance block comes from the dense factor."""
+    from test_oracle_pose_factors import _sun_problem
+    prob, factors = _sun_problem(P=P, L=60 * P, seed=7)
+    S = _per_point_stiffness(prob, seed=3)
+    none_const = np.zeros(prob.num_poses, dtype=np.uint8)
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, S,
+                  pose_const=none_const, pose_factors=factors)
+    assert ba.stats().general_structure == 1
+    ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1))
+    op = orc.OracleProblem(prob.camera, ba.poses, ba.points, prob.obs_pose, prob.obs_point, prob.obs_uvd, S,
+                           pose_const=none_const, pose_factors=factors)
+    S2, _, free_idx = op.reduced_system(1e300)
+    Sg = ba.lm_step(1e300)[0]
+    assert _rel(Sg, S2) < 1e-6
+    Sginv = np.linalg.inv(Sg)
+    for k in (1, P // 2, P - 1):
+        f = int(free_idx[k])
+        cov = ba.pose_covariance(k)
+        assert _rel(cov, Sginv[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]) < 1e-6
+        assert _rel(cov, np.linalg.inv(S2)[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]) < 1e-3
+        assert np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
+
+
 def test_structure_beyond_the_general_path_is_rejected_loudly():
     # lighting terms keep the windowed layout only
     prob, ph = synth.make_phong_problem(8, 200, seed=1)
