@@ -54,7 +54,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 def build_examples(name: str = "dataset_vo_gpu") -> str:
     """C++ drivers written against the Ceres-shaped shim (include/ceres_slam_amd/ceres_shim.hpp):
-    dataset_vo_gpu (tests/dataset_vo.cpp) and dataset_ba_phong_gpu (tests/dataset_ba_phong.cpp)."""
+    dataset_vo_gpu (tests/dataset_vo.cpp), dataset_ba_phong_gpu (tests/dataset_ba_phong.cpp) and dataset_vo_sun_gpu
+    (tests/dataset_vo_sun.cpp)."""
     root = os.path.dirname(HERE)
     src = os.path.join(root, "examples", name + ".cpp")
     out = os.path.join(root, "examples", name)

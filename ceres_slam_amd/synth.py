@@ -310,6 +310,47 @@ def write_reference_csv(prob: StereoBAProblem, dataset_path: str) -> tuple:
     return dataset_path, poses_path, map_path
 
 
+def make_sun_data(prob: StereoBAProblem, seed: int = 0, sun_sigma: float = 0.01) -> dict:
+    """Extra data of the sun-aided VO driver (tests/dataset_vo_sun.cpp, DatasetProblemSun): a 3x3 covariance per stereo
+    observation, the expected sun direction per state in the global frame, and for three states out of four an
+    observed direction in the camera frame (R_k s_g + noise) with a 2x2 azimuth / zenith covariance."""
+    rng = np.random.default_rng(seed)
+    N, P = prob.num_obs, prob.num_poses
+    A = rng.normal(size=(N, 3, 3)) * 0.1
+    obs_covars = A @ A.transpose(0, 2, 1) + np.diag(prob.stereo_obs_var)
+    sun_g = np.array([0.3, -0.8, 0.5])
+    sun_g = sun_g / np.linalg.norm(sun_g)
+    sun_dir_g = np.tile(sun_g, (P, 1))
+    has_sun = (np.arange(P) % 4) != 3
+    R = prob.poses_gt[:, 3:].reshape(P, 3, 3)
+    sun_obs = np.einsum("kij,j->ki", R, sun_g) + sun_sigma * rng.normal(size=(P, 3))
+    B = rng.normal(size=(P, 2, 2)) * 0.002
+    sun_covars = B @ B.transpose(0, 2, 1) + np.eye(2) * sun_sigma ** 2
+    return dict(obs_covars=obs_covars, sun_dir_g=sun_dir_g, sun_obs=sun_obs, sun_covars=sun_covars, has_sun=has_sun)
+
+
+def write_reference_sun_csv(prob: StereoBAProblem, sun: dict, track_path: str) -> tuple:
+    """The three input files of tests/dataset_vo_sun.cpp in the formats DatasetProblemSun::read_csv parses
+    (src/ceres_slam/dataset_problem_sun.cpp:16-170).  Returns (track_file, ref_sun_file, obs_sun_file)."""
+    base = track_path[: track_path.rfind(".")] if "." in track_path else track_path
+    c = prob.camera
+    with open(track_path, "w") as f:
+        f.write(f"{prob.num_poses},{prob.num_points}\n")
+        f.write(",".join(repr(float(c[k])) for k in ("fu", "fv", "cu", "cv", "b")) + "\n")
+        f.write(",".join(repr(float(v)) for v in _T44_rows(prob.poses_gt[0])) + "\n")
+        for k, j, uvd, cov in zip(prob.obs_pose, prob.obs_point, prob.obs_uvd, sun["obs_covars"]):
+            f.write(f"{int(k)},{int(j)}," + ",".join(repr(float(v)) for v in np.concatenate([uvd, cov.ravel()])) + "\n")
+    ref_path, obs_path = base + "_ref_sun.csv", base + "_obs_sun.csv"
+    with open(ref_path, "w") as f:
+        for k, v in enumerate(sun["sun_dir_g"]):
+            f.write(f"{k}," + ",".join(repr(float(x)) for x in v) + "\n")
+    with open(obs_path, "w") as f:
+        for k in range(prob.num_poses):
+            if sun["has_sun"][k]:
+                f.write(f"{k}," + ",".join(repr(float(x)) for x in np.concatenate([sun["sun_obs"][k], sun["sun_covars"][k].ravel()])) + "\n")
+    return track_path, ref_path, obs_path
+
+
 def read_pose_csv(path: str) -> np.ndarray:
     rows = [l for l in open(path).read().splitlines()[1:] if l.strip()]
     T = np.array([[float(x) for x in r.split(",")] for r in rows]).reshape(-1, 4, 4)

@@ -21,6 +21,16 @@
 //     problem.SetParameterLowerBound(phong_m, 0, 0.);  problem.SetParameterUpperBound(phong_m, 0, 1.); ...
 //     options.trust_region_strategy_type = ceres::DOGLEG;  options.dogleg_type = ceres::SUBSPACE_DOGLEG;
 //
+// and of the sun-aided VO driver (tests/dataset_vo_sun.cpp:28-185):
+//
+//     problem.AddResidualBlock(StereoReprojectionErrorAutomatic::Create(camera, obs, stiffness_of_point_j), NULL, pose_k, point_j);
+//     problem.AddResidualBlock(SunSensorErrorAutomatic::Create(sun_obs_c, sun_dir_g, stiffness2x2, az_thresh, zen_thresh),
+//                              new ceres::HuberLoss(huber_param), pose_k);
+//     problem.AddResidualBlock(PoseErrorAutomatic::Create(T_ref, stiffness6x6), NULL, pose_k1);
+//     ceres::Covariance covariance(covariance_options);
+//     covariance.Compute(covar_blocks, &problem);
+//     covariance.GetCovarianceBlockInTangentSpace(pose, pose, out36);
+//
 // The shim recognises the typed cost functions of this path and lowers them to observation
 // tables; it does NOT run arbitrary user functors on the GPU -- any other CostFunction is
 // rejected at AddResidualBlock with std::invalid_argument (Ceres would accept it: that is the
@@ -35,6 +45,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../ssba.h"
@@ -56,6 +67,8 @@ enum TerminationType { CONVERGENCE = 0, NO_CONVERGENCE = 1, FAILURE = 2 };
 enum LinearSolverType { SPARSE_NORMAL_CHOLESKY, SPARSE_SCHUR, DENSE_SCHUR };
 enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
 enum DoglegType { TRADITIONAL_DOGLEG, SUBSPACE_DOGLEG };
+enum CovarianceAlgorithmType { DENSE_SVD, SPARSE_QR };
+enum SparseLinearAlgebraLibraryType { SUITE_SPARSE, CX_SPARSE, EIGEN_SPARSE, NO_SPARSE };
 
 }  // namespace ceres
 
@@ -81,6 +94,35 @@ class StereoReprojectionErrorAutomatic : public ceres::CostFunction {
     std::shared_ptr<const StereoCamera> camera;
     double observation[3];
     double stiffness[9];
+};
+
+// include/ceres_slam/pose_error.hpp:59-66: prior on a pose block, r = S log(T_ref T^-1); T_ref is the 12-double
+// [t | R row-major] block (SE3Group::data()), stiffness 6x6 row-major
+class PoseErrorAutomatic : public ceres::CostFunction {
+ public:
+    static ceres::CostFunction *Create(const double T_k_0_ref[12], const double stiffness[36]) {
+        PoseErrorAutomatic *c = new PoseErrorAutomatic;
+        std::memcpy(c->T_ref, T_k_0_ref, sizeof c->T_ref);
+        std::memcpy(c->stiffness, stiffness, sizeof c->stiffness);
+        return c;
+    }
+    double T_ref[12], stiffness[36];
+};
+
+// include/ceres_slam/sun_sensor_error.hpp:108-120: azimuth / zenith error of the expected sun direction, stiffness 2x2
+class SunSensorErrorAutomatic : public ceres::CostFunction {
+ public:
+    static ceres::CostFunction *Create(const double observed_sun_dir_c[3], const double expected_sun_dir_g[3], const double stiffness[4],
+                                       double az_err_thresh, double zen_err_thresh) {
+        SunSensorErrorAutomatic *c = new SunSensorErrorAutomatic;
+        std::memcpy(c->observed, observed_sun_dir_c, sizeof c->observed);
+        std::memcpy(c->expected, expected_sun_dir_g, sizeof c->expected);
+        std::memcpy(c->stiffness, stiffness, sizeof c->stiffness);
+        c->az_thresh = az_err_thresh;
+        c->zen_thresh = zen_err_thresh;
+        return c;
+    }
+    double observed[3], expected[3], stiffness[4], az_thresh, zen_thresh;
 };
 
 // include/ceres_slam/perturbations.hpp:69-75
@@ -202,6 +244,35 @@ class Problem {
         owned_costs_.push_back(cost);
     }
 
+    // unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124): pose prior, sun sensor (optionally with HuberLoss)
+    void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block) {
+        PoseFactor f;
+        std::memset(&f, 0, sizeof f);
+        if (auto *c = dynamic_cast<ceres_slam::PoseErrorAutomatic *>(cost)) {
+            f.type = 0;
+            std::memcpy(f.data, c->T_ref, sizeof c->T_ref);
+            std::memcpy(f.stiffness, c->stiffness, sizeof c->stiffness);
+        } else if (auto *c2 = dynamic_cast<ceres_slam::SunSensorErrorAutomatic *>(cost)) {
+            f.type = 1;
+            std::memcpy(f.data, c2->observed, sizeof c2->observed);
+            std::memcpy(f.data + 3, c2->expected, sizeof c2->expected);
+            f.data[6] = c2->az_thresh; f.data[7] = c2->zen_thresh;
+            std::memcpy(f.stiffness, c2->stiffness, sizeof c2->stiffness);
+        } else {
+            throw std::invalid_argument("ceres_shim: a one-block residual must be a PoseErrorAutomatic or SunSensorErrorAutomatic");
+        }
+        if (loss) {
+            HuberLoss *h = dynamic_cast<HuberLoss *>(loss);
+            if (!h) throw std::invalid_argument("ceres_shim: loss must be NULL or ceres::HuberLoss");
+            owned_losses_[loss] = 1;
+            f.huber = h->a();
+        }
+        f.pose = pose_block;
+        block_index(pose_index_, pose_blocks_, pose_block);
+        pose_factors_.push_back(f);
+        owned_costs_.push_back(cost);
+    }
+
     void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *point_block) {
         if (auto *n = dynamic_cast<ceres_slam::NormalErrorAutomatic *>(cost)) {   // (pose, normal): dataset_ba_phong.cpp:181-188
             if (loss) throw std::invalid_argument("ceres_shim: lighting residual blocks take a NULL loss");
@@ -224,12 +295,12 @@ class Problem {
         const double a = h ? h->a() : 0.0;
         if (obs_pose_.empty()) {
             camera_ = s->camera;
-            std::memcpy(stiffness_, s->stiffness, sizeof stiffness_);
             huber_a_ = a;
-        } else if (std::memcmp(stiffness_, s->stiffness, sizeof stiffness_) != 0 || a != huber_a_ ||
+        } else if (a != huber_a_ ||
                    (s->camera != camera_ && std::memcmp(s->camera.get(), camera_.get(), sizeof(ceres_slam::StereoCamera)) != 0)) {
-            throw std::invalid_argument("ceres_shim: all residual blocks must share camera, stiffness and loss");
+            throw std::invalid_argument("ceres_shim: all stereo residual blocks must share camera and loss");
         }
+        obs_stiffness_.insert(obs_stiffness_.end(), s->stiffness, s->stiffness + 9);    // may differ per block (dataset_vo_sun.cpp:56-65)
         obs_pose_.push_back(block_index(pose_index_, pose_blocks_, pose_block));
         obs_point_.push_back(block_index(point_index_, point_blocks_, point_block));
         obs_uvd_.insert(obs_uvd_.end(), s->observation, s->observation + 3);
@@ -252,6 +323,28 @@ class Problem {
 
  private:
     friend void Solve(const Solver::Options &, Problem *, Solver::Summary *);
+    friend class Covariance;
+    // the stereo + unary-pose part of the lowering, shared by Solve and Covariance::Compute; returns the failing call or NULL
+    const char *lower_core_(ssba_problem *h, std::vector<double> &poses, std::vector<double> &points, int *rc) {
+        if ((*rc = ssba_add_pose_blocks(h, poses.data(), (uint32_t)pose_blocks_.size()))) return "ssba_add_pose_blocks";
+        if ((*rc = ssba_add_point_blocks(h, points.data(), (uint32_t)point_blocks_.size()))) return "ssba_add_point_blocks";
+        for (size_t b = 0; b < obs_pose_.size();) {      // runs of equal stiffness: one call each (a single run for the other drivers)
+            size_t e = b + 1;
+            while (e < obs_pose_.size() && std::memcmp(&obs_stiffness_[9 * e], &obs_stiffness_[9 * b], 9 * sizeof(double)) == 0) ++e;
+            if ((*rc = ssba_add_stereo_observations(h, &obs_pose_[b], &obs_point_[b], &obs_uvd_[3 * b], e - b, &obs_stiffness_[9 * b])))
+                return "ssba_add_stereo_observations";
+            b = e;
+        }
+        for (auto &kv : constant_)
+            if (pose_index_.count(kv.first) && (*rc = ssba_set_pose_constant(h, pose_index_[kv.first], 1))) return "ssba_set_pose_constant";
+        for (auto &f : pose_factors_) {
+            const uint32_t k = pose_index_[f.pose];
+            if (f.type == 0) { if ((*rc = ssba_add_pose_prior(h, k, f.data, f.stiffness, f.huber))) return "ssba_add_pose_prior"; }
+            else if ((*rc = ssba_add_sun_observation(h, k, f.data, f.data + 3, f.stiffness, f.data[6], f.data[7], f.huber))) return "ssba_add_sun_observation";
+        }
+        if (huber_a_ > 0 && (*rc = ssba_set_huber_loss(h, huber_a_))) return "ssba_set_huber_loss";
+        return nullptr;
+    }
     static uint32_t block_index(std::map<double *, uint32_t> &idx, std::vector<double *> &blocks, double *b) {
         auto it = idx.find(b);
         if (it != idx.end()) return it->second;
@@ -261,8 +354,10 @@ class Problem {
         return i;
     }
     std::shared_ptr<const ceres_slam::StereoCamera> camera_;
-    double stiffness_[9];
+    std::vector<double> obs_stiffness_;          // 9 per stereo residual block
     double huber_a_ = 0.0;
+    struct PoseFactor { int type; double *pose; double data[18], stiffness[36], huber; };
+    std::vector<PoseFactor> pose_factors_;
     std::map<double *, uint32_t> pose_index_, point_index_;
     std::vector<double *> pose_blocks_, point_blocks_;
     std::vector<uint32_t> obs_pose_, obs_point_;
@@ -300,12 +395,7 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
         if (h) ssba_destroy(h);
     };
     if (rc) return fail("ssba_create");
-    if ((rc = ssba_add_pose_blocks(h, poses.data(), (uint32_t)P.pose_blocks_.size()))) return fail("ssba_add_pose_blocks");
-    if ((rc = ssba_add_point_blocks(h, points.data(), (uint32_t)P.point_blocks_.size()))) return fail("ssba_add_point_blocks");
-    if ((rc = ssba_add_stereo_observations(h, P.obs_pose_.data(), P.obs_point_.data(), P.obs_uvd_.data(), P.obs_pose_.size(), P.stiffness_)))
-        return fail("ssba_add_stereo_observations");
-    for (auto &kv : P.constant_)
-        if (P.pose_index_.count(kv.first) && (rc = ssba_set_pose_constant(h, P.pose_index_[kv.first], 1))) return fail("ssba_set_pose_constant");
+    if (const char *where = P.lower_core_(h, poses, points, &rc)) return fail(where);
     // ---- lighting terms (tests/dataset_ba_phong.cpp:101-204) -> the config-3 tables of the C ABI ----
     std::vector<double> normals, phong, texture, intensity, normal_obs;
     std::vector<double *> normal_blocks(P.point_blocks_.size(), nullptr), phong_blocks, texture_blocks;
@@ -395,7 +485,6 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
         if ((rc = bounds(phong_blocks, SSBA_BLOCK_PHONG, 3))) return fail("ssba_set_shared_block_bounds");
         if ((rc = bounds(texture_blocks, SSBA_BLOCK_TEXTURE, 1))) return fail("ssba_set_shared_block_bounds");
     }
-    if (P.huber_a_ > 0 && (rc = ssba_set_huber_loss(h, P.huber_a_))) return fail("ssba_set_huber_loss");
     if ((rc = ssba_finalize(h))) return fail("ssba_finalize");
     ssba_options o;
     ssba_default_options(&o);
@@ -430,6 +519,66 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
         }
     }
 }
+
+// ceres::Covariance for pose blocks (tests/dataset_vo_sun.cpp:159-183): Compute evaluates the requested diagonal pose
+// blocks of (J^T J)^-1 in the tangent space at the problem's current parameter values (loss-corrected Jacobian, as
+// Ceres' default apply_loss_function = true); GetCovarianceBlockInTangentSpace copies one out (6x6 row-major).
+class Covariance {
+ public:
+    struct Options {
+        int num_threads = 1;
+        CovarianceAlgorithmType algorithm_type = SPARSE_QR;
+        SparseLinearAlgebraLibraryType sparse_linear_algebra_library_type = SUITE_SPARSE;
+        int null_space_rank = 0;
+        bool apply_loss_function = true;
+    };
+    explicit Covariance(const Options &options) : options_(options) {}
+    bool Compute(const std::vector<std::pair<const double *, const double *>> &blocks, Problem *problem) {
+        Problem &P = *problem;
+        blocks_.clear();
+        message_.clear();
+        if (!P.intensity_.empty() || !P.normals_.empty()) { message_ = "covariance is not available with lighting terms"; return false; }
+        std::vector<double> poses(P.pose_blocks_.size() * 12), points(P.point_blocks_.size() * 3);
+        for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(&poses[12 * i], P.pose_blocks_[i], 12 * sizeof(double));
+        for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(&points[3 * i], P.point_blocks_[i], 3 * sizeof(double));
+        if (!P.camera_) { message_ = "no stereo residual blocks"; return false; }
+        ssba_camera cam = {P.camera_->fu, P.camera_->fv, P.camera_->cu, P.camera_->cv, P.camera_->b};
+        ssba_problem *h = nullptr;
+        int rc = ssba_create(&cam, -1, &h);
+        const char *where = rc ? "ssba_create" : P.lower_core_(h, poses, points, &rc);
+        if (!where && (rc = ssba_finalize(h))) where = "ssba_finalize";
+        for (size_t i = 0; !where && i < blocks.size(); ++i) {
+            double *a = const_cast<double *>(blocks[i].first);
+            if (blocks[i].first != blocks[i].second || !P.pose_index_.count(a)) {
+                message_ = "only diagonal pose blocks are supported";
+                rc = SSBA_ERR_UNSUPPORTED;
+                where = "Covariance::Compute";
+                break;
+            }
+            Block b;
+            b.ptr = blocks[i].first;
+            if ((rc = ssba_pose_covariance(h, P.pose_index_[a], b.cov))) where = "ssba_pose_covariance";
+            else blocks_.push_back(b);
+        }
+        if (where && message_.empty()) message_ = std::string(where) + ": " + ssba_status_string(rc) + " (" + ssba_last_error() + ")";
+        if (h) ssba_destroy(h);
+        if (where) blocks_.clear();
+        return where == nullptr;     // like Ceres: false on a rank-deficient Jacobian (no gauge constraint)
+    }
+    bool GetCovarianceBlockInTangentSpace(const double *a, const double *b, double *out) const {
+        if (a != b) return false;
+        for (const Block &blk : blocks_)
+            if (blk.ptr == a) { std::memcpy(out, blk.cov, sizeof blk.cov); return true; }
+        return false;
+    }
+    const std::string &message() const { return message_; }
+
+ private:
+    struct Block { const double *ptr; double cov[36]; };
+    Options options_;
+    std::vector<Block> blocks_;
+    std::string message_;
+};
 
 }  // namespace ceres
 #endif
