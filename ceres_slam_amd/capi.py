@@ -33,7 +33,7 @@ SYMBOLS = [
     "ssba_set_exchange", "ssba_set_distributed", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
     "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
-    "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds",
+    "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation",
     "ssba_pose_covariance",
 ]
@@ -135,6 +135,7 @@ def load():
     L.ssba_add_light_block.argtypes = [H, _dp, C.c_int]
     L.ssba_set_shared_block_constant.argtypes = [H, C.c_int, C.c_int]
     L.ssba_set_shared_block_bounds.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.ssba_set_point_blocks_constant.argtypes = [H, C.c_int]
     L.ssba_border_system.argtypes = [H, C.POINTER(C.c_uint32), _dp, _dp, _dp, _dp]
     L.ssba_add_lighting_observations.argtypes = [H, _dp, C.c_double, _dp, _dp, C.c_uint64]
     L.ssba_add_pose_prior.argtypes = [H, C.c_uint32, _dp, _dp, C.c_double]

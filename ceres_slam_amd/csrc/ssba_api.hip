@@ -43,7 +43,7 @@ struct ssba_problem {
     std::vector<uint32_t> obs_pose, obs_point;
     std::vector<double> obs_uvd;
     double S[9] = {0};
-    bool have_S = false, per_obs_S = false;
+    bool have_S = false, per_obs_S = false, points_const = false;
     std::vector<double> obs_S;          // 9 per observation once two stereo blocks differ in stiffness
     std::vector<uint8_t> pose_const;
     double huber_a = 0.0;
@@ -401,6 +401,13 @@ int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant) {
     return SSBA_OK;
 }
 
+int ssba_set_point_blocks_constant(ssba_problem *p, int is_constant) {
+    if (!p) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    p->points_const = is_constant != 0;
+    return SSBA_OK;
+}
+
 int ssba_set_huber_loss(ssba_problem *p, double a) {
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     p->huber_a = a > 0.0 ? a : 0.0;
@@ -545,6 +552,10 @@ int ssba_finalize(ssba_problem *p) {
         int flo = 1 << 30, fhi = -1;
         for (uint32_t k : ks) { const int f = p->pose_free[k]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
         if (fhi - flo > SBP) dense = true;
+    }
+    if (p->points_const && !ph) {
+        set_error("constant position blocks are only available with lighting terms (stage 2 of --multistage)");
+        return SSBA_ERR_UNSUPPORTED;
     }
     if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
     if (p->per_obs_S) dense = true;     // per-block stiffness lives in the general layout only
@@ -859,6 +870,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.sl, (size_t)Lpad * (ph ? 6 : 3)));
     if (ph) {
         d.phong = 1;
+        d.pos_const = p->points_const ? 1 : 0;
         d.light_type = p->ph_light_type;
         d.M = (int)p->M;
         d.nsh = 3 + 4 * (int)p->M;

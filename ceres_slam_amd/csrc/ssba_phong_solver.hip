@@ -103,6 +103,10 @@ static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const doub
 #pragma unroll
         for (int i = 0; i < 18; ++i) o.Jp[24 + i] = Jnp[i];
     }
+    if (d.pos_const) {      // constant position blocks (dataset_ba_phong.cpp:213-220): their Jacobian columns leave the problem
+#pragma unroll
+        for (int m = 0; m < 7; ++m) o.Jl[6 * m] = o.Jl[6 * m + 1] = o.Jl[6 * m + 2] = 0.0;
+    }
     o.half_sq = s.half_rho + 0.5 * (ri * ri + rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2]);
 }
 
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
             for (int c = 0; c < 6; ++c)
                 d.sl[(size_t)c * d.Lpad + l] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h[tri6(c, c)])) : 1.0;
         }
-        xn = x.p[0] * x.p[0] + x.p[1] * x.p[1] + x.p[2] * x.p[2] + x.n[0] * x.n[0] + x.n[1] * x.n[1] + x.n[2] * x.n[2];
+        xn = x.n[0] * x.n[0] + x.n[1] * x.n[1] + x.n[2] * x.n[2];
+        if (!d.pos_const) xn += x.p[0] * x.p[0] + x.p[1] * x.p[1] + x.p[2] * x.p[2];
         // projected gradient |x - Plus(x, -g)|_inf: Euclidean for the position, unit-vector Plus for the normal
         const double ng[3] = {-g[3], -g[4], -g[5]};
         double nn[3];
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) {
             for (int q = 0; q < NBQ; ++q) {
                 G[q] += J19[12 + q] * ri;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) V[a * NBQ + q] += J19[6 + a] * J19[12 + q];
+                for (int a = 0; a < 6; ++a) V[a * NBQ + q] += (a < 3 && d.pos_const ? 0.0 : J19[6 + a]) * J19[12 + q];
 #pragma unroll
                 for (int q2 = q; q2 < NBQ; ++q2) H[c++] += J19[12 + q] * J19[12 + q2];
             }

@@ -177,7 +177,7 @@ struct Dev {
     double *part_ls;                                // n_lm_blocks * NLS line-search partials
     double *ls_out;                                 // NLS_OUT scalars the host reads per probe
     // unary pose residual blocks (pose prior, sun sensor), sorted by pose
-    int n_pf, pad3_;
+    int n_pf, pos_const;                            // pos_const: every position block constant (--multistage stage 2; lighting problems)
     const uint32_t *pf_start;                       // P+1
     const int *pf_type;                             // F
     const double *pf_data, *pf_S, *pf_huber;        // F*18, F*36, F

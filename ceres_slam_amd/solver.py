@@ -15,7 +15,7 @@ from . import capi
 class StereoBA:
     def __init__(self, camera: dict, poses: np.ndarray, points: np.ndarray, obs_pose, obs_point, obs_uvd,
                  stiffness, pose_const=None, huber_a: float = 0.0, device: int = -1, finalize: bool = True,
-                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0, use_bounds: bool = False,
+                 world_size: int = 1, rank: int = 0, lighting: dict = None, shared_free: int = 0, use_bounds: bool = False, points_const: bool = False,
                  partition=None, pose_factors=None):
         self.lib = capi.load()
         self.poses = np.ascontiguousarray(poses, dtype=np.float64)     # caller-owned blocks, updated in place
@@ -73,6 +73,8 @@ class StereoBA:
         self.use_bounds = bool(use_bounds)
         if lighting is not None:
             self._add_lighting(lighting)
+        if points_const:      # stage 2 of --multistage (tests/dataset_ba_phong.cpp:210-228)
+            capi.check(self.lib.ssba_set_point_blocks_constant(self.h, 1), "ssba_set_point_blocks_constant")
         if world_size > 1:
             capi.check(self.lib.ssba_set_distributed(self.h, world_size, rank), "ssba_set_distributed")
             if partition is not None:     # separator super-blocks of a super-block-aligned sharding (sharding.aligned_partition)

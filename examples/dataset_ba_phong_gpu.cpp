@@ -3,7 +3,7 @@
 // include/ceres_slam_amd/ceres_shim.hpp: the same calls the reference makes against Ceres, executed by the
 // MI355X back end.
 //
-// usage: dataset_ba_phong_gpu <dataset.csv> <init_poses.csv> <init_map.csv> <init_lights.csv> [--nolight | --dirlight]
+// usage: dataset_ba_phong_gpu <dataset.csv> <init_poses.csv> <init_map.csv> <init_lights.csv> [--nolight | --dirlight] [--multistage]
 //   dataset.csv     reference format (src/ceres_slam/dataset_problem_phong.cpp:16-117): rows
 //                   "num_states,num_vertices,num_materials" | "fu,fv,cu,cv,b" |
 //                   "stereo var (3), normal var (3), intensity var" | light position or direction |
@@ -11,8 +11,9 @@
 //   init_*.csv      initial guess in the formats the reference's write_csv emits (:177-232): 4x4 poses;
 //                   "point_id,x,y,z,nx,ny,nz,ka,ks,exponent,kd"; light "x,y,z"
 // The front end that produces the initial guess (compute_initial_guess: matching + RANSAC, :250-400) is
-// SURVEY.md section 8(f) row N2 and not part of this path.  --multistage (positions held constant in
-// stage 2, :210-246) is not supported by the GPU path.
+// SURVEY.md section 8(f) row N2 and not part of this path.  --multistage runs the reference's three stages
+// (:96-100 poses and points without lighting terms, :210-246 lighting with every pose and position block
+// constant, :249-252 everything jointly).
 // Output: <dataset>_poses.csv / _map.csv / _lights.csv at full precision + the brief report.
 #include <cmath>
 #include <fstream>
@@ -33,13 +34,14 @@ static std::vector<double> parse_row(const std::string &line) {
 
 int main(int argc, char **argv) {
     if (argc < 5) {
-        std::cerr << "usage: dataset_ba_phong_gpu <dataset.csv> <init_poses.csv> <init_map.csv> <init_lights.csv> [--nolight | --dirlight]" << std::endl;
+        std::cerr << "usage: dataset_ba_phong_gpu <dataset.csv> <init_poses.csv> <init_map.csv> <init_lights.csv> [--nolight | --dirlight] [--multistage]" << std::endl;
         return EXIT_FAILURE;
     }
-    bool use_light = true, directional_light = false;
+    bool use_light = true, directional_light = false, multi_stage = false;
     for (int a = 5; a < argc; ++a) {
         if (std::string(argv[a]) == "--nolight") use_light = false;
         if (std::string(argv[a]) == "--dirlight") directional_light = true;
+        if (std::string(argv[a]) == "--multistage") multi_stage = true;
     }
     std::ifstream f(argv[1]);
     if (!f.is_open()) { std::cerr << "Error: couldn't open " << argv[1] << std::endl; return EXIT_FAILURE; }
@@ -138,6 +140,12 @@ int main(int argc, char **argv) {
     solver_options.linear_solver_type = ceres::SPARSE_NORMAL_CHOLESKY;
     ceres::Solver::Summary summary;
 
+    if (multi_stage) {                                              // stage 1 (:96-100): poses and points only, no lighting
+        std::cerr << "Solving stage 1: poses and points" << std::endl;
+        ceres::Solve(solver_options, &problem, &summary);
+        std::cout << summary.BriefReport() << std::endl << std::endl;
+    }
+
     if (use_light) {                                                // lighting terms (:102-207)
         for (size_t i = 0; i < vertex_ids.size(); ++i) {
             const unsigned k = state_of[i], j = vertex_ids[i], m = material_ids[i];
@@ -159,6 +167,23 @@ int main(int argc, char **argv) {
             problem.SetParameterization(&normals[3 * j], unit_vector_perturbation);
         }
         if (directional_light) problem.SetParameterization(light.data(), unit_vector_perturbation);   // :201-204
+    }
+
+    if (multi_stage) {                                              // stage 2 (:210-246): lighting only
+        for (size_t i = 0; i < vertex_ids.size(); ++i) {
+            const unsigned k = state_of[i], j = vertex_ids[i];
+            if (initialized[j]) problem.SetParameterBlockConstant(&positions[3 * j]);
+            problem.SetParameterBlockConstant(&poses[12 * k]);
+        }
+        std::cerr << "Solving stage 2: lighting" << std::endl;
+        ceres::Solve(solver_options, &problem, &summary);
+        std::cout << summary.BriefReport() << std::endl << std::endl;
+        if (summary.termination_type == ceres::FAILURE && !summary.message.empty()) std::cerr << summary.message << std::endl;
+        for (size_t i = 0; i < vertex_ids.size(); ++i) {
+            const unsigned k = state_of[i], j = vertex_ids[i];
+            if (initialized[j]) problem.SetParameterBlockVariable(&positions[3 * j]);
+            if (k > 0) problem.SetParameterBlockVariable(&poses[12 * k]);
+        }
     }
 
     std::cerr << "Solving SLAM and lighting jointly" << std::endl; // :249-252

@@ -315,6 +315,7 @@ class Problem {
     }
     // poses: per block; shared lighting blocks (light, Phong parameters, textures): checked at Solve, the
     // GPU path holds ALL blocks of one kind constant or none (what the driver's DEBUG lines do)
+    // point (position) blocks: all or none (stage 2 of --multistage), lighting problems only
     void SetParameterBlockConstant(double *block) { constant_[block] = 1; }
     void SetParameterBlockVariable(double *block) { constant_.erase(block); }
     void SetParameterLowerBound(double *block, int index, double v) { lower_[block][index] = v; }
@@ -337,6 +338,10 @@ class Problem {
         }
         for (auto &kv : constant_)
             if (pose_index_.count(kv.first) && (*rc = ssba_set_pose_constant(h, pose_index_[kv.first], 1))) return "ssba_set_pose_constant";
+        size_t const_points = 0;        // position blocks: all constant (stage 2 of --multistage, dataset_ba_phong.cpp:213-220) or none
+        for (double *b : point_blocks_) const_points += constant_.count(b);
+        if (const_points != 0 && const_points != point_blocks_.size()) throw std::invalid_argument("ceres_shim: hold all point blocks constant or none");
+        if (const_points && (*rc = ssba_set_point_blocks_constant(h, 1))) return "ssba_set_point_blocks_constant";
         for (auto &f : pose_factors_) {
             const uint32_t k = pose_index_[f.pose];
             if (f.type == 0) { if ((*rc = ssba_add_pose_prior(h, k, f.data, f.stiffness, f.huber))) return "ssba_add_pose_prior"; }

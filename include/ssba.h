@@ -305,6 +305,11 @@ int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *po
                         double *r_int, double *J_int, double *r_nrm, double *J_nrm_pose,
                         double *J_nrm_n);
 
+/* replaces: problem.SetParameterBlockConstant(map_vertices[j].position().data()) on EVERY position block (stage 2 of
+ * --multistage, tests/dataset_ba_phong.cpp:210-228; SetParameterBlockVariable afterwards = 0).  Lighting problems only:
+ * the landmark block is then the normal alone.  Before ssba_finalize. */
+int ssba_set_point_blocks_constant(ssba_problem *p, int is_constant);
+
 /* ---- unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124) ------- */
 /* ssba_add_pose_prior replaces problem.AddResidualBlock(PoseErrorAutomatic::Create(T_k_0_ref, stiffness), loss,
  *   pose) (include/ceres_slam/pose_error.hpp:22-55; dataset_vo_sun.cpp:116-118): r = stiffness * log(T_ref T^-1) with

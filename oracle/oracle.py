@@ -35,7 +35,8 @@ class Problem(C.Structure):
                 ("shared_free", C.c_uint32), ("int_stiffness", C.c_double), ("normal_stiffness", C.c_double * 9),
                 ("num_materials", C.c_uint32), ("use_bounds", C.c_uint32),
                 ("num_pose_factors", C.c_uint32), ("reserved3", C.c_uint32), ("pf_pose", _u32p), ("pf_type", _u32p),
-                ("pf_data", _dp), ("pf_stiffness", _dp), ("pf_huber", _dp), ("obs_stiffness", _dp)]
+                ("pf_data", _dp), ("pf_stiffness", _dp), ("pf_huber", _dp), ("obs_stiffness", _dp),
+                ("positions_constant", C.c_uint32), ("reserved4", C.c_uint32)]
 
 
 class Options(C.Structure):
@@ -130,7 +131,7 @@ class OracleProblem:
 
     def __init__(self, camera: dict, poses, points, obs_pose, obs_point, obs_uvd, stiffness,
                  pose_const=None, huber_a: float = 0.0, lighting=None, shared_free: int = 0, use_bounds: bool = False,
-                 pose_factors=None):
+                 pose_factors=None, positions_const: bool = False):
         self.poses = np.ascontiguousarray(poses, dtype=np.float64).copy()
         self.points = np.ascontiguousarray(points, dtype=np.float64).copy()
         self.obs_pose = np.ascontiguousarray(obs_pose, dtype=np.uint32)
@@ -159,6 +160,7 @@ class OracleProblem:
         self.c.stiffness = (C.c_double * 9)(*S.reshape(9))
         self.c.pose_const = self.pose_const.ctypes.data_as(_u8p)
         self.c.huber_a = float(huber_a)
+        self.c.positions_constant = 1 if positions_const else 0     # stage 2 of --multistage (lighting problems only)
         self.ld = 3
         self.normals = None
         if pose_factors:        # list of dicts: pose, type (0 prior / 1 sun), data (<= 18), stiffness (36 or 4), huber

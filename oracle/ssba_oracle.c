@@ -443,6 +443,8 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
                 }
             }
         }
+        if (wantJ && p->positions_constant)      /* constant position blocks: their Jacobian columns leave the problem */
+            for (int m = 0; m < nr; ++m) Jl[ld * m] = Jl[ld * m + 1] = Jl[ld * m + 2] = 0.0;
         if (r_out) memcpy(r_out + nr * i, r, (size_t)nr * sizeof(double));
         if (wantJ) {
             memcpy(Jp_out + (size_t)nr * 6 * i, Jp, (size_t)nr * 6 * sizeof(double));
@@ -476,6 +478,7 @@ typedef struct {
     /* free shared blocks ("border"): column offsets in the local border vector, -1 = constant */
     int M, nb, b_light, b_phong, b_tex;
     int *pf_start, *pf_list;   /* P+1 CSR over the unary pose factors */
+    int pos_const;             /* position blocks held constant: not part of x */
 } graph_t;
 
 /* border column of entry q of the per-observation border Jacobian [phong 3 | kd | light 3] */
@@ -497,6 +500,7 @@ static void graph_build(const orc_problem *p, graph_t *g) {
     int64_t N = p->num_obs;
     g->P = P; g->L = L; g->N = N;
     g->nr = dim_nr(p); g->ld = dim_ld(p);
+    g->pos_const = p->positions_constant != 0;
     g->M = is_phong(p) ? (int)p->num_materials : 0;
     g->b_light = g->b_phong = g->b_tex = -1;
     if (is_phong(p)) {
@@ -1619,7 +1623,7 @@ static double x_sq_diff(const graph_t *g, const double *pa, const double *qa, co
     }
     for (int j = 0; j < g->L; ++j) {
         if (!g->pt_active[j]) continue;
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 3 && !g->pos_const; ++c) {
             double d = qa[3 * j + c] - (qb ? qb[3 * j + c] : 0.0);
             s += d * d;
             if (fabs(d) > m) m = fabs(d);

@@ -91,6 +91,9 @@ typedef struct {
     /* per-residual-block stereo stiffness (tests/dataset_vo_sun.cpp:56-65 builds one per map point from
      * stereo_obs_covars[j]): num_obs*9 row-major, or NULL = `stiffness` for every block */
     const double *obs_stiffness;
+    /* 1: every position block is held constant (SetParameterBlockConstant on all of them: stage 2 of --multistage,
+     * tests/dataset_ba_phong.cpp:210-228); lighting problems only -- the landmark block is then its normal alone */
+    uint32_t positions_constant, reserved4;
 } orc_problem;
 
 typedef struct {

@@ -270,3 +270,72 @@ def test_phong_unsupported_combinations_fail_loudly():
     d["normal_obs"] = d["normal_obs"][:-1]
     with pytest.raises((capi.SsbaError, AssertionError)):
         StereoBA.from_synth(prob, lighting=d)
+
+
+# ---- --multistage (tests/dataset_ba_phong.cpp:96-246): stage 2 holds every pose and position block constant ----
+@pytest.mark.parametrize("light_type", [0, 1])
+@pytest.mark.parametrize("poses_free", [False, True])
+def test_constant_positions_lighting_only_stage(light_type, poses_free):
+    prob, ph = synth.make_phong_problem(20, 800, track_len=8, seed=5, light_type=light_type)
+    d = ph.as_oracle_dict("reference")
+    const = np.ones(prob.num_poses, dtype=np.uint8)
+    if poses_free:                      # not a driver setting, but the same machinery: positions fixed, poses free
+        const[1:] = 0
+    kw = dict(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1)
+    ba = StereoBA.from_synth(prob, lighting=d, shared_free=7, use_bounds=True, pose_const=const, points_const=True)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True, pose_const=const, positions_const=True)
+    S, rhs, dp, dl, mcc = ba.lm_step(1e3)
+    dp2, dl2, mcc2 = op.lm_step(1e3)
+    assert np.abs(dl[:, :3]).max() == 0.0 and np.abs(dl2[:, :3]).max() == 0.0
+    assert _rel(dl, dl2) < 1e-7 and mcc == pytest.approx(mcc2, rel=1e-8)
+    if poses_free:
+        assert _rel(dp, dp2) < 1e-7
+    s, log = ba.solve(capi.default_options(**kw))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, **kw))
+    assert s.termination_type == s2.termination_type == 0
+    n = min(len(log["cost"]), len(log2["cost"]), 12)
+    assert log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-6)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)
+    assert np.array_equal(ba.points, prob.points_init)            # constant blocks come back bit for bit
+    if not poses_free:
+        assert np.array_equal(ba.poses, prob.poses_init)
+    assert np.abs(ba.normals - op.normals).max() < 1e-4
+    np.testing.assert_allclose(ba.light, op.light, rtol=1e-4, atol=1e-5)
+
+
+def test_phong_driver_multistage(tmp_path):
+    """dataset_ba_phong --multistage (tests/dataset_ba_phong.cpp:96-100, 210-252): stage 1 without lighting terms,
+    stage 2 lighting only with every pose and position block constant, stage 3 jointly; against the same three
+    solves on the oracle."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples("dataset_ba_phong_gpu")
+    prob, ph = synth.make_phong_problem(30, 1200, track_len=8, seed=6)
+    files = synth.write_reference_phong_csv(prob, ph, str(tmp_path / "sim.csv"), shared="reference")
+    r = subprocess.run([exe, *files, "--multistage"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    reports = [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")]
+    assert len(reports) == 3 and all("Termination: CONVERGENCE" in l for l in reports)
+    kw = dict(num_threads=4, trust_region_strategy_type=1, dogleg_type=1)
+    args = (prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness())
+    s1 = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, *args)
+    r1, _ = s1.solve(orc.driver_options(**kw))
+    d = ph.as_oracle_dict("reference")
+    s2 = orc.OracleProblem(prob.camera, s1.poses, s1.points, *args, lighting=d, shared_free=7, use_bounds=True,
+                           pose_const=np.ones(prob.num_poses, np.uint8), positions_const=True)
+    r2, _ = s2.solve(orc.driver_options(**kw))
+    d3 = dict(d, normals=s2.normals, phong=s2.phong, texture=s2.texture, light=s2.light)
+    s3 = orc.OracleProblem(prob.camera, s2.poses, s2.points, *args, lighting=d3, shared_free=7, use_bounds=True)
+    r3, _ = s3.solve(orc.driver_options(**kw))
+    finals = [float(l.split("Final cost: ")[1].split(",")[0]) for l in reports]
+    assert finals[0] == pytest.approx(r1.final_cost, rel=1e-5)
+    assert finals[1] == pytest.approx(r2.final_cost, rel=1e-4)
+    assert finals[2] == pytest.approx(r3.final_cost, rel=1e-4)
+    poses = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(poses - s3.poses).max() < 1e-4
+    lights = np.loadtxt(str(tmp_path / "sim_lights.csv"), delimiter=",", skiprows=1)
+    np.testing.assert_allclose(lights, s3.light, rtol=1e-4, atol=1e-5)
