@@ -1204,7 +1204,7 @@ static int enqueue_kernels(ssba_problem *p);
 static int enqueue_constrained_iteration(ssba_problem *p);
 
 static int enqueue_iteration(ssba_problem *p) {
-    if (p->d.constrained) return enqueue_constrained_iteration(p);   // host-driven line search: no graph
+    if (p->d.constrained) return enqueue_constrained_iteration(p);   // host-driven line search: two graph segments around the host's read
     // The kernel sequence of an iteration is fixed (all control flow is on the device), so on
     // the plain single-GPU path it is captured once and replayed: ~45 launches become one.
     if (p->use_graph && !p->xfn && !p->launcher.timing) {
@@ -1241,7 +1241,15 @@ static int enqueue_kernels(ssba_problem *p) {
 static int enqueue_constrained_iteration(ssba_problem *p) {
     Dev &d = p->d;
     Launcher &L = p->launcher;
-    int rc = enqueue_front(p);
+    // The common case -- the full step satisfies the Armijo condition at once -- is two graph replays around one
+    // host read: [linearise .. solve .. candidate + first line-search evaluation] and [accept / reject + commit].
+    // Only the extra evaluations of a search that has to shorten the step are launched one by one.
+    int rc_front = SSBA_OK;
+    int rc = run_segment(p, 0, [&] {
+        rc_front = enqueue_front(p);
+        launch_ph_ls_probe(L, d, -1.0, 0);     // first evaluation at step 1: the candidate of the update kernels is that trial point
+    });
+    if (rc_front) return rc_front;
     if (rc) return rc;
     auto fetch = [&]() -> int {
         HIPCHECK(hipMemcpyAsync(p->h_ls, d.ls_out, NLS_OUT * sizeof(double), hipMemcpyDeviceToHost, L.stream));
@@ -1249,8 +1257,6 @@ static int enqueue_constrained_iteration(ssba_problem *p) {
         HIPCHECK(hipStreamSynchronize(L.stream));
         return SSBA_OK;
     };
-    // first evaluation at step 1: the candidate of the update kernels is that trial point
-    launch_ph_ls_probe(L, d, -1.0, 0);
     if ((rc = fetch())) return rc;
     if (!p->h_state->terminated && p->h_ls[6] != 0.0) {
         Armijo a;
@@ -1269,7 +1275,7 @@ static int enqueue_constrained_iteration(ssba_problem *p) {
         if (want != at) launch_ph_ls_probe(L, d, want, 1);
         if (want != 1.0 || at != 1.0) launch_ph_ls_accept(L, d);
     }
-    launch_decide_commit(L, d);
+    if ((rc = run_segment(p, 2, [&] { launch_decide_commit(L, d); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;

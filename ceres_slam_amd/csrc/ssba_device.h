@@ -292,6 +292,7 @@ static __device__ int poly_roots_real(const double *coef_in, int ncoef, double *
         const double ang = 2.0 * 3.14159265358979323846 * i / deg + 0.4;
         zr[i] = (1.0 + bound) * cos(ang); zi[i] = (1.0 + bound) * sin(ang);
     }
+    int polished = 0;
     for (int it = 0; it < 500; ++it) {
         double worst = 0.0;
         for (int i = 0; i < deg; ++i) {
@@ -319,7 +320,8 @@ static __device__ int poly_roots_real(const double *coef_in, int ncoef, double *
             const double rel = sqrt(stepr * stepr + stepi * stepi) / (1.0 + sqrt(zr[i] * zr[i] + zi[i] * zi[i]));
             if (rel > worst) worst = rel;
         }
-        if (worst < 1e-16) break;
+        if (polished) break;                  /* cubic convergence: one sweep after the 1e-13 sweep reaches rounding level */
+        if (worst < 1e-13) polished = 1;
     }
     for (int i = 0; i < deg; ++i) {
         if (!isfinite(zr[i])) return -1;

@@ -48,6 +48,7 @@ inline int ls_poly_roots_real(const double *coef_in, int ncoef, double *re) {
     }
     std::complex<double> z[8];
     for (int i = 0; i < deg; ++i) z[i] = std::polar(1.0 + bound, 2.0 * 3.14159265358979323846 * i / deg + 0.4);
+    int polished = 0;
     for (int it = 0; it < 500; ++it) {     // Aberth-Ehrlich (Ceres: eigenvalues of the companion matrix)
         double worst = 0.0;
         for (int i = 0; i < deg; ++i) {
@@ -62,7 +63,8 @@ inline int ls_poly_roots_real(const double *coef_in, int ncoef, double *re) {
             z[i] -= step;
             worst = std::max(worst, std::abs(step) / (1.0 + std::abs(z[i])));
         }
-        if (worst < 1e-16) break;
+        if (polished) break;                  /* cubic convergence: one sweep after the 1e-13 sweep reaches rounding level */
+        if (worst < 1e-13) polished = 1;
     }
     for (int i = 0; i < deg; ++i) {
         if (!std::isfinite(z[i].real())) return -1;

@@ -1255,6 +1255,7 @@ static int poly_roots_real(const double *coef_in, int ncoef, double *re) {
     }
     double complex z[8];
     for (int i = 0; i < deg; ++i) z[i] = (1.0 + bound) * cexp(I * (2.0 * 3.14159265358979323846 * i / deg + 0.4));
+    int polished = 0;
     for (int it = 0; it < 500; ++it) {
         double worst = 0.0;
         for (int i = 0; i < deg; ++i) {
@@ -1270,7 +1271,8 @@ static int poly_roots_real(const double *coef_in, int ncoef, double *re) {
             const double rel = cabs(step) / (1.0 + cabs(z[i]));
             if (rel > worst) worst = rel;
         }
-        if (worst < 1e-16) break;
+        if (polished) break;                  /* cubic convergence: one sweep after the 1e-13 sweep reaches rounding level */
+        if (worst < 1e-13) polished = 1;
     }
     for (int i = 0; i < deg; ++i) {
         if (!isfinite(creal(z[i]))) return -1;
