@@ -53,6 +53,22 @@ def algorithmic_work(stats, phong=False):
     lv = bcr_levels(stats["num_superblocks"])
     odd = [n // 2 for n in lv[:-1]] + [1]            # blocks factored per factor / backsub launch
     nxt = lv[1:]                                     # blocks produced per reduce launch
+    bsub = list(odd)
+    if stats.get("pcr_blocks", 0):
+        # plain levels down to the first one with <= 128 blocks, then parallel cyclic reduction of those n blocks:
+        # ceil(log2 n) steps over ALL n blocks + one decoupled factor / solve, no back-substitution sweep there
+        n = stats["pcr_blocks"]
+        k = lv.index(n)
+        steps = max(n - 1, 0).bit_length()
+        odd = [m // 2 for m in lv[:k]] + [n] * (steps + 1)
+        nxt = lv[1:k + 1] + [n] * steps
+        bsub = [n] + [m // 2 for m in lv[:k]]
+        # blocks moved per processed block: plain factor 3 in + 3 out, parallel step 3 in + 2 out (D stays), last 1 + 1;
+        # plain reduce 3 in + 2 out, parallel reduce D in/out + 4 operand blocks + the coupling and its transpose
+        fact_blocks = 6 * sum(m // 2 for m in lv[:k]) + 5 * n * steps + 2 * n
+        red_blocks = 5 * sum(lv[1:k + 1]) + 8 * n * steps
+    else:
+        fact_blocks, red_blocks = 6 * sum(odd), 5 * sum(nxt)
     bd = 72
     blk = bd * bd * 8
     if phong:
@@ -79,11 +95,11 @@ def algorithmic_work(stats, phong=False):
         # slabs in (23 KB per window) + S blocks out
         "k_assemble_reduced": dict(bytes=23040 * stats["num_windows"] + B * 288 * 2, flops=0),
         # per block: Cholesky bd^3/3 + two triangular solves with 2*bd+1 right-hand sides; 3 blocks in, 3 out
-        "k_bcr_factor": dict(bytes=6 * blk * sum(odd) / len(odd), flops=(bd ** 3 / 3 + bd * bd * (2 * bd + 1)) * sum(odd) / len(odd)),
+        "k_bcr_factor": dict(bytes=blk * fact_blocks / len(odd), flops=(bd ** 3 / 3 + bd * bd * (2 * bd + 1)) * sum(odd) / len(odd)),
         # per new block: three bd^3 products (2 flop per FMA), 3 blocks in, 2 out
-        "k_bcr_reduce": dict(bytes=5 * blk * sum(nxt) / len(nxt), flops=3 * 2 * bd ** 3 * sum(nxt) / len(nxt)),
+        "k_bcr_reduce": dict(bytes=blk * red_blocks / max(len(nxt), 1), flops=3 * 2 * bd ** 3 * sum(nxt) / max(len(nxt), 1)),
         # per block: two mat-vecs + one triangular solve; 3 blocks in
-        "k_bcr_backsub": dict(bytes=3 * blk * sum(odd) / len(odd), flops=(4 * bd * bd + bd * bd) * sum(odd) / len(odd)),
+        "k_bcr_backsub": dict(bytes=3 * blk * sum(bsub) / len(bsub), flops=(4 * bd * bd + bd * bd) * sum(bsub) / len(bsub)),
     }
     if lm:
         out.update(lm)

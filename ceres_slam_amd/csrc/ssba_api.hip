@@ -982,6 +982,21 @@ int ssba_finalize(ssba_problem *p) {
         }
         d.n_levels = lev + 1;
     }
+    // parallel cyclic reduction of the top of the plan: single-GPU solves without multi-right-hand-side sweeps
+    d.pcr.level = -1;
+    {
+        const char *e = getenv("SSBA_NO_PCR");
+        if (!part && !d.nb && p->world_size == 1 && !dense && !(e && e[0] == '1')) {
+            int k = 0;
+            while (d.lev[k].n > PCR_MAX_BLOCKS) ++k;
+            const int n = d.lev[k].n;
+            d.pcr.level = k; d.pcr.n = n; d.pcr.steps = 0;
+            for (int s2 = 1; s2 < n; s2 <<= 1) ++d.pcr.steps;
+            TRY(dzero(p, &d.pcr.Lbuf, (size_t)n * blk)); TRY(dzero(p, &d.pcr.LbufT, (size_t)n * blk));
+            TRY(dzero(p, &d.pcr.YL, (size_t)n * blk)); TRY(dzero(p, &d.pcr.YU, (size_t)n * blk));
+            TRY(dzero(p, &d.pcr.yr, (size_t)n * BD));
+        }
+    }
     if (part) {
         const uint64_t ns = (uint64_t)d.n_sep;
         d.soff_D = 0;
@@ -1078,7 +1093,7 @@ int ssba_finalize(ssba_problem *p) {
     p->stats.num_superblocks = (uint32_t)d.Nsb; p->stats.num_reduced_blocks = n_sblk;
     p->stats.pose_bandwidth = bandwidth;
     p->stats.general_structure = dense ? 1u : 0u;
-    p->stats.reserved = 0;
+    p->stats.pcr_blocks = d.pcr.level >= 0 ? (uint32_t)d.pcr.n : 0u;
     if (dense) {      // the dense reduced system: its non-zero blocks and the real co-visibility span
         p->stats.num_reduced_blocks = (uint32_t)dn_blk_a.size();
         for (size_t i = 0; i < dn_blk_a.size(); ++i) p->stats.pose_bandwidth = std::max(p->stats.pose_bandwidth, dn_blk_b[i] - dn_blk_a[i]);
@@ -1789,7 +1804,7 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     launch_linearize(L, d);
     launch_schur(L, d);
     launch_finish_check(L, d);
-    launch_bcr(L, d);
+    launch_bcr(L, d, false);       // the multi-right-hand-side sweeps need the factors of every level
     HIPCHECK(hipMemsetAsync(d.Spb, 0, (size_t)d.nf_pad * 6 * NBP * sizeof(double), L.stream));
     {
         std::vector<double> unit((size_t)6 * NBP, 0.0);

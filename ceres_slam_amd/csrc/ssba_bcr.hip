@@ -98,14 +98,45 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     double *R = lds + BD * LDA;      // BD x LDR : [ L_i (72) | L_{i+1}^T (72) | r_i | pad ]
     __shared__ int sBad;
     __shared__ double sDiag[36];
-    const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
-    const int blk = top ? 0 : 2 * blockIdx.x + 1;
-    const bool hasL = !top, hasU = !top && (blk + 1 < L.n);
-    double *Dg = L.D + (size_t)blk * BD * BD;
-    double *Lg = L.L + (size_t)blk * BD * BD;
-    const double *Ug = L.L + (size_t)(hasU ? blk + 1 : blk) * BD * BD;
-    double *YUg = top ? nullptr : L.YU + (size_t)blockIdx.x * BD * BD;
-    double *rg = L.r + (size_t)blk * BD;
+    // operands and destinations.  Cyclic reduction (which = 0 / 1): odd block blk of level `lev`, everything in place.
+    // Parallel cyclic reduction (which = 2): block blockIdx.x of the plan's level at stride 2^lev; D and r stay (the
+    // reduce kernel updates them in place), the products go to the plan's buffers; the last step (top) is in place.
+    const double *Dg, *Lg, *Ug, *rin;
+    double *oD, *oYL, *oYU, *orr;
+    bool hasL, hasU, trL = false, trU = false;
+    if (which == 2) {
+        const BcrLevel &B = d.lev[d.pcr.level];
+        const int blk = blockIdx.x, s = 1 << lev;
+        hasL = !top && blk - s >= 0;
+        hasU = !top && blk + s < B.n;
+        Dg = B.D + (size_t)blk * BD * BD;
+        rin = B.r + (size_t)blk * BD;
+        if (lev == 0) {      // the level's own couplings: even-indexed ones are stored transposed
+            Lg = B.L + (size_t)blk * BD * BD;
+            Ug = B.L + (size_t)(hasU ? blk + 1 : blk) * BD * BD;
+            trL = trU = (blk & 1) == 0;
+        } else {
+            Lg = d.pcr.Lbuf + (size_t)blk * BD * BD;
+            Ug = d.pcr.LbufT + (size_t)(hasU ? blk + s : blk) * BD * BD;
+        }
+        oD = top ? B.D + (size_t)blk * BD * BD : nullptr;
+        oYL = hasL ? d.pcr.YL + (size_t)blk * BD * BD : nullptr;
+        oYU = hasU ? d.pcr.YU + (size_t)blk * BD * BD : nullptr;
+        orr = top ? B.r + (size_t)blk * BD : d.pcr.yr + (size_t)blk * BD;
+    } else {
+        const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
+        const int blk = top ? 0 : 2 * blockIdx.x + 1;
+        hasL = !top;
+        hasU = !top && (blk + 1 < L.n);
+        Dg = L.D + (size_t)blk * BD * BD;
+        Lg = L.L + (size_t)blk * BD * BD;
+        Ug = L.L + (size_t)(hasU ? blk + 1 : blk) * BD * BD;
+        rin = L.r + (size_t)blk * BD;
+        oD = L.D + (size_t)blk * BD * BD;
+        oYL = hasL ? L.L + (size_t)blk * BD * BD : nullptr;
+        oYU = top ? nullptr : L.YU + (size_t)blockIdx.x * BD * BD;
+        orr = L.r + (size_t)blk * BD;
+    }
     const int t = threadIdx.x;
     const bool has_tile = t < NT;
     const int type = has_tile ? c_tile_type[t] : 2;
@@ -125,11 +156,13 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             if (hasL) lv = L2[e];
             if (hasU) uv = U2[e];
             A[r * LDA + c] = dv.x; A[r * LDA + c + 1] = dv.y;
-            R[r * LDR + c] = lv.x; R[r * LDR + c + 1] = lv.y;
-            R[r * LDR + BD + c] = uv.x; R[r * LDR + BD + c + 1] = uv.y;   // even block: stored as L^T
+            if (!trL) { R[r * LDR + c] = lv.x; R[r * LDR + c + 1] = lv.y; }
+            else { R[c * LDR + r] = lv.x; R[(c + 1) * LDR + r] = lv.y; }
+            if (!trU) { R[r * LDR + BD + c] = uv.x; R[r * LDR + BD + c + 1] = uv.y; }   // even block: stored as L^T
+            else { R[c * LDR + BD + r] = uv.x; R[(c + 1) * LDR + BD + r] = uv.y; }
         }
         if (t < BD) {
-            R[t * LDR + 2 * BD] = rg[t];
+            R[t * LDR + 2 * BD] = rin[t];
 #pragma unroll
             for (int c = 2 * BD + 1; c < LDR; ++c) R[t * LDR + c] = 0.0;
         }
@@ -289,16 +322,16 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     STAMP(lev * 64, 40);
     // ---- bulk store ----------------------------------------------------------------
     {
-        double2 *D2 = reinterpret_cast<double2 *>(Dg);
-        double2 *L2 = reinterpret_cast<double2 *>(Lg);
-        double2 *U2 = reinterpret_cast<double2 *>(YUg);
+        double2 *D2 = reinterpret_cast<double2 *>(oD);
+        double2 *L2 = reinterpret_cast<double2 *>(oYL);
+        double2 *U2 = reinterpret_cast<double2 *>(oYU);
         for (int e = t; e < BD * BD / 2; e += FACT_THREADS) {
             const int r = (2 * e) / BD, c = 2 * e - r * BD;
-            D2[e] = make_double2(A[r * LDA + c], A[r * LDA + c + 1]);
-            if (hasL) L2[e] = make_double2(R[r * LDR + c], R[r * LDR + c + 1]);
-            if (YUg) U2[e] = make_double2(R[r * LDR + BD + c], R[r * LDR + BD + c + 1]);
+            if (oD) D2[e] = make_double2(A[r * LDA + c], A[r * LDA + c + 1]);
+            if (oYL) L2[e] = make_double2(R[r * LDR + c], R[r * LDR + c + 1]);
+            if (oYU) U2[e] = make_double2(R[r * LDR + BD + c], R[r * LDR + BD + c + 1]);
         }
-        if (t < BD) rg[t] = R[t * LDR + 2 * BD];
+        if (t < BD) orr[t] = R[t * LDR + 2 * BD];
     }
     STAMP(lev * 64, 41);
 }
@@ -341,10 +374,76 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
     extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sB = lds + BD * BD;
     __shared__ double sya[BD], syb[BD];
+    const int t = threadIdx.x;
+    if (which == 2) {
+        // parallel cyclic reduction, stride s = 2^lev: block e folds in BOTH neighbours e -+ s (D and r in place),
+        //   D_e -= YU(e-s)^T YU(e-s) + YL(e+s)^T YL(e+s) ;  r_e -= YU(e-s)^T yr(e-s) + YL(e+s)^T yr(e+s)
+        //   L'_e = -YU(e-s)^T YL(e-s)   (coupling to e - 2s), stored untransposed and transposed
+        const BcrLevel &B = d.lev[d.pcr.level];
+        const int e = blockIdx.x, s = 1 << lev, prev = e - s, next = e + s;
+        const bool hasPrev = prev >= 0, hasNext = next < B.n;
+        const bool act = t < KSPLIT * 144;
+        const int g = t / 144, tt = t - g * 144;
+        const int tr = tt / 12, tc = tt - tr * 12;
+        double acc[36];
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+        double *out, *outT = nullptr;
+        double rbase = 0.0;
+        if (blockIdx.y == 0) {
+            if (!hasPrev && !hasNext) return;
+            out = B.D + (size_t)e * BD * BD;
+            if (hasPrev) stage_block(sA, d.pcr.YU + (size_t)prev * BD * BD, RED_THREADS);
+            if (hasNext) stage_block(sB, d.pcr.YL + (size_t)next * BD * BD, RED_THREADS);
+            if (t < BD) {
+                sya[t] = hasPrev ? d.pcr.yr[(size_t)prev * BD + t] : 0.0;
+                syb[t] = hasNext ? d.pcr.yr[(size_t)next * BD + t] : 0.0;
+                rbase = B.r[(size_t)e * BD + t];
+            }
+            __syncthreads();
+            if (act) {
+                if (hasPrev) tile_mac(acc, sA, sA, g, tr, tc);
+                if (hasNext) tile_mac(acc, sB, sB, g, tr, tc);
+            }
+            if (t < BD) {
+                double v0 = 0.0, v1 = 0.0;
+                if (hasPrev) for (int k = 0; k < BD; ++k) v0 += sA[k * BD + t] * sya[k];
+                if (hasNext) for (int k = 0; k < BD; ++k) v1 += sB[k * BD + t] * syb[k];
+                B.r[(size_t)e * BD + t] = rbase - v0 - v1;
+            }
+            __syncthreads();
+        } else {
+            if (prev - s < 0) return;      // no block at e - 2s
+            out = d.pcr.Lbuf + (size_t)e * BD * BD;
+            outT = d.pcr.LbufT + (size_t)e * BD * BD;
+            stage_block(sA, d.pcr.YU + (size_t)prev * BD * BD, RED_THREADS);
+            stage_block(sB, d.pcr.YL + (size_t)prev * BD * BD, RED_THREADS);
+            __syncthreads();
+            if (act) tile_mac(acc, sA, sB, g, tr, tc);
+            __syncthreads();
+        }
+        double *part = lds;
+        if (act && g > 0) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) part[((g - 1) * 144 + tt) * 36 + i] = acc[i];
+        }
+        __syncthreads();
+        if (act && g == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double sum = (acc[6 * i + j] + part[tt * 36 + 6 * i + j]) + part[(144 + tt) * 36 + 6 * i + j];
+                    const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
+                    if (blockIdx.y == 0) out[o] -= sum;
+                    else { out[o] = -sum; outT[(size_t)(tc * 6 + j) * BD + tr * 6 + i] = -sum; }
+                }
+        }
+        return;
+    }
     const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
     const BcrLevel &N = which ? d.slev[lev + 1] : d.lev[lev + 1];
     const int m = blockIdx.x, e = 2 * m;
-    const int t = threadIdx.x;
     if (L.pin && m == L.n / 2) {
         // pinned end of a partitioned chain (old index n-1, odd): carried over unchanged as the new last block;
         // its coupling to the new block before it is the old L[n-1] (no fill-in: old n-2 is its direct neighbour)
@@ -443,11 +542,12 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
     extern __shared__ __align__(16) double lds[];
     double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
     __shared__ double sv[BD], sxm[BD], sxp[BD];
-    const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
-    const int blk = top ? 0 : 2 * blockIdx.x + 1;
+    // which = 2: last step of the parallel cyclic reduction -- every block of the plan's level is decoupled
+    const BcrLevel &L = which == 1 ? d.slev[lev] : d.lev[which == 2 ? d.pcr.level : lev];
+    const int blk = which == 2 ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const bool hasU = !top && (blk + 1 < L.n);
-    double *xb = which ? d.xsep : d.x0 + (size_t)d.chain0 * BD;     // solution at level-0 block positions
+    double *xb = which == 1 ? d.xsep : d.x0 + (size_t)d.chain0 * BD;     // solution at level-0 block positions
     double *xi = xb + (size_t)L.pos[blk] * BD;
     stage_block(sG, L.D + (size_t)blk * BD * BD, BS_THREADS);
     if (!top) stage_block(sL, L.L + (size_t)blk * BD * BD, BS_THREADS);
@@ -499,11 +599,30 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
 // blocks eliminated at a level: all odd ones, except the pinned end of a partitioned chain
 static int n_odd(const BcrLevel &lv, bool pinned) { return pinned ? (lv.n - 1) / 2 : lv.n / 2; }
 
-void launch_bcr(Launcher &L, const Dev &d) {
+void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
     const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
     const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
+    if (!d.part && allow_pcr && d.pcr.level >= 0) {
+        // cyclic reduction down to the plan's level, parallel cyclic reduction of what is left (no back-substitution
+        // sweep over those levels: log2(n) x (factor + reduce) + one decoupled solve), back-substitution of the rest
+        const int k = d.pcr.level, n = d.pcr.n;
+        for (int l = 0; l < k; ++l) {
+            const int nn = d.lev[l].n;
+            LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(nn / 2), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
+            LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((nn + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
+        }
+        for (int q = 0; q < d.pcr.steps; ++q) {
+            LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, q, 0, 2);
+            LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(n, 2), dim3(RED_THREADS), sh_reduce, d, q, 2);
+        }
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, d.pcr.steps, 1, 2);
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
+        for (int l = k - 1; l >= 0; --l)
+            LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
+        return;
+    }
     if (!d.part) {
         for (int l = 0; l + 1 < nl; ++l) {
             const int n = d.lev[l].n;

@@ -105,7 +105,7 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o);
 void launch_linearize(Launcher &L, const Dev &d);
 void launch_schur(Launcher &L, const Dev &d);
 void launch_finish_check(Launcher &L, const Dev &d);
-void launch_bcr(Launcher &L, const Dev &d);
+void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true);   // allow_pcr = false keeps the factors of every level (multi-rhs sweeps)
 // partitioned (multi-rank) solve: pack the chain ends into the separator exchange vector; after the exchange:
 // damping + convergence checks, separator BCR, scatter, back-substitution of the chain interior
 void launch_finish_local(Launcher &L, const Dev &d);

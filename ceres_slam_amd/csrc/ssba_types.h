@@ -90,6 +90,16 @@ struct BcrLevel {
     const int *pos;   // n: level-0 position of each block (i << level for a plain plan)
 };
 
+// Parallel cyclic reduction of the top of the plan (ssba_bcr.hip): from level `level` on (n <= PCR_MAX_BLOCKS blocks)
+// every block eliminates BOTH neighbours at distance 2^k in every step, so after log2(n) steps the blocks are
+// decoupled and solved directly: no back-substitution sweep over those levels.  Works in place on the level's D
+// and r; L ping-pongs through Lbuf, the factor products live in YL / YU / yr.
+struct PcrPlan {
+    int level, n, steps;            // level < 0: not used
+    double *Lbuf, *LbufT, *YL, *YU, *yr;   // n blocks each (yr: n x BD); LbufT = the couplings transposed (the "U" operands)
+};
+constexpr int PCR_MAX_BLOCKS = 128;
+
 struct Dev {
     // camera, stiffness, loss
     double fu, fv, cu, cv, b;
@@ -129,6 +139,7 @@ struct Dev {
     double *part_dl;                 // dogleg partial sums: (n_lm_blocks + n_pose_blocks + 1 [border]) * NDL
     int n_levels;
     BcrLevel lev[MAX_LEVELS];
+    PcrPlan pcr;
     // partitioned solve (one rank per contiguous chain of super-blocks): this rank's chain is
     // super-blocks [chain0, chain1] with both ends pinned; the ends of all ranks form the separator system
     int part, rank, n_sep, chain0, chain1;

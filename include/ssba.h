@@ -211,7 +211,7 @@ typedef struct {
     uint32_t pose_bandwidth;       /* max free-pose index distance of co-observers      */
     uint64_t device_bytes;         /* device memory held by the handle                  */
     uint32_t general_structure;    /* 1: tracks > SSBA_MAX_TRACK or span > 12 poses -> dense reduced system */
-    uint32_t reserved;
+    uint32_t pcr_blocks;           /* blocks handed to the parallel cyclic reduction (<= 128), 0 = plain BCR */
 } ssba_stats;
 int ssba_get_stats(ssba_problem *p, ssba_stats *st);
 

@@ -44,6 +44,29 @@ def test_bcr_block_count_edges(num_poses):
     _assert_same_solve(*_solve_both(prob))
 
 
+@pytest.mark.parametrize("num_poses", [1530, 1600, 3100])
+def test_cyclic_reduction_levels_below_the_parallel_plan(num_poses):
+    """More than 128 super-blocks: plain cyclic-reduction levels first (1 for 1 600 poses, 2 for 3 100), the parallel
+    cyclic reduction takes over at <= 128 blocks; 1 530 poses = 128 blocks exactly."""
+    prob = synth.make_problem(num_poses, 10 * num_poses, track_len=12, seed=7)
+    ba, s, log, op, s2, log2 = _solve_both(prob)
+    assert ba.stats().pcr_blocks == {1530: 128, 1600: 67, 3100: 65}[num_poses]
+    _assert_same_solve(ba, s, log, op, s2, log2)
+
+
+def test_parallel_and_plain_cyclic_reduction_agree(monkeypatch):
+    prob = synth.make_problem(300, 9000, track_len=12, seed=3)
+    ba = StereoBA.from_synth(prob)
+    s, log = ba.solve(capi.default_options(**DRIVER))
+    monkeypatch.setenv("SSBA_NO_PCR", "1")
+    ba2 = StereoBA.from_synth(prob)
+    s2, log2 = ba2.solve(capi.default_options(**DRIVER))
+    assert ba.stats().pcr_blocks == 25 and ba2.stats().pcr_blocks == 0
+    assert s.num_iterations == s2.num_iterations
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-10)
+    assert np.abs(ba.poses - ba2.poses).max() < 1e-9
+
+
 def test_full_3x3_stiffness_matrix():
     # the sun driver builds full covariances (tests/dataset_vo_sun.cpp:57-59); the stereo functor
     # takes any 3x3 stiffness (stereo_reprojection_error.hpp:49-50)

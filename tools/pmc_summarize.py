@@ -17,7 +17,8 @@ def avg(path, name):
     a = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            a[r["Kernel_Name"].split("(")[0].replace("ssba::", "")].append(float(r["Counter_Value"]))
+            kernel = r["Kernel_Name"].split("(")[0].replace("ssba::", "").replace("void ", "").split("<")[0]
+            a[kernel].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in a.items()}
 
 
