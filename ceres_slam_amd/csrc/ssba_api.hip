@@ -1005,7 +1005,7 @@ int ssba_finalize(ssba_problem *p) {
         d.soff_gp = d.soff_rhs + ns * BD;
         d.soff_hdiag = d.soff_gp + ns * BD;
         d.soff_scal = d.soff_hdiag + ns * BD;
-        d.sepv_count = d.soff_scal + NSCAL;
+        d.sepv_count = d.soff_scal + NSCAL + ns;     // + one gradient-max slot per rank (ns - 1 of them)
         TRY(dzero(p, &d.sepv, d.sepv_count));
         TRY(dzero(p, &d.xsep, (size_t)ns * BD));
         int n = d.n_sep, lev = 0;
@@ -1310,8 +1310,7 @@ static int enqueue_front(ssba_problem *p) {
         // system: ~1 MB instead of the whole reduced system) over the ranks, solve it everywhere, back-substitute
         if (!p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
         if ((rc = run_segment(p, 0, [&] { launch_linearize(L, d); launch_schur(L, d); launch_finish_local(L, d); launch_bcr(L, d); launch_sep_pack(L, d); }))) return rc;
-        if ((rc = X(d.sepv, d.sepv_count, 0))) return rc;
-        if ((rc = X(d.gmax_l, 1, 1))) return rc;
+        if ((rc = X(d.sepv, d.sepv_count, 0))) return rc;      // sums; the landmark gradient maximum travels in per-rank slots
         if ((rc = run_segment(p, 1, [&] { launch_sep_finish_check(L, d); launch_bcr_separators(L, d); launch_update_eval(L, d); launch_eval_add_pose(L, d); }))) return rc;
         if ((rc = X(d.scal2, NSCAL, 0))) return rc;
         return SSBA_OK;

@@ -567,7 +567,12 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
                 }
         }
         st.x_norm = sqrt(sc[1] + xnp + xnb);
-        st.gmax = fmax(fmax(gmp, *d.gmax_l), gmb);
+        double gml = *d.gmax_l;
+        if (d.part) {      // one slot per rank behind the scalars (k_sep_pack)
+            gml = 0.0;
+            for (int r = 0; r + 1 < d.n_sep; ++r) gml = fmax(gml, sc[NSCAL + r]);
+        }
+        st.gmax = fmax(fmax(gmp, gml), gmb);
         st.just_linearized = 0;
         sc[0] = 0.0;   // consumed: later all-reduces of the exchange vector add zeros
         sc[1] = 0.0;
@@ -1356,7 +1361,8 @@ __global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
             double *sc = d.xv + d.off_scal, *ss = d.sepv + d.soff_scal;
             if (st.just_linearized) {
                 ss[0] = sc[0]; ss[1] = sc[1] + xnp;
-                *d.gmax_l = fmax(*d.gmax_l, gmp);
+                // the maximum over ranks rides in the SUM exchange: every rank fills its own slot, the others add zeros
+                ss[NSCAL + d.rank] = fmax(*d.gmax_l, gmp);
                 sc[0] = 0.0; sc[1] = 0.0;
             }
         }
