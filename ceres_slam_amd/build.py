@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libssba.so")
-SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip"]
-HEADERS = ["ssba_types.h", "ssba_launch.h", "ssba_device.h", "ssba_phong_device.h", "ssba_linesearch.h", "ssba_posefactor_device.h", os.path.join("..", "..", "include", "ssba.h")]
+SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip", "ssba_pool.hip"]
+HEADERS = ["ssba_types.h", "ssba_pool.h", "ssba_launch.h", "ssba_device.h", "ssba_phong_device.h", "ssba_linesearch.h", "ssba_posefactor_device.h", os.path.join("..", "..", "include", "ssba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *os.environ.get("SSBA_EXTRA_FLAGS", "").split(),
          "-Wno-unused-value", "-Wno-unused-variable", "-Wno-unused-result"]
 

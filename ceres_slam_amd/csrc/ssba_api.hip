@@ -9,10 +9,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/ssba.h"
+#include "ssba_pool.h"
 #include "ssba_launch.h"
 #include "ssba_linesearch.h"
 #include "ssba_types.h"
@@ -108,7 +111,7 @@ template <class T>
 static int dalloc(ssba_problem *p, T **out, size_t n) {
     void *ptr = nullptr;
     size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
-    HIPCHECK(hipMalloc(&ptr, bytes));
+    HIPCHECK(pool_malloc(&ptr, bytes));
     p->allocs.push_back(ptr);
     p->dev_bytes += bytes;
     *out = (T *)ptr;
@@ -142,12 +145,13 @@ static void drop_graph(ssba_problem *p) {
 
 static void free_device(ssba_problem *p) {
     drop_graph(p);
-    for (void *a : p->allocs) hipFree(a);
+    if (!p->allocs.empty()) hipStreamSynchronize(p->launcher.stream);      // cached buffers go to the next handle
+    for (void *a : p->allocs) pool_free(a);
     p->allocs.clear();
     p->dev_bytes = 0;
-    if (p->h_state) { hipHostFree(p->h_state); p->h_state = nullptr; }
-    if (p->h_stage) { hipHostFree(p->h_stage); p->h_stage = nullptr; }
-    if (p->h_ls) { hipHostFree(p->h_ls); p->h_ls = nullptr; }
+    if (p->h_state) { pool_host_free(p->h_state); p->h_state = nullptr; }
+    if (p->h_stage) { pool_host_free(p->h_stage); p->h_stage = nullptr; }
+    if (p->h_ls) { pool_host_free(p->h_ls); p->h_ls = nullptr; }
     p->finalized = false;
 }
 
@@ -167,6 +171,30 @@ static int run_segment(ssba_problem *p, int idx, F body) {
     HIPCHECK(hipGraphLaunch(p->seg_exec[idx], s));
     return SSBA_OK;
 }
+
+// SSBA_API_TIMING=1: wall time per entry point, printed when the process exits (drivers that solve thousands of
+// small windows are bound by set-up cost, not by the kernels)
+struct ApiTimes {
+    bool on = getenv("SSBA_API_TIMING") != nullptr;
+    std::map<std::string, std::pair<double, long>> t;
+    ~ApiTimes() {
+        if (!on) return;
+        for (auto &kv : t) fprintf(stderr, "[ssba] %-24s %8ld calls %10.3f ms total %8.3f ms each\n", kv.first.c_str(), kv.second.second,
+                                   1e3 * kv.second.first, 1e3 * kv.second.first / std::max(1L, kv.second.second));
+    }
+};
+static ApiTimes g_api_times;
+struct ApiTimer {
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit ApiTimer(const char *n) : name(n), t0(std::chrono::steady_clock::now()) {}
+    ~ApiTimer() {
+        if (!g_api_times.on) return;
+        auto &e = g_api_times.t[name];
+        e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        e.second += 1;
+    }
+};
 
 extern "C" {
 
@@ -209,6 +237,7 @@ void ssba_default_options(ssba_options *o) {
 }
 
 int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
+    ApiTimer api_timer("ssba_create");
     if (!camera || !out) return SSBA_ERR_INVALID_ARGUMENT;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -223,7 +252,7 @@ int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
     ssba_problem *p = new ssba_problem();
     p->cam = *camera;
     p->device = device;
-    if (hipStreamCreateWithFlags(&p->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (pool_stream_acquire(&p->own_stream) != hipSuccess) {
         delete p;
         return SSBA_ERR_HIP;
     }
@@ -236,6 +265,7 @@ int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
 }
 
 int ssba_destroy(ssba_problem *p) {
+    ApiTimer api_timer("ssba_destroy");
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     hipSetDevice(p->device);
     hipStreamSynchronize(p->launcher.stream);
@@ -243,7 +273,7 @@ int ssba_destroy(ssba_problem *p) {
     free_device(p);
     if (p->ev_begin) hipEventDestroy(p->ev_begin);
     if (p->ev_end) hipEventDestroy(p->ev_end);
-    if (p->own_stream) hipStreamDestroy(p->own_stream);
+    if (p->own_stream) { hipStreamSynchronize(p->own_stream); pool_stream_release(p->own_stream); }
     delete p;
     return SSBA_OK;
 }
@@ -478,6 +508,7 @@ int ssba_get_stats(ssba_problem *p, ssba_stats *st) {
 // symbolic phase
 // ---------------------------------------------------------------------------------
 int ssba_finalize(ssba_problem *p) {
+    ApiTimer api_timer("ssba_finalize");
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->finalized) return SSBA_OK;
     if (!p->have_S && !p->obs_pose.empty()) return SSBA_ERR_INVALID_ARGUMENT;
@@ -1073,18 +1104,29 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.gmax_l, (size_t)1));
     TRY(dzero(p, &d.st, (size_t)1));
     TRY(dzero(p, &d.dbg, (size_t)8192));
-    HIPCHECK(hipHostMalloc((void **)&p->h_state, sizeof(State), hipHostMallocDefault));
-    HIPCHECK(hipHostMalloc((void **)&p->h_ls, NLS_OUT * sizeof(double), hipHostMallocDefault));
+    HIPCHECK(pool_host_malloc((void **)&p->h_state, sizeof(State)));
+    HIPCHECK(pool_host_malloc((void **)&p->h_ls, NLS_OUT * sizeof(double)));
     p->h_stage_count = std::max<size_t>((size_t)P * 12, (size_t)Lpad * 3);
-    HIPCHECK(hipHostMalloc((void **)&p->h_stage, std::max<size_t>(p->h_stage_count, 1) * sizeof(double), hipHostMallocDefault));
-    if (upload_pair_table(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
-    if (upload_bcr_tables(p->launcher.stream)) { set_error("BCR tile table upload failed"); return SSBA_ERR_HIP; }
-    if (configure_schur()) { set_error("hipFuncSetAttribute(k_schur_windows) failed"); return SSBA_ERR_HIP; }
-    if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
-    if (ph) {
-        if (upload_phong_tables(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
-        if (configure_phong()) { set_error("hipFuncSetAttribute(k_ph_schur_windows) failed"); return SSBA_ERR_HIP; }
-        if (configure_border()) { set_error("hipFuncSetAttribute(border kernels) failed"); return SSBA_ERR_HIP; }
+    HIPCHECK(pool_host_malloc((void **)&p->h_stage, std::max<size_t>(p->h_stage_count, 1) * sizeof(double)));
+    {
+        // constant tables and kernel attributes are per device, not per handle: once per process and device
+        static std::mutex mu;
+        static std::map<int, int> done;       // bit 0 stereo / reduced solve, bit 1 lighting kernels
+        std::lock_guard<std::mutex> lock(mu);
+        int &flags = done[p->device];
+        if (!(flags & 1)) {
+            if (upload_pair_table(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
+            if (upload_bcr_tables(p->launcher.stream)) { set_error("BCR tile table upload failed"); return SSBA_ERR_HIP; }
+            if (configure_schur()) { set_error("hipFuncSetAttribute(k_schur_windows) failed"); return SSBA_ERR_HIP; }
+            if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
+            flags |= 1;
+        }
+        if (ph && !(flags & 2)) {
+            if (upload_phong_tables(p->launcher.stream)) { set_error("pair table upload failed"); return SSBA_ERR_HIP; }
+            if (configure_phong()) { set_error("hipFuncSetAttribute(k_ph_schur_windows) failed"); return SSBA_ERR_HIP; }
+            if (configure_border()) { set_error("hipFuncSetAttribute(border kernels) failed"); return SSBA_ERR_HIP; }
+            flags |= 2;
+        }
     }
 #undef TRY
     p->stats.num_poses = P; p->stats.num_free_poses = (uint32_t)nfree;
@@ -1355,6 +1397,7 @@ static int reset_solver(ssba_problem *p) {
 }
 
 int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence) {
+    ApiTimer api_timer("ssba_solve_begin");
     if (!p || !o) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
     if (o->max_num_iterations < 0 || !(o->initial_trust_region_radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
@@ -1427,6 +1470,7 @@ static int fetch_state(ssba_problem *p) {
 }
 
 int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
+    ApiTimer api_timer("ssba_solve_end");
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->began) return SSBA_ERR_STATE;
     hipStream_t st = p->launcher.stream;
@@ -1478,6 +1522,7 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
 }
 
 int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
+    ApiTimer api_timer("ssba_solve");
     int rc = ssba_solve_begin(p, o, 0);
     if (rc) return rc;
     // Enqueue-ahead loop: the device decides accept/reject/convergence itself; the host
@@ -1487,7 +1532,7 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
     hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
     hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
     State *ring = nullptr;
-    if (hipHostMalloc((void **)&ring, 2 * sizeof(State), hipHostMallocDefault) != hipSuccess) return SSBA_ERR_HIP;
+    if (pool_host_malloc((void **)&ring, 2 * sizeof(State)) != hipSuccess) return SSBA_ERR_HIP;
     const long max_enqueue = (long)o->max_num_iterations + 3;
     bool done = false;
     for (long it = 0; it < max_enqueue && !done; ++it) {
@@ -1507,7 +1552,7 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
     hipStreamSynchronize(st);
     hipEventDestroy(ev[0]);
     hipEventDestroy(ev[1]);
-    hipHostFree(ring);
+    pool_host_free(ring);
     if (rc) { p->began = false; return rc; }
     return ssba_solve_end(p, s);
 }
@@ -1750,6 +1795,7 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
 // the pose's 6x6 block of (J^T J)^-1 in local coordinates = the same block of the inverse of the (undamped) reduced
 // camera system.  Six unit right-hand sides go through the block-cyclic-reduction factors of S.
 int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
+    ApiTimer api_timer("ssba_pose_covariance");
     if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
     if (p->d.part || p->d.phong) {

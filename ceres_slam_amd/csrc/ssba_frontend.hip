@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/ssba.h"
+#include "ssba_pool.h"
 
 namespace {
 
@@ -254,14 +255,14 @@ int ssba_frontend_ransac(const ssba_camera *camera, int device, uint32_t num_pai
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SSBA_OK;
 #define FE_TRY(x) do { if ((x) != hipSuccess) { rc = SSBA_ERR_HIP; goto done; } } while (0)
-    FE_TRY(hipMalloc((void **)&d_off, (num_pairs + 1) * sizeof(uint32_t)));
-    FE_TRY(hipMalloc((void **)&d_smp, (size_t)num_pairs * num_iters * 3 * sizeof(uint32_t)));
-    FE_TRY(hipMalloc((void **)&d_cnt, (size_t)num_pairs * num_iters * sizeof(uint32_t)));
-    FE_TRY(hipMalloc((void **)&d_best, num_pairs * sizeof(uint32_t)));
-    FE_TRY(hipMalloc((void **)&d_p0, (npts ? npts : 1) * 3 * sizeof(double)));
-    FE_TRY(hipMalloc((void **)&d_p1, (npts ? npts : 1) * 3 * sizeof(double)));
-    FE_TRY(hipMalloc((void **)&d_T, (size_t)num_pairs * 12 * sizeof(double)));
-    FE_TRY(hipMalloc((void **)&d_in, npts ? npts : 1));
+    FE_TRY(ssba::pool_malloc((void **)&d_off, (num_pairs + 1) * sizeof(uint32_t)));
+    FE_TRY(ssba::pool_malloc((void **)&d_smp, (size_t)num_pairs * num_iters * 3 * sizeof(uint32_t)));
+    FE_TRY(ssba::pool_malloc((void **)&d_cnt, (size_t)num_pairs * num_iters * sizeof(uint32_t)));
+    FE_TRY(ssba::pool_malloc((void **)&d_best, num_pairs * sizeof(uint32_t)));
+    FE_TRY(ssba::pool_malloc((void **)&d_p0, (npts ? npts : 1) * 3 * sizeof(double)));
+    FE_TRY(ssba::pool_malloc((void **)&d_p1, (npts ? npts : 1) * 3 * sizeof(double)));
+    FE_TRY(ssba::pool_malloc((void **)&d_T, (size_t)num_pairs * 12 * sizeof(double)));
+    FE_TRY(ssba::pool_malloc((void **)&d_in, npts ? npts : 1));
     FE_TRY(hipMemcpy(d_off, offset, (num_pairs + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     FE_TRY(hipMemcpy(d_smp, samples, (size_t)num_pairs * num_iters * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
     FE_TRY(hipMemcpy(d_p0, pts0, npts * 3 * sizeof(double), hipMemcpyHostToDevice));
@@ -286,7 +287,8 @@ done:
 #undef FE_TRY
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
-    hipFree(d_off); hipFree(d_smp); hipFree(d_cnt); hipFree(d_best); hipFree(d_p0); hipFree(d_p1); hipFree(d_T); hipFree(d_in);
+    (void)hipDeviceSynchronize();      // the buffers go back to the process-wide cache (ssba_pool.h)
+    ssba::pool_free(d_off); ssba::pool_free(d_smp); ssba::pool_free(d_cnt); ssba::pool_free(d_best); ssba::pool_free(d_p0); ssba::pool_free(d_p1); ssba::pool_free(d_T); ssba::pool_free(d_in);
     return rc;
 }
 

@@ -15,7 +15,9 @@
 // state, DOGLEG / SUBSPACE_DOGLEG, and ceres::Covariance of state k1+1 for the next window's prior.
 // Two passes as in the reference: without sun blocks (written to <track>_poses.csv), then with them
 // (<track>_<last '_' token of obs_sun_file>_poses.csv).  Poses are written at full precision.
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -71,6 +73,15 @@ static void inverse_sqrt_symmetric(int n, const double *A, double *out) {
         }
 }
 
+// SSBA_DRIVER_TIMING=1: wall time spent in the three stages of a window, printed at exit
+static double g_time[3] = {0, 0, 0};
+struct StageTimer {
+    int stage;
+    std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(int s) : stage(s), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() { g_time[stage] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 struct Dataset {
     size_t num_states = 0, num_points = 0;
     double intr[5];
@@ -92,6 +103,7 @@ static void triangulate(const Dataset &D, unsigned i, double *p) {     // stereo
 
 // DatasetProblemSun::compute_initial_guess(k1, k2) (dataset_problem_sun.cpp:250-354)
 static bool compute_initial_guess(Dataset &D, size_t k1, size_t k2) {
+    StageTimer timer(0);
     if (k2 <= k1 + 1) return true;
     const uint32_t num_iters = 400;
     std::vector<uint32_t> offset(1, 0), samples;
@@ -180,7 +192,10 @@ static void solve_window(Dataset &D, size_t k1, size_t k2, bool use_sun, double 
     solver_options.trust_region_strategy_type = ceres::DOGLEG;
     solver_options.dogleg_type = ceres::SUBSPACE_DOGLEG;
     ceres::Solver::Summary summary;
-    Solve(solver_options, &problem, &summary);
+    {
+        StageTimer timer(1);
+        Solve(solver_options, &problem, &summary);
+    }
     std::cout << summary.BriefReport() << std::endl;
     if (!summary.message.empty()) std::cerr << summary.message << std::endl;
 
@@ -191,6 +206,7 @@ static void solve_window(Dataset &D, size_t k1, size_t k2, bool use_sun, double 
     ceres::Covariance covariance(covariance_options);
     std::vector<std::pair<const double *, const double *>> covar_blocks;
     covar_blocks.push_back(std::make_pair(&D.poses[12 * (k1 + 1)], &D.poses[12 * (k1 + 1)]));
+    StageTimer timer(2);
     if (!covariance.Compute(covar_blocks, &problem)) {
         std::cout << "WARNING: Covariance computation failed! Using previous state covariance." << std::endl;
         std::copy(&D.pose_covars[36 * k1], &D.pose_covars[36 * k1] + 36, &D.pose_covars[36 * (k1 + 1)]);
@@ -309,5 +325,7 @@ int main(int argc, char **argv) {
     obs_sun = obs_sun.substr(0, obs_sun.find('.'));
     const size_t us = obs_sun.find_last_of('_');
     const std::string tag = us == std::string::npos ? obs_sun : obs_sun.substr(us + 1);
+    if (std::getenv("SSBA_DRIVER_TIMING"))
+        std::cerr << "stage seconds: initial guess " << g_time[0] << ", Solve " << g_time[1] << ", Covariance " << g_time[2] << std::endl;
     return write_poses(D, base + "_" + tag) ? EXIT_SUCCESS : EXIT_FAILURE;
 }

@@ -223,6 +223,7 @@ class Problem {
         for (auto c : owned_costs_) delete c;
         for (auto &kv : owned_losses_) delete kv.first;
         for (auto &kv : owned_params_) delete kv.first;
+        if (h_) ssba_destroy(h_);
     }
     Problem(const Problem &) = delete;
     Problem &operator=(const Problem &) = delete;
@@ -230,6 +231,7 @@ class Problem {
     // intensity residual block (tests/dataset_ba_phong.cpp:108-139)
     void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *position_block, double *normal_block,
                           double *phong_block, double *texture_block, double *light_block) {
+        ++version_;
         auto *c = dynamic_cast<ceres_slam::IntensityErrorAutomaticBase *>(cost);
         if (!c) throw std::invalid_argument("ceres_shim: a six-block residual must be an IntensityError*Automatic");
         if (loss) throw std::invalid_argument("ceres_shim: lighting residual blocks take a NULL loss");
@@ -246,6 +248,7 @@ class Problem {
 
     // unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124): pose prior, sun sensor (optionally with HuberLoss)
     void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block) {
+        ++version_;
         PoseFactor f;
         std::memset(&f, 0, sizeof f);
         if (auto *c = dynamic_cast<ceres_slam::PoseErrorAutomatic *>(cost)) {
@@ -274,6 +277,7 @@ class Problem {
     }
 
     void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *point_block) {
+        ++version_;
         if (auto *n = dynamic_cast<ceres_slam::NormalErrorAutomatic *>(cost)) {   // (pose, normal): dataset_ba_phong.cpp:181-188
             if (loss) throw std::invalid_argument("ceres_shim: lighting residual blocks take a NULL loss");
             NormalBlock b;
@@ -316,15 +320,23 @@ class Problem {
     // poses: per block; shared lighting blocks (light, Phong parameters, textures): checked at Solve, the
     // GPU path holds ALL blocks of one kind constant or none (what the driver's DEBUG lines do)
     // point (position) blocks: all or none (stage 2 of --multistage), lighting problems only
-    void SetParameterBlockConstant(double *block) { constant_[block] = 1; }
-    void SetParameterBlockVariable(double *block) { constant_.erase(block); }
-    void SetParameterLowerBound(double *block, int index, double v) { lower_[block][index] = v; }
-    void SetParameterUpperBound(double *block, int index, double v) { upper_[block][index] = v; }
+    void SetParameterBlockConstant(double *block) { if (!constant_.count(block)) { constant_[block] = 1; ++version_; } }
+    void SetParameterBlockVariable(double *block) { if (constant_.erase(block)) ++version_; }
+    void SetParameterLowerBound(double *block, int index, double v) { lower_[block][index] = v; ++version_; }
+    void SetParameterUpperBound(double *block, int index, double v) { upper_[block][index] = v; ++version_; }
     int NumResidualBlocks() const { return (int)obs_pose_.size(); }
 
  private:
     friend void Solve(const Solver::Options &, Problem *, Solver::Summary *);
+    friend const char *shim_prepare(Problem &, int *);
     friend class Covariance;
+    // back-end handle of the current structure and the contiguous staging tables it points into
+    ssba_problem *h_ = nullptr;
+    unsigned long version_ = 0, h_version_ = ~0ul;
+    std::vector<double> st_poses_, st_points_, st_normals_, st_phong_, st_texture_, st_intensity_, st_normal_obs_;
+    std::vector<double *> normal_blocks_, phong_blocks_, texture_blocks_;
+    std::vector<uint32_t> st_material_of_point_;
+    double st_light_[3] = {0, 0, 0};
     // the stereo + unary-pose part of the lowering, shared by Solve and Covariance::Compute; returns the failing call or NULL
     const char *lower_core_(ssba_problem *h, std::vector<double> &poses, std::vector<double> &points, int *rc) {
         if ((*rc = ssba_add_pose_blocks(h, poses.data(), (uint32_t)pose_blocks_.size()))) return "ssba_add_pose_blocks";
@@ -379,34 +391,49 @@ class Problem {
     std::map<LocalParameterization *, int> owned_params_;
 };
 
-// ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81).  Never throws for
-// solver outcomes: the result is in `summary` (as with Ceres); API misuse throws.
-inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
-    Problem &P = *problem;
-    *summary = Solver::Summary();
-    if (P.obs_pose_.empty()) { summary->termination_type = CONVERGENCE; summary->message = "no residual blocks"; return; }
+// Gathers the caller's blocks into the problem's contiguous staging tables (the C ABI takes block tables) and makes
+// sure a finalized handle for the problem's CURRENT structure exists: built on first use, kept across Solve /
+// Covariance::Compute calls, rebuilt after any AddResidualBlock / SetParameterBlock* / bound change.  Returns the
+// failing call (status in *rc) or NULL.
+inline const char *shim_prepare(Problem &P, int *rc_out) {
+    int &rc = *rc_out;
+    rc = 0;
     for (double *b : P.pose_blocks_)
         if (!P.parameterized_.count(b)) throw std::invalid_argument("ceres_shim: pose block without SE3Perturbation");
-    // the C ABI takes contiguous block tables: gather the caller's blocks, scatter back after
-    std::vector<double> poses(P.pose_blocks_.size() * 12), points(P.point_blocks_.size() * 3);
+    std::vector<double> &poses = P.st_poses_, &points = P.st_points_;
+    poses.resize(P.pose_blocks_.size() * 12);
+    points.resize(P.point_blocks_.size() * 3);
     for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(&poses[12 * i], P.pose_blocks_[i], 12 * sizeof(double));
     for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(&points[3 * i], P.point_blocks_[i], 3 * sizeof(double));
+    std::vector<double> &normals = P.st_normals_, &phong = P.st_phong_, &texture = P.st_texture_, &intensity = P.st_intensity_,
+                        &normal_obs = P.st_normal_obs_;
+    std::vector<double *> &normal_blocks = P.normal_blocks_, &phong_blocks = P.phong_blocks_, &texture_blocks = P.texture_blocks_;
+    std::vector<uint32_t> &material_of_point = P.st_material_of_point_;
+    double (&light)[3] = P.st_light_;
+    const bool lighting = !P.intensity_.empty();
+    if (P.h_ && P.h_version_ == P.version_) {      // same structure: only the values may have moved
+        if (lighting) {
+            for (size_t j = 0; j < P.point_blocks_.size(); ++j) std::memcpy(&normals[3 * j], normal_blocks[j], 3 * sizeof(double));
+            for (size_t m = 0; m < phong_blocks.size(); ++m) { std::memcpy(&phong[3 * m], phong_blocks[m], 3 * sizeof(double)); texture[m] = *texture_blocks[m]; }
+            std::memcpy(light, P.light_, sizeof light);
+        }
+        return nullptr;
+    }
+    if (P.h_) { ssba_destroy(P.h_); P.h_ = nullptr; }
     ssba_camera cam = {P.camera_->fu, P.camera_->fv, P.camera_->cu, P.camera_->cv, P.camera_->b};
-    ssba_problem *h = nullptr;
-    int rc = ssba_create(&cam, -1, &h);
-    auto fail = [&](const char *where) {
-        summary->termination_type = FAILURE;
-        summary->message = std::string(where) + ": " + ssba_status_string(rc) + " (" + ssba_last_error() + ")";
-        if (h) ssba_destroy(h);
+    ssba_problem *&h = P.h_;
+    rc = ssba_create(&cam, -1, &h);
+    auto fail = [&](const char *where) -> const char * {
+        if (h) { ssba_destroy(h); h = nullptr; }
+        return where;
     };
     if (rc) return fail("ssba_create");
     if (const char *where = P.lower_core_(h, poses, points, &rc)) return fail(where);
     // ---- lighting terms (tests/dataset_ba_phong.cpp:101-204) -> the config-3 tables of the C ABI ----
-    std::vector<double> normals, phong, texture, intensity, normal_obs;
-    std::vector<double *> normal_blocks(P.point_blocks_.size(), nullptr), phong_blocks, texture_blocks;
-    std::vector<uint32_t> material_of_point(P.point_blocks_.size(), 0);
-    double light[3] = {0, 0, 0};
-    const bool lighting = !P.intensity_.empty();
+    normal_blocks.assign(P.point_blocks_.size(), nullptr);
+    phong_blocks.clear();
+    texture_blocks.clear();
+    material_of_point.assign(P.point_blocks_.size(), 0);
     if (lighting) {
         const size_t N = P.obs_pose_.size();
         if (P.intensity_.size() != N || P.normals_.size() != N)
@@ -491,6 +518,27 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
         if ((rc = bounds(texture_blocks, SSBA_BLOCK_TEXTURE, 1))) return fail("ssba_set_shared_block_bounds");
     }
     if ((rc = ssba_finalize(h))) return fail("ssba_finalize");
+    P.h_version_ = P.version_;
+    return nullptr;
+}
+
+// ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81).  Never throws for
+// solver outcomes: the result is in `summary` (as with Ceres); API misuse throws.
+inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
+    Problem &P = *problem;
+    *summary = Solver::Summary();
+    if (P.obs_pose_.empty()) { summary->termination_type = CONVERGENCE; summary->message = "no residual blocks"; return; }
+    int rc = 0;
+    auto fail = [&](const char *where) {
+        summary->termination_type = FAILURE;
+        summary->message = std::string(where) + ": " + ssba_status_string(rc) + " (" + ssba_last_error() + ")";
+    };
+    if (const char *where = shim_prepare(P, &rc)) return fail(where);
+    ssba_problem *h = P.h_;
+    std::vector<double> &poses = P.st_poses_, &points = P.st_points_, &normals = P.st_normals_, &phong = P.st_phong_, &texture = P.st_texture_;
+    std::vector<double *> &normal_blocks = P.normal_blocks_, &phong_blocks = P.phong_blocks_, &texture_blocks = P.texture_blocks_;
+    double (&light)[3] = P.st_light_;
+    const bool lighting = !P.intensity_.empty();
     ssba_options o;
     ssba_default_options(&o);
     o.max_num_iterations = options.max_num_iterations;
@@ -513,7 +561,6 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
     summary->initial_cost = s.initial_cost;
     summary->final_cost = s.final_cost;
     summary->total_time_in_seconds = s.total_time_s;
-    ssba_destroy(h);
     if (summary->IsSolutionUsable()) {
         for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(P.pose_blocks_[i], &poses[12 * i], 12 * sizeof(double));
         for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(P.point_blocks_[i], &points[3 * i], 3 * sizeof(double));
@@ -543,15 +590,9 @@ class Covariance {
         blocks_.clear();
         message_.clear();
         if (!P.intensity_.empty() || !P.normals_.empty()) { message_ = "covariance is not available with lighting terms"; return false; }
-        std::vector<double> poses(P.pose_blocks_.size() * 12), points(P.point_blocks_.size() * 3);
-        for (size_t i = 0; i < P.pose_blocks_.size(); ++i) std::memcpy(&poses[12 * i], P.pose_blocks_[i], 12 * sizeof(double));
-        for (size_t i = 0; i < P.point_blocks_.size(); ++i) std::memcpy(&points[3 * i], P.point_blocks_[i], 3 * sizeof(double));
         if (!P.camera_) { message_ = "no stereo residual blocks"; return false; }
-        ssba_camera cam = {P.camera_->fu, P.camera_->fv, P.camera_->cu, P.camera_->cv, P.camera_->b};
-        ssba_problem *h = nullptr;
-        int rc = ssba_create(&cam, -1, &h);
-        const char *where = rc ? "ssba_create" : P.lower_core_(h, poses, points, &rc);
-        if (!where && (rc = ssba_finalize(h))) where = "ssba_finalize";
+        int rc = 0;
+        const char *where = shim_prepare(P, &rc);      // the handle of the preceding Solve when nothing changed since
         for (size_t i = 0; !where && i < blocks.size(); ++i) {
             double *a = const_cast<double *>(blocks[i].first);
             if (blocks[i].first != blocks[i].second || !P.pose_index_.count(a)) {
@@ -562,11 +603,10 @@ class Covariance {
             }
             Block b;
             b.ptr = blocks[i].first;
-            if ((rc = ssba_pose_covariance(h, P.pose_index_[a], b.cov))) where = "ssba_pose_covariance";
+            if ((rc = ssba_pose_covariance(P.h_, P.pose_index_[a], b.cov))) where = "ssba_pose_covariance";
             else blocks_.push_back(b);
         }
         if (where && message_.empty()) message_ = std::string(where) + ": " + ssba_status_string(rc) + " (" + ssba_last_error() + ")";
-        if (h) ssba_destroy(h);
         if (where) blocks_.clear();
         return where == nullptr;     // like Ceres: false on a rank-deficient Jacobian (no gauge constraint)
     }
