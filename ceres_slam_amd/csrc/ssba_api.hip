@@ -591,9 +591,9 @@ int ssba_finalize(ssba_problem *p) {
     if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
     if (p->per_obs_S) dense = true;     // per-block stiffness lives in the general layout only
     if (dense) {
-        if (ph || p->world_size > 1 || nfree > 4096) {
+        if (p->world_size > 1 || nfree > 4096) {
             set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
-                      "which is limited to stereo-only single-GPU problems with <= 4096 free poses in this build");
+                      "which is limited to single-GPU problems with <= 4096 free poses in this build");
             return SSBA_ERR_UNSUPPORTED;
         }
         std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) { return a.j < b.j; });
@@ -646,12 +646,17 @@ int ssba_finalize(ssba_problem *p) {
         oint.assign(ou.size(), 0.0); onx.assign(ou.size(), 0.0); ony.assign(ou.size(), 0.0); onz.assign(ou.size(), 1.0);
         lm_mat.assign(Lpad, 0);
     }
+    if (dense && ph) {
+        const size_t n1 = std::max<size_t>(N, 1);
+        ou.assign(n1, 0.0); ov.assign(n1, 0.0); od.assign(n1, 1.0);
+        oint.assign(n1, 0.0); onx.assign(n1, 0.0); ony.assign(n1, 0.0); onz.assign(n1, 1.0);
+    }
     p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
     std::vector<std::vector<uint32_t>> pose_refs(P);
     // general path: landmark-major observation arrays + the pose-major index list into them
     std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs;
     std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
-    std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b;
+    std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b, dn_pose_mat_start;
     DensePlan dplan;
     if (dense) {
         dn_lm_start.assign(Lpad + 1, 0);
@@ -659,8 +664,15 @@ int ssba_finalize(ssba_problem *p) {
             const uint32_t j = order[l].j;
             p->user_of_dev[l] = j;
             lm_mask[l] = 1u;
+            if (ph) lm_mat[l] = p->ph_mat_of_point[j];
             for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
                 const uint32_t i = lm_obs[e];
+                if (ph) {      // the lighting kernels read the same arrays as in the windowed layout, filled landmark-major
+                    const size_t o = dn_obs_pose.size();
+                    ou[o] = p->obs_uvd[3 * (size_t)i]; ov[o] = p->obs_uvd[3 * (size_t)i + 1]; od[o] = p->obs_uvd[3 * (size_t)i + 2];
+                    oint[o] = p->ph_intensity[i];
+                    onx[o] = p->ph_nobs[3 * (size_t)i]; ony[o] = p->ph_nobs[3 * (size_t)i + 1]; onz[o] = p->ph_nobs[3 * (size_t)i + 2];
+                }
                 dn_obs_pose.push_back(p->obs_pose[i]);
                 dn_obs_lm.push_back(l);
                 dn_u.push_back(p->obs_uvd[3 * (size_t)i]); dn_v.push_back(p->obs_uvd[3 * (size_t)i + 1]); dn_d.push_back(p->obs_uvd[3 * (size_t)i + 2]);
@@ -675,6 +687,17 @@ int ssba_finalize(ssba_problem *p) {
         dn_pose_obs.resize(dn_obs_pose.size());
         std::vector<uint32_t> cur2(dn_pose_start.begin(), dn_pose_start.end() - 1);
         for (uint32_t i = 0; i < dn_obs_pose.size(); ++i) dn_pose_obs[cur2[dn_obs_pose[i]]++] = i;
+        if (ph) {       // the border kernel walks a pose's observations material by material
+            for (uint32_t k = 0; k < P; ++k) {
+                std::stable_sort(dn_pose_obs.begin() + dn_pose_start[k], dn_pose_obs.begin() + dn_pose_start[k + 1],
+                                 [&](uint32_t x, uint32_t y) { return lm_mat[dn_obs_lm[x]] < lm_mat[dn_obs_lm[y]]; });
+                uint32_t q = dn_pose_start[k];
+                for (uint32_t m = 0; m <= p->M; ++m) {
+                    while (q < dn_pose_start[k + 1] && lm_mat[dn_obs_lm[dn_pose_obs[q]]] < m) ++q;
+                    dn_pose_mat_start.push_back(q);
+                }
+            }
+        }
         // blocks (a <= b) of S = H_pp - sum_l Y_l W_l^T and, per block, the observation pairs (ea, eb) of one
         // landmark that contribute Y_ea W_eb^T; sorted by block so that one wave owns one block (no atomics)
         struct Pr { uint32_t a, b, ea, eb; };
@@ -926,7 +949,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dzero(p, &d.best_sh, (size_t)d.nsh)); TRY(dzero(p, &d.init_sh, (size_t)d.nsh));
         p->h_sh.assign((size_t)d.nsh, 0.0);
         TRY(dzero(p, &d.cinv, (size_t)Lpad * 21)); TRY(dzero(p, &d.dlm, (size_t)Lpad * 6));
-        TRY(dupload(p, &d.pose_mat_start, pose_mat_start));
+        TRY(dupload(p, &d.pose_mat_start, dense ? dn_pose_mat_start : pose_mat_start));
         if (d.nb) {
             TRY(dzero(p, &d.lmV, (size_t)Lpad * 42)); TRY(dzero(p, &d.lmH, (size_t)Lpad * 28)); TRY(dzero(p, &d.lmG, (size_t)Lpad * 7));
             TRY(dzero(p, &d.part_b, (size_t)(Lpad / 256 + 1) * d.M * NBV));   // + one row of column sums
@@ -1093,7 +1116,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
         if (p->per_obs_S) TRY(dupload(p, &d.dn_Sobs, dn_Sobs));
         TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs));
-        TRY(dzero(p, &d.dn_W, dn_obs_pose.size() * 18)); TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * 18));
+        TRY(dzero(p, &d.dn_W, dn_obs_pose.size() * (ph ? 36 : 18))); TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * (ph ? 36 : 18)));
         TRY(dzero(p, &d.dn_S, (size_t)(d.dn_pad + DN_BS) * std::max(d.dn_pad, DN_BS)));
     }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
@@ -1364,8 +1387,8 @@ static int enqueue_front(ssba_problem *p) {
     }
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
             launch_finish_check(L, d);
-            if (d.dense) launch_dense_solve(L, d); else launch_bcr(L, d);
-            if (d.nb) launch_border_solve(L, d);
+            if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
+            else { launch_bcr(L, d); if (d.nb) launch_border_solve(L, d); }
             if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
             else launch_update_eval(L, d);
         }))) return rc;
@@ -1741,8 +1764,8 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
         }
         if (rhs) for (int i = 0; i < n; ++i) rhs[i] = r[i];
     }
-    if (d.dense) launch_dense_solve(L, d); else launch_bcr(L, d);
-    if (d.nb) launch_border_solve(L, d);
+    if (d.dense) launch_dense_solve(L, d);
+    else { launch_bcr(L, d); if (d.nb) launch_border_solve(L, d); }
     launch_update_eval(L, d);
     HIPCHECK(hipStreamSynchronize(L.stream));
     HIPCHECK(hipGetLastError());

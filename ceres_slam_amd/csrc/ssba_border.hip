@@ -318,6 +318,11 @@ void launch_border_solve(Launcher &L, const Dev &d) {
     LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1);
     for (int l = nl - 2; l >= 0; --l)
         LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0);
+    launch_border_finish(L, d);
+}
+
+// with Z = S_pp^-1 S_pb in Zb: the border system, its solve, and the correction of the pose step
+void launch_border_finish(Launcher &L, const Dev &d) {
     LAUNCH(KC_BORDER, k_border_gram, dim3(d.n_gram), dim3(1024), 0, d);
     LAUNCH(KC_SMALL, k_border_solve, dim3(1), dim3(1024), 0, d);
     LAUNCH(KC_SMALL, k_border_apply, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
 // 6x6 product Y_a W_b^T in registers (the loads of different pairs are independent: the kernel is bound by the
 // latency of the two gathers per pair, so pairs are spread over as many lanes as possible); the 36 partial sums are
 // then reduced over the wave by shuffles and over the four waves through LDS, both in a fixed order.
-__global__ __launch_bounds__(256) void k_dn_schur(Dev d) {
+template <int LD> __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {      // LD = 3 (position) or 6 (position + normal)
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double part[4][36];
@@ -83,18 +83,23 @@ __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0.0;
     for (uint32_t i = d.dn_blk_start[blk] + threadIdx.x; i < d.dn_blk_start[blk + 1]; i += 256) {
-        const double2 *Y2 = reinterpret_cast<const double2 *>(d.dn_Y + (size_t)d.dn_pair_a[i] * 18);
-        const double2 *W2 = reinterpret_cast<const double2 *>(d.dn_W + (size_t)d.dn_pair_b[i] * 18);
-        double y[18], w[18];
+        const double2 *Y2 = reinterpret_cast<const double2 *>(d.dn_Y + (size_t)d.dn_pair_a[i] * (6 * LD));
+        const double2 *W2 = reinterpret_cast<const double2 *>(d.dn_W + (size_t)d.dn_pair_b[i] * (6 * LD));
+        double y[6 * LD], w[6 * LD];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
+        for (int q = 0; q < 3 * LD; ++q) {
             const double2 yv = Y2[q], wv = W2[q];
             y[2 * q] = yv.x; y[2 * q + 1] = yv.y; w[2 * q] = wv.x; w[2 * q + 1] = wv.y;
         }
 #pragma unroll
         for (int r = 0; r < 6; ++r)
 #pragma unroll
-            for (int c = 0; c < 6; ++c) acc[6 * r + c] += y[3 * r] * w[3 * c] + y[3 * r + 1] * w[3 * c + 1] + y[3 * r + 2] * w[3 * c + 2];
+            for (int c = 0; c < 6; ++c) {
+                double v = acc[6 * r + c];
+#pragma unroll
+                for (int m = 0; m < LD; ++m) v += y[LD * r + m] * w[LD * c + m];
+                acc[6 * r + c] = v;
+            }
     }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {
     d.dn_S[((size_t)b * 6 + c) * lda + (size_t)a * 6 + r] = v;     // block (b, a) of the lower triangle = block (a, b)^T
 }
 
-__global__ __launch_bounds__(256) void k_dn_rhs(Dev d) {
+template <int LD> __global__ __launch_bounds__(256) void k_dn_rhs(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -124,10 +129,14 @@ __global__ __launch_bounds__(256) void k_dn_rhs(Dev d) {
     for (uint32_t i = d.dn_pose_start[k] + lane; i < d.dn_pose_start[k + 1]; i += 64) {
         const uint32_t e = d.dn_pose_obs[i];
         const int l = (int)d.dn_obs_lm[e];
-        const double g0 = d.gl[l], g1 = d.gl[(size_t)d.Lpad + l], g2 = d.gl[2 * (size_t)d.Lpad + l];
-        const double *Y = d.dn_Y + (size_t)e * 18;
+        double g[LD];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) acc[c] += Y[3 * c] * g0 + Y[3 * c + 1] * g1 + Y[3 * c + 2] * g2;
+        for (int m = 0; m < LD; ++m) g[m] = d.gl[(size_t)m * d.Lpad + l];
+        const double *Y = d.dn_Y + (size_t)e * (6 * LD);
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int m = 0; m < LD; ++m) acc[c] += Y[LD * c + m] * g[m];
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) acc[c] = wave_sum(acc[c]);
@@ -305,12 +314,34 @@ __global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i, const uint32_t *co
     xrow[j * DN_BS + c] = v;
 }
 
+// free shared blocks on the general layout: the columns of S_pb ride as rows 1..nb of the right-hand-side block row,
+// so the factorisation forward-solves them and k_dn_bwd back-substitutes them like the solve's own right-hand side
+__global__ __launch_bounds__(256) void k_dn_border_rows(Dev d, int store) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse || (store && st.step_failed)) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_dn) return;
+    const size_t lda = (size_t)d.dn_pad;
+    for (int c = 0; c < d.nb; ++c) {
+        double *row = d.dn_S + ((size_t)d.dn_pad + 1 + c) * lda;
+        if (store) d.Zb[(size_t)i * NBP + c] = row[i];         // Z = S_pp^-1 S_pb
+        else row[i] = d.Spb[(size_t)i * NBP + c];
+    }
+}
+
 // ----------------------------------------------------------------- launchers ---
 void launch_dense_schur(Launcher &L, const Dev &d) {
     if (d.dn_pad > 0) hipMemsetAsync(d.dn_S, 0, (size_t)(d.dn_pad + DN_BS) * d.dn_pad * sizeof(double), L.stream);
+    if (d.phong) {       // 6-D landmark blocks: C^-1 first, W / Y are 6x6 (ssba_phong_solver.hip)
+        launch_ph_dense_wy(L, d);
+        LAUNCH(KC_SCHUR, k_dn_schur<6>, dim3(d.dn_nblk), dim3(256), 0, d);
+        LAUNCH(KC_ASSEMBLE, k_dn_rhs<6>, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
+        if (d.nb) launch_ph_dense_border(L, d);
+        return;
+    }
     LAUNCH(KC_SCHUR, k_dn_wy, dim3((d.n_obs + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SCHUR, k_dn_schur, dim3(d.dn_nblk), dim3(256), 0, d);
-    LAUNCH(KC_ASSEMBLE, k_dn_rhs, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
+    LAUNCH(KC_SCHUR, k_dn_schur<3>, dim3(d.dn_nblk), dim3(256), 0, d);
+    LAUNCH(KC_ASSEMBLE, k_dn_rhs<3>, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
 }
 
 void launch_dense_finish(Launcher &L, const Dev &d) {
@@ -320,6 +351,11 @@ void launch_dense_finish(Launcher &L, const Dev &d) {
 void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows) {
     const DensePlan &pl = L.dense;
     const int nbk = pl.nbk;
+    const bool border = d.nb > 0 && n_rhs_rows == 1;      // the solve of an iteration (not the covariance's unit rows)
+    if (border) {
+        LAUNCH(KC_BORDER, k_dn_border_rows, dim3((d.n_dn + 255) / 256), dim3(256), 0, d, 0);
+        n_rhs_rows = 1 + d.nb;
+    }
     for (int j = 0; j < nbk; ++j) {
         const uint32_t r0 = pl.row_start[j], nr = pl.row_start[j + 1] - r0, t0 = pl.tile_start[j], nt = pl.tile_start[j + 1] - t0;
         LAUNCH(KC_BCR_FACTOR, k_dn_potrf, dim3(1), dim3(64), 0, d, j);
@@ -331,6 +367,10 @@ void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows) {
             const uint32_t c0 = pl.col_start[i], nc = pl.col_start[i + 1] - c0;
             LAUNCH(KC_BCR_BACKSUB, k_dn_bwd, dim3(nc + 1), dim3(256), 0, d, i, d.dn_cols + c0, (int)nc, (int)pl.upd_last[i], row);
         }
+    if (border) {
+        LAUNCH(KC_BORDER, k_dn_border_rows, dim3((d.n_dn + 255) / 256), dim3(256), 0, d, 1);
+        launch_border_finish(L, d);
+    }
 }
 
 }  // namespace ssba

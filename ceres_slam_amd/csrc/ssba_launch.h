@@ -132,6 +132,10 @@ void launch_ph_ls_accept(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();
 void launch_border_solve(Launcher &L, const Dev &d);
+void launch_border_finish(Launcher &L, const Dev &d);
+// lighting terms on the general layout (ssba_phong_solver.hip): C^-1 + per-observation 6x6 W / Y; the border kernels
+void launch_ph_dense_wy(Launcher &L, const Dev &d);
+void launch_ph_dense_border(Launcher &L, const Dev &d);
 void launch_bcr_multi_rhs(Launcher &L, const Dev &d);
 // general structure: dense reduced camera system (ssba_dense.hip)
 void launch_dense_schur(Launcher &L, const Dev &d);

@@ -60,6 +60,41 @@ static __device__ __forceinline__ int bcol(const Dev &d, uint32_t mat, int q) {
     return d.b_light < 0 ? -1 : d.b_light + (q - 4);
 }
 
+// Observation slots of one landmark and where their data sit (lighting kernels).  Windowed layout: the TW slots of
+// the landmark's window in the transposed ELL arrays.  General layout (tracks > TW, loop closures): the same arrays
+// hold the observations landmark-major, slot s of landmark l at dn_lm_start[l] + s.
+template <bool DN> struct PhSlots;
+template <> struct PhSlots<false> {
+    uint32_t mask, win;
+    size_t obase;
+    __device__ __forceinline__ PhSlots(const Dev &d, int l, uint32_t m)
+        : mask(m), win(d.lm_win[l]), obase((size_t)(l >> 6) * (TW * LMG) + (l & 63)) {}
+    __device__ __forceinline__ int count() const { return TW; }
+    __device__ __forceinline__ bool has(int s) const { return (mask >> s) & 1u; }
+    __device__ __forceinline__ uint32_t pose(const Dev &d, int s) const { return d.win_pose[win * TW + s]; }
+    __device__ __forceinline__ size_t at(int s) const { return obase + (size_t)s * LMG; }
+};
+template <> struct PhSlots<true> {
+    uint32_t b, n;
+    __device__ __forceinline__ PhSlots(const Dev &d, int l, uint32_t) : b(d.dn_lm_start[l]), n(d.dn_lm_start[l + 1] - d.dn_lm_start[l]) {}
+    __device__ __forceinline__ int count() const { return (int)n; }
+    __device__ __forceinline__ bool has(int) const { return true; }
+    __device__ __forceinline__ uint32_t pose(const Dev &d, int s) const { return d.dn_obs_pose[b + s]; }
+    __device__ __forceinline__ size_t at(int s) const { return (size_t)b + s; }
+};
+// observation behind entry i of the pose-major list: landmark and data index
+template <bool DN> static __device__ __forceinline__ void pose_list_entry(const Dev &d, uint32_t i, int &l, size_t &oi) {
+    if (DN) {
+        oi = d.dn_pose_obs[i];
+        l = (int)d.dn_obs_lm[oi];
+    } else {
+        const uint32_t ref = d.pose_obs_ref[i];
+        l = (int)(ref >> 4);
+        const int s = (int)(ref & 15u);
+        oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+    }
+}
+
 static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const double *__restrict__ sh, const double *__restrict__ T, const double p[3],
                                                         const double n[3], uint32_t mat, double u, double v, double dd,
                                                         double inten, const double nobs[3], bool want_pose, ObsPh &o) {
@@ -206,7 +241,7 @@ __global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
     for (int c = 0; c < 21; ++c) d.cinv[(size_t)c * d.Lpad + l] = Ci[c];
 }
 
-__global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     __shared__ double sm[4];
@@ -214,19 +249,18 @@ __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
     const uint32_t mask = d.lm_mask[l];
     double cost = 0.0, xn = 0.0, gm = 0.0;
     if (mask) {
-        const uint32_t win = d.lm_win[l];
+        const PhSlots<DN> sl(d, l, mask);
         LmIn x;
         load_lm(d, l, x);
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
         double h[21], g[6];
 #pragma unroll
         for (int i = 0; i < 21; ++i) h[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; ++i) g[i] = 0.0;
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
-            const size_t oi = obase + (size_t)s * LMG;
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
             obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, false, o);
@@ -270,7 +304,7 @@ __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ph_linearize_poses(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_poses(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     const int k = blockIdx.x;
@@ -280,11 +314,11 @@ __global__ __launch_bounds__(256) void k_ph_linearize_poses(Dev d) {
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
-    const uint32_t b = d.pose_obs_start[k], e = d.pose_obs_start[k + 1];
+    const uint32_t b = DN ? d.dn_pose_start[k] : d.pose_obs_start[k], e = DN ? d.dn_pose_start[k + 1] : d.pose_obs_start[k + 1];
     for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-        const uint32_t ref = d.pose_obs_ref[i];
-        const int l = (int)(ref >> 4), s = (int)(ref & 15u);
-        const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+        int l;
+        size_t oi;
+        pose_list_entry<DN>(d, i, l, oi);
         LmIn x;
         load_lm(d, l, x);
         const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
@@ -455,7 +489,7 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -467,8 +501,7 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
     double np_[3] = {x.p[0], x.p[1], x.p[2]}, nn[3] = {x.n[0], x.n[1], x.n[2]};
     double dl[6] = {0, 0, 0, 0, 0, 0};
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const PhSlots<DN> sl(d, l, mask);
         double gl[6], tt[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) { gl[c] = d.gl[(size_t)c * d.Lpad + l]; tt[c] = gl[c]; }
@@ -482,12 +515,12 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
         // -(J d)^T (r + J d / 2) of this landmark's rows is
         //   -(sum e.r + dl.g_l) - (sum e.e + 2 dl.(tt - g_l) + dl^T H_ll dl) / 2 :  one linearisation pass
         double er = 0.0, ee = 0.0;
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
             const int f = d.pose_free[k];
             if (f < 0 && !d.nb) continue;
-            const size_t oi = obase + (size_t)s * LMG;
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
             obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
@@ -539,10 +572,10 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
         unit_plus(x.n, dl + 3, nn);
         dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
              (nn[1] - x.n[1]) * (nn[1] - x.n[1]) + (nn[2] - x.n[2]) * (nn[2] - x.n[2]);
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
-            const size_t oi = obase + (size_t)s * LMG;
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs);
         }
@@ -576,7 +609,7 @@ __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
 __device__ __forceinline__ int tri7(int r, int c) { return r * 7 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
 
 // one lane per landmark, on linearisation: V_j (42), H_bb,j (28 unique), g_b,j (7)
-__global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     const int l = blockIdx.x * 256 + threadIdx.x;
@@ -589,18 +622,17 @@ __global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) {
 #pragma unroll
     for (int i = 0; i < 7; ++i) G[i] = 0.0;
     if (mask) {
-        const uint32_t win = d.lm_win[l];
+        const PhSlots<DN> sl(d, l, mask);
         LmIn x;
         load_lm(d, l, x);
         Shared sx;
         load_shared(d, d.sh, x.mat, sx);
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
             double ri, J19[19];
             intensity_residual(d.light_type, d.poses + (size_t)k * 12, x.p, x.n, sx.ph3, sx.kd, sx.light,
-                               d.oi[obase + (size_t)s * LMG], d.int_stiff, &ri, J19);
+                               d.oi[sl.at(s)], d.int_stiff, &ri, J19);
             int c = 0;
 #pragma unroll
             for (int q = 0; q < NBQ; ++q) {
@@ -738,7 +770,7 @@ __global__ __launch_bounds__(256) void k_ph_border_reduce(Dev d) {
 // one block per free pose, every iteration: its six rows of S_pb = H_pb - sum_j Y_j V_j.  The pose's
 // observation references are sorted by material, so a thread accumulates one material's four columns
 // at a time (plus the three light columns throughout) and the block reduces them in a fixed order.
-__global__ __launch_bounds__(256) void k_ph_border_poses(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_poses(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const int k = blockIdx.x, f = d.pose_free[k];
@@ -756,9 +788,9 @@ __global__ __launch_bounds__(256) void k_ph_border_poses(Dev d) {
         if (m < d.M) {
             const uint32_t b = d.pose_mat_start[(size_t)k * (d.M + 1) + m], e = d.pose_mat_start[(size_t)k * (d.M + 1) + m + 1];
             for (uint32_t i = b + t; i < e; i += 256) {
-                const uint32_t ref = d.pose_obs_ref[i];
-                const int l = (int)(ref >> 4), s = (int)(ref & 15u);
-                const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
+                int l;
+                size_t oi;
+                pose_list_entry<DN>(d, i, l, oi);
                 LmIn x;
                 load_lm(d, l, x);
                 const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
@@ -866,7 +898,7 @@ __global__ void k_ph_dogleg_border(Dev d) {
 
 // per landmark: Gauss-Newton back-substitution, v_l, the landmark parts of the norms and the products
 // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn) over the landmark's observations
-__global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double sm[4];
@@ -877,8 +909,7 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
     for (int q = 0; q < NDL; ++q) sums[q] = 0.0;
     double dl[6] = {0, 0, 0, 0, 0, 0}, vl[6] = {0, 0, 0, 0, 0, 0};
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const PhSlots<DN> sl(d, l, mask);
         LmIn x;
         load_lm(d, l, x);
         double gl[6], tt[6];
@@ -891,12 +922,12 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
             gbq[q] = c >= 0 ? d.bsys[BS_DB + c] : 0.0;
             vbq[q] = c >= 0 ? d.bsys[BS_VB + c] : 0.0;
         }
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
             const int f = d.pose_free[k];
             if (f < 0) continue;
-            const size_t oi = obase + (size_t)s * LMG;
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
             obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
@@ -935,11 +966,11 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
             sums[1] += D2 * dl[c] * dl[c] / s2;
             sums[2] += gl[c] * dl[c];
         }
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
             const int f = d.pose_free[k];
-            const size_t oi = obase + (size_t)s * LMG;
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
             obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
@@ -974,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
 }
 
 // per landmark: delta_l = beta * gn + gamma * v, candidate point / normal, model cost change, candidate cost
-__global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -986,8 +1017,7 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
     double np_[3] = {x.p[0], x.p[1], x.p[2]}, nn[3] = {x.n[0], x.n[1], x.n[2]};
     double dl[6] = {0, 0, 0, 0, 0, 0};
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const PhSlots<DN> sl(d, l, mask);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             dl[c] = st.beta * d.dl_gn[(size_t)c * d.Lpad + l] + st.gamma * d.vl[(size_t)c * d.Lpad + l];
@@ -1003,11 +1033,11 @@ __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
         unit_plus(x.n, dl + 3, nn);
         dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
              (nn[1] - x.n[1]) * (nn[1] - x.n[1]) + (nn[2] - x.n[2]) * (nn[2] - x.n[2]);
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
             const int f = d.pose_free[k];
-            const size_t oi = obase + (size_t)s * LMG;
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
             ObsPh o;
@@ -1057,7 +1087,7 @@ __global__ void k_ls_set_alpha(Dev d, double alpha) {
 
 // per landmark: trial point for st.ls_alpha (candidate poses / shared blocks are already in place),
 // its cost, phi', |dx_l|^2, and the alpha-independent max|delta_l| and g_l . delta_l
-__global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -1068,8 +1098,7 @@ __global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
     load_lm(d, l, x);
     double np_[3] = {x.p[0], x.p[1], x.p[2]}, nn[3] = {x.n[0], x.n[1], x.n[2]};
     if (mask && !st.step_failed) {
-        const uint32_t win = d.lm_win[l];
-        const size_t obase = (size_t)(l >> 6) * (TW * LMG) + (l & 63);
+        const PhSlots<DN> sl(d, l, mask);
         double dl[6], sdl[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -1089,11 +1118,11 @@ __global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
         unit_plus(x.n, sdl + 3, nn);
         dn = sdl[0] * sdl[0] + sdl[1] * sdl[1] + sdl[2] * sdl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
              (nn[1] - x.n[1]) * (nn[1] - x.n[1]) + (nn[2] - x.n[2]) * (nn[2] - x.n[2]);
-        for (int s = 0; s < TW; ++s) {
-            if (!((mask >> s) & 1u)) continue;
-            const uint32_t k = d.win_pose[win * TW + s];
+        for (int s = 0; s < sl.count(); ++s) {
+            if (!sl.has(s)) continue;
+            const uint32_t k = sl.pose(d, s);
             const int f = d.pose_free[k];
-            const size_t oi = obase + (size_t)s * LMG;
+            const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             ObsPh o;
             obs_ph_linearize(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi],
@@ -1180,10 +1209,60 @@ __global__ void k_ph_ls_accept(Dev d) {
 }
 
 void launch_ph_linearize(Launcher &L, const Dev &d) {
-    LAUNCH(KC_LIN_LM, k_ph_linearize_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_LIN_POSE, k_ph_linearize_poses, dim3(d.P), dim3(256), 0, d);
-    if (d.nb) LAUNCH(KC_BORDER, k_ph_border_landmarks, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_LIN_LM, (d.dense ? k_ph_linearize_landmarks<true> : k_ph_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_LIN_POSE, (d.dense ? k_ph_linearize_poses<true> : k_ph_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
+    if (d.nb) LAUNCH(KC_BORDER, (d.dense ? k_ph_border_landmarks<true> : k_ph_border_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
+// general layout: per observation W = J_p^T J_l (6x6 over the 7 residual rows) and Y = W C^-1, stored for the
+// pair-list Schur kernel of ssba_dense.hip
+__global__ __launch_bounds__(256) void k_ph_dn_wy(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= d.n_obs) return;
+    const uint32_t k = d.dn_obs_pose[e];
+    if (d.pose_free[k] < 0) return;
+    const int l = (int)d.dn_obs_lm[e];
+    LmIn x;
+    load_lm(d, l, x);
+    const double nobs[3] = {d.onx[e], d.ony[e], d.onz[e]};
+    ObsPh o;
+    obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[e], d.ov[e], d.od[e], d.oi[e], nobs, true, o);
+    double Ci[21];
+#pragma unroll
+    for (int c = 0; c < 21; ++c) Ci[c] = d.cinv[(size_t)c * d.Lpad + l];
+    double *W = d.dn_W + (size_t)e * 36, *Y = d.dn_Y + (size_t)e * 36;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double w[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int m = 0; m < 7; ++m) v += o.Jp[6 * m + a] * o.Jl[6 * m + c];
+            w[c] = v;
+            W[6 * a + c] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double v = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v += w[q] * Ci[q <= c ? tri6(q, c) : tri6(c, q)];
+            Y[6 * a + c] = v;
+        }
+    }
+}
+void launch_ph_dense_wy(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SCHUR, k_ph_dn_wy, dim3((d.n_obs + 255) / 256), dim3(256), 0, d);
+}
+void launch_ph_dense_border(Launcher &L, const Dev &d) {
+    LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
+    LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_BORDER, k_ph_border_poses<true>, dim3(d.P), dim3(256), 0, d);
+}
+
 void launch_ph_schur(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SCHUR, k_ph_schur_windows, dim3(d.n_slabs), dim3(PH_THREADS), PH_LDS_DOUBLES * sizeof(double), d);
@@ -1191,20 +1270,20 @@ void launch_ph_schur(Launcher &L, const Dev &d) {
         LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
-        LAUNCH(KC_BORDER, k_ph_border_poses, dim3(d.P), dim3(256), 0, d);
+        LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(256), 0, d);
     }
 }
 void launch_ph_backsub_eval(Launcher &L, const Dev &d) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
-    LAUNCH(KC_BACKSUB_EVAL, k_ph_backsub_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_backsub_eval<true> : k_ph_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_dogleg_border, dim3(1), dim3(64), 0, d);
-    LAUNCH(KC_DOGLEG, k_ph_dogleg_gn, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_gn<true> : k_ph_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
-    LAUNCH(KC_DOGLEG, k_ph_dogleg_eval, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_eval<true> : k_ph_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 // one evaluation of the line-search function at step `alpha` (alpha < 0: keep the current one)
 void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
@@ -1213,7 +1292,7 @@ void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
         launch_pose_update(L, d);
         if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
     }
-    LAUNCH(KC_BACKSUB_EVAL, k_ph_ls_probe, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d);
 }
 void launch_ph_ls_accept(Launcher &L, const Dev &d) {
