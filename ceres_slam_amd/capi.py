@@ -34,7 +34,7 @@ SYMBOLS = [
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
     "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant",
-    "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation",
+    "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation", "ssba_add_relative_pose",
     "ssba_pose_covariance",
 ]
 
@@ -140,6 +140,7 @@ def load():
     L.ssba_add_lighting_observations.argtypes = [H, _dp, C.c_double, _dp, _dp, C.c_uint64]
     L.ssba_add_pose_prior.argtypes = [H, C.c_uint32, _dp, _dp, C.c_double]
     L.ssba_add_sun_observation.argtypes = [H, C.c_uint32, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double]
+    L.ssba_add_relative_pose.argtypes = [H, C.c_uint32, C.c_uint32, _dp, _dp, C.c_double]
     L.ssba_pose_covariance.argtypes = [H, C.c_uint32, _dp]
     L.ssba_ransac_samples.argtypes = [C.c_uint32, C.c_uint32, C.c_int, _u32p]
     L.ssba_frontend_ransac.argtypes = [C.POINTER(Camera), C.c_int, C.c_uint32, _u32p, _dp, _dp, _u32p, C.c_uint32, C.c_double, _dp,

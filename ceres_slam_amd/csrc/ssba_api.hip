@@ -67,6 +67,8 @@ struct ssba_problem {
     // unary pose residual blocks (pose prior, sun sensor)
     struct PoseFactor { uint32_t pose; int type; double data[18], S[36], huber; };
     std::vector<PoseFactor> pose_factors;
+    struct RelFactor { uint32_t pose1, pose2; double T_ref[12], S[36], huber; };
+    std::vector<RelFactor> rel_factors;
     double *h_ls = nullptr;                // pinned: line-search scalars + state
     int num_line_search_steps = 0;
     std::vector<double> ph_intensity, ph_nobs;
@@ -378,6 +380,18 @@ int ssba_add_pose_prior(ssba_problem *p, uint32_t pose, const double T_ref[12], 
     return SSBA_OK;
 }
 
+int ssba_add_relative_pose(ssba_problem *p, uint32_t pose1, uint32_t pose2, const double T_2_1_ref[12], const double stiffness[36],
+                           double huber_a) {
+    if (!p || !T_2_1_ref || !stiffness || pose1 >= p->P || pose2 >= p->P || pose1 == pose2) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->finalized) return SSBA_ERR_STATE;
+    ssba_problem::RelFactor f{};
+    f.pose1 = pose1; f.pose2 = pose2; f.huber = huber_a > 0.0 ? huber_a : 0.0;
+    memcpy(f.T_ref, T_2_1_ref, sizeof f.T_ref);
+    memcpy(f.S, stiffness, sizeof f.S);
+    p->rel_factors.push_back(f);
+    return SSBA_OK;
+}
+
 int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observed_dir_c[3], const double expected_dir_g[3],
                              const double stiffness[4], double az_err_thresh, double zen_err_thresh, double huber_a) {
     if (!p || !observed_dir_c || !expected_dir_g || !stiffness || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
@@ -544,12 +558,33 @@ int ssba_finalize(ssba_problem *p) {
 
     // free poses: in the problem (observed) and not constant
     std::vector<uint32_t> pf_cnt(P, 0);
-    for (auto &f : p->pose_factors) {
-        pf_cnt[f.pose]++;
+    // pose-only residual blocks.  A relative-pose block becomes two half entries, one on each of its non-constant
+    // poses (types 2 / 3: data[12] the other pose, data[13] = 1 on the half that counts the cost, data[14] the
+    // position of the other half or -1); the cross terms of the two halves are added where both are free.
+    std::vector<ssba_problem::PoseFactor> pfs = p->pose_factors;
+    for (auto &f : pfs)
         if (p->pose_const[f.pose]) { set_error("a unary residual block sits on a constant pose"); return SSBA_ERR_UNSUPPORTED; }
+    for (auto &rf : p->rel_factors) {
+        const bool c1 = p->pose_const[rf.pose1], c2 = p->pose_const[rf.pose2];
+        if (c1 && c2) { set_error("a relative-pose block between two constant poses"); return SSBA_ERR_UNSUPPORTED; }
+        const int ia = (int)pfs.size(), ib = ia + (c1 ? 0 : 1);
+        for (int side = 0; side < 2; ++side) {
+            if (side == 0 ? c1 : c2) continue;
+            ssba_problem::PoseFactor f{};
+            f.pose = side == 0 ? rf.pose1 : rf.pose2;
+            f.type = 2 + side;
+            f.huber = rf.huber;
+            memcpy(f.data, rf.T_ref, sizeof rf.T_ref);
+            f.data[12] = (double)(side == 0 ? rf.pose2 : rf.pose1);
+            f.data[13] = (side == 0 || c1) ? 1.0 : 0.0;
+            f.data[14] = (c1 || c2) ? -1.0 : (double)(side == 0 ? ib : ia);      // host index for now
+            memcpy(f.S, rf.S, sizeof rf.S);
+            pfs.push_back(f);
+        }
     }
-    if (!p->pose_factors.empty() && (ph || p->world_size > 1)) {
-        set_error("pose priors / sun observations are not available with lighting terms or landmark sharding yet");
+    for (auto &f : pfs) pf_cnt[f.pose]++;
+    if (!pfs.empty() && (ph || p->world_size > 1)) {
+        set_error("pose priors / sun observations / relative-pose blocks are not available with lighting terms or landmark sharding yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     p->pose_free.assign(P, -1);
@@ -590,6 +625,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
     if (p->per_obs_S) dense = true;     // per-block stiffness lives in the general layout only
+    if (!p->rel_factors.empty()) dense = true;     // pose-pose couplings outside the landmark structure
     if (dense) {
         if (p->world_size > 1 || nfree > 4096) {
             set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
@@ -717,6 +753,10 @@ int ssba_finalize(ssba_problem *p) {
                     prs.push_back({(uint32_t)fa, (uint32_t)fb, ea, eb});
                 }
             }
+        for (auto &rf : p->rel_factors) {          // off-diagonal block of a relative-pose block (no observation pairs)
+            const int f1 = p->pose_free[rf.pose1], f2 = p->pose_free[rf.pose2];
+            if (f1 >= 0 && f2 >= 0) prs.push_back({(uint32_t)std::min(f1, f2), (uint32_t)std::max(f1, f2), 0xFFFFFFFFu, 0xFFFFFFFFu});
+        }
         std::sort(prs.begin(), prs.end(), [](const Pr &x, const Pr &y) {
             if (x.a != y.a) return x.a < y.a;
             if (x.b != y.b) return x.b < y.b;
@@ -1084,18 +1124,37 @@ int ssba_finalize(ssba_problem *p) {
         }
         d.ns_levels = lev + 1;
     }
-    if (!p->pose_factors.empty()) {
+    std::vector<uint32_t> dn_blk_rf_start, dn_blk_rf;
+    if (!pfs.empty()) {
         std::vector<uint32_t> start(P + 1, 0);
         for (uint32_t k = 0; k < P; ++k) start[k + 1] = start[k] + pf_cnt[k];
         std::vector<uint32_t> cur(start.begin(), start.end() - 1);
-        const size_t F = p->pose_factors.size();
+        const size_t F = pfs.size();
         std::vector<int> type(F);
         std::vector<double> data(F * 18), S(F * 36), hub(F);
-        for (auto &f : p->pose_factors) {     // stable: keeps the caller's order inside a pose
-            const uint32_t q = cur[f.pose]++;
+        std::vector<uint32_t> pos(F);
+        for (size_t i = 0; i < F; ++i) pos[i] = cur[pfs[i].pose]++;     // stable: keeps the caller's order inside a pose
+        for (size_t i = 0; i < F; ++i) {
+            auto &f = pfs[i];
+            const uint32_t q = pos[i];
             type[q] = f.type; hub[q] = f.huber;
             memcpy(&data[18 * (size_t)q], f.data, sizeof f.data);
+            if (f.type >= 2 && f.data[14] >= 0.0) data[18 * (size_t)q + 14] = (double)pos[(size_t)f.data[14]];
             memcpy(&S[36 * (size_t)q], f.S, sizeof f.S);
+        }
+        if (dense) {       // relative-pose blocks of every block of the reduced system: first-half entry, bit 31 = transposed
+            std::map<std::pair<uint32_t, uint32_t>, std::vector<uint32_t>> of_block;
+            for (size_t i = 0; i < F; ++i)
+                if (pfs[i].type == 2 && pfs[i].data[14] >= 0.0) {
+                    const int f1 = p->pose_free[pfs[i].pose], f2 = p->pose_free[(uint32_t)pfs[i].data[12]];
+                    of_block[{(uint32_t)std::min(f1, f2), (uint32_t)std::max(f1, f2)}].push_back(pos[i] | (f1 > f2 ? 0x80000000u : 0u));
+                }
+            dn_blk_rf_start.assign(1, 0);
+            for (size_t b = 0; b < dn_blk_a.size(); ++b) {
+                auto it = of_block.find({dn_blk_a[b], dn_blk_b[b]});
+                if (it != of_block.end()) dn_blk_rf.insert(dn_blk_rf.end(), it->second.begin(), it->second.end());
+                dn_blk_rf_start.push_back((uint32_t)dn_blk_rf.size());
+            }
         }
         d.n_pf = (int)F;
         TRY(dupload(p, &d.pf_start, start)); TRY(dupload(p, &d.pf_type, type));
@@ -1109,6 +1168,7 @@ int ssba_finalize(ssba_problem *p) {
         d.dn_nblk = (int)dn_blk_a.size();
         TRY(dupload(p, &d.dn_blk_a, dn_blk_a)); TRY(dupload(p, &d.dn_blk_b, dn_blk_b)); TRY(dupload(p, &d.dn_blk_start, dn_blk_start));
         TRY(dupload(p, &d.dn_pair_a, dn_pair_a)); TRY(dupload(p, &d.dn_pair_b, dn_pair_b));
+        if (!dn_blk_rf.empty()) { TRY(dupload(p, &d.dn_blk_rf_start, dn_blk_rf_start)); TRY(dupload(p, &d.dn_blk_rf, dn_blk_rf)); }
         TRY(dupload(p, &d.dn_rows, dplan.rows)); TRY(dupload(p, &d.dn_ti, dplan.ti)); TRY(dupload(p, &d.dn_tk, dplan.tk));
         TRY(dupload(p, &d.dn_cols, dplan.cols));
         p->launcher.dense = dplan;

@@ -23,6 +23,7 @@
 #include "ssba_types.h"
 #include "ssba_launch.h"
 #include "ssba_device.h"
+#include "ssba_posefactor_device.h"
 
 namespace ssba {
 
@@ -111,6 +112,20 @@ template <int LD> __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {    
     if (threadIdx.x >= 36) return;
     const int el = threadIdx.x, r = el / 6, c = el - r * 6;
     double v = -(part[0][el] + part[1][el] + part[2][el] + part[3][el]);
+    if (d.dn_blk_rf)      // relative-pose blocks coupling the two poses of this block: J_a^T J_b
+        for (uint32_t q = d.dn_blk_rf_start[blk]; q < d.dn_blk_rf_start[blk + 1]; ++q) {
+            const uint32_t ent = d.dn_blk_rf[q];
+            const int e1 = (int)(ent & 0x7FFFFFFFu), e2 = pf_partner(d, e1);
+            const bool swapped = (ent >> 31) != 0;       // first pose of the block is the factor's SECOND pose
+            const int k1 = d.free_pose[swapped ? b : a], k2 = d.free_pose[swapped ? a : b];
+            const double *T1 = d.poses + (size_t)k1 * 12, *T2 = d.poses + (size_t)k2 * 12;
+            double rr[6], J1[36], J2[36];
+            int dim;
+            pf_evaluate(d, e1, T1, T2, rr, J1, &dim);
+            pf_evaluate(d, e2, T2, T1, rr, J2, &dim);
+            const double *Ja = swapped ? J2 : J1, *Jb = swapped ? J1 : J2;
+            for (int m = 0; m < 6; ++m) v += Ja[6 * m + r] * Jb[6 * m + c];
+        }
     const size_t lda = (size_t)d.dn_pad;
     if (a == b) {
         if (c < r) return;    // (r, c) with r <= c stands for the symmetric pair; stored at (row 6a+c, col 6a+r)

@@ -207,10 +207,11 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
             for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
                 double r[6], J[36];
                 int dim;
-                const double cost = pf_evaluate(d, (int)e, T, r, J, &dim);
+                const int other = pf_other_pose(d, (int)e);
+                const double cost = pf_evaluate(d, (int)e, T, other >= 0 ? d.poses + (size_t)other * 12 : nullptr, r, J, &dim);
                 if (threadIdx.x < 21) { for (int m = 0; m < dim; ++m) v += J[6 * m + a] * J[6 * m + c]; }
                 else if (threadIdx.x < 27) { for (int m = 0; m < dim; ++m) v += J[6 * m + (threadIdx.x - 21)] * r[m]; }
-                else v += cost;
+                else if (pf_counts_cost(d, (int)e)) v += cost;
             }
         }
         if (threadIdx.x < 21) d.hpp[(size_t)k * 21 + threadIdx.x] = v;
@@ -649,17 +650,45 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d) {
                 if (!isfinite(eps[c])) nonfinite = 1.0;
             }
             se3_plus(T, eps, Tn);
-            if (d.n_pf)     // unary residual blocks: model cost change at x, cost at the candidate
+            if (d.n_pf)     // pose-only residual blocks: model cost change at x, cost at the candidate
                 for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
                     double r[6], J[36], rc[6];
                     int dim;
-                    pf_evaluate(d, (int)e, T, r, J, &dim);
-                    for (int m = 0; m < dim; ++m) {
-                        double jd = 0.0;
-                        for (int c = 0; c < 6; ++c) jd += J[6 * m + c] * eps[c];
-                        pf_mcc -= jd * (r[m] + 0.5 * jd);
+                    // relative-pose half entry: the other pose, its step and its candidate (computed here: the other
+                    // thread's candidate may not be written yet)
+                    const int other = pf_other_pose(d, (int)e);
+                    const double *To = nullptr;
+                    double eo[6] = {0, 0, 0, 0, 0, 0}, Tno[12];
+                    if (other >= 0) {
+                        To = d.poses + (size_t)other * 12;
+                        const int fo = d.pose_free[other];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            if (fo >= 0)
+                                eo[c] = st.ls_alpha * (st.opt.strategy ? st.beta * d.x0[(size_t)fo * 6 + c] + st.gamma * d.vp[(size_t)other * 6 + c]
+                                                                        : d.x0[(size_t)fo * 6 + c]);
+                        }
+                        if (fo >= 0) se3_plus(To, eo, Tno);
+                        else for (int c = 0; c < 12; ++c) Tno[c] = To[c];
                     }
-                    pf_cc += pf_evaluate(d, (int)e, Tn, rc, nullptr, &dim);
+                    pf_evaluate(d, (int)e, T, To, r, J, &dim);
+                    double jd[6];
+                    for (int m = 0; m < dim; ++m) {
+                        jd[m] = 0.0;
+                        for (int c = 0; c < 6; ++c) jd[m] += J[6 * m + c] * eps[c];
+                        pf_mcc -= jd[m] * (r[m] + 0.5 * jd[m]);
+                    }
+                    const int partner = pf_partner(d, (int)e);
+                    if (d.pf_type[e] == 2 && partner >= 0) {      // (J_1 d_1 + J_2 d_2) is one row vector: the cross term, once
+                        double r2[6], J2[36];
+                        pf_evaluate(d, partner, To, T, r2, J2, &dim);
+                        for (int m = 0; m < 6; ++m) {
+                            double jo = 0.0;
+                            for (int c = 0; c < 6; ++c) jo += J2[6 * m + c] * eo[c];
+                            pf_mcc -= jd[m] * jo;
+                        }
+                    }
+                    if (pf_counts_cost(d, (int)e)) pf_cc += pf_evaluate(d, (int)e, Tn, other >= 0 ? Tno : nullptr, rc, nullptr, &dim);
                 }
             // partitioned solve: the separator poses are updated by both neighbouring ranks, counted once
             const bool owned = !d.part || (f >= (d.rank == 0 ? d.chain0 : d.chain0 + 1) * SBP && f < (d.chain1 + 1) * SBP);
@@ -805,15 +834,33 @@ __global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
             }
             d.vp[(size_t)k * 6 + c] = v;
         }
-        if (d.n_pf && f >= 0)      // rows of the unary residual blocks in |J v|^2, |J gn|^2, (J v).(J gn)
+        if (d.n_pf && f >= 0)      // rows of the pose-only residual blocks in |J v|^2, |J gn|^2, (J v).(J gn)
             for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
-                double r[6], J[36];
+                double r[6], J[36], jv[6], jg[6];
                 int dim;
-                pf_evaluate(d, (int)e, d.poses + (size_t)k * 12, r, J, &dim);
+                const int other = pf_other_pose(d, (int)e), partner = pf_partner(d, (int)e);
+                const double *To = other >= 0 ? d.poses + (size_t)other * 12 : nullptr;
+                pf_evaluate(d, (int)e, d.poses + (size_t)k * 12, To, r, J, &dim);
                 for (int m = 0; m < dim; ++m) {
-                    double jv = 0.0, jg = 0.0;
-                    for (int c = 0; c < 6; ++c) { jv += J[6 * m + c] * d.vp[(size_t)k * 6 + c]; jg += J[6 * m + c] * d.x0[(size_t)f * 6 + c]; }
-                    pjv += jv * jv; pjg += jg * jg; pvg += jv * jg;
+                    jv[m] = 0.0; jg[m] = 0.0;
+                    for (int c = 0; c < 6; ++c) { jv[m] += J[6 * m + c] * d.vp[(size_t)k * 6 + c]; jg[m] += J[6 * m + c] * d.x0[(size_t)f * 6 + c]; }
+                    pjv += jv[m] * jv[m]; pjg += jg[m] * jg[m]; pvg += jv[m] * jg[m];
+                }
+                if (d.pf_type[e] == 2 && partner >= 0) {      // cross terms of the two halves of a relative-pose block
+                    const int fo = d.pose_free[other];
+                    double r2[6], J2[36], vo[6], go[6];
+                    pf_evaluate(d, partner, To, d.poses + (size_t)k * 12, r2, J2, &dim);
+                    for (int c = 0; c < 6; ++c) {      // v of the other pose, recomputed (its thread may not have stored it yet)
+                        const double so = d.sp[(size_t)fo * 6 + c], go_ = d.xv[d.off_gp + (size_t)fo * 6 + c], ho = d.xv[d.off_hdiag + (size_t)fo * 6 + c];
+                        const double D2 = fmin(fmax(ho * so * so, st.opt.min_lm_diag), st.opt.max_lm_diag);
+                        vo[c] = so * so * go_ / D2;
+                        go[c] = d.x0[(size_t)fo * 6 + c];
+                    }
+                    for (int m = 0; m < 6; ++m) {
+                        double jvo = 0.0, jgo = 0.0;
+                        for (int c = 0; c < 6; ++c) { jvo += J2[6 * m + c] * vo[c]; jgo += J2[6 * m + c] * go[c]; }
+                        pjv += 2.0 * jv[m] * jvo; pjg += 2.0 * jg[m] * jgo; pvg += jv[m] * jgo + jvo * jg[m];
+                    }
                 }
             }
     }

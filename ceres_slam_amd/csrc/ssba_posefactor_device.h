@@ -59,6 +59,47 @@ static __device__ void pf_prior(const double *T, const double *T_ref, const doub
         }
 }
 
+// RelativePoseErrorAutomatic (include/ceres_slam/relative_pose_error.hpp:22-40): r = S log(T_ref T1 T2^-1).  With
+// R_res = R_ref R1 R2^T, v = t1 - R1 R2^T t2, t_res = R_ref v + t_ref and T <- exp(eps) T on either pose:
+//   d/d eps1 = [[R_ref, -R_ref v^], [0, Jl^-1(phi) R_ref]],  d/d eps2 = [[-R_res, 0], [0, -Jr^-1(phi)]],  Jl^-1 = (Jr^-1)^T
+static __device__ void pf_rel(const double *T1, const double *T2, const double *T_ref, const double *S, double r[6], double *J1, double *J2) {
+    const double *R1 = T1 + 3, *R2 = T2 + 3, *Rr = T_ref + 3;
+    double R12[9], Rres[9], v[3], e[6];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R12[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];
+    for (int i = 0; i < 3; ++i) v[i] = T1[i] - (R12[3 * i] * T2[0] + R12[3 * i + 1] * T2[1] + R12[3 * i + 2] * T2[2]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rres[3 * i + j] = Rr[3 * i] * R12[j] + Rr[3 * i + 1] * R12[3 + j] + Rr[3 * i + 2] * R12[6 + j];
+    for (int i = 0; i < 3; ++i) e[i] = Rr[3 * i] * v[0] + Rr[3 * i + 1] * v[1] + Rr[3 * i + 2] * v[2] + T_ref[i];
+    pf_so3_log(Rres, e + 3);
+    for (int i = 0; i < 6; ++i) {
+        double a = 0.0;
+        for (int k = 0; k < 6; ++k) a += S[6 * i + k] * e[k];
+        r[i] = a;
+    }
+    if (!J1 && !J2) return;
+    double Jr[9];
+    pf_inv_right_jacobian(e + 3, Jr);
+    const double vx[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                if (j < 3) {
+                    a += S[6 * i + k] * Rr[3 * k + j];
+                    b -= S[6 * i + k] * Rres[3 * k + j];
+                } else {
+                    double rv = 0.0, jl = 0.0;
+                    for (int q = 0; q < 3; ++q) { rv += Rr[3 * k + q] * vx[3 * q + (j - 3)]; jl += Jr[3 * q + k] * Rr[3 * q + (j - 3)]; }
+                    a += -S[6 * i + k] * rv + S[6 * i + 3 + k] * jl;
+                    b -= S[6 * i + 3 + k] * Jr[3 * k + (j - 3)];
+                }
+            }
+            if (J1) J1[6 * i + j] = a;
+            if (J2) J2[6 * i + j] = b;
+        }
+}
+
 static __device__ void pf_sun(const double *T, const double *dat, const double *S, double r[2], double *J) {
     const double pi = 3.14159265358979323846;
     const double *R = T + 3;
@@ -86,12 +127,20 @@ static __device__ void pf_sun(const double *T, const double *dat, const double *
         for (int c = 0; c < 6; ++c) J[6 * i + c] = c < 3 ? 0.0 : S[2 * i] * jaz[c - 3] + S[2 * i + 1] * jzen[c - 3];
 }
 
-// factor f at pose block T: corrected residual r (dim rows) and Jacobian J (dim x 6, or NULL); returns 1/2 rho(|r|^2)
-static __device__ double pf_evaluate(const Dev &d, int f, const double *T, double r[6], double *J, int *dim_out) {
-    const int type = d.pf_type[f], dim = type == 0 ? 6 : 2;
+// the other pose of a relative-pose half entry (types 2 / 3), -1 for the unary blocks
+static __device__ __forceinline__ int pf_other_pose(const Dev &d, int f) { return d.pf_type[f] >= 2 ? (int)d.pf_data[18 * (size_t)f + 12] : -1; }
+static __device__ __forceinline__ int pf_partner(const Dev &d, int f) { return d.pf_type[f] >= 2 ? (int)d.pf_data[18 * (size_t)f + 14] : -1; }
+static __device__ __forceinline__ bool pf_counts_cost(const Dev &d, int f) { return d.pf_type[f] < 2 || d.pf_data[18 * (size_t)f + 13] != 0.0; }
+
+// factor f at pose block T (and, for the two halves of a relative-pose block, the other pose's block T_other): corrected
+// residual r (dim rows) and the Jacobian J w.r.t. THIS pose (dim x 6, or NULL); returns 1/2 rho(|r|^2)
+static __device__ double pf_evaluate(const Dev &d, int f, const double *T, const double *T_other, double r[6], double *J, int *dim_out) {
+    const int type = d.pf_type[f], dim = type == 1 ? 2 : 6;
     for (int i = 0; i < 6; ++i) r[i] = 0.0;
     if (type == 0) pf_prior(T, d.pf_data + 18 * (size_t)f, d.pf_S + 36 * (size_t)f, r, J);
-    else pf_sun(T, d.pf_data + 18 * (size_t)f, d.pf_S + 36 * (size_t)f, r, J);
+    else if (type == 1) pf_sun(T, d.pf_data + 18 * (size_t)f, d.pf_S + 36 * (size_t)f, r, J);
+    else if (type == 2) pf_rel(T, T_other, d.pf_data + 18 * (size_t)f, d.pf_S + 36 * (size_t)f, r, J, nullptr);
+    else pf_rel(T_other, T, d.pf_data + 18 * (size_t)f, d.pf_S + 36 * (size_t)f, r, nullptr, J);
     if (J) for (int i = 6 * dim; i < 36; ++i) J[i] = 0.0;
     double sq = 0.0;
     for (int i = 0; i < dim; ++i) sq += r[i] * r[i];

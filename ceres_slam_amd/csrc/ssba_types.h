@@ -205,6 +205,7 @@ struct Dev {
     // blocks (a <= b) of the reduced system with the observation pairs (of one landmark) that contribute to each
     int dn_nblk;
     const uint32_t *dn_blk_a, *dn_blk_b, *dn_blk_start, *dn_pair_a, *dn_pair_b;
+    const uint32_t *dn_blk_rf_start, *dn_blk_rf;    // per block: relative-pose entries (first half | bit 31: block is J_2^T J_1), or null
     // block-level (DN_BS) symbolic factorisation: non-zero block rows below the diagonal of every block column
     // (the rhs row last), the tile pairs of every trailing update, and the non-zero block columns of every block row
     const uint32_t *dn_rows, *dn_ti, *dn_tk, *dn_cols;

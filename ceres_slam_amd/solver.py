@@ -59,7 +59,10 @@ class StereoBA:
         for f in (pose_factors or []):      # dicts as for oracle.OracleProblem: pose, type (0 prior / 1 sun), data, stiffness, huber
             dat = np.ascontiguousarray(f["data"], dtype=np.float64).ravel()
             S = np.ascontiguousarray(f["stiffness"], dtype=np.float64).ravel()
-            if f["type"] == 0:
+            if f["type"] == 2:      # RelativePoseErrorAutomatic between pose and pose2 (tests/blowup_test.cpp:70-76)
+                capi.check(self.lib.ssba_add_relative_pose(self.h, int(f["pose"]), int(f["pose2"]), capi.dptr(np.ascontiguousarray(dat[:12])),
+                                                           capi.dptr(S), float(f.get("huber", 0.0))), "ssba_add_relative_pose")
+            elif f["type"] == 0:
                 capi.check(self.lib.ssba_add_pose_prior(self.h, int(f["pose"]), capi.dptr(dat), capi.dptr(S), float(f.get("huber", 0.0))),
                            "ssba_add_pose_prior")
             else:

@@ -109,6 +109,18 @@ class PoseErrorAutomatic : public ceres::CostFunction {
     double T_ref[12], stiffness[36];
 };
 
+// include/ceres_slam/relative_pose_error.hpp:46-57: measurement T_2_1_ref between two pose blocks, r = S log(T_ref T_1 T_2^-1)
+class RelativePoseErrorAutomatic : public ceres::CostFunction {
+ public:
+    static ceres::CostFunction *Create(const double T_2_1_ref[12], const double stiffness[36]) {
+        RelativePoseErrorAutomatic *c = new RelativePoseErrorAutomatic;
+        std::memcpy(c->T_ref, T_2_1_ref, sizeof c->T_ref);
+        std::memcpy(c->stiffness, stiffness, sizeof c->stiffness);
+        return c;
+    }
+    double T_ref[12], stiffness[36];
+};
+
 // include/ceres_slam/sun_sensor_error.hpp:108-120: azimuth / zenith error of the expected sun direction, stiffness 2x2
 class SunSensorErrorAutomatic : public ceres::CostFunction {
  public:
@@ -278,6 +290,24 @@ class Problem {
 
     void AddResidualBlock(CostFunction *cost, LossFunction *loss, double *pose_block, double *point_block) {
         ++version_;
+        if (auto *rp = dynamic_cast<ceres_slam::RelativePoseErrorAutomatic *>(cost)) {      // (pose 1, pose 2): blowup_test.cpp:70-76
+            RelFactor f;
+            std::memset(&f, 0, sizeof f);
+            f.pose1 = pose_block; f.pose2 = point_block;
+            std::memcpy(f.T_ref, rp->T_ref, sizeof f.T_ref);
+            std::memcpy(f.stiffness, rp->stiffness, sizeof f.stiffness);
+            if (loss) {
+                HuberLoss *h = dynamic_cast<HuberLoss *>(loss);
+                if (!h) throw std::invalid_argument("ceres_shim: loss must be NULL or ceres::HuberLoss");
+                owned_losses_[loss] = 1;
+                f.huber = h->a();
+            }
+            block_index(pose_index_, pose_blocks_, pose_block);
+            block_index(pose_index_, pose_blocks_, point_block);
+            rel_factors_.push_back(f);
+            owned_costs_.push_back(cost);
+            return;
+        }
         if (auto *n = dynamic_cast<ceres_slam::NormalErrorAutomatic *>(cost)) {   // (pose, normal): dataset_ba_phong.cpp:181-188
             if (loss) throw std::invalid_argument("ceres_shim: lighting residual blocks take a NULL loss");
             NormalBlock b;
@@ -359,6 +389,8 @@ class Problem {
             if (f.type == 0) { if ((*rc = ssba_add_pose_prior(h, k, f.data, f.stiffness, f.huber))) return "ssba_add_pose_prior"; }
             else if ((*rc = ssba_add_sun_observation(h, k, f.data, f.data + 3, f.stiffness, f.data[6], f.data[7], f.huber))) return "ssba_add_sun_observation";
         }
+        for (auto &f : rel_factors_)
+            if ((*rc = ssba_add_relative_pose(h, pose_index_[f.pose1], pose_index_[f.pose2], f.T_ref, f.stiffness, f.huber))) return "ssba_add_relative_pose";
         if (huber_a_ > 0 && (*rc = ssba_set_huber_loss(h, huber_a_))) return "ssba_set_huber_loss";
         return nullptr;
     }
@@ -375,6 +407,8 @@ class Problem {
     double huber_a_ = 0.0;
     struct PoseFactor { int type; double *pose; double data[18], stiffness[36], huber; };
     std::vector<PoseFactor> pose_factors_;
+    struct RelFactor { double *pose1, *pose2; double T_ref[12], stiffness[36], huber; };
+    std::vector<RelFactor> rel_factors_;
     std::map<double *, uint32_t> pose_index_, point_index_;
     std::vector<double *> pose_blocks_, point_blocks_;
     std::vector<uint32_t> obs_pose_, obs_point_;
@@ -420,7 +454,8 @@ inline const char *shim_prepare(Problem &P, int *rc_out) {
         return nullptr;
     }
     if (P.h_) { ssba_destroy(P.h_); P.h_ = nullptr; }
-    ssba_camera cam = {P.camera_->fu, P.camera_->fv, P.camera_->cu, P.camera_->cv, P.camera_->b};
+    ssba_camera cam = {1.0, 1.0, 0.0, 0.0, 1.0};      // pose-graph problems (tests/blowup_test.cpp) have no stereo block
+    if (P.camera_) cam = ssba_camera{P.camera_->fu, P.camera_->fv, P.camera_->cu, P.camera_->cv, P.camera_->b};
     ssba_problem *&h = P.h_;
     rc = ssba_create(&cam, -1, &h);
     auto fail = [&](const char *where) -> const char * {
@@ -527,7 +562,11 @@ inline const char *shim_prepare(Problem &P, int *rc_out) {
 inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
     Problem &P = *problem;
     *summary = Solver::Summary();
-    if (P.obs_pose_.empty()) { summary->termination_type = CONVERGENCE; summary->message = "no residual blocks"; return; }
+    if (P.obs_pose_.empty() && P.pose_factors_.empty() && P.rel_factors_.empty()) {
+        summary->termination_type = CONVERGENCE;
+        summary->message = "no residual blocks";
+        return;
+    }
     int rc = 0;
     auto fail = [&](const char *where) {
         summary->termination_type = FAILURE;
@@ -590,7 +629,7 @@ class Covariance {
         blocks_.clear();
         message_.clear();
         if (!P.intensity_.empty() || !P.normals_.empty()) { message_ = "covariance is not available with lighting terms"; return false; }
-        if (!P.camera_) { message_ = "no stereo residual blocks"; return false; }
+        if (P.pose_blocks_.empty()) { message_ = "no pose blocks"; return false; }
         int rc = 0;
         const char *where = shim_prepare(P, &rc);      // the handle of the preceding Solve when nothing changed since
         for (size_t i = 0; !where && i < blocks.size(); ++i) {

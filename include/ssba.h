@@ -320,6 +320,11 @@ int ssba_set_point_blocks_constant(ssba_problem *p, int is_constant);
  *   stiffness 2x2 row-major.  huber_a > 0 wraps the block in ceres::HuberLoss(huber_a) (:87-92), 0 = NULL loss.
  * Both before ssba_finalize; not on constant poses; not together with lighting terms or landmark sharding yet. */
 int ssba_add_pose_prior(ssba_problem *p, uint32_t pose, const double T_ref[12], const double stiffness[36], double huber_a);
+/* ssba_add_relative_pose replaces problem.AddResidualBlock(RelativePoseErrorAutomatic::Create(T_2_1_ref, stiffness), loss,
+ *   pose1, pose2) (include/ceres_slam/relative_pose_error.hpp:22-57; tests/blowup_test.cpp:70-76):
+ *   r = stiffness * log(T_2_1_ref * T_1 * T_2^-1), 6 residuals.  Problems with such blocks run the general-structure kernels. */
+int ssba_add_relative_pose(ssba_problem *p, uint32_t pose1, uint32_t pose2, const double T_2_1_ref[12], const double stiffness[36],
+                           double huber_a);
 int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observed_dir_c[3],
                              const double expected_dir_g[3], const double stiffness[4], double az_err_thresh,
                              double zen_err_thresh, double huber_a);

@@ -126,6 +126,25 @@ def driver_options(**kw) -> Options:
     return default_options(**base)
 
 
+def expand_relative_pose_factors(pose_factors, pose_const):
+    """A RelativePoseErrorAutomatic block (type 2: pose, pose2, data = T_2_1_ref, 6x6 stiffness) becomes two half
+    entries, one per pose block (types 2 / 3: data[12] the other pose, data[13] = 1 on the half that counts the
+    cost -- the first non-constant one --, data[14] the index of the other half)."""
+    out = []
+    for f in pose_factors:
+        if f["type"] != 2 or "pose2" not in f:
+            out.append(f)
+            continue
+        k1, k2 = int(f["pose"]), int(f["pose2"])
+        first_counts = not (pose_const[k1] and not pose_const[k2])
+        ia, ib = len(out), len(out) + 1
+        T_ref = np.asarray(f["data"], dtype=np.float64).ravel()[:12]
+        for typ, k, other, counts, partner in ((2, k1, k2, first_counts, ib), (3, k2, k1, not first_counts, ia)):
+            out.append(dict(pose=k, type=typ, data=np.concatenate([T_ref, [float(other), 1.0 if counts else 0.0, float(partner)]]),
+                            stiffness=f["stiffness"], huber=f.get("huber", 0.0)))
+    return out
+
+
 class OracleProblem:
     """Owns numpy copies of a problem and the ctypes view the C oracle reads."""
 
@@ -164,6 +183,7 @@ class OracleProblem:
         self.ld = 3
         self.normals = None
         if pose_factors:        # list of dicts: pose, type (0 prior / 1 sun), data (<= 18), stiffness (36 or 4), huber
+            pose_factors = expand_relative_pose_factors(pose_factors, self.pose_const)
             F = len(pose_factors)
             self._pf_pose = np.array([f["pose"] for f in pose_factors], dtype=np.uint32)
             self._pf_type = np.array([f["type"] for f in pose_factors], dtype=np.uint32)

@@ -325,6 +325,50 @@ void orc_pose_prior_residual(const double T[12], const double T_ref[12], const d
         }
 }
 
+/* include/ceres_slam/relative_pose_error.hpp:22-40: r = S log(T_2_1_ref * T_1_0 * T_2_0^-1), log = [t ; axis-angle].
+ * With R_res = R_ref R1 R2^T, v = t1 - R1 R2^T t2, t_res = R_ref v + t_ref and the local perturbations T <- exp(eps) T:
+ *   d/d eps1 = [[R_ref, -R_ref v^], [0, Jl^-1(phi) R_ref]],  d/d eps2 = [[-R_res, 0], [0, -Jr^-1(phi)]],  Jl^-1 = (Jr^-1)^T */
+void orc_relative_pose_residual(const double T1[12], const double T2[12], const double T_ref[12], const double S[36], double r[6],
+                                double *J1, double *J2) {
+    const double *R1 = T1 + 3, *R2 = T2 + 3, *Rr = T_ref + 3;
+    double R12[9], Rres[9], v[3], e[6];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R12[3 * i + j] = R1[3 * i] * R2[3 * j] + R1[3 * i + 1] * R2[3 * j + 1] + R1[3 * i + 2] * R2[3 * j + 2];   /* R1 R2^T */
+    for (int i = 0; i < 3; ++i) v[i] = T1[i] - (R12[3 * i] * T2[0] + R12[3 * i + 1] * T2[1] + R12[3 * i + 2] * T2[2]);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Rres[3 * i + j] = Rr[3 * i] * R12[j] + Rr[3 * i + 1] * R12[3 + j] + Rr[3 * i + 2] * R12[6 + j];
+    for (int i = 0; i < 3; ++i) e[i] = Rr[3 * i] * v[0] + Rr[3 * i + 1] * v[1] + Rr[3 * i + 2] * v[2] + T_ref[i];
+    so3_log(Rres, e + 3);
+    for (int i = 0; i < 6; ++i) {
+        double a = 0.0;
+        for (int k = 0; k < 6; ++k) a += S[6 * i + k] * e[k];
+        r[i] = a;
+    }
+    if (!J1 && !J2) return;
+    double Jr[9], Je1[36], Je2[36];
+    so3_inv_right_jacobian(e + 3, Jr);
+    memset(Je1, 0, sizeof Je1);
+    memset(Je2, 0, sizeof Je2);
+    const double vx[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double rv = 0.0, jl = 0.0;
+            for (int k = 0; k < 3; ++k) { rv += Rr[3 * i + k] * vx[3 * k + j]; jl += Jr[3 * k + i] * Rr[3 * k + j]; }
+            Je1[6 * i + j] = Rr[3 * i + j];
+            Je1[6 * i + 3 + j] = -rv;
+            Je1[6 * (3 + i) + 3 + j] = jl;                 /* (Jr^-1)^T R_ref */
+            Je2[6 * i + j] = -Rres[3 * i + j];
+            Je2[6 * (3 + i) + 3 + j] = -Jr[3 * i + j];
+        }
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < 6; ++k) { a += S[6 * i + k] * Je1[6 * k + j]; b += S[6 * i + k] * Je2[6 * k + j]; }
+            if (J1) J1[6 * i + j] = a;
+            if (J2) J2[6 * i + j] = b;
+        }
+}
+
 void orc_sun_residual(const double T[12], const double obs_c_in[3], const double exp_g_in[3], const double S[4], double az_thresh,
                       double zen_thresh, double r[2], double *J) {
     const double pi = 3.14159265358979323846;
@@ -361,21 +405,30 @@ static double pf_eval(const orc_problem *p, const double *poses, double *pf_r, d
     for (uint32_t f = 0; f < p->num_pose_factors; ++f) {
         const double *T = poses + 12 * (size_t)p->pf_pose[f], *dat = p->pf_data + 18 * (size_t)f, *S = p->pf_stiffness + 36 * (size_t)f;
         double r[6] = {0}, J[36] = {0};
-        const int dim = p->pf_type[f] == 0 ? 6 : 2;
-        if (p->pf_type[f] == 0) orc_pose_prior_residual(T, dat, S, r, pf_J ? J : NULL);
-        else orc_sun_residual(T, dat, dat + 3, S, dat[6], dat[7], r, pf_J ? J : NULL);
+        const int type = (int)p->pf_type[f], dim = type == 1 ? 2 : 6;
+        /* types 2 / 3: the two halves of a RelativePoseErrorAutomatic block (this pose is its first / second block, the
+         * other pose is dat[12]); each half carries the Jacobian of its own pose, dat[13] says which one counts the cost */
+        double counts = 1.0;
+        if (type == 0) orc_pose_prior_residual(T, dat, S, r, pf_J ? J : NULL);
+        else if (type == 1) orc_sun_residual(T, dat, dat + 3, S, dat[6], dat[7], r, pf_J ? J : NULL);
+        else {
+            const double *To = poses + 12 * (size_t)dat[12];
+            if (type == 2) orc_relative_pose_residual(T, To, dat, S, r, pf_J ? J : NULL, NULL);
+            else orc_relative_pose_residual(To, T, dat, S, r, NULL, pf_J ? J : NULL);
+            counts = dat[13];
+        }
         double sq = 0.0;
         for (int i = 0; i < dim; ++i) sq += r[i] * r[i];
         const double a = p->pf_huber ? p->pf_huber[f] : 0.0;
         if (a > 0.0) {
             double rho[3];
             orc_huber(a, sq, rho);
-            cost += 0.5 * rho[0];
+            cost += counts * 0.5 * rho[0];
             const double sc = sqrt(rho[1]);             /* corrector with rho'' <= 0: scale r and J by sqrt(rho') */
             for (int i = 0; i < dim; ++i) r[i] *= sc;
             if (pf_J) for (int i = 0; i < 6 * dim; ++i) J[i] *= sc;
         } else {
-            cost += 0.5 * sq;
+            cost += counts * 0.5 * sq;
         }
         if (pf_r) memcpy(pf_r + 6 * (size_t)f, r, sizeof r);
         if (pf_J) memcpy(pf_J + 36 * (size_t)f, J, sizeof J);
@@ -559,6 +612,11 @@ static void graph_build(const orc_problem *p, graph_t *g) {
         }
         if (hi >= 0 && hi - lo > bw) bw = hi - lo;
     }
+    for (uint32_t f = 0; f < p->num_pose_factors; ++f)      /* relative-pose blocks couple their two poses */
+        if (p->pf_type[f] == 2) {
+            const int fa = g->free_idx[p->pf_pose[f]], fb = g->free_idx[(int)p->pf_data[18 * (size_t)f + 12]];
+            if (fa >= 0 && fb >= 0 && abs(fa - fb) > bw) bw = abs(fa - fb);
+        }
     g->bw_poses = bw;
 }
 
@@ -999,6 +1057,22 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
         }
         memcpy(sc->rhs + 6 * f, gr, sizeof gr);
     }
+    /* relative-pose blocks: the off-diagonal block J_a^T J_b of their two poses (lower band) */
+    for (uint32_t e = 0; e < p->num_pose_factors; ++e) {
+        if (p->pf_type[e] != 2) continue;
+        const int other = (int)p->pf_data[18 * (size_t)e + 14];      /* index of the second half */
+        const int fa = g->free_idx[p->pf_pose[e]], fb = g->free_idx[p->pf_pose[other]];
+        if (fa < 0 || fb < 0) continue;
+        const double *Ja = w->pf_J + 36 * (size_t)e, *Jb = w->pf_J + 36 * (size_t)other;
+        const int hi = fa > fb ? fa : fb, lo = fa > fb ? fb : fa;
+        const double *Jh = fa > fb ? Ja : Jb, *Jl2 = fa > fb ? Jb : Ja;
+        for (int c = 0; c < 6; ++c)
+            for (int d = 0; d < 6; ++d) {
+                double v = 0.0;
+                for (int m = 0; m < 6; ++m) v += Jh[6 * m + c] * Jl2[6 * m + d];
+                sc->S[(size_t)(6 * hi + c) * lds + ((6 * lo + d) - (6 * hi + c) + bw)] += v * sp[6 * hi + c] * sp[6 * lo + d];
+            }
+    }
     return 0;
 }
 
@@ -1043,6 +1117,18 @@ static void step_products(const orc_problem *p, const graph_t *g, const lin_t *w
                 mcc -= jd * (r[m] + 0.5 * jd);
                 sq += jd * jd;
             }
+        }
+    }
+    for (uint32_t e = 0; e < p->num_pose_factors; ++e) {      /* relative-pose blocks: (J_a d_a + J_b d_b) is one row vector */
+        if (p->pf_type[e] != 2) continue;
+        const int other = (int)p->pf_data[18 * (size_t)e + 14], ka = (int)p->pf_pose[e], kb = (int)p->pf_pose[other];
+        if (g->free_idx[ka] < 0 || g->free_idx[kb] < 0) continue;
+        const double *Ja = w->pf_J + 36 * (size_t)e, *Jb = w->pf_J + 36 * (size_t)other;
+        for (int m = 0; m < 6; ++m) {
+            double ja = 0.0, jb = 0.0;
+            for (int c = 0; c < 6; ++c) { ja += Ja[6 * m + c] * dp[6 * (size_t)ka + c]; jb += Jb[6 * m + c] * dp[6 * (size_t)kb + c]; }
+            mcc -= ja * jb;
+            sq += 2.0 * ja * jb;
         }
     }
     if (mcc_out) *mcc_out = mcc;
@@ -1217,6 +1303,20 @@ static void jd_products(const orc_problem *p, const graph_t *g, const lin_t *w, 
                 for (int c = 0; c < 6; ++c) { j1 += J[6 * m + c] * dp1[6 * (size_t)k + c]; j2 += J[6 * m + c] * dp2[6 * (size_t)k + c]; }
                 s11 += j1 * j1; s22 += j2 * j2; s12 += j1 * j2;
             }
+        }
+    }
+    for (uint32_t e = 0; e < p->num_pose_factors; ++e) {
+        if (p->pf_type[e] != 2) continue;
+        const int other = (int)p->pf_data[18 * (size_t)e + 14], ka = (int)p->pf_pose[e], kb = (int)p->pf_pose[other];
+        if (g->free_idx[ka] < 0 || g->free_idx[kb] < 0) continue;
+        const double *Ja = w->pf_J + 36 * (size_t)e, *Jb = w->pf_J + 36 * (size_t)other;
+        for (int m = 0; m < 6; ++m) {
+            double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+            for (int c = 0; c < 6; ++c) {
+                a1 += Ja[6 * m + c] * dp1[6 * (size_t)ka + c]; a2 += Ja[6 * m + c] * dp2[6 * (size_t)ka + c];
+                b1 += Jb[6 * m + c] * dp1[6 * (size_t)kb + c]; b2 += Jb[6 * m + c] * dp2[6 * (size_t)kb + c];
+            }
+            s11 += 2.0 * a1 * b1; s22 += 2.0 * a2 * b2; s12 += a1 * b2 + b1 * a2;
         }
     }
     out[0] = s11; out[1] = s22; out[2] = s12;

@@ -83,7 +83,9 @@ typedef struct {
     /* unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124) */
     uint32_t num_pose_factors, reserved3;
     const uint32_t *pf_pose;           /* F: pose index                                                   */
-    const uint32_t *pf_type;           /* F: 0 = PoseErrorAutomatic, 1 = SunSensorErrorAutomatic          */
+    const uint32_t *pf_type;           /* F: 0 = PoseErrorAutomatic, 1 = SunSensorErrorAutomatic, 2 / 3 = the two halves of a
+                                          RelativePoseErrorAutomatic block (first / second pose block): data = T_2_1_ref (12),
+                                          the other pose, 1 if this half counts the cost, the index of the other half */
     const double *pf_data;             /* F*18: type 0: T_ref (12); type 1: observed dir (camera frame, 3),
                                           expected dir (global, 3), azimuth threshold, zenith threshold  */
     const double *pf_stiffness;        /* F*36: 6x6 (type 0) or 2x2 in the first 4 entries (type 1)       */
@@ -218,6 +220,8 @@ void orc_normal_residual(const double T[12], const double n[3], const double n_o
 
 /* unary pose residuals (row N4): corrected-free residual and local 6-column Jacobian (may be NULL) */
 void orc_pose_prior_residual(const double T[12], const double T_ref[12], const double S[36], double r[6], double *J);
+void orc_relative_pose_residual(const double T1[12], const double T2[12], const double T_ref[12], const double S[36], double r[6],
+                                double *J1, double *J2);
 void orc_sun_residual(const double T[12], const double obs_c[3], const double exp_g[3], const double S[4], double az_thresh,
                       double zen_thresh, double r[2], double *J);
 

@@ -92,3 +92,90 @@ def test_pose_factor_restrictions():
     with pytest.raises(capi.SsbaError):           # default pose_const holds pose 0 constant: the prior would sit on it
         StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
                  prob.stiffness(), pose_factors=factors)
+
+
+# ---- RelativePoseErrorAutomatic blocks (relative_pose_error.hpp, tests/blowup_test.cpp): pose-pose couplings ----
+from test_oracle_pose_factors import _odometry_factors
+
+
+@pytest.mark.parametrize("huber", [0.0, 0.05])
+@pytest.mark.parametrize("radius", [1e4, 20.0])
+def test_lm_step_with_relative_pose_blocks_matches_oracle(huber, radius):
+    prob = synth.make_problem(9, 300, track_len=5, seed=6)
+    factors = _odometry_factors(prob, huber=huber)
+    ba, op = _pair(prob, factors)
+    assert ba.stats().general_structure == 1          # the loop block couples the first and the last pose
+    S, rhs, dp, dl, mcc = ba.lm_step(radius)
+    S2, rhs2, _ = op.reduced_system(radius)
+    dp2, dl2, mcc2 = op.lm_step(radius)
+    assert _rel(S, S2) < 1e-9 and _rel(rhs, rhs2) < 1e-9
+    assert _rel(dp, dp2) < 1e-7 and _rel(dl, dl2) < 1e-7
+    assert mcc == pytest.approx(mcc2, rel=1e-8)
+    assert ba.evaluate()[0] == pytest.approx(op.cost(), rel=1e-12)
+
+
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("huber", [0.0, 0.05])
+def test_solve_with_odometry_and_loop_blocks_matches_oracle(strategy, huber):
+    prob = synth.make_problem(20, 700, track_len=6, seed=11, pose_sigma=(0.1, 0.02))
+    factors = _odometry_factors(prob, huber=huber)
+    ba, op = _pair(prob, factors)
+    kw = dict(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    s, log = ba.solve(capi.default_options(**kw))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, **kw))
+    assert s.termination_type == s2.termination_type == 0
+    n = min(len(log["cost"]), len(log2["cost"]), 12)
+    assert log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-5)
+    assert np.abs(ba.poses - op.poses).max() < 1e-4
+
+
+def test_relative_pose_block_on_a_constant_pose_and_pose_graph_only():
+    prob = synth.make_problem(8, 200, track_len=4, seed=2)
+    factors = _odometry_factors(prob, loop=True)[1:]          # no prior: pose 0 is held constant instead
+    const = np.zeros(8, np.uint8)
+    const[0] = 1
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                  pose_const=const, pose_factors=factors)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_const=const, pose_factors=factors)
+    dp, dl, mcc = ba.lm_step(100.0)[2:]
+    dp2, dl2, mcc2 = op.lm_step(100.0)
+    assert _rel(dp, dp2) < 1e-7 and mcc == pytest.approx(mcc2, rel=1e-8)
+    s, _ = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    s2, _ = op.solve(orc.driver_options(num_threads=2))
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6) and np.array_equal(ba.poses[0], prob.poses_init[0])
+    # a pose graph without any stereo block (tests/blowup_test.cpp)
+    none = (np.zeros((0, 3)), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 3)), np.eye(3))
+    pg = _odometry_factors(prob)
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), *none, pose_const=np.zeros(8, np.uint8), pose_factors=pg)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, *none, pose_const=np.zeros(8, np.uint8), pose_factors=pg)
+    s, _ = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    s2, _ = op.solve(orc.driver_options(num_threads=1))
+    assert s.termination_type == s2.termination_type == 0 and s.num_iterations == s2.num_iterations
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6, abs=1e-18)
+    assert np.abs(ba.poses - op.poses).max() < 1e-7
+
+
+def test_blowup_driver_through_the_ceres_shim():
+    """examples/blowup_test_gpu: two-state windows of one relative-pose block + the prior from the previous window's
+    covariance (tests/blowup_test.cpp:55-125) -- the trace of the covariance grows along the chain, the poses follow
+    the measurement."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples("blowup_test_gpu")
+    r = subprocess.run([exe, "8", "0.1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = np.array([[float(x) for x in l.split()] for l in r.stdout.splitlines() if l.strip()])
+    assert rows.shape == (8, 5)
+    yaw, T = 0.05, np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0])
+    meas = np.array([0, 0, -1.0, np.cos(yaw), 0, np.sin(yaw), 0, 1, 0, -np.sin(yaw), 0, np.cos(yaw)])
+    for k in range(1, 8):                       # with a stiff prior the optimum is the chained measurement
+        R = meas[3:].reshape(3, 3)
+        T = np.concatenate([R @ T[:3] + meas[:3], (R @ T[3:].reshape(3, 3)).ravel()])
+        np.testing.assert_allclose(rows[k, 1:4], T[:3], atol=1e-6)
+    assert np.all(np.diff(rows[:, 4]) > 0)      # uncertainty accumulates
+    assert rows[1, 4] == pytest.approx(6 * 0.1 ** 2 + 6e-12, rel=1e-3)      # first window: measurement noise on top of the prior

@@ -128,15 +128,21 @@ def _sun_problem(P=8, L=120, seed=2, huber=0.0):
     return prob, factors
 
 
-@pytest.mark.parametrize("huber", [0.0, 0.5])
-def test_lm_step_with_pose_factors_matches_dense_numpy_solve(huber):
-    prob, factors = _sun_problem(huber=huber)
+def _rel_res(T1, T2, T_ref, S):
+    """RelativePoseErrorAutomatic (relative_pose_error.hpp:22-40) on complex inputs: S log(T_ref T1 T2^-1)."""
+    R1, R2, Rr = T1[3:].reshape(3, 3), T2[3:].reshape(3, 3), T_ref[3:].reshape(3, 3)
+    R12 = R1 @ R2.T
+    t = Rr @ (T1[:3] - R12 @ T2[:3]) + T_ref[:3]
+    return S @ np.concatenate([t, _so3_log(Rr @ R12)])
+
+
+def _check_lm_step_against_dense(prob, factors, radius=50.0):
+    """The oracle's LM step against a dense restatement: complex-step Jacobians of every residual block, Jacobi
+    scaling, clamped LM diagonal, one dense solve."""
     none_const = np.zeros(prob.num_poses, dtype=np.uint8)                                          # no constant pose: the prior anchors
     op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
                            pose_const=none_const, pose_factors=factors)
-    radius = 50.0
     dp, dl, mcc = op.lm_step(radius)
-    # dense restatement with complex-step Jacobians
     P, Lm = prob.num_poses, prob.num_points
     rows, r = [], []
     S = prob.stiffness()
@@ -149,23 +155,31 @@ def test_lm_step_with_pose_factors_matches_dense_numpy_solve(huber):
             row[6 * k: 6 * k + 6] = Jp[m]
             row[6 * P + 3 * j: 6 * P + 3 * j + 3] = Jl[m]
             rows.append(row); r.append(ri[m])
+    cost = 0.5 * float(np.dot(r, r)) if not getattr(prob, "_huber", 0) else None
     for f in factors:
         k, T = f["pose"], prob.poses_init[f["pose"]]
+        blocks = {}
         if f["type"] == 0:
             fun = lambda X: _prior_res(X, np.asarray(f["data"]), np.asarray(f["stiffness"]).reshape(6, 6))
-        else:
+            rf, blocks[k] = fun(T).real, _cs_jac(fun, T)
+        elif f["type"] == 1:
             d = np.asarray(f["data"])
             fun = lambda X: _sun_res(X, d[:3], d[3:6], np.asarray(f["stiffness"]).reshape(2, 2), d[6], d[7])
-        rf, Jf = fun(T).real, _cs_jac(fun, T)
+            rf, blocks[k] = fun(T).real, _cs_jac(fun, T)
+        else:       # relative pose block on (pose, pose2)
+            k2, T2 = f["pose2"], prob.poses_init[f["pose2"]]
+            Tr, Sf = np.asarray(f["data"], dtype=float), np.asarray(f["stiffness"]).reshape(6, 6)
+            rf = _rel_res(T, T2, Tr, Sf).real
+            blocks[k] = _cs_jac(lambda X: _rel_res(X, T2.astype(complex), Tr, Sf), T)
+            blocks[k2] = _cs_jac(lambda X: _rel_res(T.astype(complex), X, Tr, Sf), T2)
         a = f.get("huber", 0.0)
         sq = rf @ rf
-        if a > 0 and sq > a * a:
-            sc = np.sqrt(a / np.sqrt(sq))
-            rf, Jf = rf * sc, Jf * sc
+        sc = np.sqrt(a / np.sqrt(sq)) if a > 0 and sq > a * a else 1.0
         for m in range(len(rf)):
             row = np.zeros(6 * P + 3 * Lm)
-            row[6 * k: 6 * k + 6] = Jf[m]
-            rows.append(row); r.append(rf[m])
+            for kk, Jf in blocks.items():
+                row[6 * kk: 6 * kk + 6] = Jf[m] * sc
+            rows.append(row); r.append(rf[m] * sc)
     J, r = np.array(rows), np.array(r)
     active = np.concatenate([np.ones(6 * P, bool), np.repeat(np.bincount(prob.obs_point, minlength=Lm) > 0, 3)])
     J = J[:, active]
@@ -179,6 +193,49 @@ def test_lm_step_with_pose_factors_matches_dense_numpy_solve(huber):
     np.testing.assert_allclose(dl.ravel(), delta[6 * P:], rtol=1e-7, atol=1e-9)
     Jd = J @ delta[active]
     assert mcc == pytest.approx(-Jd @ (r + 0.5 * Jd), rel=1e-8)
+    if all(f.get("huber", 0.0) == 0.0 for f in factors):
+        assert op.cost() == pytest.approx(0.5 * float(r @ r), rel=1e-12)
+    return op
+
+
+@pytest.mark.parametrize("huber", [0.0, 0.5])
+def test_lm_step_with_pose_factors_matches_dense_numpy_solve(huber):
+    prob, factors = _sun_problem(huber=huber)
+    _check_lm_step_against_dense(prob, factors)
+
+
+def _odometry_factors(prob, seed=0, loop=True, huber=0.0):
+    """RelativePoseErrorAutomatic blocks (tests/blowup_test.cpp:55-76): noisy T_2_1 between consecutive states, one
+    between the first and the last state, and the prior that holds the gauge."""
+    rng = np.random.default_rng(seed)
+    P = prob.num_poses
+    pairs = [(k, k + 1) for k in range(P - 1)] + ([(0, P - 1)] if loop else [])
+    factors = [dict(pose=0, type=0, data=prob.poses_init[0], stiffness=np.eye(6) * 1e2)]
+    for k1, k2 in pairs:
+        T1, T2 = prob.poses_gt[k1], prob.poses_gt[k2]
+        R1, R2 = T1[3:].reshape(3, 3), T2[3:].reshape(3, 3)
+        T21 = np.concatenate([T2[:3] - R2 @ R1.T @ T1[:3], (R2 @ R1.T).ravel()])
+        A = rng.normal(size=(6, 6)) * 0.3
+        factors.append(dict(pose=k1, pose2=k2, type=2, data=npr.se3_plus(T21, 0.01 * rng.normal(size=6)),
+                            stiffness=(A @ A.T + np.diag([30.0] * 3 + [100.0] * 3)).ravel(), huber=huber))
+    return factors
+
+
+@pytest.mark.parametrize("huber", [0.0, 0.05])
+def test_lm_step_with_relative_pose_blocks_matches_dense_numpy_solve(huber):
+    prob = synth.make_problem(7, 100, track_len=4, seed=6)
+    _check_lm_step_against_dense(prob, _odometry_factors(prob, huber=huber))
+
+
+def test_pose_graph_solve_pulls_the_trajectory_together():
+    """Stereo blocks + odometry + one loop factor: converges, and the odometry blocks shrink the pose error."""
+    prob = synth.make_problem(12, 240, track_len=4, seed=9, pose_sigma=(0.2, 0.03))
+    none_const = np.zeros(prob.num_poses, dtype=np.uint8)
+    args = (prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness())
+    op = orc.OracleProblem(*args, pose_const=none_const, pose_factors=_odometry_factors(prob))
+    s, _ = op.solve(orc.driver_options(num_threads=2))
+    assert s.termination_type == 0 and s.final_cost < s.initial_cost
+    assert np.abs(op.poses[:, :3] - prob.poses_gt[:, :3]).max() < np.abs(prob.poses_init[:, :3] - prob.poses_gt[:, :3]).max()
 
 
 def test_sun_aided_solve_reduces_heading_drift():
@@ -210,3 +267,25 @@ def test_per_block_stereo_stiffness():
     e = synth.project(prob.camera, q) - prob.obs_uvd
     r = np.einsum("nij,nj->ni", S, e)
     assert c.cost() == pytest.approx(0.5 * (r * r).sum(), rel=1e-12)
+
+
+def test_relative_pose_residual_and_jacobians_match_complex_step():
+    rng = np.random.default_rng(3)
+    L = orc.lib()
+    L.orc_relative_pose_residual.argtypes = [_dp] * 7
+    L.orc_relative_pose_residual.restype = None
+    p = lambda a: a.ctypes.data_as(_dp)
+    for _ in range(5):
+        T1, T2 = _rand_pose(rng), _rand_pose(rng)
+        # a measurement near the true relative pose T_2_1 = T2 T1^-1, so that the residual is a small tangent vector
+        R1, R2 = T1[3:].reshape(3, 3), T2[3:].reshape(3, 3)
+        T21 = np.concatenate([T2[:3] - R2 @ R1.T @ T1[:3], (R2 @ R1.T).ravel()])
+        T_ref = npr.se3_plus(T21, 0.1 * rng.normal(size=6))
+        A = rng.normal(size=(6, 6))
+        S = np.ascontiguousarray(A @ A.T + 6 * np.eye(6))
+        r, J1, J2 = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+        L.orc_relative_pose_residual(p(T1), p(T2), p(T_ref), p(S), p(r), p(J1), p(J2))
+        np.testing.assert_allclose(r, _rel_res(T1, T2, T_ref, S).real, rtol=1e-12, atol=1e-13)
+        assert np.abs(r).max() < 5.0
+        np.testing.assert_allclose(J1, _cs_jac(lambda X: _rel_res(X, T2.astype(complex), T_ref, S), T1), rtol=1e-7, atol=1e-8)
+        np.testing.assert_allclose(J2, _cs_jac(lambda X: _rel_res(T1.astype(complex), X, T_ref, S), T2), rtol=1e-7, atol=1e-8)
