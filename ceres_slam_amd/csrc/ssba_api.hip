@@ -610,10 +610,7 @@ int ssba_finalize(ssba_problem *p) {
         auto &ks = lm_poses[j];
         for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) ks.push_back(p->obs_pose[lm_obs[e]]);
         std::sort(ks.begin(), ks.end());
-        if (std::adjacent_find(ks.begin(), ks.end()) != ks.end()) {
-            set_error("a landmark is observed twice from the same pose");
-            return SSBA_ERR_UNSUPPORTED;
-        }
+        if (std::adjacent_find(ks.begin(), ks.end()) != ks.end()) dense = true;     // two residual blocks on one (pose, landmark): no window slot for the second
         order.push_back({j, ks.front(), ks.back()});
         int flo = 1 << 30, fhi = -1;
         for (uint32_t k : ks) { const int f = p->pose_free[k]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }

@@ -307,3 +307,23 @@ def test_phong_cpp_driver_on_a_long_track_dataset(tmp_path):
     assert float(report.split("Final cost: ")[1].split(",")[0]) == pytest.approx(s2.final_cost, rel=1e-4)
     poses = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
     assert np.abs(poses - op.poses).max() < 1e-4
+
+
+def test_two_residual_blocks_on_one_pose_landmark_pair():
+    """Ceres takes any number of residual blocks on the same parameter blocks; a repeated (pose, landmark) observation
+    has no slot in the windowed layout and runs on the general one."""
+    prob = synth.make_problem(12, 300, track_len=5, seed=13)
+    import copy
+    q = copy.copy(prob)
+    rng = np.random.default_rng(1)
+    dup = rng.choice(prob.num_obs, 40, replace=False)
+    q.obs_pose = np.concatenate([prob.obs_pose, prob.obs_pose[dup]]).astype(np.uint32)
+    q.obs_point = np.concatenate([prob.obs_point, prob.obs_point[dup]]).astype(np.uint32)
+    q.obs_uvd = np.vstack([prob.obs_uvd, prob.obs_uvd[dup] + rng.normal(size=(40, 3))])
+    ba0 = StereoBA.from_synth(q)
+    S, rhs, dp, dl, mcc = ba0.lm_step(30.0)               # at the initial guess
+    S2, rhs2, _ = orc.OracleProblem.from_synth(q).reduced_system(30.0)
+    assert _rel(S, S2) < 1e-10 and _rel(rhs, rhs2) < 1e-10
+    ba, s, log, op, s2, log2 = _solve_both(q)
+    assert ba.stats().general_structure == 1
+    _assert_same_solve(ba, s, log, op, s2, log2)
