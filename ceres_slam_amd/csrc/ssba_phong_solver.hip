@@ -770,12 +770,16 @@ __global__ __launch_bounds__(256) void k_ph_border_reduce(Dev d) {
 // one block per free pose, every iteration: its six rows of S_pb = H_pb - sum_j Y_j V_j.  The pose's
 // observation references are sorted by material, so a thread accumulates one material's four columns
 // at a time (plus the three light columns throughout) and the block reduces them in a fixed order.
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_poses(Dev d) {
+// One wave per pose: a pass covers one material's ~N_pose/M observations (C3: ~300), so a narrow block wastes few
+// lanes on the ragged last iteration of every pass (256 lanes: 531 us, 128: 440 us, 64: 400 us; splitting a pose over
+// several waves brought nothing: the kernel is bound by the dependent gathers of one observation, not by occupancy)
+constexpr int BP_THREADS = 64;
+template <bool DN> __global__ __launch_bounds__(BP_THREADS) void k_ph_border_poses(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const int k = blockIdx.x, f = d.pose_free[k];
     if (f < 0) return;
-    __shared__ double sm[4][24];
+    __shared__ double sm[BP_THREADS / 64][24];
     const int t = threadIdx.x;
     const double *T = d.poses + (size_t)k * 12;
     double accL[18];
@@ -787,7 +791,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_poses(Dev 
         for (int i = 0; i < 24; ++i) accM[i] = 0.0;
         if (m < d.M) {
             const uint32_t b = d.pose_mat_start[(size_t)k * (d.M + 1) + m], e = d.pose_mat_start[(size_t)k * (d.M + 1) + m + 1];
-            for (uint32_t i = b + t; i < e; i += 256) {
+            for (uint32_t i = b + t; i < e; i += BP_THREADS) {
                 int l;
                 size_t oi;
                 pose_list_entry<DN>(d, i, l, oi);
@@ -838,7 +842,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_poses(Dev 
         }
         __syncthreads();
         if (t < 24) {
-            const double v = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < BP_THREADS / 64; ++w) v += sm[w][t];
             int a, col;
             if (m < d.M) { a = t / 4; col = bcol(d, (uint32_t)m, t - a * 4); }
             else { a = t / 3; col = (t < 18) ? bcol(d, 0u, 4 + (t - a * 3)) : -1; }
@@ -1260,7 +1266,7 @@ void launch_ph_dense_border(Launcher &L, const Dev &d) {
     LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
     LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
-    LAUNCH(KC_BORDER, k_ph_border_poses<true>, dim3(d.P), dim3(256), 0, d);
+    LAUNCH(KC_BORDER, k_ph_border_poses<true>, dim3(d.P), dim3(BP_THREADS), 0, d);
 }
 
 void launch_ph_schur(Launcher &L, const Dev &d) {
@@ -1270,7 +1276,7 @@ void launch_ph_schur(Launcher &L, const Dev &d) {
         LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
-        LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(256), 0, d);
+        LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(BP_THREADS), 0, d);
     }
 }
 void launch_ph_backsub_eval(Launcher &L, const Dev &d) {
