@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
     const double xnp = block_sum(xn, sm);
     (void)cost;
     if (threadIdx.x != 0) return;
+    ++st.check_count;
     if (lin) {
         double *sc = d.part ? d.sepv + d.soff_scal : d.xv + d.off_scal;
         st.x_cost = sc[0];
@@ -585,7 +586,6 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
         st.se_minimum = st.se_current = st.se_reference = st.se_candidate = st.x_cost;
         st.se_acc_ref = st.se_acc_cand = 0.0;
         st.se_num_nonmono = 0;
-        st.copy_best = 0;
         log_push(d, st, st.x_cost, 0.0, 0.0, 0.0, 0);
         st.num_unsuccessful = 1;   // iteration 0 is recorded with step_is_successful = false
     } else if (st.last_successful) {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
         log_push(d, st, st.x_cost, st.cost_change, st.step_norm, st.relative_decrease, 1);
         if (st.x_cost < st.minimum_cost) {
             st.minimum_cost = st.x_cost;
-            st.copy_best = 1;
+            st.copy_best = st.check_count;
         }
     }
     if (!st.opt.ignore_convergence) {
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
 
 __global__ __launch_bounds__(256) void k_best(Dev d) {
     const State &st = *d.st;
-    if (!st.copy_best) return;
+    if (st.copy_best != st.check_count) return;       // set by the k_check just before; a later k_check moves the count on
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (size_t)d.P * 12) d.best_poses[i] = d.poses[i];
     if (i < (size_t)d.Lpad * 3) {
@@ -624,9 +624,6 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
         if (d.phong) d.best_nrm[i] = d.nrm[i];
     }
     if (d.phong && i < (size_t)d.nsh) d.best_sh[i] = d.sh[i];
-}
-__global__ void k_best_done(Dev d) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) d.st->copy_best = 0;
 }
 
 // candidate poses = Plus(x, delta_p)  [Evaluator::Plus with SE3Perturbation]
@@ -1342,7 +1339,7 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.opt = opt;
     st.iteration = 0; st.terminated = 0; st.termination_type = 1;
     st.need_linearize = 1; st.just_linearized = 0; st.last_successful = 0; st.accepted = 0;
-    st.copy_best = 0; st.step_failed = 0;
+    st.copy_best = 0; st.check_count = 0; st.step_failed = 0;
     st.num_successful = 0; st.num_unsuccessful = 0; st.num_invalid = 0; st.log_count = 0;
     st.radius = opt.initial_radius; st.decrease_factor = 2.0;
     st.x_cost = 0.0; st.x_norm = 0.0; st.gmax = 0.0; st.minimum_cost = 0.0;
@@ -1513,7 +1510,6 @@ void launch_finish_check(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
-    hipLaunchKernelGGL(k_best_done, dim3(1), dim3(64), 0, L.stream, d);
 }
 
 void launch_update_eval(Launcher &L, const Dev &d) {
@@ -1532,7 +1528,6 @@ void launch_sep_finish_check(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
-    hipLaunchKernelGGL(k_best_done, dim3(1), dim3(64), 0, L.stream, d);
 }
 void launch_sep_scatter(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_sep_scatter, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);

@@ -54,7 +54,8 @@ struct State {
     int just_linearized;      // set by the linearisation kernels, cleared by k_check
     int last_successful;      // previous iteration accepted its step
     int accepted;             // decision of the current iteration (for k_commit)
-    int copy_best;            // x improved on the best cost -> k_best copies
+    int copy_best;            // value of check_count at which x improved on the best cost: k_best copies while they are equal
+    int check_count;          // number of (non-terminated) k_check runs
     int step_failed;          // Cholesky breakdown / non-finite step this iteration
     int num_successful, num_unsuccessful, num_invalid;
     int log_count;
