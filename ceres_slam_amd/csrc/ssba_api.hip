@@ -1077,15 +1077,23 @@ int ssba_finalize(ssba_problem *p) {
     d.pcr.level = -1;
     {
         const char *e = getenv("SSBA_NO_PCR");
-        if (!part && !d.nb && p->world_size == 1 && !dense && !(e && e[0] == '1')) {
+        // with free shared blocks the border columns follow through the kept factors of every step (ssba_border.hip);
+        // that variant covers plans that are parallel from level 0 on
+        if (!part && (!d.nb || d.lev[0].n <= PCR_MAX_BLOCKS) && p->world_size == 1 && !dense && !(e && e[0] == '1')) {
             int k = 0;
             while (d.lev[k].n > PCR_MAX_BLOCKS) ++k;
             const int n = d.lev[k].n;
             d.pcr.level = k; d.pcr.n = n; d.pcr.steps = 0;
             for (int s2 = 1; s2 < n; s2 <<= 1) ++d.pcr.steps;
+            d.pcr.keep = d.nb ? 1 : 0;
+            const size_t slots = d.pcr.keep ? (size_t)std::max(d.pcr.steps, 1) * n : (size_t)n;
             TRY(dzero(p, &d.pcr.Lbuf, (size_t)n * blk)); TRY(dzero(p, &d.pcr.LbufT, (size_t)n * blk));
-            TRY(dzero(p, &d.pcr.YL, (size_t)n * blk)); TRY(dzero(p, &d.pcr.YU, (size_t)n * blk));
+            TRY(dzero(p, &d.pcr.YL, slots * blk)); TRY(dzero(p, &d.pcr.YU, slots * blk));
             TRY(dzero(p, &d.pcr.yr, (size_t)n * BD));
+            if (d.pcr.keep) {
+                TRY(dzero(p, &d.pcr.Gs, slots * blk));
+                TRY(dzero(p, &d.pcr.Bb, (size_t)n * BD * NBP)); TRY(dzero(p, &d.pcr.yB, (size_t)n * BD * NBP));
+            }
         }
     }
     if (part) {

@@ -119,9 +119,10 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             Lg = d.pcr.Lbuf + (size_t)blk * BD * BD;
             Ug = d.pcr.LbufT + (size_t)(hasU ? blk + s : blk) * BD * BD;
         }
-        oD = top ? B.D + (size_t)blk * BD * BD : nullptr;
-        oYL = hasL ? d.pcr.YL + (size_t)blk * BD * BD : nullptr;
-        oYU = hasU ? d.pcr.YU + (size_t)blk * BD * BD : nullptr;
+        const size_t so = d.pcr.keep ? (size_t)lev * B.n + blk : (size_t)blk;      // per-step slots when the border follows
+        oD = top ? B.D + (size_t)blk * BD * BD : (d.pcr.keep ? d.pcr.Gs + so * BD * BD : nullptr);
+        oYL = hasL ? d.pcr.YL + so * BD * BD : nullptr;
+        oYU = hasU ? d.pcr.YU + so * BD * BD : nullptr;
         orr = top ? B.r + (size_t)blk * BD : d.pcr.yr + (size_t)blk * BD;
     } else {
         const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
         const BcrLevel &B = d.lev[d.pcr.level];
         const int e = blockIdx.x, s = 1 << lev, prev = e - s, next = e + s;
         const bool hasPrev = prev >= 0, hasNext = next < B.n;
+        const size_t so = d.pcr.keep ? (size_t)lev * B.n : 0;
         const bool act = t < KSPLIT * 144;
         const int g = t / 144, tt = t - g * 144;
         const int tr = tt / 12, tc = tt - tr * 12;
@@ -393,8 +395,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
         if (blockIdx.y == 0) {
             if (!hasPrev && !hasNext) return;
             out = B.D + (size_t)e * BD * BD;
-            if (hasPrev) stage_block(sA, d.pcr.YU + (size_t)prev * BD * BD, RED_THREADS);
-            if (hasNext) stage_block(sB, d.pcr.YL + (size_t)next * BD * BD, RED_THREADS);
+            if (hasPrev) stage_block(sA, d.pcr.YU + (so + prev) * BD * BD, RED_THREADS);
+            if (hasNext) stage_block(sB, d.pcr.YL + (so + next) * BD * BD, RED_THREADS);
             if (t < BD) {
                 sya[t] = hasPrev ? d.pcr.yr[(size_t)prev * BD + t] : 0.0;
                 syb[t] = hasNext ? d.pcr.yr[(size_t)next * BD + t] : 0.0;
@@ -416,8 +418,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
             if (prev - s < 0) return;      // no block at e - 2s
             out = d.pcr.Lbuf + (size_t)e * BD * BD;
             outT = d.pcr.LbufT + (size_t)e * BD * BD;
-            stage_block(sA, d.pcr.YU + (size_t)prev * BD * BD, RED_THREADS);
-            stage_block(sB, d.pcr.YL + (size_t)prev * BD * BD, RED_THREADS);
+            stage_block(sA, d.pcr.YU + (so + prev) * BD * BD, RED_THREADS);
+            stage_block(sB, d.pcr.YL + (so + prev) * BD * BD, RED_THREADS);
             __syncthreads();
             if (act) tile_mac(acc, sA, sB, g, tr, tc);
             __syncthreads();

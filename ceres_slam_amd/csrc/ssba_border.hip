@@ -38,19 +38,23 @@ static __device__ __forceinline__ void stage_flat(double *dst, const double *__r
 }
 
 // odd blocks: yb = G^-1 B in place (forward substitution, column sweep; lanes = rows, a wave = 2 columns)
-__global__ __launch_bounds__(MR_THREADS) void k_bcrm_fwd(Dev d, int lev, int top) {
+// which = 2: parallel plan (ssba_bcr.hip), step `lev` of it (top: the last, decoupled one): every block, its factor of
+// that step, columns read from Bb and written to yB (the block's own columns stay for k_bcrm_upd)
+__global__ __launch_bounds__(MR_THREADS) void k_bcrm_fwd(Dev d, int lev, int top, int which) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *Gt = lds;   // Gt[k][i] = G[i][k]
-    const BcrLevel &L = d.lev[lev];
-    const int blk = top ? 0 : 2 * blockIdx.x + 1;
-    stage_pad(Gt, L.D + (size_t)blk * BD * BD, true);
-    double *B = L.B + (size_t)blk * BD * NBP;
+    const BcrLevel &L = d.lev[which == 2 ? d.pcr.level : lev];
+    const int blk = which == 2 ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
+    const double *Gsrc = which == 2 && !top ? d.pcr.Gs + ((size_t)lev * L.n + blk) * BD * BD : L.D + (size_t)blk * BD * BD;
+    stage_pad(Gt, Gsrc, true);
+    const double *Bin = which == 2 ? d.pcr.Bb + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
+    double *B = which == 2 ? d.pcr.yB + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
     const bool hiRow = lane < BD - 64;
-    double lo0 = B[lane * NBP + c0], lo1 = B[lane * NBP + c1];
-    double hi0 = hiRow ? B[(64 + lane) * NBP + c0] : 0.0, hi1 = hiRow ? B[(64 + lane) * NBP + c1] : 0.0;
+    double lo0 = Bin[lane * NBP + c0], lo1 = Bin[lane * NBP + c1];
+    double hi0 = hiRow ? Bin[(64 + lane) * NBP + c0] : 0.0, hi1 = hiRow ? Bin[(64 + lane) * NBP + c1] : 0.0;
     __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < 64; ++k) {
@@ -78,11 +82,48 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_fwd(Dev d, int lev, int top
 }
 
 // even blocks: B'(m) = B(e) - YU(e-1)^T yb(e-1) - YL(e+1)^T yb(e+1), e = 2m
-__global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev) {
+__global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev, int which) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *sA = lds, *sB = lds + BD * BD, *ya = lds + 2 * BD * BD, *yb = ya + BD * NBP;
+    if (which == 2) {
+        // parallel plan, stride s = 2^lev: B(e) -= YU(e-s)^T yB(e-s) + YL(e+s)^T yB(e+s), in place (own block only)
+        const BcrLevel &P = d.lev[d.pcr.level];
+        const int e = blockIdx.x, s = 1 << lev, prev = e - s, next = e + s;
+        const bool hasPrev = prev >= 0, hasNext = next < P.n;
+        if (!hasPrev && !hasNext) return;
+        const size_t so = (size_t)lev * P.n;
+        if (hasPrev) {
+            stage_flat(sA, d.pcr.YU + (so + prev) * BD * BD, BD * BD);
+            stage_flat(ya, d.pcr.yB + (size_t)prev * BD * NBP, BD * NBP);
+        }
+        if (hasNext) {
+            stage_flat(sB, d.pcr.YL + (so + next) * BD * BD, BD * BD);
+            stage_flat(yb, d.pcr.yB + (size_t)next * BD * NBP, BD * NBP);
+        }
+        __syncthreads();
+        const int t = threadIdx.x, r = t % BD, cg = (t / BD) * 4;
+        double *Be = d.pcr.Bb + ((size_t)e * BD + r) * NBP + cg;
+        double acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = Be[c];
+        if (hasPrev)
+            for (int k = 0; k < BD; ++k) {
+                const double a = sA[k * BD + r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] -= a * ya[k * NBP + cg + c];
+            }
+        if (hasNext)
+            for (int k = 0; k < BD; ++k) {
+                const double a = sB[k * BD + r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] -= a * yb[k * NBP + cg + c];
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Be[c] = acc[c];
+        return;
+    }
     const BcrLevel &L = d.lev[lev];
     const BcrLevel &N = d.lev[lev + 1];
     const int m = blockIdx.x, e = 2 * m;
@@ -117,13 +158,14 @@ __global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev) {
 }
 
 // odd blocks, top-down: X_i = G^-T (yb_i - YL_i X_{i-1} - YU_i X_{i+1}); X lives in d.Zb at level-0 positions
-__global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top) {
+// which = 2 (with top): the decoupled blocks of the parallel plan, X = G^-T yB for every block
+__global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top, int which) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
     double *sL = lds, *sU = lds + BD * LDT, *xm = lds + 2 * BD * LDT, *xp = xm + BD * NBP;
-    const BcrLevel &L = d.lev[lev];
-    const int blk = top ? 0 : 2 * blockIdx.x + 1;
+    const BcrLevel &L = d.lev[which == 2 ? d.pcr.level : lev];
+    const int blk = which == 2 ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
     const bool hasU = !top && (blk + 1 < L.n);
     if (!top) {
         stage_pad(sL, L.L + (size_t)blk * BD * BD, false);
@@ -133,7 +175,7 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
         stage_pad(sU, L.YU + (size_t)blockIdx.x * BD * BD, false);
         stage_flat(xp, d.Zb + (((size_t)(blk + 1) << lev) * BD) * NBP, BD * NBP);
     }
-    const double *B = L.B + (size_t)blk * BD * NBP;
+    const double *B = which == 2 ? d.pcr.yB + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
     const bool hiRow = lane < BD - 64;
     double lo0 = B[lane * NBP + c0], lo1 = B[lane * NBP + c1];
@@ -175,7 +217,7 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
         lo0 = (lane == k) ? x0 : lo0 - gl * x0;
         lo1 = (lane == k) ? x1 : lo1 - gl * x1;
     }
-    double *X = d.Zb + (((size_t)blk << lev) * BD) * NBP;
+    double *X = d.Zb + ((which == 2 ? (size_t)L.pos[blk] : ((size_t)blk << lev)) * BD) * NBP;
     X[lane * NBP + c0] = lo0;
     X[lane * NBP + c1] = lo1;
     if (hiRow) { X[(64 + lane) * NBP + c0] = hi0; X[(64 + lane) * NBP + c1] = hi1; }
@@ -296,28 +338,41 @@ void launch_bcr_multi_rhs(Launcher &L, const Dev &d) {
     hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
     for (int l = 0; l + 1 < nl; ++l) {
         const int n = d.lev[l].n;
-        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0);
-        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l);
+        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0, 0);
+        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l, 0);
     }
-    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1);
-    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1);
+    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1, 0);
+    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0);
     for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0);
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0);
 }
 
 // after launch_bcr: x0 = S_pp^-1 (-g_p^) and the level factors are in place
 void launch_border_solve(Launcher &L, const Dev &d) {
+    if (d.pcr.level >= 0 && d.pcr.keep) {
+        // the solve ran the parallel plan: the border columns follow through the kept factors of every step
+        const int n = d.pcr.n;
+        hipMemcpyAsync(d.pcr.Bb, d.Spb, (size_t)n * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
+        for (int q = 0; q < d.pcr.steps; ++q) {
+            LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, q, 0, 2);
+            LAUNCH(KC_BORDER, k_bcrm_upd, dim3(n), dim3(UPD_THREADS), SH_UPD, d, q, 2);
+        }
+        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, d.pcr.steps, 1, 2);
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(n), dim3(MR_THREADS), SH_BWD, d, 0, 1, 2);
+        launch_border_finish(L, d);
+        return;
+    }
     const int nl = d.n_levels;
     hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
     for (int l = 0; l + 1 < nl; ++l) {
         const int n = d.lev[l].n;
-        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0);
-        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l);
+        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0, 0);
+        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l, 0);
     }
-    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1);
-    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1);
+    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1, 0);
+    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0);
     for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0);
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0);
     launch_border_finish(L, d);
 }
 

@@ -98,6 +98,10 @@ struct BcrLevel {
 struct PcrPlan {
     int level, n, steps;            // level < 0: not used
     double *Lbuf, *LbufT, *YL, *YU, *yr;   // n blocks each (yr: n x BD); LbufT = the couplings transposed (the "U" operands)
+    // free shared blocks: the border columns follow through the same steps afterwards, so every step keeps its
+    // products (YL, YU hold steps x n blocks) and its factor Gs; Bb / yB are the columns and G^-1 of them (n x BD x NBP)
+    int keep;
+    double *Gs, *Bb, *yB;
 };
 constexpr int PCR_MAX_BLOCKS = 128;
 

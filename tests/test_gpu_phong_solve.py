@@ -339,3 +339,17 @@ def test_phong_driver_multistage(tmp_path):
     assert np.abs(poses - s3.poses).max() < 1e-4
     lights = np.loadtxt(str(tmp_path / "sim_lights.csv"), delimiter=",", skiprows=1)
     np.testing.assert_allclose(lights, s3.light, rtol=1e-4, atol=1e-5)
+
+
+def test_free_shared_blocks_beyond_the_parallel_plan():
+    """More than 128 super-blocks with free shared blocks: the border columns go through plain cyclic reduction
+    (the parallel plan with kept factors covers <= 128 blocks)."""
+    prob, ph = synth.make_phong_problem(1600, 8000, track_len=10, seed=4)
+    ba, op = _pair(prob, ph, 7)
+    assert ba.stats().pcr_blocks == 0
+    S, rhs, dp, dl, mcc = ba.lm_step(1e3)
+    dp2, dl2, mcc2 = op.lm_step(1e3)
+    assert _rel(dp, dp2) < 1e-6 and _rel(dl, dl2) < 1e-6
+    assert mcc == pytest.approx(mcc2, rel=1e-7)
+    small, ph2 = synth.make_phong_problem(60, 1500, track_len=10, seed=4)
+    assert _pair(small, ph2, 7)[0].stats().pcr_blocks == 5
