@@ -4,20 +4,21 @@
 // Ceres, executed by the MI355X back end.
 //
 // usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A] [--window N]
-//        dataset_vo_gpu <dataset.csv> --frontend [--huber A]
+//        dataset_vo_gpu <dataset.csv> --frontend [--huber A] [--window N]
 //   dataset.csv   reference format (src/ceres_slam/dataset_problem.cpp:16-83): row 1
 //                 "num_states,num_points", row 2 intrinsics "fu,fv,cu,cv,b", row 3 variances,
 //                 row 4 first pose (4x4 row-major), then "k,j,u,v,d" rows
 //   init_*.csv    initial guess in the format the reference's write_csv emits
 //                 (dataset_problem.cpp:144-159): header + 4x4 row-major poses; "id,x,y,z" points
-// --frontend computes the initial guess itself, as the reference's main does (tests/dataset_vo.cpp:124,
+// --frontend computes the initial guess itself window by window, as the reference's main does (tests/dataset_vo.cpp:121-127,
 // DatasetProblem::compute_initial_guess, src/ceres_slam/dataset_problem.cpp:179-270): reciprocal matches of
 // consecutive states, triangulation, the 400-iteration 3-point RANSAC of ALL state pairs in one GPU batch
 // (ssba_frontend_ransac; the draw sequence of std::mt19937(42) + std::uniform_int_distribution is
 // restated by ssba_ransac_samples), pose chaining and map initialisation from the inliers.  --window N runs the reference's sliding
-// window loop (tests/dataset_vo.cpp:121-127): states [k1, k1+N) per solve, first state of the window
-// constant, poses carried over, points reset between windows (reset_points) to the supplied guess
-// (the reference re-triangulates them in compute_initial_guess(k1, k2)).
+// window loop (tests/dataset_vo.cpp:121-127): states [k1, k1+N) per solve, first state of the window constant, poses
+// carried over; with --frontend every window recomputes its initial guess from the state the previous window left
+// (compute_initial_guess(k1, k2), then reset_points(); the map file holds the points of the last window), with
+// initial-guess files the points are reset to the supplied guess between windows.
 // Output: <dataset>_poses.csv / <dataset>_map.csv at full precision + the brief report.
 #include <cmath>
 #include <fstream>
@@ -41,7 +42,7 @@ int main(int argc, char **argv) {
     const bool use_frontend = argc >= 3 && std::string(argv[2]) == "--frontend";
     if (argc < 4 && !use_frontend) {
         std::cerr << "usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A] [--window N]\n"
-                     "       dataset_vo_gpu <dataset.csv> --frontend [--huber A]" << std::endl;
+                     "       dataset_vo_gpu <dataset.csv> --frontend [--huber A] [--window N]" << std::endl;
         return EXIT_FAILURE;
     }
     double huber = 0.0;
@@ -70,32 +71,30 @@ int main(int argc, char **argv) {
     // poses: 12 doubles [t | R row-major] per state (geometry/se3group.hpp:425-429)
     std::vector<double> poses(num_states * 12, 0.0), points(num_points * 3, 0.0);
     std::vector<bool> initialized(num_points, false);
-    if (use_frontend) {
-        // ---- DatasetProblem::compute_initial_guess(0, num_states) ----------------------------------
-        if (first_pose.size() < 16) { std::cerr << "malformed first pose" << std::endl; return EXIT_FAILURE; }
-        poses[0] = first_pose[3]; poses[1] = first_pose[7]; poses[2] = first_pose[11];
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) poses[3 + 3 * i + j] = first_pose[4 * i + j];
-        std::vector<std::vector<unsigned>> idx_of(num_states);
-        for (size_t i = 0; i < state_ids.size(); ++i)
-            if (state_ids[i] < num_states) idx_of[state_ids[i]].push_back((unsigned)i);
-        auto triangulate = [&](unsigned i, double *p) {                      // stereo_camera.hpp:112-120
-            const double b_over_d = intr[4] / obs[3 * i + 2];
-            p[0] = (obs[3 * i] - intr[2]) * b_over_d;
-            p[1] = (obs[3 * i + 1] - intr[3]) * b_over_d * (intr[0] / intr[1]);
-            p[2] = intr[0] * b_over_d;
-        };
-        std::vector<uint32_t> offset(1, 0), samples, pair_state;
+    // ---- DatasetProblem::compute_initial_guess(k1, k2) (src/ceres_slam/dataset_problem.cpp:179-270) ----------
+    std::vector<std::vector<unsigned>> idx_of(num_states);
+    for (size_t i = 0; i < state_ids.size(); ++i)
+        if (state_ids[i] < num_states) idx_of[state_ids[i]].push_back((unsigned)i);
+    auto triangulate = [&](unsigned i, double *p) {                      // stereo_camera.hpp:112-120
+        const double b_over_d = intr[4] / obs[3 * i + 2];
+        p[0] = (obs[3 * i] - intr[2]) * b_over_d;
+        p[1] = (obs[3 * i + 1] - intr[3]) * b_over_d * (intr[0] / intr[1]);
+        p[2] = intr[0] * b_over_d;
+    };
+    auto compute_initial_guess = [&](size_t k1, size_t k2) -> bool {
+        if (k2 <= k1 + 1) return true;
+        std::vector<uint32_t> offset(1, 0), samples;
         std::vector<double> pts0, pts1;
         std::vector<unsigned> match_km1;                                     // observation index in state k-1 of every match
         const uint32_t num_iters = 400;
-        for (size_t k = 1; k < num_states; ++k) {                            // :189-243
+        for (size_t k = k1 + 1; k < k2; ++k) {                               // :189-243
             std::vector<unsigned> a, b;
             std::map<unsigned, unsigned> in_k;
             for (unsigned i : idx_of[k]) in_k[point_ids[i]] = i;
             std::map<unsigned, int> kept;
             for (unsigned i : idx_of[k - 1]) if (in_k.count(point_ids[i])) { a.push_back(i); kept[point_ids[i]] = 1; }
             for (unsigned i : idx_of[k]) if (kept.count(point_ids[i])) b.push_back(i);
-            if (a.size() < 3 || a.size() != b.size()) { std::cerr << "state " << k << ": fewer than 3 matches" << std::endl; return EXIT_FAILURE; }
+            if (a.size() < 3 || a.size() != b.size()) { std::cerr << "state " << k << ": fewer than 3 matches" << std::endl; return false; }
             for (size_t m = 0; m < a.size(); ++m) {
                 double p[3];
                 triangulate(a[m], p); pts0.insert(pts0.end(), p, p + 3);
@@ -104,24 +103,25 @@ int main(int argc, char **argv) {
             }
             offset.push_back((uint32_t)(pts0.size() / 3));
             std::vector<uint32_t> smp(3 * num_iters);
-            if (ssba_ransac_samples((uint32_t)a.size(), num_iters, __GNUC__ >= 11 ? 1 : 0, smp.data())) return EXIT_FAILURE;
+            if (ssba_ransac_samples((uint32_t)a.size(), num_iters, __GNUC__ >= 11 ? 1 : 0, smp.data())) return false;
             samples.insert(samples.end(), smp.begin(), smp.end());
         }
-        const uint32_t num_pairs = (uint32_t)num_states - 1;
+        const uint32_t num_pairs = (uint32_t)(k2 - k1 - 1);
         std::vector<double> T((size_t)num_pairs * 12);
         std::vector<uint8_t> inlier(pts0.size() / 3);
         ssba_camera cam = {intr[0], intr[1], intr[2], intr[3], intr[4]};
         int rc = ssba_frontend_ransac(&cam, -1, num_pairs, offset.data(), pts0.data(), pts1.data(), samples.data(), num_iters, 4.0,
                                       T.data(), inlier.data(), nullptr, nullptr);                     // :246-249
-        if (rc) { std::cerr << "ssba_frontend_ransac: " << ssba_status_string(rc) << std::endl; return EXIT_FAILURE; }
-        for (size_t k = 1; k < num_states; ++k) {
-            const double *Tk = &T[12 * (k - 1)], *Tp = &poses[12 * (k - 1)];
+        if (rc) { std::cerr << "ssba_frontend_ransac: " << ssba_status_string(rc) << std::endl; return false; }
+        for (size_t k = k1 + 1; k < k2; ++k) {
+            const size_t q = k - k1 - 1;
+            const double *Tk = &T[12 * q], *Tp = &poses[12 * (k - 1)];
             double *Tn = &poses[12 * k];
             for (int i = 0; i < 3; ++i) {                                    // poses[k] = T_k_km1 * poses[k-1]  (:256)
                 Tn[i] = Tk[3 + 3 * i] * Tp[0] + Tk[4 + 3 * i] * Tp[1] + Tk[5 + 3 * i] * Tp[2] + Tk[i];
                 for (int j = 0; j < 3; ++j) Tn[3 + 3 * i + j] = Tk[3 + 3 * i] * Tp[3 + j] + Tk[4 + 3 * i] * Tp[6 + j] + Tk[5 + 3 * i] * Tp[9 + j];
             }
-            for (uint32_t m = offset[k - 1]; m < offset[k]; ++m) {           // :260-269
+            for (uint32_t m = offset[q]; m < offset[q + 1]; ++m) {           // :260-269
                 const unsigned j = point_ids[match_km1[m]];
                 if (!inlier[m] || j >= num_points || initialized[j]) continue;
                 const double d[3] = {pts0[3 * m] - Tp[0], pts0[3 * m + 1] - Tp[1], pts0[3 * m + 2] - Tp[2]};
@@ -129,6 +129,12 @@ int main(int argc, char **argv) {
                 initialized[j] = true;
             }
         }
+        return true;
+    };
+    if (use_frontend) {
+        if (first_pose.size() < 16) { std::cerr << "malformed first pose" << std::endl; return EXIT_FAILURE; }
+        poses[0] = first_pose[3]; poses[1] = first_pose[7]; poses[2] = first_pose[11];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) poses[3 + 3 * i + j] = first_pose[4 * i + j];
     } else {
         std::ifstream pf(argv[2]);
         if (!pf.is_open()) { std::cerr << "Error: couldn't open " << argv[2] << std::endl; return EXIT_FAILURE; }
@@ -156,7 +162,11 @@ int main(int argc, char **argv) {
     ceres::Solver::Summary summary;
     for (size_t k1 = 0; k1 + window_size <= num_states; ++k1) {                     // :121-127
     const size_t k2 = k1 + window_size;
-    if (k1 > 0) points = points_init;                                               // reset_points()
+    if (use_frontend) {                                                             // main loop of tests/dataset_vo.cpp:121-127
+        if (!compute_initial_guess(k1, k2)) return EXIT_FAILURE;                    //   compute_initial_guess(k1, k2)
+    } else if (k1 > 0) {
+        points = points_init;                                                       // reset_points() to the supplied guess
+    }
     // ---- solveWindow (tests/dataset_vo.cpp:22-85) ------------------------------------------
     ceres::Problem problem;
     const double stiffness[9] = {1.0 / std::sqrt(var[0]), 0, 0, 0, 1.0 / std::sqrt(var[1]), 0, 0, 0, 1.0 / std::sqrt(var[2])};
@@ -184,6 +194,7 @@ int main(int argc, char **argv) {
     std::cout << summary.BriefReport() << std::endl << std::endl;
     if (!summary.message.empty()) std::cerr << summary.message << std::endl;
     if (!summary.IsSolutionUsable()) break;
+    if (use_frontend && k1 + window_size < num_states) initialized.assign(num_points, false);      // reset_points() (:126)
     }   // windows
 
     // ---- write_csv (dataset_problem.cpp:121-165), full precision ----------------------------

@@ -155,3 +155,33 @@ def test_degenerate_inputs_are_rejected():
                                   np.array([0, 1, 5], dtype=np.uint32).ctypes.data_as(_u32p), 1, 4.0, capi.dptr(T), None, None, None)
     assert rc == -1            # sample index outside the pair
     assert lib.ssba_ransac_samples(2, 10, 1, smp.ctypes.data_as(_u32p)) == -1      # three distinct indices need n >= 3
+
+
+def test_cpp_driver_sliding_windows_with_its_own_front_end(tmp_path):
+    """examples/dataset_vo_gpu --frontend --window N = main() of tests/dataset_vo.cpp:116-127: per window the initial
+    guess from the state the previous window left, the solve with the window's first state constant, reset_points."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples()
+    prob = _problem(14, 700, track_len=6, seed=5)
+    W = 5
+    ds, _, _ = synth.write_reference_csv(prob, str(tmp_path / "sim.csv"))
+    r = subprocess.run([exe, ds, "--frontend", "--window", str(W)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    variant = 1 if int(subprocess.run(["g++", "-dumpversion"], capture_output=True, text=True).stdout.split(".")[0]) >= 11 else 0
+    P = prob.num_poses
+    poses = np.tile(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1.0]), (P, 1))
+    poses[0] = prob.poses_gt[0]
+    for k1 in range(0, P - W + 1):
+        sel = (prob.obs_pose >= k1) & (prob.obs_pose < k1 + W)
+        st, pt, uvd = prob.obs_pose[sel] - k1, prob.obs_point[sel], prob.obs_uvd[sel]
+        pw, xw, init, _ = frontend.compute_initial_guess(prob.camera, W, prob.num_points, st, pt, uvd, poses[k1], variant=variant,
+                                                         ransac=_oracle_ransac)
+        use = init[pt]
+        op = orc.OracleProblem(prob.camera, pw, xw, st[use], pt[use], uvd[use], prob.stiffness())      # first state of the window constant
+        op.solve(orc.driver_options(num_threads=2))
+        poses[k1:k1 + W] = op.poses
+    reports = [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")]
+    assert len(reports) == P - W + 1 and all("CONVERGENCE" in l for l in reports)
+    out = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(out - poses).max() < 1e-5
