@@ -185,3 +185,46 @@ def test_cpp_driver_sliding_windows_with_its_own_front_end(tmp_path):
     assert len(reports) == P - W + 1 and all("CONVERGENCE" in l for l in reports)
     out = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
     assert np.abs(out - poses).max() < 1e-5
+
+
+@pytest.mark.parametrize("window", [0, 12])
+def test_phong_cpp_driver_with_its_own_front_end(tmp_path, window):
+    """examples/dataset_ba_phong_gpu --frontend [--window N] = main() of tests/dataset_ba_phong.cpp:296-327: the Phong
+    initial guess (incl. the reference's material indexing), then solveWindow over the sliding windows."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples("dataset_ba_phong_gpu")
+    prob, ph = synth.make_phong_problem(20, 1200, track_len=8, seed=7, obs_var=(0.04, 0.04, 0.04))
+    files = synth.write_reference_phong_csv(prob, ph, str(tmp_path / "sim.csv"), shared="reference")
+    r = subprocess.run([exe, files[0], "--frontend"] + (["--window", str(window)] if window else []), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    variant = 1 if int(subprocess.run(["g++", "-dumpversion"], capture_output=True, text=True).stdout.split(".")[0]) >= 11 else 0
+    mat_obs = ph.material_of_point[prob.obs_point]
+    poses, positions, normals, init, mat_v, phong, texture, _ = frontend.compute_initial_guess_phong(
+        prob.camera, prob.num_poses, prob.num_points, len(ph.texture), prob.obs_pose, prob.obs_point, mat_obs, prob.obs_uvd, ph.intensity,
+        ph.normal_obs, prob.poses_gt[0], variant=variant, ransac=_oracle_ransac)
+    light = np.asarray(ph.as_oracle_dict("reference")["light"], dtype=float).copy()
+    P, W = prob.num_poses, window or prob.num_poses
+    kw = dict(num_threads=4, trust_region_strategy_type=1, dogleg_type=1)
+    finals = []
+    for k1 in range(0, P - W + 1):
+        sel = (prob.obs_pose >= k1) & (prob.obs_pose < k1 + W) & init[prob.obs_point]
+        pts = np.unique(prob.obs_point[sel])
+        remap = np.full(prob.num_points, -1)
+        remap[pts] = np.arange(len(pts))
+        d = dict(normals=normals[pts], intensity=ph.intensity[sel], normal_obs=ph.normal_obs[sel], phong=phong, texture=texture,
+                 material_of_point=mat_v[pts], light=light, light_type=ph.light_type, int_stiffness=ph.int_stiffness,
+                 normal_stiffness=ph.normal_stiffness())
+        op = orc.OracleProblem(prob.camera, poses[k1:k1 + W], positions[pts], prob.obs_pose[sel] - k1, remap[prob.obs_point[sel]].astype(np.uint32),
+                               prob.obs_uvd[sel], prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+        s2, _ = op.solve(orc.driver_options(**kw))
+        finals.append(s2.final_cost)
+        poses[k1:k1 + W], positions[pts], normals[pts] = op.poses, op.points, op.normals
+        phong, texture, light = op.phong.copy(), op.texture.copy(), op.light.copy()
+    reports = [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")]
+    assert len(reports) == len(finals)
+    got = [float(l.split("Final cost: ")[1].split(",")[0]) for l in reports]
+    np.testing.assert_allclose(got, finals, rtol=2e-4)
+    out = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    assert np.abs(out - poses).max() < 1e-4
+    assert np.abs(out[:, :3] - prob.poses_gt[:, :3]).max() < 0.1
