@@ -1182,9 +1182,6 @@ __global__ __launch_bounds__(256) void k_reduce_lin(Dev d) {
         st.just_linearized = 1;
     }
 }
-// keeps the (already reduced) scalars of the last linearisation in the exchange vector
-// on iterations that do not re-linearise, so that a sum over ranks stays correct
-__global__ void k_hold_scalars(Dev d, int nranks_dummy) { (void)d; (void)nranks_dummy; }
 
 __global__ __launch_bounds__(256) void k_reduce_eval(Dev d) {
     const State &st = *d.st;
