@@ -7,6 +7,9 @@
 //                           L' = -YU(e-1)^T YL(e-1) ;  r' = r_e - YU(e-1)^T yr(e-1) - YL(e+1)^T yr(e+1)
 //   k_bcr_backsub (odd i):  x_i = G^-T (yr - YL x_{i-1} - YU x_{i+1})      (top-down)
 // and recurses on the even blocks; the last level (one block) is a plain Cholesky solve.
+// From the first level with <= PCR_MAX_BLOCKS blocks on, the same kernels run PARALLEL cyclic reduction (which = 2,
+// PcrPlan): at stride 2^k every block is factored and folds in both neighbours at +-2^k, so after log2(n) steps the
+// blocks are decoupled and one factor + solve over all of them finishes -- no back-substitution sweep over those levels.
 // G (with 1/G_kk on its diagonal), YL and yr overwrite D_i, L_i and r_i in place.
 // Coupling blocks with an EVEN index are only ever consumed transposed (as L_{i+1}^T of the
 // odd block before them), so they are stored transposed at every level: the factor kernel

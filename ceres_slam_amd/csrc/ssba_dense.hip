@@ -1,16 +1,20 @@
-// General-structure path of the stereo-BA solve for gfx950: problems whose landmark tracks are longer than
-// the TW slots of the window layout, or whose pose co-visibility is not banded (loop closures), cannot use the
-// block-tridiagonal reduced system of ssba_kernels.hip / ssba_bcr.hip.  They keep every other kernel
+// General-structure path of the solve for gfx950: problems whose landmark tracks are longer than the TW slots of the
+// window layout, whose pose co-visibility is not banded (loop closures), or that carry what has no place in that
+// layout (a second residual block on one (pose, landmark) pair, per-block stiffness, relative-pose blocks) cannot use
+// the block-tridiagonal reduced system of ssba_kernels.hip / ssba_bcr.hip.  They keep every other kernel
 // (linearisation, back-substitution, trust-region control: templates on the observation layout) and swap the
 // middle of the iteration for
-//   k_dn_wy      per observation: W = J_p^T J_l and Y = W C^-1 (C = H_ll + damping), stored once (HBM stream)
-//   k_dn_schur   one wave per 6x6 block (a <= b) of S = H_pp - sum_l Y_a W_b^T, summing that block's observation
-//                pairs in a fixed order (no float atomics); writes the lower triangle of the dense matrix
+//   k_dn_wy      per observation: W = J_p^T J_l and Y = W C^-1 (C = H_ll + damping), stored once (HBM stream);
+//                with lighting terms k_ph_dn_wy (ssba_phong_solver.hip) stores the 6x6 versions
+//   k_dn_schur   one work-group per 6x6 block (a <= b) of S = H_pp - sum_l Y_a W_b^T: the block's observation pairs
+//                (host-built list) spread over the lanes, fixed-order reduction (no float atomics), plus the J_a^T J_b
+//                of relative-pose blocks; writes the lower triangle of the dense matrix
 //   k_dn_rhs     one wave per free pose: reduced gradient g_p - sum Y g_l, stored as an extra row of the matrix
 //   k_dn_finish  Jacobi scale at iteration 0, LM damping on the diagonal
-//   k_dn_potrf / k_dn_trsm / k_dn_syrk   right-looking blocked Cholesky (DN_BS = 64), fp64 FMA bound; the extra
-//                row makes the forward solve part of the factorisation
-//   k_dn_bwd     block back-substitution with L^T -> pose step x0
+//   k_dn_potrf / k_dn_trsm / k_dn_syrk   right-looking blocked Cholesky (DN_BS = 64); the extra rows (the right-hand
+//                side, the columns of S_pb for free shared blocks, unit vectors for a covariance block) are
+//                forward-solved as part of the factorisation
+//   k_dn_bwd     right-looking block back-substitution with L^T, one sweep per extra row -> pose step x0, S_pp^-1 S_pb
 // The factorisation skips zero 64x64 blocks: ssba_finalize runs a symbolic Cholesky at block granularity, so a
 // banded problem costs O(n b^2) and a loop closure only fills the block rows between its two ends.
 // What Ceres does here (SPARSE_SCHUR / DENSE_SCHUR on the reduced camera matrix, schur_complement_solver.cc)
