@@ -33,7 +33,7 @@ SYMBOLS = [
     "ssba_set_exchange", "ssba_set_distributed", "ssba_exchange_size", "ssba_set_kernel_timing", "ssba_kernel_times",
     "ssba_get_stats", "ssba_evaluate", "ssba_lm_step", "ssba_phong_evaluate", "ssba_status_string", "ssba_last_error",
     "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
-    "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant",
+    "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant", "ssba_release_cached_memory",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation", "ssba_add_relative_pose",
     "ssba_pose_covariance",
 ]

@@ -280,6 +280,11 @@ int ssba_destroy(ssba_problem *p) {
     return SSBA_OK;
 }
 
+int ssba_release_cached_memory(void) {
+    pool_trim();
+    return SSBA_OK;
+}
+
 int ssba_add_pose_blocks(ssba_problem *p, double *poses, uint32_t num) {
     if (!p || (!poses && num)) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->finalized) return SSBA_ERR_STATE;

@@ -15,5 +15,6 @@ hipError_t pool_host_malloc(void **out, size_t bytes);   // pinned host memory (
 void pool_host_free(void *ptr);
 hipError_t pool_stream_acquire(hipStream_t *out);    // non-blocking stream of the current device
 void pool_stream_release(hipStream_t s);             // the caller has synchronised it
+void pool_trim();                                    // hipFree / hipHostFree everything that is cached
 
 }  // namespace ssba

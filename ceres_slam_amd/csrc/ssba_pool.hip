@@ -163,4 +163,18 @@ void pool_stream_release(hipStream_t s) {
     else (void)hipStreamDestroy(s);
 }
 
+void pool_trim() {
+    Pool &P = pool();
+    std::vector<void *> dev, host;
+    {
+        std::lock_guard<std::mutex> lock(P.mu);
+        for (auto &kv : P.cached) { dev.insert(dev.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+        for (auto &kv : P.host_cached) { host.insert(host.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+        P.cached_bytes = 0;
+        P.host_cached_bytes = 0;
+    }
+    for (void *p : dev) (void)hipFree(p);
+    for (void *p : host) (void)hipHostFree(p);
+}
+
 }  // namespace ssba

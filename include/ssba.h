@@ -215,6 +215,11 @@ typedef struct {
 } ssba_stats;
 int ssba_get_stats(ssba_problem *p, ssba_stats *st);
 
+/* Destroyed handles leave their device buffers, pinned host buffers and streams in a process-wide cache for the next
+ * handle (drivers that solve thousands of small windows are bound by hipMalloc / hipFree otherwise); SSBA_POOL_MB caps
+ * the cached device bytes (default 2048, 0 = no caching).  This call frees what is cached now. */
+int ssba_release_cached_memory(void);
+
 /* ---- test hooks (parity tests call these through the C ABI) ------------------------ */
 /* Normal-equation blocks at the caller's current parameters, in user index order:
  * cost, g_p (P*6), g_l (L*3), H_pp (P*36 row-major), H_ll (L*9).  Blocks of constant
