@@ -18,6 +18,10 @@ A parameter block is a numpy row view (12 doubles ``[t | R row-major]`` for a
 pose, 3 for a point); block identity is the address of its first element, exactly
 as Ceres keys blocks by ``double*``.  Blocks are updated in place by ``Solve``.
 
+and the sun-aided driver's surface (tests/dataset_vo_sun.cpp:28-185): per-block stereo stiffness,
+``PoseErrorAutomatic`` / ``SunSensorErrorAutomatic`` on one pose block, ``RelativePoseErrorAutomatic`` on two
+(tests/blowup_test.cpp), ``Covariance.Compute`` / ``GetCovarianceBlockInTangentSpace`` for diagonal pose blocks.
+
 The C++ twin of this file is include/ceres_slam_amd/ceres_shim.hpp.
 """
 from __future__ import annotations
@@ -61,6 +65,44 @@ class StereoReprojectionErrorAutomatic(CostFunction):
     @staticmethod
     def Create(camera, observation, stiffness) -> "StereoReprojectionErrorAutomatic":
         return StereoReprojectionErrorAutomatic(camera, observation, stiffness)
+
+
+class PoseErrorAutomatic(CostFunction):
+    """include/ceres_slam/pose_error.hpp:11-74: prior r = S log(T_ref T^-1) on one pose block (6 residuals)."""
+
+    def __init__(self, T_k_0_ref, stiffness):
+        self.T_ref = np.asarray(T_k_0_ref, dtype=np.float64).reshape(12).copy()
+        self.stiffness = np.asarray(stiffness, dtype=np.float64).reshape(6, 6).copy()
+
+    @staticmethod
+    def Create(T_k_0_ref, stiffness) -> "PoseErrorAutomatic":
+        return PoseErrorAutomatic(T_k_0_ref, stiffness)
+
+
+class SunSensorErrorAutomatic(CostFunction):
+    """include/ceres_slam/sun_sensor_error.hpp:12-131: azimuth / zenith error of the expected sun direction (2 residuals)."""
+
+    def __init__(self, observed_sun_dir_c, expected_sun_dir_g, stiffness, az_err_thresh, zen_err_thresh):
+        self.observed = np.asarray(observed_sun_dir_c, dtype=np.float64).reshape(3).copy()
+        self.expected = np.asarray(expected_sun_dir_g, dtype=np.float64).reshape(3).copy()
+        self.stiffness = np.asarray(stiffness, dtype=np.float64).reshape(2, 2).copy()
+        self.az_err_thresh, self.zen_err_thresh = float(az_err_thresh), float(zen_err_thresh)
+
+    @staticmethod
+    def Create(observed_sun_dir_c, expected_sun_dir_g, stiffness, az_err_thresh, zen_err_thresh) -> "SunSensorErrorAutomatic":
+        return SunSensorErrorAutomatic(observed_sun_dir_c, expected_sun_dir_g, stiffness, az_err_thresh, zen_err_thresh)
+
+
+class RelativePoseErrorAutomatic(CostFunction):
+    """include/ceres_slam/relative_pose_error.hpp:11-67: r = S log(T_2_1_ref T_1 T_2^-1) on two pose blocks."""
+
+    def __init__(self, T_2_1_ref, stiffness):
+        self.T_ref = np.asarray(T_2_1_ref, dtype=np.float64).reshape(12).copy()
+        self.stiffness = np.asarray(stiffness, dtype=np.float64).reshape(6, 6).copy()
+
+    @staticmethod
+    def Create(T_2_1_ref, stiffness) -> "RelativePoseErrorAutomatic":
+        return RelativePoseErrorAutomatic(T_2_1_ref, stiffness)
 
 
 class LocalParameterization:
@@ -139,6 +181,8 @@ class Problem:
         self._loss = "unset"
         self._parameterized = set()
         self._constant = set()
+        self._obs_stiffness = []    # per residual block (tests/dataset_vo_sun.cpp:56-65 gives every map point its own)
+        self._pose_factors = []     # dicts as for solver.StereoBA(pose_factors=...): prior / sun / relative pose
 
     # -- graph building -----------------------------------------------------
     def _block(self, table, block, size):
@@ -156,8 +200,8 @@ class Problem:
                             "StereoReprojectionErrorAutomatic residual blocks")
         if self._camera is None:
             self._camera, self._stiffness = cost.camera, cost.stiffness
-        elif cost.camera != self._camera or not np.array_equal(cost.stiffness, self._stiffness):
-            raise ValueError("all residual blocks must share one camera and one stiffness matrix")
+        elif cost.camera != self._camera:
+            raise ValueError("all residual blocks must share one camera")
         if loss is not None and not isinstance(loss, HuberLoss):
             raise TypeError("loss must be None or HuberLoss")
         key = None if loss is None else loss.a
@@ -166,11 +210,29 @@ class Problem:
         elif self._loss != key:
             raise ValueError("all residual blocks must share the same loss function")
 
-    def AddResidualBlock(self, cost, loss, pose_block, point_block):
+    def AddResidualBlock(self, cost, loss, pose_block, point_block=None):
+        if loss is not None and not isinstance(loss, HuberLoss):
+            raise TypeError("loss must be None or HuberLoss")
+        huber = 0.0 if loss is None else loss.a
+        if isinstance(cost, (PoseErrorAutomatic, SunSensorErrorAutomatic)):       # one pose block (dataset_vo_sun.cpp:80-119)
+            if point_block is not None:
+                raise TypeError(f"{type(cost).__name__} takes one parameter block")
+            k = self._block(self._pose_blocks, pose_block, 12)
+            if isinstance(cost, PoseErrorAutomatic):
+                self._pose_factors.append(dict(pose=k, type=0, data=cost.T_ref, stiffness=cost.stiffness.ravel(), huber=huber))
+            else:
+                data = np.concatenate([cost.observed, cost.expected, [cost.az_err_thresh, cost.zen_err_thresh]])
+                self._pose_factors.append(dict(pose=k, type=1, data=data, stiffness=cost.stiffness.ravel(), huber=huber))
+            return
+        if isinstance(cost, RelativePoseErrorAutomatic):                           # two pose blocks (blowup_test.cpp:70-76)
+            k1, k2 = self._block(self._pose_blocks, pose_block, 12), self._block(self._pose_blocks, point_block, 12)
+            self._pose_factors.append(dict(pose=k1, pose2=k2, type=2, data=cost.T_ref, stiffness=cost.stiffness.ravel(), huber=huber))
+            return
         self._register(cost, loss)
         self._obs_pose.append(self._block(self._pose_blocks, pose_block, 12))
         self._obs_point.append(self._block(self._point_blocks, point_block, 3))
         self._obs_uvd.append(cost.observation)
+        self._obs_stiffness.append(cost.stiffness)
 
     def AddStereoResidualBlocks(self, camera, stiffness, loss, poses, points, pose_index, point_index, uvd):
         """Vectorised form of the driver's double loop (tests/dataset_vo.cpp:39-56): one
@@ -206,15 +268,14 @@ class Problem:
         return len(self._pose_blocks) + len(self._point_blocks)
 
 
-def Solve(options: SolverOptions, problem: Problem, summary: SolverSummary, device: int = -1):
-    """ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81)."""
-    lib = capi.load()
+def _lower(problem: Problem, device: int = -1):
+    """Gathers the caller's blocks into contiguous tables and builds the back-end handle (solver.StereoBA)."""
+    from .solver import StereoBA
     P, L = len(problem._pose_blocks), len(problem._point_blocks)
     missing = [a for a in problem._pose_blocks if a not in problem._parameterized]
     if missing:
         raise ValueError("every pose block needs SetParameterization(block, SE3Perturbation): the 12-double "
                          "block is over-parameterised")
-    # gather caller blocks into the contiguous tables the C ABI takes; scattered back below
     poses = np.empty((P, 12))
     for a, (i, view) in problem._pose_blocks.items():
         poses[i] = view.reshape(12)
@@ -223,47 +284,76 @@ def Solve(options: SolverOptions, problem: Problem, summary: SolverSummary, devi
         points[j] = view.reshape(3)
     op = np.concatenate([np.asarray(problem._obs_pose, dtype=np.uint32)] + [b[0] for b in problem._bulk]).astype(np.uint32)
     ol = np.concatenate([np.asarray(problem._obs_point, dtype=np.uint32)] + [b[1] for b in problem._bulk]).astype(np.uint32)
-    uv = np.concatenate([np.asarray(problem._obs_uvd, dtype=np.float64).reshape(-1, 3)] + [b[2] for b in problem._bulk])
-    uv = np.ascontiguousarray(uv)
-    cam = problem._camera.as_c() if problem._camera else capi.Camera(1, 1, 0, 0, 1)
-    S = np.ascontiguousarray(problem._stiffness if problem._stiffness is not None else np.eye(3)).reshape(9)
+    uv = np.ascontiguousarray(np.concatenate([np.asarray(problem._obs_uvd, dtype=np.float64).reshape(-1, 3)] + [b[2] for b in problem._bulk]))
+    shared = problem._stiffness if problem._stiffness is not None else np.eye(3)
+    per_block = [np.asarray(x) for x in problem._obs_stiffness] + [shared] * sum(b[0].shape[0] for b in problem._bulk)
+    stiffness = shared if all(np.array_equal(x, shared) for x in per_block) else np.array(per_block)
+    cam = problem._camera or StereoCamera(1.0, 1.0, 0.0, 0.0, 1.0)
+    const = np.zeros(P, dtype=np.uint8)
+    for a in problem._constant:
+        const[problem._pose_blocks[a][0]] = 1
+    ba = StereoBA(dict(fu=cam.fu, fv=cam.fv, cu=cam.cu, cv=cam.cv, b=cam.b), poses, points, op, ol, uv, stiffness, pose_const=const,
+                  huber_a=0.0 if problem._loss in ("unset", None) else problem._loss, device=device,
+                  pose_factors=problem._pose_factors or None)
+    return ba
 
-    h = C.c_void_p()
-    capi.check(lib.ssba_create(C.byref(cam), device, C.byref(h)), "ssba_create")
-    try:
-        capi.check(lib.ssba_add_pose_blocks(h, capi.dptr(poses), P), "ssba_add_pose_blocks")
-        capi.check(lib.ssba_add_point_blocks(h, capi.dptr(points), L), "ssba_add_point_blocks")
-        capi.check(lib.ssba_add_stereo_observations(
-            h, op.ctypes.data_as(capi._u32p), ol.ctypes.data_as(capi._u32p), capi.dptr(uv), op.shape[0],
-            capi.dptr(S)), "ssba_add_stereo_observations")
-        for a in problem._constant:
-            capi.check(lib.ssba_set_pose_constant(h, problem._pose_blocks[a][0], 1), "ssba_set_pose_constant")
-        if problem._loss not in ("unset", None):
-            capi.check(lib.ssba_set_huber_loss(h, problem._loss), "ssba_set_huber_loss")
-        capi.check(lib.ssba_finalize(h), "ssba_finalize")
-        s = capi.Summary()
-        o = options.as_c()
-        rc = lib.ssba_solve(h, C.byref(o), C.byref(s))
-        if rc not in (capi.SSBA_OK, -3):
-            capi.check(rc, "ssba_solve")
-        n = lib.ssba_iteration_log(h, 0, None, None, None, None, None, None, None)
-        cols = [np.zeros(n) for _ in range(6)]
-        ok = np.zeros(n, dtype=np.int32)
-        lib.ssba_iteration_log(h, n, *[capi.dptr(c) for c in cols], ok.ctypes.data_as(capi._i32p))
-    finally:
-        lib.ssba_destroy(h)
+
+def _scatter(problem: Problem, ba):
+    for a, (i, view) in problem._pose_blocks.items():
+        view.reshape(12)[:] = ba.poses[i]
+    for a, (j, view) in problem._point_blocks.items():
+        view.reshape(3)[:] = ba.points[j]
+
+
+def Solve(options: SolverOptions, problem: Problem, summary: SolverSummary, device: int = -1):
+    """ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81)."""
+    ba = _lower(problem, device)
+    s, log = ba.solve(options.as_c())
     summary.termination_type = s.termination_type
     summary.num_successful_steps = s.num_successful_steps
     summary.num_unsuccessful_steps = s.num_unsuccessful_steps
     summary.initial_cost, summary.final_cost = s.initial_cost, s.final_cost
     summary.total_time_in_seconds, summary.device_time_in_seconds = s.total_time_s, s.device_time_s
     names = ("cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease", "trust_region_radius")
-    summary.iterations = [dict({k: float(c[i]) for k, c in zip(names, cols)}, iteration=i,
-                               step_is_successful=bool(ok[i])) for i in range(n)]
-    # parameters are user-owned and updated in place, only when the solution is usable
-    if summary.IsSolutionUsable():
-        for a, (i, view) in problem._pose_blocks.items():
-            view.reshape(12)[:] = poses[i]
-        for a, (j, view) in problem._point_blocks.items():
-            view.reshape(3)[:] = points[j]
+    n = len(log["cost"])
+    summary.iterations = [dict({k: float(log[k][i]) for k in names}, iteration=i, step_is_successful=bool(log["step_is_successful"][i]))
+                          for i in range(n)]
+    if summary.IsSolutionUsable():      # parameters are user-owned and updated in place, only when the solution is usable
+        _scatter(problem, ba)
+    ba.close()
     return summary
+
+
+class Covariance:
+    """ceres::Covariance for diagonal pose blocks (tests/dataset_vo_sun.cpp:159-183): Compute evaluates the requested
+    blocks of (J^T J)^-1 in the tangent space at the problem's current values; False on a rank-deficient system."""
+
+    class Options:
+        num_threads = 1
+
+    def __init__(self, options=None):
+        self._blocks = {}
+        self.message = ""
+
+    def Compute(self, covariance_blocks, problem: Problem, device: int = -1) -> bool:
+        self._blocks = {}
+        ba = _lower(problem, device)
+        try:
+            for a, b in covariance_blocks:
+                if _addr(a) != _addr(b) or _addr(a) not in problem._pose_blocks:
+                    self.message = "only diagonal pose blocks are supported"
+                    return False
+                self._blocks[_addr(a)] = ba.pose_covariance(problem._pose_blocks[_addr(a)][0])
+        except capi.SsbaError as e:
+            self.message = str(e)
+            self._blocks = {}
+            return False
+        finally:
+            ba.close()
+        return True
+
+    def GetCovarianceBlockInTangentSpace(self, a, b, out) -> bool:
+        if _addr(a) != _addr(b) or _addr(a) not in self._blocks:
+            return False
+        np.asarray(out).reshape(6, 6)[:] = self._blocks[_addr(a)]
+        return True

@@ -179,3 +179,48 @@ def test_blowup_driver_through_the_ceres_shim():
         np.testing.assert_allclose(rows[k, 1:4], T[:3], atol=1e-6)
     assert np.all(np.diff(rows[:, 4]) > 0)      # uncertainty accumulates
     assert rows[1, 4] == pytest.approx(6 * 0.1 ** 2 + 6e-12, rel=1e-3)      # first window: measurement noise on top of the prior
+
+
+def test_sun_window_through_the_python_api_mirror():
+    """Reads like solveWindow of tests/dataset_vo_sun.cpp:28-185: per-point stereo stiffness, sun blocks with HuberLoss,
+    the pose prior, SUBSPACE_DOGLEG, then ceres::Covariance of the second state."""
+    from ceres_slam_amd import ceres_api as ceres
+    from test_gpu_general_structure import _per_point_stiffness
+    prob, factors = _sun_problem(P=6, L=400, seed=4, huber=0.5)
+    S_obs = _per_point_stiffness(prob, seed=2)
+    poses, points = prob.poses_init.copy(), prob.points_init.copy()
+    camera = ceres.StereoCamera(**prob.camera)
+    problem = ceres.Problem()
+    se3_perturbation = ceres.SE3Perturbation.Create()
+    for i in range(prob.num_obs):
+        k, j = int(prob.obs_pose[i]), int(prob.obs_point[i])
+        problem.AddResidualBlock(ceres.StereoReprojectionErrorAutomatic.Create(camera, prob.obs_uvd[i], S_obs[i]), None, poses[k], points[j])
+    for f in factors:
+        if f["type"] == 1:
+            d = np.asarray(f["data"])
+            cost = ceres.SunSensorErrorAutomatic.Create(d[:3], d[3:6], np.asarray(f["stiffness"]).reshape(2, 2), d[6], d[7])
+            problem.AddResidualBlock(cost, ceres.HuberLoss(0.5), poses[f["pose"]])
+        else:
+            problem.AddResidualBlock(ceres.PoseErrorAutomatic.Create(f["data"], np.asarray(f["stiffness"]).reshape(6, 6)), None, poses[f["pose"]])
+    for k in range(prob.num_poses):
+        problem.SetParameterization(poses[k], se3_perturbation)
+    options = ceres.SolverOptions()
+    options.max_num_iterations, options.use_nonmonotonic_steps = 1000, 1
+    options.trust_region_strategy_type, options.dogleg_type = 1, 1
+    summary = ceres.SolverSummary()
+    ceres.Solve(options, problem, summary)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, S_obs,
+                           pose_const=np.zeros(prob.num_poses, np.uint8), pose_factors=factors)
+    s2, _ = op.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1, dogleg_type=1))
+    assert summary.termination_type == ceres.CONVERGENCE
+    assert summary.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+    assert np.abs(poses - op.poses).max() < 1e-5
+    covariance = ceres.Covariance()
+    assert covariance.Compute([(poses[1], poses[1])], problem)
+    cov = np.zeros((6, 6))
+    assert covariance.GetCovarianceBlockInTangentSpace(poses[1], poses[1], cov)
+    Sred, _, free_idx = op.reduced_system(1e300)
+    f = int(free_idx[1])
+    ref = np.linalg.inv(Sred)[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]
+    assert np.abs(cov - ref).max() / np.abs(ref).max() < 2e-2 and np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
+    assert not covariance.GetCovarianceBlockInTangentSpace(poses[2], poses[2], cov)
