@@ -284,3 +284,37 @@ def test_c2_full_size_solve_matches_cpu_oracle():
     ba2 = StereoBA.from_synth(prob)
     s3, log3 = ba2.solve(capi.default_options(**DRIVER))
     assert np.array_equal(log3["cost"], log["cost"]) and np.array_equal(ba2.poses, ba.poses)
+
+
+def test_c2_full_size_invariances():
+    """Size-independent properties of the path at BASELINE config 2 size, no oracle involved: (i) translating the world
+    frame (T <- T G^-1, p <- G p, G a pure translation: a rotation would change diag(H_ll), i.e. the LM damping and
+    with it the iterates) leaves every residual and Jacobian, hence the whole cost log, unchanged up to rounding and
+    maps the solution with it; (ii) scaling the stiffness by 2 scales every cost by 4 and leaves the iterates alone
+    up to the (1 + |column|) of the Jacobi scaling."""
+    prob = synth.make_config("C2")
+    S = prob.stiffness()
+    opts = dict(DRIVER)
+    ba = StereoBA.from_synth(prob)
+    s, log = ba.solve(capi.default_options(**opts))
+    # (i) gauge transform G = (Rg, tg)
+    Rg = np.eye(3)
+    tg = np.array([30.0, -10.0, 20.0])
+    def moved(poses):
+        R = poses[:, 3:].reshape(-1, 3, 3)
+        Rn = R @ Rg.T
+        return np.concatenate([poses[:, :3] - Rn @ tg, Rn.reshape(-1, 9)], axis=1)
+    ba_g = StereoBA(prob.camera, moved(prob.poses_init), prob.points_init @ Rg.T + tg, prob.obs_pose, prob.obs_point, prob.obs_uvd, S)
+    s_g, log_g = ba_g.solve(capi.default_options(**opts))
+    assert s_g.num_iterations == s.num_iterations
+    assert log_g["step_is_successful"].tolist() == log["step_is_successful"].tolist()
+    np.testing.assert_allclose(log_g["cost"], log["cost"], rtol=1e-6)
+    assert np.abs(ba_g.poses - moved(ba.poses)).max() < 1e-5
+    assert np.abs(ba_g.points - (ba.points @ Rg.T + tg)).max() < 1e-4
+    # (ii) stiffness scaling
+    ba_s = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, 2.0 * S)
+    s_s, log_s = ba_s.solve(capi.default_options(**opts))
+    assert s_s.num_iterations == s.num_iterations
+    np.testing.assert_allclose(log_s["cost"][0], 4.0 * log["cost"][0], rtol=1e-13)        # the cost itself is homogeneous
+    np.testing.assert_allclose(log_s["cost"], 4.0 * log["cost"], rtol=1e-4)              # the path up to the 1 + |column| of the scaling
+    assert np.abs(ba_s.poses - ba.poses).max() < 1e-4
