@@ -353,3 +353,20 @@ def test_free_shared_blocks_beyond_the_parallel_plan():
     assert mcc == pytest.approx(mcc2, rel=1e-7)
     small, ph2 = synth.make_phong_problem(60, 1500, track_len=10, seed=4)
     assert _pair(small, ph2, 7)[0].stats().pcr_blocks == 5
+
+
+def test_c1_phong_driver_configuration_matches_golden():
+    """BASELINE.json configs[0] with the driver's settings against the committed golden solve."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c1_phong_driver.json")))
+    prob, ph = synth.make_phong_problem(50, 2000)
+    ba = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict("reference"), shared_free=7, use_bounds=True)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1))
+    assert s.initial_cost == pytest.approx(gold["initial_cost"], rel=1e-12)
+    n = min(len(log["cost"]), len(gold["cost"]), 12)
+    assert log["step_is_successful"][:n].tolist() == gold["step_is_successful"][:n]
+    ok = np.asarray(gold["step_is_successful"][:n], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][:n][ok], np.asarray(gold["cost"])[:n][ok], rtol=1e-6)
+    assert s.final_cost == pytest.approx(gold["final_cost"], rel=1e-4)
+    np.testing.assert_allclose(ba.poses[[1, 25, 49]], gold["poses_1_25_49"], atol=1e-4)

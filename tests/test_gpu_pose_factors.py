@@ -224,3 +224,17 @@ def test_sun_window_through_the_python_api_mirror():
     ref = np.linalg.inv(Sred)[6 * f: 6 * f + 6, 6 * f: 6 * f + 6]
     assert np.abs(cov - ref).max() / np.abs(ref).max() < 2e-2 and np.all(np.linalg.eigvalsh(0.5 * (cov + cov.T)) > 0)
     assert not covariance.GetCovarianceBlockInTangentSpace(poses[2], poses[2], cov)
+
+
+def test_sun_window_matches_golden():
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sun_window.json")))
+    prob, factors = _sun_problem(P=8, L=400, seed=4, huber=0.5)
+    ba, _ = _pair(prob, factors)
+    s, log = ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1))
+    assert s.num_iterations == gold["num_iterations"] and log["step_is_successful"].tolist() == gold["step_is_successful"]
+    np.testing.assert_allclose(log["cost"], gold["cost"], rtol=1e-7)
+    np.testing.assert_allclose(ba.poses, gold["poses"], atol=1e-5)
+    cov = ba.pose_covariance(1)
+    ref = np.asarray(gold["covariance_pose1"])
+    assert np.abs(cov - ref).max() / np.abs(ref).max() < 2e-2

@@ -1,6 +1,9 @@
 """Config 3 (stereo + Phong intensity + normal residual blocks with 6-D landmark blocks): the oracle's
 normal equations / LM step against an independent numpy restatement with complex-step Jacobians
 through the reference's Plus operators, and whole-solve sanity.  CPU only."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -50,3 +53,20 @@ def test_stereo_only_problem_is_unchanged_by_the_generalisation(c1_problem):
     op = orc.OracleProblem.from_synth(c1_problem)
     s, log = op.solve(orc.driver_options(num_threads=1))
     np.testing.assert_allclose(log["cost"], gold["cost"], rtol=1e-9)   # summation order changed, values did not
+
+
+def test_c1_phong_driver_configuration_matches_golden():
+    """BASELINE.json configs[0] with the driver's settings against tests/golden/c1_phong_driver.json (oracle output)."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "c1_phong_driver.json")))
+    prob, ph = synth.make_phong_problem(50, 2000)
+    d = ph.as_oracle_dict("reference")
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    assert op.cost() == pytest.approx(gold["initial_cost"], rel=1e-12)
+    s, log = op.solve(orc.driver_options(num_threads=4, trust_region_strategy_type=1, dogleg_type=1))
+    assert s.num_iterations == gold["num_iterations"] and log["step_is_successful"].tolist() == gold["step_is_successful"]
+    # the fixture was written single-threaded; 4 threads reorder the sums and the path amplifies that to ~1e-8
+    np.testing.assert_allclose(log["cost"], gold["cost"], rtol=1e-6)
+    assert s.final_cost == pytest.approx(gold["final_cost"], rel=1e-7)
+    np.testing.assert_allclose(op.poses[[1, 25, 49]], gold["poses_1_25_49"], atol=1e-5)
+    np.testing.assert_allclose(op.light, gold["light"], rtol=1e-6)

@@ -289,3 +289,17 @@ def test_relative_pose_residual_and_jacobians_match_complex_step():
         assert np.abs(r).max() < 5.0
         np.testing.assert_allclose(J1, _cs_jac(lambda X: _rel_res(X, T2.astype(complex), T_ref, S), T1), rtol=1e-7, atol=1e-8)
         np.testing.assert_allclose(J2, _cs_jac(lambda X: _rel_res(T1.astype(complex), X, T_ref, S), T2), rtol=1e-7, atol=1e-8)
+
+
+def test_sun_window_matches_golden():
+    """tests/golden/sun_window.json (oracle output, made by tests/golden/make_golden.py): a regression pin."""
+    import json, os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sun_window.json")))
+    prob, factors = _sun_problem(P=8, L=400, seed=4, huber=0.5)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_const=np.zeros(prob.num_poses, np.uint8), pose_factors=factors)
+    assert op.cost() == pytest.approx(gold["initial_cost"], rel=1e-12)
+    s, log = op.solve(orc.driver_options(num_threads=2, trust_region_strategy_type=1, dogleg_type=1))
+    assert s.num_iterations == gold["num_iterations"] and log["step_is_successful"].tolist() == gold["step_is_successful"]
+    np.testing.assert_allclose(log["cost"], gold["cost"], rtol=1e-9)
+    np.testing.assert_allclose(op.poses, gold["poses"], atol=1e-8)
