@@ -1027,19 +1027,23 @@ int ssba_finalize(ssba_problem *p) {
     }
     TRY(dzero(p, &d.vp, (size_t)P * 6)); TRY(dzero(p, &d.vl, (size_t)Lpad * (ph ? 6 : 3))); TRY(dzero(p, &d.dl_gn, (size_t)Lpad * (ph ? 6 : 3)));
     // BCR level plan.  Plain: all super-blocks, odd blocks eliminated level by level down to one block.
-    // Partitioned (ssba_set_partition): this rank's chain [sep[rank], sep[rank+1]] with both ends pinned, down to the
-    // two ends, plus a plain plan for the separator system (one block per chain end).
+    // Partitioned (ssba_set_partition): this rank's chain [sep[rank], sep[rank+1]]; an end shared with a neighbouring
+    // rank is pinned.  Plain levels until <= PCR_MAX_BLOCKS blocks are left, parallel cyclic reduction with pinned ends
+    // from there; the world_size - 1 shared blocks form the separator system (parallel cyclic reduction as well).
     auto upload_pos = [&](const std::vector<int> &pos, const int **out) -> int { return dupload(p, out, pos); };
-    const bool part = !p->sep_sb.empty();
+    int pcr_max = PCR_MAX_BLOCKS;               // SSBA_PCR_MAX_BLOCKS lowers it (tests: plain levels below a parallel top on small problems)
+    if (const char *e = getenv("SSBA_PCR_MAX_BLOCKS")) pcr_max = std::min(PCR_MAX_BLOCKS, std::max(2, atoi(e)));
+    const bool part = p->sep_sb.size() > 2;     // one rank: nothing is shared, the plain plan applies
     if (part) {
         if (ph) { set_error("lighting terms are not available with landmark sharding yet"); return SSBA_ERR_UNSUPPORTED; }
         if ((int)p->sep_sb.back() != d.Nsb - 1 || p->sep_sb.front() != 0) {
             set_error("ssba_set_partition: the separators must start at super-block 0 and end at the last one");
             return SSBA_ERR_INVALID_ARGUMENT;
         }
-        d.part = 1; d.rank = p->rank; d.n_sep = (int)p->sep_sb.size();
-        for (int i = 0; i < d.n_sep; ++i) d.sep_sb[i] = (int)p->sep_sb[i];
-        d.chain0 = d.sep_sb[p->rank]; d.chain1 = d.sep_sb[p->rank + 1];
+        d.part = 1; d.rank = p->rank; d.world = p->world_size; d.n_sep = p->world_size - 1;
+        for (int i = 0; i < d.n_sep; ++i) d.sep_sb[i] = (int)p->sep_sb[i + 1];
+        d.chain0 = (int)p->sep_sb[p->rank]; d.chain1 = (int)p->sep_sb[p->rank + 1];
+        d.pin0 = p->rank > 0; d.pin1 = p->rank + 1 < p->world_size;
         // every observation of this rank must fall into its chain (the sharding has to be aligned to super-blocks)
         for (uint64_t i = 0; i < N; ++i) {
             const int f = p->pose_free[p->obs_pose[i]];
@@ -1062,8 +1066,8 @@ int ssba_finalize(ssba_problem *p) {
             if (d.nb) TRY(dzero(p, &d.lev[lev].B, (size_t)n * BD * NBP));
             TRY(dzero(p, &d.lev[lev].YU, (size_t)std::max(1, n / 2) * blk));
             TRY(upload_pos(pos, &d.lev[lev].pos));
-            if (part ? n <= 2 : n == 1) break;
-            d.lev[lev].pin = (part && (n % 2 == 0)) ? 1 : 0;
+            if (part ? n <= pcr_max : n == 1) break;
+            d.lev[lev].pin = (part && d.pin1 && (n % 2 == 0)) ? 1 : 0;
             const int n2 = d.lev[lev].pin ? n / 2 + 1 : (n + 1) / 2;
             std::vector<int> pos2(n2);
             for (int m = 0; m < n2; ++m) pos2[m] = (d.lev[lev].pin && m == n2 - 1) ? pos[n - 1] : pos[2 * m];
@@ -1078,27 +1082,33 @@ int ssba_finalize(ssba_problem *p) {
         }
         d.n_levels = lev + 1;
     }
-    // parallel cyclic reduction of the top of the plan: single-GPU solves without multi-right-hand-side sweeps
+    // parallel cyclic reduction of the top of the plan: single-GPU solves without multi-right-hand-side sweeps, and the
+    // chain of a partitioned solve
     d.pcr.level = -1;
+    auto make_pcr = [&](PcrPlan &P, int level, int n, int keep, int pin0, int pin1) -> int {
+        P.level = level; P.n = n; P.steps = 0; P.keep = keep; P.pin0 = pin0; P.pin1 = pin1;
+        for (int s2 = 1; s2 < n; s2 <<= 1) ++P.steps;
+        const size_t slots = keep ? (size_t)std::max(P.steps, 1) * n : (size_t)n;
+        TRY(dzero(p, &P.Lbuf, (size_t)n * blk)); TRY(dzero(p, &P.LbufT, (size_t)n * blk));
+        TRY(dzero(p, &P.YL, slots * blk)); TRY(dzero(p, &P.YU, slots * blk));
+        TRY(dzero(p, &P.yr, (size_t)n * BD));
+        if (pin1) TRY(dzero(p, &P.Ubuf, (size_t)n * blk));
+        if (keep) {
+            TRY(dzero(p, &P.Gs, slots * blk));
+            TRY(dzero(p, &P.Bb, (size_t)n * BD * NBP)); TRY(dzero(p, &P.yB, (size_t)n * BD * NBP));
+        }
+        return SSBA_OK;
+    };
     {
         const char *e = getenv("SSBA_NO_PCR");
         // with free shared blocks the border columns follow through the kept factors of every step (ssba_border.hip);
         // that variant covers plans that are parallel from level 0 on
-        if (!part && (!d.nb || d.lev[0].n <= PCR_MAX_BLOCKS) && p->world_size == 1 && !dense && !(e && e[0] == '1')) {
+        if (part) {
+            TRY(make_pcr(d.pcr, d.n_levels - 1, d.lev[d.n_levels - 1].n, 0, d.pin0, d.pin1));
+        } else if ((!d.nb || d.lev[0].n <= pcr_max) && p->world_size == 1 && !dense && !(e && e[0] == '1')) {
             int k = 0;
-            while (d.lev[k].n > PCR_MAX_BLOCKS) ++k;
-            const int n = d.lev[k].n;
-            d.pcr.level = k; d.pcr.n = n; d.pcr.steps = 0;
-            for (int s2 = 1; s2 < n; s2 <<= 1) ++d.pcr.steps;
-            d.pcr.keep = d.nb ? 1 : 0;
-            const size_t slots = d.pcr.keep ? (size_t)std::max(d.pcr.steps, 1) * n : (size_t)n;
-            TRY(dzero(p, &d.pcr.Lbuf, (size_t)n * blk)); TRY(dzero(p, &d.pcr.LbufT, (size_t)n * blk));
-            TRY(dzero(p, &d.pcr.YL, slots * blk)); TRY(dzero(p, &d.pcr.YU, slots * blk));
-            TRY(dzero(p, &d.pcr.yr, (size_t)n * BD));
-            if (d.pcr.keep) {
-                TRY(dzero(p, &d.pcr.Gs, slots * blk));
-                TRY(dzero(p, &d.pcr.Bb, (size_t)n * BD * NBP)); TRY(dzero(p, &d.pcr.yB, (size_t)n * BD * NBP));
-            }
+            while (d.lev[k].n > pcr_max) ++k;
+            TRY(make_pcr(d.pcr, k, d.lev[k].n, d.nb ? 1 : 0, 0, 0));
         }
     }
     if (part) {
@@ -1109,30 +1119,17 @@ int ssba_finalize(ssba_problem *p) {
         d.soff_gp = d.soff_rhs + ns * BD;
         d.soff_hdiag = d.soff_gp + ns * BD;
         d.soff_scal = d.soff_hdiag + ns * BD;
-        d.sepv_count = d.soff_scal + NSCAL + ns;     // + one gradient-max slot per rank (ns - 1 of them)
+        d.sepv_count = d.soff_scal + NSCAL + (uint64_t)d.world;     // + one gradient-max slot per rank
         TRY(dzero(p, &d.sepv, d.sepv_count));
         TRY(dzero(p, &d.xsep, (size_t)ns * BD));
-        int n = d.n_sep, lev = 0;
-        d.slev[0].n = n;
+        d.slev[0].n = d.n_sep;
         d.slev[0].D = d.sepv + d.soff_D;
         d.slev[0].L = d.sepv + d.soff_L;
         d.slev[0].r = d.sepv + d.soff_rhs;
-        for (;;) {
-            TRY(dzero(p, &d.slev[lev].YU, (size_t)std::max(1, n / 2) * blk));
-            std::vector<int> pos(n);
-            for (int i = 0; i < n; ++i) pos[i] = i << lev;
-            TRY(upload_pos(pos, &d.slev[lev].pos));
-            if (n == 1) break;
-            const int n2 = (n + 1) / 2;
-            ++lev;
-            if (lev >= MAX_SLEVELS) return SSBA_ERR_UNSUPPORTED;
-            d.slev[lev].n = n2;
-            TRY(dzero(p, &d.slev[lev].D, (size_t)n2 * blk));
-            TRY(dzero(p, &d.slev[lev].L, (size_t)n2 * blk));
-            TRY(dzero(p, &d.slev[lev].r, (size_t)n2 * BD));
-            n = n2;
-        }
-        d.ns_levels = lev + 1;
+        std::vector<int> pos(d.n_sep);
+        for (int i = 0; i < d.n_sep; ++i) pos[i] = i;
+        TRY(upload_pos(pos, &d.slev[0].pos));
+        TRY(make_pcr(d.spcr, 0, d.n_sep, 0, 0, 0));
     }
     std::vector<uint32_t> dn_blk_rf_start, dn_blk_rf;
     if (!pfs.empty()) {

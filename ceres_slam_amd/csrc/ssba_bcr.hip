@@ -107,11 +107,20 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     const double *Dg, *Lg, *Ug, *rin;
     double *oD, *oYL, *oYU, *orr;
     bool hasL, hasU, trL = false, trU = false;
-    if (which == 2) {
-        const BcrLevel &B = d.lev[d.pcr.level];
-        const int blk = blockIdx.x, s = 1 << lev;
-        hasL = !top && blk - s >= 0;
-        hasU = !top && blk + s < B.n;
+    double *saveU = nullptr;      // pinned plans: own copy of the coupling to the pinned last block (see PcrPlan)
+    if (which >= 2) {
+        const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+        const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
+        const int blk = blockIdx.x, s = 1 << lev, last = B.n - 1;      // top: lev = steps, so 2^lev >= n
+        if (P.pin0 && lev == 0 && blk == 1) {
+            // from the next step on block 1 carries its coupling to the pinned block 0 (odd index: stored untransposed)
+            const double2 *s2 = reinterpret_cast<const double2 *>(B.L + (size_t)BD * BD);
+            double2 *d2 = reinterpret_cast<double2 *>(P.Lbuf + (size_t)BD * BD);
+            for (int e = threadIdx.x; e < BD * BD / 2; e += FACT_THREADS) d2[e] = s2[e];
+        }
+        if ((P.pin0 && blk == 0) || (P.pin1 && blk == last)) return;    // a pinned block is never eliminated
+        hasL = blk - s >= 0 || (P.pin0 && blk > 0);
+        hasU = blk + s <= last || (P.pin1 && blk < last);
         Dg = B.D + (size_t)blk * BD * BD;
         rin = B.r + (size_t)blk * BD;
         if (lev == 0) {      // the level's own couplings: even-indexed ones are stored transposed
@@ -119,16 +128,18 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             Ug = B.L + (size_t)(hasU ? blk + 1 : blk) * BD * BD;
             trL = trU = (blk & 1) == 0;
         } else {
-            Lg = d.pcr.Lbuf + (size_t)blk * BD * BD;
-            Ug = d.pcr.LbufT + (size_t)(hasU ? blk + s : blk) * BD * BD;
+            Lg = P.Lbuf + (size_t)blk * BD * BD;
+            Ug = (P.pin1 && blk + s > last) ? P.Ubuf + (size_t)blk * BD * BD : P.LbufT + (size_t)(hasU ? blk + s : blk) * BD * BD;
         }
-        const size_t so = d.pcr.keep ? (size_t)lev * B.n + blk : (size_t)blk;      // per-step slots when the border follows
-        oD = top ? B.D + (size_t)blk * BD * BD : (d.pcr.keep ? d.pcr.Gs + so * BD * BD : nullptr);
-        oYL = hasL ? d.pcr.YL + so * BD * BD : nullptr;
-        oYU = hasU ? d.pcr.YU + so * BD * BD : nullptr;
-        orr = top ? B.r + (size_t)blk * BD : d.pcr.yr + (size_t)blk * BD;
+        // the pinned last block folds this block in now and moves on: keep the coupling to it
+        if (P.pin1 && blk + s == last) saveU = P.Ubuf + (size_t)blk * BD * BD;
+        const size_t so = P.keep ? (size_t)lev * B.n + blk : (size_t)blk;      // per-step slots when the border follows
+        oD = top ? B.D + (size_t)blk * BD * BD : (P.keep ? P.Gs + so * BD * BD : nullptr);
+        oYL = hasL ? P.YL + so * BD * BD : nullptr;
+        oYU = hasU ? P.YU + so * BD * BD : nullptr;
+        orr = top ? B.r + (size_t)blk * BD : P.yr + (size_t)blk * BD;
     } else {
-        const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
+        const BcrLevel &L = d.lev[lev];
         const int blk = top ? 0 : 2 * blockIdx.x + 1;
         hasL = !top;
         hasU = !top && (blk + 1 < L.n);
@@ -164,6 +175,10 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             else { R[c * LDR + r] = lv.x; R[(c + 1) * LDR + r] = lv.y; }
             if (!trU) { R[r * LDR + BD + c] = uv.x; R[r * LDR + BD + c + 1] = uv.y; }   // even block: stored as L^T
             else { R[c * LDR + BD + r] = uv.x; R[(c + 1) * LDR + BD + r] = uv.y; }
+            if (saveU) {
+                if (!trU) reinterpret_cast<double2 *>(saveU)[e] = uv;
+                else { saveU[c * BD + r] = uv.x; saveU[(c + 1) * BD + r] = uv.y; }
+            }
         }
         if (t < BD) {
             R[t * LDR + 2 * BD] = rin[t];
@@ -379,14 +394,17 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
     double *sA = lds, *sB = lds + BD * BD;
     __shared__ double sya[BD], syb[BD];
     const int t = threadIdx.x;
-    if (which == 2) {
+    if (which >= 2) {
         // parallel cyclic reduction, stride s = 2^lev: block e folds in BOTH neighbours e -+ s (D and r in place),
         //   D_e -= YU(e-s)^T YU(e-s) + YL(e+s)^T YL(e+s) ;  r_e -= YU(e-s)^T yr(e-s) + YL(e+s)^T yr(e+s)
-        //   L'_e = -YU(e-s)^T YL(e-s)   (coupling to e - 2s), stored untransposed and transposed
-        const BcrLevel &B = d.lev[d.pcr.level];
-        const int e = blockIdx.x, s = 1 << lev, prev = e - s, next = e + s;
-        const bool hasPrev = prev >= 0, hasNext = next < B.n;
-        const size_t so = d.pcr.keep ? (size_t)lev * B.n : 0;
+        //   L'_e = -YU(e-s)^T YL(e-s)   (coupling to e - 2s, or to the pinned first block), stored untransposed and transposed
+        //   U'_e = -YL(e+s)^T YU(e+s)   only where it is a coupling to the pinned last block (blockIdx.y = 2; see PcrPlan)
+        const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+        const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
+        const int e = blockIdx.x, s = 1 << lev, prev = e - s, next = e + s, last = B.n - 1;
+        const int lo = P.pin0 ? 1 : 0, hi = P.pin1 ? last - 1 : last;       // the blocks that get eliminated
+        const bool hasPrev = prev >= lo, hasNext = next <= hi;
+        const size_t so = P.keep ? (size_t)lev * B.n : 0;
         const bool act = t < KSPLIT * 144;
         const int g = t / 144, tt = t - g * 144;
         const int tr = tt / 12, tc = tt - tr * 12;
@@ -398,11 +416,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
         if (blockIdx.y == 0) {
             if (!hasPrev && !hasNext) return;
             out = B.D + (size_t)e * BD * BD;
-            if (hasPrev) stage_block(sA, d.pcr.YU + (so + prev) * BD * BD, RED_THREADS);
-            if (hasNext) stage_block(sB, d.pcr.YL + (so + next) * BD * BD, RED_THREADS);
+            if (hasPrev) stage_block(sA, P.YU + (so + prev) * BD * BD, RED_THREADS);
+            if (hasNext) stage_block(sB, P.YL + (so + next) * BD * BD, RED_THREADS);
             if (t < BD) {
-                sya[t] = hasPrev ? d.pcr.yr[(size_t)prev * BD + t] : 0.0;
-                syb[t] = hasNext ? d.pcr.yr[(size_t)next * BD + t] : 0.0;
+                sya[t] = hasPrev ? P.yr[(size_t)prev * BD + t] : 0.0;
+                syb[t] = hasNext ? P.yr[(size_t)next * BD + t] : 0.0;
                 rbase = B.r[(size_t)e * BD + t];
             }
             __syncthreads();
@@ -417,12 +435,23 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 B.r[(size_t)e * BD + t] = rbase - v0 - v1;
             }
             __syncthreads();
+        } else if (blockIdx.y == 1) {
+            // the folded block e - s must have a coupling on its far side: a block at e - 2s, or the pinned first block
+            if (!hasPrev || !(prev - s >= 0 || P.pin0)) return;
+            out = P.Lbuf + (size_t)e * BD * BD;
+            outT = P.LbufT + (size_t)e * BD * BD;
+            stage_block(sA, P.YU + (so + prev) * BD * BD, RED_THREADS);
+            stage_block(sB, P.YL + (so + prev) * BD * BD, RED_THREADS);
+            __syncthreads();
+            if (act) tile_mac(acc, sA, sB, g, tr, tc);
+            __syncthreads();
         } else {
-            if (prev - s < 0) return;      // no block at e - 2s
-            out = d.pcr.Lbuf + (size_t)e * BD * BD;
-            outT = d.pcr.LbufT + (size_t)e * BD * BD;
-            stage_block(sA, d.pcr.YU + (so + prev) * BD * BD, RED_THREADS);
-            stage_block(sB, d.pcr.YL + (so + prev) * BD * BD, RED_THREADS);
+            // e + s is folded and its far side is the pinned last block, not e + 2s: that coupling has no transposed
+            // twin in the pinned block's own row, so it is computed here.  (e + 2s == last: the twin is LbufT[last].)
+            if (!P.pin1 || (P.pin0 && e == 0) || !hasNext || next + s <= last) return;
+            out = P.Ubuf + (size_t)e * BD * BD;
+            stage_block(sA, P.YL + (so + next) * BD * BD, RED_THREADS);
+            stage_block(sB, P.YU + (so + next) * BD * BD, RED_THREADS);
             __syncthreads();
             if (act) tile_mac(acc, sA, sB, g, tr, tc);
             __syncthreads();
@@ -441,13 +470,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                     const double sum = (acc[6 * i + j] + part[tt * 36 + 6 * i + j]) + part[(144 + tt) * 36 + 6 * i + j];
                     const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
                     if (blockIdx.y == 0) out[o] -= sum;
-                    else { out[o] = -sum; outT[(size_t)(tc * 6 + j) * BD + tr * 6 + i] = -sum; }
+                    else { out[o] = -sum; if (outT) outT[(size_t)(tc * 6 + j) * BD + tr * 6 + i] = -sum; }
                 }
         }
         return;
     }
-    const BcrLevel &L = which ? d.slev[lev] : d.lev[lev];
-    const BcrLevel &N = which ? d.slev[lev + 1] : d.lev[lev + 1];
+    const BcrLevel &L = d.lev[lev];
+    const BcrLevel &N = d.lev[lev + 1];
     const int m = blockIdx.x, e = 2 * m;
     if (L.pin && m == L.n / 2) {
         // pinned end of a partitioned chain (old index n-1, odd): carried over unchanged as the new last block;
@@ -547,32 +576,38 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
     extern __shared__ __align__(16) double lds[];
     double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
     __shared__ double sv[BD], sxm[BD], sxp[BD];
-    // which = 2: last step of the parallel cyclic reduction -- every block of the plan's level is decoupled
-    const BcrLevel &L = which == 1 ? d.slev[lev] : d.lev[which == 2 ? d.pcr.level : lev];
-    const int blk = which == 2 ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
+    // which = 2 / 3: last step of the parallel cyclic reduction -- every block of the plan's level is decoupled from the
+    // others; in a chain with pinned ends (partitioned solve) it still has its couplings to those (x known by now)
+    const bool pcr = which >= 2;
+    const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+    const BcrLevel &L = which == 3 ? d.slev[0] : d.lev[pcr ? d.pcr.level : lev];
+    const int blk = pcr ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const bool hasU = !top && (blk + 1 < L.n);
-    double *xb = which == 1 ? d.xsep : d.x0 + (size_t)d.chain0 * BD;     // solution at level-0 block positions
+    if (pcr && ((P.pin0 && blk == 0) || (P.pin1 && blk == L.n - 1))) return;
+    const bool hasL = pcr ? (P.pin0 != 0) : !top;
+    const bool hasU = pcr ? (P.pin1 != 0) : (!top && (blk + 1 < L.n));
+    const int iL = pcr ? 0 : blk - 1, iU = pcr ? L.n - 1 : blk + 1;
+    double *xb = which == 3 ? d.xsep : d.x0 + (size_t)d.chain0 * BD;     // solution at level-0 block positions
     double *xi = xb + (size_t)L.pos[blk] * BD;
     stage_block(sG, L.D + (size_t)blk * BD * BD, BS_THREADS);
-    if (!top) stage_block(sL, L.L + (size_t)blk * BD * BD, BS_THREADS);
-    if (hasU) stage_block(sU, L.YU + (size_t)blockIdx.x * BD * BD, BS_THREADS);
+    if (hasL) stage_block(sL, (pcr ? P.YL : L.L) + (size_t)blk * BD * BD, BS_THREADS);
+    if (hasU) stage_block(sU, pcr ? P.YU + (size_t)blk * BD * BD : L.YU + (size_t)blockIdx.x * BD * BD, BS_THREADS);
     if (t < BD) {
-        sxm[t] = top ? 0.0 : xb[(size_t)L.pos[blk - 1] * BD + t];
-        sxp[t] = hasU ? xb[(size_t)L.pos[blk + 1] * BD + t] : 0.0;
+        sxm[t] = hasL ? xb[(size_t)L.pos[iL] * BD + t] : 0.0;
+        sxp[t] = hasU ? xb[(size_t)L.pos[iU] * BD + t] : 0.0;
         sv[t] = L.r[(size_t)blk * BD + t];
     }
     __syncthreads();
     // v = yr - YL x_{i-1} - YU x_{i+1}: 8 waves x 9 rows, lanes stride the row
     for (int r = w * 9; r < w * 9 + 9; ++r) {
         double p = 0.0;
-        if (!top) {
+        if (hasL) {
             p += sL[r * BD + lane] * sxm[lane];
             if (lane < BD - 64) p += sL[r * BD + 64 + lane] * sxm[64 + lane];
-            if (hasU) {
-                p += sU[r * BD + lane] * sxp[lane];
-                if (lane < BD - 64) p += sU[r * BD + 64 + lane] * sxp[64 + lane];
-            }
+        }
+        if (hasU) {
+            p += sU[r * BD + lane] * sxp[lane];
+            if (lane < BD - 64) p += sU[r * BD + 64 + lane] * sxp[64 + lane];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o, 64);
@@ -602,7 +637,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
 }
 
 // blocks eliminated at a level: all odd ones, except the pinned end of a partitioned chain
-static int n_odd(const BcrLevel &lv, bool pinned) { return pinned ? (lv.n - 1) / 2 : lv.n / 2; }
+static int n_odd(const BcrLevel &lv, int pinned) { return pinned ? (lv.n - 1) / 2 : lv.n / 2; }
 
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
     const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
@@ -640,33 +675,39 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
         return;
     }
-    // Partitioned solve, forward part: eliminate the interior of this rank's chain (both ends pinned) down to the
-    // two ends; launch_bcr_separators() continues after the separator exchange.
-    for (int l = 0; l + 1 < nl; ++l) {
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n_odd(d.lev[l], true)), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
+    // Partitioned solve, forward part: eliminate the interior of this rank's chain.  Plain levels (the pinned end of an
+    // even-length level is carried over) down to the plan's level, then parallel cyclic reduction with pinned ends: the
+    // pinned rows end up holding this rank's share of the separator system, every other block its factor and its
+    // couplings to the pinned ones.  launch_bcr_separators() continues after the separator exchange.
+    const int k = d.pcr.level, n = d.pcr.n;
+    for (int l = 0; l < k; ++l) {
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n_odd(d.lev[l], d.lev[l].pin)), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
         LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(d.lev[l + 1].n, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
     }
+    for (int q = 0; q < d.pcr.steps; ++q) {
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, q, 0, 2);
+        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(n, d.pcr.pin1 ? 3 : 2), dim3(RED_THREADS), sh_reduce, d, q, 2);
+    }
+    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, d.pcr.steps, 1, 2);
 }
 
-// separator system (all ranks' chain ends, summed over ranks): plain BCR, replicated on every rank; then the
-// back-substitution of this rank's chain interior
+// separator system (the blocks shared by neighbouring ranks, summed over the ranks): parallel cyclic reduction,
+// replicated on every rank; then the back-substitution of this rank's chain interior
 void launch_bcr_separators(Launcher &L, const Dev &d) {
     const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
     const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
-    const int ns = d.ns_levels;
-    for (int l = 0; l + 1 < ns; ++l) {
-        const int n = d.slev[l].n;
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), sh_factor, d, l, 0, 1);
-        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l, 1);
+    const int ns = d.n_sep;
+    for (int q = 0; q < d.spcr.steps; ++q) {
+        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(ns), dim3(FACT_THREADS), sh_factor, d, q, 0, 3);
+        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(ns, 2), dim3(RED_THREADS), sh_reduce, d, q, 3);
     }
-    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), sh_factor, d, ns - 1, 1, 1);
-    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, ns - 1, 1, 1);
-    for (int l = ns - 2; l >= 0; --l)
-        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.slev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 1);
-    launch_sep_scatter(L, d);       // x0 at this rank's two chain ends <- separator solution
-    for (int l = d.n_levels - 2; l >= 0; --l)
-        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n_odd(d.lev[l], true)), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
+    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(ns), dim3(FACT_THREADS), sh_factor, d, d.spcr.steps, 1, 3);
+    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(ns), dim3(BS_THREADS), sh_backsub, d, 0, 1, 3);
+    launch_sep_scatter(L, d);       // x0 at the separator poses <- separator solution
+    LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.pcr.n), dim3(BS_THREADS), sh_backsub, d, d.pcr.level, 1, 2);
+    for (int l = d.pcr.level - 1; l >= 0; --l)
+        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n_odd(d.lev[l], d.lev[l].pin)), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
 }
 
 int configure_kernels() {

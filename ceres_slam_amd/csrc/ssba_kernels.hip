@@ -471,8 +471,8 @@ __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
     double *Dd = d.xv + d.off_D + (size_t)I * BD * BD + (size_t)row * BD + row;
     if (d.part) {
         if (I < d.chain0 || I > d.chain1) return;
-        if (I == d.chain0 || I == d.chain1) {
-            // a chain end is a separator: other ranks contribute to it too, so it is damped after the exchange
+        if ((d.pin0 && I == d.chain0) || (d.pin1 && I == d.chain1)) {
+            // a shared chain end is a separator: the neighbouring rank contributes to it too, so it is damped after the exchange
             // (k_sep_finish); only the sign convention rhs = -gradient is applied here
             d.xv[d.off_rhs + i] = f < d.nfree ? -d.xv[d.off_rhs + i] : 0.0;
             return;
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
         double gml = *d.gmax_l;
         if (d.part) {      // one slot per rank behind the scalars (k_sep_pack)
             gml = 0.0;
-            for (int r = 0; r + 1 < d.n_sep; ++r) gml = fmax(gml, sc[NSCAL + r]);
+            for (int r = 0; r < d.world; ++r) gml = fmax(gml, sc[NSCAL + r]);
         }
         st.gmax = fmax(fmax(gmp, gml), gmb);
         st.just_linearized = 0;
@@ -1357,18 +1357,22 @@ __global__ void k_reset_state(Dev d, Options opt) {
 __global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
     State &st = *d.st;
     if (st.terminated) return;
-    const BcrLevel &E = d.lev[d.n_levels - 1];       // two blocks: the chain ends
-    const int t = threadIdx.x, r = d.rank;
+    const BcrLevel &E = d.lev[d.pcr.level];          // the pinned first / last block of this level: the shared chain ends
+    const int t = threadIdx.x, r = d.rank, last = E.n - 1;
     const size_t blk = (size_t)BD * BD;
+    // separator r - 1 is this chain's first block, separator r its last one
     if (blockIdx.x < 2) {
-        double *dst = d.sepv + d.soff_D + (size_t)(r + blockIdx.x) * blk;
-        const double *src = E.D + (size_t)blockIdx.x * blk;
+        if (!(blockIdx.x ? d.pin1 : d.pin0)) return;
+        double *dst = d.sepv + d.soff_D + (size_t)(r - 1 + blockIdx.x) * blk;
+        const double *src = E.D + (size_t)(blockIdx.x ? last : 0) * blk;
         for (int i = t; i < BD * BD; i += 256) dst[i] = src[i];
     } else if (blockIdx.x == 2) {
-        // coupling of the two ends: local index 1 (odd, untransposed) -> separator index r+1 (even: transposed)
-        double *dst = d.sepv + d.soff_L + (size_t)(r + 1) * blk;
-        const double *src = E.L + blk;
-        const bool tr = ((r + 1) & 1) == 0;
+        // coupling of the two ends, S[last, first], left in the plan's buffer by the last fold of the pinned last block
+        // -> coupling block of separator r (an even index is stored transposed)
+        if (!(d.pin0 && d.pin1)) return;
+        double *dst = d.sepv + d.soff_L + (size_t)r * blk;
+        const double *src = d.pcr.Lbuf + (size_t)last * blk;
+        const bool tr = (r & 1) == 0;
         for (int i = t; i < BD * BD; i += 256) {
             const int row = i / BD, col = i - row * BD;
             dst[tr ? col * BD + row : i] = src[i];
@@ -1376,17 +1380,18 @@ __global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
     } else {
         __shared__ double sm[4];
         for (int e = 0; e < 2; ++e) {
+            if (!(e ? d.pin1 : d.pin0)) continue;
             const int sb = e ? d.chain1 : d.chain0;
             if (t < BD) {
-                d.sepv[d.soff_rhs + (size_t)(r + e) * BD + t] = E.r[(size_t)e * BD + t];
-                d.sepv[d.soff_gp + (size_t)(r + e) * BD + t] = d.xv[d.off_gp + (size_t)sb * BD + t];
-                d.sepv[d.soff_hdiag + (size_t)(r + e) * BD + t] = d.xv[d.off_hdiag + (size_t)sb * BD + t];
+                d.sepv[d.soff_rhs + (size_t)(r - 1 + e) * BD + t] = E.r[(size_t)(e ? last : 0) * BD + t];
+                d.sepv[d.soff_gp + (size_t)(r - 1 + e) * BD + t] = d.xv[d.off_gp + (size_t)sb * BD + t];
+                d.sepv[d.soff_hdiag + (size_t)(r - 1 + e) * BD + t] = d.xv[d.off_hdiag + (size_t)sb * BD + t];
             }
         }
         // interior poses of this rank: projected gradient and |x|^2 join the landmark sums of the linearisation
         double gm = 0.0, xn = 0.0;
         if (st.just_linearized) {
-            for (int i = (d.chain0 + 1) * SBP + t; i < d.chain1 * SBP && i < d.nfree; i += 256) {
+            for (int i = (d.chain0 + d.pin0) * SBP + t; i < (d.chain1 + 1 - d.pin1) * SBP && i < d.nfree; i += 256) {
                 const int k = d.free_pose[i];
                 const double *T = d.poses + (size_t)k * 12;
                 double ng[6], Tn[12];

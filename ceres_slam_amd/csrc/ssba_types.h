@@ -29,8 +29,8 @@ constexpr int BD = 6 * SBP;             // 72 rows per super-block
 constexpr int LMG = 64;                 // landmarks per ELL group (= wavefront)
 constexpr int SLAB_DOUBLES = NPAIR * 36 + TW * 6;   // per Schur work item
 constexpr int MAX_LEVELS = 24;
-constexpr int MAX_SLEVELS = 8;          // levels of the separator system of a partitioned (multi-rank) solve
-constexpr int MAX_SEP = 65;             // separators = ranks + 1
+constexpr int MAX_SLEVELS = 1;          // the separator system of a partitioned (multi-rank) solve: one level, parallel cyclic reduction
+constexpr int MAX_SEP = 65;             // separators = ranks - 1
 constexpr int NSCAL = 16;
 constexpr int NBP = 32;                 // padded width of the border of free shared blocks (nb <= NBP)
 constexpr int NBQ = 7;                  // border entries one intensity row touches: [phong 3 | kd | light 3]
@@ -102,6 +102,13 @@ struct PcrPlan {
     // products (YL, YU hold steps x n blocks) and its factor Gs; Bb / yB are the columns and G^-1 of them (n x BD x NBP)
     int keep;
     double *Gs, *Bb, *yB;
+    // partitioned solve: the first / last block of the level is a separator shared with the neighbouring rank.  A pinned
+    // block is never eliminated: it folds its neighbours in like every other block, but the others KEEP their coupling
+    // to it instead of folding it (Lbuf[i] = S[i, first] once i - 2^k < 0, Ubuf[i] = S[i, last] once i + 2^k > n - 1),
+    // so after the last step every interior block is coupled to the pinned ones only and the pinned rows hold the
+    // Schur complement of the chain interior.
+    int pin0, pin1;
+    double *Ubuf;
 };
 constexpr int PCR_MAX_BLOCKS = 128;
 
@@ -146,11 +153,12 @@ struct Dev {
     BcrLevel lev[MAX_LEVELS];
     PcrPlan pcr;
     // partitioned solve (one rank per contiguous chain of super-blocks): this rank's chain is
-    // super-blocks [chain0, chain1] with both ends pinned; the ends of all ranks form the separator system
-    int part, rank, n_sep, chain0, chain1;
-    int sep_sb[MAX_SEP];             // separator s = super-block sep_sb[s]; rank r owns the chain [sep_sb[r], sep_sb[r+1]]
-    int ns_levels;
-    BcrLevel slev[MAX_SLEVELS];      // plain BCR plan of the separator system (n_sep blocks)
+    // super-blocks [chain0, chain1]; the end it shares with a neighbouring rank is pinned (pin0: rank > 0, pin1:
+    // rank < world - 1), the world - 1 shared blocks of all ranks form the separator system
+    int part, rank, world, n_sep, chain0, chain1, pin0, pin1;
+    int sep_sb[MAX_SEP];             // separator s = super-block sep_sb[s], shared by the ranks s and s + 1
+    BcrLevel slev[MAX_SLEVELS];      // slev[0]: the separator system (n_sep blocks) inside the exchange vector
+    PcrPlan spcr;                    // its parallel cyclic reduction (replicated on every rank)
     double *sepv;                    // [Dsep | Lsep | rhs | gp | hdiag | scal]: the (small) exchange vector
     uint64_t soff_D, soff_L, soff_rhs, soff_gp, soff_hdiag, soff_scal, sepv_count;
     double *xsep;                    // n_sep * BD separator solution

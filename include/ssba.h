@@ -182,8 +182,8 @@ int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
  * super-blocks [sep[r], sep[r+1]] -- i.e. the landmark ranges are cut where the co-visibility band crosses
  * a super-block boundary, so that consecutive ranks share exactly one super-block.  Each rank then
  * eliminates the interior of its own chain of the block-tridiagonal reduced camera system and only the
- * chain ends (the separator system: (world_size + 1) blocks of 72 x 72) are summed over the ranks and
- * solved everywhere -- ~1 MB per iteration instead of the whole reduced system, and no redundant solve of
+ * shared chain ends (the separator system: (world_size - 1) blocks of 72 x 72) are summed over the ranks and
+ * solved everywhere -- < 1 MB per iteration instead of the whole reduced system, and no redundant solve of
  * the other ranks' chains.  At the end of the solve the poses are gathered (one more exchange), so every
  * rank returns the complete trajectory.  Without this call the ranks sum the whole reduced system and
  * each solves all of it (works for any sharding).  num = 0 clears the partition. */

@@ -22,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(mode, out, world=2, timeout=300, size=None):
+def _run_ranks(mode, out, world=2, timeout=300, size=None, extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
@@ -30,6 +30,7 @@ def _run_ranks(mode, out, world=2, timeout=300, size=None):
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
         if size:
             env["SSBA_TEST_SIZE"] = ",".join(str(v) for v in size)
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode, out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=timeout)[0].decode(errors="replace") for p in procs]
@@ -102,11 +103,15 @@ def test_aligned_partition_cuts_at_superblock_boundaries():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size", [(2, (40, 1600, 12)), (3, (100, 4000, 12)), (2, (300, 9000, 12)), (4, (300, 9000, 12))])
-def test_partitioned_gpu_solve_matches_unsharded_oracle(tmp_path, world, size):
-    """Partitioned reduced solve (ssba_set_partition): every rank eliminates its own chain of super-blocks with
-    pinned ends, only the separator system is summed over the ranks.  Same iterates as the unsharded solve."""
-    res = _run_ranks("gpu_part", str(tmp_path / "part"), world, size=size)
+@pytest.mark.parametrize("world,size,pcr_max", [(2, (40, 1600, 12), None), (3, (100, 4000, 12), None), (2, (300, 9000, 12), None),
+                                                (4, (300, 9000, 12), None), (2, (300, 9000, 12), 4), (4, (300, 9000, 12), 3),
+                                                (3, (420, 12000, 12), 5)])
+def test_partitioned_gpu_solve_matches_unsharded_oracle(tmp_path, world, size, pcr_max):
+    """Partitioned reduced solve (ssba_set_partition): every rank eliminates the interior of its own chain of
+    super-blocks (parallel cyclic reduction with the shared ends pinned; with SSBA_PCR_MAX_BLOCKS set, plain levels
+    first), only the separator system is summed over the ranks.  Same iterates as the unsharded solve."""
+    res = _run_ranks("gpu_part", str(tmp_path / "part"), world, size=size,
+                     extra_env={"SSBA_PCR_MAX_BLOCKS": str(pcr_max)} if pcr_max else None)
     prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21)
     op = orc.OracleProblem.from_synth(prob)
     s2, log2 = op.solve(orc.driver_options(num_threads=2))

@@ -5,7 +5,7 @@ One process plays rank r of N: it holds the rank's landmark shard of the N x C2 
 kernel sequence, with an exchange callback that does nothing (the sums over ranks are missing, so the
 iterates are meaningless, but every kernel does its normal work on its normal sizes).  What is left out is
 exactly the collective time; what is measured is the GPU + launch time per iteration that each rank pays:
-  * "partitioned": chain elimination + separator system (ssba_set_partition),
+  * "partitioned": chain elimination with pinned shared ends + separator system (ssba_set_partition),
   * "all-reduce":  the whole N x 84 super-block system solved by every rank.
 usage: python tools/rank_compute_time.py [N ...]"""
 import json
