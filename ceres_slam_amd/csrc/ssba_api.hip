@@ -83,6 +83,11 @@ struct ssba_problem {
     Launcher launcher;
     hipStream_t own_stream = nullptr;
     std::vector<void *> allocs;
+    // uploads of ssba_finalize: copied into pinned chunks and sent asynchronously on the solver's stream, released after one
+    // synchronisation at the end (a synchronous pageable hipMemcpy per array cost more than the layout work of small windows)
+    std::vector<void *> stage_chunks;
+    char *stage_cur = nullptr;
+    size_t stage_left = 0;
     uint64_t dev_bytes = 0;
     State *h_state = nullptr;   // pinned
     double *h_stage = nullptr;  // pinned staging for parameter upload/download
@@ -119,12 +124,42 @@ static int dalloc(ssba_problem *p, T **out, size_t n) {
     *out = (T *)ptr;
     return SSBA_OK;
 }
+static int stage_alloc(ssba_problem *p, size_t bytes, char **out) {
+    bytes = (bytes + 255) / 256 * 256;
+    if (bytes > p->stage_left) {
+        const size_t chunk = std::max<size_t>(bytes, p->stage_chunks.empty() ? (size_t)1 << 20 : (size_t)16 << 20);
+        void *h = nullptr;
+        HIPCHECK(pool_host_malloc(&h, chunk));
+        p->stage_chunks.push_back(h);
+        p->stage_cur = (char *)h;
+        p->stage_left = chunk;
+    }
+    *out = p->stage_cur;
+    p->stage_cur += bytes;
+    p->stage_left -= bytes;
+    return SSBA_OK;
+}
+// waits for the staged uploads and hands the chunks back to the pool
+static void stage_release(ssba_problem *p) {
+    if (p->stage_chunks.empty()) return;
+    hipStreamSynchronize(p->launcher.stream);
+    for (void *h : p->stage_chunks) pool_host_free(h);
+    p->stage_chunks.clear();
+    p->stage_cur = nullptr;
+    p->stage_left = 0;
+}
 template <class T>
 static int dupload(ssba_problem *p, const T **out, const std::vector<T> &v) {
     T *ptr = nullptr;
     int rc = dalloc(p, &ptr, v.size());
     if (rc) return rc;
-    if (!v.empty()) HIPCHECK(hipMemcpy(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    if (!v.empty()) {
+        const size_t bytes = v.size() * sizeof(T);
+        char *h = nullptr;
+        if ((rc = stage_alloc(p, bytes, &h))) return rc;
+        memcpy(h, v.data(), bytes);
+        HIPCHECK(hipMemcpyAsync(ptr, h, bytes, hipMemcpyHostToDevice, p->launcher.stream));
+    }
     *out = ptr;
     return SSBA_OK;
 }
@@ -132,7 +167,7 @@ template <class T>
 static int dzero(ssba_problem *p, T **out, size_t n) {
     int rc = dalloc(p, out, n);
     if (rc) return rc;
-    HIPCHECK(hipMemset(*out, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    HIPCHECK(hipMemsetAsync(*out, 0, std::max<size_t>(n, 1) * sizeof(T), p->launcher.stream));
     return SSBA_OK;
 }
 
@@ -147,6 +182,7 @@ static void drop_graph(ssba_problem *p) {
 
 static void free_device(ssba_problem *p) {
     drop_graph(p);
+    stage_release(p);
     if (!p->allocs.empty()) hipStreamSynchronize(p->launcher.stream);      // cached buffers go to the next handle
     for (void *a : p->allocs) pool_free(a);
     p->allocs.clear();
@@ -195,6 +231,19 @@ struct ApiTimer {
         auto &e = g_api_times.t[name];
         e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         e.second += 1;
+    }
+};
+
+// phases of one entry point: PhaseTimer t; ... t.mark("finalize: windows"); -- rows of the SSBA_API_TIMING table
+struct PhaseTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char *name) {
+        if (!g_api_times.on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        auto &e = g_api_times.t[name];
+        e.first += std::chrono::duration<double>(t1 - t0).count();
+        e.second += 1;
+        t0 = t1;
     }
 };
 
@@ -554,6 +603,7 @@ int ssba_finalize(ssba_problem *p) {
         return SSBA_ERR_UNSUPPORTED;
     }
 
+    PhaseTimer phase;
     // landmark-major observation lists (stable: keeps the caller's order)
     std::vector<uint32_t> lm_start(L + 1, 0), pose_cnt(P, 0);
     for (uint64_t i = 0; i < N; ++i) { lm_start[p->obs_point[i] + 1]++; pose_cnt[p->obs_pose[i]]++; }
@@ -601,24 +651,35 @@ int ssba_finalize(ssba_problem *p) {
         }
     const int nfree = (int)p->free_pose.size();
 
+    phase.mark("finalize: 1 landmark lists");
     // per-landmark sorted pose sets; envelope checks.  The windowed layout needs tracks <= TW and a pose co-visibility
     // span <= SBP (block-tridiagonal reduced system); anything else takes the general path with a dense reduced system.
     bool dense = false;
     struct LmInfo { uint32_t j, kmin, kmax; };
     std::vector<LmInfo> order;
     order.reserve(L);
-    std::vector<std::vector<uint32_t>> lm_poses(L);
+    std::vector<uint32_t> lm_pose_sorted(N);      // per landmark (lm_start range): its poses, ascending
+    std::vector<uint32_t> lm_obs_by_pose;         // lm_obs in that order, where it differs from the caller's (else empty)
     for (uint32_t j = 0; j < L; ++j) {
         const uint32_t n = lm_start[j + 1] - lm_start[j];
         if (n == 0) continue;
         if (n > (uint32_t)TW) dense = true;     // longer tracks than the window layout holds: general (dense) path
-        auto &ks = lm_poses[j];
-        for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) ks.push_back(p->obs_pose[lm_obs[e]]);
-        std::sort(ks.begin(), ks.end());
-        if (std::adjacent_find(ks.begin(), ks.end()) != ks.end()) dense = true;     // two residual blocks on one (pose, landmark): no window slot for the second
-        order.push_back({j, ks.front(), ks.back()});
+        uint32_t *ks = &lm_pose_sorted[lm_start[j]];
+        bool sorted = true;
+        for (uint32_t e = 0; e < n; ++e) {
+            ks[e] = p->obs_pose[lm_obs[lm_start[j] + e]];
+            if (e && ks[e] < ks[e - 1]) sorted = false;
+        }
+        if (!sorted) {      // rare (datasets list a landmark's observations by state): order the observation indices with the poses
+            if (lm_obs_by_pose.empty()) lm_obs_by_pose = lm_obs;
+            uint32_t *ob = &lm_obs_by_pose[lm_start[j]];
+            std::stable_sort(ob, ob + n, [&](uint32_t x, uint32_t y) { return p->obs_pose[x] < p->obs_pose[y]; });
+            for (uint32_t e = 0; e < n; ++e) ks[e] = p->obs_pose[ob[e]];
+        }
+        if (std::adjacent_find(ks, ks + n) != ks + n) dense = true;     // two residual blocks on one (pose, landmark): no window slot for the second
+        order.push_back({j, ks[0], ks[n - 1]});
         int flo = 1 << 30, fhi = -1;
-        for (uint32_t k : ks) { const int f = p->pose_free[k]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
+        for (uint32_t e = 0; e < n; ++e) { const int f = p->pose_free[ks[e]]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
         if (fhi - flo > SBP) dense = true;
     }
     if (p->points_const && !ph) {
@@ -644,6 +705,7 @@ int ssba_finalize(ssba_problem *p) {
     const uint32_t Lact = (uint32_t)order.size();
     const uint32_t Lpad = std::max<uint32_t>(256, (Lact + 255) / 256 * 256);
 
+    phase.mark("finalize: 2 pose sets + order");
     // greedy windows: consecutive landmarks whose pose sets fit one list of <= TW poses
     std::vector<uint32_t> win_pose, win_begin;   // win_begin has n_windows+1 entries
     std::vector<uint32_t> lm_win(Lpad, 0);
@@ -658,12 +720,13 @@ int ssba_finalize(ssba_problem *p) {
             begin = end;
         };
         for (uint32_t l = 0; l < Lact && !dense; ++l) {
-            const auto &ks = lm_poses[order[l].j];
+            const uint32_t *kb = &lm_pose_sorted[lm_start[order[l].j]], *ke = &lm_pose_sorted[lm_start[order[l].j + 1]];
+            if (std::includes(cur_set.begin(), cur_set.end(), kb, ke)) continue;      // the common case: nothing new
             merged.clear();
-            std::set_union(cur_set.begin(), cur_set.end(), ks.begin(), ks.end(), std::back_inserter(merged));
+            std::set_union(cur_set.begin(), cur_set.end(), kb, ke, std::back_inserter(merged));
             if (merged.size() > (size_t)TW) {
                 close(l);
-                cur_set = ks;
+                cur_set.assign(kb, ke);
             } else {
                 cur_set.swap(merged);
             }
@@ -674,6 +737,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     const uint32_t n_windows = (uint32_t)win_begin.size() - 1;
 
+    phase.mark("finalize: 3 windows");
     // ELL observation arrays, masks
     const uint32_t n_groups = Lpad / LMG;
     std::vector<double> ou((size_t)n_groups * TW * LMG, 0.0), ov(ou.size(), 0.0), od(ou.size(), 1.0);
@@ -690,7 +754,6 @@ int ssba_finalize(ssba_problem *p) {
         oint.assign(n1, 0.0); onx.assign(n1, 0.0); ony.assign(n1, 0.0); onz.assign(n1, 1.0);
     }
     p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
-    std::vector<std::vector<uint32_t>> pose_refs(P);
     // general path: landmark-major observation arrays + the pose-major index list into them
     std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs;
     std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
@@ -801,51 +864,54 @@ int ssba_finalize(ssba_problem *p) {
         }
         dplan.nbk = nbk;
     }
-    for (uint32_t l = 0; l < Lact && !dense; ++l) {
-        const uint32_t j = order[l].j, w = lm_win[l];
-        p->user_of_dev[l] = j;
-        if (ph) lm_mat[l] = p->ph_mat_of_point[j];
-        for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
-            const uint32_t i = lm_obs[e], k = p->obs_pose[i];
-            const uint32_t *wp = &win_pose[(size_t)w * TW];
-            const int s = (int)(std::lower_bound(wp, wp + TW, k) - wp);
-            const size_t oi = (size_t)(l / LMG) * (TW * LMG) + (size_t)s * LMG + (l % LMG);
-            ou[oi] = p->obs_uvd[3 * (size_t)i];
-            ov[oi] = p->obs_uvd[3 * (size_t)i + 1];
-            od[oi] = p->obs_uvd[3 * (size_t)i + 2];
-            if (ph) {
-                oint[oi] = p->ph_intensity[i];
-                onx[oi] = p->ph_nobs[3 * (size_t)i];
-                ony[oi] = p->ph_nobs[3 * (size_t)i + 1];
-                onz[oi] = p->ph_nobs[3 * (size_t)i + 2];
-            }
-            lm_mask[l] |= 1u << s;
-            pose_refs[k].push_back(l * 16u + (uint32_t)s);
-        }
-    }
-    std::vector<uint32_t> pose_obs_start(P + 1, 0), pose_obs_ref;
-    pose_obs_ref.reserve(N);
+    // ELL slots and the pose-major reference list (landmark*16 + slot) in one pass: a landmark's poses and its window's
+    // pose list are both ascending (one merge per landmark), and landmarks are visited in device order, so counting
+    // leaves every pose's references ascending
+    std::vector<uint32_t> pose_obs_start(P + 1, 0), pose_obs_ref(dense ? 0 : N);
     std::vector<uint32_t> pose_mat_start;   // config 3: references of a pose sorted by material, P*(M+1) offsets
     const uint32_t Mm = ph ? p->M : 0;
-    for (uint32_t k = 0; k < P; ++k) {
-        if (ph)
-            std::sort(pose_refs[k].begin(), pose_refs[k].end(), [&](uint32_t x, uint32_t y) {
-                const uint32_t mx = lm_mat[x >> 4], my = lm_mat[y >> 4];
-                return mx != my ? mx < my : x < y;
-            });
-        else
-            std::sort(pose_refs[k].begin(), pose_refs[k].end());
-        if (ph) {
-            size_t q = 0;
-            for (uint32_t m = 0; m <= Mm; ++m) {
-                while (q < pose_refs[k].size() && lm_mat[pose_refs[k][q] >> 4] < m) ++q;
-                pose_mat_start.push_back((uint32_t)(pose_obs_ref.size() + q));
+    if (!dense) {
+        for (uint32_t k = 0; k < P; ++k) pose_obs_start[k + 1] = pose_obs_start[k] + pose_cnt[k];
+        std::vector<uint32_t> at(pose_obs_start.begin(), pose_obs_start.end() - 1);
+        const uint32_t *lmo = lm_obs_by_pose.empty() ? lm_obs.data() : lm_obs_by_pose.data();
+        for (uint32_t l = 0; l < Lact; ++l) {
+            const uint32_t j = order[l].j, w = lm_win[l];
+            p->user_of_dev[l] = j;
+            if (ph) lm_mat[l] = p->ph_mat_of_point[j];
+            const uint32_t *wp = &win_pose[(size_t)w * TW];
+            const size_t base = (size_t)(l / LMG) * (TW * LMG) + (l % LMG);
+            int s = 0;
+            uint32_t mask = 0;
+            for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
+                const uint32_t i = lmo[e], k = lm_pose_sorted[e];
+                while (wp[s] != k) ++s;
+                const size_t oi = base + (size_t)s * LMG;
+                ou[oi] = p->obs_uvd[3 * (size_t)i];
+                ov[oi] = p->obs_uvd[3 * (size_t)i + 1];
+                od[oi] = p->obs_uvd[3 * (size_t)i + 2];
+                if (ph) {
+                    oint[oi] = p->ph_intensity[i];
+                    onx[oi] = p->ph_nobs[3 * (size_t)i];
+                    ony[oi] = p->ph_nobs[3 * (size_t)i + 1];
+                    onz[oi] = p->ph_nobs[3 * (size_t)i + 2];
+                }
+                mask |= 1u << s;
+                pose_obs_ref[at[k]++] = l * 16u + (uint32_t)s;
             }
+            lm_mask[l] = mask;
         }
-        pose_obs_ref.insert(pose_obs_ref.end(), pose_refs[k].begin(), pose_refs[k].end());
-        pose_obs_start[k + 1] = (uint32_t)pose_obs_ref.size();
+    }
+    for (uint32_t k = 0; k < P && ph && !dense; ++k) {
+        uint32_t *rb = &pose_obs_ref[pose_obs_start[k]], *re = &pose_obs_ref[pose_obs_start[k + 1]];
+        std::stable_sort(rb, re, [&](uint32_t x, uint32_t y) { return lm_mat[x >> 4] < lm_mat[y >> 4]; });
+        size_t q = 0;
+        for (uint32_t m = 0; m <= Mm; ++m) {
+            while (rb + q < re && lm_mat[rb[q] >> 4] < m) ++q;
+            pose_mat_start.push_back((uint32_t)(pose_obs_start[k] + q));
+        }
     }
 
+    phase.mark("finalize: 4 observation arrays");
     // Schur work items (slabs): windows, split when long
     const uint32_t kItemMax = 128;
     std::vector<uint32_t> slab_win, slab_b, slab_e;
@@ -860,6 +926,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     const uint32_t n_slabs = (uint32_t)slab_win.size();
 
+    phase.mark("finalize: 5 slabs");
     // reduced-system block structure
     struct Contrib { uint32_t a, b, c; };
     std::vector<Contrib> contribs;
@@ -869,8 +936,13 @@ int ssba_finalize(ssba_problem *p) {
         const uint32_t w = slab_win[it];
         uint32_t slot_any = 0;
         bool pair_any[NPAIR] = {false};
+        uint32_t seen[8], n_seen = 0;       // neighbouring landmarks mostly share their slot mask: expand each distinct one once
         for (uint32_t l = slab_b[it]; l < slab_e[it]; ++l) {
             const uint32_t m = lm_mask[l];
+            bool known = false;
+            for (uint32_t q = 0; q < n_seen; ++q) known |= seen[q] == m;
+            if (known) continue;
+            seen[n_seen < 8 ? n_seen++ : (l & 7u)] = m;
             slot_any |= m;
             int n = 0;
             for (int a = 0; a < TW; ++a)
@@ -897,34 +969,26 @@ int ssba_finalize(ssba_problem *p) {
         set_error("pose co-visibility bandwidth exceeds the block-tridiagonal envelope of this build");
         return SSBA_ERR_UNSUPPORTED;
     }
-    std::sort(contribs.begin(), contribs.end(), [](const Contrib &x, const Contrib &y) {
-        if (x.a != y.a) return x.a < y.a;
-        if (x.b != y.b) return x.b < y.b;
-        return x.c < y.c;
-    });
     std::vector<uint32_t> sblk_a, sblk_b, sblk_start, sblk_contrib;
-    // every free pose gets its diagonal block even without landmark contributions
+    // blocks (a, b), b - a <= SBP, in (a, b) order with their contributions ascending -- a counting sort over the
+    // (a, b - a) keys (the contributions were generated in ascending order); every free pose gets its diagonal block
+    // even without landmark contributions
     {
-        size_t ci = 0;
-        std::vector<Contrib> all;
-        all.reserve(contribs.size() + nfree);
-        for (int f = 0; f < nfree; ++f) all.push_back({(uint32_t)f, (uint32_t)f, 0xFFFFFFFFu});
-        all.insert(all.end(), contribs.begin(), contribs.end());
-        std::sort(all.begin(), all.end(), [](const Contrib &x, const Contrib &y) {
-            if (x.a != y.a) return x.a < y.a;
-            if (x.b != y.b) return x.b < y.b;
-            return x.c < y.c;
-        });
-        (void)ci;
-        for (size_t i = 0; i < all.size(); ++i) {
-            if (i == 0 || all[i].a != all[i - 1].a || all[i].b != all[i - 1].b) {
-                sblk_a.push_back(all[i].a);
-                sblk_b.push_back(all[i].b);
-                sblk_start.push_back((uint32_t)sblk_contrib.size());
-            }
-            if (all[i].c != 0xFFFFFFFFu) sblk_contrib.push_back(all[i].c);
+        const size_t nkeys = (size_t)nfree * (SBP + 1);
+        std::vector<uint32_t> kstart(nkeys + 1, 0);
+        for (auto &c : contribs) kstart[(size_t)c.a * (SBP + 1) + (c.b - c.a) + 1]++;
+        for (size_t q = 0; q < nkeys; ++q) kstart[q + 1] += kstart[q];
+        sblk_contrib.resize(contribs.size());
+        std::vector<uint32_t> at(kstart.begin(), kstart.end() - 1);
+        for (auto &c : contribs) sblk_contrib[at[(size_t)c.a * (SBP + 1) + (c.b - c.a)]++] = c.c;
+        for (size_t q = 0; q < nkeys; ++q) {
+            const uint32_t a = (uint32_t)(q / (SBP + 1)), off = (uint32_t)(q % (SBP + 1));
+            if (kstart[q + 1] == kstart[q] && off != 0) continue;
+            sblk_a.push_back(a);
+            sblk_b.push_back(a + off);
+            sblk_start.push_back(kstart[q]);
         }
-        sblk_start.push_back((uint32_t)sblk_contrib.size());
+        sblk_start.push_back((uint32_t)contribs.size());
     }
     const uint32_t n_sblk = (uint32_t)sblk_a.size();
     std::sort(prow.begin(), prow.end());
@@ -933,6 +997,7 @@ int ssba_finalize(ssba_problem *p) {
     for (int f = 0; f < nfree; ++f) prow_start[f + 1] += prow_start[f];
     for (auto &pr : prow) prow_contrib.push_back(pr.second);
 
+    phase.mark("finalize: 6 block structure");
     // ---- device mirrors ------------------------------------------------------------
     free_device(p);
     Dev &d = p->d;
@@ -1010,6 +1075,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dupload(p, &d.sblk_a, sblk_a)); TRY(dupload(p, &d.sblk_b, sblk_b));
     TRY(dupload(p, &d.sblk_start, sblk_start)); TRY(dupload(p, &d.sblk_contrib, sblk_contrib));
     TRY(dupload(p, &d.prow_start, prow_start)); TRY(dupload(p, &d.prow_contrib, prow_contrib));
+    phase.mark("finalize: 7 device mirrors");
     // exchange vector
     const uint64_t blk = (uint64_t)BD * BD;
     d.off_D = 0;
@@ -1219,6 +1285,8 @@ int ssba_finalize(ssba_problem *p) {
         }
     }
 #undef TRY
+    stage_release(p);
+    phase.mark("finalize: 8 plans + tables");
     p->stats.num_poses = P; p->stats.num_free_poses = (uint32_t)nfree;
     p->stats.num_points = L; p->stats.num_active_points = Lact;
     p->stats.num_observations = N; p->stats.num_windows = n_windows;
