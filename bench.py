@@ -169,7 +169,9 @@ def main():
             dist.init_process_group(backend)
 
     phong = args.config == "C3"           # BASELINE.json configs[2]: C2 + Phong lighting residual blocks
-    P1, L1 = synth.CONFIGS["C2" if phong else args.config]
+    robust = args.config == "C5"          # BASELINE.json configs[4]: Huber loss, 30 % outlier observations (C2 shape per GPU)
+    huber_a = 1.345 if robust else 0.0
+    P1, L1 = synth.CONFIGS["C2" if (phong or robust) else args.config]
     lighting = None
     if phong:
         if world > 1:
@@ -177,7 +179,7 @@ def main():
         prob, ph = synth.make_phong_problem(P1, L1)
         lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
-        prob = synth.make_problem(P1 * world, L1 * world)
+        prob = synth.make_problem(P1 * world, L1 * world, outlier_fraction=0.3 if robust else 0.0)
     partition = None
     if world > 1:
         # landmark ranges cut at super-block boundaries -> partitioned reduced solve (only the separator system is
@@ -193,7 +195,8 @@ def main():
         shard = sharding.whole(prob)
     ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
                   prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting,
-                  shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds), partition=partition)
+                  shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds), partition=partition,
+                  huber_a=huber_a)
     if world > 1:
         sharding.attach_torch_exchange(ba, dist)      # library kernels + collectives on one dedicated torch stream
     st = ba.stats()
@@ -295,7 +298,8 @@ def main():
                                    + ("stereo + Phong intensity + normal residual blocks, 6-D landmark blocks "
                                       f"(position + unit normal), shared_free={args.shared_free}, bounds={bool(args.bounds)}, "
                                       f"strategy={'LM' if args.dogleg < 0 else 'DOGLEG/%d' % args.dogleg}"
-                                      if phong else "reprojection-only LM (Ceres dataset_vo options)")
+                                      if phong else ("reprojection-only LM (Ceres dataset_vo options)"
+                                                     + (", HuberLoss(1.345) on every block, 30 % outlier observations" if robust else "")))
                                    + f", {world} shard(s)",
                        "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
                        "reduced_solve": ("partitioned: chain elimination per rank + separator exchange" if partition is not None
@@ -312,19 +316,19 @@ def main():
             "stats": stats,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost, lighting, args)
+            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost, lighting, args, huber_a)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None):
+def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None, huber_a=0.0):
     """CPU oracle = port with Ceres-equivalent semantics (kind "port"); bounded sample."""
     from oracle import oracle as orc
     cores = min(os.cpu_count() or 1, 16)
     if lighting is None:
-        op = orc.OracleProblem.from_synth(prob)
+        op = orc.OracleProblem.from_synth(prob, huber_a=huber_a)
     else:
         op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
                                prob.stiffness(), lighting=lighting, shared_free=args.shared_free, use_bounds=args.bounds)

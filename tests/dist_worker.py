@@ -24,7 +24,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     P, Lm, T = [int(v) for v in os.environ.get("SSBA_TEST_SIZE", "16,400,6").split(",")]
-    prob = synth.make_problem(P, Lm, track_len=T, seed=21)
+    huber_a = float(os.environ.get("SSBA_TEST_HUBER", "0"))      # with it: 30 % outlier observations (BASELINE.json configs[4])
+    prob = synth.make_problem(P, Lm, track_len=T, seed=21, outlier_fraction=0.3 if huber_a > 0 else 0.0)
     partition = None
     if mode == "gpu_part":      # super-block-aligned landmark ranges + partitioned reduced solve
         ranges, partition = sharding.aligned_partition(prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
@@ -48,7 +49,7 @@ def main():
         from ceres_slam_amd.solver import StereoBA
         torch.cuda.set_device(0)
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition)
+                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a)
         sharding.attach_torch_exchange(ba, dist)
         s, log = ba.solve(capi.default_options(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1))
         res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
