@@ -340,7 +340,25 @@ def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None, huber_a=
     s, log = op.solve(orc.driver_options(**kw))
     dt = time.perf_counter() - t0
     n = max(int(s.num_iterations) - 1, 1)
-    return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+    # also what the reference's evaluation mode costs (Jets instead of closed forms) and the reference's own
+    # thread setting (num_threads = 8, dataset_ba_phong.cpp:81-82) -- bounded samples of the same solve
+    variants = {}
+    if lighting is None:
+        def sample(threads, jets, cap=20):
+            o = orc.OracleProblem.from_synth(prob, huber_a=huber_a)
+            kv = dict(kw, num_threads=threads, max_num_iterations=cap)
+            orc.set_jacobian_mode(1 if jets else 0)
+            try:
+                t = time.perf_counter()
+                sv, _ = o.solve(orc.driver_options(**kv))
+                el = time.perf_counter() - t
+            finally:
+                orc.set_jacobian_mode(0)
+            m = max(int(sv.num_iterations) - 1, 1)
+            return {"value": m / el, "unit": "iters/s", "cores": threads, "ms_per_iter": 1e3 * el / m, "iterations": m}
+        variants["jet_autodiff_jacobians"] = sample(cores, True)
+        variants["closed_form_8_threads"] = sample(min(8, cores), False)
+    return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port", "variants": variants,
             "sample": f"{n} trust-region iterations (termination {int(s.termination_type)}) of the same "
                       f"{prob.num_obs}-observation solve: CPU restatement with Ceres-equivalent semantics, NOT Ceres "
                       f"(OpenMP, {cores} threads, analytic Jacobians, Schur + band Cholesky); {dt:.1f} s",

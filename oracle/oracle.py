@@ -90,6 +90,8 @@ def lib():
         L.orc_project.argtypes = [C.POINTER(Camera), _dp, _dp, _dp]
         L.orc_triangulate.argtypes = [C.POINTER(Camera), _dp, _dp, _dp]
         L.orc_stereo_residual.argtypes = [C.POINTER(Camera), _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_stereo_residual_autodiff.argtypes = [C.POINTER(Camera), _dp, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.orc_set_jacobian_mode.argtypes = [C.c_int]
         L.orc_huber.argtypes = [C.c_double, C.c_double, _dp]
         L.orc_default_options.argtypes = [C.POINTER(Options)]
         L.orc_cost.argtypes = [C.POINTER(Problem), C.c_int]
@@ -322,13 +324,19 @@ def triangulate(camera: dict, uvd, jac: bool = False):
     return (out, J.reshape(3, 3)) if jac else out
 
 
-def stereo_residual(camera: dict, T, p, z, S, jac: bool = False):
+def stereo_residual(camera: dict, T, p, z, S, jac: bool = False, autodiff: bool = False):
+    """autodiff=True: the Jet restatement (what AutoDiffCostFunction + AutoDiffLocalParameterization evaluate)."""
     cam = Camera(**camera)
     r, Jp, Jl = np.zeros(3), np.zeros(18), np.zeros(9)
     args = [np.ascontiguousarray(a, dtype=np.float64) for a in (T, p, z, np.asarray(S).reshape(9))]
-    lib().orc_stereo_residual(C.byref(cam), *[_p(a) for a in args], _p(r),
-                              _p(Jp) if jac else None, _p(Jl) if jac else None)
+    fn = lib().orc_stereo_residual_autodiff if autodiff else lib().orc_stereo_residual
+    fn(C.byref(cam), *[_p(a) for a in args], _p(r), _p(Jp) if jac else None, _p(Jl) if jac else None)
     return (r, Jp.reshape(3, 6), Jl.reshape(3, 3)) if jac else r
+
+
+def set_jacobian_mode(mode: int):
+    """0: closed-form Jacobians (default); 1: every stereo block through the Jet restatement (CPU-baseline timing variant)."""
+    lib().orc_set_jacobian_mode(int(mode))
 
 
 def huber(a: float, s: float):

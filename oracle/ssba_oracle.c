@@ -158,6 +158,78 @@ void orc_stereo_residual(const orc_camera *c, const double T[12], const double p
     }
 }
 
+/* ---- the same block the way the reference pays for it: forward-mode automatic differentiation ------------------
+ * ceres::AutoDiffCostFunction<StereoReprojectionErrorAutomatic, 3, 12, 3> (stereo_reprojection_error.hpp:59-69) runs
+ * the functor (:27-55) on Jets with 12 + 3 = 15 derivative lanes, which yields the AMBIENT Jacobians (3x12 w.r.t. the
+ * stored [t | R] block, 3x3 w.r.t. the point); Ceres then multiplies the pose part by the 12x6 Jacobian of
+ * AutoDiffLocalParameterization<SE3Perturbation, 12, 6> (perturbations.hpp:69-75) at eps = 0.  Restated here with a
+ * plain struct of 1 + 15 doubles so that (i) the CPU baseline can be timed in the reference's evaluation mode and
+ * (ii) the closed forms above are cross-checked against a mechanical derivation (tests/test_oracle_math.py). */
+typedef struct { double v, d[15]; } jet15;
+static inline jet15 jet_var(double v, int k) { jet15 a; a.v = v; for (int i = 0; i < 15; ++i) a.d[i] = 0.0; a.d[k] = 1.0; return a; }
+static inline jet15 jet_add(jet15 a, jet15 b) { for (int i = 0; i < 15; ++i) a.d[i] += b.d[i]; a.v += b.v; return a; }
+static inline jet15 jet_mul(jet15 a, jet15 b) { jet15 c; c.v = a.v * b.v; for (int i = 0; i < 15; ++i) c.d[i] = a.v * b.d[i] + a.d[i] * b.v; return c; }
+static inline jet15 jet_div(jet15 a, jet15 b) {      /* jet.h operator/: a/b with derivative (a' - (a/b) b') / b */
+    jet15 c; const double inv = 1.0 / b.v; c.v = a.v * inv;
+    for (int i = 0; i < 15; ++i) c.d[i] = (a.d[i] - c.v * b.d[i]) * inv;
+    return c;
+}
+static inline jet15 jet_scale(jet15 a, double s) { a.v *= s; for (int i = 0; i < 15; ++i) a.d[i] *= s; return a; }
+static inline jet15 jet_shift(jet15 a, double s) { a.v += s; return a; }
+
+/* d Plus(T, eps) / d eps at eps = 0 for the [t | R row-major] block: exp(eps) T with the reference's first-order branch
+ * (so3group.hpp:277-280, se3group.hpp:323-325): t' = (I + phi^) t + rho, R' = (I + phi^) R  =>  rows of -t^ / -(R col)^. */
+static void se3_plus_jacobian(const double T[12], double P[72]) {
+    memset(P, 0, 72 * sizeof(double));
+    for (int i = 0; i < 3; ++i) P[6 * i + i] = 1.0;
+    const double *t = T, *R = T + 3;
+    /* (phi x a)_i = sum_k (-a^)_{ik} phi_k with -a^ = [[0, a2, -a1], [-a2, 0, a0], [a1, -a0, 0]] */
+    double a[3];
+    for (int blk = 0; blk < 4; ++blk) {
+        if (blk == 0) { a[0] = t[0]; a[1] = t[1]; a[2] = t[2]; }
+        else { a[0] = R[blk - 1]; a[1] = R[3 + blk - 1]; a[2] = R[6 + blk - 1]; }     /* column blk-1 of R */
+        const double na[9] = {0, a[2], -a[1], -a[2], 0, a[0], a[1], -a[0], 0};
+        for (int i = 0; i < 3; ++i) {
+            const int row = blk == 0 ? i : 3 + 3 * i + (blk - 1);       /* t_i, or R_{i, blk-1} in row-major storage */
+            for (int k = 0; k < 3; ++k) P[6 * row + 3 + k] = na[3 * i + k];
+        }
+    }
+}
+
+void orc_stereo_residual_autodiff(const orc_camera *c, const double T[12], const double p[3], const double z[3],
+                                  const double S[9], double r[3], double *Jp, double *Jl) {
+    jet15 Tj[12], pj[3], q[3], pred[3];
+    for (int i = 0; i < 12; ++i) Tj[i] = jet_var(T[i], i);
+    for (int i = 0; i < 3; ++i) pj[i] = jet_var(p[i], 12 + i);
+    for (int i = 0; i < 3; ++i)       /* SE3Group<T>::transform (se3group.hpp:191-193): R p + t */
+        q[i] = jet_add(jet_add(jet_add(jet_mul(Tj[3 + 3 * i], pj[0]), jet_mul(Tj[3 + 3 * i + 1], pj[1])), jet_mul(Tj[3 + 3 * i + 2], pj[2])), Tj[i]);
+    /* StereoCamera::project (stereo_camera.hpp:77-84) */
+    pred[0] = jet_shift(jet_scale(jet_div(q[0], q[2]), c->fu), c->cu);
+    pred[1] = jet_shift(jet_scale(jet_div(q[1], q[2]), c->fv), c->cv);
+    { jet15 one = q[2]; one.v = 1.0; for (int i = 0; i < 15; ++i) one.d[i] = 0.0; pred[2] = jet_scale(jet_div(one, q[2]), c->fu * c->b); }
+    jet15 e[3], rr[3];
+    for (int i = 0; i < 3; ++i) e[i] = jet_shift(pred[i], -z[i]);
+    for (int i = 0; i < 3; ++i) rr[i] = jet_add(jet_add(jet_scale(e[0], S[3 * i]), jet_scale(e[1], S[3 * i + 1])), jet_scale(e[2], S[3 * i + 2]));
+    for (int i = 0; i < 3; ++i) r[i] = rr[i].v;
+    if (Jp) {
+        double P[72];
+        se3_plus_jacobian(T, P);
+        for (int m = 0; m < 3; ++m)
+            for (int col = 0; col < 6; ++col) {
+                double v = 0.0;
+                for (int k = 0; k < 12; ++k) v += rr[m].d[k] * P[6 * k + col];
+                Jp[6 * m + col] = v;
+            }
+    }
+    if (Jl)
+        for (int m = 0; m < 3; ++m)
+            for (int col = 0; col < 3; ++col) Jl[3 * m + col] = rr[m].d[12 + col];
+}
+
+/* 0: closed-form Jacobians (default), 1: the Jet restatement above for every stereo block (timing variant) */
+static int g_jacobian_mode = 0;
+void orc_set_jacobian_mode(int mode) { g_jacobian_mode = mode; }
+
 /* [Ceres 1.x loss_function.cc, HuberLoss::Evaluate; call-site shape
  * tests/dataset_vo_sun.cpp:89-95]  s = |r|^2, b = a^2 */
 void orc_huber(double a, double s, double rho[3]) {
@@ -454,9 +526,9 @@ static double evaluate(const orc_problem *p, const double *poses, const double *
         const double *T = poses + 12 * (int64_t)p->obs_pose[i];
         const int64_t j = (int64_t)p->obs_point[i];
         double r3[3], Jp3[18], Jl3[9];
-        orc_stereo_residual(&p->cam, T, points + 3 * j, p->obs_uvd + 3 * i,
-                            p->obs_stiffness ? p->obs_stiffness + 9 * i : p->stiffness, r3,
-                            wantJ ? Jp3 : NULL, wantJ ? Jl3 : NULL);
+        (g_jacobian_mode && wantJ ? orc_stereo_residual_autodiff : orc_stereo_residual)(
+            &p->cam, T, points + 3 * j, p->obs_uvd + 3 * i, p->obs_stiffness ? p->obs_stiffness + 9 * i : p->stiffness, r3,
+            wantJ ? Jp3 : NULL, wantJ ? Jl3 : NULL);
         double sq = r3[0] * r3[0] + r3[1] * r3[1] + r3[2] * r3[2];
         if (p->huber_a > 0.0) {
             double rho[3];

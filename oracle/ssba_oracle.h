@@ -43,6 +43,11 @@ void orc_triangulate(const orc_camera *c, const double uvd[3], double q[3], doub
 void orc_stereo_residual(const orc_camera *c, const double T[12], const double p[3],
                          const double z[3], const double S[9], double r[3],
                          double *Jp, double *Jl);
+/* the same block evaluated the way ceres::AutoDiffCostFunction + AutoDiffLocalParameterization do (15-lane Jets, then
+ * the 12x6 Plus Jacobian); orc_set_jacobian_mode(1) makes every linearisation use it (CPU-baseline timing variant) */
+void orc_stereo_residual_autodiff(const orc_camera *c, const double T[12], const double p[3], const double z[3],
+                                  const double S[9], double r[3], double *Jp, double *Jl);
+void orc_set_jacobian_mode(int mode);
 /* ceres::HuberLoss::Evaluate */
 void orc_huber(double a, double s, double rho[3]);
 

@@ -132,6 +132,35 @@ def test_jacobian_equals_ceres_chain_global_times_plus_jacobian():
     np.testing.assert_allclose(Jp, Jglobal @ plusJ, rtol=1e-12, atol=1e-11)
 
 
+def test_jet_restatement_of_the_autodiff_block_matches_the_closed_forms():
+    """The 15-lane Jet evaluation of the functor + the 12x6 Plus Jacobian (what AutoDiffCostFunction<..., 3, 12, 3> and
+    AutoDiffLocalParameterization<SE3Perturbation, 12, 6> compute) against the closed-form block, and a whole solve run
+    in that mode against the default one."""
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        T = synth.pose_pack(rng.normal(size=3), synth.so3_exp(rng.normal(size=3) * 0.7))
+        q = np.array([rng.uniform(-5, 5), rng.uniform(-2, 2), rng.uniform(4, 30)])
+        t, R = synth.pose_unpack(T)
+        p = R.T @ (q - t)
+        z = synth.project(CAM, q) + rng.normal(size=3)
+        A = rng.normal(size=(3, 3))
+        S = np.linalg.inv(np.linalg.cholesky(A @ A.T + np.eye(3))).T
+        r, Jp, Jl = orc.stereo_residual(CAM, T, p, z, S, jac=True)
+        r2, Jp2, Jl2 = orc.stereo_residual(CAM, T, p, z, S, jac=True, autodiff=True)
+        np.testing.assert_allclose(r2, r, rtol=1e-13, atol=1e-12)
+        np.testing.assert_allclose(Jp2, Jp, rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(Jl2, Jl, rtol=1e-12, atol=1e-10)
+    prob = synth.make_problem(12, 300, track_len=6, seed=5)
+    s1, log1 = orc.OracleProblem.from_synth(prob).solve(orc.driver_options(num_threads=2))
+    orc.set_jacobian_mode(1)
+    try:
+        s2, log2 = orc.OracleProblem.from_synth(prob).solve(orc.driver_options(num_threads=2))
+    finally:
+        orc.set_jacobian_mode(0)
+    assert s2.num_iterations == s1.num_iterations
+    np.testing.assert_allclose(log2["cost"], log1["cost"], rtol=1e-10)
+
+
 def test_huber_rho_and_corrector_gradient_identity():
     a = 1.345                                  # scripts/ba_all_devon.sh:86
     for s in (0.0, 0.5, a * a, a * a + 1e-9, 10.0, 1e4):
