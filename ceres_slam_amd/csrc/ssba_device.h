@@ -230,6 +230,27 @@ static __device__ __forceinline__ double fast_rsqrt(double a) {
     r = r * (1.5 - 0.5 * a * r * r);
     return r;
 }
+// M = L^-1 (lower triangular: m00, m10, m11, m20, m21, m22) of the damped 3x3 landmark block C = L L^T, so that
+// C^-1 = M^T M: W C^-1 W^T = (W M^T)(W M^T)^T is a symmetric product of ONE factor (k_schur_windows)
+static __device__ __forceinline__ bool chol3_inv_fast(const double h[6], const double dmp[3], double m[6]) {
+    const double c00 = h[0] + dmp[0], c11 = h[3] + dmp[1], c22 = h[5] + dmp[2];
+    if (!(c00 > 0.0)) return false;
+    const double m00 = fast_rsqrt(c00);
+    const double l10 = h[1] * m00, l20 = h[2] * m00;
+    const double d1 = c11 - l10 * l10;
+    if (!(d1 > 0.0)) return false;
+    const double m11 = fast_rsqrt(d1);
+    const double l21 = (h[4] - l20 * l10) * m11;
+    const double d2 = c22 - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return false;
+    const double m22 = fast_rsqrt(d2);
+    const double m10 = -l10 * m00 * m11;
+    m[0] = m00; m[1] = m10; m[2] = m11;
+    m[4] = -l21 * m11 * m22;
+    m[3] = -(l20 * m00 + l21 * m10) * m22;
+    m[5] = m22;
+    return true;
+}
 // inverse of the damped 3x3 landmark block, Cholesky based, reciprocal square roots only
 static __device__ __forceinline__ bool inv3_spd_fast(const double h[6], const double dmp[3], double Ci[6]) {
     const double c00 = h[0] + dmp[0], c11 = h[3] + dmp[1], c22 = h[5] + dmp[2];

@@ -220,40 +220,49 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
     }
 }
 
-// Schur complement contributions, output-stationary: one 256-thread block per work item (a
-// window or a slice of it).  Batches of 21 landmarks are half-linearised by 252 (landmark, slot)
-// producer lanes -- W = J_p^T J_l and Y = W C^-1 are recomputed from the observation, never
-// stored in HBM -- and staged through LDS; the consumers are the 78 pose pairs (sa <= sb) of the
-// window times a 3-way split of the batch (234 lanes), each lane keeping its 6x6 partial of
-// sum_j Y_aj W_bj^T in registers for the whole item.  The three partials are combined in a fixed
-// order at the end: one slab (78 blocks + 12 rhs vectors) per item, no float atomics.
+// Schur complement contributions, output-stationary on the fp64 matrix cores: one 256-thread block per work item (a
+// window or a slice of it).  Batches of 21 landmarks are half-linearised by 252 (landmark, slot) producer lanes --
+// W = J_p^T J_l is recomputed from the observation, never stored in HBM.  With C^-1 = M^T M (M = L^-1 of the damped
+// landmark block) the contribution W_a C^-1 W_b^T is the SYMMETRIC product Z_a Z_b^T of one factor Z = W M^T, so one
+// k-major matrix  Zm[k][col]  is staged in LDS: k = 3*landmark + c (63 per batch + one zero row), col = 6*slot + dof
+// (72, padded to 80); column 72 carries u = M g_l, so the reduced gradient sum_j Z u falls out of the same product.
+//     S[72 x 73] += Zm^T Zm
+// is accumulated by the four waves with v_mfma_f64_16x16x4_f64: the 15 upper 16x16 tiles of the 5 x 5 tile grid, 4 / 4 /
+// 4 / 3 per wave, accumulators resident in registers for the whole item.  (The fp64 MFMA pipe runs at its full rate from
+// ONE wave per SIMD and dependent accumulation costs nothing extra, but it IS the fp64 VALU datapath -- an MFMA wave and
+// an FMA wave on one SIMD take the sum of their times: tools/fp64_calib.hip.)  Every entry is one sum in landmark
+// order: deterministic, no partials, no float atomics.
+// Operand / result layout of the instruction (cdna_hip_programming.md): A[i = lane & 15][k = lane >> 4],
+// B[k = lane >> 4][j = lane & 15], D[row = (lane >> 4) + 4 * reg][col = lane & 15].
 constexpr int SCHUR_THREADS = 256;
-constexpr int SCHUR_BATCH = 21;   // 21 landmarks x 12 slots = 252 producer lanes
-constexpr int SCHUR_SPLIT = 3;    // 78 pairs x 3 = 234 consumer lanes, 7 landmarks each per batch
-constexpr int WY_STRIDE = 38;     // 36 doubles + 2 pad: 304 B, keeps 16-byte alignment
-constexpr int SCHUR_LDS_DOUBLES = SCHUR_BATCH * TW * WY_STRIDE + SCHUR_BATCH * 4;
+constexpr int SCHUR_BATCH = 21;                  // landmarks per batch: 21 x 12 slots = 252 producer lanes
+constexpr int SCHUR_KB = 64;                     // 63 factor rows + one zero row = 16 MFMA steps of k = 4
+constexpr int SCHUR_RS = 80;                     // row stride of Zm: 5 tiles; 80 % 32 = 16 keeps the half-wave reads conflict-free
+constexpr int SCHUR_LDS_DOUBLES = SCHUR_KB * SCHUR_RS;     // 40 960 B
+typedef double schur_d4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     extern __shared__ __align__(16) double schur_lds[];
-    double *sWY = schur_lds;                                   // [li][slot][ W(18) | Y(18) | pad ]
-    double *sGL = schur_lds + SCHUR_BATCH * TW * WY_STRIDE;    // [li][4]
+    double *sZ = schur_lds;                              // [k][col]
     const int item = blockIdx.x;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool producer = t < SCHUR_BATCH * TW;
     const int li = t / TW, s = t - li * TW;
-    const bool consumer = t < NPAIR * SCHUR_SPLIT;
-    const int grp = t / NPAIR, pr = t - grp * NPAIR;          // landmark residue class, pair
-    const int pa = consumer ? c_pair_a[pr] : 0;
-    const int pb = consumer ? c_pair_b[pr] : 0;
-    double acc[36], racc[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) racc[i] = 0.0;
+    // tiles (ti <= tj) of this wave; wave 3 has three
+    const int ti0 = wv == 0 ? 0 : wv == 1 ? 0 : wv == 2 ? 1 : 3, tj0 = wv == 0 ? 0 : wv == 1 ? 4 : wv == 2 ? 4 : 3;
+    const int ti1 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 3, tj1 = wv == 0 ? 1 : wv == 1 ? 1 : wv == 2 ? 2 : 4;
+    const int ti2 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj2 = wv == 0 ? 2 : wv == 1 ? 2 : wv == 2 ? 3 : 4;
+    const int ti3 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj3 = wv == 0 ? 3 : wv == 1 ? 3 : wv == 2 ? 4 : 4;
+    const bool has3 = wv != 3;
+    schur_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+
+    // padding columns 73..79 and the zero row k = 63 stay zero for the whole item (column 72 is rewritten every batch)
+    for (int e = t; e < SCHUR_KB * 8; e += SCHUR_THREADS) sZ[(e >> 3) * SCHUR_RS + 72 + (e & 7)] = 0.0;
+    if (t < SCHUR_RS) sZ[(SCHUR_KB - 1) * SCHUR_RS + t] = 0.0;
 
     bool pose_ok = false;
     double T[12];
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
     }
 
     // Raw inputs of this lane's (landmark, slot) for the NEXT batch are fetched from HBM while the
-    // consumers work on the current one (the loads stay in flight across the barrier and are only
+    // matrix phase works on the current one (the loads stay in flight across the barrier and are only
     // waited for at the top of the next producer phase).
     struct Raw { double u, v, dd, h[6], sc[3], p[3], g[3]; uint32_t mask; bool in_range; } raw;
     auto prefetch = [&](int l0) {
@@ -292,27 +301,30 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
 
     for (int l0 = lb; l0 < le; l0 += SCHUR_BATCH) {
         if (producer) {
-            double *dst = sWY + (li * TW + s) * WY_STRIDE;
+            double z[18];       // [c][a]: three runs of six contiguous doubles in the k-major matrix
+            double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             bool live = false;
-            if (s == 0) {
-                sGL[li * 4 + 0] = raw.in_range ? raw.g[0] : 0.0;
-                sGL[li * 4 + 1] = raw.in_range ? raw.g[1] : 0.0;
-                sGL[li * 4 + 2] = raw.in_range ? raw.g[2] : 0.0;
-            }
-            if (raw.in_range && pose_ok && ((raw.mask >> s) & 1u)) {
-                live = true;
-                double dmp[3], Ci[6];
+            if (raw.in_range) {
+                double dmp[3];
                 const double hd[3] = {raw.h[0], raw.h[3], raw.h[5]};
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
                     const double s2 = raw.sc[c] * raw.sc[c];
                     dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
                 }
-                if (!inv3_spd_fast(raw.h, dmp, Ci)) {
+                if (!chol3_inv_fast(raw.h, dmp, m)) {
                     d.st->step_failed = 1;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) Ci[c] = 0.0;
+                    for (int c = 0; c < 6; ++c) m[c] = 0.0;
                 }
+            }
+            if (s == 0) {       // u = M g_l
+                sZ[(li * 3 + 0) * SCHUR_RS + 72] = raw.in_range ? m[0] * raw.g[0] : 0.0;
+                sZ[(li * 3 + 1) * SCHUR_RS + 72] = raw.in_range ? m[1] * raw.g[0] + m[2] * raw.g[1] : 0.0;
+                sZ[(li * 3 + 2) * SCHUR_RS + 72] = raw.in_range ? m[3] * raw.g[0] + m[4] * raw.g[1] + m[5] * raw.g[2] : 0.0;
+            }
+            if (raw.in_range && pose_ok && ((raw.mask >> s) & 1u)) {
+                live = true;
                 ObsLin o;
                 obs_linearize(d, T, raw.p[0], raw.p[1], raw.p[2], raw.u, raw.v, raw.dd, o);
                 double Jp[18], Jl[9];
@@ -320,87 +332,62 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
                 jac_point(o, T, Jl);
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
-                    double w[3];
+                    double wa[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        w[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
-                    dst[3 * a + 0] = w[0];
-                    dst[3 * a + 1] = w[1];
-                    dst[3 * a + 2] = w[2];
-                    dst[18 + 3 * a + 0] = w[0] * Ci[0] + w[1] * Ci[1] + w[2] * Ci[2];
-                    dst[18 + 3 * a + 1] = w[0] * Ci[1] + w[1] * Ci[3] + w[2] * Ci[4];
-                    dst[18 + 3 * a + 2] = w[0] * Ci[2] + w[1] * Ci[4] + w[2] * Ci[5];
+                        wa[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
+                    z[a] = wa[0] * m[0];                                      // Z = W M^T
+                    z[6 + a] = wa[0] * m[1] + wa[1] * m[2];
+                    z[12 + a] = wa[0] * m[3] + wa[1] * m[4] + wa[2] * m[5];
                 }
             }
             if (!live) {
 #pragma unroll
-                for (int i = 0; i < 36; ++i) dst[i] = 0.0;
+                for (int i = 0; i < 18; ++i) z[i] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double2 *dz = reinterpret_cast<double2 *>(sZ + (li * 3 + c) * SCHUR_RS + s * 6);     // 48-byte runs, 16-byte aligned
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dz[q] = make_double2(z[6 * c + 2 * q], z[6 * c + 2 * q + 1]);
             }
         }
         __syncthreads();
         prefetch(l0 + SCHUR_BATCH);
-        if (consumer) {
-            const int nb = min(SCHUR_BATCH, le - l0);
-            for (int j = grp; j < nb; j += SCHUR_SPLIT) {
-                const double2 *Y2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pa) * WY_STRIDE + 18);
-                const double2 *W2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pb) * WY_STRIDE);
-                double y[18];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const double2 av = Y2[i];
-                    y[2 * i] = av.x; y[2 * i + 1] = av.y;
-                }
-                // W in two halves (3 columns of the block each) to keep the register footprint below
-                // the 2-waves-per-SIMD limit; three chained FMAs per output (the compiler does not
-                // re-associate `acc += a*b + c*d + e*f`, which costs a mul and an add per output)
-#pragma unroll
-                for (int hc = 0; hc < 2; ++hc) {
-                    double w[10];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {   // doubles 9*hc-1 .. : read 5 aligned pairs covering w[9*hc .. 9*hc+8]
-                        const double2 bv = W2[(9 * hc) / 2 + i];
-                        w[2 * i] = bv.x; w[2 * i + 1] = bv.y;
-                    }
-                    const int off = (9 * hc) & 1;   // 0 for the first half, 1 for the second (9 is odd)
-#pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int cc = 3 * hc + c;
-                            acc[6 * a + cc] = fma(y[3 * a + 2], w[off + 3 * c + 2],
-                                                  fma(y[3 * a + 1], w[off + 3 * c + 1], fma(y[3 * a], w[off + 3 * c], acc[6 * a + cc])));
-                        }
-                }
-                if (pa == pb) {
-                    const double g0 = sGL[j * 4], g1 = sGL[j * 4 + 1], g2 = sGL[j * 4 + 2];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) racc[a] = fma(y[3 * a + 2], g2, fma(y[3 * a + 1], g1, fma(y[3 * a], g0, racc[a])));
-                }
+        {
+            const int kq = lane >> 4, i = lane & 15;
+#pragma unroll 4
+            for (int ks = 0; ks < SCHUR_KB / 4; ++ks) {
+                const double *zr = sZ + (4 * ks + kq) * SCHUR_RS + i;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti0], zr[16 * tj0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti1], zr[16 * tj1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti2], zr[16 * tj2], acc2, 0, 0, 0);
+                if (has3) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti3], zr[16 * tj3], acc3, 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    // combine the three landmark classes in a fixed order: ((g0 + g1) + g2)
-    double *part = schur_lds;    // 2 x 78 x 42 doubles = 52 KB <= staging area
-    if (consumer && grp > 0) {
-        double *o = part + ((grp - 1) * NPAIR + pr) * 42;
+    // one slab (78 blocks + 12 rhs vectors) per item.  Diagonal pair blocks are symmetric: the upper entry (row <= col,
+    // always inside a computed tile) is written to both positions.
+    auto store_tile = [&](const schur_d4 &acc, int ti, int tj) {
+        const int col = 16 * tj + (lane & 15);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) o[i] = acc[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) o[36 + i] = racc[i];
-    }
-    __syncthreads();
-    if (consumer && grp == 0) {
-        const double *p1 = part + pr * 42, *p2 = part + (NPAIR + pr) * 42;
-        double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)pr * 36;
-#pragma unroll
-        for (int i = 0; i < 36; ++i) out[i] = (acc[i] + p1[i]) + p2[i];
-        if (pa == pb) {
-            double *ro = d.slab + (size_t)item * SLAB_DOUBLES + NPAIR * 36 + pa * 6;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) ro[a] = (racc[a] + p1[36 + a]) + p2[36 + a];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + (lane >> 4) + 4 * r;
+            if (row >= 72) continue;
+            const int a = row / 6, ra = row - 6 * a;
+            if (col == 72) { d.slab[(size_t)item * SLAB_DOUBLES + NPAIR * 36 + row] = acc[r]; continue; }
+            if (col > 72 || col < row) continue;
+            const int b = col / 6, cb = col - 6 * b;
+            double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)(a * TW - (a * (a - 1)) / 2 + (b - a)) * 36;
+            out[ra * 6 + cb] = acc[r];
+            if (a == b) out[cb * 6 + ra] = acc[r];
         }
-    }
+    };
+    store_tile(acc0, ti0, tj0);
+    store_tile(acc1, ti1, tj1);
+    store_tile(acc2, ti2, tj2);
+    if (has3) store_tile(acc3, ti3, tj3);
 }
 
 __device__ __forceinline__ int tri21(int r, int c) {   // packed upper index, r <= c

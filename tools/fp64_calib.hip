@@ -24,6 +24,52 @@ __global__ void k_fma_tp(double *out, int iters, double a, double b) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// v_mfma_f64_16x16x4_f64: D(16x16) += A(16x4) B(4x16); per lane 1 double of A, 1 of B, 4 of C/D; 2048 flop per instruction
+typedef double d4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ void k_mfma_tp(double *out, int iters, double a, double b) {
+    d4 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{threadIdx.x * 1e-9, 1.0 * i, 0.0, 0.0};
+    const double av = a + threadIdx.x * 1e-12, bv = b;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// do the fp64 MFMA pipe and the fp64 VALU overlap?  Two waves per SIMD: even waves issue MFMAs, odd waves FMAs.
+__global__ void k_mixed(double *out, int iters_mfma, int iters_fma, double a, double b) {
+    const int wv = threadIdx.x >> 6;
+    double s = 0;
+    if ((wv >> 2) == 0) {       // waves 0..3: one per SIMD
+        d4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = d4{threadIdx.x * 1e-9, 1.0 * i, 0.0, 0.0};
+        for (int it = 0; it < iters_mfma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {                    // waves 4..7: the second wave of every SIMD
+        double acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+        for (int it = 0; it < iters_fma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fma(acc[i], a, b);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += acc[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 // one wave: cycles per dependent op
 template <int OP>
 __global__ void k_chain(double *out, long long *cyc, int iters, double a, double b) {
@@ -79,6 +125,26 @@ int main() {
         float ms = time_ms([&] { hipLaunchKernelGGL(k_fma_tp<8>, blocks, threads, 0, 0, out, iters, 1.0000001, 1e-9); }, 3);
         double fl = 2.0 * 8 * iters * (double)threads * blocks;
         printf("fp64 FMA throughput, %d wave(s)/SIMD, 8 indep acc: %.1f TFLOP/s (%.3f ms)\n", wps, fl / ms / 1e9, ms);
+    }
+    for (int wps : {1, 2}) {
+        int threads = 256 * wps, blocks = 256;
+        const int it2 = 4000;
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma_tp<4>, blocks, threads, 0, 0, out, it2, 1.0000001, 1e-9); }, 3);
+        double fl = 2048.0 * 4 * it2 * (double)(threads / 64) * blocks;
+        printf("fp64 MFMA 16x16x4 throughput, %d wave(s)/SIMD, 4 indep acc: %.1f TFLOP/s (%.3f ms)\n", wps, fl / ms / 1e9, ms);
+    }
+    {
+        // alone: 4000 x 4 MFMAs take t_m, 26000 x 8 FMAs take t_f (one wave per SIMD each); together: max() if the pipes overlap, sum if shared
+        float tm = time_ms([&] { hipLaunchKernelGGL(k_mixed, 256, 512, 0, 0, out, 4000, 0, 1.0000001, 1e-9); }, 3);
+        float tf = time_ms([&] { hipLaunchKernelGGL(k_mixed, 256, 512, 0, 0, out, 0, 13000, 1.0000001, 1e-9); }, 3);
+        float tb = time_ms([&] { hipLaunchKernelGGL(k_mixed, 256, 512, 0, 0, out, 4000, 13000, 1.0000001, 1e-9); }, 3);
+        printf("fp64 MFMA wave + fp64 FMA wave on every SIMD: MFMA alone %.3f ms, FMA alone %.3f ms, together %.3f ms (sum %.3f)\n", tm, tf, tb, tm + tf);
+    }
+    {
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_mfma_tp<4>, 1, 64, 0, 0, out, 4000, 1.0000001, 1e-9); }, 3);
+        printf("one wave, 4 indep MFMA 16x16x4 chains: %.2f ns per MFMA (%.1f flop/ns)\n", ms * 1e6 / (4.0 * 4000), 2048.0 / (ms * 1e6 / (4.0 * 4000)));
+        ms = time_ms([&] { hipLaunchKernelGGL(k_mfma_tp<1>, 1, 64, 0, 0, out, 4000, 1.0000001, 1e-9); }, 3);
+        printf("one wave, 1 dependent MFMA 16x16x4 chain: %.2f ns per MFMA\n", ms * 1e6 / 4000.0);
     }
     {
         float ms = time_ms([&] { hipLaunchKernelGGL(k_fma_tp<8>, 1, 64, 0, 0, out, iters, 1.0000001, 1e-9); }, 3);
