@@ -1252,8 +1252,8 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dzero(p, &d.dn_W, dn_obs_pose.size() * (ph ? 36 : 18))); TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * (ph ? 36 : 18)));
         TRY(dzero(p, &d.dn_S, (size_t)(d.dn_pad + DN_BS) * std::max(d.dn_pad, DN_BS)));
     }
-    TRY(dzero(p, &d.part_lin, (size_t)d.n_lm_blocks * 4));
-    TRY(dzero(p, &d.part_eval, (size_t)d.n_lm_blocks * 4));
+    TRY(dzero(p, &d.part_lin, (size_t)d.n_groups * 4));       // one entry per block of 256 landmarks, or per group of 64 (window layout)
+    TRY(dzero(p, &d.part_eval, (size_t)d.n_groups * 4));
     TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * NPP));   // + one entry for the border of shared blocks
     TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks + 1) * NDL));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));

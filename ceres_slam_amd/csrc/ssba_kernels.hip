@@ -220,6 +220,91 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
     }
 }
 
+// Window layout, four lanes per landmark: one block = one group of 64 landmarks (the ELL unit), wave w takes the slots
+// w, w + 4, w + 8 of every landmark, so the loads stay coalesced (lane = landmark) and the poses of a wave are
+// broadcast reads, but four times as many waves hide the dependent fp64 chains of the linearisation.  The four
+// partial sums per landmark are combined through LDS in a fixed order by wave 0.
+constexpr int LMW_SPLIT = 4;
+__global__ __launch_bounds__(256) void k_linearize_landmarks_w(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    __shared__ double sm[4];
+    __shared__ double red[LMW_SPLIT - 1][10][LMG];
+    const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
+    const int l = blockIdx.x * LMG + li;
+    const uint32_t mask = d.lm_mask[l];
+    const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+    double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, cost = 0.0;
+    if (mask) {
+        const LmObs<false> ob(d, l, mask);
+        for (int s = w; s < TW; s += LMW_SPLIT) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
+            const double *T = d.poses + (size_t)k * 12;
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            double Jl[9];
+            jac_point(o, T, Jl);
+            cost += o.half_rho;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                h[0] += Jl[3 * i] * Jl[3 * i];
+                h[1] += Jl[3 * i] * Jl[3 * i + 1];
+                h[2] += Jl[3 * i] * Jl[3 * i + 2];
+                h[3] += Jl[3 * i + 1] * Jl[3 * i + 1];
+                h[4] += Jl[3 * i + 1] * Jl[3 * i + 2];
+                h[5] += Jl[3 * i + 2] * Jl[3 * i + 2];
+                g[0] += Jl[3 * i] * o.r[i];
+                g[1] += Jl[3 * i + 1] * o.r[i];
+                g[2] += Jl[3 * i + 2] * o.r[i];
+            }
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) red[w - 1][c][li] = h[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) red[w - 1][6 + c][li] = g[c];
+        red[w - 1][9][li] = cost;
+    }
+    __syncthreads();
+    double xn = 0.0, gm = 0.0;
+    if (w == 0) {
+#pragma unroll
+        for (int q = 0; q < LMW_SPLIT - 1; ++q) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) h[c] += red[q][c][li];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] += red[q][6 + c][li];
+            cost += red[q][9][li];
+        }
+        if (mask) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) d.hll[(size_t)c * d.Lpad + l] = h[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d.gl[(size_t)c * d.Lpad + l] = g[c];
+            if (st.iteration == 0) {   // Jacobi scaling, computed once [trust_region_minimizer.cc]
+                const double hd[3] = {h[0], h[3], h[5]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    d.sl[(size_t)c * d.Lpad + l] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(hd[c])) : 1.0;
+            }
+            xn = px * px + py * py + pz * pz;
+            gm = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
+        }
+    } else {
+        cost = 0.0;
+    }
+    const double c0 = block_sum(cost, sm);
+    const double c1 = block_sum(xn, sm);
+    const double c2 = block_max(gm, sm);
+    if (threadIdx.x == 0) {
+        d.part_lin[blockIdx.x * 4 + 0] = c0;
+        d.part_lin[blockIdx.x * 4 + 1] = c1;
+        d.part_lin[blockIdx.x * 4 + 2] = c2;
+    }
+}
+
 // Schur complement contributions, output-stationary on the fp64 matrix cores: one 256-thread block per work item (a
 // window or a slice of it).  Batches of 21 landmarks are half-linearised by 252 (landmark, slot) producer lanes --
 // W = J_p^T J_l is recomputed from the observation, never stored in HBM.  With C^-1 = M^T M (M = L^-1 of the damped
@@ -789,6 +874,106 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
 }
 
 
+// The same pass in the window layout with four lanes per landmark (see k_linearize_landmarks_w): wave w takes the slots
+// w, w + 4, w + 8; the partial sums of W^T delta_p and of the model-cost terms meet in LDS, every lane then forms
+// delta_l itself (fixed order, so the four lanes of a landmark hold identical candidates) and evaluates the candidate
+// cost of its own slots.
+__global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    __shared__ double red[LMW_SPLIT][5][LMG];
+    const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
+    const int l = blockIdx.x * LMG + li;
+    const uint32_t mask = d.lm_mask[l];
+    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
+    const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+    double nx = px, ny = py, nz = pz;
+    const bool act = mask && !st.step_failed;
+    const LmObs<false> ob(d, l, mask);
+    double tp[3] = {0.0, 0.0, 0.0}, er = 0.0, ee = 0.0;
+    if (act) {
+        for (int s = w; s < TW; s += LMW_SPLIT) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
+            const int f = d.pose_free[k];
+            if (f < 0) continue;
+            const double *T = d.poses + (size_t)k * 12;
+            ObsLin o;
+            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            double Jp[18], Jl[9], jd[3];
+            jac_pose(o, Jp);
+            jac_point(o, T, Jl);
+            const double *dp = d.x0 + (size_t)f * 6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                jd[i] = 0.0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
+                er += jd[i] * o.r[i];
+                ee += jd[i] * jd[i];
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tp[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+        }
+    }
+    red[w][0][li] = tp[0]; red[w][1][li] = tp[1]; red[w][2][li] = tp[2]; red[w][3][li] = er; red[w][4][li] = ee;
+    __syncthreads();
+    if (act) {
+        const double gl[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
+        double tt[3] = {gl[0], gl[1], gl[2]};
+        er = 0.0; ee = 0.0;
+#pragma unroll
+        for (int q = 0; q < LMW_SPLIT; ++q) {
+            tt[0] += red[q][0][li]; tt[1] += red[q][1][li]; tt[2] += red[q][2][li];
+            er += red[q][3][li]; ee += red[q][4][li];
+        }
+        double h[6], dmp[3], Ci[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
+        landmark_damping(d, st, l, h, dmp);
+        double dl[3] = {0, 0, 0};
+        if (inv3_spd(h, dmp, Ci)) {
+            dl[0] = -(Ci[0] * tt[0] + Ci[1] * tt[1] + Ci[2] * tt[2]);
+            dl[1] = -(Ci[1] * tt[0] + Ci[3] * tt[1] + Ci[4] * tt[2]);
+            dl[2] = -(Ci[2] * tt[0] + Ci[4] * tt[1] + Ci[5] * tt[2]);
+        } else if (w == 0) {
+            nonfinite = 1.0;
+        }
+        if (w == 0 && (!isfinite(dl[0]) || !isfinite(dl[1]) || !isfinite(dl[2]))) nonfinite = 1.0;
+        nx = px + dl[0]; ny = py + dl[1]; nz = pz + dl[2];
+        if (w == 0) {
+            dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2];
+            const double hd0 = h[0] * dl[0] + h[1] * dl[1] + h[2] * dl[2], hd1 = h[1] * dl[0] + h[3] * dl[1] + h[4] * dl[2],
+                         hd2 = h[2] * dl[0] + h[4] * dl[1] + h[5] * dl[2];
+            const double dg = dl[0] * gl[0] + dl[1] * gl[1] + dl[2] * gl[2];
+            const double dt = dl[0] * (tt[0] - gl[0]) + dl[1] * (tt[1] - gl[1]) + dl[2] * (tt[2] - gl[2]);
+            mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + (dl[0] * hd0 + dl[1] * hd1 + dl[2] * hd2));
+        }
+        for (int s = w; s < TW; s += LMW_SPLIT) {
+            if (!ob.has(s)) continue;
+            const uint32_t k = ob.pose(d, s);
+            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
+        }
+    }
+    if (w == 0) {
+        d.cand_pts[l] = nx;
+        d.cand_pts[(size_t)d.Lpad + l] = ny;
+        d.cand_pts[2 * (size_t)d.Lpad + l] = nz;
+    }
+    const double a = block_sum(ccost, sm);
+    const double b = block_sum(mcc, sm);
+    const double c = block_sum(dn, sm);
+    const double e = block_sum(nonfinite, sm);
+    if (threadIdx.x == 0) {
+        d.part_eval[blockIdx.x * 4 + 0] = a;
+        d.part_eval[blockIdx.x * 4 + 1] = b;
+        d.part_eval[blockIdx.x * 4 + 2] = c;
+        d.part_eval[blockIdx.x * 4 + 3] = e;
+    }
+}
+
+
 // ------------------------------------------------------------------- dogleg ---
 // TRADITIONAL_DOGLEG [Ceres 1.x dogleg_strategy.cc] in unscaled coordinates.  With the Jacobi
 // scale s and D^2 = clamp(s^2 diag(J^T J)):  gradient_ = s g / D,  Gauss-Newton step (D-scaled) =
@@ -1146,12 +1331,12 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
 
 // Sums the per-block partials of the linearisation into the exchange scalars
 // scal[0] = cost, scal[1] = |x_points|^2 and gmax_l (fixed order, one block).
-__global__ __launch_bounds__(256) void k_reduce_lin(Dev d) {
+__global__ __launch_bounds__(256) void k_reduce_lin(Dev d, int n_parts) {
     State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     __shared__ double sm[4];
     double a = 0.0, b = 0.0, c = 0.0;
-    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+    for (int i = threadIdx.x; i < n_parts; i += 256) {
         a += d.part_lin[i * 4];
         b += d.part_lin[i * 4 + 1];
         c = fmax(c, d.part_lin[i * 4 + 2]);
@@ -1170,12 +1355,12 @@ __global__ __launch_bounds__(256) void k_reduce_lin(Dev d) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_eval(Dev d) {
+__global__ __launch_bounds__(256) void k_reduce_eval(Dev d, int n_parts) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
     double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
-    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+    for (int i = threadIdx.x; i < n_parts; i += 256) {
         a += d.part_eval[i * 4];
         b += d.part_eval[i * 4 + 1];
         c += d.part_eval[i * 4 + 2];
@@ -1470,10 +1655,11 @@ void launch_linearize(Launcher &L, const Dev &d) {
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+        if (d.dense) LAUNCH(KC_LIN_LM, k_linearize_landmarks<true>, dim3(d.n_lm_blocks), dim3(256), 0, d);
+        else LAUNCH(KC_LIN_LM, k_linearize_landmarks_w, dim3(d.n_groups), dim3(256), 0, d);
         LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
     }
-    LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, (d.phong || d.dense) ? d.n_lm_blocks : d.n_groups);
 }
 
 void launch_schur(Launcher &L, const Dev &d) {
@@ -1504,8 +1690,9 @@ void launch_finish_check(Launcher &L, const Dev &d) {
 void launch_update_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_backsub_eval(L, d);
-    else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
+    else if (d.dense) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval<true>, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    else LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, (d.phong || d.dense) ? d.n_lm_blocks : d.n_groups);
 }
 
 void launch_sep_pack(Launcher &L, const Dev &d) {
@@ -1540,7 +1727,7 @@ void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_dogleg_eval(L, d);
     else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_eval<true> : k_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks);
 }
 
 void launch_decide_commit(Launcher &L, const Dev &d) {
