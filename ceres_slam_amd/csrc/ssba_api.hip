@@ -1055,7 +1055,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dzero(p, &d.sh, (size_t)d.nsh)); TRY(dzero(p, &d.cand_sh, (size_t)d.nsh));
         TRY(dzero(p, &d.best_sh, (size_t)d.nsh)); TRY(dzero(p, &d.init_sh, (size_t)d.nsh));
         p->h_sh.assign((size_t)d.nsh, 0.0);
-        TRY(dzero(p, &d.cinv, (size_t)Lpad * 21)); TRY(dzero(p, &d.dlm, (size_t)Lpad * 6));
+        TRY(dzero(p, &d.cinv, (size_t)Lpad * 21)); TRY(dzero(p, &d.cfac, (size_t)Lpad * 21)); TRY(dzero(p, &d.dlm, (size_t)Lpad * 6));
         TRY(dupload(p, &d.pose_mat_start, dense ? dn_pose_mat_start : pose_mat_start));
         if (d.nb) {
             TRY(dzero(p, &d.lmV, (size_t)Lpad * 42)); TRY(dzero(p, &d.lmH, (size_t)Lpad * 28)); TRY(dzero(p, &d.lmG, (size_t)Lpad * 7));

@@ -161,7 +161,7 @@ __device__ __forceinline__ int tri6(int r, int c) { return r * 6 - (r * (r - 1))
 
 // inverse of the damped 6x6 landmark block (packed upper h[21], diagonal damping dmp[6]) through its
 // Cholesky factor; result packed upper Ci[21].  false on breakdown.
-static __device__ __forceinline__ bool inv6_spd(const double h[21], const double dmp[6], double Ci[21]) {
+static __device__ __forceinline__ bool inv6_spd(const double h[21], const double dmp[6], double Ci[21], double *Mo = nullptr) {
     double L[6][6], M[6][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -198,6 +198,12 @@ static __device__ __forceinline__ bool inv6_spd(const double h[21], const double
             for (int k = b; k < 6; ++k) s += M[k][a] * M[k][b];
             Ci[tri6(a, b)] = s;
         }
+    if (Mo) {       // M = L^-1, packed lower, row-major: C^-1 = M^T M
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Mo[i * (i + 1) / 2 + j] = M[i][j];
+    }
     return true;
 }
 
@@ -223,22 +229,22 @@ __global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const int l = blockIdx.x * 256 + threadIdx.x;
-    double Ci[21];
+    double Ci[21], Mf[21];
 #pragma unroll
-    for (int c = 0; c < 21; ++c) Ci[c] = 0.0;
+    for (int c = 0; c < 21; ++c) { Ci[c] = 0.0; Mf[c] = 0.0; }
     if (d.lm_mask[l]) {
         double h[21], dmp[6];
 #pragma unroll
         for (int c = 0; c < 21; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
         ph_damping(d, st, l, h, dmp);
-        if (!inv6_spd(h, dmp, Ci)) {
+        if (!inv6_spd(h, dmp, Ci, Mf)) {
             d.st->step_failed = 1;
 #pragma unroll
-            for (int c = 0; c < 21; ++c) Ci[c] = 0.0;
+            for (int c = 0; c < 21; ++c) { Ci[c] = 0.0; Mf[c] = 0.0; }
         }
     }
 #pragma unroll
-    for (int c = 0; c < 21; ++c) d.cinv[(size_t)c * d.Lpad + l] = Ci[c];
+    for (int c = 0; c < 21; ++c) { d.cinv[(size_t)c * d.Lpad + l] = Ci[c]; d.cfac[(size_t)c * d.Lpad + l] = Mf[c]; }
 }
 
 template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
@@ -348,34 +354,38 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_poses(D
     }
 }
 
-// Output-stationary Schur complement for 6-D landmark blocks: same structure as k_schur_windows with
-// W, Y of size 6x6 per (landmark, slot) and K = 6 in the pair products.
+// Output-stationary Schur complement for 6-D landmark blocks on the fp64 matrix cores: the structure of
+// k_schur_windows (ssba_kernels.hip) with six factor rows per landmark.  C^-1 = M^T M comes from k_ph_invert, so
+// W_a C^-1 W_b^T = Z_a Z_b^T with Z = W M^T (6 x 6 per (landmark, slot)); Zm[k][col], k = 6*landmark + c, is staged
+// k-major in LDS (96 rows per batch of 16 landmarks, 80 columns: 72 + the gradient column u = M g_l + padding) and
+// S[72 x 73] += Zm^T Zm runs on v_mfma_f64_16x16x4_f64, the 15 upper tiles 4 / 4 / 4 / 3 per wave.
 constexpr int PH_THREADS = 256;
-constexpr int PH_BATCH = 10;      // 120 producer lanes
-constexpr int PH_SPLIT = 3;
-constexpr int PH_STRIDE = 74;     // W(36) | Y(36) | pad(2): 592 B, 16-byte aligned
-constexpr int PH_LDS_DOUBLES = PH_BATCH * TW * PH_STRIDE + PH_BATCH * 28;   // + per-landmark [Ci(21) | g_l(6) | pad]
+constexpr int PH_BATCH = 16;      // 192 producer lanes
+constexpr int PH_KB = 6 * PH_BATCH;          // 96 = 24 MFMA steps
+constexpr int PH_RS = 80;
+constexpr int PH_LDS_DOUBLES = PH_KB * PH_RS + PH_BATCH * 28;   // Zm + per-landmark [M(21) | g_l(6) | pad]
+typedef double ph_d4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     extern __shared__ __align__(16) double ph_lds[];
-    double *sWY = ph_lds;
-    double *sLM = ph_lds + PH_BATCH * TW * PH_STRIDE;
+    double *sZ = ph_lds;                         // [k][col]
+    double *sLM = ph_lds + PH_KB * PH_RS;        // [landmark][M(21) | g_l(6) | pad]
     const int item = blockIdx.x;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool producer = t < PH_BATCH * TW;
     const int li = t / TW, s = t - li * TW;
-    const bool consumer = t < NPAIR * PH_SPLIT;
-    const int grp = t / NPAIR, pr = t - grp * NPAIR;
-    const int pa = consumer ? c_ph_pair_a[pr] : 0, pb = consumer ? c_ph_pair_b[pr] : 0;
-    double acc[36], racc[6];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) racc[i] = 0.0;
+    const int ti0 = wv == 0 ? 0 : wv == 1 ? 0 : wv == 2 ? 1 : 3, tj0 = wv == 0 ? 0 : wv == 1 ? 4 : wv == 2 ? 4 : 3;
+    const int ti1 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 3, tj1 = wv == 0 ? 1 : wv == 1 ? 1 : wv == 2 ? 2 : 4;
+    const int ti2 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj2 = wv == 0 ? 2 : wv == 1 ? 2 : wv == 2 ? 3 : 4;
+    const int ti3 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj3 = wv == 0 ? 3 : wv == 1 ? 3 : wv == 2 ? 4 : 4;
+    const bool has3 = wv != 3;
+    ph_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    // padding columns 73..79 stay zero for the whole item (column 72 is rewritten every batch)
+    for (int e = t; e < PH_KB * 8; e += PH_THREADS) sZ[(e >> 3) * PH_RS + 72 + (e & 7)] = 0.0;
     bool pose_ok = false;
     uint32_t k = 0xFFFFFFFFu;
     if (producer) {
@@ -383,18 +393,29 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
         pose_ok = (k != 0xFFFFFFFFu) && d.pose_free[k] >= 0;
     }
     for (int l0 = lb; l0 < le; l0 += PH_BATCH) {
-        // phase 0: stage C^-1 (21) and g_l (6) of the batch
+        // phase 0: stage M (21) and g_l (6) of the batch
         for (int i = t; i < PH_BATCH * 27; i += PH_THREADS) {
             const int c = i / PH_BATCH, j = i - c * PH_BATCH, l = l0 + j;
             double v = 0.0;
-            if (l < le) v = c < 21 ? d.cinv[(size_t)c * d.Lpad + l] : d.gl[(size_t)(c - 21) * d.Lpad + l];
+            if (l < le) v = c < 21 ? d.cfac[(size_t)c * d.Lpad + l] : d.gl[(size_t)(c - 21) * d.Lpad + l];
             sLM[j * 28 + c] = v;
         }
         __syncthreads();
-        // phase 1: W = J_p^T J_l and Y = W C^-1 per (landmark, slot)
+        // phase 1: W = J_p^T J_l and Z = W M^T per (landmark, slot); u = M g_l per landmark
         if (producer) {
             const int l = l0 + li;
-            double *dst = sWY + (li * TW + s) * PH_STRIDE;
+            const double *Mf = sLM + li * 28;
+            if (s == 0) {
+                const double *g = Mf + 21;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int q = 0; q <= c; ++q) v += Mf[c * (c + 1) / 2 + q] * g[q];
+                    sZ[(li * 6 + c) * PH_RS + 72] = v;
+                }
+            }
+            double z[36];      // [c][a]
             bool live = false;
             if (l < le && pose_ok && ((d.lm_mask[l] >> s) & 1u)) {
                 live = true;
@@ -404,7 +425,6 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
                 const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
                 ObsPh o;
                 obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
-                const double *Ci = sLM + li * 28;
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     double w[6];
@@ -414,79 +434,61 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
 #pragma unroll
                         for (int m = 0; m < 7; ++m) v += o.Jp[6 * m + a] * o.Jl[6 * m + c];
                         w[c] = v;
-                        dst[6 * a + c] = v;
                     }
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
                         double v = 0.0;
 #pragma unroll
-                        for (int q = 0; q < 6; ++q) v += w[q] * Ci[q <= c ? tri6(q, c) : tri6(c, q)];
-                        dst[36 + 6 * a + c] = v;
+                        for (int q = 0; q <= c; ++q) v += w[q] * Mf[c * (c + 1) / 2 + q];
+                        z[6 * c + a] = v;
                     }
                 }
             }
             if (!live) {
 #pragma unroll
-                for (int i = 0; i < 72; ++i) dst[i] = 0.0;
+                for (int i = 0; i < 36; ++i) z[i] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                double2 *dz = reinterpret_cast<double2 *>(sZ + (li * 6 + c) * PH_RS + s * 6);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dz[q] = make_double2(z[6 * c + 2 * q], z[6 * c + 2 * q + 1]);
             }
         }
         __syncthreads();
-        // phase 2: pair products
-        if (consumer) {
-            const int nb = min(PH_BATCH, le - l0);
-            for (int j = grp; j < nb; j += PH_SPLIT) {
-                const double2 *Y2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pa) * PH_STRIDE + 36);
-                const double2 *W2 = reinterpret_cast<const double2 *>(sWY + (j * TW + pb) * PH_STRIDE);
-                double y[36];
-#pragma unroll
-                for (int i = 0; i < 18; ++i) { const double2 v = Y2[i]; y[2 * i] = v.x; y[2 * i + 1] = v.y; }
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    double w[6];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) { const double2 v = W2[3 * c + i]; w[2 * i] = v.x; w[2 * i + 1] = v.y; }
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        double v = acc[6 * a + c];
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) v = fma(y[6 * a + q], w[q], v);
-                        acc[6 * a + c] = v;
-                    }
-                }
-                if (pa == pb) {
-                    const double *g = sLM + j * 28 + 21;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        double v = racc[a];
-#pragma unroll
-                        for (int q = 0; q < 6; ++q) v = fma(y[6 * a + q], g[q], v);
-                        racc[a] = v;
-                    }
-                }
+        // phase 2: S += Zm^T Zm
+        {
+            const int kq = lane >> 4, i = lane & 15;
+#pragma unroll 4
+            for (int ks = 0; ks < PH_KB / 4; ++ks) {
+                const double *zr = sZ + (4 * ks + kq) * PH_RS + i;
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti0], zr[16 * tj0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti1], zr[16 * tj1], acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti2], zr[16 * tj2], acc2, 0, 0, 0);
+                if (has3) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti3], zr[16 * tj3], acc3, 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    double *part = ph_lds;   // 2 x 78 x 42 doubles
-    if (consumer && grp > 0) {
-        double *o = part + ((grp - 1) * NPAIR + pr) * 42;
+    auto store_tile = [&](const ph_d4 &acc, int ti, int tj) {
+        const int col = 16 * tj + (lane & 15);
 #pragma unroll
-        for (int i = 0; i < 36; ++i) o[i] = acc[i];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) o[36 + i] = racc[i];
-    }
-    __syncthreads();
-    if (consumer && grp == 0) {
-        const double *p1 = part + pr * 42, *p2 = part + (NPAIR + pr) * 42;
-        double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)pr * 36;
-#pragma unroll
-        for (int i = 0; i < 36; ++i) out[i] = (acc[i] + p1[i]) + p2[i];
-        if (pa == pb) {
-            double *ro = d.slab + (size_t)item * SLAB_DOUBLES + NPAIR * 36 + pa * 6;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) ro[a] = (racc[a] + p1[36 + a]) + p2[36 + a];
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ti + (lane >> 4) + 4 * r;
+            if (row >= 72) continue;
+            const int a = row / 6, ra = row - 6 * a;
+            if (col == 72) { d.slab[(size_t)item * SLAB_DOUBLES + NPAIR * 36 + row] = acc[r]; continue; }
+            if (col > 72 || col < row) continue;
+            const int b = col / 6, cb = col - 6 * b;
+            double *out = d.slab + (size_t)item * SLAB_DOUBLES + (size_t)(a * TW - (a * (a - 1)) / 2 + (b - a)) * 36;
+            out[ra * 6 + cb] = acc[r];
+            if (a == b) out[cb * 6 + ra] = acc[r];
         }
-    }
+    };
+    store_tile(acc0, ti0, tj0);
+    store_tile(acc1, ti1, tj1);
+    store_tile(acc2, ti2, tj2);
+    if (has3) store_tile(acc3, ti3, tj3);
 }
 
 template <bool DN> __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {

@@ -181,7 +181,8 @@ struct Dev {
     // shared blocks, packed ambient state [light 3 | phong 3M (ka,ks,alpha) | texture M (kd)]
     int M, nsh;
     double *sh, *cand_sh, *best_sh, *init_sh;
-    double *cinv;                                   // 21*Lpad damped landmark block inverse
+    double *cinv;                                   // 21*Lpad damped landmark block inverse C^-1 (packed upper)
+    double *cfac;                                   // 21*Lpad its factor M = L^-1 (packed lower, row-major): C^-1 = M^T M
     double *dlm;                                    // 6*Lpad landmark step (local coordinates)
     // free shared blocks = dense border of the reduced system (nb columns; offsets, -1 = constant)
     int nb, b_light, b_phong, b_tex;
