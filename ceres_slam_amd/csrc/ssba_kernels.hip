@@ -1651,15 +1651,20 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
     hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(64), 0, L.stream, d, o);
 }
 
+// Window layout: four lanes per landmark pay off while one lane per landmark leaves the SIMDs short of waves (C2: 1.5
+// waves per SIMD); from ~4 waves per SIMD on the plain mapping wins (C4: 15 600 waves; measured 0.106 / 0.224 ms vs
+// 0.133 / 0.272 ms for the split kernels).
+static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 262144; }
+
 void launch_linearize(Launcher &L, const Dev &d) {
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        if (d.dense) LAUNCH(KC_LIN_LM, k_linearize_landmarks<true>, dim3(d.n_lm_blocks), dim3(256), 0, d);
-        else LAUNCH(KC_LIN_LM, k_linearize_landmarks_w, dim3(d.n_groups), dim3(256), 0, d);
+        if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w, dim3(d.n_groups), dim3(256), 0, d);
+        else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
     }
-    LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, (d.phong || d.dense) ? d.n_lm_blocks : d.n_groups);
+    LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
 
 void launch_schur(Launcher &L, const Dev &d) {
@@ -1690,9 +1695,9 @@ void launch_finish_check(Launcher &L, const Dev &d) {
 void launch_update_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_backsub_eval(L, d);
-    else if (d.dense) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval<true>, dim3(d.n_lm_blocks), dim3(256), 0, d);
-    else LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, (d.phong || d.dense) ? d.n_lm_blocks : d.n_groups);
+    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d);
+    else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
 
 void launch_sep_pack(Launcher &L, const Dev &d) {

@@ -18,6 +18,8 @@ def avg(path, name):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
             kernel = r["Kernel_Name"].split("(")[0].replace("ssba::", "").replace("void ", "").split("<")[0]
+            if kernel.endswith("_w"):      # window-layout variants report under the kernel class of bench.py
+                kernel = kernel[:-2]
             a[kernel].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in a.items()}
 
