@@ -164,12 +164,23 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
         const double2 *D2 = reinterpret_cast<const double2 *>(Dg);
         const double2 *L2 = reinterpret_cast<const double2 *>(Lg);
         const double2 *U2 = reinterpret_cast<const double2 *>(Ug);
-        for (int e = t; e < BD * BD / 2; e += FACT_THREADS) {
+        // all 18 reads of a lane are in flight before the first LDS store (a rolled loop waits for every round trip)
+        constexpr int NLD = (BD * BD / 2 + FACT_THREADS - 1) / FACT_THREADS;
+        double2 dvv[NLD], lvv[NLD], uvv[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = t + q * FACT_THREADS;
+            const bool in = e < BD * BD / 2;
+            dvv[q] = in ? D2[e] : make_double2(0.0, 0.0);
+            lvv[q] = (in && hasL) ? L2[e] : make_double2(0.0, 0.0);
+            uvv[q] = (in && hasU) ? U2[e] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = t + q * FACT_THREADS;
+            if (e >= BD * BD / 2) continue;
             const int r = (2 * e) / BD, c = 2 * e - r * BD;
-            const double2 dv = D2[e];
-            double2 lv = make_double2(0.0, 0.0), uv = make_double2(0.0, 0.0);
-            if (hasL) lv = L2[e];
-            if (hasU) uv = U2[e];
+            const double2 dv = dvv[q], lv = lvv[q], uv = uvv[q];
             A[r * LDA + c] = dv.x; A[r * LDA + c + 1] = dv.y;
             if (!trL) { R[r * LDR + c] = lv.x; R[r * LDR + c + 1] = lv.y; }
             else { R[c * LDR + r] = lv.x; R[(c + 1) * LDR + r] = lv.y; }
@@ -361,10 +372,22 @@ constexpr int RED_THREADS = 448;
 constexpr int KSPLIT = 3;
 constexpr int KCH = BD / KSPLIT;   // 24
 
+// copy of one block, all reads of a lane in flight before its first store (nthreads is a launch constant: >= 448)
 __device__ __forceinline__ void stage_block(double *dst, const double *__restrict__ src, int nthreads) {
     const double2 *s2 = reinterpret_cast<const double2 *>(src);
     double2 *d2 = reinterpret_cast<double2 *>(dst);
-    for (int e = threadIdx.x; e < BD * BD / 2; e += nthreads) d2[e] = s2[e];
+    constexpr int NLD = (BD * BD / 2 + 447) / 448;     // 6
+    double2 v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = threadIdx.x + q * nthreads;
+        v[q] = e < BD * BD / 2 ? s2[e] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = threadIdx.x + q * nthreads;
+        if (e < BD * BD / 2) d2[e] = v[q];
+    }
 }
 
 __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const double *sB, int g, int tr, int tc) {
@@ -413,9 +436,16 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
         for (int i = 0; i < 36; ++i) acc[i] = 0.0;
         double *out, *outT = nullptr;
         double rbase = 0.0;
+        double dbase[36];
         if (blockIdx.y == 0) {
             if (!hasPrev && !hasNext) return;
             out = B.D + (size_t)e * BD * BD;
+            if (act && g == 0) {      // the tile of D this lane updates at the end: fetched now, under the products
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) dbase[6 * i + j] = out[(size_t)(tr * 6 + i) * BD + tc * 6 + j];
+            }
             if (hasPrev) stage_block(sA, P.YU + (so + prev) * BD * BD, RED_THREADS);
             if (hasNext) stage_block(sB, P.YL + (so + next) * BD * BD, RED_THREADS);
             if (t < BD) {
@@ -469,7 +499,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 for (int j = 0; j < 6; ++j) {
                     const double sum = (acc[6 * i + j] + part[tt * 36 + 6 * i + j]) + part[(144 + tt) * 36 + 6 * i + j];
                     const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
-                    if (blockIdx.y == 0) out[o] -= sum;
+                    if (blockIdx.y == 0) out[o] = dbase[6 * i + j] - sum;
                     else { out[o] = -sum; if (outT) outT[(size_t)(tc * 6 + j) * BD + tr * 6 + i] = -sum; }
                 }
         }
@@ -507,9 +537,18 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
     double *out;
     const double *base = nullptr;
     double rbase = 0.0;
+    double dbase[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) dbase[i] = 0.0;
     if (blockIdx.y == 0) {
         out = N.D + (size_t)m * BD * BD;
         base = L.D + (size_t)e * BD * BD;
+        if (act && g == 0) {      // the tile of D this lane finishes: fetched now, under the products
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) dbase[6 * i + j] = base[(size_t)(tr * 6 + i) * BD + tc * 6 + j];
+        }
         if (hasPrev) stage_block(sA, L.YU + (size_t)tp * BD * BD, RED_THREADS);
         if (hasNext) stage_block(sB, L.L + (size_t)(e + 1) * BD * BD, RED_THREADS);
         if (t < BD) {
@@ -556,7 +595,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
                 // an even-indexed coupling block of the next level is stored transposed
                 const size_t ow = (blockIdx.y == 1 && (m & 1) == 0) ? (size_t)(tc * 6 + j) * BD + tr * 6 + i : o;
-                out[ow] = (base ? base[o] : 0.0) - s;
+                out[ow] = dbase[6 * i + j] - s;
             }
     }
 }

@@ -27,14 +27,41 @@ static __device__ __forceinline__ double bcast(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-static __device__ __forceinline__ void stage_pad(double *dst, const double *__restrict__ src, bool transpose) {
-    for (int e = threadIdx.x; e < BD * BD; e += blockDim.x) {
-        const int r = e / BD, c = e - r * BD;
-        dst[transpose ? c * LDT + r : r * LDT + c] = src[e];
+// Staging copies with ALL global reads of a lane in flight before its first LDS store (a rolled copy loop waits for a
+// full memory round trip per iteration: 9 + 4 of them per operand pair in the first version of k_bcrm_upd).
+template <int NT> static __device__ __forceinline__ void stage_pad(double *dst, const double *__restrict__ src, bool transpose) {
+    constexpr int NLD = (BD * BD / 2 + NT - 1) / NT;
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = threadIdx.x + q * NT;
+        v[q] = e < BD * BD / 2 ? s2[e] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = threadIdx.x + q * NT;
+        if (e >= BD * BD / 2) continue;
+        const int r = (2 * e) / BD, c = 2 * e - r * BD;
+        if (transpose) { dst[c * LDT + r] = v[q].x; dst[(c + 1) * LDT + r] = v[q].y; }
+        else { dst[r * LDT + c] = v[q].x; dst[r * LDT + c + 1] = v[q].y; }
     }
 }
-static __device__ __forceinline__ void stage_flat(double *dst, const double *__restrict__ src, int n) {
-    for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = src[e];
+template <int N, int NT> static __device__ __forceinline__ void stage_flat(double *dst, const double *__restrict__ src) {
+    constexpr int NLD = (N / 2 + NT - 1) / NT;
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+    double2 *d2 = reinterpret_cast<double2 *>(dst);
+    double2 v[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = threadIdx.x + q * NT;
+        v[q] = e < N / 2 ? s2[e] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = threadIdx.x + q * NT;
+        if (e < N / 2) d2[e] = v[q];
+    }
 }
 
 // odd blocks: yb = G^-1 B in place (forward substitution, column sweep; lanes = rows, a wave = 2 columns)
@@ -48,7 +75,7 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_fwd(Dev d, int lev, int top
     const BcrLevel &L = d.lev[which == 2 ? d.pcr.level : lev];
     const int blk = which == 2 ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
     const double *Gsrc = which == 2 && !top ? d.pcr.Gs + ((size_t)lev * L.n + blk) * BD * BD : L.D + (size_t)blk * BD * BD;
-    stage_pad(Gt, Gsrc, true);
+    stage_pad<MR_THREADS>(Gt, Gsrc, true);
     const double *Bin = which == 2 ? d.pcr.Bb + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
     double *B = which == 2 ? d.pcr.yB + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
@@ -94,20 +121,20 @@ __global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev, int wh
         const bool hasPrev = prev >= 0, hasNext = next < P.n;
         if (!hasPrev && !hasNext) return;
         const size_t so = (size_t)lev * P.n;
-        if (hasPrev) {
-            stage_flat(sA, d.pcr.YU + (so + prev) * BD * BD, BD * BD);
-            stage_flat(ya, d.pcr.yB + (size_t)prev * BD * NBP, BD * NBP);
-        }
-        if (hasNext) {
-            stage_flat(sB, d.pcr.YL + (so + next) * BD * BD, BD * BD);
-            stage_flat(yb, d.pcr.yB + (size_t)next * BD * NBP, BD * NBP);
-        }
-        __syncthreads();
         const int t = threadIdx.x, r = t % BD, cg = (t / BD) * 4;
         double *Be = d.pcr.Bb + ((size_t)e * BD + r) * NBP + cg;
         double acc[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = Be[c];
+        for (int c = 0; c < 4; ++c) acc[c] = Be[c];       // own block: fetched under the staging, not after the barrier
+        if (hasPrev) {
+            stage_flat<BD * BD, UPD_THREADS>(sA, d.pcr.YU + (so + prev) * BD * BD);
+            stage_flat<BD * NBP, UPD_THREADS>(ya, d.pcr.yB + (size_t)prev * BD * NBP);
+        }
+        if (hasNext) {
+            stage_flat<BD * BD, UPD_THREADS>(sB, d.pcr.YL + (so + next) * BD * BD);
+            stage_flat<BD * NBP, UPD_THREADS>(yb, d.pcr.yB + (size_t)next * BD * NBP);
+        }
+        __syncthreads();
         if (hasPrev)
             for (int k = 0; k < BD; ++k) {
                 const double a = sA[k * BD + r];
@@ -128,19 +155,19 @@ __global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev, int wh
     const BcrLevel &N = d.lev[lev + 1];
     const int m = blockIdx.x, e = 2 * m;
     const bool hasPrev = e >= 1, hasNext = e + 1 < L.n;
-    if (hasPrev) {
-        stage_flat(sA, L.YU + (size_t)(m - 1) * BD * BD, BD * BD);
-        stage_flat(ya, L.B + (size_t)(e - 1) * BD * NBP, BD * NBP);
-    }
-    if (hasNext) {
-        stage_flat(sB, L.L + (size_t)(e + 1) * BD * BD, BD * BD);
-        stage_flat(yb, L.B + (size_t)(e + 1) * BD * NBP, BD * NBP);
-    }
-    __syncthreads();
     const int t = threadIdx.x, r = t % BD, cg = (t / BD) * 4;
     double acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = L.B[((size_t)e * BD + r) * NBP + cg + c];
+    if (hasPrev) {
+        stage_flat<BD * BD, UPD_THREADS>(sA, L.YU + (size_t)(m - 1) * BD * BD);
+        stage_flat<BD * NBP, UPD_THREADS>(ya, L.B + (size_t)(e - 1) * BD * NBP);
+    }
+    if (hasNext) {
+        stage_flat<BD * BD, UPD_THREADS>(sB, L.L + (size_t)(e + 1) * BD * BD);
+        stage_flat<BD * NBP, UPD_THREADS>(yb, L.B + (size_t)(e + 1) * BD * NBP);
+    }
+    __syncthreads();
     if (hasPrev)
         for (int k = 0; k < BD; ++k) {
             const double a = sA[k * BD + r];
@@ -168,12 +195,12 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
     const int blk = which == 2 ? (int)blockIdx.x : (top ? 0 : 2 * blockIdx.x + 1);
     const bool hasU = !top && (blk + 1 < L.n);
     if (!top) {
-        stage_pad(sL, L.L + (size_t)blk * BD * BD, false);
-        stage_flat(xm, d.Zb + (((size_t)(blk - 1) << lev) * BD) * NBP, BD * NBP);
+        stage_pad<MR_THREADS>(sL, L.L + (size_t)blk * BD * BD, false);
+        stage_flat<BD * NBP, MR_THREADS>(xm, d.Zb + (((size_t)(blk - 1) << lev) * BD) * NBP);
     }
     if (hasU) {
-        stage_pad(sU, L.YU + (size_t)blockIdx.x * BD * BD, false);
-        stage_flat(xp, d.Zb + (((size_t)(blk + 1) << lev) * BD) * NBP, BD * NBP);
+        stage_pad<MR_THREADS>(sU, L.YU + (size_t)blockIdx.x * BD * BD, false);
+        stage_flat<BD * NBP, MR_THREADS>(xp, d.Zb + (((size_t)(blk + 1) << lev) * BD) * NBP);
     }
     const double *B = which == 2 ? d.pcr.yB + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
     }
     __syncthreads();
     double *sG = lds;   // rows of G over the YL staging area
-    stage_pad(sG, L.D + (size_t)blk * BD * BD, false);
+    stage_pad<MR_THREADS>(sG, L.D + (size_t)blk * BD * BD, false);
     __syncthreads();
 #pragma unroll
     for (int k = BD - 1; k >= 64; --k) {
