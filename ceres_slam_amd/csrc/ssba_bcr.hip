@@ -40,9 +40,7 @@ constexpr int TILE_THREADS = 384;           // waves 0..5 own tiles
 constexpr int FACT_THREADS = 448;           // wave 6 factors the diagonal tiles one step ahead
 
 // tile table, sorted by the step in which a tile becomes final so that whole waves retire early
-__constant__ uint8_t c_tile_type[NT];   // 0 = tile of D (rb >= cb), 1 = tile of the right-hand sides
-__constant__ uint8_t c_tile_rb[NT];
-__constant__ uint8_t c_tile_cb[NT];
+__constant__ uint32_t c_tile[NT];       // type | rb << 8 | cb << 16; type 0 = tile of D (rb >= cb), 1 = tile of the right-hand sides
 
 int upload_bcr_tables(hipStream_t s) {
     struct T { int fin, type, rb, cb; };
@@ -52,11 +50,9 @@ int upload_bcr_tables(hipStream_t s) {
     for (int rb = 0; rb < NBLK; ++rb)
         for (int cb = 0; cb < NCB; ++cb) v.push_back({rb, 1, rb, cb});
     std::stable_sort(v.begin(), v.end(), [](const T &a, const T &b) { return a.fin < b.fin; });
-    uint8_t ty[NT], rb[NT], cb[NT];
-    for (int i = 0; i < NT; ++i) { ty[i] = (uint8_t)v[i].type; rb[i] = (uint8_t)v[i].rb; cb[i] = (uint8_t)v[i].cb; }
-    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tile_type), ty, NT, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tile_rb), rb, NT, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
-    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tile_cb), cb, NT, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
+    uint32_t packed[NT];
+    for (int i = 0; i < NT; ++i) packed[i] = (uint32_t)v[i].type | ((uint32_t)v[i].rb << 8) | ((uint32_t)v[i].cb << 16);
+    if (hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tile), packed, sizeof packed, 0, hipMemcpyHostToDevice, s) != hipSuccess) return -1;
     return hipStreamSynchronize(s) == hipSuccess ? 0 : -1;
 }
 
@@ -154,8 +150,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     }
     const int t = threadIdx.x;
     const bool has_tile = t < NT;
-    const int type = has_tile ? c_tile_type[t] : 2;
-    const int rb = has_tile ? c_tile_rb[t] : 0, cb = has_tile ? c_tile_cb[t] : 0;
+    const uint32_t tile = has_tile ? c_tile[t] : 2u;       // one load, consumed after the bulk load below is under way
     if (t == 0) sBad = 0;
     STAMP(lev * 64, 0);
 
@@ -197,6 +192,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             for (int c = 2 * BD + 1; c < LDR; ++c) R[t * LDR + c] = 0.0;
         }
     }
+    const int type = (int)(tile & 255u), rb = (int)((tile >> 8) & 255u), cb = (int)(tile >> 16);
     __syncthreads();
     STAMP(lev * 64, 1);
 
@@ -225,22 +221,44 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
     // square roots only scale the outputs) and stores L with 1/L_jj on the diagonal.  It does so
     // for step kb+1 while waves 0..5 run the trailing update of step kb, which takes the
     // ~1.2k-cycle pivot chain off the critical path.
-    auto diag_step = [&](int kd) {
+    // The left-looking sum over the columns of panels 0 .. kd-2 does not need panel kd-1: wave 6 forms it ahead of time
+    // (diag_pre, while waves 0..5 finalise panel kd-1), so that only the six newest columns are left on the serial chain
+    // diagonal tile -> forward substitution of its panel -> next diagonal tile, which is what a launch waits for.
+    double dpart = 0.0;
+    auto diag_pre = [&](int kd) {
         const int e = t - TILE_THREADS;
         if (e < 36) {
             const int i = e / 6, j = e - i * 6;
             const double *ri = A + (kd * 6 + i) * LDA, *rj = A + (kd * 6 + j) * LDA;
+            const int cend = (kd - 1) * 6;
             double v0 = ri[kd * 6 + j], v1 = 0.0, v2 = 0.0, v3 = 0.0;
-            for (int c = 0; c + 4 <= kd * 6; c += 4) {
+            for (int c = 0; c + 4 <= cend; c += 4) {
                 const double2 a0 = *reinterpret_cast<const double2 *>(ri + c), a1 = *reinterpret_cast<const double2 *>(ri + c + 2);
                 const double2 b0 = *reinterpret_cast<const double2 *>(rj + c), b1 = *reinterpret_cast<const double2 *>(rj + c + 2);
                 v0 -= a0.x * b0.x; v1 -= a0.y * b0.y; v2 -= a1.x * b1.x; v3 -= a1.y * b1.y;
             }
-            if ((kd * 6) & 2) {   // 6*kd is even: a remainder of two columns when kd is odd
-                const int c = kd * 6 - 2;
+            if (cend > 0 && (cend & 2)) {   // cend is even: a remainder of two columns when kd - 1 is odd
+                const int c = cend - 2;
                 v0 -= ri[c] * rj[c]; v1 -= ri[c + 1] * rj[c + 1];
             }
-            sDiag[e] = (v0 + v1) + (v2 + v3);
+            dpart = (v0 + v1) + (v2 + v3);
+        }
+    };
+    auto diag_step = [&](int kd) {
+        const int e = t - TILE_THREADS;
+        if (e < 36) {
+            const int i = e / 6, j = e - i * 6;
+            double v0 = dpart, v1 = 0.0;
+            if (kd > 0) {       // the columns of panel kd - 1
+                const double2 *ri = reinterpret_cast<const double2 *>(A + (kd * 6 + i) * LDA + (kd - 1) * 6);
+                const double2 *rj = reinterpret_cast<const double2 *>(A + (kd * 6 + j) * LDA + (kd - 1) * 6);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const double2 a = ri[q], b = rj[q];
+                    v0 -= a.x * b.x; v1 -= a.y * b.y;
+                }
+            }
+            sDiag[e] = v0 + v1;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
             }
         }
     };
-    if (t >= TILE_THREADS) diag_step(0);
+    if (t >= TILE_THREADS) { diag_pre(0); diag_step(0); }
 
     for (int kb = 0; kb < NBLK; ++kb) {
         __syncthreads();                      // (1) L(kb) is in LDS
@@ -292,6 +310,7 @@ __global__ __launch_bounds__(FACT_THREADS) void k_bcr_factor(Dev d, int lev, int
         }
         // (2) block column kb of G and block row kb of Y become final: forward substitution of
         //     each line T[x][:] against the diagonal tile (right-looking, 6 independent lines)
+        if (t >= TILE_THREADS && kb + 1 < NBLK) diag_pre(kb + 1);
         if (has_tile && fin == kb) {
             double l[6][6];
 #pragma unroll

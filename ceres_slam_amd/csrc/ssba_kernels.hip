@@ -156,28 +156,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
     const uint32_t b = DN ? d.dn_pose_start[k] : d.pose_obs_start[k], e = DN ? d.dn_pose_start[k + 1] : d.pose_obs_start[k + 1];
-    for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-        int l;
-        double ou, ov, od, Sk[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) Sk[c] = d.S[c];
-        if (DN) {
-            const uint32_t oi = d.dn_pose_obs[i];
-            l = (int)d.dn_obs_lm[oi];
-            ou = d.dn_u[oi]; ov = d.dn_v[oi]; od = d.dn_d[oi];
-            if (d.dn_Sobs) {
-#pragma unroll
-                for (int c = 0; c < 9; ++c) Sk[c] = d.dn_Sobs[(size_t)oi * 9 + c];
-            }
-        } else {
-            const uint32_t ref = d.pose_obs_ref[i];
-            l = (int)(ref >> 4);
-            const int s = (int)(ref & 15u);
-            const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
-            ou = d.ou[oi]; ov = d.ov[oi]; od = d.od[oi];
-        }
+    auto accumulate = [&](const double *Sk, double px, double py, double pz, double ou, double ov, double od) {
         ObsLin o;
-        obs_linearize_S(d, Sk, T, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], ou, ov, od, o);
+        obs_linearize_S(d, Sk, T, px, py, pz, ou, ov, od, o);
         double Jp[18];
         jac_pose(o, Jp);
         int n = 0;
@@ -190,6 +171,40 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
             }
 #pragma unroll
         for (int a = 0; a < 6; ++a) acc[21 + a] += Jp[a] * o.r[0] + Jp[6 + a] * o.r[1] + Jp[12 + a] * o.r[2];
+    };
+    double Sk[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) Sk[c] = d.S[c];
+    if (DN) {
+        for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+            const uint32_t oi = d.dn_pose_obs[i];
+            const int l = (int)d.dn_obs_lm[oi];
+            double So[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) So[c] = d.dn_Sobs ? d.dn_Sobs[(size_t)oi * 9 + c] : Sk[c];
+            accumulate(So, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], d.dn_u[oi], d.dn_v[oi], d.dn_d[oi]);
+        }
+    } else {
+        // three observations per round: their references, then their 18 operands are in flight together (a rolled loop
+        // pays two dependent memory round trips per observation)
+        constexpr int CH = 3;
+        for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += 256 * CH) {
+            uint32_t ref[CH];
+            double in[CH][6];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) ref[q] = i0 + 256 * q < e ? d.pose_obs_ref[i0 + 256 * q] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                if (ref[q] == 0xFFFFFFFFu) continue;
+                const int l = (int)(ref[q] >> 4), sl = (int)(ref[q] & 15u);
+                const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)sl * LMG + (l & 63);
+                in[q][0] = d.pts[l]; in[q][1] = d.pts[(size_t)d.Lpad + l]; in[q][2] = d.pts[2 * (size_t)d.Lpad + l];
+                in[q][3] = d.ou[oi]; in[q][4] = d.ov[oi]; in[q][5] = d.od[oi];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (ref[q] != 0xFFFFFFFFu) accumulate(Sk, in[q][0], in[q][1], in[q][2], in[q][3], in[q][4], in[q][5]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < 27; ++i) {
@@ -495,9 +510,21 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
         const uint32_t fa = d.sblk_a[blk], fb = d.sblk_b[blk];
         int er = r, ec = c;
         if (fa == fb && c > r) { er = c; ec = r; }   // read the lower triangle: exact symmetry
+        // contributions in chunks of eight: all indices, then all values in flight, summed in list order (a rolled loop pays
+        // two dependent memory round trips per contribution; a block of the band collects ~10 of them)
         double v = 0.0;
-        for (uint32_t i = d.sblk_start[blk]; i < d.sblk_start[blk + 1]; ++i)
-            v += d.slab[(size_t)(d.sblk_contrib[i] / NPAIR) * SLAB_DOUBLES + (size_t)(d.sblk_contrib[i] % NPAIR) * 36 + er * 6 + ec];
+        const uint32_t ib = d.sblk_start[blk], ie = d.sblk_start[blk + 1];
+        for (uint32_t i0 = ib; i0 < ie; i0 += 8) {
+            uint32_t cw[8];
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cw[q] = i0 + q < ie ? d.sblk_contrib[i0 + q] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                x[q] = cw[q] != 0xFFFFFFFFu ? d.slab[(size_t)(cw[q] / NPAIR) * SLAB_DOUBLES + (size_t)(cw[q] % NPAIR) * 36 + er * 6 + ec] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += x[q];
+        }
         v = -v;
         if (fa == fb) {
             const int k = d.free_pose[fa];
@@ -521,9 +548,17 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
         const int k = d.free_pose[f];
         const double g = d.gp[(size_t)k * 6 + c];
         double v = g;
-        for (uint32_t j = d.prow_start[f]; j < d.prow_start[f + 1]; ++j) {
-            const uint32_t cw = d.prow_contrib[j];
-            v -= d.slab[(size_t)(cw / TW) * SLAB_DOUBLES + NPAIR * 36 + (cw % TW) * 6 + c];
+        const uint32_t jb = d.prow_start[f], je = d.prow_start[f + 1];
+        for (uint32_t j0 = jb; j0 < je; j0 += 8) {
+            uint32_t cw[8];
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cw[q] = j0 + q < je ? d.prow_contrib[j0 + q] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                x[q] = cw[q] != 0xFFFFFFFFu ? d.slab[(size_t)(cw[q] / TW) * SLAB_DOUBLES + NPAIR * 36 + (cw[q] % TW) * 6 + c] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v -= x[q];
         }
         d.xv[d.off_rhs + i] = v;             // reduced gradient; negated in k_finish_reduced
         d.xv[d.off_gp + i] = g;
