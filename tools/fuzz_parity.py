@@ -1,0 +1,60 @@
+"""Randomised parity sweep (GPU box): small stereo problems of random shape -- pose count, landmark count, track length,
+constant poses, Huber loss, trust-region strategy -- solved by the HIP path and by the CPU oracle; compares the cost
+trace, the accept / reject sequence and the final cost.   usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from ceres_slam_amd import capi, synth  # noqa: E402
+from ceres_slam_amd.solver import StereoBA  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    bad = 0
+    for c in range(cases):
+        P = int(rng.integers(3, 70))
+        T = int(rng.integers(2, 13))
+        L = int(rng.integers(max(20, 3 * P), 40 * P + 50))
+        seed = int(rng.integers(0, 10**6))
+        huber = float(rng.choice([0.0, 0.0, 1.345]))
+        dog = int(rng.choice([-1, -1, 0, 1]))
+        prob = synth.make_problem(P, L, track_len=min(T, P), seed=seed, outlier_fraction=0.2 if huber > 0 and rng.random() < 0.5 else 0.0)
+        pose_const = np.zeros(P, dtype=np.uint8)
+        pose_const[0] = 1
+        if rng.random() < 0.4:
+            pose_const[rng.integers(0, P, size=max(1, P // 6))] = 1
+        kw = dict(max_num_iterations=60, use_nonmonotonic_steps=1)
+        okw = dict(num_threads=4, max_num_iterations=60)
+        if dog >= 0:
+            kw.update(trust_region_strategy_type=1, dogleg_type=dog)
+            okw.update(trust_region_strategy_type=1, dogleg_type=dog)
+        ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                      prob.stiffness(), pose_const=pose_const, huber_a=huber)
+        s, log = ba.solve(capi.default_options(**kw))
+        op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                               prob.stiffness(), pose_const=pose_const, huber_a=huber)
+        s2, log2 = op.solve(orc.driver_options(**okw))
+        n = min(len(log["cost"]), len(log2["cost"]), 12)
+        acc_ok = log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+        okm = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+        okm[0] = True
+        trace = float(np.max(np.abs(log["cost"][:n][okm] - log2["cost"][:n][okm]) / np.abs(log2["cost"][:n][okm])))
+        fin = abs(s.final_cost - s2.final_cost) / abs(s2.final_cost)
+        ok = acc_ok and trace < 1e-6 and fin < 1e-5
+        bad += not ok
+        print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} dogleg={dog:2d} const={int(pose_const.sum()):2d} "
+              f"general={int(ba.stats().general_structure)} iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} trace={trace:.1e} final={fin:.1e} "
+              f"{'ok' if ok else 'MISMATCH'}", flush=True)
+        ba.close()
+    print("mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
