@@ -609,10 +609,10 @@ __device__ void log_push(Dev &d, State &st, double cost, double cost_change, dou
 
 // Ceres TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue (plus the
 // reductions of EvaluateGradientAndJacobian): one block.
-__global__ __launch_bounds__(256) void k_check(Dev d) {
+__global__ __launch_bounds__(1024) void k_check(Dev d) {      // 1024 lanes: one pose each at C2 (the exponential map is a long dependent chain)
     State &st = *d.st;
     if (st.terminated) return;
-    __shared__ double sm[4];
+    __shared__ double sm[16];
     double gm = 0.0, xn = 0.0, cost = 0.0;
     const bool lin = st.just_linearized != 0;
     if (lin) {
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(256) void k_check(Dev d) {
         // interior poses of every rank went into those sums before the exchange (k_sep_pack); what is left
         // are the separator poses, whose gradient is the sum over ranks held in the separator vector
         const int npose = d.part ? d.n_sep * SBP : d.nfree;
-        for (int q = threadIdx.x; q < npose; q += 256) {
+        for (int q = threadIdx.x; q < npose; q += (int)blockDim.x) {
             int i = q;
             const double *gsrc = d.xv + d.off_gp + (size_t)q * 6;
             if (d.part) {
@@ -1722,7 +1722,7 @@ void launch_finish_local(Launcher &L, const Dev &d) {
 void launch_finish_check(Launcher &L, const Dev &d) {
     if (d.dense) launch_dense_finish(L, d);
     else LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
 }
@@ -1741,7 +1741,7 @@ void launch_sep_pack(Launcher &L, const Dev &d) {
 }
 void launch_sep_finish_check(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
 }
