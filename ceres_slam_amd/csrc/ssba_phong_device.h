@@ -7,6 +7,19 @@
 namespace ssba {
 
 static __device__ __forceinline__ double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// hardware estimates + two Newton steps: full fp64 accuracy at a fraction of the IEEE sqrt / divide chains
+static __device__ __forceinline__ double ph_rsqrt(double a) {
+    double r = __builtin_amdgcn_rsq(a);
+    r = r * (1.5 - 0.5 * a * r * r);
+    r = r * (1.5 - 0.5 * a * r * r);
+    return r;
+}
+static __device__ __forceinline__ double ph_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    r = fma(fma(-a, r, 1.0), r, r);
+    r = fma(fma(-a, r, 1.0), r, r);
+    return r;
+}
 
 struct PhongGrad { double nc[3], ell[3], cd[3], mat[3]; };   // mat = d/dkd, d/dks, d/dalpha
 
@@ -33,17 +46,20 @@ static __device__ __forceinline__ double phong_core(const double nc[3], const do
     for (int i = 0; i < 3; ++i) mt[i] = 2.0 * ldn * nc[i] - ell[i];   // phong.hpp:81-84
     const double mu2 = dot3(mt, mt);
     if (!(mu2 <= 0.0)) {                       // phong.hpp:88-90
-        const double mu = sqrt(mu2);
-        const double m[3] = {mt[0] / mu, mt[1] / mu, mt[2] / mu};
+        const double rmu = ph_rsqrt(mu2);      // reciprocal square roots + multiplications: IEEE sqrt / divide are 150 / 110 dependent cycles each
+        const double m[3] = {mt[0] * rmu, mt[1] * rmu, mt[2] * rmu};
         const double s = dot3(m, cd);
         if (!(s <= 0.0)) {                     // phong.hpp:98-100
-            const double sa = pow(s, alpha);
+            // s^alpha, s^(alpha-1) and log s from ONE logarithm and one exponential (pow is both, twice over, at extended
+            // precision: the three calls were a third of this function); |alpha| <= 20 keeps exp(alpha log s) within ~2e-15
+            const double ls = log(s);
+            const double sa = exp(alpha * ls);
             specular = ks * sa;
             if (g) {
-                const double gs = ks * alpha * pow(s, alpha - 1.0);
+                const double gs = ks * alpha * (sa * ph_rcp(s));
                 double w[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) w[i] = (cd[i] - m[i] * s) / mu;   // d s / d m~
+                for (int i = 0; i < 3; ++i) w[i] = (cd[i] - m[i] * s) * rmu;   // d s / d m~
                 const double nw = dot3(nc, w);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -52,7 +68,7 @@ static __device__ __forceinline__ double phong_core(const double nc[3], const do
                     g->cd[i] += gs * m[i];
                 }
                 g->mat[1] = sa;
-                g->mat[2] = ks * sa * log(s);
+                g->mat[2] = ks * sa * ls;
             }
         }
     }
@@ -76,7 +92,7 @@ static __device__ __forceinline__ void row_times_neg_skew(const double g[3], con
 
 // plus-Jacobian of UnitVectorPerturbation at delta = 0: (I - x x^T/|x|^2)/|x|
 static __device__ __forceinline__ void row_times_unit_plus(const double g[3], const double x[3], double out[3]) {
-    const double n2 = dot3(x, x), inv = 1.0 / sqrt(n2), gx = dot3(g, x) / n2;
+    const double n2 = dot3(x, x), inv = ph_rsqrt(n2), gx = dot3(g, x) * inv * inv;
 #pragma unroll
     for (int j = 0; j < 3; ++j) out[j] = (g[j] - gx * x[j]) * inv;
 }
@@ -96,9 +112,9 @@ static __device__ __forceinline__ void intensity_residual(int light_type, const 
     double ell[3], cd[3], v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = light_type == 0 ? lc[i] - q[i] : lc[i];
-    const double rho = sqrt(dot3(v, v)), qn = sqrt(dot3(q, q));
+    const double rrho = ph_rsqrt(dot3(v, v)), rqn = ph_rsqrt(dot3(q, q));
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { ell[i] = v[i] / rho; cd[i] = -q[i] / qn; }
+    for (int i = 0; i < 3; ++i) { ell[i] = v[i] * rrho; cd[i] = -q[i] * rqn; }
     PhongGrad g;
     const double col = phong_core(nc, ell, cd, kd, phong[1], phong[2], J19 ? &g : nullptr);
     *r = stiffness * (col - colour);
@@ -107,8 +123,8 @@ static __device__ __forceinline__ void intensity_residual(int light_type, const 
     double g_l[3], g_q[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double gv = (g.ell[i] - ell[i] * le) / rho;
-        const double gc = -(g.cd[i] - cd[i] * ce) / qn;
+        const double gv = (g.ell[i] - ell[i] * le) * rrho;
+        const double gc = -(g.cd[i] - cd[i] * ce) * rqn;
         g_l[i] = gv;
         g_q[i] = gc - (light_type == 0 ? gv : 0.0);
     }
