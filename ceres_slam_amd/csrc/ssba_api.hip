@@ -1443,7 +1443,9 @@ static int enqueue_front(ssba_problem *p);
 static int enqueue_kernels(ssba_problem *p) {
     int rc = enqueue_front(p);
     if (rc) return rc;
-    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d); }))) return rc;
+    // single GPU, LM: the decision kernel forms the evaluation sums itself (no exchange sits between them)
+    const bool fuse = !p->xfn && !p->d.constrained && p->opt.trust_region_strategy_type != 1;
+    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
@@ -1525,7 +1527,7 @@ static int enqueue_front(ssba_problem *p) {
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d); if (d.nb) launch_border_solve(L, d); }
             if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
-            else launch_update_eval(L, d);
+            else launch_update_eval(L, d, !p->xfn && !d.constrained);
         }))) return rc;
     if (p->xfn && (rc = X(d.scal2, NSCAL, 0))) return rc;
     return SSBA_OK;

@@ -1412,10 +1412,26 @@ __global__ __launch_bounds__(256) void k_reduce_eval(Dev d, int n_parts) {
 
 // The body of the Ceres trust-region loop after the candidate evaluation: step validity,
 // parameter / function tolerance, step quality, accept / reject, radius update.
-__global__ __launch_bounds__(256) void k_decide(Dev d) {
+// n_eval_parts > 0 (single GPU, no exchange between the evaluation and the decision): the sums of k_reduce_eval are
+// formed here, one launch less per iteration.
+__global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts) {
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
+    if (n_eval_parts > 0) {
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+        for (int i = threadIdx.x; i < n_eval_parts; i += 256) {
+            e0 += d.part_eval[i * 4];
+            e1 += d.part_eval[i * 4 + 1];
+            e2 += d.part_eval[i * 4 + 2];
+            e3 += d.part_eval[i * 4 + 3];
+        }
+        e0 = block_sum(e0, sm);
+        e1 = block_sum(e1, sm);
+        e2 = block_sum(e2, sm);
+        e3 = block_sum(e3, sm);
+        if (threadIdx.x == 0) { d.scal2[0] = e0; d.scal2[1] = e1; d.scal2[2] = e2; d.scal2[3] = e3; }
+    }
     double a = 0.0, b = 0.0, pcc = 0.0, pmc = 0.0;
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) {   // last entry: border of shared blocks
         a += d.part_pose[i * NPP];
@@ -1727,12 +1743,13 @@ void launch_finish_check(Launcher &L, const Dev &d) {
     LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
 }
 
-void launch_update_eval(Launcher &L, const Dev &d) {
+// fuse_reduce: the caller's launch_decide_commit(.., true) forms the evaluation sums (no exchange in between)
+void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
     if (d.phong) launch_ph_backsub_eval(L, d);
     else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
+    if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
 
 void launch_sep_pack(Launcher &L, const Dev &d) {
@@ -1770,8 +1787,8 @@ void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks);
 }
 
-void launch_decide_commit(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d);
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce) {
+    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
 }

@@ -115,9 +115,9 @@ void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
 void launch_eval_add_pose(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
-void launch_update_eval(Launcher &L, const Dev &d);
+void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
-void launch_decide_commit(Launcher &L, const Dev &d);
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false);
 // config 3 (ssba_phong_solver.hip)
 int upload_phong_tables(hipStream_t s);
 int configure_phong();
