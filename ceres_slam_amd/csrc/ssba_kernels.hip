@@ -22,6 +22,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "ssba_types.h"
 #include "ssba_launch.h"
 #include "ssba_device.h"
@@ -724,13 +726,15 @@ __global__ __launch_bounds__(1024) void k_check(Dev d) {      // 1024 lanes: one
 __global__ __launch_bounds__(256) void k_best(Dev d) {
     const State &st = *d.st;
     if (st.copy_best != st.check_count) return;       // set by the k_check just before; a later k_check moves the count on
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < (size_t)d.P * 12) d.best_poses[i] = d.poses[i];
-    if (i < (size_t)d.Lpad * 3) {
-        d.best_pts[i] = d.pts[i];
-        if (d.phong) d.best_nrm[i] = d.nrm[i];
+    const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {   // few blocks: most launches only test the flag
+        if (i < (size_t)d.P * 12) d.best_poses[i] = d.poses[i];
+        if (i < (size_t)d.Lpad * 3) {
+            d.best_pts[i] = d.pts[i];
+            if (d.phong) d.best_nrm[i] = d.nrm[i];
+        }
+        if (d.phong && i < (size_t)d.nsh) d.best_sh[i] = d.sh[i];
     }
-    if (d.phong && i < (size_t)d.nsh) d.best_sh[i] = d.sh[i];
 }
 
 // candidate poses = Plus(x, delta_p)  [Evaluator::Plus with SE3Perturbation]
@@ -1740,7 +1744,7 @@ void launch_finish_check(Launcher &L, const Dev &d) {
     else LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
-    LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+    LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }
 
 // fuse_reduce: the caller's launch_decide_commit(.., true) forms the evaluation sums (no exchange in between)
@@ -1760,7 +1764,7 @@ void launch_sep_finish_check(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
-    LAUNCH(KC_COPY, k_best, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+    LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }
 void launch_sep_scatter(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_sep_scatter, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
