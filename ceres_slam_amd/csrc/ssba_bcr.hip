@@ -409,8 +409,8 @@ __device__ __forceinline__ void stage_block(double *dst, const double *__restric
     }
 }
 
-__device__ __forceinline__ void tile_mac(double *acc, const double *sA, const double *sB, int g, int tr, int tc) {
-    for (int k = g * KCH; k < (g + 1) * KCH; ++k) {
+__device__ __forceinline__ void tile_mac_k(double *acc, const double *sA, const double *sB, int k0, int k1, int tr, int tc) {
+    for (int k = k0; k < k1; ++k) {
         double a[6], b[6];
         const double2 *pa = reinterpret_cast<const double2 *>(sA + k * BD + tr * 6);   // 16-byte aligned
         const double2 *pb = reinterpret_cast<const double2 *>(sB + k * BD + tc * 6);
@@ -425,6 +425,9 @@ __device__ __forceinline__ void tile_mac(double *acc, const double *sA, const do
 #pragma unroll
             for (int j = 0; j < 6; ++j) acc[6 * i + j] += a[i] * b[j];
     }
+}
+__device__ __forceinline__ void tile_mac(double *acc, const double *sA, const double *sB, int g, int tr, int tc) {
+    tile_mac_k(acc, sA, sB, g * KCH, (g + 1) * KCH, tr, tc);
 }
 
 // grid = (n_next, 2): y = 0 -> D' and r' ; y = 1 -> L'.  Both operand blocks are staged
@@ -457,13 +460,20 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
         double rbase = 0.0;
         double dbase[36];
         if (blockIdx.y == 0) {
+            // D_e -= YU^T YU + YL^T YL is symmetric: the 78 upper 6x6 tiles, a 4-way split over k (312 lanes), mirrored stores
             if (!hasPrev && !hasNext) return;
             out = B.D + (size_t)e * BD * BD;
-            if (act && g == 0) {      // the tile of D this lane updates at the end: fetched now, under the products
+            constexpr int SYM_SPLIT = 4, SYM_KCH = BD / SYM_SPLIT, SYM_TILES = 78;
+            const bool sact = t < SYM_SPLIT * SYM_TILES;
+            const int sg = t / SYM_TILES, stt = t - sg * SYM_TILES;
+            int sr = 0, rem = stt;
+            while (rem >= 12 - sr) { rem -= 12 - sr; ++sr; }
+            const int sc = sr + rem;
+            if (sact && sg == 0) {      // the tile of D this lane updates at the end: fetched now, under the products
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) dbase[6 * i + j] = out[(size_t)(tr * 6 + i) * BD + tc * 6 + j];
+                    for (int j = 0; j < 6; ++j) dbase[6 * i + j] = out[(size_t)(sr * 6 + i) * BD + sc * 6 + j];
             }
             if (hasPrev) stage_block(sA, P.YU + (so + prev) * BD * BD, RED_THREADS);
             if (hasNext) stage_block(sB, P.YL + (so + next) * BD * BD, RED_THREADS);
@@ -473,9 +483,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 rbase = B.r[(size_t)e * BD + t];
             }
             __syncthreads();
-            if (act) {
-                if (hasPrev) tile_mac(acc, sA, sA, g, tr, tc);
-                if (hasNext) tile_mac(acc, sB, sB, g, tr, tc);
+            if (sact) {
+                if (hasPrev) tile_mac_k(acc, sA, sA, sg * SYM_KCH, (sg + 1) * SYM_KCH, sr, sc);
+                if (hasNext) tile_mac_k(acc, sB, sB, sg * SYM_KCH, (sg + 1) * SYM_KCH, sr, sc);
             }
             if (t < BD) {
                 double v0 = 0.0, v1 = 0.0;
@@ -484,6 +494,25 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 B.r[(size_t)e * BD + t] = rbase - v0 - v1;
             }
             __syncthreads();
+            double *spart = lds;      // 3 x 78 x 36 doubles = 67 392 B <= the operand area
+            if (sact && sg > 0) {
+#pragma unroll
+                for (int i = 0; i < 36; ++i) spart[((sg - 1) * SYM_TILES + stt) * 36 + i] = acc[i];
+            }
+            __syncthreads();
+            if (sact && sg == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const double sum = ((acc[6 * i + j] + spart[stt * 36 + 6 * i + j]) + spart[(SYM_TILES + stt) * 36 + 6 * i + j]) +
+                                           spart[(2 * SYM_TILES + stt) * 36 + 6 * i + j];
+                        const double v = dbase[6 * i + j] - sum;
+                        out[(size_t)(sr * 6 + i) * BD + sc * 6 + j] = v;
+                        if (sr != sc) out[(size_t)(sc * 6 + j) * BD + sr * 6 + i] = v;
+                    }
+            }
+            return;
         } else if (blockIdx.y == 1) {
             // the folded block e - s must have a coupling on its far side: a block at e - 2s, or the pinned first block
             if (!hasPrev || !(prev - s >= 0 || P.pin0)) return;
@@ -518,8 +547,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 for (int j = 0; j < 6; ++j) {
                     const double sum = (acc[6 * i + j] + part[tt * 36 + 6 * i + j]) + part[(144 + tt) * 36 + 6 * i + j];
                     const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
-                    if (blockIdx.y == 0) out[o] = dbase[6 * i + j] - sum;
-                    else { out[o] = -sum; if (outT) outT[(size_t)(tc * 6 + j) * BD + tr * 6 + i] = -sum; }
+                    out[o] = -sum;
+                    if (outT) outT[(size_t)(tc * 6 + j) * BD + tr * 6 + i] = -sum;
                 }
         }
         return;
