@@ -589,13 +589,20 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
 #pragma unroll
     for (int i = 0; i < 36; ++i) dbase[i] = 0.0;
     if (blockIdx.y == 0) {
+        // D' = D_e - YU^T YU - YL^T YL is symmetric: the 78 upper 6x6 tiles, a 4-way split over k, mirrored stores
         out = N.D + (size_t)m * BD * BD;
         base = L.D + (size_t)e * BD * BD;
-        if (act && g == 0) {      // the tile of D this lane finishes: fetched now, under the products
+        constexpr int SYM_SPLIT = 4, SYM_KCH = BD / SYM_SPLIT, SYM_TILES = 78;
+        const bool sact = t < SYM_SPLIT * SYM_TILES;
+        const int sg = t / SYM_TILES, stt = t - sg * SYM_TILES;
+        int sr = 0, rem = stt;
+        while (rem >= 12 - sr) { rem -= 12 - sr; ++sr; }
+        const int sc = sr + rem;
+        if (sact && sg == 0) {      // the tile of D this lane finishes: fetched now, under the products
 #pragma unroll
             for (int i = 0; i < 6; ++i)
 #pragma unroll
-                for (int j = 0; j < 6; ++j) dbase[6 * i + j] = base[(size_t)(tr * 6 + i) * BD + tc * 6 + j];
+                for (int j = 0; j < 6; ++j) dbase[6 * i + j] = base[(size_t)(sr * 6 + i) * BD + sc * 6 + j];
         }
         if (hasPrev) stage_block(sA, L.YU + (size_t)tp * BD * BD, RED_THREADS);
         if (hasNext) stage_block(sB, L.L + (size_t)(e + 1) * BD * BD, RED_THREADS);
@@ -605,12 +612,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
             rbase = L.r[(size_t)e * BD + t];
         }
         __syncthreads();
-        if (act) {
-            if (hasPrev) tile_mac(acc, sA, sA, g, tr, tc);
-            if (hasNext) tile_mac(acc, sB, sB, g, tr, tc);
-        } else if (t - KSPLIT * 144 < 0) {
+        if (sact) {
+            if (hasPrev) tile_mac_k(acc, sA, sA, sg * SYM_KCH, (sg + 1) * SYM_KCH, sr, sc);
+            if (hasNext) tile_mac_k(acc, sB, sB, sg * SYM_KCH, (sg + 1) * SYM_KCH, sr, sc);
         }
-        // r' = r_e - YU(e-1)^T yr(e-1) - YL(e+1)^T yr(e+1) on the spare lanes' time: lanes 0..71
+        // r' = r_e - YU(e-1)^T yr(e-1) - YL(e+1)^T yr(e+1): lanes 0..71
         if (t < BD) {
             double v0 = 0.0, v1 = 0.0;
             if (hasPrev) for (int k = 0; k < BD; ++k) v0 += sA[k * BD + t] * sya[k];
@@ -618,6 +624,25 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
             N.r[(size_t)m * BD + t] = rbase - v0 - v1;
         }
         __syncthreads();
+        double *spart = lds;
+        if (sact && sg > 0) {
+#pragma unroll
+            for (int i = 0; i < 36; ++i) spart[((sg - 1) * SYM_TILES + stt) * 36 + i] = acc[i];
+        }
+        __syncthreads();
+        if (sact && sg == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double sum = ((acc[6 * i + j] + spart[stt * 36 + 6 * i + j]) + spart[(SYM_TILES + stt) * 36 + 6 * i + j]) +
+                                       spart[(2 * SYM_TILES + stt) * 36 + 6 * i + j];
+                    const double v = dbase[6 * i + j] - sum;
+                    out[(size_t)(sr * 6 + i) * BD + sc * 6 + j] = v;
+                    if (sr != sc) out[(size_t)(sc * 6 + j) * BD + sr * 6 + i] = v;
+                }
+        }
+        return;
     } else {
         if (m == 0) return;   // L'[0] does not exist
         out = N.L + (size_t)m * BD * BD;
@@ -643,7 +668,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_bcr_reduce(Dev d, int lev, int 
                 const size_t o = (size_t)(tr * 6 + i) * BD + tc * 6 + j;
                 // an even-indexed coupling block of the next level is stored transposed
                 const size_t ow = (blockIdx.y == 1 && (m & 1) == 0) ? (size_t)(tc * 6 + j) * BD + tr * 6 + i : o;
-                out[ow] = dbase[6 * i + j] - s;
+                out[ow] = -s;
             }
     }
 }
