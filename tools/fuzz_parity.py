@@ -38,7 +38,9 @@ def lighting_case(rng, c, P, L, T, seed):
     okm[0] = True
     trace = float(np.max(np.abs(log["cost"][:n][okm] - log2["cost"][:n][okm]) / np.abs(log2["cost"][:n][okm])))
     fin = abs(s.final_cost - s2.final_cost) / abs(s2.final_cost)
-    ok = acc_ok and trace < 1e-5 and fin < 1e-3       # the tolerances of tests/test_gpu_phong_solve.py: long flat tails
+    # the lighting model clamps the colour to [0, 1] (phong.hpp:33, utils.hpp:16-25): a far-off trial step can sit on a
+    # clamp, where the last bits decide a finite jump of the cost -- the traces may part by ~1e-5 there and meet again
+    ok = acc_ok and trace < 1e-4 and fin < 1e-6
     print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} lighting M={M} light={light_type} free={shared_free} bounds={int(bounds)} dogleg={dog:2d} "
           f"iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} trace={trace:.1e} final={fin:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     ba.close()
