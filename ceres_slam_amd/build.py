@@ -12,10 +12,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libssba.so")
-SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip", "ssba_pool.hip"]
+SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_bcr_mfma.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip", "ssba_pool.hip"]
 HEADERS = ["ssba_types.h", "ssba_pool.h", "ssba_launch.h", "ssba_device.h", "ssba_phong_device.h", "ssba_linesearch.h", "ssba_posefactor_device.h", os.path.join("..", "..", "include", "ssba.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *os.environ.get("SSBA_EXTRA_FLAGS", "").split(),
          "-Wno-unused-value", "-Wno-unused-variable", "-Wno-unused-result"]
+
+
+# per-file flags: the factor kernel's accumulator tiles are also VALU operands (pivot rows, row scaling), so the matrix
+# instructions take them from the architectural registers instead of bouncing them through v_accvgpr_read / _write
+FILE_FLAGS = {"ssba_bcr_mfma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale() -> bool:
@@ -34,7 +39,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc, *[f for f in FLAGS if f], "-c", os.path.join(CSRC, s), "-o", obj]
+        cmd = [hipcc, *[f for f in FLAGS if f], *FILE_FLAGS.get(s, []), "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

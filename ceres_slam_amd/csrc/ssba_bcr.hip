@@ -23,6 +23,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -751,9 +753,23 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
 // blocks eliminated at a level: all odd ones, except the pinned end of a partitioned chain
 static int n_odd(const BcrLevel &lv, int pinned) { return pinned ? (lv.n - 1) / 2 : lv.n / 2; }
 
+// The matrix-core kernels of ssba_bcr_mfma.hip are the production path; SSBA_BCR_LEGACY=1 selects the register-tile
+// kernels above (same contract; tests compare the two).
+static bool bcr_legacy() {
+    static const bool v = [] { const char *e = getenv("SSBA_BCR_LEGACY"); return e && e[0] == '1'; }();
+    return v;
+}
+// coupled: the blocks still have L / U operands (false for the decoupled last step of an unpinned plan)
+static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled) {
+    if (bcr_legacy()) LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(nblocks), dim3(FACT_THREADS), (size_t)FACT_LDS_DOUBLES * sizeof(double), d, lev, top, which);
+    else launch_bcr_factor_mf(L, d, nblocks, lev, top, which, coupled);
+}
+static void launch_reduce(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which) {
+    if (bcr_legacy()) LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(nblocks, ny), dim3(RED_THREADS), (size_t)2 * BD * BD * sizeof(double), d, lev, which);
+    else launch_bcr_reduce_mf(L, d, nblocks, ny, lev, which);
+}
+
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
-    const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
-    const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
     if (!d.part && allow_pcr && d.pcr.level >= 0) {
@@ -762,14 +778,14 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
         const int k = d.pcr.level, n = d.pcr.n;
         for (int l = 0; l < k; ++l) {
             const int nn = d.lev[l].n;
-            LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(nn / 2), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
-            LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((nn + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
+            launch_factor(L, d, nn / 2, l, 0, 0, true);
+            launch_reduce(L, d, (nn + 1) / 2, 2, l, 0);
         }
         for (int q = 0; q < d.pcr.steps; ++q) {
-            LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, q, 0, 2);
-            LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(n, 2), dim3(RED_THREADS), sh_reduce, d, q, 2);
+            launch_factor(L, d, n, q, 0, 2, true);
+            launch_reduce(L, d, n, 2, q, 2);
         }
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, d.pcr.steps, 1, 2);
+        launch_factor(L, d, n, d.pcr.steps, 1, 2, false);
         LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
         for (int l = k - 1; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
@@ -778,10 +794,10 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
     if (!d.part) {
         for (int l = 0; l + 1 < nl; ++l) {
             const int n = d.lev[l].n;
-            LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n / 2), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
-            LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3((n + 1) / 2, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
+            launch_factor(L, d, n / 2, l, 0, 0, true);
+            launch_reduce(L, d, (n + 1) / 2, 2, l, 0);
         }
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(1), dim3(FACT_THREADS), sh_factor, d, nl - 1, 1, 0);
+        launch_factor(L, d, 1, nl - 1, 1, 0, false);
         LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, nl - 1, 1, 0);
         for (int l = nl - 2; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
@@ -793,28 +809,26 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
     // couplings to the pinned ones.  launch_bcr_separators() continues after the separator exchange.
     const int k = d.pcr.level, n = d.pcr.n;
     for (int l = 0; l < k; ++l) {
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n_odd(d.lev[l], d.lev[l].pin)), dim3(FACT_THREADS), sh_factor, d, l, 0, 0);
-        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(d.lev[l + 1].n, 2), dim3(RED_THREADS), sh_reduce, d, l, 0);
+        launch_factor(L, d, n_odd(d.lev[l], d.lev[l].pin), l, 0, 0, true);
+        launch_reduce(L, d, d.lev[l + 1].n, 2, l, 0);
     }
     for (int q = 0; q < d.pcr.steps; ++q) {
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, q, 0, 2);
-        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(n, d.pcr.pin1 ? 3 : 2), dim3(RED_THREADS), sh_reduce, d, q, 2);
+        launch_factor(L, d, n, q, 0, 2, true);
+        launch_reduce(L, d, n, d.pcr.pin1 ? 3 : 2, q, 2);
     }
-    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(n), dim3(FACT_THREADS), sh_factor, d, d.pcr.steps, 1, 2);
+    launch_factor(L, d, n, d.pcr.steps, 1, 2, d.pcr.pin0 || d.pcr.pin1);
 }
 
 // separator system (the blocks shared by neighbouring ranks, summed over the ranks): parallel cyclic reduction,
 // replicated on every rank; then the back-substitution of this rank's chain interior
 void launch_bcr_separators(Launcher &L, const Dev &d) {
-    const size_t sh_reduce = (size_t)2 * BD * BD * sizeof(double);
-    const size_t sh_factor = (size_t)FACT_LDS_DOUBLES * sizeof(double);
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int ns = d.n_sep;
     for (int q = 0; q < d.spcr.steps; ++q) {
-        LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(ns), dim3(FACT_THREADS), sh_factor, d, q, 0, 3);
-        LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(ns, 2), dim3(RED_THREADS), sh_reduce, d, q, 3);
+        launch_factor(L, d, ns, q, 0, 3, true);
+        launch_reduce(L, d, ns, 2, q, 3);
     }
-    LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(ns), dim3(FACT_THREADS), sh_factor, d, d.spcr.steps, 1, 3);
+    launch_factor(L, d, ns, d.spcr.steps, 1, 3, false);
     LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(ns), dim3(BS_THREADS), sh_backsub, d, 0, 1, 3);
     launch_sep_scatter(L, d);       // x0 at the separator poses <- separator solution
     LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.pcr.n), dim3(BS_THREADS), sh_backsub, d, d.pcr.level, 1, 2);
@@ -827,7 +841,7 @@ int configure_kernels() {
     if (hipFuncSetAttribute((const void *)k_bcr_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, sh_reduce) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_bcr_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FACT_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_bcr_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * BD * BD * sizeof(double))) != hipSuccess) return -1;
-    return 0;
+    return configure_bcr_mf();
 }
 
 }  // namespace ssba

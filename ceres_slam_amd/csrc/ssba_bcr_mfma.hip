@@ -1,0 +1,809 @@
+// Block factor / reduce kernels of the reduced-camera solve on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Same contract as the first-generation kernels in ssba_bcr.hip (kept there as the cross-check, SSBA_BCR_LEGACY=1):
+//   k_bcr_factor_mf:  D = G G^T ; YL = G^-1 L ; YU = G^-1 U^T ; yr = G^-1 r      (G stored lower, 1/G_kk on its diagonal)
+//   k_bcr_reduce_mf:  D' = D - YU^T YU - YL^T YL ; L' = -YU^T YL ; r' = r - YU^T yr - YL^T yr
+//
+// Factor.  The 72 x 72 block is factored as U^T U on the UPPER triangle in 16-wide column tiles that live in the MFMA
+// accumulator layout (lane (g, j) = (lane >> 4, lane & 15), register q: row 4q + g, column j of the tile) for the whole
+// kernel.  That layout is closed under everything the factorisation needs:
+//   * a finished row panel X (rows = the pivots k) is, register by register, already the A *and* the B operand of the
+//     trailing update  T_ij -= X_i^T X_j  (k-step s of the instruction sums over the rows {4s + g} = register s);
+//   * the panel solve runs in sub-steps of four pivots: the 4 x 4 pivot block is factored LDL^T "uniformly" (every lane
+//     computes the same 30 scalars from v_readlane copies -- the only serial chain of the kernel: four reciprocals),
+//     its unit-lower inverse M becomes the A operand P of ONE instruction  c = M T[rows]  and the scaled pivot rows
+//     Q = -c / d the A operand of ONE instruction that updates the rows below; every other tile of the block row
+//     ([D | r] to the right of the diagonal, [L | U^T]) follows with the same two operands.
+// Only P, Q (512 B each) and the finished D panels (as A operands of other waves' updates) go through LDS; the
+// right-hand sides never leave their registers.  Square roots are off the chain: rows stay in the LDL^T scaling and
+// are multiplied by 1/sqrt(d) when they are stored.
+// Work split: a workgroup = 4 waves (one per SIMD; fp64 MFMA reaches its rate from one wave).  Wave w owns column w of
+// [D | r] (wave 0: columns 0 and 4) and factors its diagonal tile one step ahead of the others' trailing updates; the nine
+// column tiles of [L | U^T] are dealt to the waves of gridDim.y workgroups (each of which repeats the cheap D part), so a
+// chain of 84 blocks fills 252 CUs.
+//
+// Reduce.  Operands staged once in LDS (row stride 80: columns 72.. hold yr and zeros, so r' falls out of the
+// same products), output tiles dealt to the waves, K = 72 = 18 instructions per tile and product.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssba_launch.h"
+#include "ssba_types.h"
+
+namespace ssba {
+
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+
+static __device__ __forceinline__ mf_d4 mf(double a, double b, mf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+static __device__ __forceinline__ double mf_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+static __device__ __forceinline__ double mf_rcp(double a) {      // hardware estimate (~2^-26) + one Newton step
+    double r = __builtin_amdgcn_rcp(a);
+    return fma(fma(-a, r, 1.0), r, r);
+}
+static __device__ __forceinline__ double mf_rsqrt(double a) {
+    double r = __builtin_amdgcn_rsq(a);
+    r = r * (1.5 - 0.5 * a * r * r);
+    r = r * (1.5 - 0.5 * a * r * r);
+    return r;
+}
+
+#ifdef SSBA_STAMPS
+#define MF_STAMP(i) do { if (bx == 3 && by == 0 && (threadIdx.x & 63) == 0) d.dbg[(threadIdx.x >> 6) * 64 + (i)] = clock64(); } while (0)
+#else
+#define MF_STAMP(i) do { } while (0)
+#endif
+
+// XCD-aware placement: workgroups go to the eight XCDs round-robin by linear id (id % 8), and each XCD has its own L2.
+// The workgroups that share a block's operands should sit on one XCD so that the operands cross the fabric once per
+// XCD.  The n x ny (block, part) pairs are listed grouped by block % 8 and XCD c takes a contiguous run of that list
+// (its ids c, c + 8, ...): exactly n x ny ids, no padding workgroups.  id -> (block e, part y).
+static __device__ __forceinline__ void xcd_map(int id, int n, int ny, int &e, int &y) {
+    const int N = n * ny, c = id & 7;
+    int idx = id >> 3;
+    for (int k = 0; k < c; ++k) idx += (N - k + 7) >> 3;      // ids of the XCDs before c
+    e = 0; y = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int sk = ((n - k + 7) >> 3) * ny;                 // pairs of the blocks with e % 8 == k
+        if (idx < sk) { const int bq = idx / ny; y = idx - bq * ny; e = k + 8 * bq; return; }
+        idx -= sk;
+    }
+}
+static int xcd_grid(int n, int ny) { return n * ny; }
+
+constexpr int MF_THREADS = 256;
+constexpr int NDT = 5;          // tile rows / column tiles of [D | r | 0]
+constexpr int NRT = 9;          // column tiles of [L | U^T]
+
+struct FactorOps {
+    const double *Dg, *Lg, *Ug, *rin;
+    double *oD, *oYL, *oYU, *orr, *saveU;
+    bool hasL, hasU, trL, trU;
+};
+
+// operands and destinations of one block: mirrors k_bcr_factor (ssba_bcr.hip).  false: this block has nothing to do.
+static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top, int which, int bx, bool copier, FactorOps &o) {
+    o.trL = o.trU = false;
+    o.saveU = nullptr;
+    if (which >= 2) {
+        const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+        const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
+        const int blk = bx, s = 1 << lev, last = B.n - 1;
+        if (P.pin0 && lev == 0 && blk == 1 && copier) {
+            const double2 *s2 = reinterpret_cast<const double2 *>(B.L + (size_t)BD * BD);
+            double2 *d2 = reinterpret_cast<double2 *>(P.Lbuf + (size_t)BD * BD);
+            for (int e = threadIdx.x; e < BD * BD / 2; e += MF_THREADS) d2[e] = s2[e];
+        }
+        if ((P.pin0 && blk == 0) || (P.pin1 && blk == last)) return false;
+        o.hasL = blk - s >= 0 || (P.pin0 && blk > 0);
+        o.hasU = blk + s <= last || (P.pin1 && blk < last);
+        o.Dg = B.D + (size_t)blk * BD * BD;
+        o.rin = B.r + (size_t)blk * BD;
+        if (lev == 0) {
+            o.Lg = B.L + (size_t)blk * BD * BD;
+            o.Ug = B.L + (size_t)(o.hasU ? blk + 1 : blk) * BD * BD;
+            o.trL = o.trU = (blk & 1) == 0;
+        } else {
+            o.Lg = P.Lbuf + (size_t)blk * BD * BD;
+            o.Ug = (P.pin1 && blk + s > last) ? P.Ubuf + (size_t)blk * BD * BD : P.LbufT + (size_t)(o.hasU ? blk + s : blk) * BD * BD;
+        }
+        if (P.pin1 && blk + s == last) o.saveU = P.Ubuf + (size_t)blk * BD * BD;
+        const size_t so = P.keep ? (size_t)lev * B.n + blk : (size_t)blk;
+        o.oD = top ? B.D + (size_t)blk * BD * BD : (P.keep ? P.Gs + so * BD * BD : nullptr);
+        o.oYL = o.hasL ? P.YL + so * BD * BD : nullptr;
+        o.oYU = o.hasU ? P.YU + so * BD * BD : nullptr;
+        o.orr = top ? B.r + (size_t)blk * BD : P.yr + (size_t)blk * BD;
+    } else {
+        const BcrLevel &L = d.lev[lev];
+        const int blk = top ? 0 : 2 * bx + 1;
+        o.hasL = !top;
+        o.hasU = !top && (blk + 1 < L.n);
+        o.Dg = L.D + (size_t)blk * BD * BD;
+        o.Lg = L.L + (size_t)blk * BD * BD;
+        o.Ug = L.L + (size_t)(o.hasU ? blk + 1 : blk) * BD * BD;
+        o.rin = L.r + (size_t)blk * BD;
+        o.oD = L.D + (size_t)blk * BD * BD;
+        o.oYL = o.hasL ? L.L + (size_t)blk * BD * BD : nullptr;
+        o.oYU = top ? nullptr : L.YU + (size_t)bx * BD * BD;
+        o.orr = L.r + (size_t)blk * BD;
+    }
+    return true;
+}
+
+struct FactorLds {
+    // every block row has its own slots: nothing is overwritten during a factorisation, so the hand-offs below need
+    // no write-after-read protection
+    double P[NDT][4][64], Q[NDT][4][64];    // sub-step operands of the diagonal tiles: [block row][sub-step][lane]
+    double A[NDT - 1][4][4][64];            // finished D panels as A operands: [block row][column tile - 1][register][lane]
+    double piv[80], rc[80], rs[80];         // pivots d, 1/d, 1/sqrt(d) by row
+    // hand-offs between the four waves (LDS words, monotonic): no workgroup barrier inside the factorisation
+    int seqPQ;                              // sub-steps published so far: 4 k + r + 1
+    int seqA[4];                            // per column tile - 1: block rows whose panel is published (k + 1)
+    int bad;
+};
+
+// Hand-off words live in LDS and are read / written with workgroup-scope relaxed atomics (plain ds_read / ds_write):
+// the LDS unit serves the requests of a wave in issue order, so data written before the flag is visible to whoever
+// sees the flag; the compiler is kept from reordering around the flag access by an empty asm with a memory clobber.
+// The spin is wave-uniform (v_readfirstlane) and BOUNDED: a lost hand-off must never hang the GPU -- it flags the
+// step as failed instead (S.bad = 2).
+#define MF_WAIT_GE(word, v)                                                                                              \
+    do {                                                                                                                 \
+        int it_ = 0;                                                                                                     \
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (v)) { \
+            if (++it_ > (1 << 20)) { S.bad = 2; break; }                                                                 \
+            __builtin_amdgcn_s_sleep(1);                                                                                 \
+        }                                                                                                                \
+        asm volatile("" ::: "memory");                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    } while (0)
+// the store must not sink below the arithmetic that follows it (the instruction scheduler would happily post a
+// sub-step's flag a whole sub-step late): full scheduling barriers on both sides
+#define MF_POST(word, v)                                                                                                 \
+    do {                                                                                                                 \
+        asm volatile("" ::: "memory");                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        __hip_atomic_store(&(word), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    } while (0)
+
+// NRW: column tiles of [L | U^T] per wave (1: three workgroups per block, 2: two, 3: one)
+template <int NRW>
+__global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns) {
+    State &st = *d.st;
+    const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested once the operand reads are in flight
+    __shared__ FactorLds S;
+    FactorOps o;
+    int bx, by;
+    xcd_map((int)blockIdx.x, nblocks, ns, bx, by);
+    if (!factor_ops(d, lev, top, which, bx, by == 0 && !dead, o)) return;
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool storeG = by == 0;
+    // this workgroup's share of the nine right-hand-side column tiles, dealt to waves 1, 2, 3, 0, 1, ... (wave 0 owns the
+    // longest column of [D | r] and two diagonal tiles: it comes last)
+    const int rfirst = (by * NRT) / ns, rcnt = ((by + 1) * NRT) / ns - rfirst;
+    int rcol[NRW];
+    bool ract[NRW];
+#pragma unroll
+    for (int q = 0; q < NRW; ++q) {
+        const int idx = ((w + 3) & 3) + 4 * q;
+        rcol[q] = rfirst + idx;
+        ract[q] = idx < rcnt && ((rcol[q] <= 4 && o.hasL) || (rcol[q] >= 4 && o.hasU));
+    }
+    const int dj = w == 0 ? 4 : w;          // column tile of [D | r] this wave owns (wave 0 also owns tile (0, 0))
+    if (t == 0) { S.bad = 0; S.seqPQ = 0; }
+    if (t < 4) S.seqA[t] = 0;
+    if (t < 8) { S.piv[72 + t] = 1.0; S.rc[72 + t] = 1.0; }
+    MF_STAMP(0);
+
+    // ---- load: straight into the accumulator layout (128-byte row segments): one per-lane base pointer per column
+    //      tile, compile-time row offsets, every load issued before the first is waited for ----------------------
+    mf_d4 dt[NDT], d00, rt[NRW][NDT];
+    {
+        const int colD = 16 * dj + j;
+        const double *pD = o.Dg + g * BD + min(colD, BD - 1), *pr = o.rin + g;
+        double rv[NDT][4];
+#pragma unroll
+        for (int k = 0; k < NDT; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = k < 4 || q < 2;           // rows 72..79 are padding
+                dt[k][q] = (in && k <= dj) ? pD[(16 * k + 4 * q) * BD] : 0.0;
+                rv[k][q] = (in && w == 0) ? pr[16 * k + 4 * q] : 0.0;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;
+        bool rok[NRW];
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) {
+            const int col = 16 * rcol[q] + j;
+            const bool isL = col < BD;
+            const int cc = isL ? col : col - BD;
+            const bool tr = o.trL;                       // trL == trU (ssba_bcr.hip: even blocks of level 0)
+            const double *base = isL ? o.Lg : o.Ug;
+            rok[q] = ract[q] && (isL ? o.hasL : o.hasU);
+            if (!ract[q]) {
+#pragma unroll
+                for (int k = 0; k < NDT; ++k) rt[q][k] = mf_d4{0.0, 0.0, 0.0, 0.0};
+            } else if (tr) {
+                const double *pp = base + cc * BD + g;
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = (k < 4 || qq < 2) ? pp[16 * k + 4 * qq] : 0.0;
+            } else {
+                const double *pp = base + g * BD + cc;
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = (k < 4 || qq < 2) ? pp[(16 * k + 4 * qq) * BD] : 0.0;
+            }
+        }
+        if (dead) return;
+        // masks: column 72 of [D | r] is the right-hand side, the columns after it are zero; absent couplings are zero
+        if (dj == 4) {
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dt[k][q] = colD < BD ? dt[k][q] : colD == BD ? rv[k][q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) {
+            if (!ract[q]) continue;
+            if (!rok[q]) {
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = 0.0;
+            }
+            const int col = 16 * rcol[q] + j;
+            if (o.saveU && rok[q] && col >= BD) {
+                double *ps = o.saveU + g * BD + col - BD;
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (k < 4 || qq < 2) ps[(16 * k + 4 * qq) * BD] = rt[q][k][qq];
+            }
+        }
+    }
+
+    // lane masks of the sub-step operands (all-ones / zero words): bit selects instead of branches
+    auto mk = [](bool c) { return c ? 0xFFFFFFFFu : 0u; };
+    const uint32_t mG0 = mk(g == 0), mG1 = mk(g == 1), mG2 = mk(g == 2), mG3 = mk(g == 3);
+    const uint32_t mDiag = mk(j < 4 && g == j);
+    const uint32_t m10 = mk(j == 1 && g == 0), m20 = mk(j == 2 && g == 0), m21 = mk(j == 2 && g == 1);
+    const uint32_t m30 = mk(j == 3 && g == 0), m31 = mk(j == 3 && g == 1), m32 = mk(j == 3 && g == 2);
+    auto sel = [](double v, uint32_t m, double acc) {      // (v & m) | acc, bitwise
+        const uint32_t lo = ((uint32_t)__double2loint(v) & m) | (uint32_t)__double2loint(acc);
+        const uint32_t hi = ((uint32_t)__double2hiint(v) & m) | (uint32_t)__double2hiint(acc);
+        return __hiloint2double((int)hi, (int)lo);
+    };
+    // ---- sub-steps of a diagonal tile T (block row k; nsub = 4, or 2 for the half tile of rows 64..71) -----------
+    // A non-positive pivot is not handled here (that would sit on the chain): it ends up in S.piv and is found after
+    // the factorisation; nothing below loops on data, so garbage just flows through.
+    auto factor_tile = [&](mf_d4 &T, int k, int nsub) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nsub) break;
+            const int b = 4 * r;      // S[a][c] = T[4r + a][4r + c] sits in register r of lane 16 a + 4r + c
+            const double tr = T[r];
+            const double s00 = mf_readlane(tr, b), s10 = mf_readlane(tr, 16 + b), s20 = mf_readlane(tr, 32 + b), s30 = mf_readlane(tr, 48 + b);
+            const double s11 = mf_readlane(tr, 16 + b + 1);
+            double s21 = mf_readlane(tr, 32 + b + 1), s31 = mf_readlane(tr, 48 + b + 1);
+            const double s22 = mf_readlane(tr, 32 + b + 2);
+            double s32 = mf_readlane(tr, 48 + b + 2);
+            const double s33 = mf_readlane(tr, 48 + b + 3);
+            // LDL^T of the pivot block: unit lower l, pivots d.  The serial chain is, per pivot: hardware reciprocal
+            // estimate x0 -> { t = s x0 , e = 1 - d x0 } -> l = t + t e  (= s / d to ~2^-52) -> next pivot; the refined
+            // reciprocal itself (x0 + x0 e, for the row scaling) is off the chain.
+            const double x0 = __builtin_amdgcn_rcp(s00), e0 = fma(-s00, x0, 1.0);
+            const double t10 = s10 * x0, t20 = s20 * x0, t30 = s30 * x0;
+            const double l10 = fma(t10, e0, t10), l20 = fma(t20, e0, t20), l30 = fma(t30, e0, t30);
+            const double d1 = fma(-s10, l10, s11);
+            s21 = fma(-s20, l10, s21); s31 = fma(-s30, l10, s31);
+            const double x1 = __builtin_amdgcn_rcp(d1), e1 = fma(-d1, x1, 1.0);
+            const double t21 = s21 * x1, t31 = s31 * x1;
+            const double l21 = fma(t21, e1, t21), l31 = fma(t31, e1, t31);
+            const double d2 = fma(-s21, l21, fma(-s20, l20, s22));
+            s32 = fma(-s31, l21, fma(-s30, l20, s32));
+            const double x2 = __builtin_amdgcn_rcp(d2), e2 = fma(-d2, x2, 1.0);
+            const double t32 = s32 * x2;
+            const double l32 = fma(t32, e2, t32);
+            const double d3 = fma(-s32, l32, fma(-s31, l31, fma(-s30, l30, s33)));
+            const double x3 = __builtin_amdgcn_rcp(d3), e3 = fma(-d3, x3, 1.0);
+            const double rc0 = fma(x0, e0, x0), rc1 = fma(x1, e1, x1), rc2 = fma(x2, e2, x2), rc3 = fma(x3, e3, x3);
+            // M = l^-1 (unit lower); P: lane (g, i = j) holds M[i][g] for i < 4
+            const double n20 = fma(l21, l10, -l20);
+            const double n31 = fma(l32, l21, -l31);
+            const double n30 = -fma(l32, n20, fma(l31, -l10, l30));
+            double Pv = sel(1.0, mDiag, 0.0);
+            Pv = sel(-l10, m10, Pv); Pv = sel(n20, m20, Pv); Pv = sel(-l21, m21, Pv);
+            Pv = sel(n31, m31, Pv); Pv = sel(-l32, m32, Pv); Pv = sel(n30, m30, Pv);
+            const mf_d4 y4 = mf(Pv, tr, mf_d4{0.0, 0.0, 0.0, 0.0});
+            double rcg = sel(rc0, mG0, 0.0);
+            rcg = sel(rc1, mG1, rcg); rcg = sel(rc2, mG2, rcg); rcg = sel(rc3, mG3, rcg);
+            const double qs = sel(-rcg, mk(j > b + 3), 0.0);
+            const double y = y4[0];             // lane (g, j): unnormalised pivot row c_g[j] = (d l^T ...)[4r + g][j]
+            T[r] = y;
+            const double Qv = y * qs;
+            if (r + 1 < nsub) T = mf(Qv, y, T);
+            S.P[k][r][lane] = Pv;
+            S.Q[k][r][lane] = Qv;
+            if (lane == 0) {        // uniform values: one lane publishes the four pivots and their reciprocals
+                double *pp = &S.piv[16 * k + b], *pr = &S.rc[16 * k + b];
+                pp[0] = s00; pp[1] = d1; pp[2] = d2; pp[3] = d3;
+                pr[0] = rc0; pr[1] = rc1; pr[2] = rc2; pr[3] = rc3;
+            }
+            MF_POST(S.seqPQ, 4 * k + r + 1);
+        }
+    };
+    // Two instruction streams per wave.  The D stream (this wave's column of [D | r]) is what the next factorisation
+    // waits for, so it runs first in every block row: forward substitution of tile (k, dj) sub-step by sub-step as the
+    // diagonal tile's operands arrive; a finished register of it is at once the A operand (-x / d(row)) and the B
+    // operand of the update of the wave's OWN diagonal tile (dj, dj), and goes out to LDS as the A operand of
+    // everybody's updates of block row dj.  The R stream (the wave's tiles of [L | U^T]) follows one block row behind
+    // and fills the time the wave would otherwise spend waiting for the next diagonal tile.
+    auto d_panel = [&](int k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            MF_WAIT_GE(S.seqPQ, 4 * k + r + 1);
+            const double Pv = S.P[k][r][lane], Qv = S.Q[k][r][lane];
+            const double rcr = S.rc[16 * k + 4 * r + g];
+            const mf_d4 yd = mf(Pv, dt[k][r], mf_d4{0.0, 0.0, 0.0, 0.0});
+            const double y = yd[0];
+            dt[k][r] = y;
+            const double a = -y * rcr;
+            S.A[k][dj - 1][r][lane] = a;
+#pragma unroll
+            for (int i = 1; i < NDT; ++i)
+                if (i == dj) dt[i] = mf(a, y, dt[i]);
+            if (r < 3) dt[k] = mf(Qv, y, dt[k]);
+        }
+        MF_POST(S.seqA[dj - 1], k + 1);
+    };
+    // tiles (i, dj), k < i < dj, of the D column: updated with the panels of the other columns
+    auto d_update = [&](int k) {
+#pragma unroll
+        for (int i = 1; i < NDT - 1; ++i) {
+            if (i <= k || i >= dj) continue;
+            MF_WAIT_GE(S.seqA[i - 1], k + 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dt[i] = mf(S.A[k][i - 1][s][lane], dt[k][s], dt[i]);
+        }
+    };
+    auto r_step = [&](int k) {
+        const int nsub = k < 4 ? 4 : 2;
+        MF_WAIT_GE(S.seqPQ, 4 * k + nsub);          // this stream lags: the whole diagonal tile is normally long done
+        double Pa[4], Qa[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { Pa[r] = r < nsub ? S.P[k][r][lane] : 0.0; Qa[r] = r < nsub ? S.Q[k][r][lane] : 0.0; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= nsub) break;
+            const double Pv = Pa[r], Qv = Qa[r];
+            mf_d4 yq[NRW];
+#pragma unroll
+            for (int q = 0; q < NRW; ++q)
+                if (ract[q]) yq[q] = mf(Pv, rt[q][k][r], mf_d4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+            for (int q = 0; q < NRW; ++q)
+                if (ract[q]) {
+                    rt[q][k][r] = yq[q][0];
+                    if (r + 1 < nsub) rt[q][k] = mf(Qv, yq[q][0], rt[q][k]);
+                }
+        }
+        // the panels of block row k (this stream lags, they are normally all there): one pass over the flags, then all
+        // A operands in one batch of LDS reads
+#pragma unroll
+        for (int i = 1; i < NDT; ++i)
+            if (i > k) MF_WAIT_GE(S.seqA[i - 1], k + 1);
+        double a[NDT][4];
+#pragma unroll
+        for (int i = 1; i < NDT; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[i][s] = i > k ? S.A[k][i - 1][s][lane] : 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 1; i < NDT; ++i) {
+                if (i <= k) continue;
+#pragma unroll
+                for (int q = 0; q < NRW; ++q)
+                    if (ract[q]) rt[q][i] = mf(a[i][s], rt[q][k][s], rt[q][i]);
+            }
+    };
+
+    MF_STAMP(1);
+    __syncthreads();
+    if (w == 0) factor_tile(d00, 0, 4);
+#pragma unroll
+    for (int k = 0; k < NDT; ++k) {
+        MF_STAMP(2 + 4 * k);
+        if (dj > k) d_panel(k);
+        MF_STAMP(3 + 4 * k);
+        if (k + 1 < NDT && dj == k + 1) factor_tile(dt[k + 1], k + 1, k + 1 < 4 ? 4 : 2);   // the next diagonal tile is this wave's
+        MF_STAMP(4 + 4 * k);
+        if (dj > k + 1) d_update(k);
+        if (k >= 1) r_step(k - 1);
+        MF_STAMP(5 + 4 * k);
+    }
+    r_step(NDT - 1);
+    MF_STAMP(30);
+    __syncthreads();
+    if (t < BD) {
+        const double pv = S.piv[t];
+        if (!(pv > 0.0) || !(pv < INFINITY)) S.bad = 1;        // Cholesky breakdown: the step is rejected (Ceres: LM retries with a smaller radius)
+        S.rs[t] = mf_rsqrt(pv);
+    }
+    __syncthreads();
+    if (S.bad) {
+        if (t == 0) st.step_failed = 1;
+        return;
+    }
+
+    // ---- store: rows scaled by 1/sqrt(d) ---------------------------------------------------------------------
+    double rsv[NDT][4];
+#pragma unroll
+    for (int k = 0; k < NDT; ++k)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) rsv[k][qq] = (k < 4 || qq < 2) ? S.rs[16 * k + 4 * qq + g] : 0.0;
+#pragma unroll
+    for (int q = 0; q < NRW; ++q) {
+        if (!ract[q]) continue;
+        const int col = 16 * rcol[q] + j;
+        double *dst = col < BD ? o.oYL : o.oYU;
+        if (!dst) continue;
+        double *pp = dst + g * BD + (col < BD ? col : col - BD);
+#pragma unroll
+        for (int k = 0; k < NDT; ++k)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (k < 4 || qq < 2) pp[(16 * k + 4 * qq) * BD] = rt[q][k][qq] * rsv[k][qq];
+    }
+    if (storeG) {
+        // G = U^T: column c of U is row c of G; lane (g, j) of tile (k, c) holds U[16 k + 4 q + g][16 c + j]
+        auto store_g = [&](const mf_d4 &T, int k, int c, bool diag) {
+            const int col = 16 * c + j;
+            if (col < BD && o.oD) {
+                double *pp = o.oD + col * BD + g;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    if (!(k < 4 || qq < 2)) continue;
+                    const int row = 16 * k + 4 * qq + g;
+                    if (!diag || col >= row) pp[16 * k + 4 * qq] = (diag && col == row) ? rsv[k][qq] : T[qq] * rsv[k][qq];
+                }
+            }
+            if (col == BD) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (k < 4 || qq < 2) o.orr[16 * k + 4 * qq + g] = T[qq] * rsv[k][qq];
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < NDT; ++k)
+            if (k <= dj) store_g(dt[k], k, dj, k == dj);
+        if (w == 0) store_g(d00, 0, 0, true);
+    }
+    MF_STAMP(31);
+}
+
+// ---- reduce ---------------------------------------------------------------------------------------------------
+constexpr int RS = 80;                      // LDS row stride of a staged operand (columns 72..79: yr | zeros)
+constexpr int RED_LDS_DOUBLES = 3 * BD * RS;
+constexpr int STAGE_NLD = (BD * BD / 2 + MF_THREADS - 1) / MF_THREADS;     // 11 double2 per lane and operand
+
+struct StageRegs { double2 v[STAGE_NLD]; double y; };
+
+// global reads of a BD x BD row-major block (or zeros) + its right-hand-side column: issued, not waited for
+static __device__ __forceinline__ void stage_issue(StageRegs &R, const double *__restrict__ src, const double *__restrict__ yv) {
+    const double2 *s2 = reinterpret_cast<const double2 *>(src);
+#pragma unroll
+    for (int q = 0; q < STAGE_NLD; ++q) {
+        const int e = threadIdx.x + q * MF_THREADS;
+        R.v[q] = (src && e < BD * BD / 2) ? s2[e] : make_double2(0.0, 0.0);
+    }
+    R.y = (threadIdx.x < BD && yv) ? yv[threadIdx.x] : 0.0;
+}
+static __device__ __forceinline__ void stage_write(double *dst, const StageRegs &R) {
+#pragma unroll
+    for (int q = 0; q < STAGE_NLD; ++q) {
+        const int e = threadIdx.x + q * MF_THREADS;
+        if (e >= BD * BD / 2) continue;
+        const int r = (2 * e) / BD, c = 2 * e - r * BD;
+        *reinterpret_cast<double2 *>(dst + r * RS + c) = R.v[q];
+    }
+    if (threadIdx.x < BD) {
+        double *p = dst + threadIdx.x * RS + BD;
+        p[0] = R.y;
+#pragma unroll
+        for (int c = 1; c < 8; ++c) p[c] = 0.0;
+    }
+}
+
+// operands of one product  A(:, 16 ti ..)^T B(:, 16 tj ..)  over the BD staged rows: 36 LDS reads, then 18 instructions.
+// The reads of the next product are issued before the instructions of the current one (the compiler would otherwise
+// sink every read to its use and pay an LDS round trip per instruction pair).
+struct TnOps { double a[BD / 4], b[BD / 4]; };
+static __device__ __forceinline__ void tn_load(TnOps &O, const double *sA, const double *sB, int ti, int tj, int g, int j) {
+    const double *pa = sA + g * RS + 16 * ti + j, *pb = sB + g * RS + 16 * tj + j;
+#pragma unroll
+    for (int s = 0; s < BD / 4; ++s) { O.a[s] = pa[4 * s * RS]; O.b[s] = pb[4 * s * RS]; }
+}
+static __device__ __forceinline__ mf_d4 tn_mma(const TnOps &O, mf_d4 acc) {
+#pragma unroll
+    for (int s = 0; s < BD / 4; ++s) acc = mf(O.a[s], O.b[s], acc);
+    return acc;
+}
+// keeps the operand reads issued above it ahead of the matrix instructions below it (memory clobber for the compiler's
+// middle end, a scheduling barrier for the machine scheduler, which would otherwise sink the reads again)
+#define MF_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// One block's reduction as a job of three staged operands -- A0 = YU(prev) | yr(prev), A1 = YL(next) | yr(next),
+// A2 = YL(prev) -- and 55 units of 18 instructions: the 15 upper tiles of  D' = D - A0^T A0 - A1^T A1  (two units
+// each; column 72 of the staged operands makes r' = r - A0^T yr - A1^T yr fall out of the same tiles) and the 25 tiles
+// of the new coupling  -(A0^T A2).  Three workgroups (12 waves) share the units, at most five per wave.
+struct ReduceJob {
+    const double *a0, *ya0, *a1, *ya1, *a2;
+    const double *dbase, *rbase;            // D and r of the block (inputs of the symmetric part)
+    double *dout, *rout;                    // D', r'
+    double *out, *outT;                     // -(A0^T A2) and its transpose (either may be null)
+    bool sym, cpl;                          // which parts exist (chain ends, pinned blocks)
+};
+
+#ifdef SSBA_STAMPS
+#define RJ_STAMP(i) do { if (stamp_here && (threadIdx.x & 63) == 0) dbg[2048 + (threadIdx.x >> 6) * 64 + 16 * wg + (i)] = clock64(); } while (0)
+#else
+#define RJ_STAMP(i) do { } while (0)
+#endif
+// wg / nwg: this workgroup's index among the workgroups of the job.  dead: the solver state says "nothing to do"
+// (read by the caller; tested here, after the operand reads are in flight).
+static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *lds, int wg, int nwg, int dead, unsigned long long *dbg, bool stamp_here) {
+    double *sA0 = lds, *sA1 = lds + BD * RS, *sA2 = lds + 2 * BD * RS;
+    const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15, w = t >> 6;
+    const int W = 4 * wg + w, NW = 4 * nwg;     // wave index among the job's waves
+    RJ_STAMP(0);
+    StageRegs R0, R1, R2;
+    stage_issue(R0, (J.sym || J.cpl) ? J.a0 : nullptr, J.sym ? J.ya0 : nullptr);
+    stage_issue(R1, J.sym ? J.a1 : nullptr, J.sym ? J.ya1 : nullptr);
+    stage_issue(R2, J.cpl ? J.a2 : nullptr, nullptr);
+    if (dead) return;
+    // units of this wave: symmetric tiles n = W, W + NW (< 15); coupling tiles: the first ones go to the waves with
+    // a single symmetric tile so that nobody gets more than five units
+    constexpr int NSYM = 2, NCPL = 4;
+    int sti[NSYM], stj[NSYM], cti[NCPL], ctj[NCPL];
+    bool shave[NSYM], chave[NCPL];
+    double base[NSYM][4], rb[NSYM][4];
+    // waves 0 .. nextra-1 hold two symmetric tiles (none in a job without a symmetric part: coupling to a pinned block)
+    const int nextra = (J.sym && 15 - NW > 0) ? 15 - NW : 0;
+#pragma unroll
+    for (int sl = 0; sl < NSYM; ++sl) {
+        const int n = W + NW * sl;
+        shave[sl] = J.sym && n < 15;
+        // n -> (ti, tj): rows of the upper triangle start at 0, 5, 9, 12, 14
+        const int a = n >= 14 ? 4 : n >= 12 ? 3 : n >= 9 ? 2 : n >= 5 ? 1 : 0;
+        const int st0 = a == 4 ? 14 : a == 3 ? 12 : a == 2 ? 9 : a == 1 ? 5 : 0;
+        sti[sl] = a;
+        stj[sl] = min(a + (n - st0), NDT - 1);
+        // the entries of D / r this lane finishes: fetched now, under the staging
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rowc = min(16 * sti[sl] + 4 * q + g, BD - 1), colc = min(16 * stj[sl] + j, BD - 1);
+            base[sl][q] = shave[sl] ? J.dbase[rowc * BD + colc] : 0.0;
+            rb[sl][q] = shave[sl] ? J.rbase[rowc] : 0.0;
+        }
+    }
+    {
+        // 25 coupling tiles over the waves: waves with two symmetric tiles take one, the others share the rest evenly
+        const int light = NW - nextra;                  // waves with one symmetric tile
+#pragma unroll
+        for (int sl = 0; sl < NCPL; ++sl) {
+            int c;
+            if (W < nextra) c = sl == 0 ? W : 25;
+            else c = nextra + (W - nextra) + light * sl;
+            chave[sl] = J.cpl && c < 25;
+            c = min(c, 24);
+            cti[sl] = c / 5;
+            ctj[sl] = c - 5 * cti[sl];
+        }
+    }
+    stage_write(sA0, R0);
+    stage_write(sA1, R1);
+    stage_write(sA2, R2);
+    RJ_STAMP(1);
+    __syncthreads();
+    RJ_STAMP(2);
+    const bool p0 = J.a0 != nullptr, p1 = J.a1 != nullptr;
+    // products in order, operand reads one product ahead of the instructions (two register sets, alternating)
+    TnOps O0, O1;
+    mf_d4 sacc[NSYM], cacc[NCPL];
+#pragma unroll
+    for (int sl = 0; sl < NSYM; ++sl) sacc[sl] = mf_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int sl = 0; sl < NCPL; ++sl) cacc[sl] = mf_d4{0.0, 0.0, 0.0, 0.0};
+    const bool u0 = shave[0] && p0, u1 = shave[0] && p1, u2 = shave[1] && p0, u3 = shave[1] && p1;
+    if (u0) tn_load(O0, sA0, sA0, sti[0], stj[0], g, j);
+    MF_FENCE();
+    if (u1) tn_load(O1, sA1, sA1, sti[0], stj[0], g, j);
+    MF_FENCE();
+    if (u0) sacc[0] = tn_mma(O0, sacc[0]);
+    RJ_STAMP(4);
+    MF_FENCE();
+    if (u2) tn_load(O0, sA0, sA0, sti[1], stj[1], g, j);
+    MF_FENCE();
+    if (u1) sacc[0] = tn_mma(O1, sacc[0]);
+    RJ_STAMP(5);
+    MF_FENCE();
+    if (u3) tn_load(O1, sA1, sA1, sti[1], stj[1], g, j);
+    MF_FENCE();
+    if (u2) sacc[1] = tn_mma(O0, sacc[1]);
+    RJ_STAMP(6);
+    MF_FENCE();
+    if (chave[0]) tn_load(O0, sA0, sA2, cti[0], ctj[0], g, j);
+    MF_FENCE();
+    if (u3) sacc[1] = tn_mma(O1, sacc[1]);
+    RJ_STAMP(7);
+    MF_FENCE();
+    if (chave[1]) tn_load(O1, sA0, sA2, cti[1], ctj[1], g, j);
+    MF_FENCE();
+    if (chave[0]) cacc[0] = tn_mma(O0, cacc[0]);
+    RJ_STAMP(8);
+    MF_FENCE();
+    if (chave[2]) tn_load(O0, sA0, sA2, cti[2], ctj[2], g, j);
+    MF_FENCE();
+    if (chave[1]) cacc[1] = tn_mma(O1, cacc[1]);
+    RJ_STAMP(9);
+    MF_FENCE();
+    if (chave[3]) tn_load(O1, sA0, sA2, cti[3], ctj[3], g, j);
+    MF_FENCE();
+    if (chave[2]) cacc[2] = tn_mma(O0, cacc[2]);
+    RJ_STAMP(10);
+    MF_FENCE();
+    if (chave[3]) cacc[3] = tn_mma(O1, cacc[3]);
+    RJ_STAMP(11);
+#pragma unroll
+    for (int sl = 0; sl < NSYM; ++sl) {
+        if (!shave[sl]) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * sti[sl] + 4 * q + g, col = 16 * stj[sl] + j;
+            if (row >= BD) continue;
+            if (col < BD) {
+                const double v = base[sl][q] - sacc[sl][q];
+                if (sti[sl] != stj[sl] || col >= row) {
+                    J.dout[row * BD + col] = v;
+                    if (col != row) J.dout[col * BD + row] = v;
+                }
+            } else if (col == BD) J.rout[row] = rb[sl][q] - sacc[sl][q];
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < NCPL; ++sl) {
+        if (!chave[sl]) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = 16 * cti[sl] + 4 * q + g, col = 16 * ctj[sl] + j;
+            if (row >= BD || col >= BD) continue;
+            if (J.out) J.out[row * BD + col] = -cacc[sl][q];
+            if (J.outT) J.outT[col * BD + row] = -cacc[sl][q];
+        }
+    }
+    RJ_STAMP(12);
+}
+
+// 1-D grid of xcd_grid(blocks, ny) workgroups, ny = 3 (+ 2 for the coupling to a pinned last block).  Parallel cyclic
+// reduction (which >= 2): D', r' in place, L' (+ its transpose) into the plan's buffers.  Plain levels (which = 0):
+// D', r', L' of the next level.  Same operand rules as k_bcr_reduce (ssba_bcr.hip).
+__global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, int which, int nblocks, int ny) {
+    const State &st = *d.st;
+    const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested after the operand reads have been issued
+    extern __shared__ __align__(16) double lds[];
+    int bx, y;
+    xcd_map((int)blockIdx.x, nblocks, ny, bx, y);
+    ReduceJob J;
+    J.a0 = J.a1 = J.a2 = J.ya0 = J.ya1 = J.dbase = J.rbase = nullptr;
+    J.dout = J.rout = J.out = J.outT = nullptr;
+    J.sym = J.cpl = false;
+    int wg = y, nwg = 3;
+    if (which >= 2) {
+        const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+        const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
+        const int e = bx, s = 1 << lev, prev = e - s, next = e + s, last = B.n - 1;
+        const int lo = P.pin0 ? 1 : 0, hi = P.pin1 ? last - 1 : last;
+        const bool hasPrev = prev >= lo, hasNext = next <= hi;
+        const size_t so = P.keep ? (size_t)lev * B.n : 0;
+        if (y < 3) {
+            J.sym = hasPrev || hasNext;
+            J.cpl = hasPrev && (prev - s >= 0 || P.pin0);
+            if (hasPrev) { J.a0 = P.YU + (so + prev) * BD * BD; J.ya0 = P.yr + (size_t)prev * BD; }
+            if (hasNext) { J.a1 = P.YL + (so + next) * BD * BD; J.ya1 = P.yr + (size_t)next * BD; }
+            if (J.cpl) J.a2 = P.YL + (so + prev) * BD * BD;
+            J.dbase = J.dout = B.D + (size_t)e * BD * BD;
+            J.rbase = J.rout = B.r + (size_t)e * BD;
+            J.out = P.Lbuf + (size_t)e * BD * BD;
+            J.outT = P.LbufT + (size_t)e * BD * BD;
+        } else {
+            // e + s is folded and its far side is the pinned last block: that coupling has no transposed twin in the
+            // pinned block's own row, so it is computed here (two workgroups)
+            if (!P.pin1 || (P.pin0 && e == 0) || !hasNext || next + s <= last) return;
+            J.cpl = true;
+            J.a0 = P.YL + (so + next) * BD * BD;
+            J.a2 = P.YU + (so + next) * BD * BD;
+            J.out = P.Ubuf + (size_t)e * BD * BD;
+            wg = y - 3; nwg = 2;
+        }
+    } else {
+        const BcrLevel &L = d.lev[lev];
+        const BcrLevel &N = d.lev[lev + 1];
+        const int m = bx, e = 2 * m, t = threadIdx.x;
+        if (L.pin && m == L.n / 2) {
+            // pinned end of a partitioned chain: carried over unchanged (see k_bcr_reduce)
+            if (dead) return;
+            const int src = L.n - 1;
+            if (y == 0) {
+                const double2 *s2 = reinterpret_cast<const double2 *>(L.D + (size_t)src * BD * BD);
+                double2 *d2 = reinterpret_cast<double2 *>(N.D + (size_t)m * BD * BD);
+                for (int i = t; i < BD * BD / 2; i += MF_THREADS) d2[i] = s2[i];
+                if (t < BD) N.r[(size_t)m * BD + t] = L.r[(size_t)src * BD + t];
+            } else if (y == 1) {
+                const double *sl = L.L + (size_t)src * BD * BD;
+                double *dl = N.L + (size_t)m * BD * BD;
+                const bool tr = (m & 1) == 0;
+                for (int i = t; i < BD * BD; i += MF_THREADS) {
+                    const int r = i / BD, c = i - r * BD;
+                    dl[tr ? c * BD + r : i] = sl[i];
+                }
+            }
+            return;
+        }
+        if (y >= 3) return;
+        const bool hasPrev = e - 1 >= 0, hasNext = e + 1 < L.n && !(L.pin && e + 1 == L.n - 1);
+        const int tp = (e - 2) / 2;
+        J.sym = true;
+        J.cpl = m > 0;
+        if (hasPrev) { J.a0 = L.YU + (size_t)tp * BD * BD; J.ya0 = L.r + (size_t)(e - 1) * BD; }
+        if (hasNext) { J.a1 = L.L + (size_t)(e + 1) * BD * BD; J.ya1 = L.r + (size_t)(e + 1) * BD; }
+        if (J.cpl) J.a2 = L.L + (size_t)(e - 1) * BD * BD;
+        J.dbase = L.D + (size_t)e * BD * BD;
+        J.rbase = L.r + (size_t)e * BD;
+        J.dout = N.D + (size_t)m * BD * BD;
+        J.rout = N.r + (size_t)m * BD;
+        // an even-indexed coupling block of the next level is stored transposed
+        if ((m & 1) == 0) J.outT = N.L + (size_t)m * BD * BD;
+        else J.out = N.L + (size_t)m * BD * BD;
+    }
+    reduce_job(J, lds, wg, nwg, dead, d.dbg, bx == 5);
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled) {
+    // workgroups per block: fill the chip when the level is short; blocks without couplings (the decoupled last step)
+    // have no right-hand-side tiles to share out
+    // Several workgroups per block all read D and r while the first of them writes G and yr: only where those go to
+    // buffers of their own (the steps of a parallel plan before its last one).  Plain levels and last steps work in
+    // place (G over D, yr over r) and keep one workgroup per block.
+    const bool in_place = top || which < 2;
+    const int ns = (!coupled || in_place) ? 1 : nblocks <= 85 ? 3 : nblocks <= 128 ? 2 : 1;
+    const int grid = xcd_grid(nblocks, ns);
+    if (ns == 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
+    else if (ns == 2) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
+    else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
+}
+
+// ny_legacy: 2, or 3 with the coupling to a pinned last block (the grid.y of k_bcr_reduce)
+void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy, int lev, int which) {
+    const int ny = ny_legacy == 3 ? 5 : 3;
+    LAUNCH(KC_BCR_REDUCE, k_bcr_reduce_mf, dim3(xcd_grid(nblocks, ny)), dim3(MF_THREADS), (size_t)RED_LDS_DOUBLES * sizeof(double), d, lev, which, nblocks, ny);
+}
+
+int configure_bcr_mf() {
+    if (hipFuncSetAttribute((const void *)k_bcr_reduce_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RED_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    return 0;
+}
+
+}  // namespace ssba

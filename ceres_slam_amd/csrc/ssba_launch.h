@@ -101,6 +101,10 @@ int upload_pair_table(hipStream_t s);
 int upload_bcr_tables(hipStream_t s);
 int configure_kernels();
 int configure_schur();
+// matrix-core block factor / reduce of the reduced-camera solve (ssba_bcr_mfma.hip)
+int configure_bcr_mf();
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled);
+void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 void launch_linearize(Launcher &L, const Dev &d);
 void launch_schur(Launcher &L, const Dev &d);

@@ -1,0 +1,245 @@
+// Stand-alone check + timing of the matrix-core factor / reduce kernels of the reduced-camera solve
+// (ceres_slam_amd/csrc/ssba_bcr_mfma.hip) on synthetic block-tridiagonal data: the kernels are driven through a
+// hand-filled Dev (parallel cyclic reduction plan of n blocks), their outputs are compared with a host Cholesky, and
+// launches are timed with HIP events.  Not part of the product path.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I ceres_slam_amd/csrc tools/bcr_bench.hip -o tools/bcr_bench && tools/bcr_bench [n]
+#include "../ceres_slam_amd/csrc/ssba_bcr_mfma.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+using namespace ssba;
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static void chol(const double *A, double *G) {      // lower, row-major BD x BD
+    memset(G, 0, sizeof(double) * BD * BD);
+    for (int j = 0; j < BD; ++j) {
+        double s = A[j * BD + j];
+        for (int k = 0; k < j; ++k) s -= G[j * BD + k] * G[j * BD + k];
+        const double g = sqrt(s);
+        G[j * BD + j] = g;
+        for (int i = j + 1; i < BD; ++i) {
+            double v = A[i * BD + j];
+            for (int k = 0; k < j; ++k) v -= G[i * BD + k] * G[j * BD + k];
+            G[i * BD + j] = v / g;
+        }
+    }
+}
+static void fwd(const double *G, const double *B, double *Y, int ncol) {   // Y = G^-1 B, B row-major BD x ncol
+    for (int c = 0; c < ncol; ++c)
+        for (int i = 0; i < BD; ++i) {
+            double v = B[i * ncol + c];
+            for (int k = 0; k < i; ++k) v -= G[i * BD + k] * Y[k * ncol + c];
+            Y[i * ncol + c] = v / G[i * BD + i];
+        }
+}
+static double maxrel(const double *a, const double *b, size_t n) {
+    double e = 0, m = 0;
+    for (size_t i = 0; i < n; ++i) { e = fmax(e, fabs(a[i] - b[i])); m = fmax(m, fabs(b[i])); }
+    return e / fmax(m, 1e-300);
+}
+
+template <class T> static T *dalloc(size_t n) { T *p; CHK(hipMalloc(&p, n * sizeof(T))); CHK(hipMemset(p, 0, n * sizeof(T))); return p; }
+
+int main(int argc, char **argv) {
+    const int n = argc > 1 ? atoi(argv[1]) : 84;
+    const size_t blk = (size_t)BD * BD;
+    std::mt19937_64 rng(42);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    std::vector<double> hD(n * blk), hL(n * blk), hLb(n * blk), hLbT(n * blk), hr(n * BD);
+    for (int b = 0; b < n; ++b) {
+        std::vector<double> A(BD * 2 * BD);
+        for (auto &v : A) v = nd(rng);
+        for (int i = 0; i < BD; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double s = 0;
+                for (int k = 0; k < 2 * BD; ++k) s += A[i * 2 * BD + k] * A[j * 2 * BD + k];
+                s = s / (2 * BD) + (i == j ? 1.0 : 0.0);
+                hD[b * blk + i * BD + j] = hD[b * blk + j * BD + i] = s;
+            }
+    }
+    for (auto &v : hL) v = 0.3 * nd(rng);
+    for (auto &v : hLb) v = 0.3 * nd(rng);
+    for (auto &v : hLbT) v = 0.3 * nd(rng);
+    for (auto &v : hr) v = nd(rng);
+
+    Dev d;
+    memset(&d, 0, sizeof d);
+    d.st = dalloc<State>(1);
+    d.dbg = dalloc<unsigned long long>(8192);
+    d.n_levels = 1;
+    d.lev[0].n = n;
+    d.lev[0].D = dalloc<double>(n * blk); d.lev[0].L = dalloc<double>(n * blk); d.lev[0].r = dalloc<double>(n * BD);
+    d.pcr.level = 0; d.pcr.n = n; d.pcr.steps = 0;
+    for (int s2 = 1; s2 < n; s2 <<= 1) ++d.pcr.steps;
+    d.pcr.Lbuf = dalloc<double>(n * blk); d.pcr.LbufT = dalloc<double>(n * blk);
+    d.pcr.YL = dalloc<double>(n * blk); d.pcr.YU = dalloc<double>(n * blk); d.pcr.yr = dalloc<double>(n * BD);
+    auto upload = [&] {
+        CHK(hipMemcpy(d.lev[0].D, hD.data(), n * blk * 8, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(d.lev[0].L, hL.data(), n * blk * 8, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(d.lev[0].r, hr.data(), n * BD * 8, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(d.pcr.Lbuf, hLb.data(), n * blk * 8, hipMemcpyHostToDevice));
+        CHK(hipMemcpy(d.pcr.LbufT, hLbT.data(), n * blk * 8, hipMemcpyHostToDevice));
+    };
+    upload();
+    if (configure_bcr_mf()) { printf("configure failed\n"); return 1; }
+    Launcher L;
+    CHK(hipStreamCreate(&L.stream));
+
+    std::vector<double> G(n * blk), gYL(n * blk), gYU(n * blk), gyr(n * BD), oYL(n * blk), oYU(n * blk), oyr(n * BD);
+    for (int b = 0; b < n; ++b) chol(&hD[b * blk], &G[b * blk]);
+    // ---- factor, step lev = 1 (operands Lbuf / LbufT, no transposed storage) ----
+    for (int lev : {1, 0}) {
+        const int s = 1 << lev, last = n - 1;
+        launch_bcr_factor_mf(L, d, n, lev, 0, 2, true);
+        CHK(hipStreamSynchronize(L.stream));
+        CHK(hipMemcpy(oYL.data(), d.pcr.YL, n * blk * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(oYU.data(), d.pcr.YU, n * blk * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(oyr.data(), d.pcr.yr, n * BD * 8, hipMemcpyDeviceToHost));
+        double eL = 0, eU = 0, er = 0;
+        std::vector<double> Bm(blk), Y(blk), yv(BD);
+        for (int b = 0; b < n; ++b) {
+            const bool hasL = b - s >= 0, hasU = b + s <= last;
+            if (hasL) {
+                for (int i = 0; i < BD; ++i)
+                    for (int j = 0; j < BD; ++j)
+                        Bm[i * BD + j] = lev == 0 ? ((b & 1) == 0 ? hL[b * blk + j * BD + i] : hL[b * blk + i * BD + j]) : hLb[b * blk + i * BD + j];
+                fwd(&G[b * blk], Bm.data(), Y.data(), BD);
+                eL = fmax(eL, maxrel(&oYL[b * blk], Y.data(), blk));
+                if (lev == 1) memcpy(&gYL[b * blk], Y.data(), blk * 8);
+            }
+            if (hasU) {
+                const int u = lev == 0 ? b + 1 : b + s;
+                for (int i = 0; i < BD; ++i)
+                    for (int j = 0; j < BD; ++j)
+                        Bm[i * BD + j] = lev == 0 ? ((b & 1) == 0 ? hL[u * blk + j * BD + i] : hL[u * blk + i * BD + j]) : hLbT[u * blk + i * BD + j];
+                fwd(&G[b * blk], Bm.data(), Y.data(), BD);
+                eU = fmax(eU, maxrel(&oYU[b * blk], Y.data(), blk));
+                if (lev == 1) memcpy(&gYU[b * blk], Y.data(), blk * 8);
+            }
+            fwd(&G[b * blk], &hr[b * BD], yv.data(), 1);
+            er = fmax(er, maxrel(&oyr[b * BD], yv.data(), BD));
+            if (lev == 1) memcpy(&gyr[b * BD], yv.data(), BD * 8);
+        }
+        printf("factor lev %d: max rel err YL %.2e YU %.2e yr %.2e\n", lev, eL, eU, er);
+    }
+    // ---- reduce, step lev = 1, from the factor outputs of lev 1 ----
+    {
+        const int lev = 1, s = 2, last = n - 1;
+        launch_bcr_factor_mf(L, d, n, lev, 0, 2, true);
+        launch_bcr_reduce_mf(L, d, n, 2, lev, 2);
+        CHK(hipStreamSynchronize(L.stream));
+        std::vector<double> oD(n * blk), orr(n * BD), oLb(n * blk), oLbT(n * blk);
+        CHK(hipMemcpy(oD.data(), d.lev[0].D, n * blk * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(orr.data(), d.lev[0].r, n * BD * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(oLb.data(), d.pcr.Lbuf, n * blk * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(oLbT.data(), d.pcr.LbufT, n * blk * 8, hipMemcpyDeviceToHost));
+        double eD = 0, er = 0, eL = 0, eLT = 0;
+        std::vector<double> rD(blk), rr(BD), rL(blk), rLT(blk);
+        for (int e = 0; e < n; ++e) {
+            const int prev = e - s, next = e + s;
+            const bool hasPrev = prev >= 0, hasNext = next <= last;
+            memcpy(rD.data(), &hD[e * blk], blk * 8);
+            memcpy(rr.data(), &hr[e * BD], BD * 8);
+            for (int i = 0; i < BD; ++i) {
+                for (int j = 0; j < BD; ++j) {
+                    double v = 0;
+                    if (hasPrev) for (int k = 0; k < BD; ++k) v += gYU[prev * blk + k * BD + i] * gYU[prev * blk + k * BD + j];
+                    if (hasNext) for (int k = 0; k < BD; ++k) v += gYL[next * blk + k * BD + i] * gYL[next * blk + k * BD + j];
+                    rD[i * BD + j] -= v;
+                }
+                double v = 0;
+                if (hasPrev) for (int k = 0; k < BD; ++k) v += gYU[prev * blk + k * BD + i] * gyr[prev * BD + k];
+                if (hasNext) for (int k = 0; k < BD; ++k) v += gYL[next * blk + k * BD + i] * gyr[next * BD + k];
+                rr[i] -= v;
+            }
+            eD = fmax(eD, maxrel(&oD[e * blk], rD.data(), blk));
+            er = fmax(er, maxrel(&orr[e * BD], rr.data(), BD));
+            if (hasPrev && prev - s >= 0) {
+                for (int i = 0; i < BD; ++i)
+                    for (int j = 0; j < BD; ++j) {
+                        double v = 0;
+                        for (int k = 0; k < BD; ++k) v += gYU[prev * blk + k * BD + i] * gYL[prev * blk + k * BD + j];
+                        rL[i * BD + j] = -v;
+                        rLT[j * BD + i] = -v;
+                    }
+                eL = fmax(eL, maxrel(&oLb[e * blk], rL.data(), blk));
+                eLT = fmax(eLT, maxrel(&oLbT[e * blk], rLT.data(), blk));
+            }
+        }
+        printf("reduce lev 1: max rel err D %.2e r %.2e Lbuf %.2e LbufT %.2e\n", eD, er, eL, eLT);
+        upload();
+    }
+    // ---- top step: G in place ----
+    {
+        launch_bcr_factor_mf(L, d, n, d.pcr.steps, 1, 2, false);
+        CHK(hipStreamSynchronize(L.stream));
+        std::vector<double> oD(n * blk), orr(n * BD);
+        CHK(hipMemcpy(oD.data(), d.lev[0].D, n * blk * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(orr.data(), d.lev[0].r, n * BD * 8, hipMemcpyDeviceToHost));
+        double eG = 0, er = 0;
+        std::vector<double> yv(BD);
+        for (int b = 0; b < n; ++b) {
+            for (int i = 0; i < BD; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    const double ref = i == j ? 1.0 / G[b * blk + i * BD + j] : G[b * blk + i * BD + j];
+                    eG = fmax(eG, fabs(oD[b * blk + i * BD + j] - ref));
+                }
+            fwd(&G[b * blk], &hr[b * BD], yv.data(), 1);
+            er = fmax(er, maxrel(&orr[b * BD], yv.data(), BD));
+        }
+        printf("factor top: max abs err G %.2e, rel err yr %.2e\n", eG, er);
+        upload();
+    }
+    // ---- timing ----
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    auto time_us = [&](auto fn, int reps) {
+        fn();
+        CHK(hipStreamSynchronize(L.stream));
+        CHK(hipEventRecord(e0, L.stream));
+        for (int i = 0; i < reps; ++i) fn();
+        CHK(hipEventRecord(e1, L.stream));
+        CHK(hipEventSynchronize(e1));
+        float ms;
+        CHK(hipEventElapsedTime(&ms, e0, e1));
+        return 1000.0 * ms / reps;
+    };
+    printf("n = %d blocks\n", n);
+    printf("factor (coupled, lev 1):   %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, 1, 0, 2, true); }, 50));
+    printf("factor (coupled, lev 0):   %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, 0, 0, 2, true); }, 50));
+    printf("factor (decoupled, top=0): %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, 1, 0, 2, false); }, 50));
+    launch_bcr_factor_mf(L, d, n, 1, 0, 2, true);
+    printf("reduce (lev 1):            %.2f us / launch\n", time_us([&] { launch_bcr_reduce_mf(L, d, n, 2, 1, 2); }, 50));
+#ifdef SSBA_STAMPS
+    {
+        upload();
+        CHK(hipMemset(d.dbg, 0, 8192 * 8));
+        launch_bcr_factor_mf(L, d, n, 1, 0, 2, true);
+        CHK(hipStreamSynchronize(L.stream));
+        std::vector<unsigned long long> st(8192);
+        CHK(hipMemcpy(st.data(), d.dbg, 8192 * 8, hipMemcpyDeviceToHost));
+        for (int w = 0; w < 4; ++w) {
+            printf("wave %d stamps (cycles since first):", w);
+            for (int i = 0; i < 40; ++i) if (st[w * 64 + i]) printf(" [%d]%lld", i, (long long)(st[w * 64 + i] - st[0]));
+            printf("\n");
+        }
+        CHK(hipMemset(d.dbg, 0, 8192 * 8));
+        launch_bcr_reduce_mf(L, d, n, 2, 1, 2);
+        CHK(hipStreamSynchronize(L.stream));
+        CHK(hipMemcpy(st.data(), d.dbg, 8192 * 8, hipMemcpyDeviceToHost));
+        for (int y = 0; y < 3; ++y)
+            for (int w = 0; w < 4; ++w) {
+                const unsigned long long *q = &st[2048 + w * 64 + 16 * y];
+                printf("reduce y %d wave %d:", y, w);
+                for (int i = 1; i < 13; ++i) if (q[i]) printf(" [%d]%lld", i, (long long)(q[i] - q[0]));
+                printf("\n");
+            }
+    }
+#endif
+    return 0;
+}
