@@ -1401,6 +1401,9 @@ static int ensure_log(ssba_problem *p, int capacity) {
     if (capacity <= p->log_capacity) return SSBA_OK;
     Dev &d = p->d;
     int rc;
+    // kernels take Dev by value: a captured graph has the old log pointers and capacity baked in and would keep
+    // writing there while ssba_solve_end reads the new (zero-filled) buffers
+    drop_graph(p);
     if ((rc = dzero(p, &d.log.cost, (size_t)capacity))) return rc;
     if ((rc = dzero(p, &d.log.cost_change, (size_t)capacity))) return rc;
     if ((rc = dzero(p, &d.log.gmax, (size_t)capacity))) return rc;
@@ -1787,6 +1790,8 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
         set_error("lighting terms: landmark sharding is not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
+    if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != opt.trust_region_strategy_type)
+        drop_graph(p);   // other kernel sequence (as in ssba_solve_begin)
     p->opt = opt;
     p->ignore_convergence = 1;
     p->d.huber_a = p->huber_a;

@@ -495,7 +495,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
 
 // ---- reduce ---------------------------------------------------------------------------------------------------
 constexpr int RS = 80;                      // LDS row stride of a staged operand (columns 72..79: yr | zeros)
-constexpr int RED_LDS_DOUBLES = 3 * BD * RS;
+constexpr int RED_OPERAND_DOUBLES = 3 * BD * RS;
+constexpr int RED_LDS_DOUBLES = RED_OPERAND_DOUBLES + 4 * 16 * 17;
 constexpr int STAGE_NLD = (BD * BD / 2 + MF_THREADS - 1) / MF_THREADS;     // 11 double2 per lane and operand
 
 struct StageRegs { double2 v[STAGE_NLD]; double y; };
@@ -612,14 +613,11 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
             ctj[sl] = c - 5 * cti[sl];
         }
     }
-    stage_write(sA0, R0);
-    stage_write(sA1, R1);
-    stage_write(sA2, R2);
-    RJ_STAMP(1);
-    __syncthreads();
-    RJ_STAMP(2);
     const bool p0 = J.a0 != nullptr, p1 = J.a1 != nullptr;
-    // products in order, operand reads one product ahead of the instructions (two register sets, alternating)
+    // products in order, operand reads one product ahead of the instructions (two register sets, alternating).
+    // (Tried: grouping the products by operand and writing A1 / A2 to LDS between the instruction batches so that
+    // their staging hides under the A0 products -- the two extra barriers cost more than the overlap gains, because
+    // the waves with two symmetric tiles make every phase wait: 12.8 -> 14.1 us per launch.)
     TnOps O0, O1;
     mf_d4 sacc[NSYM], cacc[NCPL];
 #pragma unroll
@@ -627,6 +625,12 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
 #pragma unroll
     for (int sl = 0; sl < NCPL; ++sl) cacc[sl] = mf_d4{0.0, 0.0, 0.0, 0.0};
     const bool u0 = shave[0] && p0, u1 = shave[0] && p1, u2 = shave[1] && p0, u3 = shave[1] && p1;
+    stage_write(sA0, R0);
+    stage_write(sA1, R1);
+    stage_write(sA2, R2);
+    RJ_STAMP(1);
+    __syncthreads();
+    RJ_STAMP(2);
     if (u0) tn_load(O0, sA0, sA0, sti[0], stj[0], g, j);
     MF_FENCE();
     if (u1) tn_load(O1, sA1, sA1, sti[0], stj[0], g, j);
@@ -666,31 +670,63 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
     MF_FENCE();
     if (chave[3]) cacc[3] = tn_mma(O1, cacc[3]);
     RJ_STAMP(11);
+    // ---- stores.  The mirror images (lower triangle of D', transposed coupling) go through a per-wave LDS tile so
+    //      that they leave as 128-byte row segments too instead of 64 scattered doubles per instruction ----------
+    double *scr = lds + RED_OPERAND_DOUBLES + w * (16 * 17);      // a private tile per wave, behind the staged operands
+    auto transposed = [&](const mf_d4 &v) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scr[j * 17 + 4 * q + g] = v[q];
+        MF_FENCE();
+        mf_d4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = scr[(4 * q + g) * 17 + j];
+        MF_FENCE();
+        return r;
+    };
 #pragma unroll
     for (int sl = 0; sl < NSYM; ++sl) {
         if (!shave[sl]) continue;
+        mf_d4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = 16 * sti[sl] + 4 * q + g, col = 16 * stj[sl] + j;
-            if (row >= BD) continue;
-            if (col < BD) {
-                const double v = base[sl][q] - sacc[sl][q];
-                if (sti[sl] != stj[sl] || col >= row) {
-                    J.dout[row * BD + col] = v;
-                    if (col != row) J.dout[col * BD + row] = v;
-                }
-            } else if (col == BD) J.rout[row] = rb[sl][q] - sacc[sl][q];
+        for (int q = 0; q < 4; ++q) v[q] = base[sl][q] - sacc[sl][q];
+        const int r0 = 16 * sti[sl] + g, c0 = 16 * stj[sl] + j;
+        if (c0 < BD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + 4 * q < BD) J.dout[(r0 + 4 * q) * BD + c0] = v[q];
+        } else if (c0 == BD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + 4 * q < BD) J.rout[r0 + 4 * q] = rb[sl][q] - sacc[sl][q];
+        }
+        if (sti[sl] != stj[sl]) {       // the tile below the diagonal: rows of tile column tj, columns of tile row ti
+            const mf_d4 vt = transposed(v);
+            const int r1 = 16 * stj[sl] + g, c1 = 16 * sti[sl] + j;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r1 + 4 * q < BD) J.dout[(r1 + 4 * q) * BD + c1] = vt[q];
         }
     }
 #pragma unroll
     for (int sl = 0; sl < NCPL; ++sl) {
         if (!chave[sl]) continue;
+        mf_d4 v;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = 16 * cti[sl] + 4 * q + g, col = 16 * ctj[sl] + j;
-            if (row >= BD || col >= BD) continue;
-            if (J.out) J.out[row * BD + col] = -cacc[sl][q];
-            if (J.outT) J.outT[col * BD + row] = -cacc[sl][q];
+        for (int q = 0; q < 4; ++q) v[q] = -cacc[sl][q];
+        const int r0 = 16 * cti[sl] + g, c0 = 16 * ctj[sl] + j;
+        if (J.out && c0 < BD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + 4 * q < BD) J.out[(r0 + 4 * q) * BD + c0] = v[q];
+        }
+        if (J.outT) {
+            const mf_d4 vt = transposed(v);
+            const int r1 = 16 * ctj[sl] + g, c1 = 16 * cti[sl] + j;
+            if (c1 < BD) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r1 + 4 * q < BD) J.outT[(r1 + 4 * q) * BD + c1] = vt[q];
+            }
         }
     }
     RJ_STAMP(12);

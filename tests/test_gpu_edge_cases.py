@@ -144,6 +144,41 @@ def test_handle_reuse_solve_twice_and_set_huber_after_finalize():
     assert s3.final_cost == pytest.approx(s4.final_cost, rel=1e-6)
 
 
+def test_handle_reuse_with_other_options_recaptures_the_graph():
+    """A second ssba_solve on the same handle with a larger iteration cap reallocates the iteration log; the captured
+    hipGraph has the old log pointers baked in and must be dropped (it used to report final_cost = 0 and an all-zero
+    log).  Same for solve -> evaluate -> solve with a small cap, and for LM -> dogleg on one handle."""
+    prob = synth.make_problem(14, 400, track_len=6, seed=10)
+    op = orc.OracleProblem.from_synth(prob)
+    s_ref, log_ref = op.solve(orc.driver_options(num_threads=2))
+    ba = StereoBA.from_synth(prob)
+    s1, log1 = ba.solve(capi.default_options(max_num_iterations=5, use_nonmonotonic_steps=1))
+    assert s1.num_iterations <= 6
+    np.testing.assert_allclose(log1["cost"], log_ref["cost"][:len(log1["cost"])], rtol=1e-9)
+    ba.poses[:] = prob.poses_init
+    ba.points[:] = prob.points_init
+    s2, log2 = ba.solve(capi.default_options(**DRIVER))          # cap 1000: the log is reallocated
+    assert s2.num_iterations == s_ref.num_iterations
+    np.testing.assert_allclose(log2["cost"], log_ref["cost"], rtol=1e-9)
+    assert s2.final_cost == pytest.approx(s_ref.final_cost, rel=1e-6) and s2.final_cost > 0
+    # solve (small cap) -> evaluate (needs 16 log entries) -> solve
+    ba2 = StereoBA.from_synth(prob)
+    ba2.solve(capi.default_options(max_num_iterations=3, use_nonmonotonic_steps=1))
+    ba2.poses[:] = prob.poses_init
+    ba2.points[:] = prob.points_init
+    cost0 = ba2.evaluate()[0]
+    assert cost0 == pytest.approx(s_ref.initial_cost, rel=1e-12)
+    s3, log3 = ba2.solve(capi.default_options(max_num_iterations=4, use_nonmonotonic_steps=1))
+    np.testing.assert_allclose(log3["cost"], log_ref["cost"][:len(log3["cost"])], rtol=1e-9)
+    # LM graph, then a dogleg solve on the same handle
+    ba2.poses[:] = prob.poses_init
+    ba2.points[:] = prob.points_init
+    s4, _ = ba2.solve(capi.default_options(trust_region_strategy_type=1, **DRIVER))
+    s5, _ = op.__class__.from_synth(prob).solve(orc.driver_options(trust_region_strategy_type=1, num_threads=2))
+    assert s4.num_iterations == s5.num_iterations
+    assert s4.final_cost == pytest.approx(s5.final_cost, rel=1e-6)
+
+
 @pytest.mark.parametrize("dogleg_type", [0, 1])
 @pytest.mark.parametrize("huber_a", [0.0, 1.345])
 @pytest.mark.parametrize("size", [(16, 500, 8), (50, 2000, 12)])
