@@ -22,14 +22,19 @@ def main():
     import torch.distributed as dist
     from ceres_slam_amd import sharding, synth
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     P, Lm, T = [int(v) for v in os.environ.get("SSBA_TEST_SIZE", "16,400,6").split(",")]
     huber_a = float(os.environ.get("SSBA_TEST_HUBER", "0"))      # with it: 30 % outlier observations (BASELINE.json configs[4])
     prob = synth.make_problem(P, Lm, track_len=T, seed=21, outlier_fraction=0.3 if huber_a > 0 else 0.0)
     partition = None
     if mode == "gpu_part":      # super-block-aligned landmark ranges + partitioned reduced solve
-        ranges, partition = sharding.aligned_partition(prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
-        shard = sharding.shard_by_landmarks(prob, world, rank, ranges=ranges)
+        cut = sharding.aligned_partition(prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
+        if cut is None:         # no super-block-aligned cut exists: plain landmark sharding, whole reduced system summed (as bench.py does)
+            shard = sharding.shard_by_landmarks(prob, world, rank)
+        else:
+            ranges, partition = cut
+            shard = sharding.shard_by_landmarks(prob, world, rank, ranges=ranges)
     else:
         shard = sharding.shard_by_landmarks(prob, world, rank)
     res = {"rank": rank, "num_local_obs": int(shard.obs_pose.shape[0]), "num_local_points": int(shard.points.shape[0])}

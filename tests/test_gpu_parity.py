@@ -96,14 +96,30 @@ def test_c1_solve_matches_golden(c1_problem):
 
 
 def test_huber_outlier_solve_matches_oracle():
-    prob = synth.make_config("C1", outlier_fraction=0.3)       # BASELINE.json config 5 shape
+    """BASELINE.json config 5 shape at C1 size.  The converged runs end in a long flat tail where the stop iteration is
+    rounding-sensitive, so the end points are compared at a FIXED iteration count (both runs cut at the same cap,
+    well before the tail) at the 1e-6 bar; the converged runs are compared over their common prefix."""
+    prob = synth.make_config("C1", outlier_fraction=0.3)
+    K = 20
+    ba = StereoBA.from_synth(prob, huber_a=1.345)
+    s, log = ba.solve(capi.default_options(max_num_iterations=K, use_nonmonotonic_steps=1))
+    op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, max_num_iterations=K))
+    assert s.num_iterations == s2.num_iterations
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-8)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)       # north-star bar
+    assert np.abs(ba.poses - op.poses).max() < 1e-6
+    # run to convergence: same path for as long as both run, same best cost over that prefix
     ba = StereoBA.from_synth(prob, huber_a=1.345)
     s, log = ba.solve(capi.default_options(**DRIVER))
     op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
     s2, log2 = op.solve(orc.driver_options(num_threads=4))
-    n = min(len(log["cost"]), len(log2["cost"]), 15)
-    np.testing.assert_allclose(log["cost"][:n], log2["cost"][:n], rtol=1e-8)
-    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)   # long flat tail: stop point is rounding-sensitive
+    n = min(len(log["cost"]), len(log2["cost"]))
+    assert log["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    np.testing.assert_allclose(log["cost"][:n], log2["cost"][:n], rtol=1e-7)
+    assert log["cost"][:n].min() == pytest.approx(log2["cost"][:n].min(), rel=1e-6)
+    assert abs(int(s.num_iterations) - int(s2.num_iterations)) <= 3
 
 
 def test_reference_style_driver_through_the_api_mirror(tiny_problem):

@@ -103,31 +103,42 @@ def test_aligned_partition_cuts_at_superblock_boundaries():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size,pcr_max", [(2, (40, 1600, 12), None), (3, (100, 4000, 12), None), (2, (300, 9000, 12), None),
-                                                (4, (300, 9000, 12), None), (2, (300, 9000, 12), 4), (4, (300, 9000, 12), 3),
-                                                (3, (420, 12000, 12), 5)])
-def test_partitioned_gpu_solve_matches_unsharded_oracle(tmp_path, world, size, pcr_max):
+@pytest.mark.parametrize("world,size,pcr_max,maxit", [(2, (40, 1600, 12), None, 0), (3, (100, 4000, 12), None, 30), (2, (300, 9000, 12), None, 30),
+                                                      (4, (300, 9000, 12), None, 0), (2, (300, 9000, 12), 4, 30), (4, (300, 9000, 12), 3, 30),
+                                                      (3, (420, 12000, 12), 5, 30)])
+def test_partitioned_gpu_solve_matches_unsharded_oracle(tmp_path, world, size, pcr_max, maxit):
     """Partitioned reduced solve (ssba_set_partition): every rank eliminates the interior of its own chain of
     super-blocks (parallel cyclic reduction with the shared ends pinned; with SSBA_PCR_MAX_BLOCKS set, plain levels
-    first), only the separator system is summed over the ranks.  Same iterates as the unsharded solve."""
-    res = _run_ranks("gpu_part", str(tmp_path / "part"), world, size=size,
-                     extra_env={"SSBA_PCR_MAX_BLOCKS": str(pcr_max)} if pcr_max else None)
+    first), only the separator system is summed over the ranks.  Same iterates as the unsharded solve.
+    maxit > 0: both runs are cut at that iteration count, before the flat tail of the convergence, and EVERYTHING is
+    compared at the 1e-6 bar (landmarks, gradient norms, step norms included); maxit = 0: run to convergence."""
+    env = {}
+    if pcr_max:
+        env["SSBA_PCR_MAX_BLOCKS"] = str(pcr_max)
+    if maxit:
+        env["SSBA_TEST_MAXIT"] = str(maxit)
+    res = _run_ranks("gpu_part", str(tmp_path / "part"), world, size=size, extra_env=env or None)
     prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21)
     op = orc.OracleProblem.from_synth(prob)
-    s2, log2 = op.solve(orc.driver_options(num_threads=2))
+    s2, log2 = op.solve(orc.driver_options(num_threads=2, **({"max_num_iterations": maxit} if maxit else {})))
     for r in res:
-        assert r["termination"] == s2.termination_type == 0
+        assert r["termination"] == s2.termination_type
+        assert r["num_iterations"] == s2.num_iterations
         assert r["accept"] == log2["step_is_successful"].tolist()
         ok = np.asarray(log2["step_is_successful"], dtype=bool)
         ok[0] = True
         np.testing.assert_allclose(np.asarray(r["cost"])[ok], log2["cost"][ok], rtol=1e-8)
-        np.testing.assert_allclose(r["gmax"], log2["gradient_max_norm"], rtol=1e-3)      # late gradients: cancellation
-        np.testing.assert_allclose(r["step_norm"], log2["step_norm"], rtol=1e-5, atol=1e-12)
         assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
         assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6              # every rank has the whole trajectory
-        # far landmarks are weakly constrained in depth: 1e-4 relative after ~70 iterations of a flat tail
         ref = op.points[r["point_ids"]]
-        assert (np.abs(np.asarray(r["points"]) - ref) / (1 + np.abs(ref))).max() < 1e-4
+        if maxit:
+            np.testing.assert_allclose(r["gmax"], log2["gradient_max_norm"], rtol=1e-6)
+            np.testing.assert_allclose(r["step_norm"], log2["step_norm"], rtol=1e-6, atol=1e-12)
+            assert (np.abs(np.asarray(r["points"]) - ref) / (1 + np.abs(ref))).max() < 1e-6
+        else:
+            # converged runs: far landmarks are weakly constrained in depth and drift along the flat tail (~70
+            # iterations); their 1e-6 comparison is the job of the fixed-iteration cases above
+            assert (np.abs(np.asarray(r["points"]) - ref) / (1 + np.abs(ref))).max() < 1e-4
     assert res[0]["poses"] == res[1]["poses"]                                      # bit-identical across ranks
 
 
@@ -135,17 +146,20 @@ def test_partitioned_gpu_solve_matches_unsharded_oracle(tmp_path, world, size, p
 @pytest.mark.parametrize("world", [2, 3])
 def test_partitioned_huber_solve_with_outliers_matches_unsharded_oracle(tmp_path, world):
     """BASELINE.json configs[4] in small: HuberLoss on every block, 30 % outlier observations, landmarks sharded over
-    the ranks with the partitioned reduced solve.  Same accept / reject sequence and costs as the unsharded oracle."""
+    the ranks with the partitioned reduced solve.  Both runs are cut at the same iteration count (before the flat tail
+    whose stop point is rounding-sensitive): same accept / reject sequence, costs and end point at the 1e-6 bar."""
     size = (100, 4000, 12)
-    res = _run_ranks("gpu_part", str(tmp_path / "hub"), world, size=size, extra_env={"SSBA_TEST_HUBER": "1.345"})
+    K = 25
+    res = _run_ranks("gpu_part", str(tmp_path / "hub"), world, size=size, extra_env={"SSBA_TEST_HUBER": "1.345", "SSBA_TEST_MAXIT": str(K)})
     prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21, outlier_fraction=0.3)
     op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
-    s2, log2 = op.solve(orc.driver_options(num_threads=2))
-    n = min(len(log2["cost"]), 15)
+    s2, log2 = op.solve(orc.driver_options(num_threads=2, max_num_iterations=K))
     for r in res:
-        assert r["accept"][:n] == log2["step_is_successful"][:n].tolist()
-        ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
+        assert r["num_iterations"] == s2.num_iterations
+        assert r["accept"] == log2["step_is_successful"].tolist()
+        ok = np.asarray(log2["step_is_successful"], dtype=bool)
         ok[0] = True
-        np.testing.assert_allclose(np.asarray(r["cost"])[:n][ok], log2["cost"][:n][ok], rtol=1e-8)
-        assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-4)       # long flat tail: the stop point is rounding-sensitive
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log2["cost"][ok], rtol=1e-8)
+        assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
+        assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6
     assert res[0]["poses"] == res[1]["poses"]

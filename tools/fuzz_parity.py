@@ -37,7 +37,8 @@ def lighting_case(rng, c, P, L, T, seed):
     okm = np.asarray(log2["step_is_successful"][:n], dtype=bool)
     okm[0] = True
     trace = float(np.max(np.abs(log["cost"][:n][okm] - log2["cost"][:n][okm]) / np.abs(log2["cost"][:n][okm])))
-    fin = abs(s.final_cost - s2.final_cost) / abs(s2.final_cost)
+    nall = min(len(log["cost"]), len(log2["cost"]))      # end points compared where both runs exist: best cost of the common prefix
+    fin = abs(log["cost"][:nall].min() - log2["cost"][:nall].min()) / abs(log2["cost"][:nall].min())
     # the lighting model clamps the colour to [0, 1] (phong.hpp:33, utils.hpp:16-25): a far-off trial step can sit on a
     # clamp, where the last bits decide a finite jump of the cost -- the traces may part by ~1e-5 there and meet again
     ok = acc_ok and trace < 1e-4 and fin < 1e-6
@@ -82,9 +83,11 @@ def main():
         okm = np.asarray(log2["step_is_successful"][:n], dtype=bool)
         okm[0] = True
         trace = float(np.max(np.abs(log["cost"][:n][okm] - log2["cost"][:n][okm]) / np.abs(log2["cost"][:n][okm])))
-        fin = abs(s.final_cost - s2.final_cost) / abs(s2.final_cost)
-        capped = int(s.num_iterations) >= kw["max_num_iterations"] or int(s2.num_iterations) >= kw["max_num_iterations"]
-        ok = acc_ok and trace < 1e-6 and (fin < 1e-5 or capped)      # a run cut off at the iteration cap has no meaningful end point
+        # end points at a fixed iteration count: the best cost over the iterations both runs have (a converged run's stop
+        # iteration is rounding-sensitive in a flat tail; its path is not)
+        nall = min(len(log["cost"]), len(log2["cost"]))
+        fin = abs(log["cost"][:nall].min() - log2["cost"][:nall].min()) / abs(log2["cost"][:nall].min())
+        ok = acc_ok and trace < 1e-6 and fin < 1e-6
         bad += not ok
         print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} dogleg={dog:2d} const={int(pose_const.sum()):2d} "
               f"general={int(ba.stats().general_structure)} iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} trace={trace:.1e} final={fin:.1e} "
