@@ -197,8 +197,28 @@ def main():
                   prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting,
                   shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds), partition=partition,
                   huber_a=huber_a)
+    exchange = "none"
     if world > 1:
-        sharding.attach_torch_exchange(ba, dist)      # library kernels + collectives on one dedicated torch stream
+        # native exchange: libssba.so enqueues ncclAllReduce (RCCL over xGMI) itself on its stream; torch.distributed only
+        # carries the 128-byte unique id.  SSBA_BENCH_EXCHANGE=torch (or a gloo rehearsal) routes the collectives through
+        # torch.distributed instead; so does a failed RCCL set-up on any rank.
+        want_native = backend == "nccl" and os.environ.get("SSBA_BENCH_EXCHANGE", "rccl") != "torch"
+        ok = 0
+        if want_native:
+            try:
+                sharding.attach_rccl_exchange(ba, dist)
+                ok = 1
+            except Exception as e:      # noqa: BLE001 -- any failure falls back, on every rank
+                print(f"[bench] rank {rank}: native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            exchange = "rccl (native, in libssba.so)"
+        else:
+            ba.set_exchange(None)
+            sharding.attach_torch_exchange(ba, dist)      # library kernels + collectives on one dedicated torch stream
+            exchange = f"torch.distributed ({backend})"
     st = ba.stats()
     stats = {k: int(getattr(st, k)) for k, _ in capi.Stats._fields_}
 
@@ -302,6 +322,7 @@ def main():
                                                      + (", HuberLoss(1.345) on every block, 30 % outlier observations" if robust else "")))
                                    + f", {world} shard(s)",
                        "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
+                       "exchange": exchange,
                        "reduced_solve": ("partitioned: chain elimination per rank + separator exchange" if partition is not None
                                          else ("replicated after an all-reduce of the reduced system" if world > 1 else "single GPU")),
                        "exchange_doubles_per_iteration": int(ba.exchange_size()) if world > 1 else 0,

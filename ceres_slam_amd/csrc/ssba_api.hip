@@ -16,6 +16,9 @@
 
 #include "../../include/ssba.h"
 #include "ssba_pool.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "ssba_launch.h"
 #include "ssba_linesearch.h"
 #include "ssba_types.h"
@@ -95,6 +98,7 @@ struct ssba_problem {
     ssba_exchange_fn xfn = nullptr;
     void *xctx = nullptr;
     int world_size = 1, rank = 0;
+    ncclComm_t rccl_comm = nullptr;        // native exchange (ssba_set_rccl): all-reduces enqueued on the solver's stream
     std::vector<uint32_t> sep_sb;          // partitioned solve: separator super-blocks (world_size + 1 entries)
     // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
     hipGraph_t graph = nullptr;
@@ -315,6 +319,8 @@ int ssba_create(const ssba_camera *camera, int device, ssba_problem **out) {
     return SSBA_OK;
 }
 
+static void rccl_release(ssba_problem *p);
+
 int ssba_destroy(ssba_problem *p) {
     ApiTimer api_timer("ssba_destroy");
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
@@ -322,6 +328,7 @@ int ssba_destroy(ssba_problem *p) {
     hipStreamSynchronize(p->launcher.stream);
     p->launcher.destroy();
     free_device(p);
+    rccl_release(p);
     if (p->ev_begin) hipEventDestroy(p->ev_begin);
     if (p->ev_end) hipEventDestroy(p->ev_end);
     if (p->own_stream) { hipStreamSynchronize(p->own_stream); pool_stream_release(p->own_stream); }
@@ -517,6 +524,83 @@ int ssba_set_stream(ssba_problem *p, void *hip_stream) {
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->began) return SSBA_ERR_STATE;
     p->launcher.stream = hip_stream ? (hipStream_t)hip_stream : p->own_stream;
+    return SSBA_OK;
+}
+
+// ---- native RCCL exchange ----------------------------------------------------------------------------------------
+// The collectives of a sharded solve (the reduced pose system or, partitioned, the separator system,
+// plus 16 scalars) are ncclAllReduce calls enqueued by the library itself on the solver's stream, between the captured
+// kernel segments of an iteration -- no host language in the loop, so the C++ shim and the example drivers can shard
+// too.  librccl.so is loaded on first use (dlopen): a single-GPU process never maps it.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi *rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) return a;
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.lib, "ncclCommInitRank");
+        a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
+        return a;
+    }();
+    return &api;
+}
+int rccl_exchange(void *ctx, void *buf, uint64_t count, int op) {
+    ssba_problem *p = (ssba_problem *)ctx;
+    RcclApi *a = rccl_api();
+    const ncclResult_t r = a->AllReduce(buf, buf, (size_t)count, ncclDouble, op == 1 ? ncclMax : ncclSum, p->rccl_comm, p->launcher.stream);
+    if (r != ncclSuccess) { set_error(std::string("ncclAllReduce: ") + a->GetErrorString(r)); return 1; }
+    return 0;
+}
+}  // namespace
+
+static void rccl_release(ssba_problem *p) {
+    if (!p->rccl_comm) return;
+    hipStreamSynchronize(p->launcher.stream);
+    rccl_api()->CommDestroy(p->rccl_comm);
+    p->rccl_comm = nullptr;
+    if (p->xfn == rccl_exchange) { p->xfn = nullptr; p->xctx = nullptr; }
+}
+
+int ssba_rccl_unique_id(void *out, uint64_t size) {
+    if (!out || size < sizeof(ncclUniqueId)) return SSBA_ERR_INVALID_ARGUMENT;
+    RcclApi *a = rccl_api();
+    if (!a->ok) { set_error("librccl.so could not be loaded"); return SSBA_ERR_UNSUPPORTED; }
+    ncclUniqueId id;
+    const ncclResult_t r = a->GetUniqueId(&id);
+    if (r != ncclSuccess) { set_error(std::string("ncclGetUniqueId: ") + a->GetErrorString(r)); return SSBA_ERR_HIP; }
+    memcpy(out, &id, sizeof id);
+    return SSBA_OK;
+}
+
+int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size) {
+    if (!p || !unique_id || size < sizeof(ncclUniqueId)) return SSBA_ERR_INVALID_ARGUMENT;
+    if (p->began) return SSBA_ERR_STATE;
+    RcclApi *a = rccl_api();
+    if (!a->ok) { set_error("librccl.so could not be loaded"); return SSBA_ERR_UNSUPPORTED; }
+    HIPCHECK(hipSetDevice(p->device));
+    rccl_release(p);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    const ncclResult_t r = a->CommInitRank(&p->rccl_comm, p->world_size, id, p->rank);
+    if (r != ncclSuccess) { p->rccl_comm = nullptr; set_error(std::string("ncclCommInitRank: ") + a->GetErrorString(r)); return SSBA_ERR_HIP; }
+    p->xfn = rccl_exchange;
+    p->xctx = p;
     return SSBA_OK;
 }
 

@@ -131,3 +131,15 @@ def attach_torch_exchange(ba, dist, group=None):
     ba.set_exchange(exchange)
     ba._exchange_stream = stream
     return stream
+
+
+def attach_rccl_exchange(ba, dist=None, group=None):
+    """Native exchange (ssba_set_rccl): the library calls ncclAllReduce itself on its own stream -- no Python between
+    the kernel segments of an iteration.  Only the 128-byte RCCL unique id travels through `dist` (any
+    torch.distributed backend; None for a single rank), once."""
+    world = 1 if dist is None else dist.get_world_size(group)
+    rank = 0 if dist is None else dist.get_rank(group)
+    ids = [ba.rccl_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ids, src=0, group=group)
+    ba.set_rccl(ids[0])

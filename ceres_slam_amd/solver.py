@@ -199,6 +199,19 @@ class StereoBA:
         self._xcb = capi.EXCHANGE_FN(tramp)
         capi.check(self.lib.ssba_set_exchange(self.h, self._xcb, None), "ssba_set_exchange")
 
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        """128 bytes from ncclGetUniqueId (rank 0 calls this and hands them to the other ranks)."""
+        buf = C.create_string_buffer(128)
+        capi.check(capi.load().ssba_rccl_unique_id(buf, 128), "ssba_rccl_unique_id")
+        return buf.raw
+
+    def set_rccl(self, unique_id: bytes):
+        """Native exchange: the library enqueues ncclAllReduce itself on its stream (collective call, every rank)."""
+        self._xcb = None
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        capi.check(self.lib.ssba_set_rccl(self.h, buf, 128), "ssba_set_rccl")
+
     def exchange_size(self) -> int:
         n = C.c_uint64()
         capi.check(self.lib.ssba_exchange_size(self.h, C.byref(n)), "ssba_exchange_size")

@@ -188,6 +188,15 @@ int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
  * rank returns the complete trajectory.  Without this call the ranks sum the whole reduced system and
  * each solves all of it (works for any sharding).  num = 0 clears the partition. */
 int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, uint32_t num);
+/* Native exchange: the library itself enqueues ncclAllReduce (RCCL over xGMI) on the solver's stream at the exchange
+ * points -- one process per GPU, no host language in the loop (this is what a sharded
+ * tests/dataset_vo.cpp:22-85 links against).  Rank 0 calls ssba_rccl_unique_id (128 bytes) and hands the bytes to the
+ * other ranks by whatever the application has (MPI, a file, torch.distributed); every rank then calls ssba_set_rccl
+ * AFTER ssba_set_distributed(world_size, rank) -- a collective call: it returns once all ranks have joined.  It
+ * replaces any callback set with ssba_set_exchange.  librccl.so is loaded on first use. */
+#define SSBA_RCCL_UNIQUE_ID_BYTES 128
+int ssba_rccl_unique_id(void *out, uint64_t size);
+int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size);
 /* number of doubles in the per-iteration reduced-system exchange */
 int ssba_exchange_size(ssba_problem *p, uint64_t *count);
 

@@ -163,3 +163,27 @@ def test_partitioned_huber_solve_with_outliers_matches_unsharded_oracle(tmp_path
         assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
         assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6
     assert res[0]["poses"] == res[1]["poses"]
+
+
+@pytest.mark.gpu
+def test_native_rccl_exchange_world_of_one():
+    """ssba_set_rccl: the library's own ncclAllReduce calls at the exchange points (a communicator of one rank here -- the
+    test box has one GPU; more ranks use the same code with a shared unique id).  The sharded code path (all poses kept,
+    kernel segments around the exchange points) must reproduce the plain single-GPU solve."""
+    from ceres_slam_amd import capi
+    from ceres_slam_amd.solver import StereoBA
+    prob = synth.make_config("C1")
+    opts = dict(max_num_iterations=1000, use_nonmonotonic_steps=1)
+    ref = StereoBA.from_synth(prob)
+    s0, log0 = ref.solve(capi.default_options(**opts))
+    ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                  prob.stiffness(), world_size=1, rank=0)
+    sharding.attach_rccl_exchange(ba, None)
+    s, log = ba.solve(capi.default_options(**opts))
+    assert s.num_iterations == s0.num_iterations
+    assert log["step_is_successful"].tolist() == log0["step_is_successful"].tolist()
+    np.testing.assert_allclose(log["cost"], log0["cost"], rtol=1e-10)
+    assert np.abs(ba.poses - ref.poses).max() < 1e-9
+    op = orc.OracleProblem.from_synth(prob)
+    s2, _ = op.solve(orc.driver_options(num_threads=4))
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
