@@ -65,7 +65,8 @@ def build_examples(name: str = "dataset_vo_gpu") -> str:
     src = os.path.join(root, "examples", name + ".cpp")
     out = os.path.join(root, "examples", name)
     build_library()
-    deps = [src, os.path.join(root, "include", "ssba.h"), os.path.join(root, "include", "ceres_slam_amd", "ceres_shim.hpp"), LIB]
+    inc = os.path.join(root, "include", "ceres_slam_amd")
+    deps = [src, os.path.join(root, "include", "ssba.h"), LIB] + [os.path.join(inc, h) for h in sorted(os.listdir(inc)) if h.endswith(".hpp")]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-I" + os.path.join(root, "include"), src, "-o", out,

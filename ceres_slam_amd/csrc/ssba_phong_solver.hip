@@ -664,6 +664,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_landmarks(
 // one lane per landmark, every iteration (after k_ph_invert): the landmark's contribution to
 // S_bb, g_b^, diag(H_bb) and g_b, summed per material over the block of 256 landmarks (fixed order).
 constexpr int BSP = 17;   // components per LDS pass (3 passes cover NBV = 49)
+constexpr int SSBA_MAX_MATERIALS_DEV = 15;   // = SSBA_MAX_MATERIALS (ssba.h): BSP x M lanes of a 256-lane block sum the per-material partials
 __global__ __launch_bounds__(256) void k_ph_border_schur(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(64) void k_ph_border_colsum(Dev d) {
 __global__ __launch_bounds__(256) void k_ph_border_reduce(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
-    __shared__ double tot[8 * NBV];
+    __shared__ double tot[SSBA_MAX_MATERIALS_DEV * NBV];
     const int t = threadIdx.x;
     for (int idx = t; idx < d.M * NBV; idx += 256) tot[idx] = d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx];
     for (int i = t; i < BS_S; i += 256) d.bsys[i] = 0.0;     // Sbb | rhsb | gb | hb

@@ -370,3 +370,21 @@ def test_c1_phong_driver_configuration_matches_golden():
     np.testing.assert_allclose(log["cost"][:n][ok], np.asarray(gold["cost"])[:n][ok], rtol=1e-6)
     assert s.final_cost == pytest.approx(gold["final_cost"], rel=1e-4)
     np.testing.assert_allclose(ba.poses[[1, 25, 49]], gold["poses_1_25_49"], atol=1e-4)
+
+
+def test_twelve_materials_with_free_light_and_textures():
+    """The reference sizes materials / textures from the dataset file (dataset_problem_phong.cpp:266-278); more than the
+    first build's seven: 12 materials, light and texture blocks free (a border of 3 + 12 columns), Phong parameters
+    constant, against the oracle."""
+    prob, ph = synth.make_phong_problem(30, 1500, num_materials=12, seed=5)
+    shared_free = 0b101
+    ba, op = _pair(prob, ph, shared_free=shared_free)
+    s, log = ba.solve(capi.default_options(max_num_iterations=25, use_nonmonotonic_steps=1))
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, max_num_iterations=25))
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    ok = np.asarray(log2["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][ok], log2["cost"][ok], rtol=1e-7)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+    assert np.abs(ba.poses - op.poses).max() < 1e-6
+    assert np.abs(ba.texture - op.texture).max() < 1e-6 and np.abs(ba.light - op.light).max() < 1e-5
