@@ -1604,17 +1604,20 @@ static int enqueue_front(ssba_problem *p) {
         if ((rc = X(d.scal2, NSCAL, 0))) return rc;
         return SSBA_OK;
     }
-    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d); }))) return rc;
+    // single GPU: the small launches between the big kernels are folded into their neighbours (ssba_kernels.hip, k_check)
+    const bool fuse_ctrl = !p->xfn && !d.constrained && !d.nb;
+    const bool fuse_best = fuse_ctrl && p->opt.trust_region_strategy_type != 1;
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl); }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if ((rc = X(d.gmax_l, 1, 1))) return rc;
     }
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
-            launch_finish_check(L, d);
+            launch_finish_check(L, d, fuse_ctrl, fuse_best);
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d); if (d.nb) launch_border_solve(L, d); }
             if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
-            else launch_update_eval(L, d, !p->xfn && !d.constrained);
+            else launch_update_eval(L, d, !p->xfn && !d.constrained, fuse_best);
         }))) return rc;
     if (p->xfn && (rc = X(d.scal2, NSCAL, 0))) return rc;
     return SSBA_OK;

@@ -343,12 +343,20 @@ constexpr int SCHUR_RS = 80;                     // row stride of Zm: 5 tiles; 8
 constexpr int SCHUR_LDS_DOUBLES = SCHUR_KB * SCHUR_RS;     // 40 960 B
 typedef double schur_d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d) {
+// n_zero > 0: the first n_zero workgroups clear the block-tridiagonal reduced system (D and L of every super-block) that
+// k_assemble_reduced fills next -- a memset launch less per iteration, hidden beside the Schur items.
+__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n_zero) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
+    if ((int)blockIdx.x < n_zero) {
+        double2 *z = reinterpret_cast<double2 *>(d.xv + d.off_D);
+        const size_t n2 = (size_t)d.Nsb * BD * BD;               // 2 x Nsb blocks of BD x BD doubles = n2 double2
+        for (size_t i = (size_t)blockIdx.x * SCHUR_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * SCHUR_THREADS) z[i] = make_double2(0.0, 0.0);
+        return;
+    }
     extern __shared__ __align__(16) double schur_lds[];
     double *sZ = schur_lds;                              // [k][col]
-    const int item = blockIdx.x;
+    const int item = (int)blockIdx.x - n_zero;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -499,7 +507,10 @@ __device__ __forceinline__ int tri21(int r, int c) {   // packed upper index, r 
 // Gathers the slabs into the block-tridiagonal reduced system (pure stores, fixed
 // summation order): one thread per (6x6 block, element), plus one thread per rhs entry.
 // S = H_pp - sum slabs (pose damping is added after the exchange, in k_finish_reduced).
-__global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
+// fuse_finish (single GPU: nothing is exchanged between this kernel and the solve): the work of k_finish_reduced is done
+// here -- Jacobi scale of the poses at iteration 0, LM damping on the diagonal, rhs = -reduced gradient, identity rows
+// for the padding of the last super-block.
+__global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -530,7 +541,16 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
         v = -v;
         if (fa == fb) {
             const int k = d.free_pose[fa];
-            v += d.hpp[(size_t)k * 21 + tri21(min(r, c), max(r, c))];
+            const double h = d.hpp[(size_t)k * 21 + tri21(min(r, c), max(r, c))];
+            v += h;
+            if (fuse_finish && r == c) {
+                const size_t i = (size_t)fa * 6 + r;
+                double sc;
+                if (st.iteration == 0) { sc = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0; d.sp[i] = sc; }
+                else sc = d.sp[i];
+                const double s2 = sc * sc;
+                v += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
+            }
         }
         const uint32_t Ia = fa / SBP, Ib = fb / SBP;
         const int row = (int)(fa - Ia * SBP) * 6 + r, col = (int)(fb - Ib * SBP) * 6 + c;
@@ -562,9 +582,14 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v -= x[q];
         }
-        d.xv[d.off_rhs + i] = v;             // reduced gradient; negated in k_finish_reduced
+        d.xv[d.off_rhs + i] = fuse_finish ? -v : v;             // reduced gradient; negated here or in k_finish_reduced
         d.xv[d.off_gp + i] = g;
         d.xv[d.off_hdiag + i] = d.hpp[(size_t)k * 21 + tri21(c, c)];
+    } else if (fuse_finish && gid < n_el + (size_t)d.nf_pad * 6) {       // padding rows of the last super-block: identity
+        const size_t i = gid - n_el;
+        const int f = (int)(i / 6), c = (int)(i - (size_t)f * 6), I = f / SBP, row = (f - I * SBP) * 6 + c;
+        d.xv[d.off_D + (size_t)I * BD * BD + (size_t)row * BD + row] = 1.0;
+        d.xv[d.off_rhs + i] = 0.0;
     }
 }
 
@@ -611,12 +636,32 @@ __device__ void log_push(Dev &d, State &st, double cost, double cost_change, dou
 
 // Ceres TrustRegionMinimizer::FinalizeIterationAndCheckIfMinimizerCanContinue (plus the
 // reductions of EvaluateGradientAndJacobian): one block.
-__global__ __launch_bounds__(1024) void k_check(Dev d) {      // 1024 lanes: one pose each at C2 (the exponential map is a long dependent chain)
+// fused_parts > 0 (single GPU, windowed stereo layout: nothing is exchanged between the linearisation and this kernel):
+// the block also does the work of k_reduce_lin (sums of the linearisation partials); k_finish_reduced's work is done by
+// k_assemble_reduced(.., fuse_finish) -- two launches less per iteration.  (A first version did k_finish_reduced's
+// work here too: 6 000 scattered diagonal entries from ONE block cost 16 us against 5 us for the 24-block launch.)
+__global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      // 1024 lanes: one pose each at C2 (the exponential map is a long dependent chain)
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[16];
     double gm = 0.0, xn = 0.0, cost = 0.0;
-    const bool lin = st.just_linearized != 0;
+    const bool lin = fused_parts > 0 ? st.need_linearize != 0 : st.just_linearized != 0;
+    double f_cost = 0.0, f_xn = 0.0, f_gml = 0.0;
+    if (fused_parts > 0) {
+        if (lin) {          // k_reduce_lin
+            double a = 0.0, b = 0.0, c = 0.0;
+            for (int i = threadIdx.x; i < fused_parts; i += (int)blockDim.x) {
+                a += d.part_lin[i * 4];
+                b += d.part_lin[i * 4 + 1];
+                c = fmax(c, d.part_lin[i * 4 + 2]);
+            }
+            if (d.n_pf)
+                for (int k = threadIdx.x; k < d.P; k += (int)blockDim.x) a += d.pf_cost[k];
+            f_cost = block_sum(a, sm);
+            f_xn = block_sum(b, sm);
+            f_gml = block_max(c, sm);
+        }
+    }
     if (lin) {
         // landmark partials (already all-reduced in scal[] when sharded: see host).  Partitioned solve: the
         // interior poses of every rank went into those sums before the exchange (k_sep_pack); what is left
@@ -651,6 +696,10 @@ __global__ __launch_bounds__(1024) void k_check(Dev d) {      // 1024 lanes: one
     ++st.check_count;
     if (lin) {
         double *sc = d.part ? d.sepv + d.soff_scal : d.xv + d.off_scal;
+        if (fused_parts > 0) {
+            sc[0] = f_cost; sc[1] = f_xn; *d.gmax_l = f_gml;
+            st.need_linearize = 0;
+        }
         st.x_cost = sc[0];
         double xnb = 0.0, gmb = 0.0;
         if (d.nb) {   // free shared blocks: |x_b|^2 and |x_b - Plus(x_b, -g_b)|_inf
@@ -738,8 +787,17 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
 }
 
 // candidate poses = Plus(x, delta_p)  [Evaluator::Plus with SE3Perturbation]
-__global__ __launch_bounds__(256) void k_pose_update(Dev d) {
+// fuse_best: also does k_best's share for the poses (x -> best when the k_check of this iteration saw the cost improve;
+// like k_best, before the termination test -- the improving iterate may be the converged one)
+__global__ __launch_bounds__(256) void k_pose_update(Dev d, int fuse_best) {
     const State &st = *d.st;
+    if (fuse_best && st.copy_best == st.check_count) {
+        const int kk = blockIdx.x * 256 + threadIdx.x;
+        if (kk < d.P) {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) d.best_poses[(size_t)kk * 12 + c] = d.poses[(size_t)kk * 12 + c];
+        }
+    }
     if (st.terminated) return;
     __shared__ double sm[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -917,8 +975,14 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
 // w, w + 4, w + 8; the partial sums of W^T delta_p and of the model-cost terms meet in LDS, every lane then forms
 // delta_l itself (fixed order, so the four lanes of a landmark hold identical candidates) and evaluates the candidate
 // cost of its own slots.
-__global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d) {
+// fuse_best: also does k_best's share for the points (see k_pose_update)
+__global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
     const State &st = *d.st;
+    if (fuse_best && st.copy_best == st.check_count && threadIdx.x < LMG) {
+        const int lb = blockIdx.x * LMG + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d.best_pts[(size_t)c * d.Lpad + lb] = d.pts[(size_t)c * d.Lpad + lb];
+    }
     if (st.terminated) return;
     __shared__ double sm[4];
     __shared__ double red[LMW_SPLIT][5][LMG];
@@ -1711,7 +1775,10 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
 // 0.133 / 0.272 ms for the split kernels).
 static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 262144; }
 
-void launch_linearize(Launcher &L, const Dev &d) {
+// fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
+static bool ctrl_fusable(const Dev &d) { return !d.phong && !d.dense && !d.part; }
+void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl) {
+    fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
@@ -1719,39 +1786,47 @@ void launch_linearize(Launcher &L, const Dev &d) {
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
     }
-    LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
+    if (!fuse_ctrl) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
 
-void launch_schur(Launcher &L, const Dev &d) {
+void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
+    fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
+    const int n_zero = fuse_ctrl ? 128 : 0;
     if (d.phong) launch_ph_schur(L, d);
-    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d);
-    if (d.part) {   // only this rank's chain is assembled and eliminated
+    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero);
+    if (fuse_ctrl) {
+    } else if (d.part) {   // only this rank's chain is assembled and eliminated
         const size_t n = (size_t)(d.chain1 - d.chain0 + 1) * BD * BD * sizeof(double);
         hipMemsetAsync(d.xv + d.off_D + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
         hipMemsetAsync(d.xv + d.off_L + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
     } else
     hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
-    const size_t n = (size_t)d.n_sblk * 36 + (size_t)d.nfree * 6;
-    LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+    const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6;
+    LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0);
 }
 
 void launch_finish_local(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
 }
 
-void launch_finish_check(Launcher &L, const Dev &d) {
+// fuse_ctrl: one launch instead of k_finish_reduced + k_check (+ the k_reduce_lin skipped by launch_linearize);
+// fuse_best: k_best's copy is done by the update / evaluation kernels of launch_update_eval(.., fuse_best)
+void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_best) {
+    fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
     if (d.dense) launch_dense_finish(L, d);
-    else LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d);
+    else if (!fuse_ctrl) LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
+    if (fuse_best && ctrl_fusable(d) && lm_split(d)) return;
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }
 
 // fuse_reduce: the caller's launch_decide_commit(.., true) forms the evaluation sums (no exchange in between)
-void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce) {
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
+void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_best) {
+    const int fb = fuse_best && ctrl_fusable(d) && lm_split(d) ? 1 : 0;
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
     if (d.phong) launch_ph_backsub_eval(L, d);
-    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d);
+    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
@@ -1762,7 +1837,7 @@ void launch_sep_pack(Launcher &L, const Dev &d) {
 }
 void launch_sep_finish_check(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d);
+    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, 0);
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }
@@ -1777,7 +1852,7 @@ void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses) {
 }
 
 void launch_pose_update(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, 0);
 }
 
 void launch_dogleg_eval(Launcher &L, const Dev &d) {
@@ -1785,7 +1860,7 @@ void launch_dogleg_eval(Launcher &L, const Dev &d) {
     if (d.phong) launch_ph_dogleg_gn(L, d);
     else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_gn<true> : k_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, 0);
     if (d.phong) launch_ph_dogleg_eval(L, d);
     else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_eval<true> : k_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks);

@@ -106,9 +106,9 @@ int configure_bcr_mf();
 void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled);
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
-void launch_linearize(Launcher &L, const Dev &d);
-void launch_schur(Launcher &L, const Dev &d);
-void launch_finish_check(Launcher &L, const Dev &d);
+void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false);    // fuse_ctrl / fuse_best: see ssba_kernels.hip (k_check)
+void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false);
+void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false);
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true);   // allow_pcr = false keeps the factors of every level (multi-rhs sweeps)
 // partitioned (multi-rank) solve: pack the chain ends into the separator exchange vector; after the exchange:
 // damping + convergence checks, separator BCR, scatter, back-substitution of the chain interior
@@ -119,7 +119,7 @@ void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
 void launch_eval_add_pose(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
-void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false);
+void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
 void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false);
 // config 3 (ssba_phong_solver.hip)
