@@ -171,7 +171,7 @@ struct FactorLds {
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     } while (0)
 
-// NRW: column tiles of [L | U^T] per wave (1: three workgroups per block, 2: two, 3: one)
+// NRW: column tiles of [L | U^T] per wave (1: three workgroups per block, 2: two, 3: one, 0: none -- blocks without couplings)
 template <int NRW>
 __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns) {
     State &st = *d.st;
@@ -187,8 +187,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     // this workgroup's share of the nine right-hand-side column tiles, dealt to waves 1, 2, 3, 0, 1, ... (wave 0 owns the
     // longest column of [D | r] and two diagonal tiles: it comes last)
     const int rfirst = (by * NRT) / ns, rcnt = ((by + 1) * NRT) / ns - rfirst;
-    int rcol[NRW];
-    bool ract[NRW];
+    constexpr int NRA = NRW > 0 ? NRW : 1;        // array extents (NRW = 0: the decoupled last step has no right-hand-side tiles)
+    int rcol[NRA];
+    bool ract[NRA];
 #pragma unroll
     for (int q = 0; q < NRW; ++q) {
         const int idx = ((w + 3) & 3) + 4 * q;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
 
     // ---- load: straight into the accumulator layout (128-byte row segments): one per-lane base pointer per column
     //      tile, compile-time row offsets, every load issued before the first is waited for ----------------------
-    mf_d4 dt[NDT], d00, rt[NRW][NDT];
+    mf_d4 dt[NDT], d00, rt[NRA][NDT];
     {
         const int colD = 16 * dj + j;
         const double *pD = o.Dg + g * BD + min(colD, BD - 1), *pr = o.rin + g;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
             }
 #pragma unroll
         for (int q = 0; q < 4; ++q) d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;
-        bool rok[NRW];
+        bool rok[NRA];
 #pragma unroll
         for (int q = 0; q < NRW; ++q) {
             const int col = 16 * rcol[q] + j;
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
         for (int r = 0; r < 4; ++r) {
             if (r >= nsub) break;
             const double Pv = Pa[r], Qv = Qa[r];
-            mf_d4 yq[NRW];
+            mf_d4 yq[NRA];
 #pragma unroll
             for (int q = 0; q < NRW; ++q)
                 if (ract[q]) yq[q] = mf(Pv, rt[q][k][r], mf_d4{0.0, 0.0, 0.0, 0.0});
@@ -826,7 +827,8 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
     const bool in_place = top || which < 2;
     const int ns = (!coupled || in_place) ? 1 : nblocks <= 85 ? 3 : nblocks <= 128 ? 2 : 1;
     const int grid = xcd_grid(nblocks, ns);
-    if (ns == 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
+    if (!coupled) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
+    else if (ns == 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
     else if (ns == 2) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
     else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
 }

@@ -212,7 +212,7 @@ int main(int argc, char **argv) {
     printf("n = %d blocks\n", n);
     printf("factor (coupled, lev 1):   %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, 1, 0, 2, true); }, 50));
     printf("factor (coupled, lev 0):   %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, 0, 0, 2, true); }, 50));
-    printf("factor (decoupled, top=0): %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, 1, 0, 2, false); }, 50));
+    printf("factor (decoupled, top=0): %.2f us / launch\n", time_us([&] { launch_bcr_factor_mf(L, d, n, d.pcr.steps, 0, 2, false); }, 50));
     launch_bcr_factor_mf(L, d, n, 1, 0, 2, true);
     printf("reduce (lev 1):            %.2f us / launch\n", time_us([&] { launch_bcr_reduce_mf(L, d, n, 2, 1, 2); }, 50));
 #ifdef SSBA_STAMPS
