@@ -64,9 +64,10 @@ def algorithmic_work(stats, phong=False):
         nxt = lv[1:k + 1] + [n] * steps
         bsub = [n] + [m // 2 for m in lv[:k]]
         # blocks moved per processed block: plain factor 3 in + 3 out, parallel step 3 in + 2 out (D stays), last 1 + 1;
-        # plain reduce 3 in + 2 out, parallel reduce D in/out + 4 operand blocks + the coupling and its transpose
+        # plain reduce 3 in + 2 out, parallel reduce D in/out + 3 operand blocks (YU, YL of the folded block before, YL of
+        # the one after) + the coupling and its transpose
         fact_blocks = 6 * sum(m // 2 for m in lv[:k]) + 5 * n * steps + 2 * n
-        red_blocks = 5 * sum(lv[1:k + 1]) + 8 * n * steps
+        red_blocks = 5 * sum(lv[1:k + 1]) + 7 * n * steps
     else:
         fact_blocks, red_blocks = 6 * sum(odd), 5 * sum(nxt)
     bd = 72
@@ -108,11 +109,50 @@ def algorithmic_work(stats, phong=False):
 
 def pmc_traffic(config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (bench.py
-    cannot collect PMC counters itself); tools/pmc_summarize.py documents the correction."""
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_{config.lower()}.json")
-    if not os.path.exists(path):
-        return {}
-    return {k: v["traffic_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}
+    cannot collect PMC counters itself); tools/pmc_summarize.py documents the correction.  Returns (traffic by kernel
+    class, the file it came from): the newest round's file under profiles/ -- a REPLAYED figure, not measured in this run."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{config.lower()}.json")))
+    if not paths:
+        return {}, None
+    path = paths[-1]
+    return {k: v["traffic_bytes_per_launch"] for k, v in json.load(open(path))["kernels"].items()}, os.path.relpath(path, ROOT)
+
+
+def measured_peaks():
+    """Peaks measured on this GPU model with tools/fp64_calib.hip (newest profiles/r*_fp64_calibration.txt), to read the
+    roofline fractions against what the chip delivers rather than against the data-sheet figures."""
+    import glob
+    import re
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fp64_calibration.txt")))
+    out = {"hbm_spec_GBs": HBM_PEAK_GBS, "fp64_spec_TFLOPs": FP64_PEAK_TFLOPS}
+    if not paths:
+        return out
+    txt = open(paths[-1]).read()
+    out["source"] = os.path.relpath(paths[-1], ROOT)
+    m = re.search(r"HBM copy[^:]*: ([0-9.]+) GB/s", txt)
+    if m:
+        out["hbm_copy_measured_GBs"] = float(m.group(1))
+    m = re.search(r"fp64 MFMA 16x16x4 throughput, 1 wave\(s\)/SIMD, 4 indep acc: ([0-9.]+) TFLOP/s", txt)
+    if m:
+        out["fp64_mfma_measured_TFLOPs"] = float(m.group(1))
+    m = re.search(r"fp64 FMA throughput, 4 wave\(s\)/SIMD, 8 indep acc: ([0-9.]+) TFLOP/s", txt)
+    if m:
+        out["fp64_valu_measured_TFLOPs"] = float(m.group(1))
+    return out
+
+
+def whole_iteration_work(stats):
+    """compulsory HBM bytes and flops of ONE trust-region iteration of the matrix-free design,
+    from the problem sizes alone (N observations, P free poses, L landmarks, B stored 6x6 blocks of S, track length T,
+    half-bandwidth w of S in poses)."""
+    N, L, P = stats["num_observations"], stats["num_active_points"], stats["num_free_poses"]
+    B, T, w = stats["num_reduced_blocks"], stats["num_observations"] / max(stats["num_active_points"], 1), stats["pose_bandwidth"] + 1
+    n = 6 * P
+    byt = 128 * N + P * 96 * 2 + L * 24 * 2 + L * (48 + 24) * 2 + P * (168 + 48) * 2 + 3 * B * 288 + n * 8 * 4
+    flo = 430 * N + L * (T * (T + 1) / 2 * 324 + T * 54) + n * (6 * w) ** 2 + 60 * N
+    return dict(N=N, P=P, L=L, B=B, T=round(T, 3), half_bandwidth_poses=w, bytes=byt, flops=flo,
+                formula="bytes = 128 N + 192 P + 48 L + 144 L + 432 P + 864 B + 32 n; flops = 430 N + L (T(T+1)/2 324 + 54 T) + n (6 w)^2 + 60 N; n = 6 P")
 
 
 def roofline_of(work, avg_ms):
@@ -293,12 +333,20 @@ def main():
         roof = roofline_of(work[dom], per_kernel[dom])
         roof["kernel"] = dom
         roof_all = {k: roofline_of(work[k], per_kernel[k]) for k in work if per_kernel.get(k)}
-        traffic = pmc_traffic(args.config) if world == 1 else {}
+        traffic, traffic_src = pmc_traffic(args.config) if world == 1 else ({}, None)
         for k, r in roof_all.items():
             r["traffic"] = traffic.get(k)
             r["algorithmic_bytes"] = work[k]["bytes"]
         roof["traffic"] = traffic.get(dom)
+        roof["traffic_source"] = f"{traffic_src} (rocprofv3 --pmc passes of the same command; replayed, not measured in this run)" if traffic_src else None
         roof["algorithmic_bytes"] = work[dom]["bytes"]
+        wi = whole_iteration_work(stats)
+        wi["ms"] = ms
+        wi["achieved_GBs"] = wi["bytes"] / (ms * 1e-3) / 1e9
+        wi["achieved_TFLOPs"] = wi["flops"] / (ms * 1e-3) / 1e12
+        wi["frac_hbm"] = wi["achieved_GBs"] / HBM_PEAK_GBS
+        wi["frac_fp64"] = wi["achieved_TFLOPs"] / FP64_PEAK_TFLOPS
+        wi["floor_us_at_hbm_peak"] = wi["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
         out = {
             "metric": "gauss_newton_iters_per_sec",
             "value": joint_ips * world,
@@ -333,6 +381,8 @@ def main():
                        "solve_device_s": solve_device_s},
             "roofline": roof,
             "roofline_by_kernel": roof_all,
+            "roofline_whole_iteration": wi,
+            "peaks": measured_peaks(),
             "kernel_ms_per_iter": {k: round(v, 5) for k, v in iter_kernel_ms.items()},
             "stats": stats,
         }

@@ -106,6 +106,11 @@ __global__ void k_lds_read(double *out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc0 + acc1;
 }
 
+// STREAM-style copy: 16 bytes per lane, read + write; bytes moved = 2 x n
+__global__ void k_copy(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 template <class F> float time_ms(F f, int reps) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); hipDeviceSynchronize();
@@ -168,6 +173,16 @@ int main() {
         float ms = time_ms([&] { run_chain(op); }, 3);
         hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         printf("dependent %-9s: %.1f clock64 ticks/op, %.1f ns/op\n", names[op], (double)h / 4000, ms * 1e6 / 4000);
+    }
+    {
+        // HBM: 1 GiB read + 1 GiB written per launch (far beyond the 256 MiB Infinity Cache)
+        const size_t n = (size_t)1 << 26;      // double2 elements
+        double2 *a, *b;
+        CHK(hipMalloc(&a, n * 16)); CHK(hipMalloc(&b, n * 16));
+        CHK(hipMemset(a, 0, n * 16));
+        float ms = time_ms([&] { hipLaunchKernelGGL(k_copy, 256 * 16, 256, 0, 0, a, b, n); }, 5);
+        printf("HBM copy (1 GiB read + 1 GiB write per launch): %.0f GB/s\n", 2.0 * n * 16 / ms / 1e6);
+        hipFree(a); hipFree(b);
     }
     {
         float ms = time_ms([&] { hipLaunchKernelGGL(k_lds_read, 256, 256, 0, 0, out, 4000); }, 3);

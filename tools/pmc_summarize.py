@@ -20,6 +20,8 @@ def avg(path, name):
             kernel = r["Kernel_Name"].split("(")[0].replace("ssba::", "").replace("void ", "").split("<")[0]
             if kernel.endswith("_w"):      # window-layout variants report under the kernel class of bench.py
                 kernel = kernel[:-2]
+            if kernel.endswith("_mf"):     # matrix-core block factor / reduce (ssba_bcr_mfma.hip)
+                kernel = kernel[:-3]
             a[kernel].append(float(r["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in a.items()}
 
