@@ -139,7 +139,7 @@ struct FactorLds {
     // no write-after-read protection
     double P[NDT][4][64], Q[NDT][4][64];    // sub-step operands of the diagonal tiles: [block row][sub-step][lane]
     double A[NDT - 1][4][4][64];            // finished D panels as A operands: [block row][column tile - 1][register][lane]
-    double piv[80], rc[80], rs[80];         // pivots d, 1/d, 1/sqrt(d) by row
+    double rc[80], rs[80];                  // 1 / pivot, 1 / sqrt(pivot) by row
     // hand-offs between the four waves (LDS words, monotonic): no workgroup barrier inside the factorisation
     int seqPQ;                              // sub-steps published so far: 4 k + r + 1
     int seqA[4];                            // per column tile - 1: block rows whose panel is published (k + 1)
@@ -199,7 +199,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     const int dj = w == 0 ? 4 : w;          // column tile of [D | r] this wave owns (wave 0 also owns tile (0, 0))
     if (t == 0) { S.bad = 0; S.seqPQ = 0; }
     if (t < 4) S.seqA[t] = 0;
-    if (t < 8) { S.piv[72 + t] = 1.0; S.rc[72 + t] = 1.0; }
+    if (t < 8) S.rc[72 + t] = 1.0;
+    // the only workgroup barrier before the end of the factorisation: the hand-off words are initialised.  It sits BEFORE
+    // the loads so that wave 0 can start on the first diagonal tile as soon as ITS data is there, without waiting for the
+    // other waves' right-hand-side tiles.
+    __syncthreads();
     MF_STAMP(0);
 
     // ---- load: straight into the accumulator layout (128-byte row segments): one per-lane base pointer per column
@@ -210,6 +214,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
         const double *pD = o.Dg + g * BD + min(colD, BD - 1), *pr = o.rin + g;
         double rv[NDT][4];
 #pragma unroll
+        for (int q = 0; q < 4; ++q) d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;      // first: the first diagonal tile waits for nothing else
+#pragma unroll
         for (int k = 0; k < NDT; ++k)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -217,8 +223,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
                 dt[k][q] = (in && k <= dj) ? pD[(16 * k + 4 * q) * BD] : 0.0;
                 rv[k][q] = (in && w == 0) ? pr[16 * k + 4 * q] : 0.0;
             }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;
         bool rok[NRA];
 #pragma unroll
         for (int q = 0; q < NRW; ++q) {
@@ -280,6 +284,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     const uint32_t mDiag = mk(j < 4 && g == j);
     const uint32_t m10 = mk(j == 1 && g == 0), m20 = mk(j == 2 && g == 0), m21 = mk(j == 2 && g == 1);
     const uint32_t m30 = mk(j == 3 && g == 0), m31 = mk(j == 3 && g == 1), m32 = mk(j == 3 && g == 2);
+    // the same masks as 0 / 1 factors: a blend of wave-uniform values into the per-lane operand is a short chain of FMAs
+    // (8 issue cycles each) instead of two v_cndmask + one v_or per term
+    const double kDiag = mDiag ? 1.0 : 0.0, k10 = m10 ? 1.0 : 0.0, k20 = m20 ? 1.0 : 0.0, k21 = m21 ? 1.0 : 0.0;
+    const double k30 = m30 ? 1.0 : 0.0, k31 = m31 ? 1.0 : 0.0, k32 = m32 ? 1.0 : 0.0;
+    const double kG0 = mG0 ? 1.0 : 0.0, kG1 = mG1 ? 1.0 : 0.0, kG2 = mG2 ? 1.0 : 0.0, kG3 = mG3 ? 1.0 : 0.0;
     auto sel = [](double v, uint32_t m, double acc) {      // (v & m) | acc, bitwise
         const uint32_t lo = ((uint32_t)__double2loint(v) & m) | (uint32_t)__double2loint(acc);
         const uint32_t hi = ((uint32_t)__double2hiint(v) & m) | (uint32_t)__double2hiint(acc);
@@ -323,24 +332,23 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
             const double n20 = fma(l21, l10, -l20);
             const double n31 = fma(l32, l21, -l31);
             const double n30 = -fma(l32, n20, fma(l31, -l10, l30));
-            double Pv = sel(1.0, mDiag, 0.0);
-            Pv = sel(-l10, m10, Pv); Pv = sel(n20, m20, Pv); Pv = sel(-l21, m21, Pv);
-            Pv = sel(n31, m31, Pv); Pv = sel(-l32, m32, Pv); Pv = sel(n30, m30, Pv);
+            // P = sum of entry x lane mask; the terms known early first, the last pivot's (n31, l32, n30) at the end
+            double Pv = fma(-l10, k10, kDiag);
+            Pv = fma(n20, k20, Pv);
+            Pv = fma(-l21, k21, Pv);
+            Pv = fma(n31, k31, Pv);
+            Pv = fma(-l32, k32, Pv);
+            Pv = fma(n30, k30, Pv);
             const mf_d4 y4 = mf(Pv, tr, mf_d4{0.0, 0.0, 0.0, 0.0});
-            double rcg = sel(rc0, mG0, 0.0);
-            rcg = sel(rc1, mG1, rcg); rcg = sel(rc2, mG2, rcg); rcg = sel(rc3, mG3, rcg);
-            const double qs = sel(-rcg, mk(j > b + 3), 0.0);
+            const double rcg = fma(rc3, kG3, fma(rc2, kG2, fma(rc1, kG1, rc0 * kG0)));
+            const double qs = (j > b + 3) ? -rcg : 0.0;
             const double y = y4[0];             // lane (g, j): unnormalised pivot row c_g[j] = (d l^T ...)[4r + g][j]
             T[r] = y;
             const double Qv = y * qs;
             if (r + 1 < nsub) T = mf(Qv, y, T);
             S.P[k][r][lane] = Pv;
             S.Q[k][r][lane] = Qv;
-            if (lane == 0) {        // uniform values: one lane publishes the four pivots and their reciprocals
-                double *pp = &S.piv[16 * k + b], *pr = &S.rc[16 * k + b];
-                pp[0] = s00; pp[1] = d1; pp[2] = d2; pp[3] = d3;
-                pr[0] = rc0; pr[1] = rc1; pr[2] = rc2; pr[3] = rc3;
-            }
+            if (j == 0) S.rc[16 * k + b + g] = rcg;         // four lanes, one reciprocal pivot each
             MF_POST(S.seqPQ, 4 * k + r + 1);
         }
     };
@@ -421,7 +429,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     };
 
     MF_STAMP(1);
-    __syncthreads();
     if (w == 0) factor_tile(d00, 0, 4);
 #pragma unroll
     for (int k = 0; k < NDT; ++k) {
@@ -438,9 +445,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     MF_STAMP(30);
     __syncthreads();
     if (t < BD) {
-        const double pv = S.piv[t];
-        if (!(pv > 0.0) || !(pv < INFINITY)) S.bad = 1;        // Cholesky breakdown: the step is rejected (Ceres: LM retries with a smaller radius)
-        S.rs[t] = mf_rsqrt(pv);
+        // 1 / pivot: a non-positive or non-finite pivot shows here (negative, infinite or NaN reciprocal): Cholesky breakdown,
+        // the step is rejected (Ceres: LM retries with a smaller radius)
+        const double rc = S.rc[t];
+        if (!(rc > 0.0) || !(rc < INFINITY)) S.bad = 1;
+        S.rs[t] = sqrt(rc);
     }
     __syncthreads();
     if (S.bad) {
