@@ -359,20 +359,45 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     // everybody's updates of block row dj.  The R stream (the wave's tiles of [L | U^T]) follows one block row behind
     // and fills the time the wave would otherwise spend waiting for the next diagonal tile.
     auto d_panel = [&](int k) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            MF_WAIT_GE(S.seqPQ, 4 * k + r + 1);
-            const double Pv = S.P[k][r][lane], Qv = S.Q[k][r][lane];
-            const double rcr = S.rc[16 * k + 4 * r + g];
+        auto sub = [&](int r, double Pv, double Qv, double rcr) {
             const mf_d4 yd = mf(Pv, dt[k][r], mf_d4{0.0, 0.0, 0.0, 0.0});
             const double y = yd[0];
             dt[k][r] = y;
             const double a = -y * rcr;
             S.A[k][dj - 1][r][lane] = a;
+            if (r < 3) dt[k] = mf(Qv, y, dt[k]);      // the next sub-step waits for this one: issued before the update of (dj, dj)
 #pragma unroll
             for (int i = 1; i < NDT; ++i)
                 if (i == dj) dt[i] = mf(a, y, dt[i]);
-            if (r < 3) dt[k] = mf(Qv, y, dt[k]);
+        };
+        // a wave that arrives late finds the whole diagonal tile published: one look at the hand-off word, all twelve
+        // operand reads in one batch (otherwise every sub-step pays a flag read and an operand read round trip)
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S.seqPQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 4 * k + 4) {
+            asm volatile("" ::: "memory");
+            double Pa[4], Qa[4], ra[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { Pa[r] = S.P[k][r][lane]; Qa[r] = S.Q[k][r][lane]; ra[r] = S.rc[16 * k + 4 * r + g]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sub(r, Pa[r], Qa[r], ra[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // flag and operands in ONE batch of LDS reads (the LDS serves a wave's reads in order: operands read
+                // after a flag value that says "published" are the published ones); retried until the flag is there
+                double Pv, Qv, rcr;
+                int it_ = 0;
+                for (;;) {
+                    const int f = __hip_atomic_load(&S.seqPQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");
+                    Pv = S.P[k][r][lane]; Qv = S.Q[k][r][lane]; rcr = S.rc[16 * k + 4 * r + g];
+                    asm volatile("" ::: "memory");
+                    if (__builtin_amdgcn_readfirstlane(f) >= 4 * k + r + 1) break;
+                    if (++it_ > (1 << 20)) { S.bad = 2; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sub(r, Pv, Qv, rcr);
+            }
         }
         MF_POST(S.seqA[dj - 1], k + 1);
     };
