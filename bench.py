@@ -214,9 +214,9 @@ def main():
     P1, L1 = synth.CONFIGS["C2" if (phong or robust) else args.config]
     lighting = None
     if phong:
-        if world > 1:
-            raise SystemExit("config C3 (lighting terms) is single-GPU in this build")
-        prob, ph = synth.make_phong_problem(P1, L1)
+        if world > 1 and args.shared_free:
+            raise SystemExit("config C3 with FREE shared blocks is single-GPU in this build (constant shared blocks shard)")
+        prob, ph = synth.make_phong_problem(P1 * world, L1 * world)
         lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
         prob = synth.make_problem(P1 * world, L1 * world, outlier_fraction=0.3 if robust else 0.0)
@@ -233,6 +233,10 @@ def main():
             shard = sharding.shard_by_landmarks(prob, world, rank)
     else:
         shard = sharding.whole(prob)
+    if phong and world > 1:      # this rank's landmarks and their lighting observations
+        sel = np.isin(prob.obs_point, shard.point_ids)
+        lighting = dict(lighting, normals=lighting["normals"][shard.point_ids], material_of_point=lighting["material_of_point"][shard.point_ids],
+                        intensity=lighting["intensity"][sel], normal_obs=lighting["normal_obs"][sel])
     ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
                   prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting,
                   shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds), partition=partition,

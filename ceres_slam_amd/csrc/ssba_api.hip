@@ -677,8 +677,11 @@ int ssba_finalize(ssba_problem *p) {
             set_error("lighting terms need a normal and a material for every point, and the light");
             return SSBA_ERR_INVALID_ARGUMENT;
         }
-        if (p->world_size > 1) {
-            set_error("lighting terms are not available with landmark sharding yet");
+        // Landmark sharding: the lighting terms of a landmark live on its rank like the stereo terms; what
+        // does not shard yet is the border of FREE shared blocks (its sums over all landmarks would have to ride in the
+        // exchange vector).  Constant light / Phong / texture blocks -- stage 1 of the reference driver -- are fine.
+        if (p->world_size > 1 && p->shared_const != 7u) {
+            set_error("landmark sharding with FREE shared lighting blocks is not available yet: hold light, Phong and texture blocks constant");
             return SSBA_ERR_UNSUPPORTED;
         }
     }
@@ -1185,7 +1188,7 @@ int ssba_finalize(ssba_problem *p) {
     if (const char *e = getenv("SSBA_PCR_MAX_BLOCKS")) pcr_max = std::min(PCR_MAX_BLOCKS, std::max(2, atoi(e)));
     const bool part = p->sep_sb.size() > 2;     // one rank: nothing is shared, the plain plan applies
     if (part) {
-        if (ph) { set_error("lighting terms are not available with landmark sharding yet"); return SSBA_ERR_UNSUPPORTED; }
+        if (ph && d.nb) { set_error("landmark sharding with free shared lighting blocks is not available yet"); return SSBA_ERR_UNSUPPORTED; }
         if ((int)p->sep_sb.back() != d.Nsb - 1 || p->sep_sb.front() != 0) {
             set_error("ssba_set_partition: the separators must start at super-block 0 and end at the last one");
             return SSBA_ERR_INVALID_ARGUMENT;
@@ -1658,8 +1661,8 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         return SSBA_ERR_UNSUPPORTED;
     }
     if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
-    if (p->d.phong && p->xfn) {
-        set_error("lighting terms: landmark sharding is not available yet");
+    if (p->d.phong && p->xfn && p->d.nb) {
+        set_error("lighting terms: landmark sharding with free shared blocks is not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
@@ -1873,8 +1876,8 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     ssba_options opt;
     if (o) opt = *o; else ssba_default_options(&opt);
     if (radius > 0.0) opt.initial_trust_region_radius = radius;
-    if (p->d.phong && p->xfn) {
-        set_error("lighting terms: landmark sharding is not available yet");
+    if (p->d.phong && p->xfn && p->d.nb) {
+        set_error("lighting terms: landmark sharding with free shared blocks is not available yet");
         return SSBA_ERR_UNSUPPORTED;
     }
     if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != opt.trust_region_strategy_type)

@@ -26,7 +26,13 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
     P, Lm, T = [int(v) for v in os.environ.get("SSBA_TEST_SIZE", "16,400,6").split(",")]
     huber_a = float(os.environ.get("SSBA_TEST_HUBER", "0"))      # with it: 30 % outlier observations (BASELINE.json configs[4])
-    prob = synth.make_problem(P, Lm, track_len=T, seed=21, outlier_fraction=0.3 if huber_a > 0 else 0.0)
+    lighting = None
+    if mode.endswith("_phong"):     # BASELINE.json configs[2] sharded: lighting terms of a landmark live on its rank
+        mode = mode[:-6]
+        prob, ph = synth.make_phong_problem(P, Lm, track_len=T, seed=21)
+        lighting = ph.as_oracle_dict("truth")       # shared light / Phong / texture blocks constant
+    else:
+        prob = synth.make_problem(P, Lm, track_len=T, seed=21, outlier_fraction=0.3 if huber_a > 0 else 0.0)
     partition = None
     if mode == "gpu_part":      # super-block-aligned landmark ranges + partitioned reduced solve
         cut = sharding.aligned_partition(prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
@@ -53,8 +59,13 @@ def main():
         from ceres_slam_amd import capi
         from ceres_slam_amd.solver import StereoBA
         torch.cuda.set_device(0)
+        lt = None
+        if lighting is not None:        # this rank's landmarks and observations
+            sel = np.isin(prob.obs_point, shard.point_ids)
+            lt = dict(lighting, normals=lighting["normals"][shard.point_ids], material_of_point=lighting["material_of_point"][shard.point_ids],
+                      intensity=lighting["intensity"][sel], normal_obs=lighting["normal_obs"][sel])
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a)
+                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a, lighting=lt)
         sharding.attach_torch_exchange(ba, dist)
         s, log = ba.solve(capi.default_options(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1))
         res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
@@ -62,6 +73,8 @@ def main():
                    poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist(),
                    partition=None if partition is None else partition.tolist(), accept=log["step_is_successful"].tolist(),
                    gmax=log["gradient_max_norm"].tolist(), step_norm=log["step_norm"].tolist())
+        if lt is not None:
+            res["normals"] = ba.normals.tolist()
     with open(f"{out}.{rank}.json", "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -187,3 +187,28 @@ def test_native_rccl_exchange_world_of_one():
     op = orc.OracleProblem.from_synth(prob)
     s2, _ = op.solve(orc.driver_options(num_threads=4))
     assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world", [("gpu_phong", 2), ("gpu_part_phong", 3)])
+def test_sharded_lighting_terms_match_unsharded_oracle(tmp_path, mode, world):
+    """BASELINE.json configs[2] sharded: stereo + Phong intensity + normal blocks with the shared light /
+    material / texture blocks constant, landmarks (with their lighting observations) split over the ranks -- summing the
+    whole reduced system (gpu_phong) and with the partitioned reduced solve (gpu_part_phong)."""
+    size, K = (60, 2400, 12), 20
+    res = _run_ranks(mode, str(tmp_path / "ph"), world, size=size, extra_env={"SSBA_TEST_MAXIT": str(K)})
+    prob, ph = synth.make_phong_problem(size[0], size[1], track_len=size[2], seed=21)
+    d = ph.as_oracle_dict("truth")
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d)
+    s2, log2 = op.solve(orc.driver_options(num_threads=2, max_num_iterations=K))
+    for r in res:
+        assert r["num_iterations"] == s2.num_iterations
+        assert r["accept"] == log2["step_is_successful"].tolist()
+        ok = np.asarray(log2["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log2["cost"][ok], rtol=1e-8)
+        assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
+        assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6
+        assert np.abs(np.asarray(r["normals"]) - op.normals[r["point_ids"]]).max() < 1e-6
+    assert res[0]["poses"] == res[1]["poses"]
