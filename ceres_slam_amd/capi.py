@@ -35,7 +35,7 @@ SYMBOLS = [
     "ssba_add_normal_blocks", "ssba_add_material_blocks", "ssba_add_light_block", "ssba_set_shared_block_constant",
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant", "ssba_release_cached_memory",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation", "ssba_add_relative_pose",
-    "ssba_pose_covariance", "ssba_rccl_unique_id", "ssba_set_rccl",
+    "ssba_pose_covariance", "ssba_rccl_unique_id", "ssba_set_rccl", "ssba_frontend_vo",
 ]
 
 
@@ -122,6 +122,8 @@ def load():
     L.ssba_set_exchange.argtypes = [H, EXCHANGE_FN, C.c_void_p]
     L.ssba_set_distributed.argtypes = [H, C.c_int, C.c_int]
     L.ssba_set_partition.argtypes = [H, _u32p, C.c_uint32]
+    L.ssba_frontend_vo.argtypes = [C.POINTER(Camera), C.c_int, C.c_uint32, _u32p, _u32p, _dp, C.c_uint32, C.c_uint32, C.c_double, C.c_int,
+                                   _dp, _dp, C.POINTER(C.c_uint8), _u32p, _u32p, _dp]
     L.ssba_rccl_unique_id.argtypes = [C.c_void_p, C.c_uint64]
     L.ssba_set_rccl.argtypes = [H, C.c_void_p, C.c_uint64]
     L.ssba_exchange_size.argtypes = [H, C.POINTER(C.c_uint64)]

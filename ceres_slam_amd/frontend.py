@@ -156,3 +156,30 @@ def compute_initial_guess_phong(camera: dict, num_states: int, num_points: int, 
             initialized[j] = True
     return poses, positions, normals, initialized, material_of_vertex, phong, texture, dict(
         pairs=len(pairs), matches=int(sum(len(p[0]) for p in pairs)), inliers=int(counts.sum()), ransac_device_s=secs)
+
+
+def compute_initial_guess_device(camera: dict, num_states: int, num_points: int, obs_state, obs_point, obs_uvd, first_pose,
+                                 num_iters: int = 400, thresh: float = 4.0, variant: int = 1, device: int = -1):
+    """DatasetProblem::compute_initial_guess(0, num_states) entirely on the device (ssba_frontend_vo): matching,
+    triangulation, RANSAC, pose chaining and map initialisation.  Returns (poses, points, initialized, stats)."""
+    import ctypes as C
+    lib = capi.load()
+    obs_state = np.asarray(obs_state)
+    order = np.argsort(obs_state, kind="stable")             # observations grouped by state, file order inside a state
+    start = np.zeros(num_states + 1, dtype=np.uint32)
+    np.cumsum(np.bincount(obs_state, minlength=num_states), out=start[1:])
+    ids = np.ascontiguousarray(np.asarray(obs_point)[order], dtype=np.uint32)
+    uvd = np.ascontiguousarray(np.asarray(obs_uvd, dtype=np.float64)[order])
+    poses = np.zeros((num_states, 12))
+    poses[0] = first_pose
+    points = np.zeros((num_points, 3))
+    init = np.zeros(num_points, dtype=np.uint8)
+    mcnt = np.zeros(max(num_states - 1, 1), dtype=np.uint32)
+    icnt = np.zeros(max(num_states - 1, 1), dtype=np.uint32)
+    secs = C.c_double(0.0)
+    cam = capi.Camera(**camera)
+    u32p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    capi.check(lib.ssba_frontend_vo(C.byref(cam), device, num_states, start.ctypes.data_as(u32p), ids.ctypes.data_as(u32p), capi.dptr(uvd),
+                                    num_points, num_iters, thresh, variant, capi.dptr(poses), capi.dptr(points), init.ctypes.data_as(u8p),
+                                    mcnt.ctypes.data_as(u32p), icnt.ctypes.data_as(u32p), C.byref(secs)), "ssba_frontend_vo")
+    return poses, points, init.astype(bool), dict(matches=int(mcnt[:num_states - 1].sum()), inliers=int(icnt[:num_states - 1].sum()), device_s=secs.value)

@@ -6,10 +6,10 @@
 // (geometry/se3group.hpp:425-429), map_points[j].data() the 3 doubles of Point3D -- exactly the pointers the reference's
 // solveWindow hands to ceres::Problem::AddResidualBlock (tests/dataset_vo.cpp:41-56).
 //
-// compute_initial_guess follows dataset_problem.cpp:179-270 step by step (reciprocal matches of consecutive states,
-// StereoCamera::triangulate, 3-point RANSAC alignment, pose chaining, map initialisation from the inliers) but runs the
-// 400 RANSAC hypotheses of ALL state pairs of the call in one GPU batch (ssba_frontend_ransac); the draw sequence of
-// std::mt19937(42) + std::uniform_int_distribution (point_cloud_aligner.cpp:70-76) is restated by ssba_ransac_samples.
+// compute_initial_guess does what dataset_problem.cpp:179-270 does (reciprocal matches of consecutive states,
+// StereoCamera::triangulate, 3-point RANSAC alignment, pose chaining, map initialisation from the inliers), all of it
+// on the device in one call (ssba_frontend_vo) for all state pairs of the range at once; the draw sequence of
+// std::mt19937(42) + std::uniform_int_distribution (point_cloud_aligner.cpp:70-76) is reproduced there.
 //
 // Beyond the reference: read_initial_guess() loads the `_poses.csv` / `_map.csv` pair that write_csv emits (so that a
 // saved state can be resumed), and write_csv prints full double precision (the reference's IOFormat(4) is lossy,
@@ -223,52 +223,38 @@ class DatasetProblem {
     //! (dataset_problem.cpp:179-270); k2 = 0 means all states.  Returns false if a state pair has fewer than three
     //! matches or the device is not available (the reference would carry on with garbage).
     bool compute_initial_guess(uint k1 = 0, uint k2 = 0) {
-        if (k2 == 0) k2 = num_states;
+        if (k1 >= k2) { k1 = 0; k2 = num_states; }                                // :184-187
         if (k2 <= k1 + 1) return true;
-        const Camera &cam = *camera;
-        const uint32_t num_iters = 400;                                          // point_cloud_aligner.cpp:68
-        std::vector<uint32_t> offset(1, 0), samples;
-        std::vector<double> pts0, pts1;
-        std::vector<uint> match_km1;                                             // observation index in state k-1 of every match
-        for (uint k = k1 + 1; k < k2; ++k) {                                     // :189-243
-            // features seen in both k-1 and k, in the order of each state's observation list (:209-222)
-            std::map<uint, uint> in_k;
-            for (uint i : state_indices_[k]) in_k[point_ids[i]] = i;
-            std::vector<uint> a, b;
-            std::map<uint, int> kept;
-            for (uint i : state_indices_[k - 1])
-                if (in_k.count(point_ids[i])) { a.push_back(i); kept[point_ids[i]] = 1; }
-            for (uint i : state_indices_[k])
-                if (kept.count(point_ids[i])) b.push_back(i);
-            if (a.size() < 3 || a.size() != b.size()) { std::cerr << "state " << k << ": fewer than 3 matches" << std::endl; return false; }
-            for (size_t m = 0; m < a.size(); ++m) {                              // :225-230
-                const Point p0 = detail::triangulate(cam, stereo_obs_list[a[m]].data()), p1 = detail::triangulate(cam, stereo_obs_list[b[m]].data());
-                pts0.insert(pts0.end(), p0.v, p0.v + 3);
-                pts1.insert(pts1.end(), p1.v, p1.v + 3);
-                match_km1.push_back(a[m]);
+        // the observations of the states [k1, k2), grouped by state in file order: what obs_indices_at_state walks (:197-206)
+        const uint ns = k2 - k1;
+        std::vector<uint32_t> state_start(ns + 1, 0), ids;
+        std::vector<double> uvd;
+        for (uint k = k1; k < k2; ++k) {
+            for (uint i : state_indices_[k]) {
+                ids.push_back(point_ids[i]);
+                uvd.insert(uvd.end(), stereo_obs_list[i].v, stereo_obs_list[i].v + 3);
             }
-            offset.push_back((uint32_t)(pts0.size() / 3));
-            std::vector<uint32_t> smp(3 * num_iters);
-            if (ssba_ransac_samples((uint32_t)a.size(), num_iters, __GNUC__ >= 11 ? 1 : 0, smp.data())) return false;
-            samples.insert(samples.end(), smp.begin(), smp.end());
+            state_start[k - k1 + 1] = (uint32_t)ids.size();
         }
-        const uint32_t num_pairs = k2 - k1 - 1;
-        std::vector<double> T((size_t)num_pairs * 12);
-        std::vector<uint8_t> inlier(pts0.size() / 3);
+        // everything else -- matching, triangulation, 400-hypothesis RANSAC per pair (threshold 4 px^2, :246-249), pose
+        // chaining (:255) and map initialisation (:259-269) -- runs on the device in one call
+        std::vector<double> P((size_t)ns * 12), M((size_t)num_points * 3);
+        std::vector<uint8_t> init(num_points);
+        for (int c = 0; c < 12; ++c) P[c] = poses[k1].v[c];
+        for (uint j = 0; j < num_points; ++j) {
+            init[j] = initialized_point[j] ? 1 : 0;
+            for (int c = 0; c < 3; ++c) M[3 * (size_t)j + c] = map_points[j].v[c];
+        }
+        const Camera &cam = *camera;
         ssba_camera c = {cam.fu, cam.fv, cam.cu, cam.cv, cam.b};
-        const int rc = ssba_frontend_ransac(&c, -1, num_pairs, offset.data(), pts0.data(), pts1.data(), samples.data(), num_iters, 4.0,
-                                            T.data(), inlier.data(), nullptr, nullptr);          // :246-249, threshold 4 px^2 (:248)
-        if (rc) { std::cerr << "ssba_frontend_ransac: " << ssba_status_string(rc) << std::endl; return false; }
-        for (uint k = k1 + 1; k < k2; ++k) {
-            const uint q = k - k1 - 1;
-            SE3 T_k_km1;
-            for (int i = 0; i < 12; ++i) T_k_km1.v[i] = T[12 * (size_t)q + i];
-            poses[k] = T_k_km1 * poses[k - 1];                                   // :255
-            const SE3 T_0_km1 = poses[k - 1].inverse();
-            for (uint32_t m = offset[q]; m < offset[q + 1]; ++m) {               // :259-269
-                const uint j = point_ids[match_km1[m]];
-                if (!inlier[m] || j >= num_points || initialized_point[j]) continue;
-                map_points[j] = T_0_km1 * Point(pts0[3 * (size_t)m], pts0[3 * (size_t)m + 1], pts0[3 * (size_t)m + 2]);
+        const int rc = ssba_frontend_vo(&c, -1, ns, state_start.data(), ids.data(), uvd.data(), num_points, 400, 4.0, __GNUC__ >= 11 ? 1 : 0,
+                                        P.data(), M.data(), init.data(), nullptr, nullptr, nullptr);
+        if (rc) { std::cerr << "ssba_frontend_vo: " << ssba_status_string(rc) << std::endl; return false; }
+        for (uint k = k1 + 1; k < k2; ++k)
+            for (int cc = 0; cc < 12; ++cc) poses[k].v[cc] = P[12 * (size_t)(k - k1) + cc];
+        for (uint j = 0; j < num_points; ++j) {
+            if (init[j] && !initialized_point[j]) {
+                map_points[j] = Point(M[3 * (size_t)j], M[3 * (size_t)j + 1], M[3 * (size_t)j + 2]);
                 initialized_point[j] = true;
             }
         }

@@ -363,6 +363,20 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]);
  * ssba_ransac_samples (host) restates the reference's draw sequence (:69-91): std::mt19937 re-seeded with 42 in
  * every call and std::uniform_int_distribution<uint>(0, n-1), three distinct indices per iteration.  The
  * distribution is implementation-defined; libstdcxx_variant 1 = libstdc++ >= 11, 0 = libstdc++ <= 10. */
+/* ssba_frontend_vo: the WHOLE DatasetProblem::compute_initial_guess(k1, k2) (src/ceres_slam/dataset_problem.cpp:179-270) on the
+ * device for `num_states` consecutive states: reciprocal matches of every pair of consecutive states by landmark id
+ * (:209-222; both lists in their state's order, paired by position), StereoCamera::triangulate of the matches
+ * (:225-230), the num_iters-hypothesis 3-point RANSAC of ALL pairs (one lane per alignment, one workgroup per inlier count;
+ * the draws are the reference's: std::mt19937(42) + uniform_int_distribution, libstdcxx_variant as for
+ * ssba_ransac_samples), pose chaining poses[k] = T_k_km1 * poses[k-1] (:255) and the map initialisation from the inliers
+ * of the first pair that sees a landmark (:259-269).  Observations of state k are the entries
+ * [state_start[k], state_start[k+1]) of point_id / uvd (3 per observation).  poses: num_states x 12, poses[0] is the input;
+ * map_points (num_points x 3) and initialized (num_points flags) are updated for newly initialised landmarks only.
+ * match_count / inlier_count (num_states - 1; may be NULL).  SSBA_ERR_NUMERICAL_FAILURE: a pair has fewer than 3 matches. */
+int ssba_frontend_vo(const ssba_camera *camera, int device, uint32_t num_states, const uint32_t *state_start,
+                     const uint32_t *point_id, const double *uvd, uint32_t num_points, uint32_t num_iters, double thresh,
+                     int libstdcxx_variant, double *poses, double *map_points, uint8_t *initialized, uint32_t *match_count,
+                     uint32_t *inlier_count, double *device_time_s);
 int ssba_ransac_samples(uint32_t n, uint32_t num_iters, int libstdcxx_variant, uint32_t *idx3);
 int ssba_frontend_ransac(const ssba_camera *camera, int device, uint32_t num_pairs, const uint32_t *offset,
                          const double *pts0, const double *pts1, const uint32_t *samples, uint32_t num_iters,

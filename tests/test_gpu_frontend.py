@@ -228,3 +228,18 @@ def test_phong_cpp_driver_with_its_own_front_end(tmp_path, window):
     out = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
     assert np.abs(out - poses).max() < 1e-4
     assert np.abs(out[:, :3] - prob.poses_gt[:, :3]).max() < 0.1
+
+
+@pytest.mark.parametrize("outliers", [0.0, 0.2])
+def test_device_vo_front_end_matches_the_oracle_backed_pipeline(outliers):
+    """ssba_frontend_vo: matching, triangulation, RANSAC, pose chaining and map initialisation on the device (nothing of
+    compute_initial_guess is left to the host) against the same pipeline with the oracle's RANSAC."""
+    prob = _problem(40, 3000, outlier_fraction=outliers)
+    args = (prob.camera, prob.num_poses, prob.num_points, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.poses_gt[0])
+    poses, points, init, stats = frontend.compute_initial_guess_device(*args)
+    poses2, points2, init2, stats2 = frontend.compute_initial_guess(*args, ransac=_oracle_ransac)
+    assert stats["matches"] == stats2["matches"] and stats["inliers"] == stats2["inliers"]
+    np.testing.assert_allclose(poses, poses2, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(init, init2)
+    np.testing.assert_allclose(points[init], points2[init], rtol=1e-6, atol=1e-6)
+    assert stats["device_s"] > 0
