@@ -1341,7 +1341,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_groups * 4));       // one entry per block of 256 landmarks, or per group of 64 (window layout)
     TRY(dzero(p, &d.part_eval, (size_t)d.n_groups * 4));
-    TRY(dzero(p, &d.part_pose, (size_t)(d.n_pose_blocks + 1) * NPP));   // + one entry for the border of shared blocks
+    TRY(dzero(p, &d.part_pose, (size_t)(std::max(d.n_pose_blocks, d.Nsb) + 1) * NPP));   // + one entry for the border of shared blocks
     TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks + 1) * NDL));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));
@@ -1530,12 +1530,19 @@ static int enqueue_iteration(ssba_problem *p) {
 
 static int enqueue_front(ssba_problem *p);
 
+// single GPU, LM, windowed stereo layout: the linearisation kernels commit the accepted step (ssba_kernels.hip:
+// launch_linearize); SSBA_NO_FUSE_ALL=1 keeps the k_commit launch (A/B, tests)
+static bool fuse_all_launches(const ssba_problem *p) {
+    static const bool off = [] { const char *e = getenv("SSBA_NO_FUSE_ALL"); return e && e[0] == '1'; }();
+    return !off && !p->xfn && !p->d.constrained && !p->d.nb && p->opt.trust_region_strategy_type != 1 && launch_can_fuse_all(p->d);
+}
+
 static int enqueue_kernels(ssba_problem *p) {
     int rc = enqueue_front(p);
     if (rc) return rc;
     // single GPU, LM: the decision kernel forms the evaluation sums itself (no exchange sits between them)
     const bool fuse = !p->xfn && !p->d.constrained && p->opt.trust_region_strategy_type != 1;
-    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse); }))) return rc;
+    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p)); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
@@ -1610,7 +1617,8 @@ static int enqueue_front(ssba_problem *p) {
     // single GPU: the small launches between the big kernels are folded into their neighbours (ssba_kernels.hip, k_check)
     const bool fuse_ctrl = !p->xfn && !d.constrained && !d.nb;
     const bool fuse_best = fuse_ctrl && p->opt.trust_region_strategy_type != 1;
-    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl); }))) return rc;
+    const bool fuse_all = fuse_all_launches(p);
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl); }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if ((rc = X(d.gmax_l, 1, 1))) return rc;

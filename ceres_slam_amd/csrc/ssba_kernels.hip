@@ -145,15 +145,14 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_landmarks(
 // One block per pose: gathers that pose's observations through the pose-major
 // reference list, accumulates the 21 unique entries of H_pp and g_p in registers and
 // reduces them across the block in a fixed order (no float atomics).
-template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev d) {
-    const State &st = *d.st;
-    if (st.terminated || !st.need_linearize) return;
-    const int k = blockIdx.x;
-    if (d.pose_free[k] < 0) return;
+// PS / PT: where the current iterate lives (the candidate buffers when the launch also commits the step the last
+// iteration accepted; then `commit` copies this pose into d.poses).  Call with the whole workgroup, k a free pose.
+template <bool DN> __device__ __forceinline__ void lin_pose_body(const Dev &d, int k, const double *__restrict__ PS,
+                                                                 const double *__restrict__ PT, bool commit) {
     __shared__ double sm[4][27];
     double T[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = d.poses[(size_t)k * 12 + i];
+    for (int i = 0; i < 12; ++i) T[i] = PS[(size_t)k * 12 + i];
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
@@ -184,7 +183,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
             double So[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) So[c] = d.dn_Sobs ? d.dn_Sobs[(size_t)oi * 9 + c] : Sk[c];
-            accumulate(So, d.pts[l], d.pts[(size_t)d.Lpad + l], d.pts[2 * (size_t)d.Lpad + l], d.dn_u[oi], d.dn_v[oi], d.dn_d[oi]);
+            accumulate(So, PT[l], PT[(size_t)d.Lpad + l], PT[2 * (size_t)d.Lpad + l], d.dn_u[oi], d.dn_v[oi], d.dn_d[oi]);
         }
     } else {
         // three observations per round: their references, then their 18 operands are in flight together (a rolled loop
@@ -200,7 +199,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
                 if (ref[q] == 0xFFFFFFFFu) continue;
                 const int l = (int)(ref[q] >> 4), sl = (int)(ref[q] & 15u);
                 const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)sl * LMG + (l & 63);
-                in[q][0] = d.pts[l]; in[q][1] = d.pts[(size_t)d.Lpad + l]; in[q][2] = d.pts[2 * (size_t)d.Lpad + l];
+                in[q][0] = PT[l]; in[q][1] = PT[(size_t)d.Lpad + l]; in[q][2] = PT[2 * (size_t)d.Lpad + l];
                 in[q][3] = d.ou[oi]; in[q][4] = d.ov[oi]; in[q][5] = d.od[oi];
             }
 #pragma unroll
@@ -225,7 +224,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
                 double r[6], J[36];
                 int dim;
                 const int other = pf_other_pose(d, (int)e);
-                const double cost = pf_evaluate(d, (int)e, T, other >= 0 ? d.poses + (size_t)other * 12 : nullptr, r, J, &dim);
+                const double cost = pf_evaluate(d, (int)e, T, other >= 0 ? PS + (size_t)other * 12 : nullptr, r, J, &dim);
                 if (threadIdx.x < 21) { for (int m = 0; m < dim; ++m) v += J[6 * m + a] * J[6 * m + c]; }
                 else if (threadIdx.x < 27) { for (int m = 0; m < dim; ++m) v += J[6 * m + (threadIdx.x - 21)] * r[m]; }
                 else if (pf_counts_cost(d, (int)e)) v += cost;
@@ -235,6 +234,17 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
         else if (threadIdx.x < 27) d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
         else if (d.n_pf) d.pf_cost[k] = v;
     }
+    if (commit && threadIdx.x >= 64 && threadIdx.x < 76) d.poses[(size_t)k * 12 + threadIdx.x - 64] = PS[(size_t)k * 12 + threadIdx.x - 64];
+}
+// fuse (single GPU, LM): the step the decision kernel accepted is committed on the way -- the iterate is read from the
+// candidate buffers and this pose written to x (k_linearize_landmarks_w(.., fuse), which runs first, did the points and
+// read the candidate poses too), so k_commit is not launched.
+template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev d, int fuse) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    if (d.pose_free[blockIdx.x] < 0) return;
+    const bool commit = fuse && st.accepted;
+    lin_pose_body<DN>(d, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
 
 // Window layout, four lanes per landmark: one block = one group of 64 landmarks (the ELL unit), wave w takes the slots
@@ -242,22 +252,23 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
 // broadcast reads, but four times as many waves hide the dependent fp64 chains of the linearisation.  The four
 // partial sums per landmark are combined through LDS in a fixed order by wave 0.
 constexpr int LMW_SPLIT = 4;
-__global__ __launch_bounds__(256) void k_linearize_landmarks_w(Dev d) {
-    const State &st = *d.st;
-    if (st.terminated || !st.need_linearize) return;
+// PS / PT / commit: see lin_pose_body
+__device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &st, int grp, const double *__restrict__ PS,
+                                                     const double *__restrict__ PT, bool commit) {
     __shared__ double sm[4];
     __shared__ double red[LMW_SPLIT - 1][10][LMG];
     const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
-    const int l = blockIdx.x * LMG + li;
+    const int l = grp * LMG + li;
     const uint32_t mask = d.lm_mask[l];
-    const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+    const double px = PT[l], py = PT[(size_t)d.Lpad + l], pz = PT[2 * (size_t)d.Lpad + l];
+    if (commit && w == 0) { d.pts[l] = px; d.pts[(size_t)d.Lpad + l] = py; d.pts[2 * (size_t)d.Lpad + l] = pz; }
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, cost = 0.0;
     if (mask) {
         const LmObs<false> ob(d, l, mask);
         for (int s = w; s < TW; s += LMW_SPLIT) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
-            const double *T = d.poses + (size_t)k * 12;
+            const double *T = PS + (size_t)k * 12;
             ObsLin o;
             obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             double Jl[9];
@@ -316,11 +327,18 @@ __global__ __launch_bounds__(256) void k_linearize_landmarks_w(Dev d) {
     const double c1 = block_sum(xn, sm);
     const double c2 = block_max(gm, sm);
     if (threadIdx.x == 0) {
-        d.part_lin[blockIdx.x * 4 + 0] = c0;
-        d.part_lin[blockIdx.x * 4 + 1] = c1;
-        d.part_lin[blockIdx.x * 4 + 2] = c2;
+        d.part_lin[grp * 4 + 0] = c0;
+        d.part_lin[grp * 4 + 1] = c1;
+        d.part_lin[grp * 4 + 2] = c2;
     }
 }
+__global__ __launch_bounds__(256) void k_linearize_landmarks_w(Dev d, int fuse) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    const bool commit = fuse && st.accepted;
+    lin_landmarks_w_body(d, st, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
+}
+
 
 // Schur complement contributions, output-stationary on the fp64 matrix cores: one 256-thread block per work item (a
 // window or a slice of it).  Batches of 21 landmarks are half-linearised by 252 (landmark, slot) producer lanes --
@@ -656,7 +674,8 @@ __global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      /
                 c = fmax(c, d.part_lin[i * 4 + 2]);
             }
             if (d.n_pf)
-                for (int k = threadIdx.x; k < d.P; k += (int)blockDim.x) a += d.pf_cost[k];
+                for (int k = threadIdx.x; k < d.P; k += (int)blockDim.x)
+                    a += d.pf_cost[k];
             f_cost = block_sum(a, sm);
             f_xn = block_sum(b, sm);
             f_gml = block_max(c, sm);
@@ -771,6 +790,7 @@ __global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      /
     st.ls_alpha = 1.0;
     // step_failed may already carry a landmark-block breakdown from k_schur_windows
 }
+
 
 __global__ __launch_bounds__(256) void k_best(Dev d) {
     const State &st = *d.st;
@@ -970,6 +990,139 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
     }
 }
 
+
+// The body of the Ceres trust-region loop after the candidate evaluation: step validity,
+// parameter / function tolerance, step quality, accept / reject, radius update.
+// n_eval_parts > 0 (single GPU, no exchange between the evaluation and the decision): the sums of k_reduce_eval are
+// formed here, one launch less per iteration.
+__device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts, int n_pose_parts) {
+    __shared__ double sm[4];
+    if (n_eval_parts > 0) {
+        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
+        for (int i = threadIdx.x; i < n_eval_parts; i += 256) {
+            e0 += d.part_eval[i * 4];
+            e1 += d.part_eval[i * 4 + 1];
+            e2 += d.part_eval[i * 4 + 2];
+            e3 += d.part_eval[i * 4 + 3];
+        }
+        e0 = block_sum(e0, sm);
+        e1 = block_sum(e1, sm);
+        e2 = block_sum(e2, sm);
+        e3 = block_sum(e3, sm);
+        if (threadIdx.x == 0) { d.scal2[0] = e0; d.scal2[1] = e1; d.scal2[2] = e2; d.scal2[3] = e3; }
+    }
+    double a = 0.0, b = 0.0, pcc = 0.0, pmc = 0.0;
+    for (int i = threadIdx.x; i < n_pose_parts + (d.nb ? 1 : 0); i += 256) {   // last entry: border of shared blocks
+        a += d.part_pose[i * NPP];
+        b += d.part_pose[i * NPP + 1];
+        if (d.n_pf && i < n_pose_parts) { pcc += d.part_pose[i * NPP + 2]; pmc += d.part_pose[i * NPP + 3]; }
+    }
+    a = block_sum(a, sm);
+    b = block_sum(b, sm);
+    pcc = block_sum(pcc, sm);
+    pmc = block_sum(pmc, sm);
+    if (threadIdx.x != 0) return;
+    if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_eval_add_pose), summed over ranks
+    const Options &o = st.opt;
+    const double candidate_cost_raw = d.scal2[0] + pcc;      // + unary pose residual blocks
+    const double mcc = d.scal2[1] + pmc;
+    const double step_norm = sqrt(d.scal2[2] + a);
+    const bool finite_step = (d.scal2[3] + b) == 0.0 && !st.step_failed;
+    st.model_cost_change = mcc;
+    // ComputeTrustRegionStep: LINEAR_SOLVER_FAILURE or model_cost_change <= 0 -> invalid
+    const bool step_is_valid = finite_step && (mcc > 0.0);
+    st.step_failed = 0;
+    if (!step_is_valid) {
+        // HandleInvalidStep
+        if (++st.num_invalid >= o.max_invalid && !o.ignore_convergence) {
+            st.terminated = 1; st.termination_type = 2;   // FAILURE
+        }
+        if (o.strategy) {            // DoglegStrategy::StepIsInvalid
+            st.mu *= 10.0; st.dl_reuse = 0;
+        } else {
+            st.radius /= st.decrease_factor;
+            st.decrease_factor *= 2.0;
+        }
+        ++st.num_unsuccessful;
+        log_push(d, st, st.x_cost, 0.0, 0.0, 0.0, 0);
+        return;
+    }
+    st.num_invalid = 0;
+    const double candidate_cost = isfinite(candidate_cost_raw) ? candidate_cost_raw : DBL_MAX;
+    st.candidate_cost = candidate_cost;
+    st.step_norm = step_norm;
+    st.cost_change = st.x_cost - candidate_cost;
+    if (!o.ignore_convergence) {
+        // ParameterToleranceReached
+        if (step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) {
+            st.terminated = 1; st.termination_type = 0; return;
+        }
+        // FunctionToleranceReached
+        if (fabs(st.cost_change) <= o.function_tolerance * st.x_cost) {
+            st.terminated = 1; st.termination_type = 0; return;
+        }
+    }
+    // TrustRegionStepEvaluator::StepQuality
+    const double rd0 = (st.se_current - candidate_cost) / mcc;
+    const double rd1 = (st.se_reference - candidate_cost) / (st.se_acc_ref + mcc);
+    const double rd = rd0 > rd1 ? rd0 : rd1;
+    st.relative_decrease = rd;
+    if (rd > o.min_relative_decrease) {
+        // HandleSuccessfulStep (re-linearisation happens at the top of the next iteration)
+        st.accepted = 1;
+        st.last_successful = 1;
+        st.need_linearize = 1;
+        ++st.num_successful;
+        if (o.strategy) {
+            // DoglegStrategy::StepAccepted
+            if (rd < 0.25) st.radius *= 0.5;
+            if (rd > 0.75) st.radius = fmax(st.radius, 3.0 * st.dl_step_norm);
+            st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+            st.dl_reuse = 0;
+        } else {
+            // LevenbergMarquardtStrategy::StepAccepted
+            const double tq = 2.0 * rd - 1.0;
+            st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
+            st.radius = fmin(o.max_radius, st.radius);
+            st.decrease_factor = 2.0;
+        }
+        // TrustRegionStepEvaluator::StepAccepted
+        st.se_current = candidate_cost;
+        st.se_acc_cand += mcc;
+        st.se_acc_ref += mcc;
+        if (st.se_current < st.se_minimum) {
+            st.se_minimum = st.se_current;
+            st.se_num_nonmono = 0;
+            st.se_candidate = st.se_current;
+            st.se_acc_cand = 0.0;
+        } else {
+            ++st.se_num_nonmono;
+            if (st.se_current > st.se_candidate) {
+                st.se_candidate = st.se_current;
+                st.se_acc_cand = 0.0;
+            }
+        }
+        if (st.se_num_nonmono == o.max_nonmono) {
+            st.se_reference = st.se_candidate;
+            st.se_acc_ref = st.se_acc_cand;
+        }
+    } else {
+        // HandleUnsuccessfulStep: StepRejected
+        if (o.strategy) {
+            st.radius *= 0.5; st.dl_reuse = 1;
+        } else {
+            st.radius /= st.decrease_factor;
+            st.decrease_factor *= 2.0;
+        }
+        ++st.num_unsuccessful;
+        log_push(d, st, candidate_cost, st.cost_change, step_norm, rd, 0);
+    }
+}
+__global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    decide_body(d, st, n_eval_parts, d.n_pose_blocks);
+}
 
 // The same pass in the window layout with four lanes per landmark (see k_linearize_landmarks_w): wave w takes the slots
 // w, w + 4, w + 8; the partial sums of W^T delta_p and of the model-cost terms meet in LDS, every lane then forms
@@ -1478,136 +1631,6 @@ __global__ __launch_bounds__(256) void k_reduce_eval(Dev d, int n_parts) {
     }
 }
 
-// The body of the Ceres trust-region loop after the candidate evaluation: step validity,
-// parameter / function tolerance, step quality, accept / reject, radius update.
-// n_eval_parts > 0 (single GPU, no exchange between the evaluation and the decision): the sums of k_reduce_eval are
-// formed here, one launch less per iteration.
-__global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts) {
-    State &st = *d.st;
-    if (st.terminated) return;
-    __shared__ double sm[4];
-    if (n_eval_parts > 0) {
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
-        for (int i = threadIdx.x; i < n_eval_parts; i += 256) {
-            e0 += d.part_eval[i * 4];
-            e1 += d.part_eval[i * 4 + 1];
-            e2 += d.part_eval[i * 4 + 2];
-            e3 += d.part_eval[i * 4 + 3];
-        }
-        e0 = block_sum(e0, sm);
-        e1 = block_sum(e1, sm);
-        e2 = block_sum(e2, sm);
-        e3 = block_sum(e3, sm);
-        if (threadIdx.x == 0) { d.scal2[0] = e0; d.scal2[1] = e1; d.scal2[2] = e2; d.scal2[3] = e3; }
-    }
-    double a = 0.0, b = 0.0, pcc = 0.0, pmc = 0.0;
-    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) {   // last entry: border of shared blocks
-        a += d.part_pose[i * NPP];
-        b += d.part_pose[i * NPP + 1];
-        if (d.n_pf && i < d.n_pose_blocks) { pcc += d.part_pose[i * NPP + 2]; pmc += d.part_pose[i * NPP + 3]; }
-    }
-    a = block_sum(a, sm);
-    b = block_sum(b, sm);
-    pcc = block_sum(pcc, sm);
-    pmc = block_sum(pmc, sm);
-    if (threadIdx.x != 0) return;
-    if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_eval_add_pose), summed over ranks
-    const Options &o = st.opt;
-    const double candidate_cost_raw = d.scal2[0] + pcc;      // + unary pose residual blocks
-    const double mcc = d.scal2[1] + pmc;
-    const double step_norm = sqrt(d.scal2[2] + a);
-    const bool finite_step = (d.scal2[3] + b) == 0.0 && !st.step_failed;
-    st.model_cost_change = mcc;
-    // ComputeTrustRegionStep: LINEAR_SOLVER_FAILURE or model_cost_change <= 0 -> invalid
-    const bool step_is_valid = finite_step && (mcc > 0.0);
-    st.step_failed = 0;
-    if (!step_is_valid) {
-        // HandleInvalidStep
-        if (++st.num_invalid >= o.max_invalid && !o.ignore_convergence) {
-            st.terminated = 1; st.termination_type = 2;   // FAILURE
-        }
-        if (o.strategy) {            // DoglegStrategy::StepIsInvalid
-            st.mu *= 10.0; st.dl_reuse = 0;
-        } else {
-            st.radius /= st.decrease_factor;
-            st.decrease_factor *= 2.0;
-        }
-        ++st.num_unsuccessful;
-        log_push(d, st, st.x_cost, 0.0, 0.0, 0.0, 0);
-        return;
-    }
-    st.num_invalid = 0;
-    const double candidate_cost = isfinite(candidate_cost_raw) ? candidate_cost_raw : DBL_MAX;
-    st.candidate_cost = candidate_cost;
-    st.step_norm = step_norm;
-    st.cost_change = st.x_cost - candidate_cost;
-    if (!o.ignore_convergence) {
-        // ParameterToleranceReached
-        if (step_norm <= o.parameter_tolerance * (st.x_norm + o.parameter_tolerance)) {
-            st.terminated = 1; st.termination_type = 0; return;
-        }
-        // FunctionToleranceReached
-        if (fabs(st.cost_change) <= o.function_tolerance * st.x_cost) {
-            st.terminated = 1; st.termination_type = 0; return;
-        }
-    }
-    // TrustRegionStepEvaluator::StepQuality
-    const double rd0 = (st.se_current - candidate_cost) / mcc;
-    const double rd1 = (st.se_reference - candidate_cost) / (st.se_acc_ref + mcc);
-    const double rd = rd0 > rd1 ? rd0 : rd1;
-    st.relative_decrease = rd;
-    if (rd > o.min_relative_decrease) {
-        // HandleSuccessfulStep (re-linearisation happens at the top of the next iteration)
-        st.accepted = 1;
-        st.last_successful = 1;
-        st.need_linearize = 1;
-        ++st.num_successful;
-        if (o.strategy) {
-            // DoglegStrategy::StepAccepted
-            if (rd < 0.25) st.radius *= 0.5;
-            if (rd > 0.75) st.radius = fmax(st.radius, 3.0 * st.dl_step_norm);
-            st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
-            st.dl_reuse = 0;
-        } else {
-            // LevenbergMarquardtStrategy::StepAccepted
-            const double tq = 2.0 * rd - 1.0;
-            st.radius = st.radius / fmax(1.0 / 3.0, 1.0 - tq * tq * tq);
-            st.radius = fmin(o.max_radius, st.radius);
-            st.decrease_factor = 2.0;
-        }
-        // TrustRegionStepEvaluator::StepAccepted
-        st.se_current = candidate_cost;
-        st.se_acc_cand += mcc;
-        st.se_acc_ref += mcc;
-        if (st.se_current < st.se_minimum) {
-            st.se_minimum = st.se_current;
-            st.se_num_nonmono = 0;
-            st.se_candidate = st.se_current;
-            st.se_acc_cand = 0.0;
-        } else {
-            ++st.se_num_nonmono;
-            if (st.se_current > st.se_candidate) {
-                st.se_candidate = st.se_current;
-                st.se_acc_cand = 0.0;
-            }
-        }
-        if (st.se_num_nonmono == o.max_nonmono) {
-            st.se_reference = st.se_candidate;
-            st.se_acc_ref = st.se_acc_cand;
-        }
-    } else {
-        // HandleUnsuccessfulStep: StepRejected
-        if (o.strategy) {
-            st.radius *= 0.5; st.dl_reuse = 1;
-        } else {
-            st.radius /= st.decrease_factor;
-            st.decrease_factor *= 2.0;
-        }
-        ++st.num_unsuccessful;
-        log_push(d, st, candidate_cost, st.cost_change, step_norm, rd, 0);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_commit(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.accepted) return;
@@ -1777,14 +1800,17 @@ static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 26
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
 static bool ctrl_fusable(const Dev &d) { return !d.phong && !d.dense && !d.part; }
-void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl) {
+bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && lm_split(d); }
+// fuse_all (single GPU, LM, windowed stereo layout, launch_can_fuse_all): the linearisation kernels commit the accepted
+// step on the way (no k_commit launch)
+void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w, dim3(d.n_groups), dim3(256), 0, d);
+        if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w, dim3(d.n_groups), dim3(256), 0, d, fuse_all ? 1 : 0);
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
+        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d, fuse_all ? 1 : 0);
     }
     if (!fuse_ctrl) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
@@ -1866,8 +1892,9 @@ void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks);
 }
 
-void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce) {
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all) {
     LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
+    if (fuse_all) return;       // the next linearisation commits (launch_linearize)
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
 }

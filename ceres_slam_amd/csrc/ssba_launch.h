@@ -106,7 +106,8 @@ int configure_bcr_mf();
 void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled);
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
-void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false);    // fuse_ctrl / fuse_best: see ssba_kernels.hip (k_check)
+bool launch_can_fuse_all(const Dev &d);
+void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false);
 void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false);
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true);   // allow_pcr = false keeps the factors of every level (multi-rhs sweeps)
@@ -121,7 +122,7 @@ void launch_eval_add_pose(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
-void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false);
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false);
 // config 3 (ssba_phong_solver.hip)
 int upload_phong_tables(hipStream_t s);
 int configure_phong();
