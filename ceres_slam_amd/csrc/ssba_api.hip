@@ -741,7 +741,8 @@ int ssba_finalize(ssba_problem *p) {
     phase.mark("finalize: 1 landmark lists");
     // per-landmark sorted pose sets; envelope checks.  The windowed layout needs tracks <= TW and a pose co-visibility
     // span <= SBP (block-tridiagonal reduced system); anything else takes the general path with a dense reduced system.
-    bool dense = false;
+    bool dense = false, span_violation = false;
+    std::vector<uint32_t> wide;         // landmarks whose free poses span more than SBP
     struct LmInfo { uint32_t j, kmin, kmax; };
     std::vector<LmInfo> order;
     order.reserve(L);
@@ -767,7 +768,7 @@ int ssba_finalize(ssba_problem *p) {
         order.push_back({j, ks[0], ks[n - 1]});
         int flo = 1 << 30, fhi = -1;
         for (uint32_t e = 0; e < n; ++e) { const int f = p->pose_free[ks[e]]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
-        if (fhi - flo > SBP) dense = true;
+        if (fhi - flo > SBP) { span_violation = true; wide.push_back(j); }
     }
     if (p->points_const && !ph) {
         set_error("constant position blocks are only available with lighting terms (stage 2 of --multistage)");
@@ -776,6 +777,54 @@ int ssba_finalize(ssba_problem *p) {
     if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
     if (p->per_obs_S) dense = true;     // per-block stiffness lives in the general layout only
     if (!p->rel_factors.empty()) dense = true;     // pose-pose couplings outside the landmark structure
+    // Closure border: when the only thing outside the windowed envelope is the co-visibility span of a few landmarks
+    // (a loop closure: the last states see landmarks of the first ones), the far poses of those landmarks -- at most
+    // NBP / 6 = 5 -- leave the chain and become a dense border of the block-tridiagonal system, solved with the
+    // machinery of the free shared blocks of config 3 (ssba_border.hip).  They keep their place among the free poses
+    // (numbered last), their rows of the chain system are identity rows.  Everything else takes the general path.
+    int nchain = nfree;
+    if (span_violation && !dense) {
+        const char *e = getenv("SSBA_NO_CLOSURE_BORDER");
+        bool ok = !(e && e[0] == '1') && !ph && p->world_size == 1 && !p->per_obs_S && p->rel_factors.empty() && pfs.empty();
+        std::vector<uint8_t> is_border(nfree, 0);
+        int nborder = 0;
+        for (size_t q = 0; q < wide.size() && ok; ++q) {
+            const uint32_t j = wide[q];
+            const uint32_t *ks = &lm_pose_sorted[lm_start[j]];
+            const uint32_t n = lm_start[j + 1] - lm_start[j];
+            int flo = 1 << 30;
+            for (uint32_t e = 0; e < n; ++e) { const int f = p->pose_free[ks[e]]; if (f >= 0) flo = std::min(flo, f); }
+            for (uint32_t e = 0; e < n; ++e) {
+                const int f = p->pose_free[ks[e]];
+                if (f >= 0 && f - flo > SBP && !is_border[f]) { is_border[f] = 1; if (++nborder > NBP / 6) ok = false; }
+            }
+        }
+        if (ok) {       // what is left of every landmark's pose set must fit the envelope
+            std::vector<int> chain_index(nfree, -1);
+            int c = 0;
+            for (int f = 0; f < nfree; ++f) if (!is_border[f]) chain_index[f] = c++;
+            for (uint32_t j = 0; j < L && ok; ++j) {
+                int flo = 1 << 30, fhi = -1;
+                for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
+                    const int f = p->pose_free[lm_pose_sorted[e]];
+                    if (f >= 0 && !is_border[f]) { flo = std::min(flo, chain_index[f]); fhi = std::max(fhi, chain_index[f]); }
+                }
+                if (fhi - flo > SBP) ok = false;
+            }
+            if (ok) {   // renumber: chain poses in their order, border poses last
+                nchain = c;
+                std::vector<int> nf(nfree);
+                int b = nchain;
+                for (int f = 0; f < nfree; ++f) nf[f] = is_border[f] ? b++ : chain_index[f];
+                std::vector<int> fp(nfree);
+                for (int f = 0; f < nfree; ++f) fp[nf[f]] = p->free_pose[f];
+                p->free_pose = fp;
+                for (int f = 0; f < nfree; ++f) p->pose_free[p->free_pose[f]] = f;
+            }
+        }
+        if (!ok) dense = true;
+    }
+    const int nborder = nfree - nchain;
     if (dense) {
         if (p->world_size > 1 || nfree > 4096) {
             set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
@@ -1018,6 +1067,8 @@ int ssba_finalize(ssba_problem *p) {
     struct Contrib { uint32_t a, b, c; };
     std::vector<Contrib> contribs;
     std::vector<std::pair<uint32_t, uint32_t>> prow;   // (free pose, slab*TW+slot)
+    std::vector<Contrib> cb_contribs;                  // closure border: (row free pose, border pose, slab pair | bit 31: transposed)
+    std::vector<std::pair<uint32_t, uint32_t>> cb_prow;
     uint32_t bandwidth = 0;
     for (uint32_t it = 0; it < n_slabs; ++it) {
         const uint32_t w = slab_win[it];
@@ -1043,13 +1094,19 @@ int ssba_finalize(ssba_problem *p) {
                 const uint32_t ka = win_pose[(size_t)w * TW + a], kb = win_pose[(size_t)w * TW + b];
                 const int fa = p->pose_free[ka], fb = p->pose_free[kb];
                 if (fa < 0 || fb < 0) continue;
+                if (fa >= nchain || fb >= nchain) {     // a block of the closure border: row = the smaller free index
+                    const bool swap = fa > fb;          // slab block is (slot a rows) x (slot b columns)
+                    cb_contribs.push_back({(uint32_t)(swap ? fb : fa), (uint32_t)(swap ? fa : fb), (it * NPAIR + (uint32_t)n) | (swap ? 0x80000000u : 0u)});
+                    continue;
+                }
                 contribs.push_back({(uint32_t)fa, (uint32_t)fb, it * NPAIR + (uint32_t)n});
                 bandwidth = std::max<uint32_t>(bandwidth, (uint32_t)(fb - fa));
             }
         for (int s = 0; s < TW; ++s) {
             if (!((slot_any >> s) & 1u)) continue;
             const int f = p->pose_free[win_pose[(size_t)w * TW + s]];
-            if (f >= 0) prow.push_back({(uint32_t)f, it * TW + (uint32_t)s});
+            if (f >= nchain) cb_prow.push_back({(uint32_t)f, it * TW + (uint32_t)s});
+            else if (f >= 0) prow.push_back({(uint32_t)f, it * TW + (uint32_t)s});
         }
     }
     if (bandwidth > (uint32_t)SBP) {      // cannot happen: such problems took the dense path above
@@ -1061,7 +1118,7 @@ int ssba_finalize(ssba_problem *p) {
     // (a, b - a) keys (the contributions were generated in ascending order); every free pose gets its diagonal block
     // even without landmark contributions
     {
-        const size_t nkeys = (size_t)nfree * (SBP + 1);
+        const size_t nkeys = (size_t)nchain * (SBP + 1);
         std::vector<uint32_t> kstart(nkeys + 1, 0);
         for (auto &c : contribs) kstart[(size_t)c.a * (SBP + 1) + (c.b - c.a) + 1]++;
         for (size_t q = 0; q < nkeys; ++q) kstart[q + 1] += kstart[q];
@@ -1083,6 +1140,31 @@ int ssba_finalize(ssba_problem *p) {
     for (auto &pr : prow) prow_start[pr.first + 1]++;
     for (int f = 0; f < nfree; ++f) prow_start[f + 1] += prow_start[f];
     for (auto &pr : prow) prow_contrib.push_back(pr.second);
+    // closure border: blocks (row free pose, border pose) in order, every border pose with its diagonal block; then one
+    // pseudo-block per border pose for its right-hand-side contributions (b = 0xFFFFFFFF)
+    std::vector<uint32_t> cb_a, cb_b, cb_start, cb_contrib;
+    if (nborder) {
+        for (int f = nchain; f < nfree; ++f) cb_contribs.push_back({(uint32_t)f, (uint32_t)f, 0xFFFFFFFFu});   // marker: diagonal block exists
+        std::stable_sort(cb_contribs.begin(), cb_contribs.end(), [](const Contrib &x, const Contrib &y) {
+            if (x.a != y.a) return x.a < y.a;
+            if (x.b != y.b) return x.b < y.b;
+            return (x.c == 0xFFFFFFFFu) > (y.c == 0xFFFFFFFFu);
+        });
+        for (size_t i = 0; i < cb_contribs.size(); ++i) {
+            if (i == 0 || cb_contribs[i].a != cb_contribs[i - 1].a || cb_contribs[i].b != cb_contribs[i - 1].b) {
+                cb_a.push_back(cb_contribs[i].a); cb_b.push_back(cb_contribs[i].b);
+                cb_start.push_back((uint32_t)cb_contrib.size());
+            }
+            if (cb_contribs[i].c != 0xFFFFFFFFu) cb_contrib.push_back(cb_contribs[i].c);
+        }
+        std::sort(cb_prow.begin(), cb_prow.end());
+        for (int f = nchain; f < nfree; ++f) {
+            cb_a.push_back((uint32_t)f); cb_b.push_back(0xFFFFFFFFu);
+            cb_start.push_back((uint32_t)cb_contrib.size());
+            for (auto &pr : cb_prow) if ((int)pr.first == f) cb_contrib.push_back(pr.second);
+        }
+        cb_start.push_back((uint32_t)cb_contrib.size());
+    }
 
     phase.mark("finalize: 6 block structure");
     // ---- device mirrors ------------------------------------------------------------
@@ -1092,7 +1174,7 @@ int ssba_finalize(ssba_problem *p) {
     d.fu = p->cam.fu; d.fv = p->cam.fv; d.cu = p->cam.cu; d.cv = p->cam.cv; d.b = p->cam.b;
     memcpy(d.S, p->S, sizeof d.S);
     d.huber_a = p->huber_a;
-    d.P = (int)P; d.nfree = nfree;
+    d.P = (int)P; d.nfree = nfree; d.nchain = nchain;
     d.Nsb = std::max(1, (nfree + SBP - 1) / SBP);
     d.nf_pad = d.Nsb * SBP;
     d.Lpad = (int)Lpad; d.n_groups = (int)n_groups; d.n_windows = (int)n_windows;
@@ -1162,6 +1244,15 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dupload(p, &d.sblk_a, sblk_a)); TRY(dupload(p, &d.sblk_b, sblk_b));
     TRY(dupload(p, &d.sblk_start, sblk_start)); TRY(dupload(p, &d.sblk_contrib, sblk_contrib));
     TRY(dupload(p, &d.prow_start, prow_start)); TRY(dupload(p, &d.prow_contrib, prow_contrib));
+    if (nborder) {      // closure border: 6 columns per border pose
+        d.cb = 1; d.nb = 6 * nborder; d.n_cb = (int)cb_a.size();
+        d.b_light = d.b_phong = d.b_tex = -1;
+        TRY(dupload(p, &d.cb_a, cb_a)); TRY(dupload(p, &d.cb_b, cb_b));
+        TRY(dupload(p, &d.cb_start, cb_start)); TRY(dupload(p, &d.cb_contrib, cb_contrib));
+        TRY(dzero(p, &d.bsys, (size_t)BS_COUNT));
+        d.n_gram = 64;
+        TRY(dzero(p, &d.part_g, (size_t)d.n_gram * (NBP * NBP + NBP)));
+    }
     phase.mark("finalize: 7 device mirrors");
     // exchange vector
     const uint64_t blk = (uint64_t)BD * BD;
@@ -1379,7 +1470,7 @@ int ssba_finalize(ssba_problem *p) {
     p->stats.num_observations = N; p->stats.num_windows = n_windows;
     p->stats.num_superblocks = (uint32_t)d.Nsb; p->stats.num_reduced_blocks = n_sblk;
     p->stats.pose_bandwidth = bandwidth;
-    p->stats.general_structure = dense ? 1u : 0u;
+    p->stats.general_structure = dense ? 1u : nborder ? 2u : 0u;      // 2: windowed layout + closure border
     p->stats.pcr_blocks = d.pcr.level >= 0 ? (uint32_t)d.pcr.n : 0u;
     if (dense) {      // the dense reduced system: its non-zero blocks and the real co-visibility span
         p->stats.num_reduced_blocks = (uint32_t)dn_blk_a.size();
@@ -1669,6 +1760,10 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         return SSBA_ERR_UNSUPPORTED;
     }
     if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
+    if (o->trust_region_strategy_type == 1 && p->d.cb) {
+        set_error("DOGLEG is not available with a closure border yet; SSBA_NO_CLOSURE_BORDER=1 at ssba_finalize selects the general path");
+        return SSBA_ERR_UNSUPPORTED;
+    }
     if (p->d.phong && p->xfn && p->d.nb) {
         set_error("lighting terms: landmark sharding with free shared blocks is not available yet");
         return SSBA_ERR_UNSUPPORTED;
@@ -2061,8 +2156,9 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     ApiTimer api_timer("ssba_pose_covariance");
     if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
-    if (p->d.part || p->d.phong) {
-        set_error("covariance: not available on partitioned problems or with lighting terms");
+    if (p->d.part || p->d.phong || p->d.cb) {
+        set_error("covariance: not available on partitioned problems, with lighting terms or with a closure border "
+                  "(SSBA_NO_CLOSURE_BORDER=1 at ssba_finalize selects the general path)");
         return SSBA_ERR_UNSUPPORTED;
     }
     const int f = p->pose_free[pose];

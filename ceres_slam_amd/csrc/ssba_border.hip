@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void k_border_apply(Dev d) {
     if (i >= d.nf_pad * 6) return;
     double v = d.x0[i];
     for (int c = 0; c < d.nb; ++c) v -= d.Zb[(size_t)i * NBP + c] * d.bsys[BS_DB + c];
+    if (d.cb && i >= d.nchain * 6 && i < d.nfree * 6) v = d.bsys[BS_DB + (i - d.nchain * 6)];     // closure border: these poses ARE the border
     d.x0[i] = v;
 }
 

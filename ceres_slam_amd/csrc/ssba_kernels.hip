@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
             return;
         }
     }
-    if (f < d.nfree) {
+    if (f < d.nchain) {        // (the poses of a closure border keep identity rows in the chain system)
         const double h = d.xv[d.off_hdiag + i];
         if (st.iteration == 0) d.sp[i] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
         const double s = d.sp[i], s2 = s * s;
@@ -639,6 +639,51 @@ __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
     } else {
         *Dd = 1.0;
         d.xv[d.off_rhs + i] = 0.0;
+    }
+}
+
+// Closure border (ssba_finalize): the blocks of the reduced system that involve a border pose, gathered from the Schur
+// slabs like k_assemble_reduced does for the chain: S_pb (chain pose rows x 6 columns per border pose) = - sum slabs,
+// S_bb = H_pp(border) - sum slabs, and per border pose the reduced gradient, gradient, diag H_pp and (iteration 0) the
+// Jacobi scale.  One thread per (block, element); contribution codes carry bit 31 when the slab block is the transpose.
+__global__ __launch_bounds__(256) void k_cb_assemble(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int blk = (int)(gid / 36);
+    if (blk >= d.n_cb) return;
+    const int e = (int)(gid - (size_t)blk * 36), r = e / 6, c = e - 6 * r;
+    const uint32_t fa = d.cb_a[blk], fb = d.cb_b[blk];
+    const uint32_t ib = d.cb_start[blk], ie = d.cb_start[blk + 1];
+    if (fb == 0xFFFFFFFFu) {        // right-hand side and diagonal terms of border pose fa
+        if (e >= 6) return;
+        const int k = d.free_pose[fa], col = ((int)fa - d.nchain) * 6 + e;
+        const double g = d.gp[(size_t)k * 6 + e], h = d.hpp[(size_t)k * 21 + tri21(e, e)];
+        double v = g;
+        for (uint32_t i = ib; i < ie; ++i) {
+            const uint32_t cw = d.cb_contrib[i];
+            v -= d.slab[(size_t)(cw / TW) * SLAB_DOUBLES + NPAIR * 36 + (cw % TW) * 6 + e];
+        }
+        d.bsys[BS_RHS + col] = v;
+        d.bsys[BS_G + col] = g;
+        d.bsys[BS_H + col] = h;
+        if (st.iteration == 0) d.bsys[BS_S + col] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+        return;
+    }
+    double v = 0.0;
+    for (uint32_t i = ib; i < ie; ++i) {
+        const uint32_t cw = d.cb_contrib[i], code = cw & 0x7FFFFFFFu;
+        v += d.slab[(size_t)(code / NPAIR) * SLAB_DOUBLES + (size_t)(code % NPAIR) * 36 + ((cw >> 31) ? c * 6 + r : r * 6 + c)];
+    }
+    const int col = ((int)fb - d.nchain) * 6 + c;
+    if ((int)fa < d.nchain) {
+        d.Spb[((size_t)fa * 6 + r) * NBP + col] = -v;
+    } else {
+        const int row = ((int)fa - d.nchain) * 6 + r;
+        double sv = -v;
+        if (fa == fb) sv += d.hpp[(size_t)d.free_pose[fa] * 21 + tri21(r < c ? r : c, r < c ? c : r)];
+        d.bsys[BS_SBB + row * NBP + col] = sv;
+        if (fa != fb) d.bsys[BS_SBB + col * NBP + row] = sv;
     }
 }
 
@@ -1829,6 +1874,7 @@ void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
     hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6;
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0);
+    if (d.cb) LAUNCH(KC_BORDER, k_cb_assemble, dim3((unsigned)(((size_t)d.n_cb * 36 + 255) / 256)), dim3(256), 0, d);
 }
 
 void launch_finish_local(Launcher &L, const Dev &d) {

@@ -186,6 +186,10 @@ struct Dev {
     double *dlm;                                    // 6*Lpad landmark step (local coordinates)
     // free shared blocks = dense border of the reduced system (nb columns; offsets, -1 = constant)
     int nb, b_light, b_phong, b_tex;
+    // closure border (stereo problems with a loop closure): the last nfree - nchain free poses are border columns
+    // (6 each) of the block-tridiagonal system instead of chain rows; cb_* = the slab contributions of their blocks
+    int cb, nchain, n_cb;
+    const uint32_t *cb_a, *cb_b, *cb_start, *cb_contrib;
     const uint32_t *pose_mat_start;                 // P*(M+1): pose_obs_ref is sorted by material inside a pose
     double *lmV, *lmH, *lmG;                        // per landmark: H_lb 42, H_bb 28, g_b 7 (component-major)
     double *part_b;                                 // n_lm_blocks * M * NBV

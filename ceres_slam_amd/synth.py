@@ -237,26 +237,44 @@ def make_problem(num_poses: int, num_points: int, *, track_len: int = 12, seed: 
         outlier_mask=outlier_mask)
 
 
+def _in_view(cam, q, min_depth: float = 2.0):
+    """Points (camera frame) in front of the camera and inside the image."""
+    z = np.where(q[:, 2] > min_depth, q[:, 2], np.inf)
+    u, v = cam["fu"] * q[:, 0] / z + cam["cu"], cam["fv"] * q[:, 1] / z + cam["cv"]
+    return (q[:, 2] > min_depth) & (u >= 0) & (u < IMAGE_W) & (v >= 0) & (v < IMAGE_H)
+
+
 def add_loop_closure(prob: StereoBAProblem, num_states: int = 3, num_landmarks: int = 60, seed: int = 2,
-                     sigma: float = 0.5) -> StereoBAProblem:
+                     sigma: float = 0.5, max_track: int | None = None) -> StereoBAProblem:
     """Copy of `prob` in which landmarks first seen from the first three states are observed again from the last
     `num_states` states (they pass through the ground-truth poses, so the problem stays consistent): the pose
-    co-visibility is no longer banded, which is what a loop closure does to the reduced camera system."""
+    co-visibility is no longer banded, which is what a loop closure does to the reduced camera system.  `max_track`
+    keeps the re-observed landmarks within that many observations (12: the windowed layout still holds them, and the
+    library carries the closing states as a border of the block-tridiagonal system instead of taking the general path)."""
     import copy
     rng = np.random.default_rng(seed)
     P = prob.num_poses
     seen_first = np.zeros(prob.num_points, bool)
     seen_first[prob.obs_point[prob.obs_pose < 3]] = True
+    if max_track is not None:       # only landmarks whose track stays within max_track observations after the closure
+        seen_first &= np.bincount(prob.obs_point, minlength=prob.num_points) + num_states <= max_track
     first = np.flatnonzero(seen_first)[:num_landmarks]
     k_new, j_new, uvd_new = [], [], []
-    for k in range(P - num_states, P):
+    k_end = P
+    if max_track is not None:       # close the loop from the latest states that still have those landmarks in front of them
+        for k in range(P - 1, 15 + num_states, -1):
+            t, R = prob.poses_gt[k, :3], prob.poses_gt[k, 3:].reshape(3, 3)
+            if int(_in_view(prob.camera, prob.points_gt[first] @ R.T + t).sum()) >= max(8, len(first) // 8):
+                k_end = k + 1
+                break
+    for k in range(k_end - num_states, k_end):
         already = set(prob.obs_point[prob.obs_pose == k].tolist())
         cand = np.asarray([j for j in first if j not in already], dtype=np.int64)
         if cand.size == 0:
             continue
         t, R = prob.poses_gt[k, :3], prob.poses_gt[k, 3:].reshape(3, 3)
         q = prob.points_gt[cand] @ R.T + t
-        ok = q[:, 2] > 0.5
+        ok = q[:, 2] > 0.5 if max_track is None else _in_view(prob.camera, q)
         uvd = project(prob.camera, q[ok]) + rng.normal(size=(int(ok.sum()), 3)) * sigma
         uvd[:, 2] = np.maximum(uvd[:, 2], 0.25)
         k_new += [k] * int(ok.sum())

@@ -600,6 +600,7 @@ typedef struct {
     int64_t *pt_start;   /* L+1 CSR (landmark-major)                              */
     int64_t *pt_obs;     /* N                                                     */
     int bw_poses;        /* max |free_idx(a)-free_idx(b)| over co-observing poses */
+    int *lo_pose;        /* nfree: lowest free index coupled to this free pose (<= itself): row profile of S */
     /* free shared blocks ("border"): column offsets in the local border vector, -1 = constant */
     int M, nb, b_light, b_phong, b_tex;
     int *pf_start, *pf_list;   /* P+1 CSR over the unary pose factors */
@@ -616,7 +617,7 @@ static int bcol(const graph_t *g, uint32_t mat, int q) {
 static void graph_free(graph_t *g) {
     free(g->free_idx); free(g->free_pose); free(g->pt_active);
     free(g->pose_start); free(g->pose_obs); free(g->pt_start); free(g->pt_obs);
-    free(g->pf_start); free(g->pf_list);
+    free(g->pf_start); free(g->pf_list); free(g->lo_pose);
 }
 
 static void graph_build(const orc_problem *p, graph_t *g) {
@@ -672,6 +673,8 @@ static void graph_build(const orc_problem *p, graph_t *g) {
         else g->free_idx[k] = -1;
     }
     g->nfree = nf;
+    g->lo_pose = malloc((size_t)(nf > 0 ? nf : 1) * sizeof(int));
+    for (int f = 0; f < nf; ++f) g->lo_pose[f] = f;
     int bw = 0;
     for (int j = 0; j < L; ++j) {
         g->pt_active[j] = g->pt_start[j + 1] > g->pt_start[j];
@@ -683,11 +686,19 @@ static void graph_build(const orc_problem *p, graph_t *g) {
             if (f > hi) hi = f;
         }
         if (hi >= 0 && hi - lo > bw) bw = hi - lo;
+        for (int64_t e = g->pt_start[j]; e < g->pt_start[j + 1]; ++e) {
+            int f = g->free_idx[p->obs_pose[g->pt_obs[e]]];
+            if (f >= 0 && lo < g->lo_pose[f]) g->lo_pose[f] = lo;
+        }
     }
     for (uint32_t f = 0; f < p->num_pose_factors; ++f)      /* relative-pose blocks couple their two poses */
         if (p->pf_type[f] == 2) {
             const int fa = g->free_idx[p->pf_pose[f]], fb = g->free_idx[(int)p->pf_data[18 * (size_t)f + 12]];
             if (fa >= 0 && fb >= 0 && abs(fa - fb) > bw) bw = abs(fa - fb);
+            if (fa >= 0 && fb >= 0) {
+                const int hi = fa > fb ? fa : fb, lo = fa > fb ? fb : fa;
+                if (lo < g->lo_pose[hi]) g->lo_pose[hi] = lo;
+            }
         }
     g->bw_poses = bw;
 }
@@ -728,46 +739,78 @@ static int inv_spd(int n, const double *C, double *Ci) {
     return 0;
 }
 
-/* banded Cholesky, lower band storage A[i*(bw+1) + (j-i+bw)], j in [i-bw, i] */
-static int band_cholesky(double *A, int n, int bw) {
-    const int ld = bw + 1;
-    for (int j = 0; j < n; ++j) {
-        double d = A[(size_t)j * ld + bw];
-        int k0 = j - bw < 0 ? 0 : j - bw;
-        for (int k = k0; k < j; ++k) {
-            double l = A[(size_t)j * ld + (k - j + bw)];
-            d -= l * l;
-        }
-        if (!(d > 0.0) || !isfinite(d)) return -1;
-        d = sqrt(d);
-        A[(size_t)j * ld + bw] = d;
-        int iend = j + bw < n - 1 ? j + bw : n - 1;
-#pragma omp parallel for schedule(static) if (iend - j > 256)
-        for (int i = j + 1; i <= iend; ++i) {
-            double s = A[(size_t)i * ld + (j - i + bw)];
-            int kk0 = i - bw < 0 ? 0 : i - bw;
-            if (kk0 < k0) kk0 = k0;
-            for (int k = kk0; k < j; ++k)
-                s -= A[(size_t)i * ld + (k - i + bw)] * A[(size_t)j * ld + (k - j + bw)];
-            A[(size_t)i * ld + (j - i + bw)] = s / d;
+/* Profile (envelope) Cholesky.  Row i of the lower triangle is stored from its first structural column first[i] to the
+ * diagonal: entry (i, j) at A[rp[i] + j - first[i]].  Cholesky fill stays inside the profile (George & Liu), so a banded
+ * trajectory costs what a band solver costs, and a loop closure -- a few late poses coupled to the first ones -- only
+ * makes those few rows long instead of widening a band to the whole matrix.  Every entry is ONE sum in ascending k,
+ * the same arithmetic as the band version this replaces (entries of the band outside the profile were exact zeros). */
+typedef struct {
+    int n;
+    int *first;      /* n                                        */
+    size_t *rp;      /* n + 1  row offsets                        */
+    size_t *cp;      /* n + 1  column lists (rows k > i with first[k] <= i), for the backward substitution */
+    int *crow;
+} profile_t;
+
+static void profile_free(profile_t *pr) {
+    free(pr->first); free(pr->rp); free(pr->cp); free(pr->crow);
+    memset(pr, 0, sizeof *pr);
+}
+
+/* first[] given: row offsets and the column lists */
+static void profile_finish(profile_t *pr) {
+    const int n = pr->n;
+    pr->rp = malloc(((size_t)n + 1) * sizeof(size_t));
+    pr->cp = calloc((size_t)n + 2, sizeof(size_t));
+    pr->rp[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        pr->rp[i + 1] = pr->rp[i] + (size_t)(i - pr->first[i] + 1);
+        for (int j = pr->first[i]; j < i; ++j) pr->cp[j + 2]++;
+    }
+    for (int j = 0; j < n; ++j) pr->cp[j + 2] += pr->cp[j + 1];
+    pr->crow = malloc((pr->cp[n + 1] > 0 ? pr->cp[n + 1] : 1) * sizeof(int));
+    for (int i = 0; i < n; ++i)        /* rows ascending: every column list ends up ascending */
+        for (int j = pr->first[i]; j < i; ++j) pr->crow[pr->cp[j + 1]++] = i;
+    /* cp[j + 1] now marks the end of column j's list, i.e. cp[j] .. cp[j + 1] is the list of column j */
+}
+
+static int profile_cholesky(double *A, const profile_t *pr) {
+    const int n = pr->n;
+    for (int i = 0; i < n; ++i) {
+        double *Ai = A + pr->rp[i];
+        const int fi = pr->first[i];
+        for (int j = fi; j <= i; ++j) {
+            const double *Aj = A + pr->rp[j];
+            const int fj = pr->first[j];
+            double s = Ai[j - fi];
+            for (int k = fi > fj ? fi : fj; k < j; ++k) s -= Ai[k - fi] * Aj[k - fj];
+            if (j < i) {
+                Ai[j - fi] = s / Aj[j - fj];
+            } else {
+                if (!(s > 0.0) || !isfinite(s)) return -1;
+                Ai[j - fi] = sqrt(s);
+            }
         }
     }
     return 0;
 }
 
-static void band_solve(const double *A, int n, int bw, double *x) {
-    const int ld = bw + 1;
+static void profile_solve(const double *A, const profile_t *pr, double *x) {
+    const int n = pr->n;
     for (int i = 0; i < n; ++i) {
+        const double *Ai = A + pr->rp[i];
+        const int fi = pr->first[i];
         double s = x[i];
-        int k0 = i - bw < 0 ? 0 : i - bw;
-        for (int k = k0; k < i; ++k) s -= A[(size_t)i * ld + (k - i + bw)] * x[k];
-        x[i] = s / A[(size_t)i * ld + bw];
+        for (int k = fi; k < i; ++k) s -= Ai[k - fi] * x[k];
+        x[i] = s / Ai[i - fi];
     }
     for (int i = n - 1; i >= 0; --i) {
         double s = x[i];
-        int kend = i + bw < n - 1 ? i + bw : n - 1;
-        for (int k = i + 1; k <= kend; ++k) s -= A[(size_t)k * ld + (i - k + bw)] * x[k];
-        x[i] = s / A[(size_t)i * ld + bw];
+        for (size_t q = pr->cp[i]; q < pr->cp[i + 1]; ++q) {
+            const int k = pr->crow[q];
+            s -= A[pr->rp[k] + (size_t)(i - pr->first[k])] * x[k];
+        }
+        x[i] = s / A[pr->rp[i] + (size_t)(i - pr->first[i])];
     }
 }
 
@@ -910,7 +953,8 @@ static void jacobi_scale(const graph_t *g, const lin_t *w, int enabled, double *
 }
 
 typedef struct {
-    double *S;    /* band storage n x (bw+1)                               */
+    double *S;    /* profile storage (profile_t pr): row i from its first column to the diagonal */
+    profile_t pr;
     double *rhs;  /* n                                                     */
     double *Ci;   /* L*LD*LD inverse of damped landmark blocks (scaled)     */
     double *W;    /* N*6*LD  Jp_s^T Jl_s                                    */
@@ -937,8 +981,13 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
     if (bw > n - 1) bw = n - 1;
     if (bw < 0) bw = 0;
     sc->n = n; sc->bw = bw;
-    const int lds = bw + 1;
-    sc->S = calloc((size_t)(n > 0 ? n : 1) * lds, sizeof(double));
+    sc->pr.n = n;
+    sc->pr.first = malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    for (int f = 0; f < nf; ++f)
+        for (int c = 0; c < 6; ++c) sc->pr.first[6 * f + c] = 6 * g->lo_pose[f];
+    profile_finish(&sc->pr);
+#define SIDX(i, j) (sc->pr.rp[(i)] + (size_t)((j) - sc->pr.first[(i)]))
+    sc->S = calloc(sc->pr.rp[n] > 0 ? sc->pr.rp[n] : 1, sizeof(double));
     sc->rhs = calloc((size_t)(n > 0 ? n : 1), sizeof(double));
     sc->Ci = malloc((size_t)(L > 0 ? L : 1) * ld * ld * sizeof(double));
     sc->W = malloc((size_t)(g->N > 0 ? g->N : 1) * 6 * ld * sizeof(double));
@@ -1085,7 +1134,7 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
         }
         for (int c = 0; c < 6; ++c)
             for (int d = 0; d <= c; ++d)
-                sc->S[(size_t)(6 * f + c) * lds + (d - c + bw)] += B[6 * c + d];
+                sc->S[SIDX(6 * f + c, 6 * f + d)] += B[6 * c + d];
         for (int64_t e = g->pose_start[k]; e < g->pose_start[k + 1]; ++e) {
             int64_t i = g->pose_obs[e];
             int j = (int)p->obs_point[i];
@@ -1122,7 +1171,7 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
                     for (int d = 0; d <= dmax; ++d) {
                         double v = 0.0;
                         for (int q = 0; q < ld; ++q) v += Y[ld * c + q] * W2[ld * d + q];
-                        sc->S[(size_t)(6 * f + c) * lds + ((6 * f2 + d) - (6 * f + c) + bw)] -= v;
+                        sc->S[SIDX(6 * f + c, 6 * f2 + d)] -= v;
                     }
                 }
             }
@@ -1142,13 +1191,15 @@ static int build_reduced(const orc_problem *p, const graph_t *g, const lin_t *w,
             for (int d = 0; d < 6; ++d) {
                 double v = 0.0;
                 for (int m = 0; m < 6; ++m) v += Jh[6 * m + c] * Jl2[6 * m + d];
-                sc->S[(size_t)(6 * hi + c) * lds + ((6 * lo + d) - (6 * hi + c) + bw)] += v * sp[6 * hi + c] * sp[6 * lo + d];
+                sc->S[SIDX(6 * hi + c, 6 * lo + d)] += v * sp[6 * hi + c] * sp[6 * lo + d];
             }
     }
     return 0;
 }
 
+#undef SIDX
 static void schur_free(schur_t *sc) {
+    profile_free(&sc->pr);
     free(sc->S); free(sc->rhs); free(sc->Ci); free(sc->W); free(sc->gl_s);
     free(sc->Spb); free(sc->Sbb); free(sc->rhs_b); free(sc->V);
 }
@@ -1249,8 +1300,8 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
     if (t_schur) *t_schur += t1 - t0;
     if (rc) { schur_free(&sc); return -1; }
     if (sc.n > 0) {
-        if (band_cholesky(sc.S, sc.n, sc.bw)) { schur_free(&sc); return -1; }
-        band_solve(sc.S, sc.n, sc.bw, sc.rhs);
+        if (profile_cholesky(sc.S, &sc.pr)) { schur_free(&sc); return -1; }
+        profile_solve(sc.S, &sc.pr, sc.rhs);
     }
     double *yb = calloc((size_t)nb + 1, sizeof(double));
     if (nb) {
@@ -1260,7 +1311,7 @@ static int lm_step(const orc_problem *p, const graph_t *g, const lin_t *w, const
         double *Z = malloc((size_t)(n > 0 ? n : 1) * nb * sizeof(double)), *col = malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
         for (int c = 0; c < nb; ++c) {
             for (int i = 0; i < n; ++i) col[i] = sc.Spb[(size_t)i * nb + c];
-            if (n > 0) band_solve(sc.S, n, sc.bw, col);
+            if (n > 0) profile_solve(sc.S, &sc.pr, col);
             for (int i = 0; i < n; ++i) Z[(size_t)i * nb + c] = col[i];
         }
         double *T = malloc((size_t)nb * nb * sizeof(double));
@@ -1690,14 +1741,13 @@ int orc_reduced_system(const orc_problem *p, double radius, const orc_options *o
         /* un-scale: S_unscaled = diag(1/s) S_s diag(1/s), rhs_unscaled = -(1/s) rhs_s
          * so that S_unscaled * delta = rhs_unscaled (delta = -s .* y).  With free shared blocks the
          * system is the (n + nb) arrowhead [S_pp S_pb; S_pb^T S_bb], leading dimension n + nb. */
-        int n = sc.n, ld = sc.bw + 1, nb = sc.nb, nt = n + nb;
+        int n = sc.n, nb = sc.nb, nt = n + nb;
         for (int i = 0; i < nt; ++i)
             for (int j = 0; j < nt; ++j) S[(size_t)i * nt + j] = 0.0;
         for (int i = 0; i < n; ++i) rhs[i] = -sc.rhs[i] / sp[i];
         for (int i = 0; i < n; ++i) {
-            int j0 = i - sc.bw < 0 ? 0 : i - sc.bw;
-            for (int j = j0; j <= i; ++j) {
-                double v = sc.S[(size_t)i * ld + (j - i + sc.bw)] / (sp[i] * sp[j]);
+            for (int j = sc.pr.first[i]; j <= i; ++j) {
+                double v = sc.S[sc.pr.rp[i] + (size_t)(j - sc.pr.first[i])] / (sp[i] * sp[j]);
                 S[(size_t)i * nt + j] = v;
                 S[(size_t)j * nt + i] = v;
             }

@@ -79,3 +79,19 @@ def test_c4_full_size_single_gpu_and_four_rank_partitioned(tmp_path):
         assert np.abs(np.asarray(r["poses"]) - ba.poses).max() < 1e-7
     for r in res[1:]:
         assert r["poses"] == res[0]["poses"]           # bit for bit across ranks
+
+
+def test_c4_size_loop_closure_on_the_border_path_matches_cpu_oracle():
+    """A loop closure at configs[3]'s size: 10 000 poses / 1 000 000 landmarks, the last states re-observe 300 landmarks
+    of the first ones.  The general path stores the reduced system densely (<= 4 096 poses); here the three closing states
+    ride as an 18-column border of the 834-block chain (plain cyclic-reduction levels + parallel top + multi-right-hand-side
+    sweeps).  The oracle factors the same system with its profile Cholesky (18 long rows)."""
+    K = 8
+    prob = synth.add_loop_closure(synth.make_problem(10000, 1000000, track_len=12, seed=21), num_landmarks=300, max_track=12)
+    ba = StereoBA.from_synth(prob)
+    st = ba.stats()
+    assert st.general_structure == 2 and st.num_superblocks == 834
+    s, log = ba.solve(capi.default_options(max_num_iterations=K, use_nonmonotonic_steps=1))
+    op = orc.OracleProblem.from_synth(prob)
+    s2, log2 = op.solve(orc.driver_options(num_threads=16, max_num_iterations=K))
+    _compare(s, log, s2, log2, ba, op, cost_rtol=1e-7)

@@ -103,15 +103,75 @@ def test_renumbered_states_match_oracle(strategy, huber_a):
         assert np.abs(ba.poses[new_of_old] - ba0.poses).max() < 1e-6
 
 
-def test_loop_closure_observations():
-    """A banded trajectory plus landmarks of the first states seen again from the last ones."""
+@contextmanager
+def _no_closure_border():
+    os.environ["SSBA_NO_CLOSURE_BORDER"] = "1"
+    try:
+        yield
+    finally:
+        del os.environ["SSBA_NO_CLOSURE_BORDER"]
+
+
+@pytest.mark.parametrize("border", [True, False])
+def test_loop_closure_observations(border):
+    """A banded trajectory plus landmarks of the first states seen again from the last ones.  With at most 12
+    observations per landmark the closing states become a border of the block-tridiagonal system (general_structure
+    == 2, windowed kernels); SSBA_NO_CLOSURE_BORDER=1 sends the same problem down the general path."""
     prob = synth.make_problem(40, 1600, track_len=6, seed=9)
     q = synth.add_loop_closure(prob, num_states=3, num_landmarks=60)
     assert q.num_obs > prob.num_obs + 20
-    ba, s, log, op, s2, log2 = _solve_both(q, huber_a=1.345)
+    if border:
+        ba, s, log, op, s2, log2 = _solve_both(q, huber_a=1.345)
+    else:
+        with _no_closure_border():
+            ba, s, log, op, s2, log2 = _solve_both(q, huber_a=1.345)
     st = ba.stats()
-    assert st.general_structure == 1 and st.pose_bandwidth >= 36
+    assert st.general_structure == (2 if border else 1)
+    if not border:
+        assert st.pose_bandwidth >= 36
     _assert_same_solve(ba, s, log, op, s2, log2)
+
+
+@pytest.mark.parametrize("size,pcr_max", [((100, 3000, 8), None), ((100, 3000, 8), "4"), ((300, 6000, 9), None)])
+def test_closure_border_chain_lengths(size, pcr_max):
+    """The closure border on chains of 9 and 25 super-blocks, with the parallel plan and with plain cyclic-reduction
+    levels below it (SSBA_PCR_MAX_BLOCKS): same iterates as the oracle's banded solve of the whole system."""
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=5, pose_sigma=(0.004, 0.001))     # little drift: a closure that fits
+    q = synth.add_loop_closure(prob, num_states=3, num_landmarks=80, max_track=12)
+    if pcr_max:
+        os.environ["SSBA_PCR_MAX_BLOCKS"] = pcr_max
+    try:
+        ba, s, log, op, s2, log2 = _solve_both(q)
+    finally:
+        os.environ.pop("SSBA_PCR_MAX_BLOCKS", None)
+    assert ba.stats().general_structure == 2
+    _assert_same_solve(ba, s, log, op, s2, log2)
+
+
+def test_closure_border_equals_general_path():
+    """Both routes for the same loop closure: chain + border against the blocked Cholesky of the general path."""
+    prob = synth.make_problem(120, 4000, track_len=9, seed=12, pose_sigma=(0.004, 0.001))
+    q = synth.add_loop_closure(prob, num_states=4, num_landmarks=100, max_track=12)
+    opt = capi.default_options(max_num_iterations=15)
+    ba = StereoBA.from_synth(q)
+    s, log = ba.solve(opt)
+    with _no_closure_border():
+        ba2 = StereoBA.from_synth(q)
+        s2, log2 = ba2.solve(opt)
+    assert ba.stats().general_structure == 2 and ba2.stats().general_structure == 1
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-9)
+    assert np.abs(ba.poses - ba2.poses).max() < 1e-7
+
+
+def test_closure_border_rejects_what_it_cannot_do():
+    prob = synth.make_problem(40, 1600, track_len=6, seed=9)
+    q = synth.add_loop_closure(prob, num_states=3, num_landmarks=60)
+    ba = StereoBA.from_synth(q)
+    with pytest.raises(capi.SsbaError):
+        ba.solve(capi.default_options(max_num_iterations=5, trust_region_strategy_type=1))
+    with pytest.raises(capi.SsbaError):
+        ba.pose_covariance(39)
 
 
 def test_constant_states_and_nothing_free_on_the_general_path():

@@ -72,6 +72,11 @@ def main():
     run_case("P600_L60000_track24", lambda: synth.make_problem(600, 60000, track_len=24), args.steps, False)
     # C2: 1000 states on a circle of 1000 x 0.5 m, so the last states see the landmarks of the first ones
     run_case("C2_loop_closure", lambda: synth.add_loop_closure(synth.make_config("C2"), num_landmarks=300), args.steps, False)
+    # the same closure on landmarks that keep <= 12 observations: the closing states ride as a border of the
+    # block-tridiagonal system (general_structure == 2, windowed kernels + ssba_border.hip)
+    run_case("C2_loop_closure_border", lambda: synth.add_loop_closure(synth.make_config("C2"), num_landmarks=300, max_track=12), args.steps, False)
+    run_case("C4_loop_closure_border", lambda: synth.add_loop_closure(synth.make_problem(10000, 1000000, track_len=12, seed=21), num_landmarks=300, max_track=12),
+             args.steps, False)
     run_case("C2_windowed", lambda: synth.make_config("C2"), args.steps, False)
     run_case("C2_forced_dense", lambda: synth.make_config("C2"), args.steps, True)
 
