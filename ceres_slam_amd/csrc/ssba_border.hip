@@ -250,18 +250,41 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
     if (hiRow) { X[(64 + lane) * NBP + c0] = hi0; X[(64 + lane) * NBP + c1] = hi1; }
 }
 
-// partial sums of S_pb^T [Zb | x0] over a slice of pose rows: thread (a, b) of the NBP x NBP result
+// partial sums of S_pb^T [Zb | x0] over a slice of pose rows: thread (a, b) of the NBP x NBP result.  The slice goes
+// through LDS in chunks of GRAM_ROWS rows (bulk loads, all in flight) -- the first version read its two operands from
+// global memory row by row: ~95 dependent round trips per workgroup, 31 us for 0.2 MFLOP.
+constexpr int GRAM_ROWS = 96;
 __global__ __launch_bounds__(1024) void k_border_gram(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
+    __shared__ double sS[GRAM_ROWS * NBP], sZ[GRAM_ROWS * NBP], sx[GRAM_ROWS];
     const int t = threadIdx.x, a = t / NBP, b = t - a * NBP;
     const int rows = d.nf_pad * 6, per = (rows + d.n_gram - 1) / d.n_gram;
     const int r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
     double acc = 0.0, av = 0.0;
-    for (int i = r0; i < r1; ++i) {
-        const double s = d.Spb[(size_t)i * NBP + a];
-        acc += s * d.Zb[(size_t)i * NBP + b];
-        if (b == 0) av += s * d.x0[i];
+    for (int c0 = r0; c0 < r1; c0 += GRAM_ROWS) {
+        const int n = min(GRAM_ROWS, r1 - c0);
+        double vs[3], vz[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = t + q * 1024;
+            vs[q] = e < n * NBP ? d.Spb[(size_t)c0 * NBP + e] : 0.0;
+            vz[q] = e < n * NBP ? d.Zb[(size_t)c0 * NBP + e] : 0.0;
+        }
+        const double xv = t < n ? d.x0[c0 + t] : 0.0;
+        __syncthreads();            // the previous chunk has been consumed
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = t + q * 1024;
+            if (e < GRAM_ROWS * NBP) { sS[e] = vs[q]; sZ[e] = vz[q]; }
+        }
+        if (t < GRAM_ROWS) sx[t] = xv;
+        __syncthreads();
+        for (int i = 0; i < n; ++i) {
+            const double sv = sS[i * NBP + a];
+            acc += sv * sZ[i * NBP + b];
+            if (b == 0) av += sv * sx[i];
+        }
     }
     double *out = d.part_g + (size_t)blockIdx.x * (NBP * NBP + NBP);
     out[t] = acc;
@@ -275,16 +298,31 @@ __global__ __launch_bounds__(1024) void k_border_solve(Dev d) {
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     __shared__ double T[NBP * (NBP + 1)];
     __shared__ double rb[NBP];
-    __shared__ int sBad;
     const int t = threadIdx.x, a = t / NBP, b = t - a * NBP, nb = d.nb;
-    if (t == 0) sBad = 0;
     {
-        double g = 0.0, gt = 0.0;
-        for (int q = 0; q < d.n_gram; ++q) {
-            const double *pg = d.part_g + (size_t)q * (NBP * NBP + NBP);
-            g += pg[a * NBP + b];
-            gt += pg[b * NBP + a];
+        // partial sums in list order, eight loads in flight at a time; the transpose comes from LDS
+        __shared__ double G[NBP * (NBP + 1)];
+        double g = 0.0;
+        for (int q0 = 0; q0 < d.n_gram; q0 += 8) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = q0 + u < d.n_gram ? d.part_g[(size_t)(q0 + u) * (NBP * NBP + NBP) + a * NBP + b] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += x[u];
         }
+        G[a * (NBP + 1) + b] = g;
+        double gv = 0.0;
+        if (b == 0) {
+            for (int q0 = 0; q0 < d.n_gram; q0 += 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = q0 + u < d.n_gram ? d.part_g[(size_t)(q0 + u) * (NBP * NBP + NBP) + NBP * NBP + a] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gv += x[u];
+            }
+        }
+        __syncthreads();
+        const double gt = G[b * (NBP + 1) + a];
         // symmetrised against rounding (only the lower triangle is read below)
         double v = 0.5 * ((d.bsys[BS_SBB + a * NBP + b] - g) + (d.bsys[BS_SBB + b * NBP + a] - gt));
         if (a == b) {
@@ -299,42 +337,49 @@ __global__ __launch_bounds__(1024) void k_border_solve(Dev d) {
             v = 0.0;
         }
         T[a * (NBP + 1) + b] = v;
-        if (b == 0) {
-            double gv = 0.0;
-            for (int q = 0; q < d.n_gram; ++q) gv += d.part_g[(size_t)q * (NBP * NBP + NBP) + NBP * NBP + a];
-            rb[a] = a < nb ? -d.bsys[BS_RHS + a] - gv : 0.0;
-        }
+        if (b == 0) rb[a] = a < nb ? -d.bsys[BS_RHS + a] - gv : 0.0;
     }
     __syncthreads();
     if (t >= 64) return;
-    const int i = t;   // lane = row (lanes >= NBP idle)
+    // One wave, lane = row, the row in REGISTERS: a right-looking Cholesky whose pivot column travels by v_readlane
+    // (the first version kept T in LDS and paid three LDS operations per multiply-add and two fences per column: 88 us
+    // for 32 columns).  Same arithmetic, same order: entry (i, c) loses l_ij l_cj for j ascending.
+    const int i = t & (NBP - 1);   // lanes >= NBP mirror a row and are ignored
+    double row[NBP];
+#pragma unroll
+    for (int c = 0; c < NBP; ++c) row[c] = T[i * (NBP + 1) + c];
+    bool bad = false;
+#pragma unroll
     for (int j = 0; j < NBP; ++j) {
-        const double piv = T[j * (NBP + 1) + j];
-        if (!(piv > 0.0) || !isfinite(piv)) { if (i == 0) sBad = 1; break; }
+        const double piv = bcast(row[j], j);
+        if (!(piv > 0.0) || !isfinite(piv)) bad = true;
         const double rs = 1.0 / sqrt(piv);
-        double lij = 0.0;
-        if (i < NBP && i >= j) { lij = T[i * (NBP + 1) + j] * rs; T[i * (NBP + 1) + j] = lij; }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (i < NBP && i > j)
-            for (int c = j + 1; c <= i; ++c) T[i * (NBP + 1) + c] -= lij * T[c * (NBP + 1) + j];
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const double lij = row[j] * rs;       // meaningful on lanes i >= j
+        row[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < NBP; ++c) row[c] -= lij * bcast(lij, c);      // meaningful on lanes i >= c
     }
-    if (sBad) { if (i == 0) st.step_failed = 1; return; }
+    if (bad) { if (t == 0) st.step_failed = 1; return; }
+    if (t < NBP) {
+#pragma unroll
+        for (int c = 0; c < NBP; ++c) T[i * (NBP + 1) + c] = row[c];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // forward and backward substitution (lane i owns rb[i])
-    double v = i < NBP ? rb[i] : 0.0;
+    double v = t < NBP ? rb[i] : 0.0;
+#pragma unroll
     for (int j = 0; j < NBP; ++j) {
-        const double yj = bcast(v, j) / T[j * (NBP + 1) + j];
-        if (i == j) v = yj;
-        else if (i > j && i < NBP) v -= T[i * (NBP + 1) + j] * yj;
+        const double yj = bcast(v, j) / bcast(row[j], j);
+        if (t == j) v = yj;
+        else if (t > j && t < NBP) v -= row[j] * yj;
     }
     for (int j = NBP - 1; j >= 0; --j) {
         const double xj = bcast(v, j) / T[j * (NBP + 1) + j];
-        if (i == j) v = xj;
-        else if (i < j) v -= T[j * (NBP + 1) + i] * xj;
+        if (t == j) v = xj;
+        else if (t < j) v -= T[j * (NBP + 1) + t] * xj;
     }
-    if (i < NBP) d.bsys[BS_DB + i] = i < nb ? v : 0.0;
+    if (t < NBP) d.bsys[BS_DB + t] = t < nb ? v : 0.0;
 }
 
 // dp = x0 - Zb db
