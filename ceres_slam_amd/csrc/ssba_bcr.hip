@@ -760,44 +760,55 @@ static bool bcr_legacy() {
     return v;
 }
 // coupled: the blocks still have L / U operands (false for the decoupled last step of an unpinned plan)
-static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled) {
+static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false) {
     if (bcr_legacy()) LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(nblocks), dim3(FACT_THREADS), (size_t)FACT_LDS_DOUBLES * sizeof(double), d, lev, top, which);
-    else launch_bcr_factor_mf(L, d, nblocks, lev, top, which, coupled);
+    else launch_bcr_factor_mf(L, d, nblocks, lev, top, which, coupled, ride);
 }
-static void launch_reduce(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which) {
+static void launch_reduce(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false) {
     if (bcr_legacy()) LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(nblocks, ny), dim3(RED_THREADS), (size_t)2 * BD * BD * sizeof(double), d, lev, which);
-    else launch_bcr_reduce_mf(L, d, nblocks, ny, lev, which);
+    else launch_bcr_reduce_mf(L, d, nblocks, ny, lev, which, ride);
+}
+// The border columns (free shared blocks of config 3, closure border) go through the forward part of the solve INSIDE
+// the matrix-core factor / reduce launches -- two more right-hand-side tiles -- instead of a forward + update launch per
+// level afterwards (ssba_border.hip).  SSBA_BORDER_SWEEPS=1 keeps the separate sweeps (A/B, tests).
+bool bcr_border_rides(const Dev &d) {
+    static const bool off = [] { const char *e = getenv("SSBA_BORDER_SWEEPS"); return e && e[0] == '1'; }();
+    return d.nb > 0 && !d.part && !d.dense && !bcr_legacy() && !off;
 }
 
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
+    const bool ride = allow_pcr && bcr_border_rides(d);
     if (!d.part && allow_pcr && d.pcr.level >= 0) {
         // cyclic reduction down to the plan's level, parallel cyclic reduction of what is left (no back-substitution
         // sweep over those levels: log2(n) x (factor + reduce) + one decoupled solve), back-substitution of the rest
         const int k = d.pcr.level, n = d.pcr.n;
+        if (ride)       // (a plan with border columns always starts at level 0: ssba_finalize)
+            hipMemcpyAsync(d.pcr.Bb, d.Spb, (size_t)n * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
         for (int l = 0; l < k; ++l) {
             const int nn = d.lev[l].n;
             launch_factor(L, d, nn / 2, l, 0, 0, true);
             launch_reduce(L, d, (nn + 1) / 2, 2, l, 0);
         }
         for (int q = 0; q < d.pcr.steps; ++q) {
-            launch_factor(L, d, n, q, 0, 2, true);
-            launch_reduce(L, d, n, 2, q, 2);
+            launch_factor(L, d, n, q, 0, 2, true, ride);
+            launch_reduce(L, d, n, 2, q, 2, ride);
         }
-        launch_factor(L, d, n, d.pcr.steps, 1, 2, false);
+        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride);
         LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
         for (int l = k - 1; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
         return;
     }
     if (!d.part) {
+        if (ride) hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
         for (int l = 0; l + 1 < nl; ++l) {
             const int n = d.lev[l].n;
-            launch_factor(L, d, n / 2, l, 0, 0, true);
-            launch_reduce(L, d, (n + 1) / 2, 2, l, 0);
+            launch_factor(L, d, n / 2, l, 0, 0, true, ride);
+            launch_reduce(L, d, (n + 1) / 2, 2, l, 0, ride);
         }
-        launch_factor(L, d, 1, nl - 1, 1, 0, false);
+        launch_factor(L, d, 1, nl - 1, 1, 0, false, ride);
         LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(1), dim3(BS_THREADS), sh_backsub, d, nl - 1, 1, 0);
         for (int l = nl - 2; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);

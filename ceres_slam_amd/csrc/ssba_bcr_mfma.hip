@@ -80,15 +80,18 @@ constexpr int NDT = 5;          // tile rows / column tiles of [D | r | 0]
 constexpr int NRT = 9;          // column tiles of [L | U^T]
 
 struct FactorOps {
-    const double *Dg, *Lg, *Ug, *rin;
-    double *oD, *oYL, *oYU, *orr, *saveU;
+    const double *Dg, *Lg, *Ug, *rin, *Bg;
+    double *oD, *oYL, *oYU, *orr, *saveU, *oYB;
     bool hasL, hasU, trL, trU;
 };
 
 // operands and destinations of one block: mirrors k_bcr_factor (ssba_bcr.hip).  false: this block has nothing to do.
-static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top, int which, int bx, bool copier, FactorOps &o) {
+// ride: the border columns (d.nb > 0: free shared blocks, closure border) go through the factorisation as two more
+// column tiles of the right-hand sides -- yB = G^-1 B, what k_bcrm_fwd (ssba_border.hip) did in a launch of its own
+static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top, int which, int bx, bool copier, bool ride, FactorOps &o) {
     o.trL = o.trU = false;
     o.saveU = nullptr;
+    o.Bg = nullptr; o.oYB = nullptr;
     if (which >= 2) {
         const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
         const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
@@ -117,6 +120,7 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
         o.oYL = o.hasL ? P.YL + so * BD * BD : nullptr;
         o.oYU = o.hasU ? P.YU + so * BD * BD : nullptr;
         o.orr = top ? B.r + (size_t)blk * BD : P.yr + (size_t)blk * BD;
+        if (ride && which == 2) { o.Bg = P.Bb + (size_t)blk * BD * NBP; o.oYB = P.yB + (size_t)blk * BD * NBP; }
     } else {
         const BcrLevel &L = d.lev[lev];
         const int blk = top ? 0 : 2 * bx + 1;
@@ -130,6 +134,7 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
         o.oYL = o.hasL ? L.L + (size_t)blk * BD * BD : nullptr;
         o.oYU = top ? nullptr : L.YU + (size_t)bx * BD * BD;
         o.orr = L.r + (size_t)blk * BD;
+        if (ride) { o.Bg = L.B + (size_t)blk * BD * NBP; o.oYB = L.B + (size_t)blk * BD * NBP; }
     }
     return true;
 }
@@ -172,21 +177,23 @@ struct FactorLds {
     } while (0)
 
 // NRW: column tiles of [L | U^T] per wave (1: three workgroups per block, 2: two, 3: one, 0: none -- blocks without couplings)
+// rlo .. nrt: the column tiles of the right-hand sides [L | U^T | B] this launch carries (0 .. 9 without border columns,
+// 0 .. 11 with them, 9 .. 11 for decoupled blocks with border columns)
 template <int NRW>
-__global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns) {
+__global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt) {
     State &st = *d.st;
     const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested once the operand reads are in flight
     __shared__ FactorLds S;
     FactorOps o;
     int bx, by;
     xcd_map((int)blockIdx.x, nblocks, ns, bx, by);
-    if (!factor_ops(d, lev, top, which, bx, by == 0 && !dead, o)) return;
+    if (!factor_ops(d, lev, top, which, bx, by == 0 && !dead, nrt > NRT, o)) return;
     const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool storeG = by == 0;
     // this workgroup's share of the nine right-hand-side column tiles, dealt to waves 1, 2, 3, 0, 1, ... (wave 0 owns the
     // longest column of [D | r] and two diagonal tiles: it comes last)
-    const int rfirst = (by * NRT) / ns, rcnt = ((by + 1) * NRT) / ns - rfirst;
+    const int rfirst = rlo + (by * (nrt - rlo)) / ns, rcnt = rlo + ((by + 1) * (nrt - rlo)) / ns - rfirst;
     constexpr int NRA = NRW > 0 ? NRW : 1;        // array extents (NRW = 0: the decoupled last step has no right-hand-side tiles)
     int rcol[NRA];
     bool ract[NRA];
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     for (int q = 0; q < NRW; ++q) {
         const int idx = ((w + 3) & 3) + 4 * q;
         rcol[q] = rfirst + idx;
-        ract[q] = idx < rcnt && ((rcol[q] <= 4 && o.hasL) || (rcol[q] >= 4 && o.hasU));
+        ract[q] = idx < rcnt && ((rcol[q] <= 4 && o.hasL) || (rcol[q] >= 4 && rcol[q] < NRT && o.hasU) || (rcol[q] >= NRT && o.Bg));
     }
     const int dj = w == 0 ? 4 : w;          // column tile of [D | r] this wave owns (wave 0 also owns tile (0, 0))
     if (t == 0) { S.bad = 0; S.seqPQ = 0; }
@@ -227,14 +234,20 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
 #pragma unroll
         for (int q = 0; q < NRW; ++q) {
             const int col = 16 * rcol[q] + j;
-            const bool isL = col < BD;
+            const bool isL = col < BD, isB = rcol[q] >= NRT;
             const int cc = isL ? col : col - BD;
             const bool tr = o.trL;                       // trL == trU (ssba_bcr.hip: even blocks of level 0)
             const double *base = isL ? o.Lg : o.Ug;
-            rok[q] = ract[q] && (isL ? o.hasL : o.hasU);
+            rok[q] = ract[q] && (isB || (isL ? o.hasL : o.hasU));
             if (!ract[q]) {
 #pragma unroll
                 for (int k = 0; k < NDT; ++k) rt[q][k] = mf_d4{0.0, 0.0, 0.0, 0.0};
+            } else if (isB) {                            // border columns: BD x NBP, row-major
+                const double *pp = o.Bg + g * NBP + (col - 2 * BD);
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = (k < 4 || qq < 2) ? pp[(16 * k + 4 * qq) * NBP] : 0.0;
             } else if (tr) {
                 const double *pp = base + cc * BD + g;
 #pragma unroll
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
                     for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = 0.0;
             }
             const int col = 16 * rcol[q] + j;
-            if (o.saveU && rok[q] && col >= BD) {
+            if (o.saveU && rok[q] && col >= BD && rcol[q] < NRT) {
                 double *ps = o.saveU + g * BD + col - BD;
 #pragma unroll
                 for (int k = 0; k < NDT; ++k)
@@ -492,6 +505,15 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     for (int q = 0; q < NRW; ++q) {
         if (!ract[q]) continue;
         const int col = 16 * rcol[q] + j;
+        if (rcol[q] >= NRT) {        // yB = G^-1 B
+            double *pb = o.oYB + g * NBP + (col - 2 * BD);
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (k < 4 || qq < 2) pb[(16 * k + 4 * qq) * NBP] = rt[q][k][qq] * rsv[k][qq];
+            continue;
+        }
         double *dst = col < BD ? o.oYL : o.oYU;
         if (!dst) continue;
         double *pp = dst + g * BD + (col < BD ? col : col - BD);
@@ -590,7 +612,12 @@ struct ReduceJob {
     double *dout, *rout;                    // D', r'
     double *out, *outT;                     // -(A0^T A2) and its transpose (either may be null)
     bool sym, cpl;                          // which parts exist (chain ends, pinned blocks)
+    // border columns riding along (null without them):  B' = B - A0(:, :72)^T yB(prev) - A1(:, :72)^T yB(next),
+    // BD x NBP row-major each -- what k_bcrm_upd (ssba_border.hip) did in a launch of its own
+    const double *yb0, *yb1, *bbase;
+    double *bout;
 };
+constexpr int BRS = 40;                     // LDS row stride of a staged yB: two of them fit exactly where A2 sat
 
 #ifdef SSBA_STAMPS
 #define RJ_STAMP(i) do { if (stamp_here && (threadIdx.x & 63) == 0) dbg[2048 + (threadIdx.x >> 6) * 64 + 16 * wg + (i)] = clock64(); } while (0)
@@ -705,6 +732,26 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
     MF_FENCE();
     if (chave[3]) cacc[3] = tn_mma(O1, cacc[3]);
     RJ_STAMP(11);
+    // border columns: their operand reads are issued here and land while the tiles above are stored
+    constexpr int YB_NLD = (BD * NBP / 2 + MF_THREADS - 1) / MF_THREADS;      // 5 double2 per lane and operand
+    double2 yv0[YB_NLD], yv1[YB_NLD];
+    const int bti = min(W >> 1, NDT - 1), btj = W & 1;       // this wave's 16 x 16 tile of the BD x NBP columns (10 tiles)
+    const bool bhave = J.bout != nullptr && W < 2 * NDT;
+    double bb[4];
+    if (J.bout) {
+#pragma unroll
+        for (int q = 0; q < YB_NLD; ++q) {
+            const int e = t + q * MF_THREADS;
+            const bool in = e < BD * NBP / 2;
+            yv0[q] = (J.yb0 && in) ? reinterpret_cast<const double2 *>(J.yb0)[e] : make_double2(0.0, 0.0);
+            yv1[q] = (J.yb1 && in) ? reinterpret_cast<const double2 *>(J.yb1)[e] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rowc = min(16 * bti + 4 * q + g, BD - 1);
+            bb[q] = bhave ? J.bbase[rowc * NBP + 16 * btj + j] : 0.0;
+        }
+    }
     // ---- stores.  The mirror images (lower triangle of D', transposed coupling) go through a per-wave LDS tile so
     //      that they leave as 128-byte row segments too instead of 64 scattered doubles per instruction ----------
     double *scr = lds + RED_OPERAND_DOUBLES + w * (16 * 17);      // a private tile per wave, behind the staged operands
@@ -765,12 +812,49 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
         }
     }
     RJ_STAMP(12);
+    if (J.bout) {
+        double *sY0 = sA2, *sY1 = sA2 + BD * BRS;
+        __syncthreads();            // every wave is through with A2
+#pragma unroll
+        for (int q = 0; q < YB_NLD; ++q) {
+            const int e = t + q * MF_THREADS;
+            if (e >= BD * NBP / 2) continue;
+            const int r = (2 * e) / NBP, c = 2 * e - r * NBP;
+            *reinterpret_cast<double2 *>(sY0 + r * BRS + c) = yv0[q];
+            *reinterpret_cast<double2 *>(sY1 + r * BRS + c) = yv1[q];
+        }
+        __syncthreads();
+        if (bhave) {
+            mf_d4 acc = mf_d4{0.0, 0.0, 0.0, 0.0};
+            const double *pa0 = sA0 + g * RS + 16 * bti + j, *pa1 = sA1 + g * RS + 16 * bti + j;
+            const double *pb0 = sY0 + g * BRS + 16 * btj + j, *pb1 = sY1 + g * BRS + 16 * btj + j;
+            double a[BD / 4], b[BD / 4];
+            if (J.yb0) {
+#pragma unroll
+                for (int k = 0; k < BD / 4; ++k) { a[k] = pa0[4 * k * RS]; b[k] = pb0[4 * k * BRS]; }
+                MF_FENCE();
+#pragma unroll
+                for (int k = 0; k < BD / 4; ++k) acc = mf(a[k], b[k], acc);
+            }
+            if (J.yb1) {
+#pragma unroll
+                for (int k = 0; k < BD / 4; ++k) { a[k] = pa1[4 * k * RS]; b[k] = pb1[4 * k * BRS]; }
+                MF_FENCE();
+#pragma unroll
+                for (int k = 0; k < BD / 4; ++k) acc = mf(a[k], b[k], acc);
+            }
+            const int r0 = 16 * bti + g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + 4 * q < BD) J.bout[(r0 + 4 * q) * NBP + 16 * btj + j] = bb[q] - acc[q];
+        }
+    }
 }
 
 // 1-D grid of xcd_grid(blocks, ny) workgroups, ny = 3 (+ 2 for the coupling to a pinned last block).  Parallel cyclic
 // reduction (which >= 2): D', r' in place, L' (+ its transpose) into the plan's buffers.  Plain levels (which = 0):
 // D', r', L' of the next level.  Same operand rules as k_bcr_reduce (ssba_bcr.hip).
-__global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, int which, int nblocks, int ny) {
+__global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, int which, int nblocks, int ny, int ride) {
     const State &st = *d.st;
     const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested after the operand reads have been issued
     extern __shared__ __align__(16) double lds[];
@@ -779,6 +863,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
     ReduceJob J;
     J.a0 = J.a1 = J.a2 = J.ya0 = J.ya1 = J.dbase = J.rbase = nullptr;
     J.dout = J.rout = J.out = J.outT = nullptr;
+    J.yb0 = J.yb1 = J.bbase = nullptr; J.bout = nullptr;
     J.sym = J.cpl = false;
     int wg = y, nwg = 3;
     if (which >= 2) {
@@ -798,6 +883,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
             J.rbase = J.rout = B.r + (size_t)e * BD;
             J.out = P.Lbuf + (size_t)e * BD * BD;
             J.outT = P.LbufT + (size_t)e * BD * BD;
+            if (ride && which == 2 && J.sym) {
+                if (hasPrev) J.yb0 = P.yB + (size_t)prev * BD * NBP;
+                if (hasNext) J.yb1 = P.yB + (size_t)next * BD * NBP;
+                J.bbase = J.bout = P.Bb + (size_t)e * BD * NBP;
+            }
         } else {
             // e + s is folded and its far side is the pinned last block: that coupling has no transposed twin in the
             // pinned block's own row, so it is computed here (two workgroups)
@@ -847,30 +937,40 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
         // an even-indexed coupling block of the next level is stored transposed
         if ((m & 1) == 0) J.outT = N.L + (size_t)m * BD * BD;
         else J.out = N.L + (size_t)m * BD * BD;
+        if (ride) {
+            if (hasPrev) J.yb0 = L.B + (size_t)(e - 1) * BD * NBP;
+            if (hasNext) J.yb1 = L.B + (size_t)(e + 1) * BD * NBP;
+            J.bbase = L.B + (size_t)e * BD * NBP;
+            J.bout = N.B + (size_t)m * BD * NBP;
+        }
     }
     reduce_job(J, lds, wg, nwg, dead, d.dbg, bx == 5);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
-void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled) {
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride) {
     // workgroups per block: fill the chip when the level is short; blocks without couplings (the decoupled last step)
     // have no right-hand-side tiles to share out
     // Several workgroups per block all read D and r while the first of them writes G and yr: only where those go to
     // buffers of their own (the steps of a parallel plan before its last one).  Plain levels and last steps work in
     // place (G over D, yr over r) and keep one workgroup per block.
+    // ride: two more column tiles (the border columns); a fourth workgroup per block keeps wave 0 of every workgroup
+    // -- the one that owns the pivots -- free of right-hand-side tiles (the factor kernel's LDS lets 3 workgroups share a CU)
     const bool in_place = top || which < 2;
-    const int ns = (!coupled || in_place) ? 1 : nblocks <= 85 ? 3 : nblocks <= 128 ? 2 : 1;
+    const int rlo = (!coupled && ride) ? NRT : 0, nrt = ride ? NRT + 2 : NRT;
+    const int ns = (!coupled || in_place) ? 1 : nblocks <= 85 ? (ride ? 4 : 3) : nblocks <= 128 ? 2 : 1;
+    const int per_wg = (nrt - rlo + ns - 1) / ns;
     const int grid = xcd_grid(nblocks, ns);
-    if (!coupled) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
-    else if (ns == 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
-    else if (ns == 2) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
-    else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns);
+    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
+    else if (per_wg <= 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
+    else if (per_wg <= 7) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
+    else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
 }
 
 // ny_legacy: 2, or 3 with the coupling to a pinned last block (the grid.y of k_bcr_reduce)
-void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy, int lev, int which) {
+void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy, int lev, int which, bool ride) {
     const int ny = ny_legacy == 3 ? 5 : 3;
-    LAUNCH(KC_BCR_REDUCE, k_bcr_reduce_mf, dim3(xcd_grid(nblocks, ny)), dim3(MF_THREADS), (size_t)RED_LDS_DOUBLES * sizeof(double), d, lev, which, nblocks, ny);
+    LAUNCH(KC_BCR_REDUCE, k_bcr_reduce_mf, dim3(xcd_grid(nblocks, ny)), dim3(MF_THREADS), (size_t)RED_LDS_DOUBLES * sizeof(double), d, lev, which, nblocks, ny, ride ? 1 : 0);
 }
 
 int configure_bcr_mf() {

@@ -422,27 +422,34 @@ void launch_bcr_multi_rhs(Launcher &L, const Dev &d) {
 
 // after launch_bcr: x0 = S_pp^-1 (-g_p^) and the level factors are in place
 void launch_border_solve(Launcher &L, const Dev &d) {
+    // rode: launch_bcr has taken the border columns through the forward part already (yB = G^-1 B per block and level
+    // sit where k_bcrm_fwd would have left them); only the backward part is left
+    const bool rode = bcr_border_rides(d);
     if (d.pcr.level >= 0 && d.pcr.keep) {
         // the solve ran the parallel plan: the border columns follow through the kept factors of every step
         const int n = d.pcr.n;
-        hipMemcpyAsync(d.pcr.Bb, d.Spb, (size_t)n * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
-        for (int q = 0; q < d.pcr.steps; ++q) {
-            LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, q, 0, 2);
-            LAUNCH(KC_BORDER, k_bcrm_upd, dim3(n), dim3(UPD_THREADS), SH_UPD, d, q, 2);
+        if (!rode) {
+            hipMemcpyAsync(d.pcr.Bb, d.Spb, (size_t)n * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
+            for (int q = 0; q < d.pcr.steps; ++q) {
+                LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, q, 0, 2);
+                LAUNCH(KC_BORDER, k_bcrm_upd, dim3(n), dim3(UPD_THREADS), SH_UPD, d, q, 2);
+            }
+            LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, d.pcr.steps, 1, 2);
         }
-        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, d.pcr.steps, 1, 2);
         LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(n), dim3(MR_THREADS), SH_BWD, d, 0, 1, 2);
         launch_border_finish(L, d);
         return;
     }
     const int nl = d.n_levels;
-    hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
-    for (int l = 0; l + 1 < nl; ++l) {
-        const int n = d.lev[l].n;
-        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0, 0);
-        LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l, 0);
+    if (!rode) {
+        hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
+        for (int l = 0; l + 1 < nl; ++l) {
+            const int n = d.lev[l].n;
+            LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n / 2), dim3(MR_THREADS), SH_FWD, d, l, 0, 0);
+            LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l, 0);
+        }
+        LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1, 0);
     }
-    LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1, 0);
     LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0);
     for (int l = nl - 2; l >= 0; --l)
         LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0);

@@ -103,13 +103,14 @@ int configure_kernels();
 int configure_schur();
 // matrix-core block factor / reduce of the reduced-camera solve (ssba_bcr_mfma.hip)
 int configure_bcr_mf();
-void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled);
-void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which);
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false);
+void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
 void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false);
 void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false);
+bool bcr_border_rides(const Dev &d);      // the border columns go through the forward part of the solve inside the factor / reduce launches
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true);   // allow_pcr = false keeps the factors of every level (multi-rhs sweeps)
 // partitioned (multi-rank) solve: pack the chain ends into the separator exchange vector; after the exchange:
 // damping + convergence checks, separator BCR, scatter, back-substitution of the chain interior

@@ -35,7 +35,10 @@ extern "C" {
 
 #define SSBA_VERSION 1
 /* longest landmark track (observations of one landmark) of the windowed layout; problems with longer tracks, or
- * with co-observing free poses more than 12 apart, run the general-structure kernels (ssba_stats.general_structure) */
+ * with co-observing free poses more than 12 apart, run the general-structure kernels (ssba_stats.general_structure = 1)
+ * -- except a loop closure whose far side is at most 5 states and whose landmarks keep <= 12 observations: those
+ * states become a border of the block-tridiagonal reduced system and the windowed kernels stay (general_structure = 2;
+ * any number of poses, LM only; SSBA_NO_CLOSURE_BORDER=1 in the environment of ssba_finalize selects the general path) */
 #define SSBA_MAX_TRACK 12
 
 typedef struct ssba_problem ssba_problem;
@@ -219,7 +222,7 @@ typedef struct {
     uint32_t num_reduced_blocks;   /* non-zero 6x6 blocks of S (upper incl. diagonal)   */
     uint32_t pose_bandwidth;       /* max free-pose index distance of co-observers      */
     uint64_t device_bytes;         /* device memory held by the handle                  */
-    uint32_t general_structure;    /* 1: tracks > SSBA_MAX_TRACK or span > 12 poses -> dense reduced system */
+    uint32_t general_structure;    /* 1: tracks > SSBA_MAX_TRACK or span > 12 poses -> dense reduced system; 2: windowed layout + closure border */
     uint32_t pcr_blocks;           /* blocks handed to the parallel cyclic reduction (<= 128), 0 = plain BCR */
 } ssba_stats;
 int ssba_get_stats(ssba_problem *p, ssba_stats *st);
