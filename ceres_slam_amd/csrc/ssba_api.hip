@@ -1228,6 +1228,13 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.pose_mat_start, dense ? dn_pose_mat_start : pose_mat_start));
         if (d.nb) {
             TRY(dzero(p, &d.lmV, (size_t)Lpad * 42)); TRY(dzero(p, &d.lmH, (size_t)Lpad * 28)); TRY(dzero(p, &d.lmG, (size_t)Lpad * 7));
+            const char *e = getenv("SSBA_BORDER_POSE_KERNEL");       // 1: the pose-by-pose kernel k_ph_border_poses (A/B, tests)
+            if (!dense && !(e && e[0] == '1')) {
+                TRY(dzero(p, &d.lmMV, (size_t)Lpad * 42));
+                TRY(dzero(p, &d.Hpb, (size_t)std::max(1, (nfree + SBP - 1) / SBP) * SBP * 6 * NBP));
+                TRY(dzero(p, &d.slabB, (size_t)n_slabs * 72 * NBP));
+                TRY(dzero(p, &d.HpbL, (size_t)P * p->M * 18));
+            }
             TRY(dzero(p, &d.part_b, (size_t)(Lpad / 256 + 1) * d.M * NBV));   // + one row of column sums
             TRY(dzero(p, &d.bsys, (size_t)BS_COUNT));
             d.n_gram = 64;

@@ -249,6 +249,20 @@ __global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
     }
 #pragma unroll
     for (int c = 0; c < 21; ++c) { d.cinv[(size_t)c * d.Lpad + l] = Ci[c]; d.cfac[(size_t)c * d.Lpad + l] = Mf[c]; }
+    if (d.lmMV) {       // M V_j (6 x 7): the border columns of this landmark's rows in the Schur product (k_ph_schur_windows<true>)
+        double V[42];
+#pragma unroll
+        for (int i = 0; i < 42; ++i) V[i] = d.lmV[(size_t)i * d.Lpad + l];
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) {
+                double v = 0.0;
+#pragma unroll
+                for (int b = 0; b <= c; ++b) v += Mf[c * (c + 1) / 2 + b] * V[b * NBQ + q];
+                d.lmMV[(size_t)(c * NBQ + q) * d.Lpad + l] = v;
+            }
+    }
 }
 
 template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
@@ -366,19 +380,77 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_poses(D
 // W_a C^-1 W_b^T = Z_a Z_b^T with Z = W M^T (6 x 6 per (landmark, slot)); Zm[k][col], k = 6*landmark + c, is staged
 // k-major in LDS (96 rows per batch of 16 landmarks, 80 columns: 72 + the gradient column u = M g_l + padding) and
 // S[72 x 73] += Zm^T Zm runs on v_mfma_f64_16x16x4_f64, the 15 upper tiles 4 / 4 / 4 / 3 per wave.
+// W = J_p^T J_l of one observation (6 x 6, [a][c]; the 7 residual rows: stereo 3, intensity 1, normal 3), built part by
+// part so that only one part's Jacobians are alive at a time (the full ObsPh -- 7 x 6 twice -- plus W and Z is more
+// than a wave's registers at two waves per SIMD).  Same products in the same row order as the generic loop over
+// obs_ph_linearize's output.
+static __device__ __forceinline__ void ph_W(const Dev &d, const double *__restrict__ sh, const double *__restrict__ T, const LmIn &x,
+                                            double u, double v, double dd, double inten, const double nobs[3], double W[36]) {
+    {
+        ObsLin s;
+        obs_linearize(d, T, x.p[0], x.p[1], x.p[2], u, v, dd, s);
+        double Jl3[9], Jp3[18];
+        jac_point(s, T, Jl3);
+        jac_pose(s, Jp3);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                W[6 * a + c] = d.pos_const ? 0.0 : Jp3[a] * Jl3[c] + Jp3[6 + a] * Jl3[3 + c] + Jp3[12 + a] * Jl3[6 + c];
+    }
+    {
+        Shared sx;
+        load_shared(d, sh, x.mat, sx);
+        double ri, J19[19];
+        intensity_residual(d.light_type, T, x.p, x.n, sx.ph3, sx.kd, sx.light, inten, d.int_stiff, &ri, J19);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) W[6 * a + c] += d.pos_const ? 0.0 : J19[a] * J19[6 + c];
+#pragma unroll
+            for (int c = 3; c < 6; ++c) W[6 * a + c] = J19[a] * J19[6 + c];
+        }
+    }
+    {
+        double rn[3], Jnp[18], Jnn[9];
+        normal_residual(T, x.n, nobs, d.Sn, rn, Jnp, Jnn);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) W[6 * a + 3 + c] += Jnp[6 * m + a] * Jnn[3 * m + c];
+    }
+}
+
 constexpr int PH_THREADS = 256;
-constexpr int PH_BATCH = 16;      // 192 producer lanes
-constexpr int PH_KB = 6 * PH_BATCH;          // 96 = 24 MFMA steps
-constexpr int PH_RS = 80;
-constexpr int PH_LDS_DOUBLES = PH_KB * PH_RS + PH_BATCH * 28;   // Zm + per-landmark [M(21) | g_l(6) | pad]
+// BORDER (free shared blocks, windowed layout): the pose rows of the border, S_pb = H_pb - sum_j W_j C_j^-1 V_j, ride in
+// the same product.  With C^-1 = M^T M the sum is  sum_j Z_j (M V_j) , i.e. Zm^T [MV]: every k-row (landmark, c) gets 32
+// more columns holding row c of M V_j at the border columns of the landmark's material (zero elsewhere), and the waves
+// accumulate ten more 16 x 16 tiles (72 x 32) per item, stored to slabB and gathered by k_ph_spb_assemble; H_pb comes
+// from k_ph_hpb on linearisation.  This replaces k_ph_border_poses, which re-linearised every observation a fifth time per
+// iteration from one wave per pose (400 us at C3).  The wider k-major matrix costs LDS: batches of 12 landmarks
+// (72 x 112 doubles) keep two workgroups on a CU.
+template <bool BORDER> struct PhSchurCfg {
+    static constexpr int BATCH = BORDER ? 13 : 16;          // 156 / 192 producer lanes
+    static constexpr int KB = (6 * BATCH + 3) / 4 * 4;      // 80 / 96 factor rows (78 used) = 20 / 24 MFMA steps
+    // row stride: 72 + gradient column + padding; BORDER: the border columns start at 74 -- over the padding, whose
+    // content only reaches output entries that are never stored
+    static constexpr int BC0 = 74;
+    static constexpr int RS = BORDER ? BC0 + NBP : 80;
+    static constexpr int LMW = BORDER ? 72 : 28;            // per-landmark staging: M (21) | g_l (6) | pad | M V (42) | material
+    static constexpr int LDS_DOUBLES = KB * RS + BATCH * LMW;
+};
 typedef double ph_d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
+template <bool BORDER> __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
+    typedef PhSchurCfg<BORDER> C;
+    constexpr int PH_BATCH = C::BATCH, PH_KB = C::KB, PH_RS = C::RS, LMW = C::LMW, BC0 = C::BC0;
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     extern __shared__ __align__(16) double ph_lds[];
     double *sZ = ph_lds;                         // [k][col]
-    double *sLM = ph_lds + PH_KB * PH_RS;        // [landmark][M(21) | g_l(6) | pad]
+    double *sLM = ph_lds + PH_KB * PH_RS;        // [landmark][M(21) | g_l(6) | pad | M V (42) | material]
     const int item = blockIdx.x;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
@@ -390,9 +462,19 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
     const int ti2 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj2 = wv == 0 ? 2 : wv == 1 ? 2 : wv == 2 ? 3 : 4;
     const int ti3 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj3 = wv == 0 ? 3 : wv == 1 ? 3 : wv == 2 ? 4 : 4;
     const bool has3 = wv != 3;
-    ph_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    // padding columns 73..79 stay zero for the whole item (column 72 is rewritten every batch)
-    for (int e = t; e < PH_KB * 8; e += PH_THREADS) sZ[(e >> 3) * PH_RS + 72 + (e & 7)] = 0.0;
+    // border tiles n = wv, wv + 4, wv + 8 (< 10): rows of tile n % 5, columns 80 + 16 (n / 5) ..
+    const int bi0 = wv, bi1 = (wv + 4) % 5, bi2 = (wv + 8) % 5;
+    const int bj0 = 5, bj1 = 5 + (wv + 4) / 5, bj2 = 6;
+    const bool hasb2 = wv + 8 < 10;
+    ph_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0, bac0 = acc0, bac1 = acc0, bac2 = acc0;
+    // padding columns 73..79 stay zero for the whole item (column 72 is rewritten every batch); BORDER: the padding is
+    // column 73, the k-rows beyond 6 x BATCH stay zero
+    if (!BORDER) {
+        for (int e = t; e < PH_KB * 8; e += PH_THREADS) sZ[(e >> 3) * PH_RS + 72 + (e & 7)] = 0.0;
+    } else {
+        for (int e = t; e < PH_KB; e += PH_THREADS) sZ[e * PH_RS + 73] = 0.0;
+        for (int e = t; e < (PH_KB - 6 * PH_BATCH) * PH_RS; e += PH_THREADS) sZ[6 * PH_BATCH * PH_RS + e] = 0.0;
+    }
     bool pose_ok = false;
     uint32_t k = 0xFFFFFFFFu;
     if (producer) {
@@ -400,18 +482,26 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
         pose_ok = (k != 0xFFFFFFFFu) && d.pose_free[k] >= 0;
     }
     for (int l0 = lb; l0 < le; l0 += PH_BATCH) {
-        // phase 0: stage M (21) and g_l (6) of the batch
+        // phase 0: stage M (21) and g_l (6) of the batch (+ M V and the material)
         for (int i = t; i < PH_BATCH * 27; i += PH_THREADS) {
             const int c = i / PH_BATCH, j = i - c * PH_BATCH, l = l0 + j;
             double v = 0.0;
             if (l < le) v = c < 21 ? d.cfac[(size_t)c * d.Lpad + l] : d.gl[(size_t)(c - 21) * d.Lpad + l];
-            sLM[j * 28 + c] = v;
+            sLM[j * LMW + c] = v;
+        }
+        if (BORDER) {
+            for (int i = t; i < PH_BATCH * 43; i += PH_THREADS) {
+                const int c = i / PH_BATCH, j = i - c * PH_BATCH, l = l0 + j;
+                double v = 0.0;
+                if (l < le) v = c < 42 ? d.lmMV[(size_t)c * d.Lpad + l] : (double)d.lm_mat[l];
+                sLM[j * LMW + 28 + c] = v;
+            }
         }
         __syncthreads();
         // phase 1: W = J_p^T J_l and Z = W M^T per (landmark, slot); u = M g_l per landmark
         if (producer) {
             const int l = l0 + li;
-            const double *Mf = sLM + li * 28;
+            const double *Mf = sLM + li * LMW;
             if (s == 0) {
                 const double *g = Mf + 21;
 #pragma unroll
@@ -422,6 +512,18 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
                     sZ[(li * 6 + c) * PH_RS + 72] = v;
                 }
             }
+            if (BORDER) {       // lane (landmark, s): half s / 6 of the border columns of k-row (landmark, s % 6)
+                const int c = s % 6, h = s / 6;
+                double *row = sZ + (li * 6 + c) * PH_RS + BC0 + 16 * h;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) reinterpret_cast<double2 *>(row)[q] = make_double2(0.0, 0.0);
+                const uint32_t mat = (uint32_t)Mf[28 + 42];
+#pragma unroll
+                for (int q = 0; q < NBQ; ++q) {
+                    const int col = bcol(d, mat, q);
+                    if (col >= 0 && (col >> 4) == h) row[col & 15] = Mf[28 + c * NBQ + q];
+                }
+            }
             double z[36];      // [c][a]
             bool live = false;
             if (l < le && pose_ok && ((d.lm_mask[l] >> s) & 1u)) {
@@ -430,26 +532,17 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
                 load_lm(d, l, x);
                 const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
                 const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-                ObsPh o;
-                obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+                double W[36];
+                ph_W(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, W);
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    double w[6];
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int m = 0; m < 7; ++m) if (jl_nz(m, c)) v += o.Jp[6 * m + a] * o.Jl[6 * m + c];
-                        w[c] = v;
-                    }
+                for (int a = 0; a < 6; ++a)
 #pragma unroll
                     for (int c = 0; c < 6; ++c) {
                         double v = 0.0;
 #pragma unroll
-                        for (int q = 0; q <= c; ++q) v += w[q] * Mf[c * (c + 1) / 2 + q];
+                        for (int q = 0; q <= c; ++q) v += W[6 * a + q] * Mf[c * (c + 1) / 2 + q];
                         z[6 * c + a] = v;
                     }
-                }
             }
             if (!live) {
 #pragma unroll
@@ -463,16 +556,21 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
             }
         }
         __syncthreads();
-        // phase 2: S += Zm^T Zm
+        // phase 2: S += Zm^T Zm  (BORDER: + Zm^T [M V])
         {
             const int kq = lane >> 4, i = lane & 15;
-#pragma unroll 4
+#pragma unroll 2
             for (int ks = 0; ks < PH_KB / 4; ++ks) {
                 const double *zr = sZ + (4 * ks + kq) * PH_RS + i;
                 acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti0], zr[16 * tj0], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti1], zr[16 * tj1], acc1, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti2], zr[16 * tj2], acc2, 0, 0, 0);
                 if (has3) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti3], zr[16 * tj3], acc3, 0, 0, 0);
+                if (BORDER) {
+                    bac0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * bi0], zr[BC0 + 16 * (bj0 - 5)], bac0, 0, 0, 0);
+                    bac1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * bi1], zr[BC0 + 16 * (bj1 - 5)], bac1, 0, 0, 0);
+                    if (hasb2) bac2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * bi2], zr[BC0 + 16 * (bj2 - 5)], bac2, 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -496,6 +594,87 @@ __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
     store_tile(acc1, ti1, tj1);
     store_tile(acc2, ti2, tj2);
     if (has3) store_tile(acc3, ti3, tj3);
+    if (BORDER) {
+        auto store_border = [&](const ph_d4 &acc, int ti, int tj) {
+            const int col = 16 * (tj - 5) + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + (lane >> 4) + 4 * r;
+                if (row < 72) d.slabB[((size_t)item * 72 + row) * NBP + col] = acc[r];
+            }
+        };
+        store_border(bac0, bi0, bj0);
+        store_border(bac1, bi1, bj1);
+        if (hasb2) store_border(bac2, bi2, bj2);
+    }
+}
+
+// On linearisation, windowed layout: H_pb of every free pose = sum over its observations of
+// (intensity row of J_p)^T (x) j_b -- the part of S_pb that does not depend on the trust-region radius.  One wave per
+// (pose, material): the pose's references are sorted by material, so the wave owns four columns of H_pb outright and
+// leaves its share of the three light columns as a partial that k_ph_spb_assemble sums over the materials in order.
+// (One workgroup per pose walking the materials one after the other: 82 us -- a pass has ~170 observations.)
+__global__ __launch_bounds__(64) void k_ph_hpb(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    const int k = blockIdx.x / d.M, m = blockIdx.x - k * d.M, f = d.pose_free[k];
+    if (f < 0) return;
+    const int t = threadIdx.x;
+    const double *T = d.poses + (size_t)k * 12;
+    double acc[42];
+#pragma unroll
+    for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+    const uint32_t b = d.pose_mat_start[(size_t)k * (d.M + 1) + m], e = d.pose_mat_start[(size_t)k * (d.M + 1) + m + 1];
+    Shared sx;
+    load_shared(d, d.sh, (uint32_t)m, sx);
+    for (uint32_t i = b + t; i < e; i += 64) {
+        int l;
+        size_t oi;
+        pose_list_entry<false>(d, i, l, oi);
+        LmIn x;
+        load_lm(d, l, x);
+        double ri, J19[19];
+        intensity_residual(d.light_type, T, x.p, x.n, sx.ph3, sx.kd, sx.light, d.oi[oi], d.int_stiff, &ri, J19);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int q = 0; q < NBQ; ++q) acc[q < 4 ? a * 4 + q : 24 + a * 3 + (q - 4)] += J19[a] * J19[12 + q];
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int i = 0; i < 42; ++i) {
+        const double v = wave_sum(acc[i]);
+        const double v0 = __shfl(v, 0, 64);
+        if (t == i) mine = v0;
+    }
+    if (t < 24) {
+        const int a = t / 4, col = bcol(d, (uint32_t)m, t - a * 4);
+        if (col >= 0) d.Hpb[((size_t)f * 6 + a) * NBP + col] = mine;
+    } else if (t < 42) {
+        d.HpbL[((size_t)k * d.M + m) * 18 + (t - 24)] = mine;
+    }
+}
+
+// S_pb = H_pb - sum over the Schur items of their border tiles (k_ph_schur_windows<true>): one thread per entry, the
+// items of a pose in list order (the prow lists of k_assemble_reduced)
+__global__ __launch_bounds__(256) void k_ph_spb_assemble(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)d.nfree * 6 * NBP) return;
+    const int col = (int)(gid % NBP), row = (int)(gid / NBP), f = row / 6, a = row - 6 * f;
+    double v = d.Hpb[gid];
+    if (d.b_light >= 0 && col >= d.b_light && col < d.b_light + 3) {        // light columns: the materials' partials, in order
+        const size_t base = (size_t)d.free_pose[f] * d.M * 18 + a * 3 + (col - d.b_light);
+        v = 0.0;
+        for (int m = 0; m < d.M; ++m) v += d.HpbL[base + (size_t)m * 18];
+    }
+    if (col < d.nb)
+        for (uint32_t i = d.prow_start[f]; i < d.prow_start[f + 1]; ++i) {
+            const uint32_t cw = d.prow_contrib[i];
+            v -= d.slabB[((size_t)(cw / TW) * 72 + (cw % TW) * 6 + a) * NBP + col];
+        }
+    d.Spb[gid] = v;
 }
 
 template <bool DN> __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
@@ -745,36 +924,37 @@ __global__ __launch_bounds__(64) void k_ph_border_colsum(Dev d) {
     if (lane == 0) d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx] = a;
 }
 
-// scatters the summed partials into the border system (one block)
-__global__ __launch_bounds__(256) void k_ph_border_reduce(Dev d) {
+// scatters the summed partials into the border system (one block): thread (c, c2) owns entry (c, c2) of S_bb and
+// collects its contributions -- one per material for a material's own columns, all materials for the light columns --
+// in material order (the first version did the whole scatter on one lane: 35 us)
+__global__ __launch_bounds__(1024) void k_ph_border_reduce(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double tot[SSBA_MAX_MATERIALS_DEV * NBV];
     const int t = threadIdx.x;
-    for (int idx = t; idx < d.M * NBV; idx += 256) tot[idx] = d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx];
-    for (int i = t; i < BS_S; i += 256) d.bsys[i] = 0.0;     // Sbb | rhsb | gb | hb
+    for (int idx = t; idx < d.M * NBV; idx += 1024) tot[idx] = d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx];
     __syncthreads();
-    if (t != 0) return;
-    double *S = d.bsys + BS_SBB;
+    const int c = t / NBP, c2 = t - c * NBP;
+    double sv = 0.0, rhs = 0.0, hh = 0.0, gg = 0.0;
     for (int m = 0; m < d.M; ++m) {
         const double *tm = tot + m * NBV;
-        for (int q = 0; q < NBQ; ++q) {
-            const int c = bcol(d, (uint32_t)m, q);
-            if (c < 0) continue;
-            d.bsys[BS_RHS + c] += tm[28 + q];
-            d.bsys[BS_H + c] += tm[35 + q];
-            d.bsys[BS_G + c] += tm[42 + q];
-            for (int q2 = q; q2 < NBQ; ++q2) {
-                const int c2 = bcol(d, (uint32_t)m, q2);
-                if (c2 < 0) continue;
-                const double v = tm[tri7(q, q2)];
-                S[c * NBP + c2] += v;
-                if (c2 != c) S[c2 * NBP + c] += v;
-            }
+        int q = -1, q2 = -1;
+#pragma unroll
+        for (int x = 0; x < NBQ; ++x) {
+            const int cc = bcol(d, (uint32_t)m, x);
+            if (cc == c) q = x;
+            if (cc == c2) q2 = x;
         }
+        if (q >= 0 && q2 >= 0) sv += tm[q <= q2 ? tri7(q, q2) : tri7(q2, q)];
+        if (q >= 0 && c2 == 0) { rhs += tm[28 + q]; hh += tm[35 + q]; gg += tm[42 + q]; }
     }
-    if (st.iteration == 0)
-        for (int c = 0; c < d.nb; ++c) d.bsys[BS_S + c] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(d.bsys[BS_H + c])) : 1.0;
+    d.bsys[BS_SBB + c * NBP + c2] = (c < d.nb && c2 < d.nb) ? sv : 0.0;
+    if (c2 == 0) {
+        d.bsys[BS_RHS + c] = c < d.nb ? rhs : 0.0;
+        d.bsys[BS_H + c] = c < d.nb ? hh : 0.0;
+        d.bsys[BS_G + c] = c < d.nb ? gg : 0.0;
+        if (st.iteration == 0 && c < d.nb) d.bsys[BS_S + c] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(hh)) : 1.0;
+    }
 }
 
 // one block per free pose, every iteration: its six rows of S_pb = H_pb - sum_j Y_j V_j.  The pose's
@@ -1228,6 +1408,7 @@ void launch_ph_linearize(Launcher &L, const Dev &d) {
     LAUNCH(KC_LIN_LM, (d.dense ? k_ph_linearize_landmarks<true> : k_ph_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_LIN_POSE, (d.dense ? k_ph_linearize_poses<true> : k_ph_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
     if (d.nb) LAUNCH(KC_BORDER, (d.dense ? k_ph_border_landmarks<true> : k_ph_border_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+    if (d.lmMV) LAUNCH(KC_BORDER, k_ph_hpb, dim3(d.P * d.M), dim3(64), 0, d);
 }
 // general layout: per observation W = J_p^T J_l (6x6 over the 7 residual rows) and Y = W C^-1, stored for the
 // pair-list Schur kernel of ssba_dense.hip
@@ -1275,18 +1456,21 @@ void launch_ph_dense_wy(Launcher &L, const Dev &d) {
 void launch_ph_dense_border(Launcher &L, const Dev &d) {
     LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
-    LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(1024), 0, d);
     LAUNCH(KC_BORDER, k_ph_border_poses<true>, dim3(d.P), dim3(BP_THREADS), 0, d);
 }
 
 void launch_ph_schur(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SCHUR, k_ph_schur_windows, dim3(d.n_slabs), dim3(PH_THREADS), PH_LDS_DOUBLES * sizeof(double), d);
+    if (d.lmMV) LAUNCH(KC_SCHUR, k_ph_schur_windows<true>, dim3(d.n_slabs), dim3(PH_THREADS), PhSchurCfg<true>::LDS_DOUBLES * sizeof(double), d);
+    else LAUNCH(KC_SCHUR, k_ph_schur_windows<false>, dim3(d.n_slabs), dim3(PH_THREADS), PhSchurCfg<false>::LDS_DOUBLES * sizeof(double), d);
     if (d.nb) {
         LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
-        LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(256), 0, d);
-        LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(BP_THREADS), 0, d);
+        LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(1024), 0, d);
+        // pose rows of the border: from the Schur product's border tiles (windowed layout), or pose by pose
+        if (d.lmMV) LAUNCH(KC_BORDER, k_ph_spb_assemble, dim3((unsigned)(((size_t)d.nfree * 6 * NBP + 255) / 256)), dim3(256), 0, d);
+        else LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(BP_THREADS), 0, d);
     }
 }
 void launch_ph_backsub_eval(Launcher &L, const Dev &d) {
@@ -1315,8 +1499,10 @@ void launch_ph_ls_accept(Launcher &L, const Dev &d) {
     hipLaunchKernelGGL(k_ph_ls_accept, dim3(1), dim3(64), 0, L.stream, d);
 }
 int configure_phong() {
-    return hipFuncSetAttribute((const void *)k_ph_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(PH_LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
+    if (hipFuncSetAttribute((const void *)k_ph_schur_windows<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(PhSchurCfg<false>::LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    return hipFuncSetAttribute((const void *)k_ph_schur_windows<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(PhSchurCfg<true>::LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
 }
 
 }  // namespace ssba

@@ -192,6 +192,10 @@ struct Dev {
     const uint32_t *cb_a, *cb_b, *cb_start, *cb_contrib;
     const uint32_t *pose_mat_start;                 // P*(M+1): pose_obs_ref is sorted by material inside a pose
     double *lmV, *lmH, *lmG;                        // per landmark: H_lb 42, H_bb 28, g_b 7 (component-major)
+    // windowed layout: the pose rows of the border ride in the Schur product (k_ph_schur_windows<true>)
+    double *lmMV;                                   // per landmark M V_j (42, component-major); null: k_ph_border_poses instead
+    double *Hpb, *HpbL;                             // nf_pad*6 x NBP   H_pb (k_ph_hpb, on linearisation); P x M x 18 light-column partials
+    double *slabB;                                  // n_slabs x 72 x NBP   border tiles of the Schur items
     double *part_b;                                 // n_lm_blocks * M * NBV
     double *Spb;                                    // nf_pad*6 x NBP   S_pb (rows of free poses)
     double *Zb;                                     // nf_pad*6 x NBP   S_pp^-1 S_pb
