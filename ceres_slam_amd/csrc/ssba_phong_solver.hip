@@ -14,6 +14,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "ssba_device.h"
 #include "ssba_launch.h"
 #include "ssba_phong_device.h"
@@ -58,6 +60,13 @@ static __device__ __forceinline__ int bcol(const Dev &d, uint32_t mat, int q) {
     if (q < 3) return d.b_phong < 0 ? -1 : d.b_phong + 3 * (int)mat + q;
     if (q == 3) return d.b_tex < 0 ? -1 : d.b_tex + (int)mat;
     return d.b_light < 0 ? -1 : d.b_light + (q - 4);
+}
+
+struct LmIn { double p[3], n[3]; uint32_t mat; };
+static __device__ __forceinline__ void load_lm(const Dev &d, int l, LmIn &x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x.p[c] = d.pts[(size_t)c * d.Lpad + l]; x.n[c] = d.nrm[(size_t)c * d.Lpad + l]; }
+    x.mat = d.lm_mat[l];
 }
 
 // Observation slots of one landmark and where their data sit (lighting kernels).  Windowed layout: the TW slots of
@@ -145,6 +154,57 @@ static __device__ __forceinline__ void obs_ph_linearize(const Dev &d, const doub
     o.half_sq = s.half_rho + 0.5 * (ri * ri + rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2]);
 }
 
+// The same seven residual rows handed out part by part -- stereo rows 0..2, intensity row 3, normal rows 4..6 -- so that a
+// kernel that only folds rows into sums never holds the whole 7 x 6 Jacobians (obs_ph_linearize's ObsPh is 100 doubles;
+// the landmark kernels built on it sat at 330-370 registers, one wave per SIMD).  fn(part, m, r, jp, jl, jb):
+//   part   std::integral_constant<int, 0 / 1 / 2>; the landmark columns of the part's rows that can be non-zero are
+//          [ph_jl_lo(part), ph_jl_hi(part))  (positions for the stereo rows, all six for the intensity row, the normal for
+//          the normal rows)
+//   m, r   row index and residual;  jp: row m of J_p (6 entries, only with want_pose);  jl: row m of J_l (6 entries,
+//          structural zeros filled in, position columns zeroed for constant position blocks);  jb: the seven border
+//          entries of the intensity row, nullptr for the other rows.
+// Returns 1/2 |r|^2 (with the stereo loss applied).
+__host__ __device__ constexpr int ph_jl_lo(int part) { return part == 2 ? 3 : 0; }
+__host__ __device__ constexpr int ph_jl_hi(int part) { return part == 0 ? 3 : 6; }
+template <class F>
+static __device__ __forceinline__ double ph_rows(const Dev &d, const double *__restrict__ sh, const double *__restrict__ T, const LmIn &x,
+                                                 double u, double v, double dd, double inten, const double nobs[3], bool want_pose, F &&fn) {
+    double half_sq;
+    {
+        ObsLin s;
+        obs_linearize(d, T, x.p[0], x.p[1], x.p[2], u, v, dd, s);
+        double Jl3[9], Jp3[18];
+        jac_point(s, T, Jl3);
+        if (want_pose) jac_pose(s, Jp3);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const double jl[6] = {d.pos_const ? 0.0 : Jl3[3 * m], d.pos_const ? 0.0 : Jl3[3 * m + 1], d.pos_const ? 0.0 : Jl3[3 * m + 2], 0.0, 0.0, 0.0};
+            fn(std::integral_constant<int, 0>(), m, s.r[m], Jp3 + 6 * m, jl, (const double *)nullptr);
+        }
+        half_sq = s.half_rho;
+    }
+    {
+        Shared sx;
+        load_shared(d, sh, x.mat, sx);
+        double ri, J19[19];
+        intensity_residual(d.light_type, T, x.p, x.n, sx.ph3, sx.kd, sx.light, inten, d.int_stiff, &ri, J19);
+        const double jl[6] = {d.pos_const ? 0.0 : J19[6], d.pos_const ? 0.0 : J19[7], d.pos_const ? 0.0 : J19[8], J19[9], J19[10], J19[11]};
+        fn(std::integral_constant<int, 1>(), 3, ri, J19, jl, J19 + 12);
+        half_sq += 0.5 * ri * ri;
+    }
+    {
+        double rn[3], Jnp[18], Jnn[9];
+        normal_residual(T, x.n, nobs, d.Sn, rn, Jnp, Jnn);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const double jl[6] = {0.0, 0.0, 0.0, Jnn[3 * m], Jnn[3 * m + 1], Jnn[3 * m + 2]};
+            fn(std::integral_constant<int, 2>(), 4 + m, rn[m], Jnp + 6 * m, jl, (const double *)nullptr);
+        }
+        half_sq += 0.5 * (rn[0] * rn[0] + rn[1] * rn[1] + rn[2] * rn[2]);
+    }
+    return half_sq;
+}
+
 // residuals only (candidate evaluation)
 static __device__ __forceinline__ double obs_ph_cost(const Dev &d, const double *__restrict__ sh, const double *__restrict__ T,
                                                      const double p[3], const double n[3], uint32_t mat, double u, double v,
@@ -219,12 +279,6 @@ static __device__ __forceinline__ void ph_damping(const Dev &d, const State &st,
     }
 }
 
-struct LmIn { double p[3], n[3]; uint32_t mat; };
-static __device__ __forceinline__ void load_lm(const Dev &d, int l, LmIn &x) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { x.p[c] = d.pts[(size_t)c * d.Lpad + l]; x.n[c] = d.nrm[(size_t)c * d.Lpad + l]; }
-    x.mat = d.lm_mat[l];
-}
 
 // ------------------------------------------------------------------ kernels ---
 // One lane per landmark: C^-1 = (H_ll + D^2)^-1 for the current radius; read by the Schur producers
@@ -265,7 +319,7 @@ __global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
     }
 }
 
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_landmarks(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_landmarks(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     __shared__ double sm[4];
@@ -677,7 +731,7 @@ __global__ __launch_bounds__(256) void k_ph_spb_assemble(Dev d) {
     d.Spb[gid] = v;
 }
 
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_backsub_eval(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -710,25 +764,28 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_backsub_eval(Dev 
             if (f < 0 && !d.nb) continue;
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
+            double dp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (f >= 0) {
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                double e = 0.0;
-                if (f >= 0) {
-                    const double *dp = d.x0 + (size_t)f * 6;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) e += o.Jp[6 * m + c] * dp[c];
-                }
-                if (m == 3) {
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) e += o.jb[q] * dbq[q];
-                }
-                er += e * o.r[m];
-                ee += e * e;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (jl_nz(m, c)) tt[c] += o.Jl[6 * m + c] * e;
+                for (int c = 0; c < 6; ++c) dp[c] = d.x0[(size_t)f * 6 + c];
             }
+            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0,
+                    [&](auto part, int, double r, const double *jp, const double *jl, const double *jb) {
+                        constexpr int P = decltype(part)::value;
+                        double e = 0.0;
+                        if (f >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) e += jp[c] * dp[c];
+                        }
+                        if (P == 1) {
+#pragma unroll
+                            for (int q = 0; q < NBQ; ++q) e += jb[q] * dbq[q];
+                        }
+                        er += e * r;
+                        ee += e * e;
+#pragma unroll
+                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) tt[c] += jl[c] * e;
+                    });
         }
         double Ci[21];
 #pragma unroll
@@ -1094,7 +1151,7 @@ __global__ void k_ph_dogleg_border(Dev d) {
 
 // per landmark: Gauss-Newton back-substitution, v_l, the landmark parts of the norms and the products
 // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn) over the landmark's observations
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_gn(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double sm[4];
@@ -1125,17 +1182,18 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) 
             if (f < 0) continue;
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
-            const double *dp = d.x0 + (size_t)f * 6;
+            double dp[6];
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                double jd = 0.0;
+            for (int c = 0; c < 6; ++c) dp[c] = d.x0[(size_t)f * 6 + c];
+            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true,
+                    [&](auto part, int, double, const double *jp, const double *jl, const double *) {
+                        constexpr int P = decltype(part)::value;
+                        double jd = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) jd += o.Jp[6 * m + c] * dp[c];
+                        for (int c = 0; c < 6; ++c) jd += jp[c] * dp[c];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) if (jl_nz(m, c)) tt[c] += o.Jl[6 * m + c] * jd;
-            }
+                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) tt[c] += jl[c] * jd;
+                    });
         }
         if (d.nb) {
 #pragma unroll
@@ -1168,24 +1226,27 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) 
             const int f = d.pose_free[k];
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0, o);
+            double vp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, gp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (f >= 0) {
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                double jv = 0.0, jg = 0.0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (jl_nz(m, c)) { jv += o.Jl[6 * m + c] * vl[c]; jg += o.Jl[6 * m + c] * dl[c]; }
-                if (f >= 0) {
-                    const double *vp = d.vp + (size_t)k * 6, *gp = d.x0 + (size_t)f * 6;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) { jv += o.Jp[6 * m + c] * vp[c]; jg += o.Jp[6 * m + c] * gp[c]; }
-                }
-                if (m == 3) {
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) { jv += o.jb[q] * vbq[q]; jg += o.jb[q] * gbq[q]; }
-                }
-                sums[3] += jv * jv; sums[4] += jg * jg; sums[5] += jv * jg;
+                for (int c = 0; c < 6; ++c) { vp[c] = d.vp[(size_t)k * 6 + c]; gp[c] = d.x0[(size_t)f * 6 + c]; }
             }
+            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0,
+                    [&](auto part, int, double, const double *jp, const double *jl, const double *jb) {
+                        constexpr int P = decltype(part)::value;
+                        double jv = 0.0, jg = 0.0;
+#pragma unroll
+                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) { jv += jl[c] * vl[c]; jg += jl[c] * dl[c]; }
+                        if (f >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) { jv += jp[c] * vp[c]; jg += jp[c] * gp[c]; }
+                        }
+                        if (P == 1) {
+#pragma unroll
+                            for (int q = 0; q < NBQ; ++q) { jv += jb[q] * vbq[q]; jg += jb[q] * gbq[q]; }
+                        }
+                        sums[3] += jv * jv; sums[4] += jg * jg; sums[5] += jv * jg;
+                    });
         }
     }
 #pragma unroll
@@ -1201,7 +1262,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_gn(Dev d) 
 }
 
 // per landmark: delta_l = beta * gn + gamma * v, candidate point / normal, model cost change, candidate cost
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_eval(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -1236,24 +1297,27 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_dogleg_eval(Dev d
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
-            ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, u, v, dd, inten, nobs, f >= 0, o);
+            double dp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (f >= 0) {
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                double jd = 0.0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (jl_nz(m, c)) jd += o.Jl[6 * m + c] * dl[c];
-                if (f >= 0) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c)
-                        jd += o.Jp[6 * m + c] * (st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c]);
-                }
-                if (m == 3) {
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) jd += o.jb[q] * dbq[q];
-                }
-                mcc -= jd * (o.r[m] + 0.5 * jd);
+                for (int c = 0; c < 6; ++c) dp[c] = st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c];
             }
+            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, u, v, dd, inten, nobs, f >= 0,
+                    [&](auto part, int, double r, const double *jp, const double *jl, const double *jb) {
+                        constexpr int P = decltype(part)::value;
+                        double jd = 0.0;
+#pragma unroll
+                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) jd += jl[c] * dl[c];
+                        if (f >= 0) {
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) jd += jp[c] * dp[c];
+                        }
+                        if (P == 1) {
+#pragma unroll
+                            for (int q = 0; q < NBQ; ++q) jd += jb[q] * dbq[q];
+                        }
+                        mcc -= jd * (r + 0.5 * jd);
+                    });
             ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, u, v, dd, inten, nobs);
         }
     }
@@ -1283,7 +1347,7 @@ __global__ void k_ls_set_alpha(Dev d, double alpha) {
 
 // per landmark: trial point for st.ls_alpha (candidate poses / shared blocks are already in place),
 // its cost, phi', |dx_l|^2, and the alpha-independent max|delta_l| and g_l . delta_l
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_ls_probe(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
@@ -1320,29 +1384,32 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_probe(Dev d) {
             const int f = d.pose_free[k];
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            ObsPh o;
-            obs_ph_linearize(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi],
-                             nobs, f >= 0, o);
-            cost += o.half_sq;
+            double dp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (f >= 0) {
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                double jd = 0.0;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) if (jl_nz(m, c)) jd += o.Jl[6 * m + c] * dl[c];
-                if (f >= 0) {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        const double dpc = st.opt.strategy ? st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c]
-                                                           : d.x0[(size_t)f * 6 + c];
-                        jd += o.Jp[6 * m + c] * dpc;
-                    }
-                }
-                if (m == 3) {
-#pragma unroll
-                    for (int q = 0; q < NBQ; ++q) jd += o.jb[q] * dbq[q];
-                }
-                dphi += o.r[m] * jd;
+                for (int c = 0; c < 6; ++c)
+                    dp[c] = st.opt.strategy ? st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[(size_t)f * 6 + c];
             }
+            LmIn xt;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { xt.p[c] = np_[c]; xt.n[c] = nn[c]; }
+            xt.mat = x.mat;
+            cost += ph_rows(d, d.cand_sh, d.cand_poses + (size_t)k * 12, xt, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0,
+                            [&](auto part, int, double r, const double *jp, const double *jl, const double *jb) {
+                                constexpr int P = decltype(part)::value;
+                                double jd = 0.0;
+#pragma unroll
+                                for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) jd += jl[c] * dl[c];
+                                if (f >= 0) {
+#pragma unroll
+                                    for (int c = 0; c < 6; ++c) jd += jp[c] * dp[c];
+                                }
+                                if (P == 1) {
+#pragma unroll
+                                    for (int q = 0; q < NBQ; ++q) jd += jb[q] * dbq[q];
+                                }
+                                dphi += r * jd;
+                            });
         }
     }
 #pragma unroll
