@@ -340,22 +340,16 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_land
             const uint32_t k = sl.pose(d, s);
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            ObsPh o;
-            obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, false, o);
-            cost += o.half_sq;
+            cost += ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, false,
+                            [&](auto part, int, double r, const double *, const double *jl, const double *) {
+                                constexpr int P = decltype(part)::value;
 #pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                int q = 0;
+                                for (int a = ph_jl_lo(P); a < ph_jl_hi(P); ++a) {
+                                    g[a] += jl[a] * r;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    if (jl_nz(m, a)) g[a] += o.Jl[6 * m + a] * o.r[m];
-#pragma unroll
-                    for (int b = a; b < 6; ++b) {
-                        if (jl_nz(m, a) && jl_nz(m, b)) h[q] += o.Jl[6 * m + a] * o.Jl[6 * m + b];
-                        ++q;
-                    }
-                }
-            }
+                                    for (int b = a; b < ph_jl_hi(P); ++b) h[tri6(a, b)] += jl[a] * jl[b];
+                                }
+                            });
         }
 #pragma unroll
         for (int c = 0; c < 21; ++c) d.hll[(size_t)c * d.Lpad + l] = h[c];
@@ -403,18 +397,16 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_poses(D
         LmIn x;
         load_lm(d, l, x);
         const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-        ObsPh o;
-        obs_ph_linearize(d, d.sh, T, x.p, x.n, x.mat, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true, o);
+        ph_rows(d, d.sh, T, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true,
+                [&](auto, int, double r, const double *jp, const double *, const double *) {
+                    int n = 0;
 #pragma unroll
-        for (int m = 0; m < 7; ++m) {
-            int n = 0;
+                    for (int a = 0; a < 6; ++a) {
+                        acc[21 + a] += jp[a] * r;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                acc[21 + a] += o.Jp[6 * m + a] * o.r[m];
-#pragma unroll
-                for (int c = a; c < 6; ++c) acc[n++] += o.Jp[6 * m + a] * o.Jp[6 * m + c];
-            }
-        }
+                        for (int c = a; c < 6; ++c) acc[n++] += jp[a] * jp[c];
+                    }
+                });
     }
 #pragma unroll
     for (int i = 0; i < 27; ++i) {
