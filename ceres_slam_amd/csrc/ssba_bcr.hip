@@ -772,8 +772,8 @@ static void launch_reduce(Launcher &L, const Dev &d, int nblocks, int ny, int le
 // the matrix-core factor / reduce launches -- two more right-hand-side tiles -- instead of a forward + update launch per
 // level afterwards (ssba_border.hip).  SSBA_BORDER_SWEEPS=1 keeps the separate sweeps (A/B, tests).
 bool bcr_border_rides(const Dev &d) {
-    static const bool off = [] { const char *e = getenv("SSBA_BORDER_SWEEPS"); return e && e[0] == '1'; }();
-    return d.nb > 0 && !d.part && !d.dense && !bcr_legacy() && !off;
+    const char *e = getenv("SSBA_BORDER_SWEEPS");        // read per call: tests switch it between handles
+    return d.nb > 0 && !d.part && !d.dense && !bcr_legacy() && !(e && e[0] == '1');
 }
 
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {

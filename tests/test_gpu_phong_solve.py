@@ -388,3 +388,33 @@ def test_twelve_materials_with_free_light_and_textures():
     assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
     assert np.abs(ba.poses - op.poses).max() < 1e-6
     assert np.abs(ba.texture - op.texture).max() < 1e-6 and np.abs(ba.light - op.light).max() < 1e-5
+
+
+@pytest.mark.parametrize("switch", ["SSBA_BORDER_POSE_KERNEL", "SSBA_BORDER_SWEEPS", "SSBA_BCR_LEGACY_BORDER"])
+def test_border_routes_agree(switch):
+    """The production route of the free shared blocks -- pose rows of S_pb out of the Schur product's border tiles, border
+    columns riding in the matrix-core factor / reduce launches -- against the first-generation kernels it replaced
+    (pose-by-pose S_pb; separate forward / update sweeps per level), on a chain with the parallel plan and on one with
+    plain cyclic-reduction levels."""
+    import os
+    for size, pcr_max in (((60, 2400), None), ((60, 2400), "2")):
+        prob, ph = synth.make_phong_problem(*size, seed=8)
+        env = {"SSBA_BORDER_POSE_KERNEL": {"SSBA_BORDER_POSE_KERNEL": "1"}, "SSBA_BORDER_SWEEPS": {"SSBA_BORDER_SWEEPS": "1"},
+               "SSBA_BCR_LEGACY_BORDER": {"SSBA_BORDER_POSE_KERNEL": "1", "SSBA_BORDER_SWEEPS": "1"}}[switch]
+        if pcr_max:
+            env = dict(env, SSBA_PCR_MAX_BLOCKS=pcr_max)
+            os.environ["SSBA_PCR_MAX_BLOCKS"] = pcr_max
+        try:
+            ba, _ = _pair(prob, ph, 7)
+            s, log = ba.solve(capi.default_options(max_num_iterations=12, use_nonmonotonic_steps=1))
+            for k, v in env.items():
+                os.environ[k] = v
+            ba2, _ = _pair(prob, ph, 7)
+            s2, log2 = ba2.solve(capi.default_options(max_num_iterations=12, use_nonmonotonic_steps=1))
+        finally:
+            for k in list(env) + ["SSBA_PCR_MAX_BLOCKS"]:
+                os.environ.pop(k, None)
+        assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+        np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-9)
+        assert np.abs(ba.poses - ba2.poses).max() < 1e-8
+        np.testing.assert_allclose(ba.light, ba2.light, rtol=1e-8, atol=1e-10)
