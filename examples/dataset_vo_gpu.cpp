@@ -19,26 +19,52 @@
 // carried over; with --frontend every window recomputes its initial guess from the state the previous window left
 // (compute_initial_guess(k1, k2), then reset_points(); the map file holds the points of the last window), with
 // initial-guess files the points are reset to the supplied guess between windows.
+// --gpus N (full batch only): N processes, one per GPU, each holding the landmarks j with j * N / num_points == rank and
+// all their observations; the reduced camera systems of the shards are summed by ncclAllReduce (RCCL over xGMI) inside
+// libssba.so at every iteration, no host code in the loop (include/ssba.h: ssba_set_distributed, ssba_set_rccl).  The
+// program forks its N - 1 peers itself before anything touches a GPU (rank r sees GPU r through HIP_VISIBLE_DEVICES),
+// rank 0 hands out the RCCL id and collects the map points of the other ranks through pipes, and writes the output.
+// --gpus 1 runs the same path with a communicator of one rank.
 // Output: <dataset>_poses.csv / <dataset>_map.csv at full precision + the brief report.
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cmath>
+#include <cstdint>
 #include <iostream>
 
 #include "ceres_slam_amd/ceres_shim.hpp"
 #include "ceres_slam_amd/dataset_problem.hpp"
 
+// landmark sharding of --gpus N
+static int g_world = 0, g_rank = 0;
+static unsigned char g_rccl_id[SSBA_RCCL_UNIQUE_ID_BYTES];
+static bool owned(ceres_slam::uint j, ceres_slam::uint num_points) {
+    return g_world <= 1 || (int)((uint64_t)j * (uint64_t)g_world / num_points) == g_rank;
+}
+
 // tests/dataset_vo.cpp:22-85
 static bool solveWindow(ceres_slam::DatasetProblem &dataset, ceres_slam::uint k1, ceres_slam::uint k2, double huber) {
-    std::cerr << "Working on interval [" << k1 << "," << k2 << ")" << std::endl;
+    if (g_rank == 0) std::cerr << "Working on interval [" << k1 << "," << k2 << ")" << std::endl;
     ceres::Problem problem;
+    if (g_world > 0) problem.SetDistributed(g_world, g_rank, g_rccl_id);
     // stiffness = Sigma^-1/2 of the (diagonal) observation covariance (:29-32)
     const double *var = dataset.stereo_obs_var.data();
     const double stereo_obs_stiffness[9] = {1.0 / std::sqrt(var[0]), 0, 0, 0, 1.0 / std::sqrt(var[1]), 0, 0, 0, 1.0 / std::sqrt(var[2])};
     ceres::LocalParameterization *se3_perturbation = ceres_slam::SE3Perturbation::Create();
     for (ceres_slam::uint k = k1; k < k2; ++k) {
         bool used = false;
+        if (g_world > 0) {      // a shard: the pose blocks of all states with observations, on every rank, in the same order
+            for (ceres_slam::uint i : dataset.obs_indices_at_state(k)) {
+                const ceres_slam::uint j = dataset.point_ids[i];
+                if (j < dataset.num_points && dataset.initialized_point[j]) { used = true; break; }
+            }
+            if (used) problem.AddParameterBlock(dataset.poses[k].data(), 12);
+        }
         for (ceres_slam::uint i : dataset.obs_indices_at_state(k)) {
             const ceres_slam::uint j = dataset.point_ids[i];
             if (j >= dataset.num_points || !dataset.initialized_point[j]) continue;     // only initialised map points (:45)
+            if (!owned(j, dataset.num_points)) continue;
             ceres::CostFunction *stereo_cost =
                 ceres_slam::StereoReprojectionErrorAutomatic::Create(dataset.camera, dataset.stereo_obs_list[i].data(), stereo_obs_stiffness);
             problem.AddResidualBlock(stereo_cost, huber > 0 ? new ceres::HuberLoss(huber) : NULL, dataset.poses[k].data(),
@@ -57,7 +83,7 @@ static bool solveWindow(ceres_slam::DatasetProblem &dataset, ceres_slam::uint k1
     solver_options.use_nonmonotonic_steps = true;
     ceres::Solver::Summary summary;
     ceres::Solve(solver_options, &problem, &summary);
-    std::cout << summary.BriefReport() << std::endl << std::endl;
+    if (g_rank == 0) std::cout << summary.BriefReport() << std::endl << std::endl;
     if (!summary.message.empty()) std::cerr << summary.message << std::endl;
     return summary.IsSolutionUsable();
 }
@@ -66,15 +92,51 @@ static bool solveWindow(ceres_slam::DatasetProblem &dataset, ceres_slam::uint k1
 int main(int argc, char **argv) {
     const bool use_frontend = argc >= 3 && std::string(argv[2]) == "--frontend";
     if (argc < 4 && !use_frontend) {
-        std::cerr << "usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A] [--window N]\n"
-                     "       dataset_vo_gpu <dataset.csv> --frontend [--huber A] [--window N]" << std::endl;
+        std::cerr << "usage: dataset_vo_gpu <dataset.csv> <init_poses.csv> <init_map.csv> [--huber A] [--window N] [--gpus N]\n"
+                     "       dataset_vo_gpu <dataset.csv> --frontend [--huber A] [--window N] [--gpus N]" << std::endl;
         return EXIT_FAILURE;
     }
     double huber = 0.0;
     ceres_slam::uint window_size = 0;
+    int gpus = 0;
     for (int a = use_frontend ? 3 : 4; a + 1 < argc; ++a) {
         if (std::string(argv[a]) == "--huber") huber = std::atof(argv[a + 1]);
         if (std::string(argv[a]) == "--window") window_size = (ceres_slam::uint)std::atoi(argv[a + 1]);
+        if (std::string(argv[a]) == "--gpus") gpus = std::atoi(argv[a + 1]);
+    }
+    // --gpus N: fork the peers before anything touches a GPU; pipes: id (rank 0 -> r), map points (r -> rank 0)
+    std::vector<int> id_w, pts_r;
+    std::vector<pid_t> peers;
+    int my_id_r = -1, my_pts_w = -1;
+    if (gpus > 0) {
+        if (window_size != 0) { std::cerr << "--gpus: full batch only (one communicator per run)" << std::endl; return EXIT_FAILURE; }
+        g_world = gpus;
+        for (int r = 1; r < gpus; ++r) {
+            int a[2], b[2];
+            if (pipe(a) || pipe(b)) { perror("pipe"); return EXIT_FAILURE; }
+            const pid_t pid = fork();
+            if (pid < 0) { perror("fork"); return EXIT_FAILURE; }
+            if (pid == 0) {     // peer r
+                g_rank = r;
+                close(a[1]); close(b[0]);
+                for (int fd : id_w) close(fd);
+                for (int fd : pts_r) close(fd);
+                id_w.clear(); pts_r.clear(); peers.clear();
+                my_id_r = a[0]; my_pts_w = b[1];
+                break;
+            }
+            close(a[0]); close(b[1]);
+            id_w.push_back(a[1]); pts_r.push_back(b[0]); peers.push_back(pid);
+        }
+        if (gpus > 1) setenv("HIP_VISIBLE_DEVICES", std::to_string(g_rank).c_str(), 1);
+        if (g_rank == 0) {
+            if (ssba_rccl_unique_id(g_rccl_id, sizeof g_rccl_id)) { std::cerr << "ssba_rccl_unique_id: " << ssba_last_error() << std::endl; return EXIT_FAILURE; }
+            for (int fd : id_w)
+                if (write(fd, g_rccl_id, sizeof g_rccl_id) != (ssize_t)sizeof g_rccl_id) { perror("write"); return EXIT_FAILURE; }
+        } else if (read(my_id_r, g_rccl_id, sizeof g_rccl_id) != (ssize_t)sizeof g_rccl_id) {
+            perror("read");
+            return EXIT_FAILURE;
+        }
     }
     const std::string filename(argv[1]);
     ceres_slam::DatasetProblem dataset;
@@ -95,6 +157,38 @@ int main(int argc, char **argv) {
         // reset_points() (:126).  The reference also resets after the LAST window and so writes an empty map file; the
         // points of the last window are kept here
         if (use_frontend && k1 + window_size < dataset.num_states) dataset.reset_points();
+    }
+    if (g_world > 1) {      // the map points live on their ranks: collect them on rank 0
+        struct Rec { uint32_t j; double p[3]; };
+        if (g_rank > 0) {
+            std::vector<Rec> out;
+            for (ceres_slam::uint j = 0; j < dataset.num_points; ++j)
+                if (dataset.initialized_point[j] && owned(j, dataset.num_points))
+                    out.push_back(Rec{(uint32_t)j, {dataset.map_points[j].data()[0], dataset.map_points[j].data()[1], dataset.map_points[j].data()[2]}});
+            const uint64_t n = out.size();
+            bool ok = write(my_pts_w, &n, sizeof n) == (ssize_t)sizeof n;
+            const char *bytes = reinterpret_cast<const char *>(out.data());
+            for (size_t off = 0; ok && off < n * sizeof(Rec);) {
+                const ssize_t w = write(my_pts_w, bytes + off, n * sizeof(Rec) - off);
+                if (w <= 0) ok = false; else off += (size_t)w;
+            }
+            return usable && ok ? EXIT_SUCCESS : EXIT_FAILURE;
+        }
+        for (size_t r = 0; r < pts_r.size(); ++r) {
+            uint64_t n = 0;
+            bool ok = read(pts_r[r], &n, sizeof n) == (ssize_t)sizeof n;
+            std::vector<Rec> in(ok ? n : 0);
+            char *bytes = reinterpret_cast<char *>(in.data());
+            for (size_t off = 0; ok && off < n * sizeof(Rec);) {
+                const ssize_t g = read(pts_r[r], bytes + off, n * sizeof(Rec) - off);
+                if (g <= 0) ok = false; else off += (size_t)g;
+            }
+            for (const Rec &q : in)
+                for (int c = 0; c < 3; ++c) dataset.map_points[q.j].data()[c] = q.p[c];
+            int status = 0;
+            waitpid(peers[r], &status, 0);
+            if (!ok || !WIFEXITED(status) || WEXITSTATUS(status) != 0) usable = false;
+        }
     }
     dataset.write_csv(filename);
     return usable ? EXIT_SUCCESS : EXIT_FAILURE;

@@ -340,6 +340,25 @@ class Problem {
         obs_uvd_.insert(obs_uvd_.end(), s->observation, s->observation + 3);
         owned_costs_.push_back(cost);
     }
+    // Ceres: Problem::AddParameterBlock(values, size, local_parameterization).  Registers a pose block (size 12) or a
+    // point block (size 3) ahead of its residual blocks.  Sharded runs (SetDistributed) need it for the poses: every rank
+    // must hold every pose, in the same order, also where it owns no observation of it.
+    void AddParameterBlock(double *values, int size, LocalParameterization *lp = nullptr) {
+        ++version_;
+        if (size == 12) block_index(pose_index_, pose_blocks_, values);
+        else if (size == 3) block_index(point_index_, point_blocks_, values);
+        else throw std::invalid_argument("ceres_shim: AddParameterBlock takes pose (12) or point (3) blocks");
+        if (lp) SetParameterization(values, lp);
+    }
+    // Extension (not in Ceres): this problem is one shard of a landmark-sharded problem -- rank `rank` of `world_size`
+    // processes, one per GPU; the shards' reduced camera systems are summed by ncclAllReduce inside libssba.so
+    // (ssba_set_distributed + ssba_set_rccl; the 128-byte id comes from ssba_rccl_unique_id on rank 0).  Every rank adds all
+    // pose blocks (AddParameterBlock) and the residual blocks of its own landmarks; Solve is then a collective call.
+    void SetDistributed(int world_size, int rank, const void *rccl_unique_id) {
+        ++version_;
+        dist_world_ = world_size; dist_rank_ = rank;
+        std::memcpy(dist_id_, rccl_unique_id, sizeof dist_id_);
+    }
     void SetParameterization(double *block, LocalParameterization *lp) {
         owned_params_[lp] = 1;
         if (dynamic_cast<ceres_slam::UnitVectorPerturbation *>(lp)) { unit_vector_[block] = 1; return; }   // normals, light direction
@@ -410,6 +429,8 @@ class Problem {
     struct RelFactor { double *pose1, *pose2; double T_ref[12], stiffness[36], huber; };
     std::vector<RelFactor> rel_factors_;
     std::map<double *, uint32_t> pose_index_, point_index_;
+    int dist_world_ = 0, dist_rank_ = 0;
+    unsigned char dist_id_[SSBA_RCCL_UNIQUE_ID_BYTES];
     std::vector<double *> pose_blocks_, point_blocks_;
     std::vector<uint32_t> obs_pose_, obs_point_;
     std::vector<double> obs_uvd_;
@@ -463,6 +484,7 @@ inline const char *shim_prepare(Problem &P, int *rc_out) {
         return where;
     };
     if (rc) return fail("ssba_create");
+    if (P.dist_world_ > 0 && (rc = ssba_set_distributed(h, P.dist_world_, P.dist_rank_))) return fail("ssba_set_distributed");
     if (const char *where = P.lower_core_(h, poses, points, &rc)) return fail(where);
     // ---- lighting terms (tests/dataset_ba_phong.cpp:101-204) -> the config-3 tables of the C ABI ----
     normal_blocks.assign(P.point_blocks_.size(), nullptr);
@@ -553,6 +575,7 @@ inline const char *shim_prepare(Problem &P, int *rc_out) {
         if ((rc = bounds(texture_blocks, SSBA_BLOCK_TEXTURE, 1))) return fail("ssba_set_shared_block_bounds");
     }
     if ((rc = ssba_finalize(h))) return fail("ssba_finalize");
+    if (P.dist_world_ > 0 && (rc = ssba_set_rccl(h, P.dist_id_, sizeof P.dist_id_))) return fail("ssba_set_rccl");
     P.h_version_ = P.version_;
     return nullptr;
 }
@@ -562,7 +585,7 @@ inline const char *shim_prepare(Problem &P, int *rc_out) {
 inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summary *summary) {
     Problem &P = *problem;
     *summary = Solver::Summary();
-    if (P.obs_pose_.empty() && P.pose_factors_.empty() && P.rel_factors_.empty()) {
+    if (P.obs_pose_.empty() && P.pose_factors_.empty() && P.rel_factors_.empty() && P.dist_world_ <= 1) {     // (a shard without blocks still joins the collectives)
         summary->termination_type = CONVERGENCE;
         summary->message = "no residual blocks";
         return;

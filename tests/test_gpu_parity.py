@@ -219,6 +219,26 @@ def test_cpp_driver_through_ceres_shim_matches_oracle(tmp_path):
     assert np.abs(poses - op.poses).max() < 1e-6
 
 
+def test_cpp_driver_with_the_native_rccl_exchange(tmp_path):
+    """examples/dataset_vo_gpu --gpus 1: the sharded code path of the C++ driver (ceres::Problem::SetDistributed ->
+    ssba_set_distributed + ssba_set_rccl, a communicator of one rank, every exchange point an ncclAllReduce enqueued by
+    libssba.so) must reproduce the plain run bit for bit.  More ranks need more GPUs than the test box has; the sharding
+    arithmetic itself is covered by tests/test_sharding.py."""
+    import subprocess
+    from ceres_slam_amd import build
+    exe = build.build_examples()
+    prob = synth.make_problem(12, 150, track_len=6, seed=9)
+    ds, ip, im = synth.write_reference_csv(prob, str(tmp_path / "sim.csv"))
+    r0 = subprocess.run([exe, ds, ip, im], capture_output=True, text=True, timeout=120)
+    assert r0.returncode == 0, r0.stderr
+    poses0 = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
+    r1 = subprocess.run([exe, ds, ip, im, "--gpus", "1"], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stderr
+    report = lambda r: [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")]       # (RCCL prints a banner)
+    assert report(r1) == report(r0) and len(report(r0)) == 1
+    assert np.array_equal(synth.read_pose_csv(str(tmp_path / "sim_poses.csv")), poses0)
+
+
 def test_cpp_driver_sliding_windows(tmp_path):
     """--window N: the reference's loop over windows of N states (tests/dataset_vo.cpp:121-127), one
     problem per window through the shim; the oracle runs the same sequence of sub-problems."""
