@@ -1895,7 +1895,13 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
     hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
     hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
     State *ring = nullptr;
-    if (pool_host_malloc((void **)&ring, 2 * sizeof(State)) != hipSuccess) return SSBA_ERR_HIP;
+    if (pool_host_malloc((void **)&ring, 2 * sizeof(State)) != hipSuccess) {
+        hipEventDestroy(ev[0]);
+        hipEventDestroy(ev[1]);
+        p->began = false;
+        set_error("pinned host allocation failed");
+        return SSBA_ERR_HIP;
+    }
     const long max_enqueue = (long)o->max_num_iterations + 3;
     bool done = false;
     for (long it = 0; it < max_enqueue && !done; ++it) {

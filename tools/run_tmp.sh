@@ -1,3 +1,3 @@
-timeout -k 10 900 python -m pytest tests/test_gpu_phong_solve.py -x -q -m gpu > gpurun_out/t5.log 2>&1; tail -3 gpurun_out/t5.log
-for a in "" "--shared-free 7" "--shared-free 7 --bounds --dogleg 1"; do timeout -k 10 200 python bench.py --config C3 $a --no-cpu-baseline > gpurun_out/b_c3f.json 2>/dev/null; python -c "
-import json; j=json.loads(open('gpurun_out/b_c3f.json').read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step']); k=j['kernel_ms_per_iter']; print({x:k[x] for x in ['k_linearize_landmarks','k_backsub_eval','k_dogleg_gn+k_dogleg_eval','small(control,reductions)']})"; done
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py tests/test_gpu_sun_driver.py -x -q -m gpu > gpurun_out/t1.log 2>&1; tail -3 gpurun_out/t1.log
+timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/b1.json 2> gpurun_out/b1.err; python -c "
+import json; j=json.loads(open('gpurun_out/b1.json').read().strip().splitlines()[-1]); print(j['value'], j['ms_per_step']); print(j['kernel_ms_per_iter'])"
