@@ -173,3 +173,24 @@ def test_dogleg_and_lm_reach_the_same_minimum(c1_problem):
     assert sb.termination_type == 0 and sb.num_iterations < sa.num_iterations
     assert sb.final_cost == pytest.approx(sa.final_cost, rel=1e-5)
     assert np.abs(a.poses - b.poses).max() < 1e-3
+
+
+@pytest.mark.parametrize("radius", [1e4, 3.0])
+def test_loop_closure_step_of_the_profile_solver_matches_sparse_direct_solve(radius):
+    """The oracle's reduced solve is a profile (envelope) Cholesky: banded rows stay short, the rows of a loop closure's
+    closing states reach back to the first columns.  Its LM step on such a problem against the independent numpy / scipy
+    normal-equation solve (no Schur complement, no band assumption), and its reduced system against a dense solve."""
+    prob = synth.make_problem(40, 1200, track_len=6, seed=9)
+    q = synth.add_loop_closure(prob, num_states=3, num_landmarks=60)
+    assert q.num_obs > prob.num_obs + 20
+    op = orc.OracleProblem.from_synth(q)
+    dp, dl, mcc = op.lm_step(radius)
+    ref = _np_ba(q, 0.0)
+    dp2, dl2, mcc2, _, _ = ref.lm_step(q.poses_init, q.points_init, radius)
+    np.testing.assert_allclose(dp, dp2, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dl, dl2, rtol=1e-8, atol=1e-9)
+    assert mcc == pytest.approx(mcc2, rel=1e-9)
+    S, rhs, free_idx = op.reduced_system(radius)
+    assert np.count_nonzero(S[-18:, :18]) > 0          # the closure: last three states coupled to the first ones
+    x = np.linalg.solve(S, rhs).reshape(-1, 6)
+    np.testing.assert_allclose(dp[free_idx >= 0], x, rtol=1e-8, atol=1e-11)
