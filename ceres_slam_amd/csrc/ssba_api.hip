@@ -677,13 +677,9 @@ int ssba_finalize(ssba_problem *p) {
             set_error("lighting terms need a normal and a material for every point, and the light");
             return SSBA_ERR_INVALID_ARGUMENT;
         }
-        // Landmark sharding: the lighting terms of a landmark live on its rank like the stereo terms; what
-        // does not shard yet is the border of FREE shared blocks (its sums over all landmarks would have to ride in the
-        // exchange vector).  Constant light / Phong / texture blocks -- stage 1 of the reference driver -- are fine.
-        if (p->world_size > 1 && p->shared_const != 7u) {
-            set_error("landmark sharding with FREE shared lighting blocks is not available yet: hold light, Phong and texture blocks constant");
-            return SSBA_ERR_UNSUPPORTED;
-        }
+        // Landmark sharding: the lighting terms of a landmark live on its rank like the stereo terms.  With
+        // FREE shared blocks the border sums over all landmarks (S_pb, S_bb, reduced border gradient) are exchanged next to
+        // the reduced system (enqueue_front); that exists for the all-reduce mode, not for the partitioned reduced solve.
     }
     if (N >= (1ull << 28) || L >= (1u << 27)) {
         set_error("problem too large for the 32-bit observation references of this build");
@@ -1720,8 +1716,13 @@ static int enqueue_front(ssba_problem *p) {
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if ((rc = X(d.gmax_l, 1, 1))) return rc;
+        if (d.nb) {     // free shared blocks: every rank holds the border sums of ITS landmarks
+            if ((rc = X(d.Spb, (uint64_t)d.nf_pad * 6 * NBP, 0))) return rc;
+            if ((rc = X(d.bsys, (uint64_t)BS_S, 0))) return rc;       // S_bb | reduced gradient | g_b | diag H_bb
+        }
     }
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
+            if (p->xfn && d.nb) launch_border_scale(L, d);      // Jacobi scale of the border from the SUMMED diagonal
             launch_finish_check(L, d, fuse_ctrl, fuse_best);
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d); if (d.nb) launch_border_solve(L, d); }
@@ -1771,8 +1772,8 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         set_error("DOGLEG is not available with a closure border yet; SSBA_NO_CLOSURE_BORDER=1 at ssba_finalize selects the general path");
         return SSBA_ERR_UNSUPPORTED;
     }
-    if (p->d.phong && p->xfn && p->d.nb) {
-        set_error("lighting terms: landmark sharding with free shared blocks is not available yet");
+    if (p->d.phong && p->xfn && p->d.nb && (p->d.constrained || p->d.dense)) {
+        set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
         return SSBA_ERR_UNSUPPORTED;
     }
     if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
@@ -1992,8 +1993,8 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     ssba_options opt;
     if (o) opt = *o; else ssba_default_options(&opt);
     if (radius > 0.0) opt.initial_trust_region_radius = radius;
-    if (p->d.phong && p->xfn && p->d.nb) {
-        set_error("lighting terms: landmark sharding with free shared blocks is not available yet");
+    if (p->d.phong && p->xfn && p->d.nb && (p->d.constrained || p->d.dense)) {
+        set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
         return SSBA_ERR_UNSUPPORTED;
     }
     if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != opt.trust_region_strategy_type)

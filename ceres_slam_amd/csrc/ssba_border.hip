@@ -394,6 +394,16 @@ __global__ __launch_bounds__(256) void k_border_apply(Dev d) {
     d.x0[i] = v;
 }
 
+// sharded problems: the Jacobi scale of the border columns from diag H_bb summed over the ranks (single GPU:
+// k_ph_border_reduce does it where it forms the sums)
+__global__ void k_border_scale(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated || st.iteration != 0) return;
+    const int c = threadIdx.x;
+    if (c < d.nb) d.bsys[BS_S + c] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(d.bsys[BS_H + c])) : 1.0;
+}
+void launch_border_scale(Launcher &L, const Dev &d) { LAUNCH(KC_SMALL, k_border_scale, dim3(1), dim3(64), 0, d); }
+
 static constexpr size_t SH_FWD = (size_t)BD * LDT * sizeof(double);
 static constexpr size_t SH_UPD = (size_t)(2 * BD * BD + 2 * BD * NBP) * sizeof(double);
 static constexpr size_t SH_BWD = (size_t)(2 * BD * LDT + 2 * BD * NBP) * sizeof(double);

@@ -139,6 +139,7 @@ void launch_ph_ls_accept(Launcher &L, const Dev &d);
 int configure_border();
 void launch_border_solve(Launcher &L, const Dev &d);
 void launch_border_finish(Launcher &L, const Dev &d);
+void launch_border_scale(Launcher &L, const Dev &d);
 // lighting terms on the general layout (ssba_phong_solver.hip): C^-1 + per-observation 6x6 W / Y; the border kernels
 void launch_ph_dense_wy(Launcher &L, const Dev &d);
 void launch_ph_dense_border(Launcher &L, const Dev &d);

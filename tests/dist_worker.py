@@ -27,10 +27,13 @@ def main():
     P, Lm, T = [int(v) for v in os.environ.get("SSBA_TEST_SIZE", "16,400,6").split(",")]
     huber_a = float(os.environ.get("SSBA_TEST_HUBER", "0"))      # with it: 30 % outlier observations (BASELINE.json configs[4])
     lighting = None
-    if mode.endswith("_phong"):     # BASELINE.json configs[2] sharded: lighting terms of a landmark live on its rank
-        mode = mode[:-6]
+    shared_free = 0
+    if mode.endswith("_phong") or mode.endswith("_phongfree"):     # BASELINE.json configs[2] sharded: lighting terms of a landmark live on its rank
+        shared_free = 7 if mode.endswith("free") else 0
+        mode = mode[:mode.rindex("_")]
         prob, ph = synth.make_phong_problem(P, Lm, track_len=T, seed=21)
-        lighting = ph.as_oracle_dict("truth")       # shared light / Phong / texture blocks constant
+        # shared light / Phong / texture blocks constant, or free (their border sums ride next to the reduced system)
+        lighting = ph.as_oracle_dict("perturbed" if shared_free else "truth")
     else:
         prob = synth.make_problem(P, Lm, track_len=T, seed=21, outlier_fraction=0.3 if huber_a > 0 else 0.0)
     partition = None
@@ -65,7 +68,8 @@ def main():
             lt = dict(lighting, normals=lighting["normals"][shard.point_ids], material_of_point=lighting["material_of_point"][shard.point_ids],
                       intensity=lighting["intensity"][sel], normal_obs=lighting["normal_obs"][sel])
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
-                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a, lighting=lt)
+                      prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a, lighting=lt,
+                      shared_free=shared_free)
         sharding.attach_torch_exchange(ba, dist)
         s, log = ba.solve(capi.default_options(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1))
         res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
@@ -75,6 +79,9 @@ def main():
                    gmax=log["gradient_max_norm"].tolist(), step_norm=log["step_norm"].tolist())
         if lt is not None:
             res["normals"] = ba.normals.tolist()
+            res["light"] = np.asarray(ba.light).tolist()
+            res["phong"] = np.asarray(ba.phong).tolist()
+            res["texture"] = np.asarray(ba.texture).tolist()
     with open(f"{out}.{rank}.json", "w") as f:
         json.dump(res, f)
     dist.barrier()

@@ -212,3 +212,29 @@ def test_sharded_lighting_terms_match_unsharded_oracle(tmp_path, mode, world):
         assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6
         assert np.abs(np.asarray(r["normals"]) - op.normals[r["point_ids"]]).max() < 1e-6
     assert res[0]["poses"] == res[1]["poses"]
+
+
+@pytest.mark.gpu
+def test_sharded_lighting_terms_with_free_shared_blocks(tmp_path):
+    """The same with the light, Phong and texture blocks FREE: every rank forms the border sums (S_pb, S_bb, reduced border
+    gradient) of its own landmarks, they are summed over the ranks next to the reduced system, and every rank solves the
+    arrowhead system; the shared blocks come out identical on all ranks and equal to the unsharded oracle's."""
+    size, K = (60, 2400, 12), 15
+    res = _run_ranks("gpu_phongfree", str(tmp_path / "phf"), 2, size=size, extra_env={"SSBA_TEST_MAXIT": str(K)})
+    prob, ph = synth.make_phong_problem(size[0], size[1], track_len=size[2], seed=21)
+    d = ph.as_oracle_dict("perturbed")
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7)
+    s2, log2 = op.solve(orc.driver_options(num_threads=2, max_num_iterations=K))
+    for r in res:
+        assert r["num_iterations"] == s2.num_iterations
+        assert r["accept"] == log2["step_is_successful"].tolist()
+        ok = np.asarray(log2["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log2["cost"][ok], rtol=1e-7)
+        assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
+        assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6
+        np.testing.assert_allclose(r["light"], op.light, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(r["phong"], op.phong, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(r["texture"], op.texture, rtol=1e-6)
+    assert res[0]["poses"] == res[1]["poses"] and res[0]["light"] == res[1]["light"]
