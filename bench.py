@@ -214,8 +214,8 @@ def main():
     P1, L1 = synth.CONFIGS["C2" if (phong or robust) else args.config]
     lighting = None
     if phong:
-        if world > 1 and args.shared_free:
-            raise SystemExit("config C3 with FREE shared blocks is single-GPU in this build (constant shared blocks shard)")
+        if world > 1 and args.shared_free and (args.bounds or args.dogleg >= 0):
+            raise SystemExit("config C3 with FREE shared blocks shards with LM and without bounds only")
         prob, ph = synth.make_phong_problem(P1 * world, L1 * world)
         lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
@@ -224,7 +224,8 @@ def main():
     if world > 1:
         # landmark ranges cut at super-block boundaries -> partitioned reduced solve (only the separator system is
         # exchanged); SSBA_NO_PARTITION=1 or an unalignable problem falls back to summing the whole reduced system
-        cut = None if os.environ.get("SSBA_NO_PARTITION") == "1" else sharding.aligned_partition(
+        # (free shared lighting blocks: their border sums are exchanged in the all-reduce mode only)
+        cut = None if os.environ.get("SSBA_NO_PARTITION") == "1" or (phong and args.shared_free) else sharding.aligned_partition(
             prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
         if cut is not None:
             shard = sharding.shard_by_landmarks(prob, world, rank, ranges=cut[0])
