@@ -686,7 +686,7 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 constexpr int BS_THREADS = 512;
 __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int top, int which) {
     const State &st = *d.st;
-    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    const int dead = st.terminated | st.step_failed | st.dl_reuse;      // tested once the staging reads are in flight (a cold read)
     extern __shared__ __align__(16) double lds[];
     double *sG = lds, *sL = lds + BD * BD, *sU = lds + 2 * BD * BD;
     __shared__ double sv[BD], sxm[BD], sxp[BD];
@@ -711,6 +711,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_bcr_backsub(Dev d, int lev, int 
         sxp[t] = hasU ? xb[(size_t)L.pos[iU] * BD + t] : 0.0;
         sv[t] = L.r[(size_t)blk * BD + t];
     }
+    if (dead) return;
     __syncthreads();
     // v = yr - YL x_{i-1} - YU x_{i+1}: 8 waves x 9 rows, lanes stride the row
     for (int r = w * 9; r < w * 9 + 9; ++r) {

@@ -365,8 +365,12 @@ typedef double schur_d4 __attribute__((ext_vector_type(4)));
 // k_assemble_reduced fills next -- a memset launch less per iteration, hidden beside the Schur items.
 __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n_zero) {
     const State &st = *d.st;
-    if (st.terminated || st.dl_reuse) return;
+    // the solver state is written by the previous launch on another XCD: its read is a ~2 us round trip.  It is tested
+    // after the item's first operand reads have been issued, not before (a launch that returns at once measures 4.5 us
+    // against 2.75 us for an empty kernel: that difference sits at the head of every kernel that tests the state first)
+    const int dead = st.terminated | st.dl_reuse;
     if ((int)blockIdx.x < n_zero) {
+        if (dead) return;
         double2 *z = reinterpret_cast<double2 *>(d.xv + d.off_D);
         const size_t n2 = (size_t)d.Nsb * BD * BD;               // 2 x Nsb blocks of BD x BD doubles = n2 double2
         for (size_t i = (size_t)blockIdx.x * SCHUR_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * SCHUR_THREADS) z[i] = make_double2(0.0, 0.0);
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
         }
     };
     prefetch(lb);
+    if (dead) return;
 
     for (int l0 = lb; l0 < le; l0 += SCHUR_BATCH) {
         if (producer) {
@@ -530,7 +535,7 @@ __device__ __forceinline__ int tri21(int r, int c) {   // packed upper index, r 
 // for the padding of the last super-block.
 __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish) {
     const State &st = *d.st;
-    if (st.terminated || st.dl_reuse) return;
+    const int dead = st.terminated | st.dl_reuse;        // tested once the first index reads are in flight (a cold read)
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t n_el = (size_t)d.n_sblk * 36;
     double *D0 = d.xv + d.off_D, *L0 = d.xv + d.off_L;
@@ -539,17 +544,22 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish
         const int e = (int)(gid - (size_t)blk * 36);
         int r = e / 6, c = e - r * 6;
         const uint32_t fa = d.sblk_a[blk], fb = d.sblk_b[blk];
+        const uint32_t ib0 = d.sblk_start[blk], ie0 = d.sblk_start[blk + 1];
+        uint32_t cw0[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cw0[q] = ib0 + q < ie0 ? d.sblk_contrib[ib0 + q] : 0xFFFFFFFFu;
+        if (dead) return;
         int er = r, ec = c;
         if (fa == fb && c > r) { er = c; ec = r; }   // read the lower triangle: exact symmetry
         // contributions in chunks of eight: all indices, then all values in flight, summed in list order (a rolled loop pays
         // two dependent memory round trips per contribution; a block of the band collects ~10 of them)
         double v = 0.0;
-        const uint32_t ib = d.sblk_start[blk], ie = d.sblk_start[blk + 1];
+        const uint32_t ib = ib0, ie = ie0;
         for (uint32_t i0 = ib; i0 < ie; i0 += 8) {
             uint32_t cw[8];
             double x[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) cw[q] = i0 + q < ie ? d.sblk_contrib[i0 + q] : 0xFFFFFFFFu;
+            for (int q = 0; q < 8; ++q) cw[q] = i0 == ib ? cw0[q] : (i0 + q < ie ? d.sblk_contrib[i0 + q] : 0xFFFFFFFFu);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 x[q] = cw[q] != 0xFFFFFFFFu ? d.slab[(size_t)(cw[q] / NPAIR) * SLAB_DOUBLES + (size_t)(cw[q] % NPAIR) * 36 + er * 6 + ec] : 0.0;
@@ -581,6 +591,8 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish
             if ((Ib - (uint32_t)d.chain0) & 1u) L0[(size_t)Ib * BD * BD + (size_t)col * BD + row] = v;
             else L0[(size_t)Ib * BD * BD + (size_t)row * BD + col] = v;
         }
+    } else if (dead) {
+        return;
     } else if (gid < n_el + (size_t)d.nfree * 6) {
         const size_t i = gid - n_el;
         const uint32_t f = (uint32_t)(i / 6);
@@ -856,20 +868,25 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
 // like k_best, before the termination test -- the improving iterate may be the converged one)
 __global__ __launch_bounds__(256) void k_pose_update(Dev d, int fuse_best) {
     const State &st = *d.st;
-    if (fuse_best && st.copy_best == st.check_count) {
-        const int kk = blockIdx.x * 256 + threadIdx.x;
-        if (kk < d.P) {
-#pragma unroll
-            for (int c = 0; c < 12; ++c) d.best_poses[(size_t)kk * 12 + c] = d.poses[(size_t)kk * 12 + c];
-        }
-    }
-    if (st.terminated) return;
     __shared__ double sm[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
+    // operand reads first, the solver state (a cold read: see k_schur_windows) is tested with them in flight
+    double Tk[12];
+    int fk = -1;
+    if (k < d.P) {
+        fk = d.pose_free[k];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) Tk[c] = d.poses[(size_t)k * 12 + c];
+    }
+    if (fuse_best && st.copy_best == st.check_count && k < d.P) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) d.best_poses[(size_t)k * 12 + c] = Tk[c];
+    }
+    if (st.terminated) return;
     double dn = 0.0, nonfinite = 0.0, pf_cc = 0.0, pf_mcc = 0.0;
     if (k < d.P) {
-        const int f = d.pose_free[k];
-        const double *T = d.poses + (size_t)k * 12;
+        const int f = fk;
+        const double *T = Tk;
         double *C = d.cand_poses + (size_t)k * 12;
         if (f >= 0 && !st.step_failed) {
             double eps[6], Tn[12];
@@ -1066,7 +1083,8 @@ __device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts,
     b = block_sum(b, sm);
     pcc = block_sum(pcc, sm);
     pmc = block_sum(pmc, sm);
-    if (threadIdx.x != 0) return;
+    // (the solver state is a cold read at the head of a launch: tested here, with the partial sums already formed)
+    if (threadIdx.x != 0 || st.terminated) return;
     if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_eval_add_pose), summed over ranks
     const Options &o = st.opt;
     const double candidate_cost_raw = d.scal2[0] + pcc;      // + unary pose residual blocks
@@ -1165,8 +1183,7 @@ __device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts,
 }
 __global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts) {
     State &st = *d.st;
-    if (st.terminated) return;
-    decide_body(d, st, n_eval_parts, d.n_pose_blocks);
+    decide_body(d, st, n_eval_parts, d.n_pose_blocks);       // tests st.terminated itself, after its partial sums are read
 }
 
 // The same pass in the window layout with four lanes per landmark (see k_linearize_landmarks_w): wave w takes the slots
@@ -1176,19 +1193,18 @@ __global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts) {
 // fuse_best: also does k_best's share for the points (see k_pose_update)
 __global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
     const State &st = *d.st;
-    if (fuse_best && st.copy_best == st.check_count && threadIdx.x < LMG) {
-        const int lb = blockIdx.x * LMG + threadIdx.x;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) d.best_pts[(size_t)c * d.Lpad + lb] = d.pts[(size_t)c * d.Lpad + lb];
-    }
-    if (st.terminated) return;
     __shared__ double sm[4];
     __shared__ double red[LMW_SPLIT][5][LMG];
     const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
     const int l = blockIdx.x * LMG + li;
+    // operand reads first, the solver state (a cold read: see k_schur_windows) is tested with them in flight
     const uint32_t mask = d.lm_mask[l];
-    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
     const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
+    if (fuse_best && st.copy_best == st.check_count && w == 0) {
+        d.best_pts[l] = px; d.best_pts[(size_t)d.Lpad + l] = py; d.best_pts[2 * (size_t)d.Lpad + l] = pz;
+    }
+    if (st.terminated) return;
+    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
     double nx = px, ny = py, nz = pz;
     const bool act = mask && !st.step_failed;
     const LmObs<false> ob(d, l, mask);
