@@ -761,9 +761,9 @@ static bool bcr_legacy() {
     return v;
 }
 // coupled: the blocks still have L / U operands (false for the decoupled last step of an unpinned plan)
-static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false) {
+static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, bool solve = false) {
     if (bcr_legacy()) LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(nblocks), dim3(FACT_THREADS), (size_t)FACT_LDS_DOUBLES * sizeof(double), d, lev, top, which);
-    else launch_bcr_factor_mf(L, d, nblocks, lev, top, which, coupled, ride);
+    else launch_bcr_factor_mf(L, d, nblocks, lev, top, which, coupled, ride, solve);
 }
 static void launch_reduce(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false) {
     if (bcr_legacy()) LAUNCH(KC_BCR_REDUCE, k_bcr_reduce, dim3(nblocks, ny), dim3(RED_THREADS), (size_t)2 * BD * BD * sizeof(double), d, lev, which);
@@ -796,8 +796,11 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
             launch_factor(L, d, n, q, 0, 2, true, ride);
             launch_reduce(L, d, n, 2, q, 2, ride);
         }
-        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride);
-        LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
+        // the decoupled last step solves its blocks itself (matrix-core kernels, no border columns): no k_bcr_backsub launch
+        const char *nf = getenv("SSBA_NO_FUSED_SOLVE");
+        const bool fsolve = !ride && !bcr_legacy() && !(nf && nf[0] == '1');
+        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride, fsolve);
+        if (!fsolve) LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
         for (int l = k - 1; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
         return;

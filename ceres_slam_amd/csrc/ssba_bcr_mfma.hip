@@ -81,7 +81,7 @@ constexpr int NRT = 9;          // column tiles of [L | U^T]
 
 struct FactorOps {
     const double *Dg, *Lg, *Ug, *rin, *Bg;
-    double *oD, *oYL, *oYU, *orr, *saveU, *oYB;
+    double *oD, *oYL, *oYU, *orr, *saveU, *oYB, *xsol;
     bool hasL, hasU, trL, trU;
 };
 
@@ -91,7 +91,7 @@ struct FactorOps {
 static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top, int which, int bx, bool copier, bool ride, FactorOps &o) {
     o.trL = o.trU = false;
     o.saveU = nullptr;
-    o.Bg = nullptr; o.oYB = nullptr;
+    o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
     if (which >= 2) {
         const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
         const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
@@ -121,6 +121,7 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
         o.oYU = o.hasU ? P.YU + so * BD * BD : nullptr;
         o.orr = top ? B.r + (size_t)blk * BD : P.yr + (size_t)blk * BD;
         if (ride && which == 2) { o.Bg = P.Bb + (size_t)blk * BD * NBP; o.oYB = P.yB + (size_t)blk * BD * NBP; }
+        if (top && which == 2) o.xsol = d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[blk] * BD;        // used by the decoupled launch with `solve`
     } else {
         const BcrLevel &L = d.lev[lev];
         const int blk = top ? 0 : 2 * bx + 1;
@@ -179,8 +180,10 @@ struct FactorLds {
 // NRW: column tiles of [L | U^T] per wave (1: three workgroups per block, 2: two, 3: one, 0: none -- blocks without couplings)
 // rlo .. nrt: the column tiles of the right-hand sides [L | U^T | B] this launch carries (0 .. 9 without border columns,
 // 0 .. 11 with them, 9 .. 11 for decoupled blocks with border columns)
+// solve (decoupled blocks without border columns, NRW = 0): the workgroup also solves  G^T x = yr  -- the block's part of
+// the solution -- from an LDS copy of G, which is what k_bcr_backsub did in a launch of its own.
 template <int NRW>
-__global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt) {
+__global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt, int solve) {
     State &st = *d.st;
     const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested once the operand reads are in flight
     __shared__ FactorLds S;
@@ -523,29 +526,68 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
             for (int qq = 0; qq < 4; ++qq)
                 if (k < 4 || qq < 2) pp[(16 * k + 4 * qq) * BD] = rt[q][k][qq] * rsv[k][qq];
     }
+    extern __shared__ __align__(16) double mf_solve_lds[];        // solve: G (BD x BD) | yr (BD)
+    const bool do_solve = NRW == 0 && solve && o.xsol;
     if (storeG) {
         // G = U^T: column c of U is row c of G; lane (g, j) of tile (k, c) holds U[16 k + 4 q + g][16 c + j]
         auto store_g = [&](const mf_d4 &T, int k, int c, bool diag) {
             const int col = 16 * c + j;
             if (col < BD && o.oD) {
                 double *pp = o.oD + col * BD + g;
+                double *pl = mf_solve_lds + col * BD + g;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     if (!(k < 4 || qq < 2)) continue;
                     const int row = 16 * k + 4 * qq + g;
-                    if (!diag || col >= row) pp[16 * k + 4 * qq] = (diag && col == row) ? rsv[k][qq] : T[qq] * rsv[k][qq];
+                    if (!diag || col >= row) {
+                        const double v = (diag && col == row) ? rsv[k][qq] : T[qq] * rsv[k][qq];
+                        pp[16 * k + 4 * qq] = v;
+                        if (do_solve) pl[16 * k + 4 * qq] = v;
+                    }
                 }
             }
             if (col == BD) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq)
-                    if (k < 4 || qq < 2) o.orr[16 * k + 4 * qq + g] = T[qq] * rsv[k][qq];
+                    if (k < 4 || qq < 2) {
+                        const double v = T[qq] * rsv[k][qq];
+                        o.orr[16 * k + 4 * qq + g] = v;
+                        if (do_solve) mf_solve_lds[BD * BD + 16 * k + 4 * qq + g] = v;
+                    }
             }
         };
 #pragma unroll
         for (int k = 0; k < NDT; ++k)
             if (k <= dj) store_g(dt[k], k, dj, k == dj);
         if (w == 0) store_g(d00, 0, 0, true);
+    }
+    if (do_solve) {
+        // wave 0: G^T x = yr by a column sweep from the bottom (k_bcr_backsub's); the diagonal of G holds 1 / G_kk
+        __syncthreads();
+        if (w == 0) {
+            const double *sG = mf_solve_lds, *sv = mf_solve_lds + BD * BD;
+            auto bc = [](double v, int ln) {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), ln), __builtin_amdgcn_readlane(__double2loint(v), ln));
+            };
+            double lo = sv[lane];
+            double hi = lane < BD - 64 ? sv[64 + lane] : 0.0;
+#pragma unroll
+            for (int k = BD - 1; k >= 64; --k) {
+                const double xk = bc(hi, k - 64) * sG[k * BD + k];
+                const double gl = sG[k * BD + lane];
+                const double gh = (lane < k - 64) ? sG[k * BD + 64 + lane] : 0.0;
+                lo -= gl * xk;
+                hi = (lane == k - 64) ? xk : hi - gh * xk;
+            }
+#pragma unroll
+            for (int k = 63; k >= 0; --k) {
+                const double xk = bc(lo, k) * sG[k * BD + k];
+                const double gl = (lane < k) ? sG[k * BD + lane] : 0.0;
+                lo = (lane == k) ? xk : lo - gl * xk;
+            }
+            o.xsol[lane] = lo;
+            if (lane < BD - 64) o.xsol[64 + lane] = hi;
+        }
     }
     MF_STAMP(31);
 }
@@ -948,7 +990,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
-void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride) {
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride, bool solve) {
     // workgroups per block: fill the chip when the level is short; blocks without couplings (the decoupled last step)
     // have no right-hand-side tiles to share out
     // Several workgroups per block all read D and r while the first of them writes G and yr: only where those go to
@@ -961,10 +1003,11 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
     const int ns = (!coupled || in_place) ? 1 : nblocks <= 85 ? (ride ? 4 : 3) : nblocks <= 128 ? 2 : 1;
     const int per_wg = (nrt - rlo + ns - 1) / ns;
     const int grid = xcd_grid(nblocks, ns);
-    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
-    else if (per_wg <= 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
-    else if (per_wg <= 7) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
-    else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt);
+    const size_t sh_solve = (size_t)(BD * BD + BD) * sizeof(double);
+    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), solve ? sh_solve : 0, d, lev, top, which, nblocks, ns, rlo, nrt, solve ? 1 : 0);
+    else if (per_wg <= 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
+    else if (per_wg <= 7) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
+    else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
 }
 
 // ny_legacy: 2, or 3 with the coupling to a pinned last block (the grid.y of k_bcr_reduce)
@@ -975,6 +1018,7 @@ void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy,
 
 int configure_bcr_mf() {
     if (hipFuncSetAttribute((const void *)k_bcr_reduce_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RED_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BD * BD + BD) * sizeof(double))) != hipSuccess) return -1;
     return 0;
 }
 

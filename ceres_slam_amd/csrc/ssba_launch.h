@@ -103,7 +103,7 @@ int configure_kernels();
 int configure_schur();
 // matrix-core block factor / reduce of the reduced-camera solve (ssba_bcr_mfma.hip)
 int configure_bcr_mf();
-void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false);
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, bool solve = false);
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
