@@ -1636,7 +1636,8 @@ static int enqueue_kernels(ssba_problem *p) {
     if (rc) return rc;
     // single GPU, LM: the decision kernel forms the evaluation sums itself (no exchange sits between them)
     const bool fuse = !p->xfn && !p->d.constrained && p->opt.trust_region_strategy_type != 1;
-    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p)); }))) return rc;
+    const bool fuse_upd = fuse_all_launches(p) && !p->d.dense && bcr_updates_poses(p->d);       // the reduced solve updated the poses, one partial per block
+    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p), fuse_upd ? p->d.pcr.n : -1); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
@@ -1724,10 +1725,11 @@ static int enqueue_front(ssba_problem *p) {
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
             if (p->xfn && d.nb) launch_border_scale(L, d);      // Jacobi scale of the border from the SUMMED diagonal
             launch_finish_check(L, d, fuse_ctrl, fuse_best);
+            const bool fuse_upd = fuse_all && !d.dense && bcr_updates_poses(d);     // the last step of the reduced solve updates the poses
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
-            else { launch_bcr(L, d); if (d.nb) launch_border_solve(L, d); }
+            else { launch_bcr(L, d, true, fuse_upd); if (d.nb) launch_border_solve(L, d); }
             if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
-            else launch_update_eval(L, d, !p->xfn && !d.constrained, fuse_best);
+            else launch_update_eval(L, d, !p->xfn && !d.constrained, fuse_best, fuse_upd);
         }))) return rc;
     if (p->xfn && (rc = X(d.scal2, NSCAL, 0))) return rc;
     return SSBA_OK;

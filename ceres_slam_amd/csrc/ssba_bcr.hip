@@ -761,7 +761,7 @@ static bool bcr_legacy() {
     return v;
 }
 // coupled: the blocks still have L / U operands (false for the decoupled last step of an unpinned plan)
-static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, bool solve = false) {
+static void launch_factor(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, int solve = 0) {
     if (bcr_legacy()) LAUNCH(KC_BCR_FACTOR, k_bcr_factor, dim3(nblocks), dim3(FACT_THREADS), (size_t)FACT_LDS_DOUBLES * sizeof(double), d, lev, top, which);
     else launch_bcr_factor_mf(L, d, nblocks, lev, top, which, coupled, ride, solve);
 }
@@ -777,7 +777,14 @@ bool bcr_border_rides(const Dev &d) {
     return d.nb > 0 && !d.part && !d.dense && !bcr_legacy() && !(e && e[0] == '1');
 }
 
-void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
+// the decoupled last step of a plan that covers the whole chain can solve its blocks AND update their poses
+static bool bcr_fused_solve(const Dev &d) {
+    const char *nf = getenv("SSBA_NO_FUSED_SOLVE");
+    return !d.part && d.pcr.level >= 0 && !bcr_border_rides(d) && d.nb == 0 && !bcr_legacy() && !(nf && nf[0] == '1');
+}
+bool bcr_updates_poses(const Dev &d) { return bcr_fused_solve(d) && d.pcr.level == 0 && d.n_pf == 0; }
+
+void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
     const bool ride = allow_pcr && bcr_border_rides(d);
@@ -797,9 +804,8 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr) {
             launch_reduce(L, d, n, 2, q, 2, ride);
         }
         // the decoupled last step solves its blocks itself (matrix-core kernels, no border columns): no k_bcr_backsub launch
-        const char *nf = getenv("SSBA_NO_FUSED_SOLVE");
-        const bool fsolve = !ride && !bcr_legacy() && !(nf && nf[0] == '1');
-        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride, fsolve);
+        const bool fsolve = bcr_fused_solve(d);
+        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride, fsolve ? (fuse_update && bcr_updates_poses(d) ? 2 : 1) : 0);
         if (!fsolve) LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
         for (int l = k - 1; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);

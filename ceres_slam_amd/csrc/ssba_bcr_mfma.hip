@@ -28,6 +28,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "ssba_device.h"
 #include "ssba_launch.h"
 #include "ssba_types.h"
 
@@ -82,6 +83,7 @@ constexpr int NRT = 9;          // column tiles of [L | U^T]
 struct FactorOps {
     const double *Dg, *Lg, *Ug, *rin, *Bg;
     double *oD, *oYL, *oYU, *orr, *saveU, *oYB, *xsol;
+    int f0;                                 // first free pose of the block (solve + pose update)
     bool hasL, hasU, trL, trU;
 };
 
@@ -121,7 +123,10 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
         o.oYU = o.hasU ? P.YU + so * BD * BD : nullptr;
         o.orr = top ? B.r + (size_t)blk * BD : P.yr + (size_t)blk * BD;
         if (ride && which == 2) { o.Bg = P.Bb + (size_t)blk * BD * NBP; o.oYB = P.yB + (size_t)blk * BD * NBP; }
-        if (top && which == 2) o.xsol = d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[blk] * BD;        // used by the decoupled launch with `solve`
+        if (top && which == 2) {        // used by the decoupled launch with `solve`
+            o.xsol = d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[blk] * BD;
+            o.f0 = (d.chain0 + B.pos[blk]) * SBP;
+        }
     } else {
         const BcrLevel &L = d.lev[lev];
         const int blk = top ? 0 : 2 * bx + 1;
@@ -587,6 +592,40 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
             }
             o.xsol[lane] = lo;
             if (lane < BD - 64) o.xsol[64 + lane] = hi;
+            if (solve == 2) {
+                // ... and updates its twelve poses: candidate = Plus(x, delta_p), |dx|^2 and the non-finite flag as this
+                // block's partial sums (k_pose_update's job; k_decide reads one partial per block then); the copy of x to
+                // the best iterate is k_backsub_eval_w's (it has to happen after termination too)
+                double *sx = mf_solve_lds + BD * BD + BD;
+                sx[lane] = lo;
+                if (lane < BD - 64) sx[64 + lane] = hi;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double dn = 0.0, nonfinite = 0.0;
+                const int f = o.f0 + lane;
+                if (lane < SBP && f < d.nfree) {
+                    const int k = d.free_pose[f];
+                    double T[12], eps[6], Tn[12];
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) T[c] = d.poses[(size_t)k * 12 + c];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        eps[c] = sx[6 * lane + c] * st.ls_alpha;
+                        if (!isfinite(eps[c])) nonfinite = 1.0;
+                    }
+                    se3_plus(T, eps, Tn);
+#pragma unroll
+                    for (int c = 0; c < 12; ++c) {
+                        d.cand_poses[(size_t)k * 12 + c] = Tn[c];
+                        const double df = Tn[c] - T[c];
+                        dn += df * df;
+                    }
+                }
+                const double a = wave_sum(dn), b = wave_sum(nonfinite);
+                if (lane == 0) {
+                    double *pp = d.part_pose + (size_t)bx * NPP;
+                    pp[0] = a; pp[1] = b; pp[2] = 0.0; pp[3] = 0.0;
+                }
+            }
         }
     }
     MF_STAMP(31);
@@ -990,7 +1029,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
-void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride, bool solve) {
+// solve: 0 no, 1 the decoupled blocks solve themselves, 2 ... and update their poses
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride, int solve) {
     // workgroups per block: fill the chip when the level is short; blocks without couplings (the decoupled last step)
     // have no right-hand-side tiles to share out
     // Several workgroups per block all read D and r while the first of them writes G and yr: only where those go to
@@ -1003,8 +1043,8 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
     const int ns = (!coupled || in_place) ? 1 : nblocks <= 85 ? (ride ? 4 : 3) : nblocks <= 128 ? 2 : 1;
     const int per_wg = (nrt - rlo + ns - 1) / ns;
     const int grid = xcd_grid(nblocks, ns);
-    const size_t sh_solve = (size_t)(BD * BD + BD) * sizeof(double);
-    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), solve ? sh_solve : 0, d, lev, top, which, nblocks, ns, rlo, nrt, solve ? 1 : 0);
+    const size_t sh_solve = (size_t)(BD * BD + 2 * BD) * sizeof(double);
+    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), solve ? sh_solve : 0, d, lev, top, which, nblocks, ns, rlo, nrt, solve);
     else if (per_wg <= 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
     else if (per_wg <= 7) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
     else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
@@ -1018,7 +1058,7 @@ void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy,
 
 int configure_bcr_mf() {
     if (hipFuncSetAttribute((const void *)k_bcr_reduce_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RED_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BD * BD + BD) * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BD * BD + 2 * BD) * sizeof(double))) != hipSuccess) return -1;
     return 0;
 }
 

@@ -1181,9 +1181,9 @@ __device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts,
         log_push(d, st, candidate_cost, st.cost_change, step_norm, rd, 0);
     }
 }
-__global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts) {
+__global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts, int n_pose_parts) {
     State &st = *d.st;
-    decide_body(d, st, n_eval_parts, d.n_pose_blocks);       // tests st.terminated itself, after its partial sums are read
+    decide_body(d, st, n_eval_parts, n_pose_parts);       // tests st.terminated itself, after its partial sums are read
 }
 
 // The same pass in the window layout with four lanes per landmark (see k_linearize_landmarks_w): wave w takes the slots
@@ -1200,8 +1200,12 @@ __global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
     // operand reads first, the solver state (a cold read: see k_schur_windows) is tested with them in flight
     const uint32_t mask = d.lm_mask[l];
     const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
-    if (fuse_best && st.copy_best == st.check_count && w == 0) {
-        d.best_pts[l] = px; d.best_pts[(size_t)d.Lpad + l] = py; d.best_pts[2 * (size_t)d.Lpad + l] = pz;
+    if (fuse_best && st.copy_best == st.check_count) {
+        if (w == 0) { d.best_pts[l] = px; d.best_pts[(size_t)d.Lpad + l] = py; d.best_pts[2 * (size_t)d.Lpad + l] = pz; }
+        // fuse_best == 2: the poses too (the reduced solve updated them itself, and it does nothing once the solver has
+        // terminated -- the improving iterate may be the converged one)
+        const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (fuse_best == 2 && gi < (size_t)d.P * 12) d.best_poses[gi] = d.poses[gi];
     }
     if (st.terminated) return;
     double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
@@ -1910,11 +1914,11 @@ void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_be
 }
 
 // fuse_reduce: the caller's launch_decide_commit(.., true) forms the evaluation sums (no exchange in between)
-void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_best) {
+void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_best, bool pose_update_done) {
     const int fb = fuse_best && ctrl_fusable(d) && lm_split(d) ? 1 : 0;
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
+    if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
     if (d.phong) launch_ph_backsub_eval(L, d);
-    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, fb);
+    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
@@ -1954,8 +1958,9 @@ void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks);
 }
 
-void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all) {
-    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all, int n_pose_parts) {
+    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0,
+           n_pose_parts >= 0 ? n_pose_parts : d.n_pose_blocks);
     if (fuse_all) return;       // the next linearisation commits (launch_linearize)
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);

@@ -103,7 +103,7 @@ int configure_kernels();
 int configure_schur();
 // matrix-core block factor / reduce of the reduced-camera solve (ssba_bcr_mfma.hip)
 int configure_bcr_mf();
-void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, bool solve = false);
+void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, int solve = 0);
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
@@ -111,7 +111,9 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fu
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false);
 void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false);
 bool bcr_border_rides(const Dev &d);      // the border columns go through the forward part of the solve inside the factor / reduce launches
-void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true);   // allow_pcr = false keeps the factors of every level (multi-rhs sweeps)
+// fuse_update: the last step of the plan also updates the poses (bcr_updates_poses(d) must hold)
+bool bcr_updates_poses(const Dev &d);
+void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true, bool fuse_update = false);   // allow_pcr = false keeps the factors of every level (multi-rhs sweeps)
 // partitioned (multi-rank) solve: pack the chain ends into the separator exchange vector; after the exchange:
 // damping + convergence checks, separator BCR, scatter, back-substitution of the chain interior
 void launch_finish_local(Launcher &L, const Dev &d);
@@ -121,9 +123,9 @@ void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
 void launch_eval_add_pose(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
-void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false);
+void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false, bool pose_update_done = false);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
-void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false);
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false, int n_pose_parts = -1);
 // config 3 (ssba_phong_solver.hip)
 int upload_phong_tables(hipStream_t s);
 int configure_phong();
