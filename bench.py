@@ -287,8 +287,9 @@ def main():
         while done < n_steps:
             if done and done % period == 0:
                 ba.restart()
-            ba.step(1)
-            done += 1
+            k = min(n_steps - done, period - done % period)      # up to the next restart in one call (graph replays of two iterations)
+            ba.step(k)
+            done += k
 
     ba.solve_begin(opts, ignore_convergence=True)
     run(args.warmup, False)

@@ -103,6 +103,8 @@ struct ssba_problem {
     // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph2 = nullptr;            // GRAPH_ITERS iterations per replay (ssba_solve_step(n >= GRAPH_ITERS)): 1/8 of the replay gaps
+    hipGraphExec_t gexec2 = nullptr;
     // multi-rank: the kernel runs between the exchange points are captured as separate graphs
     hipGraph_t seg_graph[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t seg_exec[3] = {nullptr, nullptr, nullptr};
@@ -177,6 +179,8 @@ static int dzero(ssba_problem *p, T **out, size_t n) {
 
 static void drop_graph(ssba_problem *p) {
     if (p->gexec) { hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    if (p->gexec2) { hipGraphExecDestroy(p->gexec2); p->gexec2 = nullptr; }
+    if (p->graph2) { hipGraphDestroy(p->graph2); p->graph2 = nullptr; }
     if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
     for (int i = 0; i < 3; ++i) {
         if (p->seg_exec[i]) { hipGraphExecDestroy(p->seg_exec[i]); p->seg_exec[i] = nullptr; }
@@ -1624,6 +1628,28 @@ static int enqueue_iteration(ssba_problem *p) {
 
 static int enqueue_front(ssba_problem *p);
 
+// GRAPH_ITERS iterations in one graph replay (the plain single-GPU path, ssba_solve_step): the sequence is fixed and
+// every kernel turns into a no-op once the state says "terminated", so a batch is safe to enqueue blindly; it saves
+// 7/8 of the ~9 us between replays.  (ssba_solve polls the state one replay behind and keeps single iterations: idle
+// iterations after termination would cost what the batches save.)  Returns SSBA_ERR_STATE when this handle does not
+// replay graphs (the caller falls back to single iterations).
+constexpr int GRAPH_ITERS = 8;
+static int enqueue_batch(ssba_problem *p) {
+    if (p->d.constrained || !p->use_graph || p->xfn || p->launcher.timing) return SSBA_ERR_STATE;
+    hipStream_t s = p->launcher.stream;
+    if (!p->gexec2) {
+        HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        int rc = 0;
+        for (int i = 0; i < GRAPH_ITERS && !rc; ++i) rc = enqueue_kernels(p);
+        hipError_t e = hipStreamEndCapture(s, &p->graph2);
+        if (rc) return rc;
+        if (e != hipSuccess) { set_error(std::string("hipStreamEndCapture: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+        HIPCHECK(hipGraphInstantiate(&p->gexec2, p->graph2, nullptr, nullptr, 0));
+    }
+    HIPCHECK(hipGraphLaunch(p->gexec2, s));
+    return SSBA_OK;
+}
+
 // single GPU, LM, windowed stereo layout: the linearisation kernels commit the accepted step (ssba_kernels.hip:
 // launch_linearize); SSBA_NO_FUSE_ALL=1 keeps the k_commit launch (A/B, tests)
 static bool fuse_all_launches(const ssba_problem *p) {
@@ -1815,7 +1841,13 @@ int ssba_solve_restart(ssba_problem *p) {
 int ssba_solve_step(ssba_problem *p, int n) {
     if (!p || n < 0) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->began) return SSBA_ERR_STATE;
-    for (int i = 0; i < n; ++i) {
+    int i = 0;
+    for (; i + GRAPH_ITERS <= n; i += GRAPH_ITERS) {         // batches where the handle replays graphs
+        const int rc = enqueue_batch(p);
+        if (rc == SSBA_ERR_STATE) break;
+        if (rc) return rc;
+    }
+    for (; i < n; ++i) {
         int rc = enqueue_iteration(p);
         if (rc) return rc;
     }
@@ -1908,7 +1940,8 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
     const long max_enqueue = (long)o->max_num_iterations + 3;
     bool done = false;
     for (long it = 0; it < max_enqueue && !done; ++it) {
-        rc = enqueue_iteration(p);
+        rc = enqueue_iteration(p);      // (one iteration per replay here: the host polls one round behind, and idle iterations
+                                        // after termination would cost what pairs save)
         if (rc) break;
         const int slot = (int)(it & 1);
         hipMemcpyAsync(&ring[slot], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st);
