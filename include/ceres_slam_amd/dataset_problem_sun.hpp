@@ -1,0 +1,269 @@
+// DatasetProblemSun -- the host-side data model of the reference's sun-aided VO driver
+// (/root/reference include/ceres_slam/dataset_problem_sun.hpp:14-104, src/ceres_slam/dataset_problem_sun.cpp), with the same
+// public fields and the same method set (read_csv(track, ref_sun, obs_sun) / write_csv / obs_indices_at_state /
+// obs_indices_for_feature / reset_points / compute_initial_guess), written against plain arrays instead of Eigen.  It owns
+// the parameter memory the solve mutates in place (poses[k].data(): 12 doubles [t | R row-major]; map_points[j].data(): 3)
+// and the per-state 6 x 6 pose covariances the driver chains from window to window (tests/dataset_vo_sun.cpp:159-183).
+//
+// compute_initial_guess(k1, k2) does what dataset_problem_sun.cpp:250-354 does -- reciprocal matches of consecutive
+// states, StereoCamera::triangulate, 3-point RANSAC alignment (400 hypotheses, 4 px^2 threshold), pose chaining, map
+// initialisation from the inliers -- with the RANSAC of all state pairs of the window in one GPU batch
+// (ssba_frontend_ransac; the draw sequence of std::mt19937(42) + std::uniform_int_distribution comes from
+// ssba_ransac_samples).  write_csv prints full double precision (the reference's IOFormat(4) is lossy).
+#pragma once
+#include <array>
+#include <cmath>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "ceres_slam_amd/ceres_shim.hpp"
+#include "ceres_slam_amd/dataset_problem.hpp"
+
+namespace ceres_slam {
+
+// Eigen::SelfAdjointEigenSolver<M>(A).operatorInverseSqrt() for n <= 6: cyclic Jacobi, V diag(1/sqrt(w)) V^T
+inline void inverse_sqrt_symmetric(int n, const double *A, double *out) {
+    double a[36], v[36];
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) { a[i * n + j] = 0.5 * (A[i * n + j] + A[j * n + i]); v[i * n + j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) (i == j ? diag : off) += a[i * n + j] * a[i * n + j];
+        if (off <= 1e-32 * diag) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                if (a[p * n + q] == 0.0) continue;
+                const double theta = (a[q * n + q] - a[p * n + p]) / (2.0 * a[p * n + q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) {      // A <- A J
+                    const double akp = a[k * n + p], akq = a[k * n + q];
+                    a[k * n + p] = c * akp - s * akq; a[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {      // A <- J^T A
+                    const double apk = a[p * n + k], aqk = a[q * n + k];
+                    a[p * n + k] = c * apk - s * aqk; a[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = v[k * n + p], vkq = v[k * n + q];
+                    v[k * n + p] = c * vkp - s * vkq; v[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += v[i * n + k] * v[j * n + k] / std::sqrt(a[k * n + k]);
+            out[i * n + j] = s;
+        }
+}
+
+
+//! Class for reading the sun-aided VO datasets from file (dataset_problem_sun.hpp:15-101)
+class DatasetProblemSun {
+   public:
+    typedef StereoCamera Camera;
+    typedef std::array<double, 9> ObservationCovariance;      //!< 3 x 3 row-major (Camera::ObservationCovariance)
+    typedef std::array<double, 4> SunCovariance;              //!< 2 x 2 row-major (azimuth, zenith)
+    typedef std::array<double, 36> AdjointMatrix;             //!< 6 x 6 row-major (SE3::AdjointMatrix)
+
+    DatasetProblemSun() {}
+
+    //! Camera model
+    std::shared_ptr<const Camera> camera;
+    //! Pose ID
+    std::vector<uint> state_ids;
+    //! Number of states to optimize
+    uint num_states = 0;
+    //! Number of map points to optimize
+    uint num_points = 0;
+    //! Camera poses in base frame (to be estimated)
+    std::vector<SE3> poses;
+    //! Covariances of camera poses in base frame (to be estimated)
+    std::vector<AdjointMatrix> pose_covars;
+    //! Map points in base frame (to be estimated)
+    std::vector<Point> map_points;
+    //! Map point IDs in stereo_obs_list
+    std::vector<uint> point_ids;
+    //! True if map point j has been initialized
+    std::vector<bool> initialized_point;
+    //! List of stereo observations
+    std::vector<Point> stereo_obs_list;
+    //! Covariance of stereo observations
+    std::vector<ObservationCovariance> stereo_obs_covars;
+    //! List of sun direction observations (camera frame)
+    std::vector<Vector> sun_obs_list;
+    //! Covariance of sun direction observations
+    std::vector<SunCovariance> sun_obs_covars;
+    //! True if state k has a sun observation
+    std::vector<bool> state_has_sun_obs;
+    //! Sun direction in the global (ENU) frame
+    std::vector<Vector> sun_dir_g;
+
+    //! Read dataset from CSV files (dataset_problem_sun.cpp:16-170): track file "num_states,num_points" / "fu,fv,cu,cv,b" /
+    //! first pose (4 x 4 row-major) / "k,j,u,v,d,c00..c22" rows; reference sun "k,e,n,u"; observed sun "k,x,y,z,c00,c01,c10,c11"
+    bool read_csv(const std::string &track_file, const std::string &ref_sun_file, const std::string &obs_sun_file) {
+        std::ifstream f(track_file);
+        if (!f.is_open()) { std::cerr << "Error: couldn't open " << track_file << std::endl; return false; }
+        std::string line;
+        std::getline(f, line); const std::vector<double> meta = parse_row_(line);
+        std::getline(f, line); const std::vector<double> intr = parse_row_(line);
+        std::getline(f, line); const std::vector<double> first_pose = parse_row_(line);
+        if (meta.size() < 2 || intr.size() < 5 || first_pose.size() < 16) { std::cerr << "malformed header" << std::endl; return false; }
+        num_states = (uint)meta[0]; num_points = (uint)meta[1];
+        camera = std::make_shared<const Camera>(intr[0], intr[1], intr[2], intr[3], intr[4]);
+        while (std::getline(f, line)) {
+            const std::vector<double> r = parse_row_(line);
+            if (r.size() < 14) continue;
+            state_ids.push_back((uint)r[0]); point_ids.push_back((uint)r[1]);
+            stereo_obs_list.push_back(Point(r[2], r[3], r[4]));
+            ObservationCovariance c;
+            std::copy(r.begin() + 5, r.begin() + 14, c.begin());
+            stereo_obs_covars.push_back(c);
+        }
+        poses.assign(num_states, SE3());
+        if (num_states) poses[0] = SE3::from_rows(first_pose.data());
+        AdjointMatrix tiny;
+        tiny.fill(0.0);
+        for (int c = 0; c < 6; ++c) tiny[7 * c] = 1e-12;                  // dataset_problem_sun.cpp:81
+        pose_covars.assign(num_states, AdjointMatrix());
+        for (auto &m : pose_covars) m.fill(0.0);
+        if (num_states) pose_covars[0] = tiny;
+        map_points.assign(num_points, Point());
+        initialized_point.assign(num_points, false);
+        state_indices_.assign(num_states, std::vector<uint>());
+        feature_indices_.assign(num_points, std::vector<uint>());
+        for (size_t i = 0; i < state_ids.size(); ++i) {
+            if (state_ids[i] >= num_states || point_ids[i] >= num_points) { std::cerr << "observation out of range" << std::endl; return false; }
+            state_indices_[state_ids[i]].push_back((uint)i);
+            feature_indices_[point_ids[i]].push_back((uint)i);
+        }
+        for (uint j : point_ids)      // solveWindow indexes the per-observation covariance list by POINT id (dataset_vo_sun.cpp:58)
+            if ((size_t)j >= stereo_obs_covars.size()) { std::cerr << "point id beyond the covariance list" << std::endl; return false; }
+        sun_dir_g.assign(num_states, Vector());
+        sun_obs_list.assign(num_states, Vector());
+        SunCovariance z;
+        z.fill(0.0);
+        sun_obs_covars.assign(num_states, z);
+        state_has_sun_obs.assign(num_states, false);
+        std::ifstream f2(ref_sun_file);
+        if (!f2.is_open()) { std::cerr << "Error: couldn't open " << ref_sun_file << std::endl; return false; }
+        while (std::getline(f2, line)) {
+            const std::vector<double> r = parse_row_(line);
+            if (r.size() < 4 || (size_t)r[0] >= num_states) continue;
+            sun_dir_g[(size_t)r[0]] = Vector(r[1], r[2], r[3]);
+        }
+        std::ifstream f3(obs_sun_file);
+        if (!f3.is_open()) { std::cerr << "Error: couldn't open " << obs_sun_file << std::endl; return false; }
+        while (std::getline(f3, line)) {
+            const std::vector<double> r = parse_row_(line);
+            if (r.size() < 8 || (size_t)r[0] >= num_states) continue;
+            const size_t k = (size_t)r[0];
+            sun_obs_list[k] = Vector(r[1], r[2], r[3]);
+            std::copy(r.begin() + 4, r.begin() + 8, sun_obs_covars[k].begin());
+            state_has_sun_obs[k] = true;
+        }
+        return true;
+    }
+
+    //! Write result to a CSV file: <filename>_poses.csv (dataset_problem_sun.cpp:172-232)
+    bool write_csv(const std::string &filename) const {
+        std::cout << "Outputting to file:\n\t" << filename + "_poses.csv" << std::endl;
+        std::ofstream po(filename + "_poses.csv");
+        if (!po.is_open()) return false;
+        po.precision(17);
+        po << "T_00, T_01, T_02, T_03,T_10, T_11, T_12, T_13,T_20, T_21, T_22, T_23,T_30, T_31, T_32, T_33" << std::endl;
+        for (uint k = 0; k < num_states; ++k) {
+            const double *T = poses[k].data();
+            for (int i = 0; i < 3; ++i) po << T[3 + 3 * i] << "," << T[4 + 3 * i] << "," << T[5 + 3 * i] << "," << T[i] << ",";
+            po << "0,0,0,1" << std::endl;
+        }
+        return true;
+    }
+
+    //! Return list of indices corresponding to a specified state index
+    const std::vector<uint> &obs_indices_at_state(uint k) const { return state_indices_[k]; }
+    //! Return list of indices corresponding to a specified feature index
+    const std::vector<uint> &obs_indices_for_feature(uint j) const { return feature_indices_[j]; }
+    //! Reset initialization flags for all points
+    void reset_points() { initialized_point.assign(num_points, false); }
+
+    //! Generate initial guess for poses and map points (dataset_problem_sun.cpp:250-354)
+    bool compute_initial_guess(uint k1 = 0, uint k2 = 0) {
+        if (k2 == 0) k2 = num_states;
+        if (k2 <= k1 + 1) return true;
+        const uint32_t num_iters = 400;
+        std::vector<uint32_t> offset(1, 0), samples;
+        std::vector<double> pts0, pts1;
+        std::vector<uint> match_km1;
+        for (uint k = k1 + 1; k < k2; ++k) {
+            std::vector<uint> a, b;
+            std::map<uint, uint> in_k;
+            for (uint i : state_indices_[k]) in_k[point_ids[i]] = i;
+            std::map<uint, int> kept;
+            for (uint i : state_indices_[k - 1]) if (in_k.count(point_ids[i])) { a.push_back(i); kept[point_ids[i]] = 1; }
+            for (uint i : state_indices_[k]) if (kept.count(point_ids[i])) b.push_back(i);
+            if (a.size() < 3 || a.size() != b.size()) { std::cout << "WARNING: Fewer than 3 inliers found." << std::endl; return false; }
+            for (size_t m = 0; m < a.size(); ++m) {
+                double p[3];
+                triangulate_(a[m], p); pts0.insert(pts0.end(), p, p + 3);
+                triangulate_(b[m], p); pts1.insert(pts1.end(), p, p + 3);
+                match_km1.push_back(a[m]);
+            }
+            offset.push_back((uint32_t)(pts0.size() / 3));
+            std::vector<uint32_t> smp(3 * num_iters);
+            if (ssba_ransac_samples((uint32_t)a.size(), num_iters, __GNUC__ >= 11 ? 1 : 0, smp.data())) return false;
+            samples.insert(samples.end(), smp.begin(), smp.end());
+        }
+        const uint32_t num_pairs = (uint32_t)(k2 - k1 - 1);
+        std::vector<double> T((size_t)num_pairs * 12);
+        std::vector<uint8_t> inlier(pts0.size() / 3);
+        std::vector<uint32_t> count(num_pairs);
+        ssba_camera cam = {camera->fu, camera->fv, camera->cu, camera->cv, camera->b};
+        const int rc = ssba_frontend_ransac(&cam, -1, num_pairs, offset.data(), pts0.data(), pts1.data(), samples.data(), num_iters, 4.0,
+                                            T.data(), inlier.data(), count.data(), nullptr);              // :315-318
+        if (rc) { std::cerr << "ssba_frontend_ransac: " << ssba_status_string(rc) << " (" << ssba_last_error() << ")" << std::endl; return false; }
+        for (uint k = k1 + 1; k < k2; ++k) {
+            const size_t q = k - k1 - 1;
+            if (count[q] < 3) { std::cout << "WARNING: Fewer than 3 inliers found." << std::endl; return false; }   // :325-328
+            SE3 T_k_km1;
+            std::copy(&T[12 * q], &T[12 * q] + 12, T_k_km1.data());
+            poses[k] = T_k_km1 * poses[k - 1];                                   // :331
+            const double *Tp = poses[k - 1].data();
+            for (uint32_t m = offset[q]; m < offset[q + 1]; ++m) {               // :335-350
+                const uint j = point_ids[match_km1[m]];
+                if (!inlier[m] || j >= num_points || initialized_point[j]) continue;
+                const double d[3] = {pts0[3 * m] - Tp[0], pts0[3 * m + 1] - Tp[1], pts0[3 * m + 2] - Tp[2]};
+                for (int c = 0; c < 3; ++c) map_points[j].data()[c] = Tp[3 + c] * d[0] + Tp[6 + c] * d[1] + Tp[9 + c] * d[2];
+                initialized_point[j] = true;
+            }
+        }
+        return true;
+    }
+
+   private:
+    std::vector<std::vector<uint>> state_indices_, feature_indices_;
+    static std::vector<double> parse_row_(const std::string &line) {
+        std::vector<double> v;
+        std::stringstream ss(line);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) {
+            try { v.push_back(std::stod(tok)); } catch (...) { v.clear(); return v; }
+        }
+        return v;
+    }
+    void triangulate_(uint i, double *p) const {     // stereo_camera.hpp:112-120
+        const double *o = stereo_obs_list[i].data();
+        const double b_over_d = camera->b / o[2];
+        p[0] = (o[0] - camera->cu) * b_over_d;
+        p[1] = (o[1] - camera->cv) * b_over_d * (camera->fu / camera->fv);
+        p[2] = camera->fu * b_over_d;
+    }
+};
+
+}  // namespace ceres_slam
