@@ -112,15 +112,18 @@ def test_huber_with_outliers_matches_independent_loop_and_beats_truth_cost():
     # BASELINE.json config 5: Huber a = 1.345 (scripts/ba_all_devon.sh:86), 30 % outliers
     prob = synth.make_problem(8, 60, track_len=5, seed=11, outlier_fraction=0.3)
     op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
-    s, log = op.solve(orc.driver_options(num_threads=2))
+    # a long, slowly converging run (~340 steps to the flat tail): both loops are cut at the same iteration count and
+    # compared there at the north-star bar -- accept / reject sequence, cost trace, end point
+    K = 25
+    s, log = op.solve(orc.driver_options(num_threads=2, max_num_iterations=K))
     ref = _np_ba(prob, huber_a=1.345)
-    _, _, rlog = ref.solve()
-    # long, slowly converging run: compare the first 40 iterations step by step,
-    # then only the end point (rounding differences accumulate over ~340 steps)
+    _, _, rlog = ref.solve(max_iter=K)
+    n = min(len(log["cost"]), len(rlog))
+    assert n >= K
     np.testing.assert_allclose(log["cost"][:12], [c for c, _ in rlog][:12], rtol=1e-9)
-    np.testing.assert_allclose(log["cost"][:40], [c for c, _ in rlog][:40], rtol=1e-5)
-    assert log["step_is_successful"][:40].tolist() == [int(ok) for _, ok in rlog][:40]
-    assert s.final_cost == pytest.approx(min(c for c, _ in rlog), rel=1e-2)  # flat tail: stop point is rounding-sensitive
+    np.testing.assert_allclose(log["cost"][:n], [c for c, _ in rlog][:n], rtol=1e-6)
+    assert log["step_is_successful"][:n].tolist() == [int(ok) for _, ok in rlog][:n]
+    assert s.final_cost == pytest.approx(min(c for c, _ in rlog[:n]), rel=1e-6)
     # the minimiser must end below the robustified cost of the ground truth
     prob = synth.make_config("C1", outlier_fraction=0.3)
     op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
