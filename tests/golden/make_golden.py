@@ -59,6 +59,13 @@ def main():
         "trust_region_radius": log["trust_region_radius"].tolist(),
         "poses_1_25_49": op.poses[[1, 25, 49]].tolist(), "light": op.light.tolist(), "phong": op.phong.tolist(), "texture": op.texture.tolist(),
     }
+    # the same solve cut at 12 iterations: an end point that is a parity statement (the converged run stops on a flat,
+    # rounding-sensitive tail)
+    op12 = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                             prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s12, _ = op12.solve(orc.driver_options(num_threads=1, trust_region_strategy_type=1, dogleg_type=1, max_num_iterations=12))
+    out["at_12_iterations"] = {"final_cost": s12.final_cost, "poses_1_25_49": op12.poses[[1, 25, 49]].tolist(), "light": op12.light.tolist(),
+                               "texture": op12.texture.tolist()}
     with open(os.path.join(HERE, "c1_phong_driver.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote c1_phong_driver.json:", s.num_iterations, "iterations, final cost", s.final_cost)

@@ -37,6 +37,23 @@ def _assert_same_solve(ba, s, log, op, s2, log2, pose_tol=1e-6):
     assert np.abs(ba.poses - op.poses).max() < pose_tol
 
 
+def assert_fixed_count_parity(ba, op, K, cost_rtol=1e-7, threads=4, **kw):
+    """Both sides cut at the same iteration count K and compared there at the north-star bar: identical accept / reject
+    sequence, cost trace of the accepted iterates, final cost to 1e-6 relative.  (A solve that runs to convergence through a
+    long flat tail stops at a rounding-sensitive iteration; its end point is not a parity statement.)  Solves from the
+    handles' current state: call it on freshly built pairs."""
+    kw = dict(kw, max_num_iterations=K)
+    s, log = ba.solve(capi.default_options(**kw))
+    s2, log2 = op.solve(orc.driver_options(num_threads=threads, **kw))
+    assert s.num_iterations == s2.num_iterations
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    ok = np.asarray(log2["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][ok], log2["cost"][ok], rtol=cost_rtol)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+    return s, log, s2, log2
+
+
 @pytest.mark.parametrize("num_poses", [2, 3, 12, 13, 14, 25, 26, 37, 49, 61, 97, 150])
 def test_bcr_block_count_edges(num_poses):
     """1, 2, 3, ... super-blocks incl. padded last blocks and odd/even level sizes."""
@@ -107,10 +124,10 @@ def test_option_variations(opts):
 
 def test_huber_medium_scale():
     prob = synth.make_problem(120, 8000, track_len=12, seed=8, outlier_fraction=0.3)
-    ba, s, log, op, s2, log2 = _solve_both(prob, huber_a=1.345)
-    n = min(len(log["cost"]), len(log2["cost"]), 20)
-    np.testing.assert_allclose(log["cost"][:n], log2["cost"][:n], rtol=1e-8)
-    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-4)
+    ba = StereoBA.from_synth(prob, huber_a=1.345)
+    op = orc.OracleProblem.from_synth(prob, huber_a=1.345)
+    assert_fixed_count_parity(ba, op, 20, cost_rtol=1e-8, threads=2, use_nonmonotonic_steps=1)
+    assert np.abs(ba.poses - op.poses).max() < 1e-6
 
 
 def test_point_behind_camera_gives_rejected_steps_not_garbage():
@@ -191,4 +208,4 @@ def test_dogleg_strategy_matches_oracle(size, huber_a, dogleg_type):
     np.testing.assert_allclose(log["trust_region_radius"], log2["trust_region_radius"], rtol=1e-6)
     if huber_a == 0.0:   # same minimum as Levenberg-Marquardt (the robustified runs stop on different flat tails)
         ba_lm, s_lm, *_ = _solve_both(prob)
-        assert s.final_cost == pytest.approx(s_lm.final_cost, rel=1e-4)
+        assert s.final_cost == pytest.approx(s_lm.final_cost, rel=1e-4)       # two different minimisers, each stopping on its own tolerance: not a parity statement

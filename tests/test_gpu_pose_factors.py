@@ -7,6 +7,7 @@ import pytest
 from ceres_slam_amd import capi, synth
 from ceres_slam_amd.solver import StereoBA
 from oracle import oracle as orc
+from test_gpu_edge_cases import assert_fixed_count_parity
 from test_oracle_pose_factors import _sun_problem
 
 pytestmark = pytest.mark.gpu
@@ -53,7 +54,8 @@ def test_sun_aided_solve_matches_oracle(strategy, huber):
     ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
     ok[0] = True
     np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-7)
-    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-5)
+    # the end point at the north-star bar: the same solve cut at a fixed iteration count (fresh handles)
+    assert_fixed_count_parity(*_pair(prob, factors), 12, **{k: v for k, v in kw.items() if k != "max_num_iterations"})
     assert np.abs(ba.poses - op.poses).max() < 1e-4
     assert np.abs(ba.poses[0] - prob.poses_init[0]).max() < 0.02       # the prior holds the first pose
 
@@ -129,7 +131,7 @@ def test_solve_with_odometry_and_loop_blocks_matches_oracle(strategy, huber):
     ok = np.asarray(log2["step_is_successful"][:n], dtype=bool)
     ok[0] = True
     np.testing.assert_allclose(log["cost"][:n][ok], log2["cost"][:n][ok], rtol=1e-7)
-    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-5)
+    assert_fixed_count_parity(*_pair(prob, factors), 12, **{k: v for k, v in kw.items() if k != "max_num_iterations"})
     assert np.abs(ba.poses - op.poses).max() < 1e-4
 
 
