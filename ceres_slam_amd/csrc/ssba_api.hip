@@ -1729,15 +1729,16 @@ static int enqueue_front(ssba_problem *p) {
         // partitioned reduced solve: eliminate this rank's chain interior, sum the chain ends (the separator
         // system: ~1 MB instead of the whole reduced system) over the ranks, solve it everywhere, back-substitute
         if (!p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
+        const bool pbest = !d.constrained && !d.nb && p->opt.trust_region_strategy_type != 1;      // see fuse_best below
         if ((rc = run_segment(p, 0, [&] { launch_linearize(L, d); launch_schur(L, d); launch_finish_local(L, d); launch_bcr(L, d); launch_sep_pack(L, d); }))) return rc;
         if ((rc = X(d.sepv, d.sepv_count, 0))) return rc;      // sums; the landmark gradient maximum travels in per-rank slots
-        if ((rc = run_segment(p, 1, [&] { launch_sep_finish_check(L, d); launch_bcr_separators(L, d); launch_update_eval(L, d); launch_eval_add_pose(L, d); }))) return rc;
+        if ((rc = run_segment(p, 1, [&] { launch_sep_finish_check(L, d, pbest); launch_bcr_separators(L, d); launch_update_eval(L, d, false, pbest); launch_eval_add_pose(L, d); }))) return rc;
         if ((rc = X(d.scal2, NSCAL, 0))) return rc;
         return SSBA_OK;
     }
     // single GPU: the small launches between the big kernels are folded into their neighbours (ssba_kernels.hip, k_check)
     const bool fuse_ctrl = !p->xfn && !d.constrained && !d.nb;
-    const bool fuse_best = fuse_ctrl && p->opt.trust_region_strategy_type != 1;
+    const bool fuse_best = !d.constrained && !d.nb && p->opt.trust_region_strategy_type != 1;      // with an exchange too: none sits between k_check and the update
     const bool fuse_all = fuse_all_launches(p);
     if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl); }))) return rc;
     if (p->xfn) {

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "ssba_device.h"
 #include "ssba_launch.h"
@@ -935,12 +936,17 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
 // 1-D grid of xcd_grid(blocks, ny) workgroups, ny = 3 (+ 2 for the coupling to a pinned last block).  Parallel cyclic
 // reduction (which >= 2): D', r' in place, L' (+ its transpose) into the plan's buffers.  Plain levels (which = 0):
 // D', r', L' of the next level.  Same operand rules as k_bcr_reduce (ssba_bcr.hip).
-__global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, int which, int nblocks, int ny, int ride) {
+__global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, int which, int nblocks, int ny, int ride, int x_lo) {
     const State &st = *d.st;
     const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested after the operand reads have been issued
     extern __shared__ __align__(16) double lds[];
     int bx, y;
-    xcd_map((int)blockIdx.x, nblocks, ny, bx, y);
+    if ((int)blockIdx.x < nblocks * ny) xcd_map((int)blockIdx.x, nblocks, ny, bx, y);
+    else {      // tail of the grid: the two extra workgroups of the blocks x_lo.. that couple to a pinned last block
+        const int j = (int)blockIdx.x - nblocks * ny;
+        bx = x_lo + (j >> 1);
+        y = 3 + (j & 1);
+    }
     ReduceJob J;
     J.a0 = J.a1 = J.a2 = J.ya0 = J.ya1 = J.dbase = J.rbase = nullptr;
     J.dout = J.rout = J.out = J.outT = nullptr;
@@ -1052,8 +1058,20 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
 
 // ny_legacy: 2, or 3 with the coupling to a pinned last block (the grid.y of k_bcr_reduce)
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy, int lev, int which, bool ride) {
-    const int ny = ny_legacy == 3 ? 5 : 3;
-    LAUNCH(KC_BCR_REDUCE, k_bcr_reduce_mf, dim3(xcd_grid(nblocks, ny)), dim3(MF_THREADS), (size_t)RED_LDS_DOUBLES * sizeof(double), d, lev, which, nblocks, ny, ride ? 1 : 0);
+    // ny_legacy == 3 (a partitioned chain whose last block is pinned): the blocks e with e + s inside the chain and
+    // e + 2 s beyond its last block also compute the coupling of e to that block -- two more workgroups each, listed
+    // after the 3 n regular ones (a 5 n grid with 2 n - 2 s workgroups that return at once held a CU's LDS each while
+    // they did: 17-21 us per launch against 11.6)
+    int n_extra = 0, x_lo = 0;
+    if (ny_legacy == 3 && which >= 2) {
+        const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+        const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
+        const int s = 1 << lev, last = B.n - 1, hi = P.pin1 ? last - 1 : last;
+        x_lo = std::max(P.pin0 ? 1 : 0, last - 2 * s + 1);
+        const int x_hi = hi - s;
+        if (P.pin1 && x_hi >= x_lo) n_extra = x_hi - x_lo + 1;
+    }
+    LAUNCH(KC_BCR_REDUCE, k_bcr_reduce_mf, dim3(xcd_grid(nblocks, 3) + 2 * n_extra), dim3(MF_THREADS), (size_t)RED_LDS_DOUBLES * sizeof(double), d, lev, which, nblocks, 3, ride ? 1 : 0, x_lo);
 }
 
 int configure_bcr_mf() {

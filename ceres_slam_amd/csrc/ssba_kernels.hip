@@ -244,6 +244,14 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
     if (st.terminated || !st.need_linearize) return;
     if (d.pose_free[blockIdx.x] < 0) return;
     const bool commit = fuse && st.accepted;
+    if (!fuse) {
+        // a landmark shard sees a fraction of the poses (rank r of N: its own ~P/N and the neighbours' edges): the blocks
+        // of a pose nothing refers to here stay at the zeros they were allocated with, and the workgroup leaves at once
+        // (rank 4 of 8 at C2 x 8: 98 -> ~30 us per launch)
+        const int k = (int)blockIdx.x;
+        const bool no_obs = DN ? d.dn_pose_start[k] == d.dn_pose_start[k + 1] : d.pose_obs_start[k] == d.pose_obs_start[k + 1];
+        if (no_obs && (!d.n_pf || d.pf_start[k] == d.pf_start[k + 1])) return;
+    }
     lin_pose_body<DN>(d, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
 
@@ -371,9 +379,14 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
     const int dead = st.terminated | st.dl_reuse;
     if ((int)blockIdx.x < n_zero) {
         if (dead) return;
-        double2 *z = reinterpret_cast<double2 *>(d.xv + d.off_D);
-        const size_t n2 = (size_t)d.Nsb * BD * BD;               // 2 x Nsb blocks of BD x BD doubles = n2 double2
-        for (size_t i = (size_t)blockIdx.x * SCHUR_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * SCHUR_THREADS) z[i] = make_double2(0.0, 0.0);
+        // D and L of every super-block; of this rank's chain only in a partitioned solve (the rest is never assembled)
+        const size_t b0 = d.part ? (size_t)d.chain0 * BD * BD : 0;
+        const size_t n2 = (d.part ? (size_t)(d.chain1 - d.chain0 + 1) : (size_t)d.Nsb) * (BD * BD / 2);       // double2 per range
+        double2 *zD = reinterpret_cast<double2 *>(d.xv + d.off_D + b0), *zL = reinterpret_cast<double2 *>(d.xv + d.off_L + b0);
+        for (size_t i = (size_t)blockIdx.x * SCHUR_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * SCHUR_THREADS) {
+            zD[i] = make_double2(0.0, 0.0);
+            zL[i] = make_double2(0.0, 0.0);
+        }
         return;
     }
     extern __shared__ __align__(16) double schur_lds[];
@@ -1865,6 +1878,9 @@ static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 26
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
 static bool ctrl_fusable(const Dev &d) { return !d.phong && !d.dense && !d.part; }
+// fuse_best (the copy of x to the best iterate rides in the update / evaluation kernels): no exchange sits between k_check's
+// decision and those kernels in any mode, so the partitioned multi-GPU solve takes it too
+static bool best_fusable(const Dev &d) { return !d.phong && !d.dense && lm_split(d); }
 bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && lm_split(d); }
 // fuse_all (single GPU, LM, windowed stereo layout, launch_can_fuse_all): the linearisation kernels commit the accepted
 // step on the way (no k_commit launch)
@@ -1882,10 +1898,10 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all) 
 
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
-    const int n_zero = fuse_ctrl ? 128 : 0;
+    const int n_zero = d.phong ? 0 : 128;       // the stereo Schur launch clears the reduced system on the way
     if (d.phong) launch_ph_schur(L, d);
     else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero);
-    if (fuse_ctrl) {
+    if (n_zero) {
     } else if (d.part) {   // only this rank's chain is assembled and eliminated
         const size_t n = (size_t)(d.chain1 - d.chain0 + 1) * BD * BD * sizeof(double);
         hipMemsetAsync(d.xv + d.off_D + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
@@ -1908,14 +1924,14 @@ void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_be
     if (d.dense) launch_dense_finish(L, d);
     else if (!fuse_ctrl) LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
-    if (fuse_best && ctrl_fusable(d) && lm_split(d)) return;
+    if (fuse_best && best_fusable(d)) return;
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }
 
 // fuse_reduce: the caller's launch_decide_commit(.., true) forms the evaluation sums (no exchange in between)
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_best, bool pose_update_done) {
-    const int fb = fuse_best && ctrl_fusable(d) && lm_split(d) ? 1 : 0;
+    const int fb = fuse_best && best_fusable(d) ? 1 : 0;
     if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
     if (d.phong) launch_ph_backsub_eval(L, d);
     else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
@@ -1927,9 +1943,10 @@ void launch_sep_pack(Launcher &L, const Dev &d) {
     hipMemsetAsync(d.sepv, 0, (size_t)d.sepv_count * sizeof(double), L.stream);
     LAUNCH(KC_SMALL, k_sep_pack, dim3(4), dim3(256), 0, d);
 }
-void launch_sep_finish_check(Launcher &L, const Dev &d) {
+void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best) {
     LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, 0);
+    if (fuse_best && best_fusable(d)) return;
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }

@@ -118,7 +118,7 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr = true, bool fuse_upda
 // damping + convergence checks, separator BCR, scatter, back-substitution of the chain interior
 void launch_finish_local(Launcher &L, const Dev &d);
 void launch_sep_pack(Launcher &L, const Dev &d);
-void launch_sep_finish_check(Launcher &L, const Dev &d);
+void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best = false);
 void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
 void launch_eval_add_pose(Launcher &L, const Dev &d);
