@@ -1730,9 +1730,9 @@ static int enqueue_front(ssba_problem *p) {
         // system: ~1 MB instead of the whole reduced system) over the ranks, solve it everywhere, back-substitute
         if (!p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
         const bool pbest = !d.constrained && !d.nb && p->opt.trust_region_strategy_type != 1;      // see fuse_best below
-        if ((rc = run_segment(p, 0, [&] { launch_linearize(L, d); launch_schur(L, d); launch_finish_local(L, d); launch_bcr(L, d); launch_sep_pack(L, d); }))) return rc;
+        if ((rc = run_segment(p, 0, [&] { launch_linearize(L, d, false, false, !d.phong); launch_schur(L, d); launch_finish_local(L, d); launch_bcr(L, d); launch_sep_pack(L, d); }))) return rc;
         if ((rc = X(d.sepv, d.sepv_count, 0))) return rc;      // sums; the landmark gradient maximum travels in per-rank slots
-        if ((rc = run_segment(p, 1, [&] { launch_sep_finish_check(L, d, pbest); launch_bcr_separators(L, d); launch_update_eval(L, d, false, pbest); launch_eval_add_pose(L, d); }))) return rc;
+        if ((rc = run_segment(p, 1, [&] { launch_sep_finish_check(L, d, pbest); launch_bcr_separators(L, d); launch_update_eval(L, d, false, pbest); }))) return rc;
         if ((rc = X(d.scal2, NSCAL, 0))) return rc;
         return SSBA_OK;
     }

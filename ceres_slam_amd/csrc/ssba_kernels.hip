@@ -642,6 +642,8 @@ __global__ __launch_bounds__(256) void k_finish_reduced(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (d.part)     // the separator vector (last iteration's sums: consumed) is cleared for k_sep_pack -- no memset launch
+        for (size_t q = (size_t)i; q < d.sepv_count; q += (size_t)gridDim.x * 256) d.sepv[q] = 0.0;
     if (i >= d.nf_pad * 6) return;
     const int f = i / 6, c = i - f * 6;
     const int I = f / SBP, row = (f - I * SBP) * 6 + c;
@@ -1098,7 +1100,7 @@ __device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts,
     pmc = block_sum(pmc, sm);
     // (the solver state is a cold read at the head of a launch: tested here, with the partial sums already formed)
     if (threadIdx.x != 0 || st.terminated) return;
-    if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_eval_add_pose), summed over ranks
+    if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_reduce_eval(.., add_pose)), summed over ranks
     const Options &o = st.opt;
     const double candidate_cost_raw = d.scal2[0] + pcc;      // + unary pose residual blocks
     const double mcc = d.scal2[1] + pmc;
@@ -1689,23 +1691,28 @@ __global__ __launch_bounds__(256) void k_reduce_lin(Dev d, int n_parts) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_eval(Dev d, int n_parts) {
+// add_pose (partitioned solve): the pose part of |dx|^2 and of the non-finite flag (owned poses only: k_pose_update's
+// partials) joins the landmark sums before the exchange -- k_eval_add_pose's work, one launch less
+__global__ __launch_bounds__(256) void k_reduce_eval(Dev d, int n_parts, int add_pose) {
     const State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
-    double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
+    double a = 0.0, b = 0.0, c = 0.0, e = 0.0, pa = 0.0, pb = 0.0;
     for (int i = threadIdx.x; i < n_parts; i += 256) {
         a += d.part_eval[i * 4];
         b += d.part_eval[i * 4 + 1];
         c += d.part_eval[i * 4 + 2];
         e += d.part_eval[i * 4 + 3];
     }
+    if (add_pose)
+        for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) { pa += d.part_pose[i * NPP]; pb += d.part_pose[i * NPP + 1]; }
     a = block_sum(a, sm);
     b = block_sum(b, sm);
     c = block_sum(c, sm);
     e = block_sum(e, sm);
+    if (add_pose) { pa = block_sum(pa, sm); pb = block_sum(pb, sm); }
     if (threadIdx.x == 0) {
-        d.scal2[0] = a; d.scal2[1] = b; d.scal2[2] = c; d.scal2[3] = e;
+        d.scal2[0] = a; d.scal2[1] = b; d.scal2[2] = c + pa; d.scal2[3] = e + pb;
     }
 }
 
@@ -1746,7 +1753,9 @@ __global__ void k_reset_state(Dev d, Options opt) {
 // elimination of the chain interior (ssba_bcr.hip, pinned ends) the two end blocks hold this rank's share of
 // the separator system; k_sep_pack writes them, the ends' gradient / diag(H_pp) and the scalars of the
 // linearisation into the (zeroed) separator vector, which the ranks then sum.
-__global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
+// n_lin_parts > 0: the last workgroup also forms the sums of the linearisation partials (k_reduce_lin's work: that launch
+// is skipped; nothing between the linearisation and this kernel reads them).
+__global__ __launch_bounds__(256) void k_sep_pack(Dev d, int n_lin_parts) {
     State &st = *d.st;
     if (st.terminated) return;
     const BcrLevel &E = d.lev[d.pcr.level];          // the pinned first / last block of this level: the shared chain ends
@@ -1780,9 +1789,23 @@ __global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
                 d.sepv[d.soff_hdiag + (size_t)(r - 1 + e) * BD + t] = d.xv[d.off_hdiag + (size_t)sb * BD + t];
             }
         }
+        const bool fused = n_lin_parts > 0, lin = fused ? st.need_linearize != 0 : st.just_linearized != 0;
+        double la = 0.0, lb = 0.0, lc = 0.0;
+        if (fused && lin) {
+            for (int i = t; i < n_lin_parts; i += 256) {
+                la += d.part_lin[i * 4];
+                lb += d.part_lin[i * 4 + 1];
+                lc = fmax(lc, d.part_lin[i * 4 + 2]);
+            }
+            if (d.n_pf)
+                for (int k = t; k < d.P; k += 256) la += d.pf_cost[k];     // unary pose residual blocks
+            la = block_sum(la, sm);
+            lb = block_sum(lb, sm);
+            lc = block_max(lc, sm);
+        }
         // interior poses of this rank: projected gradient and |x|^2 join the landmark sums of the linearisation
         double gm = 0.0, xn = 0.0;
-        if (st.just_linearized) {
+        if (lin) {
             for (int i = (d.chain0 + d.pin0) * SBP + t; i < (d.chain1 + 1 - d.pin1) * SBP && i < d.nfree; i += 256) {
                 const int k = d.free_pose[i];
                 const double *T = d.poses + (size_t)k * 12;
@@ -1797,7 +1820,8 @@ __global__ __launch_bounds__(256) void k_sep_pack(Dev d) {
         const double gmp = block_max(gm, sm), xnp = block_sum(xn, sm);
         if (t == 0) {
             double *sc = d.xv + d.off_scal, *ss = d.sepv + d.soff_scal;
-            if (st.just_linearized) {
+            if (lin) {
+                if (fused) { sc[0] = la; sc[1] = lb; *d.gmax_l = lc; st.need_linearize = 0; st.just_linearized = 1; }
                 ss[0] = sc[0]; ss[1] = sc[1] + xnp;
                 // the maximum over ranks rides in the SUM exchange: every rank fills its own slot, the others add zeros
                 ss[NSCAL + d.rank] = fmax(*d.gmax_l, gmp);
@@ -1839,18 +1863,6 @@ __global__ __launch_bounds__(256) void k_sep_scatter(Dev d) {
     d.x0[(size_t)d.sep_sb[s] * BD + row] = d.xsep[q];
 }
 
-// pose part of |dx|^2 and of the non-finite flag (owned poses only) joins the landmark sums before the exchange
-__global__ __launch_bounds__(256) void k_eval_add_pose(Dev d) {
-    const State &st = *d.st;
-    if (st.terminated) return;
-    __shared__ double sm[4];
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < d.n_pose_blocks; i += 256) { a += d.part_pose[i * NPP]; b += d.part_pose[i * NPP + 1]; }
-    a = block_sum(a, sm);
-    b = block_sum(b, sm);
-    if (threadIdx.x == 0) { d.scal2[2] += a; d.scal2[3] += b; }
-}
-
 // zero the poses another rank owns, so that a sum over ranks gathers the solution
 __global__ __launch_bounds__(256) void k_mask_unowned_poses(Dev d, double *poses) {
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1884,7 +1896,8 @@ static bool best_fusable(const Dev &d) { return !d.phong && !d.dense && lm_split
 bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && lm_split(d); }
 // fuse_all (single GPU, LM, windowed stereo layout, launch_can_fuse_all): the linearisation kernels commit the accepted
 // step on the way (no k_commit launch)
-void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all) {
+// skip_reduce (partitioned solve): k_sep_pack(.., n_lin_parts) forms the sums of the partials
+void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, bool skip_reduce) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
     if (d.phong) {
         launch_ph_linearize(L, d);
@@ -1893,7 +1906,7 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all) 
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d, fuse_all ? 1 : 0);
     }
-    if (!fuse_ctrl) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
+    if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
 
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
@@ -1936,12 +1949,11 @@ void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_b
     if (d.phong) launch_ph_backsub_eval(L, d);
     else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
+    if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks, d.part ? 1 : 0);
 }
 
-void launch_sep_pack(Launcher &L, const Dev &d) {
-    hipMemsetAsync(d.sepv, 0, (size_t)d.sepv_count * sizeof(double), L.stream);
-    LAUNCH(KC_SMALL, k_sep_pack, dim3(4), dim3(256), 0, d);
+void launch_sep_pack(Launcher &L, const Dev &d) {       // (the separator vector was cleared by k_finish_reduced)
+    LAUNCH(KC_SMALL, k_sep_pack, dim3(4), dim3(256), 0, d, d.phong ? 0 : (lm_split(d) ? d.n_groups : d.n_lm_blocks));
 }
 void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best) {
     LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
@@ -1952,9 +1964,6 @@ void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best) {
 }
 void launch_sep_scatter(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_sep_scatter, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
-}
-void launch_eval_add_pose(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_eval_add_pose, dim3(1), dim3(256), 0, d);
 }
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses) {
     LAUNCH(KC_SMALL, k_mask_unowned_poses, dim3((d.P + 255) / 256), dim3(256), 0, d, poses);
@@ -1972,7 +1981,7 @@ void launch_dogleg_eval(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, 0);
     if (d.phong) launch_ph_dogleg_eval(L, d);
     else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_eval<true> : k_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks);
+    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks, 0);
 }
 
 void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all, int n_pose_parts) {

@@ -107,7 +107,7 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
-void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)
+void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false, bool skip_reduce = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false);
 void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false);
 bool bcr_border_rides(const Dev &d);      // the border columns go through the forward part of the solve inside the factor / reduce launches
@@ -121,7 +121,6 @@ void launch_sep_pack(Launcher &L, const Dev &d);
 void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best = false);
 void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
-void launch_eval_add_pose(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false, bool pose_update_done = false);
 void launch_dogleg_eval(Launcher &L, const Dev &d);
