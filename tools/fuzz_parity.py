@@ -1,7 +1,8 @@
 """Randomised parity sweep (GPU box): small stereo problems of random shape -- pose count, landmark count, track length,
 constant poses, Huber loss, trust-region strategy; every fourth case with lighting terms (point / directional light,
 1-5 materials, shared blocks constant or free, with or without bounds) -- solved by the HIP path and by the CPU oracle;
-compares the cost trace, the accept / reject sequence and the final cost.   usage: python tools/fuzz_parity.py [cases] [seed]"""
+compares the cost trace, the accept / reject sequence and the final cost.
+usage: python tools/fuzz_parity.py [cases] [seed]  |  python tools/fuzz_parity.py mid [cases] [seed]  (mid_size below)"""
 import os
 import sys
 
@@ -64,7 +65,61 @@ def lighting_case(rng, c, P, L, T, seed):
     return 0 if ok else 1
 
 
+def mid_size(cases, seed0):
+    """Mid-size sweep: 13-600 poses (2-50 super-blocks: every depth of the cyclic-reduction plans, padded last blocks,
+    odd block counts), tracks up to 20 (the general path beyond 12), loop closures (border of the block-tridiagonal
+    system when the tracks allow it), constant poses, Huber; eight iterations of each run are compared."""
+    rng = np.random.default_rng(seed0)
+    bad = 0
+    for c in range(cases):
+        P = int(rng.integers(13, 600))
+        T = int(rng.integers(3, 13)) if rng.random() < 0.8 else int(rng.integers(13, 21))
+        L = int(rng.integers(8 * P, 30 * P))
+        seed = int(rng.integers(0, 10**6))
+        huber = float(rng.choice([0.0, 0.0, 1.345]))
+        closure = int(rng.choice([0, 0, 1, 2])) if P > 40 else 0       # 1: tracks stay within 12 observations (border), 2: within 40
+        prob = synth.make_problem(P, L, track_len=T, seed=seed, outlier_fraction=0.1 if huber > 0 else 0.0)
+        if closure:
+            prob = synth.add_loop_closure(prob, num_states=int(rng.integers(1, 5)), num_landmarks=int(rng.integers(20, 120)),
+                                          seed=seed, max_track=12 if closure == 1 else 40)      # (None: re-observations far outside the image, costs of 1e13)
+        pose_const = np.zeros(P, dtype=np.uint8)
+        pose_const[0] = 1
+        if rng.random() < 0.3:
+            pose_const[rng.integers(0, P, size=max(1, P // 20))] = 1
+        kw = dict(max_num_iterations=8, use_nonmonotonic_steps=1)
+        only = os.environ.get("FUZZ_ONLY")
+        if only is not None and int(only) != c:
+            continue
+        ba = StereoBA(prob.camera, prob.poses_init.copy(), prob.points_init.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                      prob.stiffness(), pose_const=pose_const, huber_a=huber)
+        s, log = ba.solve(capi.default_options(**kw))
+        mk = lambda: orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                                       prob.stiffness(), pose_const=pose_const, huber_a=huber)
+        op = mk()
+        s2, log2 = op.solve(orc.driver_options(num_threads=8, **kw))
+        _, log_b = mk().solve(orc.driver_options(num_threads=3, **kw))
+        nall = horizon(log2, log_b, min(len(log["cost"]), len(log2["cost"])))
+        acc_ok = log["step_is_successful"][:nall].tolist() == log2["step_is_successful"][:nall].tolist()
+        okm = np.asarray(log2["step_is_successful"][:nall], dtype=bool)
+        okm[0] = True
+        trace = float(np.max(np.abs(log["cost"][:nall][okm] - log2["cost"][:nall][okm]) / np.abs(log2["cost"][:nall][okm])))
+        dpose = float(np.abs(ba.poses - op.poses).max()) if nall == len(log2["cost"]) == len(log["cost"]) else float("nan")
+        ok = acc_ok and trace < 1e-6 and not dpose > 1e-6
+        bad += not ok
+        if only is not None:
+            for i in range(min(len(log["cost"]), len(log2["cost"]))):
+                print(f"   it {i}: hip {log['cost'][i]:.12e} {int(log['step_is_successful'][i])}  oracle {log2['cost'][i]:.12e} {int(log2['step_is_successful'][i])}  oracle(3 thr) {log_b['cost'][i]:.12e}")
+        print(f"mid {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} closure={closure} const={int(pose_const.sum()):2d} "
+              f"general={int(ba.stats().general_structure)} sb={int(ba.stats().num_superblocks)} iters={int(s.num_iterations):2d}/{int(s2.num_iterations):2d} "
+              f"horizon={nall:2d} trace={trace:.1e} dpose={dpose:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+        ba.close()
+    print("mismatches:", bad)
+    return 1 if bad else 0
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "mid":
+        return mid_size(int(sys.argv[2]) if len(sys.argv) > 2 else 40, int(sys.argv[3]) if len(sys.argv) > 3 else 11)
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
     bad = 0
