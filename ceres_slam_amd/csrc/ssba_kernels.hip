@@ -1889,11 +1889,11 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
 static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 262144; }
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
-static bool ctrl_fusable(const Dev &d) { return !d.phong && !d.dense && !d.part; }
+static bool ctrl_fusable(const Dev &d) { return !d.dense && !d.part; }       // (lighting terms included: same partial sums, same reduced system)
 // fuse_best (the copy of x to the best iterate rides in the update / evaluation kernels): no exchange sits between k_check's
 // decision and those kernels in any mode, so the partitioned multi-GPU solve takes it too
-static bool best_fusable(const Dev &d) { return !d.phong && !d.dense && lm_split(d); }
-bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && lm_split(d); }
+static bool best_fusable(const Dev &d) { return !d.dense && !d.nb && (d.phong || lm_split(d)); }       // (free shared blocks have a best copy of their own: k_best)
+bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && !d.phong && lm_split(d); }
 // fuse_all (single GPU, LM, windowed stereo layout, launch_can_fuse_all): the linearisation kernels commit the accepted
 // step on the way (no k_commit launch)
 // skip_reduce (partitioned solve): k_sep_pack(.., n_lin_parts) forms the sums of the partials
@@ -1911,16 +1911,10 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
 
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
-    const int n_zero = d.phong ? 0 : 128;       // the stereo Schur launch clears the reduced system on the way
+    // the reduced system is cleared on the way: by 128 extra workgroups of the stereo Schur launch, by k_ph_invert with lighting terms
+    const int n_zero = 128;
     if (d.phong) launch_ph_schur(L, d);
     else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero);
-    if (n_zero) {
-    } else if (d.part) {   // only this rank's chain is assembled and eliminated
-        const size_t n = (size_t)(d.chain1 - d.chain0 + 1) * BD * BD * sizeof(double);
-        hipMemsetAsync(d.xv + d.off_D + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
-        hipMemsetAsync(d.xv + d.off_L + (size_t)d.chain0 * BD * BD, 0, n, L.stream);
-    } else
-    hipMemsetAsync(d.xv + d.off_D, 0, (size_t)2 * d.Nsb * BD * BD * sizeof(double), L.stream);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6;
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0);
     if (d.cb) LAUNCH(KC_BORDER, k_cb_assemble, dim3((unsigned)(((size_t)d.n_cb * 36 + 255) / 256)), dim3(256), 0, d);
@@ -1946,7 +1940,7 @@ void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_be
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_best, bool pose_update_done) {
     const int fb = fuse_best && best_fusable(d) ? 1 : 0;
     if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
-    if (d.phong) launch_ph_backsub_eval(L, d);
+    if (d.phong) launch_ph_backsub_eval(L, d, fb);
     else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks, d.part ? 1 : 0);

@@ -283,10 +283,21 @@ static __device__ __forceinline__ void ph_damping(const Dev &d, const State &st,
 // ------------------------------------------------------------------ kernels ---
 // One lane per landmark: C^-1 = (H_ll + D^2)^-1 for the current radius; read by the Schur producers
 // and the back-substitution (a radius change alone re-runs this, not the linearisation).
+// Also clears the block-tridiagonal reduced system (D and L of every super-block; of this rank's chain in a partitioned
+// solve) that k_assemble_reduced fills after the Schur launch -- no memset launch.
 __global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     const int l = blockIdx.x * 256 + threadIdx.x;
+    {
+        const size_t b0 = d.part ? (size_t)d.chain0 * BD * BD : 0;
+        const size_t n2 = (d.part ? (size_t)(d.chain1 - d.chain0 + 1) : (size_t)d.Nsb) * (BD * BD / 2);       // double2 per range
+        double2 *zD = reinterpret_cast<double2 *>(d.xv + d.off_D + b0), *zL = reinterpret_cast<double2 *>(d.xv + d.off_L + b0);
+        for (size_t i = (size_t)l; i < n2; i += (size_t)gridDim.x * 256) {
+            zD[i] = make_double2(0.0, 0.0);
+            zL[i] = make_double2(0.0, 0.0);
+        }
+    }
     double Ci[21], Mf[21];
 #pragma unroll
     for (int c = 0; c < 21; ++c) { Ci[c] = 0.0; Mf[c] = 0.0; }
@@ -723,15 +734,21 @@ __global__ __launch_bounds__(256) void k_ph_spb_assemble(Dev d) {
     d.Spb[gid] = v;
 }
 
-template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_backsub_eval(Dev d) {
+// fuse_best (constant shared blocks): also does k_best's share for the landmarks (x -> best when the k_check of this
+// iteration saw the cost improve; before the termination test, like k_backsub_eval_w)
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_backsub_eval(Dev d, int fuse_best) {
     const State &st = *d.st;
-    if (st.terminated) return;
     __shared__ double sm[4];
     const int l = blockIdx.x * 256 + threadIdx.x;
     const uint32_t mask = d.lm_mask[l];
-    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
     LmIn x;
     load_lm(d, l, x);
+    if (fuse_best && st.copy_best == st.check_count) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { d.best_pts[(size_t)c * d.Lpad + l] = x.p[c]; d.best_nrm[(size_t)c * d.Lpad + l] = x.n[c]; }
+    }
+    if (st.terminated) return;
+    double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
     double np_[3] = {x.p[0], x.p[1], x.p[2]}, nn[3] = {x.n[0], x.n[1], x.n[2]};
     double dl[6] = {0, 0, 0, 0, 0, 0};
     if (mask && !st.step_failed) {
@@ -1532,9 +1549,9 @@ void launch_ph_schur(Launcher &L, const Dev &d) {
         else LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(BP_THREADS), 0, d);
     }
 }
-void launch_ph_backsub_eval(Launcher &L, const Dev &d) {
+void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
-    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_backsub_eval<true> : k_ph_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_backsub_eval<true> : k_ph_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, fuse_best);
 }
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
     if (d.nb) LAUNCH(KC_SMALL, k_ph_dogleg_border, dim3(1), dim3(64), 0, d);
