@@ -147,9 +147,10 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_landmarks(
 // reduces them across the block in a fixed order (no float atomics).
 // PS / PT: where the current iterate lives (the candidate buffers when the launch also commits the step the last
 // iteration accepted; then `commit` copies this pose into d.poses).  Call with the whole workgroup, k a free pose.
-template <bool DN> __device__ __forceinline__ void lin_pose_body(const Dev &d, int k, const double *__restrict__ PS,
+constexpr int LP_THREADS = 128, LP_CHUNK = 5;
+template <bool DN, int NT, int CH> __device__ __forceinline__ void lin_pose_body(const Dev &d, int k, const double *__restrict__ PS,
                                                                  const double *__restrict__ PT, bool commit) {
-    __shared__ double sm[4][27];
+    __shared__ double sm[NT / 64][27];
     double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = PS[(size_t)k * 12 + i];
@@ -177,7 +178,7 @@ template <bool DN> __device__ __forceinline__ void lin_pose_body(const Dev &d, i
 #pragma unroll
     for (int c = 0; c < 9; ++c) Sk[c] = d.S[c];
     if (DN) {
-        for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
+        for (uint32_t i = b + threadIdx.x; i < e; i += NT) {
             const uint32_t oi = d.dn_pose_obs[i];
             const int l = (int)d.dn_obs_lm[oi];
             double So[9];
@@ -186,14 +187,13 @@ template <bool DN> __device__ __forceinline__ void lin_pose_body(const Dev &d, i
             accumulate(So, PT[l], PT[(size_t)d.Lpad + l], PT[2 * (size_t)d.Lpad + l], d.dn_u[oi], d.dn_v[oi], d.dn_d[oi]);
         }
     } else {
-        // three observations per round: their references, then their 18 operands are in flight together (a rolled loop
+        // CH observations per round: their references, then their 6 CH operands are in flight together (a rolled loop
         // pays two dependent memory round trips per observation)
-        constexpr int CH = 3;
-        for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += 256 * CH) {
+        for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += NT * CH) {
             uint32_t ref[CH];
             double in[CH][6];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) ref[q] = i0 + 256 * q < e ? d.pose_obs_ref[i0 + 256 * q] : 0xFFFFFFFFu;
+            for (int q = 0; q < CH; ++q) ref[q] = i0 + NT * q < e ? d.pose_obs_ref[i0 + NT * q] : 0xFFFFFFFFu;
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 if (ref[q] == 0xFFFFFFFFu) continue;
@@ -214,7 +214,10 @@ template <bool DN> __device__ __forceinline__ void lin_pose_body(const Dev &d, i
     }
     __syncthreads();
     if (threadIdx.x < 28) {
-        double v = threadIdx.x < 27 ? sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x] : 0.0;
+        double v = 0.0;
+        if (threadIdx.x < 27)
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) v += sm[w][threadIdx.x];
         if (d.n_pf) {
             // unary residual blocks of this pose (pose prior, sun sensor): every one of the 28 lanes evaluates them
             // and takes its own entry of J^T J (21), J^T r (6) or the cost (lane 27)
@@ -234,12 +237,13 @@ template <bool DN> __device__ __forceinline__ void lin_pose_body(const Dev &d, i
         else if (threadIdx.x < 27) d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
         else if (d.n_pf) d.pf_cost[k] = v;
     }
-    if (commit && threadIdx.x >= 64 && threadIdx.x < 76) d.poses[(size_t)k * 12 + threadIdx.x - 64] = PS[(size_t)k * 12 + threadIdx.x - 64];
+    constexpr int CL = NT >= 128 ? 64 : 32;      // commit lanes: clear of the 28 lanes that store the sums
+    if (commit && threadIdx.x >= CL && threadIdx.x < CL + 12) d.poses[(size_t)k * 12 + threadIdx.x - CL] = PS[(size_t)k * 12 + threadIdx.x - CL];
 }
 // fuse (single GPU, LM): the step the decision kernel accepted is committed on the way -- the iterate is read from the
 // candidate buffers and this pose written to x (k_linearize_landmarks_w(.., fuse), which runs first, did the points and
 // read the candidate poses too), so k_commit is not launched.
-template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev d, int fuse) {
+template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_linearize_poses(Dev d, int fuse) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     if (d.pose_free[blockIdx.x] < 0) return;
@@ -252,19 +256,21 @@ template <bool DN> __global__ __launch_bounds__(256) void k_linearize_poses(Dev 
         const bool no_obs = DN ? d.dn_pose_start[k] == d.dn_pose_start[k + 1] : d.pose_obs_start[k] == d.pose_obs_start[k + 1];
         if (no_obs && (!d.n_pf || d.pf_start[k] == d.pf_start[k + 1])) return;
     }
-    lin_pose_body<DN>(d, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
+    lin_pose_body<DN, NT, CH>(d, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
 
-// Window layout, four lanes per landmark: one block = one group of 64 landmarks (the ELL unit), wave w takes the slots
-// w, w + 4, w + 8 of every landmark, so the loads stay coalesced (lane = landmark) and the poses of a wave are
-// broadcast reads, but four times as many waves hide the dependent fp64 chains of the linearisation.  The four
-// partial sums per landmark are combined through LDS in a fixed order by wave 0.
-constexpr int LMW_SPLIT = 4;
+// Window layout, SP lanes per landmark: one block = one group of 64 landmarks (the ELL unit), wave w takes the slots
+// w, w + SP, w + 2 SP, ... of every landmark, so the loads stay coalesced (lane = landmark) and the poses of a wave are
+// broadcast reads, but SP times as many waves hide the dependent fp64 chains of the linearisation.  The SP partial
+// sums per landmark are combined through LDS in a fixed order by wave 0.
+// Waves per 64 landmarks (template parameter SP of the two kernels).  Sweep on C2 (profiles/r02_landmark_kernel_shape.txt):
+// 1 / 2 / 3 / 4 / 6 waves -> 19.6 / 16.7 / 18.8 / 19.5 / 27.0 us (linearisation), 38.4 / 30.4 / 33.8 / 34.1 / 48.4 us (evaluation).
+constexpr int LMW_SPLIT = 2;
 // PS / PT / commit: see lin_pose_body
-__device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &st, int grp, const double *__restrict__ PS,
+template <int SP> __device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &st, int grp, const double *__restrict__ PS,
                                                      const double *__restrict__ PT, bool commit) {
-    __shared__ double sm[4];
-    __shared__ double red[LMW_SPLIT - 1][10][LMG];
+    __shared__ double sm[SP];
+    __shared__ double red[SP > 1 ? SP - 1 : 1][10][LMG];
     const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
     const int l = grp * LMG + li;
     const uint32_t mask = d.lm_mask[l];
@@ -273,7 +279,7 @@ __device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, cost = 0.0;
     if (mask) {
         const LmObs<false> ob(d, l, mask);
-        for (int s = w; s < TW; s += LMW_SPLIT) {
+        for (int s = w; s < TW; s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
             const double *T = PS + (size_t)k * 12;
@@ -307,7 +313,7 @@ __device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &
     double xn = 0.0, gm = 0.0;
     if (w == 0) {
 #pragma unroll
-        for (int q = 0; q < LMW_SPLIT - 1; ++q) {
+        for (int q = 0; q < SP - 1; ++q) {
 #pragma unroll
             for (int c = 0; c < 6; ++c) h[c] += red[q][c][li];
 #pragma unroll
@@ -340,11 +346,11 @@ __device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &
         d.part_lin[grp * 4 + 2] = c2;
     }
 }
-__global__ __launch_bounds__(256) void k_linearize_landmarks_w(Dev d, int fuse) {
+template <int SP> __global__ __launch_bounds__(64 * SP) void k_linearize_landmarks_w(Dev d, int fuse) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     const bool commit = fuse && st.accepted;
-    lin_landmarks_w_body(d, st, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
+    lin_landmarks_w_body<SP>(d, st, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
 
 
@@ -1201,15 +1207,15 @@ __global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts, int n_p
     decide_body(d, st, n_eval_parts, n_pose_parts);       // tests st.terminated itself, after its partial sums are read
 }
 
-// The same pass in the window layout with four lanes per landmark (see k_linearize_landmarks_w): wave w takes the slots
-// w, w + 4, w + 8; the partial sums of W^T delta_p and of the model-cost terms meet in LDS, every lane then forms
-// delta_l itself (fixed order, so the four lanes of a landmark hold identical candidates) and evaluates the candidate
+// The same pass in the window layout with SP lanes per landmark (see k_linearize_landmarks_w): wave w takes the slots
+// w, w + SP, ...; the partial sums of W^T delta_p and of the model-cost terms meet in LDS, every lane then forms
+// delta_l itself (fixed order, so the SP lanes of a landmark hold identical candidates) and evaluates the candidate
 // cost of its own slots.
 // fuse_best: also does k_best's share for the points (see k_pose_update)
-__global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
+template <int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_eval_w(Dev d, int fuse_best) {
     const State &st = *d.st;
-    __shared__ double sm[4];
-    __shared__ double red[LMW_SPLIT][5][LMG];
+    __shared__ double sm[SP];
+    __shared__ double red[SP][5][LMG];
     const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
     const int l = blockIdx.x * LMG + li;
     // operand reads first, the solver state (a cold read: see k_schur_windows) is tested with them in flight
@@ -1219,8 +1225,9 @@ __global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
         if (w == 0) { d.best_pts[l] = px; d.best_pts[(size_t)d.Lpad + l] = py; d.best_pts[2 * (size_t)d.Lpad + l] = pz; }
         // fuse_best == 2: the poses too (the reduced solve updated them itself, and it does nothing once the solver has
         // terminated -- the improving iterate may be the converged one)
-        const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x;
-        if (fuse_best == 2 && gi < (size_t)d.P * 12) d.best_poses[gi] = d.poses[gi];
+        if (fuse_best == 2)       // (grid-stride: few landmarks and many poses must still be covered)
+            for (size_t gi = (size_t)blockIdx.x * (64 * SP) + threadIdx.x; gi < (size_t)d.P * 12; gi += (size_t)gridDim.x * (64 * SP))
+                d.best_poses[gi] = d.poses[gi];
     }
     if (st.terminated) return;
     double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
@@ -1229,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
     const LmObs<false> ob(d, l, mask);
     double tp[3] = {0.0, 0.0, 0.0}, er = 0.0, ee = 0.0;
     if (act) {
-        for (int s = w; s < TW; s += LMW_SPLIT) {
+        for (int s = w; s < TW; s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
             const int f = d.pose_free[k];
@@ -1260,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
         double tt[3] = {gl[0], gl[1], gl[2]};
         er = 0.0; ee = 0.0;
 #pragma unroll
-        for (int q = 0; q < LMW_SPLIT; ++q) {
+        for (int q = 0; q < SP; ++q) {
             tt[0] += red[q][0][li]; tt[1] += red[q][1][li]; tt[2] += red[q][2][li];
             er += red[q][3][li]; ee += red[q][4][li];
         }
@@ -1286,7 +1293,7 @@ __global__ __launch_bounds__(256) void k_backsub_eval_w(Dev d, int fuse_best) {
             const double dt = dl[0] * (tt[0] - gl[0]) + dl[1] * (tt[1] - gl[1]) + dl[2] * (tt[2] - gl[2]);
             mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + (dl[0] * hd0 + dl[1] * hd1 + dl[2] * hd2));
         }
-        for (int s = w; s < TW; s += LMW_SPLIT) {
+        for (int s = w; s < TW; s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
             ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
@@ -1883,7 +1890,7 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
     hipLaunchKernelGGL(k_reset_state, dim3(1), dim3(64), 0, L.stream, d, o);
 }
 
-// Window layout: four lanes per landmark pay off while one lane per landmark leaves the SIMDs short of waves (C2: 1.5
+// Window layout: several lanes per landmark pay off while one lane per landmark leaves the SIMDs short of waves (C2: 1.5
 // waves per SIMD); from ~4 waves per SIMD on the plain mapping wins (C4: 15 600 waves; measured 0.106 / 0.224 ms vs
 // 0.133 / 0.272 ms for the split kernels).
 static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 262144; }
@@ -1902,9 +1909,11 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w, dim3(d.n_groups), dim3(256), 0, d, fuse_all ? 1 : 0);
+        if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true> : k_linearize_poses<false>), dim3(d.P), dim3(256), 0, d, fuse_all ? 1 : 0);
+        // 128 lanes per pose, five observations in flight per lane (sweep on C2, profiles/r02_pose_kernel_shape.txt: 64 / 128 / 192 /
+        // 256 / 512 lanes x 3-10 observations: 24.5 us here, 31 us for 256 x 3, 51 us for 512 x 3)
+        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true, LP_THREADS, LP_CHUNK> : k_linearize_poses<false, LP_THREADS, LP_CHUNK>), dim3(d.P), dim3(LP_THREADS), 0, d, fuse_all ? 1 : 0);
     }
     if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
@@ -1941,7 +1950,7 @@ void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_b
     const int fb = fuse_best && best_fusable(d) ? 1 : 0;
     if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
     if (d.phong) launch_ph_backsub_eval(L, d, fb);
-    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w, dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
+    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks, d.part ? 1 : 0);
 }
