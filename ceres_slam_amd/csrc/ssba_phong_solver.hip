@@ -390,34 +390,51 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_land
     }
 }
 
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_poses(Dev d) {
+template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_ph_linearize_poses(Dev d) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     const int k = blockIdx.x;
     if (d.pose_free[k] < 0) return;
-    __shared__ double sm[4][27];
+    __shared__ double sm[NT / 64][27];
     const double *T = d.poses + (size_t)k * 12;
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
     const uint32_t b = DN ? d.dn_pose_start[k] : d.pose_obs_start[k], e = DN ? d.dn_pose_start[k + 1] : d.pose_obs_start[k + 1];
-    for (uint32_t i = b + threadIdx.x; i < e; i += 256) {
-        int l;
-        size_t oi;
-        pose_list_entry<DN>(d, i, l, oi);
-        LmIn x;
-        load_lm(d, l, x);
-        const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-        ph_rows(d, d.sh, T, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true,
-                [&](auto, int, double r, const double *jp, const double *, const double *) {
-                    int n = 0;
+    // CH observations per round: their list entries, then their 13 operands each are in flight together (a rolled loop pays
+    // two dependent memory round trips per observation)
+    for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += NT * CH) {
+        int l[CH];
+        size_t oi[CH];
+        LmIn x[CH];
+        double in[CH][7];
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        acc[21 + a] += jp[a] * r;
+        for (int q = 0; q < CH; ++q) {
+            l[q] = -1;
+            if (i0 + NT * q < e) pose_list_entry<DN>(d, i0 + NT * q, l[q], oi[q]);
+        }
 #pragma unroll
-                        for (int c = a; c < 6; ++c) acc[n++] += jp[a] * jp[c];
-                    }
-                });
+        for (int q = 0; q < CH; ++q) {
+            if (l[q] < 0) continue;
+            load_lm(d, l[q], x[q]);
+            in[q][0] = d.onx[oi[q]]; in[q][1] = d.ony[oi[q]]; in[q][2] = d.onz[oi[q]];
+            in[q][3] = d.ou[oi[q]]; in[q][4] = d.ov[oi[q]]; in[q][5] = d.od[oi[q]]; in[q][6] = d.oi[oi[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            if (l[q] < 0) continue;
+            const double nobs[3] = {in[q][0], in[q][1], in[q][2]};
+            ph_rows(d, d.sh, T, x[q], in[q][3], in[q][4], in[q][5], in[q][6], nobs, true,
+                    [&](auto, int, double r, const double *jp, const double *, const double *) {
+                        int n = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) {
+                            acc[21 + a] += jp[a] * r;
+#pragma unroll
+                            for (int c = a; c < 6; ++c) acc[n++] += jp[a] * jp[c];
+                        }
+                    });
+        }
     }
 #pragma unroll
     for (int i = 0; i < 27; ++i) {
@@ -426,7 +443,9 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_linearize_poses(D
     }
     __syncthreads();
     if (threadIdx.x < 27) {
-        const double v = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) v += sm[w][threadIdx.x];
         if (threadIdx.x < 21) d.hpp[(size_t)k * 21 + threadIdx.x] = v;
         else d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
     }
@@ -1482,7 +1501,10 @@ __global__ void k_ph_ls_accept(Dev d) {
 
 void launch_ph_linearize(Launcher &L, const Dev &d) {
     LAUNCH(KC_LIN_LM, (d.dense ? k_ph_linearize_landmarks<true> : k_ph_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_LIN_POSE, (d.dense ? k_ph_linearize_poses<true> : k_ph_linearize_poses<false>), dim3(d.P), dim3(256), 0, d);
+    // two observations in flight per lane: 54 us against 60 for the rolled loop at C3; three need 274 registers and lose (75 us),
+    // 128 lanes per pose lose too (64-76 us) -- unlike the stereo kernel, whose 175 registers leave room for five
+    if (d.dense) LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<true, 256, 1>), dim3(d.P), dim3(256), 0, d);
+    else LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<false, 256, 2>), dim3(d.P), dim3(256), 0, d);
     if (d.nb) LAUNCH(KC_BORDER, (d.dense ? k_ph_border_landmarks<true> : k_ph_border_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (d.lmMV) LAUNCH(KC_BORDER, k_ph_hpb, dim3(d.P * d.M), dim3(64), 0, d);
 }

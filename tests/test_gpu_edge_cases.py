@@ -54,6 +54,16 @@ def assert_fixed_count_parity(ba, op, K, cost_rtol=1e-7, threads=4, **kw):
     return s, log, s2, log2
 
 
+def test_many_poses_few_landmarks():
+    """Fewer landmark groups than pose blocks: the copies of the best iterate that ride in the landmark kernels (twelve
+    doubles per pose spread over the lanes of the evaluation launch) must still cover every pose -- 150 poses with 10
+    groups of 64 landmarks are 1 800 doubles for 1 280 lanes."""
+    prob = synth.make_problem(150, 600, track_len=8, seed=5)
+    ba, s, log, op, s2, log2 = _solve_both(prob)
+    assert ba.stats().general_structure == 0
+    _assert_same_solve(ba, s, log, op, s2, log2)
+
+
 @pytest.mark.parametrize("num_poses", [2, 3, 12, 13, 14, 25, 26, 37, 49, 61, 97, 150])
 def test_bcr_block_count_edges(num_poses):
     """1, 2, 3, ... super-blocks incl. padded last blocks and odd/even level sizes."""
