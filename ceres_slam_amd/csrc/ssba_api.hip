@@ -1429,6 +1429,7 @@ int ssba_finalize(ssba_problem *p) {
         if (!dn_blk_rf.empty()) { TRY(dupload(p, &d.dn_blk_rf_start, dn_blk_rf_start)); TRY(dupload(p, &d.dn_blk_rf, dn_blk_rf)); }
         TRY(dupload(p, &d.dn_rows, dplan.rows)); TRY(dupload(p, &d.dn_ti, dplan.ti)); TRY(dupload(p, &d.dn_tk, dplan.tk));
         TRY(dupload(p, &d.dn_cols, dplan.cols));
+        TRY(dupload(p, &d.dn_row_start, dplan.row_start));
         p->launcher.dense = dplan;
         TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
@@ -1460,6 +1461,7 @@ int ssba_finalize(ssba_problem *p) {
             if (upload_bcr_tables(p->launcher.stream)) { set_error("BCR tile table upload failed"); return SSBA_ERR_HIP; }
             if (configure_schur()) { set_error("hipFuncSetAttribute(k_schur_windows) failed"); return SSBA_ERR_HIP; }
             if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
+            if (configure_dense()) { set_error("hipFuncSetAttribute(k_dn_*_mf) failed"); return SSBA_ERR_HIP; }
             flags |= 1;
         }
         if (ph && !(flags & 2)) {

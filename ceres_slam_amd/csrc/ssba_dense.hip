@@ -23,6 +23,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssba_types.h"
 #include "ssba_launch.h"
@@ -74,37 +75,55 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
     }
 }
 
-// One work-group per block.  Every thread takes every 256th observation pair of the block and accumulates the whole
-// 6x6 product Y_a W_b^T in registers (the loads of different pairs are independent: the kernel is bound by the
-// latency of the two gathers per pair, so pairs are spread over as many lanes as possible); the 36 partial sums are
-// then reduced over the wave by shuffles and over the four waves through LDS, both in a fixed order.
-template <int LD> __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {      // LD = 3 (position) or 6 (position + normal)
+// One work-group per block.  Every thread takes every NT-th observation pair of the block and accumulates the whole
+// 6x6 product Y_a W_b^T in registers; the 36 partial sums are then reduced over the wave by shuffles and over the waves
+// through LDS, both in a fixed order.  The kernel is bound by the two gathers per pair: ONE wave per block with three
+// pairs in flight per lane beats four waves with one (P = 600, tracks of 24: 1.41 against 1.91 ms; 64 x 1: 1.54,
+// 128 x 2: 1.49, 64 x 4: 1.41) -- the cross-wave reduction and the workgroup's tail cost more than the parallelism brings.
+template <int LD, int NT, int CH> __global__ __launch_bounds__(NT) void k_dn_schur(Dev d) {      // LD = 3 (position) or 6 (position + normal)
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
-    __shared__ double part[4][36];
+    __shared__ double part[NT / 64][36];
     const int blk = blockIdx.x;
     const uint32_t a = d.dn_blk_a[blk], b = d.dn_blk_b[blk];
     double acc[36];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0.0;
-    for (uint32_t i = d.dn_blk_start[blk] + threadIdx.x; i < d.dn_blk_start[blk + 1]; i += 256) {
-        const double2 *Y2 = reinterpret_cast<const double2 *>(d.dn_Y + (size_t)d.dn_pair_a[i] * (6 * LD));
-        const double2 *W2 = reinterpret_cast<const double2 *>(d.dn_W + (size_t)d.dn_pair_b[i] * (6 * LD));
-        double y[6 * LD], w[6 * LD];
+    // CH pairs per round: their two references, then their 2 x 6 LD operands are in flight together
+    const uint32_t ie = d.dn_blk_start[blk + 1];
+    for (uint32_t i0 = d.dn_blk_start[blk] + threadIdx.x; i0 < ie; i0 += NT * CH) {
+        uint32_t pa[CH], pb[CH];
+        double y[CH][6 * LD], w[CH][6 * LD];
 #pragma unroll
-        for (int q = 0; q < 3 * LD; ++q) {
-            const double2 yv = Y2[q], wv = W2[q];
-            y[2 * q] = yv.x; y[2 * q + 1] = yv.y; w[2 * q] = wv.x; w[2 * q + 1] = wv.y;
+        for (int u = 0; u < CH; ++u) {
+            const bool on = i0 + NT * u < ie;
+            pa[u] = on ? d.dn_pair_a[i0 + NT * u] : 0xFFFFFFFFu;
+            pb[u] = on ? d.dn_pair_b[i0 + NT * u] : 0u;
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int u = 0; u < CH; ++u) {
+            if (pa[u] == 0xFFFFFFFFu) continue;
+            const double2 *Y2 = reinterpret_cast<const double2 *>(d.dn_Y + (size_t)pa[u] * (6 * LD));
+            const double2 *W2 = reinterpret_cast<const double2 *>(d.dn_W + (size_t)pb[u] * (6 * LD));
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                double v = acc[6 * r + c];
-#pragma unroll
-                for (int m = 0; m < LD; ++m) v += y[LD * r + m] * w[LD * c + m];
-                acc[6 * r + c] = v;
+            for (int q = 0; q < 3 * LD; ++q) {
+                const double2 yv = Y2[q], wv = W2[q];
+                y[u][2 * q] = yv.x; y[u][2 * q + 1] = yv.y; w[u][2 * q] = wv.x; w[u][2 * q + 1] = wv.y;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (pa[u] == 0xFFFFFFFFu) continue;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    double v = acc[6 * r + c];
+#pragma unroll
+                    for (int m = 0; m < LD; ++m) v += y[u][LD * r + m] * w[u][LD * c + m];
+                    acc[6 * r + c] = v;
+                }
+        }
     }
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -115,7 +134,9 @@ template <int LD> __global__ __launch_bounds__(256) void k_dn_schur(Dev d) {    
     __syncthreads();
     if (threadIdx.x >= 36) return;
     const int el = threadIdx.x, r = el / 6, c = el - r * 6;
-    double v = -(part[0][el] + part[1][el] + part[2][el] + part[3][el]);
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) v -= part[w][el];
     if (d.dn_blk_rf)      // relative-pose blocks coupling the two poses of this block: J_a^T J_b
         for (uint32_t q = d.dn_blk_rf_start[blk]; q < d.dn_blk_rf_start[blk + 1]; ++q) {
             const uint32_t ent = d.dn_blk_rf[q];
@@ -289,6 +310,132 @@ __global__ __launch_bounds__(256) void k_dn_syrk(Dev d, int j, const uint32_t *t
         for (int b = 0; b < 4; ++b) C[(size_t)(ty + 16 * a) * lda + tx + 16 * b] -= acc[a][b];
 }
 
+// ---- the same two steps on the fp64 matrix cores ---------------------------------------------------------------
+// v_mfma_f64_16x16x4_f64: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[row = (lane >> 4) + 4 reg][col = lane & 15].
+// A 64 x 64 block is a 4 x 4 grid of 16 x 16 tiles; wave w of a 256-thread work-group owns tile row w.  Operands sit
+// row-major in LDS with a row stride of 68 doubles: a lane reads element (16 t + (lane & 15), 4 ks + (lane >> 4)), i.e.
+// bank (8 (lane & 15) + 2 (lane >> 4)) mod 64 -- every even bank exactly twice per 64-lane read, the minimum for 8-byte reads.
+typedef double dn_d4 __attribute__((ext_vector_type(4)));
+constexpr int DN_LS = 68;
+constexpr int DN_MF_THREADS = 256;
+
+// 64 x 64 doubles, row-major with stride lda in global memory -> LDS (stride DN_LS), coalesced 16-byte loads
+static __device__ __forceinline__ void dn_stage(double *__restrict__ dst, const double *__restrict__ src, size_t lda) {
+#pragma unroll
+    for (int q = 0; q < (DN_BS * DN_BS / 2) / DN_MF_THREADS; ++q) {
+        const int idx = q * DN_MF_THREADS + (int)threadIdx.x, row = idx / (DN_BS / 2), c2 = idx - row * (DN_BS / 2);
+        const double2 v = *reinterpret_cast<const double2 *>(src + (size_t)row * lda + 2 * c2);
+        *reinterpret_cast<double2 *>(dst + row * DN_LS + 2 * c2) = v;
+    }
+}
+
+// trailing update A_ik -= L_ij L_kj^T on the matrix cores: one 64 x 64 tile per work-group, both panels staged in LDS,
+// wave w accumulates tile row w (four accumulators, 16 steps of k = 4)
+__global__ __launch_bounds__(DN_MF_THREADS) void k_dn_syrk_mf(Dev d, int j, const uint32_t *ti, const uint32_t *tk) {
+    const State &st = *d.st;
+    const int i = (int)ti[blockIdx.x], k = (int)tk[blockIdx.x];
+    extern __shared__ __align__(16) double dn_lds[];
+    double *sA = dn_lds, *sB = dn_lds + DN_BS * DN_LS;
+    const size_t lda = (size_t)d.dn_pad;
+    // (a dead launch reads panels that hold no factor -- harmless -- and leaves before it writes)
+    dn_stage(sA, d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)j * DN_BS, lda);
+    if (k != i) dn_stage(sB, d.dn_S + ((size_t)k * DN_BS) * lda + (size_t)j * DN_BS, lda);
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    __syncthreads();
+    const double *pB = k != i ? sB : sA;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    dn_d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = dn_d4{0.0, 0.0, 0.0, 0.0};
+    const double *pa = sA + (16 * w + li) * DN_LS + kq, *pb = pB + li * DN_LS + kq;
+#pragma unroll 4
+    for (int ks = 0; ks < DN_BS / 4; ++ks) {
+        const double a = pa[4 * ks];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[16 * t * DN_LS + 4 * ks], acc[t], 0, 0, 0);
+    }
+    double *C = d.dn_S + ((size_t)i * DN_BS + 16 * w + kq) * lda + (size_t)k * DN_BS + li;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * lda + 16 * t] -= acc[t][r];
+}
+
+// rows of the panel below the diagonal block, X = A L_jj^-T, blocked by 16 on the matrix cores:
+//   X_b = (A_b - sum_{c < b} X_c L_bc^T) inv(L_bb)^T,   b = 0 .. 3,
+// with the four 16 x 16 diagonal inverses formed first (wave w inverts block w: lane c < 16 solves L_ww x = e_c by forward
+// substitution, broadcast reads of L from LDS).  Wave w owns the 16 rows of tile row w; a result tile goes through LDS to
+// change from the accumulator layout to the A-operand layout (wave-private rows, but the barrier keeps the code simple).
+__global__ __launch_bounds__(DN_MF_THREADS) void k_dn_trsm_mf(Dev d, int j, const uint32_t *rows) {
+    const State &st = *d.st;
+    extern __shared__ __align__(16) double dn_lds[];
+    double *sX = dn_lds, *sL = dn_lds + DN_BS * DN_LS, *sI = sL + DN_BS * DN_LS;       // A -> X in place | L_jj | the four inverses [b][r][c], stride DN_LS/4... see below
+    const size_t lda = (size_t)d.dn_pad;
+    const int i = (int)rows[blockIdx.x];
+    dn_stage(sX, d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)j * DN_BS, lda);
+    dn_stage(sL, d.dn_S + ((size_t)j * DN_BS) * lda + (size_t)j * DN_BS, lda);
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    // inverse of diagonal block w: column li (lanes 0..15), stored row-major at sI[(16 w + r) * 20 + c]
+    constexpr int IS = 20;      // row stride of an inverse block (16 + 4: keeps the operand reads below conflict-free in pairs)
+    if (lane < 16) {
+        const double *Lw = sL + (16 * w) * DN_LS + 16 * w;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double sum = r == li ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < r; ++c) sum -= Lw[r * DN_LS + c] * x[c];      // x[c] = 0 for c < li: the products vanish
+            x[r] = r >= li ? sum / Lw[r * DN_LS + r] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sI[(16 * w + r) * IS + li] = x[r];
+    }
+    __syncthreads();
+    for (int b = 0; b < 4; ++b) {
+        // T = A_b - sum_{c<b} X_c L_bc^T   (rows of wave w)
+        dn_d4 t4;
+        {
+            const double *src = sX + (16 * w + kq) * DN_LS + 16 * b + li;
+            t4 = dn_d4{src[0], src[4 * DN_LS], src[8 * DN_LS], src[12 * DN_LS]};
+        }
+        for (int c = 0; c < b; ++c) {
+            const double *pa = sX + (16 * w + li) * DN_LS + 16 * c + kq;             // X_c as the A operand
+            const double *pb = sL + (16 * b + li) * DN_LS + 16 * c + kq;             // B[k][jj] = L[16 b + jj][16 c + k]
+            dn_d4 neg = dn_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) neg = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], neg, 0, 0, 0);
+            t4 -= neg;
+        }
+        __syncthreads();       // every wave has read column block b of its rows (and the finished blocks) before it is overwritten
+        {
+            double *dst = sX + (16 * w + kq) * DN_LS + 16 * b + li;
+            dst[0] = t4[0]; dst[4 * DN_LS] = t4[1]; dst[8 * DN_LS] = t4[2]; dst[12 * DN_LS] = t4[3];
+        }
+        __syncthreads();
+        // X_b = T inv(L_bb)^T:  A = T (from LDS), B[k][jj] = inv[jj][k]
+        const double *pa = sX + (16 * w + li) * DN_LS + 16 * b + kq;
+        const double *pb = sI + (16 * b + li) * IS + kq;
+        dn_d4 x4 = dn_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) x4 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], x4, 0, 0, 0);
+        __syncthreads();
+        {
+            double *dst = sX + (16 * w + kq) * DN_LS + 16 * b + li;
+            dst[0] = x4[0]; dst[4 * DN_LS] = x4[1]; dst[8 * DN_LS] = x4[2]; dst[12 * DN_LS] = x4[3];
+        }
+        __syncthreads();
+    }
+    // X -> global, coalesced rows
+    double *A = d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)j * DN_BS;
+#pragma unroll
+    for (int q = 0; q < (DN_BS * DN_BS / 2) / DN_MF_THREADS; ++q) {
+        const int idx = q * DN_MF_THREADS + (int)threadIdx.x, row = idx / (DN_BS / 2), c2 = idx - row * (DN_BS / 2);
+        *reinterpret_cast<double2 *>(A + (size_t)row * lda + 2 * c2) = *reinterpret_cast<const double2 *>(sX + row * DN_LS + 2 * c2);
+    }
+}
+
 // Back-substitution L^T x = y in the rhs row, right-looking: step i (block row i of L, x_i known) subtracts
 // L_ij^T x_i from y_j for the non-zero blocks j < i (cols[], one work-group each); the last work-group owns
 // j = i - 1, whose y is complete after its own update, and solves x_{i-1} = L_{i-1,i-1}^-T y_{i-1} right away.
@@ -333,6 +480,61 @@ __global__ __launch_bounds__(256) void k_dn_bwd(Dev d, int i, const uint32_t *co
     xrow[j * DN_BS + c] = v;
 }
 
+// The whole back-substitution of one right-hand-side row in ONE work-group (one per row, all rows in one launch),
+// left-looking: for block column j = nbk - 1 .. 0,  y_j -= sum_{i > j} L_ij^T x_i  over the non-zero blocks of column j
+// (rows[] of the factorisation plan; the x_i are final), then x_j = L_jj^-T y_j by wave 0.  A banded problem has ~3
+// blocks per column: ~5 us per step against a launch (~18 us) per step of k_dn_bwd -- the chain of nbk dependent launches
+// per row was a sixth of a general-structure iteration.
+__global__ __launch_bounds__(256) void k_dn_bwd_all(Dev d, int nbk) {
+    const State &st = *d.st;
+    if (st.terminated || st.step_failed || st.dl_reuse) return;
+    __shared__ double part[4][DN_BS];
+    const size_t lda = (size_t)d.dn_pad;
+    const int row = blockIdx.x, tid = threadIdx.x, c = tid & 63, q = tid >> 6;
+    double *xrow = d.dn_S + (size_t)(d.dn_pad + row) * lda;
+    for (int j = nbk - 1; j >= 0; --j) {
+        double s = 0.0;
+        const uint32_t r0 = d.dn_row_start[j], r1 = d.dn_row_start[j + 1] - 1;       // the last entry is the right-hand-side block row
+        // the factor is read once, from HBM, by this one work-group: all loads of a block are issued before the first is
+        // used (a rolled loop pays a memory round trip per row).  Wave 0 keeps column c of L_jj in registers for the solve.
+        const double *Lj = d.dn_S + ((size_t)j * DN_BS) * lda + (size_t)j * DN_BS;
+        double tc[DN_BS];
+        if (q == 0) {
+#pragma unroll
+            for (int m = 0; m < DN_BS; ++m) tc[m] = Lj[(size_t)m * lda + c];
+        }
+        for (uint32_t e = r0; e < r1; ++e) {
+            const int i = (int)d.dn_rows[e];
+            const double *Lij = d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)j * DN_BS;
+            const double *xi = xrow + (size_t)i * DN_BS;
+            double lv[DN_BS / 4], xv[DN_BS / 4];
+#pragma unroll
+            for (int m = 0; m < DN_BS / 4; ++m) { lv[m] = Lij[(size_t)(q + 4 * m) * lda + c]; xv[m] = xi[q + 4 * m]; }
+#pragma unroll
+            for (int m = 0; m < DN_BS / 4; ++m) s += lv[m] * xv[m];
+        }
+        part[q][c] = s;
+        __syncthreads();
+        if (q == 0) {
+            double v = xrow[j * DN_BS + c] - (part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+            // one wave: lane c owns x_c and column c of L_jj (= row c of L_jj^T); the finished x_m travels by v_readlane
+            double rdiag = 1.0;
+#pragma unroll
+            for (int m = 0; m < DN_BS; ++m) rdiag = c == m ? 1.0 / tc[m] : rdiag;
+#pragma unroll
+            for (int m = DN_BS - 1; m >= 0; --m) {
+                const double xm = lane_value(v * rdiag, m);
+                v = c == m ? xm : (c < m ? v - tc[m] * xm : v);
+            }
+            const int g = j * DN_BS + c;
+            if (g < d.n_dn && row == 0) d.x0[g] = v;
+            xrow[j * DN_BS + c] = v;
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+}
+
 // free shared blocks on the general layout: the columns of S_pb ride as rows 1..nb of the right-hand-side block row,
 // so the factorisation forward-solves them and k_dn_bwd back-substitutes them like the solve's own right-hand side
 __global__ __launch_bounds__(256) void k_dn_border_rows(Dev d, int store) {
@@ -349,17 +551,23 @@ __global__ __launch_bounds__(256) void k_dn_border_rows(Dev d, int store) {
 }
 
 // ----------------------------------------------------------------- launchers ---
+constexpr size_t DN_SYRK_LDS = (size_t)2 * DN_BS * DN_LS * sizeof(double);                       // 69 632 B
+constexpr size_t DN_TRSM_LDS = (size_t)(2 * DN_BS * DN_LS + DN_BS * 20) * sizeof(double);       // 79 872 B
+int configure_dense() {
+    if (hipFuncSetAttribute((const void *)k_dn_syrk_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYRK_LDS) != hipSuccess) return -1;
+    return hipFuncSetAttribute((const void *)k_dn_trsm_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_TRSM_LDS) == hipSuccess ? 0 : -1;
+}
 void launch_dense_schur(Launcher &L, const Dev &d) {
     if (d.dn_pad > 0) hipMemsetAsync(d.dn_S, 0, (size_t)(d.dn_pad + DN_BS) * d.dn_pad * sizeof(double), L.stream);
     if (d.phong) {       // 6-D landmark blocks: C^-1 first, W / Y are 6x6 (ssba_phong_solver.hip)
         launch_ph_dense_wy(L, d);
-        LAUNCH(KC_SCHUR, k_dn_schur<6>, dim3(d.dn_nblk), dim3(256), 0, d);
+        LAUNCH(KC_SCHUR, (k_dn_schur<6, 64, 2>), dim3(d.dn_nblk), dim3(64), 0, d);
         LAUNCH(KC_ASSEMBLE, k_dn_rhs<6>, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
         if (d.nb) launch_ph_dense_border(L, d);
         return;
     }
     LAUNCH(KC_SCHUR, k_dn_wy, dim3((d.n_obs + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SCHUR, k_dn_schur<3>, dim3(d.dn_nblk), dim3(256), 0, d);
+    LAUNCH(KC_SCHUR, (k_dn_schur<3, 64, 3>), dim3(d.dn_nblk), dim3(64), 0, d);
     LAUNCH(KC_ASSEMBLE, k_dn_rhs<3>, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
 }
 
@@ -370,6 +578,9 @@ void launch_dense_finish(Launcher &L, const Dev &d) {
 void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows) {
     const DensePlan &pl = L.dense;
     const int nbk = pl.nbk;
+    // SSBA_DENSE_VALU=1: the panel solve and the trailing update on the fp64 VALU (the r01 kernels; A/B partner, tests)
+    const char *lv = getenv("SSBA_DENSE_VALU");
+    const bool legacy = lv && lv[0] == '1';
     const bool border = d.nb > 0 && n_rhs_rows == 1;      // the solve of an iteration (not the covariance's unit rows)
     if (border) {
         LAUNCH(KC_BORDER, k_dn_border_rows, dim3((d.n_dn + 255) / 256), dim3(256), 0, d, 0);
@@ -378,9 +589,16 @@ void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows) {
     for (int j = 0; j < nbk; ++j) {
         const uint32_t r0 = pl.row_start[j], nr = pl.row_start[j + 1] - r0, t0 = pl.tile_start[j], nt = pl.tile_start[j + 1] - t0;
         LAUNCH(KC_BCR_FACTOR, k_dn_potrf, dim3(1), dim3(64), 0, d, j);
-        LAUNCH(KC_BCR_FACTOR, k_dn_trsm, dim3(nr), dim3(64), 0, d, j, d.dn_rows + r0);
-        LAUNCH(KC_BCR_REDUCE, k_dn_syrk, dim3(nt), dim3(256), 0, d, j, d.dn_ti + t0, d.dn_tk + t0);
+        if (legacy) {
+            LAUNCH(KC_BCR_FACTOR, k_dn_trsm, dim3(nr), dim3(64), 0, d, j, d.dn_rows + r0);
+            LAUNCH(KC_BCR_REDUCE, k_dn_syrk, dim3(nt), dim3(256), 0, d, j, d.dn_ti + t0, d.dn_tk + t0);
+        } else {
+            LAUNCH(KC_BCR_FACTOR, k_dn_trsm_mf, dim3(nr), dim3(DN_MF_THREADS), DN_TRSM_LDS, d, j, d.dn_rows + r0);
+            LAUNCH(KC_BCR_REDUCE, k_dn_syrk_mf, dim3(nt), dim3(DN_MF_THREADS), DN_SYRK_LDS, d, j, d.dn_ti + t0, d.dn_tk + t0);
+        }
     }
+    if (!legacy) LAUNCH(KC_BCR_BACKSUB, k_dn_bwd_all, dim3(n_rhs_rows), dim3(256), 0, d, nbk);
+    else
     for (int row = 0; row < n_rhs_rows; ++row)
         for (int i = nbk; i >= 1; --i) {
             const uint32_t c0 = pl.col_start[i], nc = pl.col_start[i + 1] - c0;

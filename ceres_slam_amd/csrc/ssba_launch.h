@@ -101,6 +101,7 @@ int upload_pair_table(hipStream_t s);
 int upload_bcr_tables(hipStream_t s);
 int configure_kernels();
 int configure_schur();
+int configure_dense();
 // matrix-core block factor / reduce of the reduced-camera solve (ssba_bcr_mfma.hip)
 int configure_bcr_mf();
 void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, int solve = 0);

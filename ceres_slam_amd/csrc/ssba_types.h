@@ -230,7 +230,7 @@ struct Dev {
     const uint32_t *dn_blk_rf_start, *dn_blk_rf;    // per block: relative-pose entries (first half | bit 31: block is J_2^T J_1), or null
     // block-level (DN_BS) symbolic factorisation: non-zero block rows below the diagonal of every block column
     // (the rhs row last), the tile pairs of every trailing update, and the non-zero block columns of every block row
-    const uint32_t *dn_rows, *dn_ti, *dn_tk, *dn_cols;
+    const uint32_t *dn_rows, *dn_ti, *dn_tk, *dn_cols, *dn_row_start;
     double *dn_S;                                   // (dn_pad + DN_BS) x dn_pad, row-major, lower triangle; row dn_pad holds the
                                                     // right-hand side, so the factorisation leaves L^-1 rhs there
 };
