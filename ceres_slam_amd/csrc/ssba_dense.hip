@@ -340,13 +340,18 @@ __global__ __launch_bounds__(DN_MF_THREADS) void k_dn_syrk_mf(Dev d, int j, cons
     // (a dead launch reads panels that hold no factor -- harmless -- and leaves before it writes)
     dn_stage(sA, d.dn_S + ((size_t)i * DN_BS) * lda + (size_t)j * DN_BS, lda);
     if (k != i) dn_stage(sB, d.dn_S + ((size_t)k * DN_BS) * lda + (size_t)j * DN_BS, lda);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    // the tile to be updated is read while the panels are still on their way (all three come from HBM: the panels were
+    // written on other XCDs a launch ago; read after the product, this round trip alone was 6 of the launch's 15.7 us)
+    double *C = d.dn_S + ((size_t)i * DN_BS + 16 * w + kq) * lda + (size_t)k * DN_BS + li;
+    dn_d4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = -C[(size_t)(4 * r) * lda + 16 * t];
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     __syncthreads();
     const double *pB = k != i ? sB : sA;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
-    dn_d4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = dn_d4{0.0, 0.0, 0.0, 0.0};
     const double *pa = sA + (16 * w + li) * DN_LS + kq, *pb = pB + li * DN_LS + kq;
 #pragma unroll 4
     for (int ks = 0; ks < DN_BS / 4; ++ks) {
@@ -354,11 +359,10 @@ __global__ __launch_bounds__(DN_MF_THREADS) void k_dn_syrk_mf(Dev d, int j, cons
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[16 * t * DN_LS + 4 * ks], acc[t], 0, 0, 0);
     }
-    double *C = d.dn_S + ((size_t)i * DN_BS + 16 * w + kq) * lda + (size_t)k * DN_BS + li;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * lda + 16 * t] -= acc[t][r];
+        for (int r = 0; r < 4; ++r) C[(size_t)(4 * r) * lda + 16 * t] = -acc[t][r];       // -( -C + L L^T ) = C - L L^T
 }
 
 // rows of the panel below the diagonal block, X = A L_jj^-T, blocked by 16 on the matrix cores:
