@@ -1440,6 +1440,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_groups * 4));       // one entry per block of 256 landmarks, or per group of 64 (window layout)
     TRY(dzero(p, &d.part_eval, (size_t)d.n_groups * 4));
+    TRY(dzero(p, &d.part_chk, (size_t)std::max<uint32_t>(d.nfree, 1) * 2));
     TRY(dzero(p, &d.part_pose, (size_t)(std::max(d.n_pose_blocks, d.Nsb) + 1) * NPP));   // + one entry for the border of shared blocks
     TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks + 1) * NDL));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));

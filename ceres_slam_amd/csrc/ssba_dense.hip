@@ -11,10 +11,14 @@
 //                of relative-pose blocks; writes the lower triangle of the dense matrix
 //   k_dn_rhs     one wave per free pose: reduced gradient g_p - sum Y g_l, stored as an extra row of the matrix
 //   k_dn_finish  Jacobi scale at iteration 0, LM damping on the diagonal
-//   k_dn_potrf / k_dn_trsm / k_dn_syrk   right-looking blocked Cholesky (DN_BS = 64); the extra rows (the right-hand
-//                side, the columns of S_pb for free shared blocks, unit vectors for a covariance block) are
-//                forward-solved as part of the factorisation
-//   k_dn_bwd     right-looking block back-substitution with L^T, one sweep per extra row -> pose step x0, S_pp^-1 S_pb
+//   k_dn_potrf / k_dn_trsm_mf / k_dn_syrk_mf   right-looking blocked Cholesky (DN_BS = 64): the diagonal block by one wave
+//                (rows in registers, v_readlane), the panel solve and the trailing update on the fp64 matrix cores
+//                (v_mfma_f64_16x16x4_f64; the panel solve blocked by 16 with explicit inverses of the diagonal 16 x 16
+//                blocks).  The extra rows (the right-hand side, the columns of S_pb for free shared blocks, unit vectors
+//                for a covariance block) are forward-solved as part of the factorisation.  k_dn_trsm / k_dn_syrk: the
+//                same two steps on the fp64 VALU (r01; SSBA_DENSE_VALU=1, the A/B partner)
+//   k_dn_bwd_all block back-substitution with L^T, left-looking, the whole sweep of one extra row in ONE work-group (all
+//                rows in one launch) -> pose step x0, S_pp^-1 S_pb.  k_dn_bwd: one launch per block column (r01)
 // The factorisation skips zero 64x64 blocks: ssba_finalize runs a symbolic Cholesky at block granularity, so a
 // banded problem costs O(n b^2) and a loop closure only fills the block rows between its two ends.
 // What Ceres does here (SPARSE_SCHUR / DENSE_SCHUR on the reduced camera matrix, schur_complement_solver.cc)

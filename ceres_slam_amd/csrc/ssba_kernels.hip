@@ -639,6 +639,19 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish
         const int f = (int)(i / 6), c = (int)(i - (size_t)f * 6), I = f / SBP, row = (f - I * SBP) * 6 + c;
         d.xv[d.off_D + (size_t)I * BD * BD + (size_t)row * BD + row] = 1.0;
         d.xv[d.off_rhs + i] = 0.0;
+    } else if (fuse_finish && gid < n_el + (size_t)d.nf_pad * 6 + (size_t)d.nfree) {
+        // one lane per free pose: its share of k_check's projected-gradient norm |x - Plus(x, -g)|_inf and of |x|^2 (an SE(3)
+        // exponential per pose: 1 000 of them side by side here instead of on the 1 024 lanes of the one k_check work-group)
+        const int f = (int)(gid - n_el - (size_t)d.nf_pad * 6), k = d.free_pose[f];
+        const double *T = d.poses + (size_t)k * 12;
+        double ng[6], Tn[12], gm = 0.0, xn = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ng[c] = -d.gp[(size_t)k * 6 + c];
+        se3_plus(T, ng, Tn);
+#pragma unroll
+        for (int c = 0; c < 12; ++c) { gm = fmax(gm, fabs(T[c] - Tn[c])); xn += T[c] * T[c]; }
+        d.part_chk[2 * f] = gm;
+        d.part_chk[2 * f + 1] = xn;
     }
 }
 
@@ -764,6 +777,9 @@ __global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      /
         // interior poses of every rank went into those sums before the exchange (k_sep_pack); what is left
         // are the separator poses, whose gradient is the sum over ranks held in the separator vector
         const int npose = d.part ? d.n_sep * SBP : d.nfree;
+        if (fused_parts > 0) {       // per pose by k_assemble_reduced(.., fuse_finish)
+            for (int q = threadIdx.x; q < d.nfree; q += (int)blockDim.x) { gm = fmax(gm, d.part_chk[2 * q]); xn += d.part_chk[2 * q + 1]; }
+        } else
         for (int q = threadIdx.x; q < npose; q += (int)blockDim.x) {
             int i = q;
             const double *gsrc = d.xv + d.off_gp + (size_t)q * 6;
@@ -1924,7 +1940,7 @@ void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
     const int n_zero = 128;
     if (d.phong) launch_ph_schur(L, d);
     else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero);
-    const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6;
+    const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6 + (fuse_ctrl ? (size_t)d.nfree : 0);
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0);
     if (d.cb) LAUNCH(KC_BORDER, k_cb_assemble, dim3((unsigned)(((size_t)d.n_cb * 36 + 255) / 256)), dim3(256), 0, d);
 }

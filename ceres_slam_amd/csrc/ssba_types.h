@@ -164,6 +164,7 @@ struct Dev {
     double *xsep;                    // n_sep * BD separator solution
     // reductions
     double *part_lin;                // n_lm_blocks*4: cost, |x_pts|^2, max|g_l|, -
+    double *part_chk;                               // [nfree][2]: projected-gradient norm and |x|^2 of a pose (k_assemble_reduced -> k_check)
     double *part_eval;               // n_lm_blocks*4: cand cost, mcc, |dl|^2, nonfinite
     double *part_pose;               // ceil(P/256)*2: |dx_pose|^2, nonfinite
     double *scal2;                   // NSCAL: second exchange vector

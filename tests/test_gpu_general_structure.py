@@ -86,6 +86,28 @@ def test_long_tracks_match_oracle(size):
     _assert_same_solve(ba, s, log, op, s2, log2)
 
 
+def test_matrix_core_and_valu_factorisations_agree(monkeypatch):
+    """The blocked Cholesky of the general path on the fp64 matrix cores (k_dn_trsm_mf / k_dn_syrk_mf, back-substitution
+    in one work-group) against the r01 kernels on the fp64 VALU (SSBA_DENSE_VALU=1): same accept / reject sequence,
+    cost trace to 1e-9, poses to 1e-8 -- on a banded problem (long tracks) and on one with fill (renumbered states)."""
+    for prob in (synth.make_problem(150, 4000, track_len=16, seed=16), _permuted(synth.make_problem(90, 2700, track_len=8, seed=3), 5)[0]):
+        out = []
+        for valu in ("0", "1"):
+            monkeypatch.setenv("SSBA_DENSE_VALU", valu)
+            ba = StereoBA.from_synth(prob)
+            assert ba.stats().general_structure == 1
+            s, log = ba.solve(capi.default_options(max_num_iterations=30, use_nonmonotonic_steps=1))
+            out.append((s, log, ba.poses.copy()))
+            ba.close()
+        (s0, l0, p0), (s1, l1, p1) = out
+        assert s0.num_iterations == s1.num_iterations
+        assert l0["step_is_successful"].tolist() == l1["step_is_successful"].tolist()
+        ok = np.asarray(l0["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(l0["cost"][ok], l1["cost"][ok], rtol=1e-9)
+        assert np.abs(p0 - p1).max() < 1e-8
+
+
 @pytest.mark.parametrize("strategy", [(0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("huber_a", [0.0, 1.345])
 def test_renumbered_states_match_oracle(strategy, huber_a):
