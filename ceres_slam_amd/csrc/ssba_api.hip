@@ -1743,7 +1743,10 @@ static int enqueue_front(ssba_problem *p) {
     const bool fuse_ctrl = !p->xfn && !d.constrained && !d.nb;
     const bool fuse_best = !d.constrained && !d.nb && p->opt.trust_region_strategy_type != 1;      // with an exchange too: none sits between k_check and the update
     const bool fuse_all = fuse_all_launches(p);
-    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl); }))) return rc;
+    // k_check's work rides in the Schur launch (ssba_kernels.hip: k_schur_windows); SSBA_CHECK_LAUNCH=1 keeps the launch (A/B, tests)
+    static const bool check_launch = [] { const char *e = getenv("SSBA_CHECK_LAUNCH"); return e && e[0] == '1'; }();
+    const bool check_in_schur = fuse_all && !check_launch;
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl, check_in_schur); }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if ((rc = X(d.gmax_l, 1, 1))) return rc;
@@ -1754,7 +1757,7 @@ static int enqueue_front(ssba_problem *p) {
     }
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
             if (p->xfn && d.nb) launch_border_scale(L, d);      // Jacobi scale of the border from the SUMMED diagonal
-            launch_finish_check(L, d, fuse_ctrl, fuse_best);
+            launch_finish_check(L, d, fuse_ctrl, fuse_best, check_in_schur);
             const bool fuse_upd = fuse_all && !d.dense && bcr_updates_poses(d);     // the last step of the reduced solve updates the poses
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d, true, fuse_upd); if (d.nb) launch_border_solve(L, d); }

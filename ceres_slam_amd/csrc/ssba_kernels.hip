@@ -377,7 +377,15 @@ typedef double schur_d4 __attribute__((ext_vector_type(4)));
 
 // n_zero > 0: the first n_zero workgroups clear the block-tridiagonal reduced system (D and L of every super-block) that
 // k_assemble_reduced fills next -- a memset launch less per iteration, hidden beside the Schur items.
-__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n_zero) {
+// check_parts > 0 (single GPU, LM: launch_schur(.., check_in_schur)): one more work-group at the end of the grid does
+// k_check's work (the sums of the linearisation partials, the projected-gradient norm over the poses, the convergence tests
+// and the iteration bookkeeping).  Everything it reads was written by the linearisation launches, nothing it writes is read by
+// the Schur items (radius, options and the termination flag apart -- a stale 0 there costs one wasted pass), so the
+// 10 us dependent launch disappears inside this 75 us one.  k_assemble_reduced, which now runs AFTER the iteration
+// counter was advanced, is told so (its `it0`).
+__device__ __forceinline__ void check_body(Dev &d, int fused_parts, bool in_schur);
+__global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n_zero, int check_parts) {
+    if (check_parts > 0 && blockIdx.x == gridDim.x - 1) { check_body(d, check_parts, true); return; }
     const State &st = *d.st;
     // the solver state is written by the previous launch on another XCD: its read is a ~2 us round trip.  It is tested
     // after the item's first operand reads have been issued, not before (a launch that returns at once measures 4.5 us
@@ -552,7 +560,7 @@ __device__ __forceinline__ int tri21(int r, int c) {   // packed upper index, r 
 // fuse_finish (single GPU: nothing is exchanged between this kernel and the solve): the work of k_finish_reduced is done
 // here -- Jacobi scale of the poses at iteration 0, LM damping on the diagonal, rhs = -reduced gradient, identity rows
 // for the padding of the last super-block.
-__global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish) {
+__global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish, int it0) {      // it0: value of st.iteration in the first pass (1 when k_check's work ran before this launch)
     const State &st = *d.st;
     const int dead = st.terminated | st.dl_reuse;        // tested once the first index reads are in flight (a cold read)
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(256) void k_assemble_reduced(Dev d, int fuse_finish
             if (fuse_finish && r == c) {
                 const size_t i = (size_t)fa * 6 + r;
                 double sc;
-                if (st.iteration == 0) { sc = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0; d.sp[i] = sc; }
+                if (st.iteration == it0) { sc = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0; d.sp[i] = sc; }
                 else sc = d.sp[i];
                 const double s2 = sc * sc;
                 v += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
@@ -749,7 +757,9 @@ __device__ void log_push(Dev &d, State &st, double cost, double cost_change, dou
 // the block also does the work of k_reduce_lin (sums of the linearisation partials); k_finish_reduced's work is done by
 // k_assemble_reduced(.., fuse_finish) -- two launches less per iteration.  (A first version did k_finish_reduced's
 // work here too: 6 000 scattered diagonal entries from ONE block cost 16 us against 5 us for the 24-block launch.)
-__global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      // 1024 lanes: one pose each at C2 (the exponential map is a long dependent chain)
+// in_schur (check_body called from the extra work-group of k_schur_windows, i.e. BEFORE k_assemble_reduced): the per-pose
+// partials of k_assemble_reduced do not exist yet -- the poses are walked here, from g_p, hidden inside the 75 us launch
+__device__ __forceinline__ void check_body(Dev &d, int fused_parts, bool in_schur) {
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[16];
@@ -777,12 +787,12 @@ __global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      /
         // interior poses of every rank went into those sums before the exchange (k_sep_pack); what is left
         // are the separator poses, whose gradient is the sum over ranks held in the separator vector
         const int npose = d.part ? d.n_sep * SBP : d.nfree;
-        if (fused_parts > 0) {       // per pose by k_assemble_reduced(.., fuse_finish)
+        if (fused_parts > 0 && !in_schur) {       // per pose by k_assemble_reduced(.., fuse_finish)
             for (int q = threadIdx.x; q < d.nfree; q += (int)blockDim.x) { gm = fmax(gm, d.part_chk[2 * q]); xn += d.part_chk[2 * q + 1]; }
         } else
         for (int q = threadIdx.x; q < npose; q += (int)blockDim.x) {
             int i = q;
-            const double *gsrc = d.xv + d.off_gp + (size_t)q * 6;
+            const double *gsrc = in_schur ? d.gp + (size_t)d.free_pose[q] * 6 : d.xv + d.off_gp + (size_t)q * 6;
             if (d.part) {
                 const int s = q / SBP;
                 i = d.sep_sb[s] * SBP + (q - s * SBP);
@@ -883,6 +893,9 @@ __global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      /
     st.accepted = 0;
     st.ls_alpha = 1.0;
     // step_failed may already carry a landmark-block breakdown from k_schur_windows
+}
+__global__ __launch_bounds__(1024) void k_check(Dev d, int fused_parts) {      // 1024 lanes: one pose each at C2 (the exponential map is a long dependent chain)
+    check_body(d, fused_parts, false);
 }
 
 
@@ -1934,14 +1947,15 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
     if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
 }
 
-void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl) {
+void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl, bool check_in_schur) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
+    check_in_schur = check_in_schur && fuse_ctrl && !d.phong && lm_split(d);
     // the reduced system is cleared on the way: by 128 extra workgroups of the stereo Schur launch, by k_ph_invert with lighting terms
     const int n_zero = 128;
     if (d.phong) launch_ph_schur(L, d);
-    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero);
+    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero + (check_in_schur ? 1 : 0)), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero, check_in_schur ? d.n_groups : 0);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6 + (fuse_ctrl ? (size_t)d.nfree : 0);
-    LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0);
+    LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0, check_in_schur ? 1 : 0);
     if (d.cb) LAUNCH(KC_BORDER, k_cb_assemble, dim3((unsigned)(((size_t)d.n_cb * 36 + 255) / 256)), dim3(256), 0, d);
 }
 
@@ -1951,11 +1965,12 @@ void launch_finish_local(Launcher &L, const Dev &d) {
 
 // fuse_ctrl: one launch instead of k_finish_reduced + k_check (+ the k_reduce_lin skipped by launch_linearize);
 // fuse_best: k_best's copy is done by the update / evaluation kernels of launch_update_eval(.., fuse_best)
-void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_best) {
+void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_best, bool check_in_schur) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
+    check_in_schur = check_in_schur && fuse_ctrl && !d.phong && lm_split(d);
     if (d.dense) launch_dense_finish(L, d);
     else if (!fuse_ctrl) LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
+    if (!check_in_schur) LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
     if (fuse_best && best_fusable(d)) return;
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);

@@ -109,8 +109,8 @@ void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int le
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
 void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false, bool skip_reduce = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)
-void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false);
-void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false);
+void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool check_in_schur = false);
+void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false, bool check_in_schur = false);
 bool bcr_border_rides(const Dev &d);      // the border columns go through the forward part of the solve inside the factor / reduce launches
 // fuse_update: the last step of the plan also updates the poses (bcr_updates_poses(d) must hold)
 bool bcr_updates_poses(const Dev &d);
