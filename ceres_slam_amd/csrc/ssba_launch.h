@@ -130,7 +130,7 @@ void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, b
 int upload_phong_tables(hipStream_t s);
 int configure_phong();
 void launch_ph_linearize(Launcher &L, const Dev &d);
-void launch_ph_schur(Launcher &L, const Dev &d);
+void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur = false);
 void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best = 0);
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d);
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d);

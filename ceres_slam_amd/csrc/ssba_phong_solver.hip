@@ -20,6 +20,7 @@
 #include "ssba_launch.h"
 #include "ssba_phong_device.h"
 #include "ssba_types.h"
+#include "ssba_check.h"
 
 namespace ssba {
 
@@ -519,9 +520,11 @@ template <bool BORDER> struct PhSchurCfg {
 };
 typedef double ph_d4 __attribute__((ext_vector_type(4)));
 
-template <bool BORDER> __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d) {
+// check_parts > 0: one more work-group at the end of the grid does k_check's work (see k_schur_windows, ssba_kernels.hip)
+template <bool BORDER> __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d, int check_parts) {
     typedef PhSchurCfg<BORDER> C;
     constexpr int PH_BATCH = C::BATCH, PH_KB = C::KB, PH_RS = C::RS, LMW = C::LMW, BC0 = C::BC0;
+    if (check_parts > 0 && blockIdx.x == gridDim.x - 1) { check_body(d, check_parts, true); return; }
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     extern __shared__ __align__(16) double ph_lds[];
@@ -1558,10 +1561,11 @@ void launch_ph_dense_border(Launcher &L, const Dev &d) {
     LAUNCH(KC_BORDER, k_ph_border_poses<true>, dim3(d.P), dim3(BP_THREADS), 0, d);
 }
 
-void launch_ph_schur(Launcher &L, const Dev &d) {
+void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur) {
     LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
-    if (d.lmMV) LAUNCH(KC_SCHUR, k_ph_schur_windows<true>, dim3(d.n_slabs), dim3(PH_THREADS), PhSchurCfg<true>::LDS_DOUBLES * sizeof(double), d);
-    else LAUNCH(KC_SCHUR, k_ph_schur_windows<false>, dim3(d.n_slabs), dim3(PH_THREADS), PhSchurCfg<false>::LDS_DOUBLES * sizeof(double), d);
+    const int cp = check_in_schur ? d.n_lm_blocks : 0, xg = check_in_schur ? 1 : 0;
+    if (d.lmMV) LAUNCH(KC_SCHUR, k_ph_schur_windows<true>, dim3(d.n_slabs + xg), dim3(PH_THREADS), PhSchurCfg<true>::LDS_DOUBLES * sizeof(double), d, cp);
+    else LAUNCH(KC_SCHUR, k_ph_schur_windows<false>, dim3(d.n_slabs + xg), dim3(PH_THREADS), PhSchurCfg<false>::LDS_DOUBLES * sizeof(double), d, cp);
     if (d.nb) {
         LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
         LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
