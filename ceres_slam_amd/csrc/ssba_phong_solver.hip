@@ -13,6 +13,7 @@
 #include <float.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -286,15 +287,16 @@ static __device__ __forceinline__ void ph_damping(const Dev &d, const State &st,
 // and the back-substitution (a radius change alone re-runs this, not the linearisation).
 // Also clears the block-tridiagonal reduced system (D and L of every super-block; of this rank's chain in a partitioned
 // solve) that k_assemble_reduced fills after the Schur launch -- no memset launch.
-__global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
+// blk / nblk: this work-group's index among the n_lm_blocks that share the pass (k_ph_invert, or the tail of k_ph_linpose_invert)
+static __device__ __forceinline__ void ph_invert_body(const Dev &d, int blk, int nblk) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blk * 256 + threadIdx.x;
     {
         const size_t b0 = d.part ? (size_t)d.chain0 * BD * BD : 0;
         const size_t n2 = (d.part ? (size_t)(d.chain1 - d.chain0 + 1) : (size_t)d.Nsb) * (BD * BD / 2);       // double2 per range
         double2 *zD = reinterpret_cast<double2 *>(d.xv + d.off_D + b0), *zL = reinterpret_cast<double2 *>(d.xv + d.off_L + b0);
-        for (size_t i = (size_t)l; i < n2; i += (size_t)gridDim.x * 256) {
+        for (size_t i = (size_t)l; i < n2; i += (size_t)nblk * 256) {
             zD[i] = make_double2(0.0, 0.0);
             zL[i] = make_double2(0.0, 0.0);
         }
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(256) void k_ph_invert(Dev d) {
             }
     }
 }
+__global__ __launch_bounds__(256) void k_ph_invert(Dev d) { ph_invert_body(d, (int)blockIdx.x, (int)gridDim.x); }
 
 template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_landmarks(Dev d) {
     const State &st = *d.st;
@@ -391,10 +394,9 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_land
     }
 }
 
-template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_ph_linearize_poses(Dev d) {
+template <bool DN, int NT, int CH> static __device__ __forceinline__ void ph_lin_pose_body(const Dev &d, int k) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
-    const int k = blockIdx.x;
     if (d.pose_free[k] < 0) return;
     __shared__ double sm[NT / 64][27];
     const double *T = d.poses + (size_t)k * 12;
@@ -450,6 +452,14 @@ template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_ph_li
         if (threadIdx.x < 21) d.hpp[(size_t)k * 21 + threadIdx.x] = v;
         else d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
     }
+}
+template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_ph_linearize_poses(Dev d) { ph_lin_pose_body<DN, NT, CH>(d, (int)blockIdx.x); }
+// Pose linearisation and the inversion of the damped landmark blocks in ONE launch (windowed layout, constant shared
+// blocks): both only need the landmark linearisation, so the n_lm_blocks inversion work-groups run beside the P pose
+// work-groups instead of as a launch of their own between them and the Schur kernel (-20 us on the chain at C3).
+__global__ __launch_bounds__(256, 2) void k_ph_linpose_invert(Dev d) {
+    if ((int)blockIdx.x < d.P) ph_lin_pose_body<false, 256, 2>(d, (int)blockIdx.x);
+    else ph_invert_body(d, (int)blockIdx.x - d.P, d.n_lm_blocks);
 }
 
 // Output-stationary Schur complement for 6-D landmark blocks on the fp64 matrix cores: the structure of
@@ -1502,11 +1512,18 @@ __global__ void k_ph_ls_accept(Dev d) {
     d.scal2[3] = d.ls_out[3];
 }
 
+// (with free shared blocks the inversion also forms M V from k_ph_border_landmarks' output, which runs after the poses;
+// SSBA_PH_INVERT_LAUNCH=1 keeps the launch of its own: A/B, tests)
+static bool ph_invert_with_poses(const Dev &d) {
+    const char *e = getenv("SSBA_PH_INVERT_LAUNCH");
+    return !d.dense && !d.nb && !(e && e[0] == '1');
+}
 void launch_ph_linearize(Launcher &L, const Dev &d) {
     LAUNCH(KC_LIN_LM, (d.dense ? k_ph_linearize_landmarks<true> : k_ph_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     // two observations in flight per lane: 54 us against 60 for the rolled loop at C3; three need 274 registers and lose (75 us),
     // 128 lanes per pose lose too (64-76 us) -- unlike the stereo kernel, whose 175 registers leave room for five
     if (d.dense) LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<true, 256, 1>), dim3(d.P), dim3(256), 0, d);
+    else if (ph_invert_with_poses(d)) LAUNCH(KC_LIN_POSE, k_ph_linpose_invert, dim3(d.P + d.n_lm_blocks), dim3(256), 0, d);
     else LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<false, 256, 2>), dim3(d.P), dim3(256), 0, d);
     if (d.nb) LAUNCH(KC_BORDER, (d.dense ? k_ph_border_landmarks<true> : k_ph_border_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (d.lmMV) LAUNCH(KC_BORDER, k_ph_hpb, dim3(d.P * d.M), dim3(64), 0, d);
@@ -1562,7 +1579,7 @@ void launch_ph_dense_border(Launcher &L, const Dev &d) {
 }
 
 void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur) {
-    LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
+    if (!ph_invert_with_poses(d)) LAUNCH(KC_SMALL, k_ph_invert, dim3(d.n_lm_blocks), dim3(256), 0, d);
     const int cp = check_in_schur ? d.n_lm_blocks : 0, xg = check_in_schur ? 1 : 0;
     if (d.lmMV) LAUNCH(KC_SCHUR, k_ph_schur_windows<true>, dim3(d.n_slabs + xg), dim3(PH_THREADS), PhSchurCfg<true>::LDS_DOUBLES * sizeof(double), d, cp);
     else LAUNCH(KC_SCHUR, k_ph_schur_windows<false>, dim3(d.n_slabs + xg), dim3(PH_THREADS), PhSchurCfg<false>::LDS_DOUBLES * sizeof(double), d, cp);
