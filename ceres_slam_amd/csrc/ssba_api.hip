@@ -549,9 +549,15 @@ struct RcclApi {
 RcclApi *rccl_api() {
     static RcclApi api = [] {
         RcclApi a;
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // a copy the process has mapped already (PyTorch ships and uses its own librccl.so) is taken before a second one
+        // is loaded from the ROCm installation: two RCCL instances in one process share no state
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (a.lib) break;
+        }
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            if (a.lib) break;
+            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!a.lib) return a;
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.lib, "ncclGetUniqueId");
