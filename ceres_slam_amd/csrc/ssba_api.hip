@@ -1441,7 +1441,9 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
         if (p->per_obs_S) TRY(dupload(p, &d.dn_Sobs, dn_Sobs));
         TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs));
-        TRY(dzero(p, &d.dn_W, dn_obs_pose.size() * (ph ? 36 : 18))); TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * (ph ? 36 : 18)));
+        TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * (ph ? 36 : 18)));
+        d.dn_W = d.dn_Y;        // one factor Z = W M^T for both sides of a pair product (k_dn_wy, k_ph_dn_wy)
+        TRY(dzero(p, &d.dn_Mg, (size_t)Lpad * (ph ? 6 : 3)));
         TRY(dzero(p, &d.dn_S, (size_t)(d.dn_pad + DN_BS) * std::max(d.dn_pad, DN_BS)));
     }
     TRY(dzero(p, &d.part_lin, (size_t)d.n_groups * 4));       // one entry per block of 256 landmarks, or per group of 64 (window layout)

@@ -4,7 +4,8 @@
 // the block-tridiagonal reduced system of ssba_kernels.hip / ssba_bcr.hip.  They keep every other kernel
 // (linearisation, back-substitution, trust-region control: templates on the observation layout) and swap the
 // middle of the iteration for
-//   k_dn_wy      per observation: W = J_p^T J_l and Y = W C^-1 (C = H_ll + damping), stored once (HBM stream);
+//   k_dn_wy      per observation: Z = W M^T with W = J_p^T J_l and C^-1 = M^T M (C = H_ll + damping), stored once (HBM stream:
+//                W C^-1 W^T = Z Z^T, one factor for both sides of a pair);
 //                with lighting terms k_ph_dn_wy (ssba_phong_solver.hip) stores the 6x6 versions
 //   k_dn_schur   one work-group per 6x6 block (a <= b) of S = H_pp - sum_l Y_a W_b^T: the block's observation pairs
 //                (host-built list) spread over the lanes, fixed-order reduction (no float atomics), plus the J_a^T J_b
@@ -48,14 +49,23 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
     const uint32_t k = d.dn_obs_pose[e];
     if (d.pose_free[k] < 0) return;      // rows of constant poses are never read
     const int l = (int)d.dn_obs_lm[e];
-    double h[6], dmp[3], Ci[6];
+    // C^-1 = M^T M (M = L^-1 of the damped block): ONE factor Z = W M^T per observation serves both sides of every pair
+    // product, W_a C^-1 W_b^T = Z_a Z_b^T -- half the bytes of the (W, Y = W C^-1) pair the r01 kernel stored, and with
+    // them the gathers of k_dn_schur fit the 256 MB of MALL at the sizes this path is meant for
+    double h[6], dmp[3], m[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
     landmark_damping(d, st, l, h, dmp);
-    if (!inv3_spd(h, dmp, Ci)) {
+    if (!chol3_inv_fast(h, dmp, m)) {
         d.st->step_failed = 1;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) Ci[c] = 0.0;
+        for (int c = 0; c < 6; ++c) m[c] = 0.0;
+    }
+    {       // u = M g_l for k_dn_rhs (every observation of the landmark writes the same three values)
+        const double g0 = d.gl[l], g1 = d.gl[(size_t)d.Lpad + l], g2 = d.gl[2 * (size_t)d.Lpad + l];
+        d.dn_Mg[l] = m[0] * g0;
+        d.dn_Mg[(size_t)d.Lpad + l] = m[1] * g0 + m[2] * g1;
+        d.dn_Mg[2 * (size_t)d.Lpad + l] = m[3] * g0 + m[4] * g1 + m[5] * g2;
     }
     const double *T = d.poses + (size_t)k * 12;
     ObsLin o;
@@ -66,16 +76,15 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
     double Jp[18], Jl[9];
     jac_pose(o, Jp);
     jac_point(o, T, Jl);
-    double *W = d.dn_W + (size_t)e * 18, *Y = d.dn_Y + (size_t)e * 18;
+    double *Z = d.dn_Y + (size_t)e * 18;       // (d.dn_W is the same buffer on this path: ssba_finalize)
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         double w[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) w[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
-        W[3 * a + 0] = w[0]; W[3 * a + 1] = w[1]; W[3 * a + 2] = w[2];
-        Y[3 * a + 0] = w[0] * Ci[0] + w[1] * Ci[1] + w[2] * Ci[2];
-        Y[3 * a + 1] = w[0] * Ci[1] + w[1] * Ci[3] + w[2] * Ci[4];
-        Y[3 * a + 2] = w[0] * Ci[2] + w[1] * Ci[4] + w[2] * Ci[5];
+        Z[3 * a + 0] = w[0] * m[0];
+        Z[3 * a + 1] = w[0] * m[1] + w[1] * m[2];
+        Z[3 * a + 2] = w[0] * m[3] + w[1] * m[4] + w[2] * m[5];
     }
 }
 
@@ -175,7 +184,7 @@ template <int LD> __global__ __launch_bounds__(256) void k_dn_rhs(Dev d) {
         const int l = (int)d.dn_obs_lm[e];
         double g[LD];
 #pragma unroll
-        for (int m = 0; m < LD; ++m) g[m] = d.gl[(size_t)m * d.Lpad + l];
+        for (int m = 0; m < LD; ++m) g[m] = d.dn_Mg[(size_t)m * d.Lpad + l];      // Y holds Z = W M^T, so M g_l goes with it
         const double *Y = d.dn_Y + (size_t)e * (6 * LD);
 #pragma unroll
         for (int c = 0; c < 6; ++c)

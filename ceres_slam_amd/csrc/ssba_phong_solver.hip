@@ -1543,10 +1543,19 @@ __global__ __launch_bounds__(256) void k_ph_dn_wy(Dev d) {
     const double nobs[3] = {d.onx[e], d.ony[e], d.onz[e]};
     ObsPh o;
     obs_ph_linearize(d, d.sh, d.poses + (size_t)k * 12, x.p, x.n, x.mat, d.ou[e], d.ov[e], d.od[e], d.oi[e], nobs, true, o);
-    double Ci[21];
+    // one factor Z = W M^T per observation (C^-1 = M^T M, M from k_ph_invert) for both sides of every pair product, and
+    // u = M g_l per landmark for the right-hand side: see k_dn_wy (ssba_dense.hip)
+    double Mf[21];
 #pragma unroll
-    for (int c = 0; c < 21; ++c) Ci[c] = d.cinv[(size_t)c * d.Lpad + l];
-    double *W = d.dn_W + (size_t)e * 36, *Y = d.dn_Y + (size_t)e * 36;
+    for (int c = 0; c < 21; ++c) Mf[c] = d.cfac[(size_t)c * d.Lpad + l];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b <= c; ++b) v += Mf[c * (c + 1) / 2 + b] * d.gl[(size_t)b * d.Lpad + l];
+        d.dn_Mg[(size_t)c * d.Lpad + l] = v;
+    }
+    double *Z = d.dn_Y + (size_t)e * 36;       // (d.dn_W is the same buffer)
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         double w[6];
@@ -1556,14 +1565,13 @@ __global__ __launch_bounds__(256) void k_ph_dn_wy(Dev d) {
 #pragma unroll
             for (int m = 0; m < 7; ++m) if (jl_nz(m, c)) v += o.Jp[6 * m + a] * o.Jl[6 * m + c];
             w[c] = v;
-            W[6 * a + c] = v;
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             double v = 0.0;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) v += w[q] * Ci[q <= c ? tri6(q, c) : tri6(c, q)];
-            Y[6 * a + c] = v;
+            for (int b = 0; b <= c; ++b) v += w[b] * Mf[c * (c + 1) / 2 + b];
+            Z[6 * a + c] = v;
         }
     }
 }

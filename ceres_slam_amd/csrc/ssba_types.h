@@ -224,7 +224,8 @@ struct Dev {
     const double *dn_Sobs;                          // N*9 or null: one stiffness per stereo residual block (dataset_vo_sun.cpp:56-65)
     const uint32_t *dn_pose_start, *dn_pose_obs;    // P+1, N: landmark-major observation indices of a pose
     const uint32_t *dn_obs_lm;                      // N: landmark of an observation
-    double *dn_W, *dn_Y;                            // N*18: J_p^T J_l and its product with C^-1, per observation
+    double *dn_W, *dn_Y;                            // per observation: ONE buffer of N*18 (lighting: N*36), Z = W M^T with C^-1 = M^T M
+    double *dn_Mg;                                  // M g_l per landmark (3 or 6 x Lpad)
     // blocks (a <= b) of the reduced system with the observation pairs (of one landmark) that contribute to each
     int dn_nblk;
     const uint32_t *dn_blk_a, *dn_blk_b, *dn_blk_start, *dn_pair_a, *dn_pair_b;
