@@ -897,7 +897,7 @@ int ssba_finalize(ssba_problem *p) {
     }
     p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
     // general path: landmark-major observation arrays + the pose-major index list into them
-    std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs;
+    std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs, dn_zpos;
     std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
     std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b, dn_pose_mat_start;
     DensePlan dplan;
@@ -941,6 +941,10 @@ int ssba_finalize(ssba_problem *p) {
                 }
             }
         }
+        // the per-observation factor Z (k_dn_wy) is stored POSE-major: the pairs of a block (a, b) then walk through pose a's
+        // and pose b's records in ascending order instead of striding through a landmark-major array
+        dn_zpos.resize(dn_obs_pose.size());
+        for (uint32_t i = 0; i < dn_pose_obs.size(); ++i) dn_zpos[dn_pose_obs[i]] = i;
         // blocks (a <= b) of S = H_pp - sum_l Y_l W_l^T and, per block, the observation pairs (ea, eb) of one
         // landmark that contribute Y_ea W_eb^T; sorted by block so that one wave owns one block (no atomics)
         struct Pr { uint32_t a, b, ea, eb; };
@@ -975,7 +979,7 @@ int ssba_finalize(ssba_problem *p) {
                 dn_blk_a.push_back(prs[i].a); dn_blk_b.push_back(prs[i].b);
                 dn_blk_start.push_back((uint32_t)dn_pair_a.size());
             }
-            if (prs[i].ea != 0xFFFFFFFFu) { dn_pair_a.push_back(prs[i].ea); dn_pair_b.push_back(prs[i].eb); }
+            if (prs[i].ea != 0xFFFFFFFFu) { dn_pair_a.push_back(dn_zpos[prs[i].ea]); dn_pair_b.push_back(dn_zpos[prs[i].eb]); }
         }
         dn_blk_start.push_back((uint32_t)dn_pair_a.size());
         // symbolic Cholesky at DN_BS-block granularity (natural order): banded problems stay banded, a loop closure
@@ -1440,7 +1444,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
         if (p->per_obs_S) TRY(dupload(p, &d.dn_Sobs, dn_Sobs));
-        TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs));
+        TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs)); TRY(dupload(p, &d.dn_zpos, dn_zpos));
         TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * (ph ? 36 : 18)));
         d.dn_W = d.dn_Y;        // one factor Z = W M^T for both sides of a pair product (k_dn_wy, k_ph_dn_wy)
         TRY(dzero(p, &d.dn_Mg, (size_t)Lpad * (ph ? 6 : 3)));

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_dn_wy(Dev d) {
     double Jp[18], Jl[9];
     jac_pose(o, Jp);
     jac_point(o, T, Jl);
-    double *Z = d.dn_Y + (size_t)e * 18;       // (d.dn_W is the same buffer on this path: ssba_finalize)
+    double *Z = d.dn_Y + (size_t)d.dn_zpos[e] * 18;       // pose-major record (d.dn_W is the same buffer: ssba_finalize)
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         double w[3];
@@ -185,7 +185,7 @@ template <int LD> __global__ __launch_bounds__(256) void k_dn_rhs(Dev d) {
         double g[LD];
 #pragma unroll
         for (int m = 0; m < LD; ++m) g[m] = d.dn_Mg[(size_t)m * d.Lpad + l];      // Y holds Z = W M^T, so M g_l goes with it
-        const double *Y = d.dn_Y + (size_t)e * (6 * LD);
+        const double *Y = d.dn_Y + (size_t)i * (6 * LD);       // pose-major: entry i of the pose's list
 #pragma unroll
         for (int c = 0; c < 6; ++c)
 #pragma unroll

@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(256) void k_ph_dn_wy(Dev d) {
         for (int b = 0; b <= c; ++b) v += Mf[c * (c + 1) / 2 + b] * d.gl[(size_t)b * d.Lpad + l];
         d.dn_Mg[(size_t)c * d.Lpad + l] = v;
     }
-    double *Z = d.dn_Y + (size_t)e * 36;       // (d.dn_W is the same buffer)
+    double *Z = d.dn_Y + (size_t)d.dn_zpos[e] * 36;       // pose-major record (d.dn_W is the same buffer)
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         double w[6];

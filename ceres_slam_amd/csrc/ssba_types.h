@@ -225,6 +225,7 @@ struct Dev {
     const uint32_t *dn_pose_start, *dn_pose_obs;    // P+1, N: landmark-major observation indices of a pose
     const uint32_t *dn_obs_lm;                      // N: landmark of an observation
     double *dn_W, *dn_Y;                            // per observation: ONE buffer of N*18 (lighting: N*36), Z = W M^T with C^-1 = M^T M
+    const uint32_t *dn_zpos;                        // observation -> its record in dn_Y (pose-major)
     double *dn_Mg;                                  // M g_l per landmark (3 or 6 x Lpad)
     // blocks (a <= b) of the reduced system with the observation pairs (of one landmark) that contribute to each
     int dn_nblk;
