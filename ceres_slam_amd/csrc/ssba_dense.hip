@@ -5,12 +5,12 @@
 // (linearisation, back-substitution, trust-region control: templates on the observation layout) and swap the
 // middle of the iteration for
 //   k_dn_wy      per observation: Z = W M^T with W = J_p^T J_l and C^-1 = M^T M (C = H_ll + damping), stored once (HBM stream:
-//                W C^-1 W^T = Z Z^T, one factor for both sides of a pair);
-//                with lighting terms k_ph_dn_wy (ssba_phong_solver.hip) stores the 6x6 versions
-//   k_dn_schur   one work-group per 6x6 block (a <= b) of S = H_pp - sum_l Y_a W_b^T: the block's observation pairs
-//                (host-built list) spread over the lanes, fixed-order reduction (no float atomics), plus the J_a^T J_b
-//                of relative-pose blocks; writes the lower triangle of the dense matrix
-//   k_dn_rhs     one wave per free pose: reduced gradient g_p - sum Y g_l, stored as an extra row of the matrix
+//                W C^-1 W^T = Z Z^T, one factor for both sides of a pair), records in POSE-major order (dn_zpos);
+//                with lighting terms k_ph_dn_wy (ssba_phong_solver.hip) stores the 6x6 version
+//   k_dn_schur   one wave per 6x6 block (a <= b) of S = H_pp - sum_l Z_a Z_b^T: the block's observation pairs
+//                (host-built list of record positions) spread over the lanes, fixed-order reduction (no float atomics),
+//                plus the J_a^T J_b of relative-pose blocks; writes the lower triangle of the dense matrix
+//   k_dn_rhs     one wave per free pose: reduced gradient g_p - sum Z (M g_l), stored as an extra row of the matrix
 //   k_dn_finish  Jacobi scale at iteration 0, LM damping on the diagonal
 //   k_dn_potrf / k_dn_trsm_mf / k_dn_syrk_mf   right-looking blocked Cholesky (DN_BS = 64): the diagonal block by one wave
 //                (rows in registers, v_readlane), the panel solve and the trailing update on the fp64 matrix cores
