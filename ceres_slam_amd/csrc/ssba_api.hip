@@ -1756,7 +1756,8 @@ static int enqueue_front(ssba_problem *p) {
     const bool fuse_best = !d.constrained && !d.nb && p->opt.trust_region_strategy_type != 1;      // with an exchange too: none sits between k_check and the update
     const bool fuse_all = fuse_all_launches(p);
     // k_check's work rides in the Schur launch (ssba_kernels.hip: k_schur_windows); SSBA_CHECK_LAUNCH=1 keeps the launch (A/B, tests)
-    static const bool check_launch = [] { const char *e = getenv("SSBA_CHECK_LAUNCH"); return e && e[0] == '1'; }();
+    const char *cl_env = getenv("SSBA_CHECK_LAUNCH");       // (read at every capture: tests switch it between handles)
+    const bool check_launch = cl_env && cl_env[0] == '1';
     const bool check_in_schur = fuse_ctrl && p->opt.trust_region_strategy_type != 1 && (fuse_all || d.phong) && !check_launch;
     if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl, check_in_schur); }))) return rc;
     if (p->xfn) {

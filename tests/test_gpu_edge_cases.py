@@ -54,6 +54,31 @@ def assert_fixed_count_parity(ba, op, K, cost_rtol=1e-7, threads=4, **kw):
     return s, log, s2, log2
 
 
+@pytest.mark.parametrize("lighting", [False, True])
+def test_check_inside_the_schur_launch_equals_the_check_launch(monkeypatch, lighting):
+    """k_check's work done by one extra work-group of the Schur launch (the default on the single-GPU LM path) against the
+    launch of its own (SSBA_CHECK_LAUNCH=1): same iteration count, accept / reject sequence and termination, cost trace to
+    1e-12 (only the order of two sums over the poses differs), poses to 1e-10."""
+    if lighting:
+        prob, ph = synth.make_phong_problem(40, 1600, num_materials=3, seed=4)
+        kw = dict(lighting=ph.as_oracle_dict("truth"))
+    else:
+        prob, kw = synth.make_problem(60, 2400, track_len=9, seed=12), {}
+    out = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("SSBA_CHECK_LAUNCH", env)
+        ba = StereoBA.from_synth(prob, **kw)
+        s, log = ba.solve(capi.default_options(**DRIVER))
+        out.append((s, log, ba.poses.copy()))
+        ba.close()
+    (s0, l0, p0), (s1, l1, p1) = out
+    assert s0.num_iterations == s1.num_iterations and s0.termination_type == s1.termination_type
+    assert l0["step_is_successful"].tolist() == l1["step_is_successful"].tolist()
+    np.testing.assert_allclose(l0["cost"], l1["cost"], rtol=1e-12)
+    np.testing.assert_allclose(l0["gradient_max_norm"], l1["gradient_max_norm"], rtol=1e-12)
+    assert np.abs(p0 - p1).max() < 1e-10
+
+
 def test_many_poses_few_landmarks():
     """Fewer landmark groups than pose blocks: the copies of the best iterate that ride in the landmark kernels (twelve
     doubles per pose spread over the lanes of the evaluation launch) must still cover every pose -- 150 poses with 10
