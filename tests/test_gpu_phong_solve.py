@@ -429,3 +429,20 @@ def test_border_routes_agree(switch):
         np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-9)
         assert np.abs(ba.poses - ba2.poses).max() < 1e-8
         np.testing.assert_allclose(ba.light, ba2.light, rtol=1e-8, atol=1e-10)
+
+
+def test_inversion_beside_the_pose_linearisation_is_the_same_arithmetic(monkeypatch):
+    """Constant shared blocks: the inversion of the damped landmark blocks runs in the pose linearisation's launch
+    (k_ph_linpose_invert) by default and as a launch of its own with SSBA_PH_INVERT_LAUNCH=1 -- the same per-work-group
+    code either way, so the two solves agree bit for bit."""
+    prob, ph = synth.make_phong_problem(50, 2000, num_materials=4, seed=6)
+    out = []
+    for env in ("0", "1"):
+        monkeypatch.setenv("SSBA_PH_INVERT_LAUNCH", env)
+        ba = StereoBA.from_synth(prob, lighting=ph.as_oracle_dict("truth"))
+        s, log = ba.solve(capi.default_options(max_num_iterations=25, use_nonmonotonic_steps=1))
+        out.append((s, log, ba.poses.copy(), ba.points.copy()))
+        ba.close()
+    (s0, l0, p0, x0), (s1, l1, p1, x1) = out
+    assert s0.num_iterations == s1.num_iterations
+    assert np.array_equal(l0["cost"], l1["cost"]) and np.array_equal(p0, p1) and np.array_equal(x0, x1)
