@@ -109,6 +109,7 @@ struct ssba_problem {
     hipGraph_t seg_graph[3] = {nullptr, nullptr, nullptr};
     hipGraphExec_t seg_exec[3] = {nullptr, nullptr, nullptr};
     bool use_graph = true;
+    int eager_iters = 0;                      // iterations enqueued kernel by kernel since the last graph was dropped (enqueue_iteration)
     // solve bookkeeping
     bool began = false;
     ssba_options opt{};
@@ -1618,6 +1619,7 @@ static int ensure_log(ssba_problem *p, int capacity) {
 
 // one trust-region iteration, enqueue only
 static int enqueue_kernels(ssba_problem *p);
+constexpr int LAZY_GRAPH_ITERS = 6;
 
 static int enqueue_constrained_iteration(ssba_problem *p);
 
@@ -1627,6 +1629,11 @@ static int enqueue_iteration(ssba_problem *p) {
     // the plain single-GPU path it is captured once and replayed: ~45 launches become one.
     if (p->use_graph && !p->xfn && !p->launcher.timing) {
         hipStream_t s = p->launcher.stream;
+        // A graph pays from the seventh iteration on: capture + instantiation (and its destruction with the handle, or at the
+        // next call that changes a kernel argument) cost about what six iterations gain from the replay.  The thousands of
+        // two-state windows the reference's scripts solve converge in fewer (examples/dataset_vo_sun_gpu: 3.6 -> 3.2 ms per
+        // window); a C2 solve pays 6 x 0.2 ms once.
+        if (!p->gexec && p->eager_iters < LAZY_GRAPH_ITERS) { ++p->eager_iters; return enqueue_kernels(p); }
         if (!p->gexec) {
             HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
             int rc = enqueue_kernels(p);
