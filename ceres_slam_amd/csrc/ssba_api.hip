@@ -118,6 +118,7 @@ struct ssba_problem {
     std::chrono::steady_clock::time_point t_begin;
     std::vector<double> log_cost, log_cost_change, log_gmax, log_step, log_rd, log_radius;
     std::vector<int32_t> log_ok;
+    std::vector<double> log_stage;
     int log_capacity = 0;
 };
 
@@ -1605,13 +1606,14 @@ static int ensure_log(ssba_problem *p, int capacity) {
     // kernels take Dev by value: a captured graph has the old log pointers and capacity baked in and would keep
     // writing there while ssba_solve_end reads the new (zero-filled) buffers
     drop_graph(p);
-    if ((rc = dzero(p, &d.log.cost, (size_t)capacity))) return rc;
-    if ((rc = dzero(p, &d.log.cost_change, (size_t)capacity))) return rc;
-    if ((rc = dzero(p, &d.log.gmax, (size_t)capacity))) return rc;
-    if ((rc = dzero(p, &d.log.step_norm, (size_t)capacity))) return rc;
-    if ((rc = dzero(p, &d.log.relative_decrease, (size_t)capacity))) return rc;
-    if ((rc = dzero(p, &d.log.radius, (size_t)capacity))) return rc;
-    if ((rc = dzero(p, &d.log.successful, (size_t)capacity))) return rc;
+    // the seven columns of the iteration log in ONE buffer: one zero-fill here and one read-back in ssba_solve_end instead of
+    // seven each (a blocking 50-byte hipMemcpy costs what a 50-kilobyte one does: ~15 us; two-state windows solve in 3 iterations)
+    double *blk = nullptr;
+    if ((rc = dzero(p, &blk, (size_t)7 * capacity))) return rc;
+    d.log.cost = blk; d.log.cost_change = blk + capacity; d.log.gmax = blk + 2 * (size_t)capacity;
+    d.log.step_norm = blk + 3 * (size_t)capacity; d.log.relative_decrease = blk + 4 * (size_t)capacity;
+    d.log.radius = blk + 5 * (size_t)capacity;
+    d.log.successful = reinterpret_cast<int32_t *>(blk + 6 * (size_t)capacity);
     d.log.capacity = capacity;
     p->log_capacity = capacity;
     return SSBA_OK;
@@ -1907,7 +1909,20 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
     const int n = std::min(S.log_count, p->d.log.capacity);
     p->log_cost.resize(n); p->log_cost_change.resize(n); p->log_gmax.resize(n); p->log_step.resize(n);
     p->log_rd.resize(n); p->log_radius.resize(n); p->log_ok.resize(n);
-    if (n > 0) {
+    if (n > 0 && (size_t)7 * p->d.log.capacity * sizeof(double) <= (size_t)256 << 10) {
+        // the whole log block in one transfer (ensure_log): columns at stride `capacity`
+        const size_t cap = (size_t)p->d.log.capacity;
+        p->log_stage.resize(7 * cap);
+        HIPCHECK(hipMemcpy(p->log_stage.data(), p->d.log.cost, (6 * cap + (cap + 1) / 2) * sizeof(double), hipMemcpyDeviceToHost));
+        const double *b = p->log_stage.data();
+        std::copy(b, b + n, p->log_cost.begin());
+        std::copy(b + cap, b + cap + n, p->log_cost_change.begin());
+        std::copy(b + 2 * cap, b + 2 * cap + n, p->log_gmax.begin());
+        std::copy(b + 3 * cap, b + 3 * cap + n, p->log_step.begin());
+        std::copy(b + 4 * cap, b + 4 * cap + n, p->log_rd.begin());
+        std::copy(b + 5 * cap, b + 5 * cap + n, p->log_radius.begin());
+        memcpy(p->log_ok.data(), b + 6 * cap, (size_t)n * sizeof(int32_t));
+    } else if (n > 0) {
         HIPCHECK(hipMemcpy(p->log_cost.data(), p->d.log.cost, n * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHECK(hipMemcpy(p->log_cost_change.data(), p->d.log.cost_change, n * sizeof(double), hipMemcpyDeviceToHost));
         HIPCHECK(hipMemcpy(p->log_gmax.data(), p->d.log.gmax, n * sizeof(double), hipMemcpyDeviceToHost));
