@@ -9,10 +9,13 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <algorithm>
 #include <string>
 #include <vector>
+#include <map>
+#include <mutex>
 
 #include "../../include/ssba.h"
 #include "ssba_pool.h"
@@ -531,56 +534,69 @@ int ssba_frontend_vo(const ssba_camera *camera, int device, uint32_t num_states,
         uint32_t *b = sorted.data() + state_start[k], *e = sorted.data() + state_start[k + 1];
         if (!std::is_sorted(b, e)) std::sort(b, e);
     }
-    // raw std::mt19937(42) stream: 3 draws per iteration + rejections + duplicate redraws; 16 x that is far beyond need
+    // raw std::mt19937(42) stream: 3 draws per iteration + rejections + duplicate redraws; 16 x that is far beyond need.
+    // The stream is the same for every call with the same iteration count: generated and uploaded once per process and device.
     const uint32_t nraw = 48 * num_iters + 1024;
-    std::vector<uint32_t> raw(nraw);
-    { Mt19937 g(42u); for (uint32_t i = 0; i < nraw; ++i) raw[i] = g.next(); }
+    static std::mutex raw_mu;
+    static std::map<std::pair<int, uint32_t>, uint32_t *> raw_cache;
 
-    uint32_t *d_start = nullptr, *d_id = nullptr, *d_sorted = nullptr, *d_mobs = nullptr, *d_mcnt = nullptr, *d_raw = nullptr, *d_smp = nullptr,
-             *d_cnt = nullptr, *d_best = nullptr, *d_first = nullptr;
-    double *d_uvd = nullptr, *d_p0 = nullptr, *d_p1 = nullptr, *d_Th = nullptr, *d_Tp = nullptr, *d_poses = nullptr, *d_map = nullptr;
-    uint8_t *d_in = nullptr, *d_init = nullptr;
-    int *d_status = nullptr;
+    // ONE device buffer for everything, laid out so that the inputs go up in one transfer and the results come back in one
+    // (a window of two states is a few kilobytes: eight blocking uploads and six downloads were most of this call's 0.9 ms):
+    //   [ start | id | sorted | uvd | in | first || status | mcnt | best | poses | map | init ] + scratch
+    //     <------------------------- upload ------------------------------------------------->
+    //                                              <----------------- download -------------->
+    const size_t Nn = N ? N : 1, NP = num_points ? num_points : 1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_start = take((num_states + 1) * sizeof(uint32_t)), o_id = take(Nn * sizeof(uint32_t)), o_sorted = take(Nn * sizeof(uint32_t)),
+                 o_uvd = take(Nn * 3 * sizeof(double)), o_in = take(Nn), o_first = take(NP * sizeof(uint32_t));
+    const size_t o_status = take(sizeof(int)), o_mcnt = take(num_pairs * sizeof(uint32_t)), o_best = take(num_pairs * sizeof(uint32_t)),
+                 o_poses = take((size_t)num_states * 12 * sizeof(double)), o_map = take(NP * 3 * sizeof(double)), o_init = take(NP);
+    const size_t up_bytes = off;
+    const size_t o_mobs = take(Nn * sizeof(uint32_t)), o_smp = take((size_t)num_pairs * num_iters * 3 * sizeof(uint32_t)),
+                 o_cnt = take((size_t)num_pairs * num_iters * sizeof(uint32_t)), o_p0 = take(Nn * 3 * sizeof(double)),
+                 o_p1 = take(Nn * 3 * sizeof(double)), o_Th = take((size_t)num_pairs * num_iters * 12 * sizeof(double)),
+                 o_Tp = take((size_t)num_pairs * 12 * sizeof(double));
+    const size_t total_bytes = off;
+    char *arena = nullptr;
+    uint32_t *d_raw = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SSBA_OK, status = 0;
-    const size_t Nn = N ? N : 1, NP = num_points ? num_points : 1;
+    std::vector<char> host(up_bytes, 0);
 #define FE_TRY(x) do { if ((x) != hipSuccess) { rc = SSBA_ERR_HIP; goto done; } } while (0)
-    FE_TRY(ssba::pool_malloc((void **)&d_start, (num_states + 1) * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_id, Nn * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_sorted, Nn * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_mobs, Nn * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_mcnt, num_pairs * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_raw, nraw * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_smp, (size_t)num_pairs * num_iters * 3 * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_cnt, (size_t)num_pairs * num_iters * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_best, num_pairs * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_first, NP * sizeof(uint32_t)));
-    FE_TRY(ssba::pool_malloc((void **)&d_uvd, Nn * 3 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_p0, Nn * 3 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_p1, Nn * 3 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_Th, (size_t)num_pairs * num_iters * 12 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_Tp, (size_t)num_pairs * 12 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_poses, (size_t)num_states * 12 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_map, NP * 3 * sizeof(double)));
-    FE_TRY(ssba::pool_malloc((void **)&d_in, Nn));
-    FE_TRY(ssba::pool_malloc((void **)&d_init, NP));
-    FE_TRY(ssba::pool_malloc((void **)&d_status, sizeof(int)));
-    FE_TRY(hipMemcpy(d_start, state_start, (num_states + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_id, point_id, N * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_sorted, sorted.data(), N * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_uvd, uvd, N * 3 * sizeof(double), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_raw, raw.data(), nraw * sizeof(uint32_t), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_poses, poses, 12 * sizeof(double), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_map, map_points, (size_t)num_points * 3 * sizeof(double), hipMemcpyHostToDevice));
-    FE_TRY(hipMemcpy(d_init, initialized, num_points, hipMemcpyHostToDevice));
-    FE_TRY(hipMemset(d_first, 0xFF, NP * sizeof(uint32_t)));
-    FE_TRY(hipMemset(d_status, 0, sizeof(int)));
-    FE_TRY(hipMemset(d_in, 0, Nn));
+    {
+        std::lock_guard<std::mutex> lock(raw_mu);
+        uint32_t *&slot = raw_cache[{device, nraw}];
+        if (!slot) {
+            std::vector<uint32_t> raw(nraw);
+            { Mt19937 g(42u); for (uint32_t i = 0; i < nraw; ++i) raw[i] = g.next(); }
+            FE_TRY(hipMalloc((void **)&slot, nraw * sizeof(uint32_t)));
+            FE_TRY(hipMemcpy(slot, raw.data(), nraw * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        d_raw = slot;
+    }
+    FE_TRY(ssba::pool_malloc((void **)&arena, total_bytes));
+    memcpy(host.data() + o_start, state_start, (num_states + 1) * sizeof(uint32_t));
+    memcpy(host.data() + o_id, point_id, N * sizeof(uint32_t));
+    memcpy(host.data() + o_sorted, sorted.data(), N * sizeof(uint32_t));
+    memcpy(host.data() + o_uvd, uvd, N * 3 * sizeof(double));
+    memset(host.data() + o_first, 0xFF, NP * sizeof(uint32_t));
+    memcpy(host.data() + o_poses, poses, 12 * sizeof(double));
+    memcpy(host.data() + o_map, map_points, (size_t)num_points * 3 * sizeof(double));
+    memcpy(host.data() + o_init, initialized, num_points);
+    FE_TRY(hipMemcpy(arena, host.data(), up_bytes, hipMemcpyHostToDevice));
+    {
+    uint32_t *d_start = (uint32_t *)(arena + o_start), *d_id = (uint32_t *)(arena + o_id), *d_sorted = (uint32_t *)(arena + o_sorted),
+             *d_mobs = (uint32_t *)(arena + o_mobs), *d_mcnt = (uint32_t *)(arena + o_mcnt), *d_smp = (uint32_t *)(arena + o_smp),
+             *d_cnt = (uint32_t *)(arena + o_cnt), *d_best = (uint32_t *)(arena + o_best), *d_first = (uint32_t *)(arena + o_first);
+    double *d_uvd = (double *)(arena + o_uvd), *d_p0 = (double *)(arena + o_p0), *d_p1 = (double *)(arena + o_p1), *d_Th = (double *)(arena + o_Th),
+           *d_Tp = (double *)(arena + o_Tp), *d_poses = (double *)(arena + o_poses), *d_map = (double *)(arena + o_map);
+    uint8_t *d_in = (uint8_t *)(arena + o_in), *d_init = (uint8_t *)(arena + o_init);
+    int *d_status = (int *)(arena + o_status);
     {
         const Cam cam = {camera->fu, camera->fv, camera->cu, camera->cv, camera->b};
         const size_t nh = (size_t)num_pairs * num_iters;
-        hipEventCreate(&e0); hipEventCreate(&e1);
-        hipEventRecord(e0, nullptr);
+        if (device_time_s) { hipEventCreate(&e0); hipEventCreate(&e1); hipEventRecord(e0, nullptr); }
         hipLaunchKernelGGL(k_fe_match, dim3(num_pairs), dim3(256), 0, nullptr, cam, d_start, d_id, d_sorted, d_uvd, d_mobs, d_p0, d_p1, d_mcnt);
         hipLaunchKernelGGL(k_fe_samples, dim3((num_pairs + 63) / 64), dim3(64), 0, nullptr, d_raw, nraw, d_mcnt, num_pairs, num_iters, libstdcxx_variant, d_smp, d_status);
         hipLaunchKernelGGL(k_fe_align, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, nullptr, d_start, d_p0, d_p1, d_smp, d_mcnt, num_pairs, num_iters, d_Th);
@@ -589,29 +605,30 @@ int ssba_frontend_vo(const ssba_camera *camera, int device, uint32_t num_states,
         hipLaunchKernelGGL(k_fe_chain, dim3(1), dim3(64), 0, nullptr, d_Tp, num_pairs, d_poses);
         hipLaunchKernelGGL(k_fe_map_first, dim3(num_pairs), dim3(256), 0, nullptr, d_start, d_id, d_mobs, d_mcnt, d_in, d_init, num_points, d_first);
         hipLaunchKernelGGL(k_fe_map_write, dim3(num_pairs), dim3(256), 0, nullptr, d_start, d_id, d_mobs, d_mcnt, d_in, d_init, num_points, d_first, d_p0, d_poses, d_map);
-        hipEventRecord(e1, nullptr);
+        if (device_time_s) hipEventRecord(e1, nullptr);
         FE_TRY(hipDeviceSynchronize());
         FE_TRY(hipGetLastError());
         float ms = 0.f;
         if (device_time_s && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) *device_time_s = 1e-3 * ms;
     }
-    FE_TRY(hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost));
-    if (match_count) FE_TRY(hipMemcpy(match_count, d_mcnt, num_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (inlier_count) FE_TRY(hipMemcpy(inlier_count, d_best, num_pairs * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (status == 1) { g_fe_error = "a pair of consecutive states has fewer than three matches"; rc = SSBA_ERR_NUMERICAL_FAILURE; goto done; }
-    if (status == 2) { g_fe_error = "random stream exhausted"; rc = SSBA_ERR_NUMERICAL_FAILURE; goto done; }
-    FE_TRY(hipMemcpy(poses, d_poses, (size_t)num_states * 12 * sizeof(double), hipMemcpyDeviceToHost));
-    FE_TRY(hipMemcpy(map_points, d_map, (size_t)num_points * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    FE_TRY(hipMemcpy(initialized, d_init, num_points, hipMemcpyDeviceToHost));
+    }
+    {
+        const size_t down = up_bytes - o_status;
+        FE_TRY(hipMemcpy(host.data() + o_status, arena + o_status, down, hipMemcpyDeviceToHost));
+        memcpy(&status, host.data() + o_status, sizeof(int));
+        if (match_count) memcpy(match_count, host.data() + o_mcnt, num_pairs * sizeof(uint32_t));
+        if (inlier_count) memcpy(inlier_count, host.data() + o_best, num_pairs * sizeof(uint32_t));
+        if (status == 1) { g_fe_error = "a pair of consecutive states has fewer than three matches"; rc = SSBA_ERR_NUMERICAL_FAILURE; goto done; }
+        if (status == 2) { g_fe_error = "random stream exhausted"; rc = SSBA_ERR_NUMERICAL_FAILURE; goto done; }
+        memcpy(poses, host.data() + o_poses, (size_t)num_states * 12 * sizeof(double));
+        memcpy(map_points, host.data() + o_map, (size_t)num_points * 3 * sizeof(double));
+        memcpy(initialized, host.data() + o_init, num_points);
+    }
 done:
 #undef FE_TRY
     if (e0) hipEventDestroy(e0);
     if (e1) hipEventDestroy(e1);
-    (void)hipDeviceSynchronize();
-    ssba::pool_free(d_start); ssba::pool_free(d_id); ssba::pool_free(d_sorted); ssba::pool_free(d_mobs); ssba::pool_free(d_mcnt); ssba::pool_free(d_raw);
-    ssba::pool_free(d_smp); ssba::pool_free(d_cnt); ssba::pool_free(d_best); ssba::pool_free(d_first); ssba::pool_free(d_uvd); ssba::pool_free(d_p0);
-    ssba::pool_free(d_p1); ssba::pool_free(d_Th); ssba::pool_free(d_Tp); ssba::pool_free(d_poses); ssba::pool_free(d_map); ssba::pool_free(d_in);
-    ssba::pool_free(d_init); ssba::pool_free(d_status);
+    if (arena) { (void)hipDeviceSynchronize(); ssba::pool_free(arena); }
     return rc;
 }
 
