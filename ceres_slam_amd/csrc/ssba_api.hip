@@ -86,6 +86,8 @@ struct ssba_problem {
     Launcher launcher;
     hipStream_t own_stream = nullptr;
     std::vector<void *> allocs;
+    bool defer_zero = false;                  // ssba_finalize: zero-fills are collected and done by ONE launch (flush_zero)
+    std::vector<ZeroRange> zero_list;
     // uploads of ssba_finalize: copied into pinned chunks and sent asynchronously on the solver's stream, released after one
     // synchronisation at the end (a synchronous pageable hipMemcpy per array cost more than the layout work of small windows)
     std::vector<void *> stage_chunks;
@@ -175,7 +177,29 @@ template <class T>
 static int dzero(ssba_problem *p, T **out, size_t n) {
     int rc = dalloc(p, out, n);
     if (rc) return rc;
-    HIPCHECK(hipMemsetAsync(*out, 0, std::max<size_t>(n, 1) * sizeof(T), p->launcher.stream));
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    if (p->defer_zero) {      // chunks of <= 1 MiB: one work-group each
+        for (size_t o = 0; o < bytes; o += (size_t)1 << 20) p->zero_list.push_back({(char *)*out + o, (uint64_t)std::min<size_t>(bytes - o, (size_t)1 << 20)});
+        return SSBA_OK;
+    }
+    HIPCHECK(hipMemsetAsync(*out, 0, bytes, p->launcher.stream));
+    return SSBA_OK;
+}
+// The ~70 zero-fills of ssba_finalize in one launch (each hipMemsetAsync costs the host ~2 us: 0.15 ms per handle, which is
+// what a two-state window notices); buffers come 256-byte aligned from the pool.
+static int flush_zero(ssba_problem *p) {
+    p->defer_zero = false;
+    if (p->zero_list.empty()) return SSBA_OK;
+    const size_t bytes = p->zero_list.size() * sizeof(ZeroRange);
+    ZeroRange *dl = nullptr;
+    int rc = dalloc(p, &dl, p->zero_list.size());
+    if (rc) return rc;
+    char *h = nullptr;
+    if ((rc = stage_alloc(p, bytes, &h))) return rc;
+    memcpy(h, p->zero_list.data(), bytes);
+    HIPCHECK(hipMemcpyAsync(dl, h, bytes, hipMemcpyHostToDevice, p->launcher.stream));
+    launch_zero_ranges(p->launcher.stream, dl, (int)p->zero_list.size());
+    p->zero_list.clear();
     return SSBA_OK;
 }
 
@@ -1197,6 +1221,7 @@ int ssba_finalize(ssba_problem *p) {
     d.n_obs = (uint32_t)N;
     int rc;
 #define TRY(x) do { rc = (x); if (rc) return rc; } while (0)
+    p->defer_zero = true;       // until flush_zero() below
     TRY(dzero(p, &d.poses, (size_t)P * 12)); TRY(dzero(p, &d.cand_poses, (size_t)P * 12));
     TRY(dzero(p, &d.best_poses, (size_t)P * 12)); TRY(dzero(p, &d.init_poses, (size_t)P * 12));
     TRY(dzero(p, &d.pts, (size_t)Lpad * 3)); TRY(dzero(p, &d.cand_pts, (size_t)Lpad * 3));
@@ -1486,6 +1511,7 @@ int ssba_finalize(ssba_problem *p) {
             flags |= 2;
         }
     }
+    TRY(flush_zero(p));
 #undef TRY
     stage_release(p);
     phase.mark("finalize: 8 plans + tables");

@@ -1756,6 +1756,19 @@ __global__ __launch_bounds__(256) void k_mask_unowned_poses(Dev d, double *poses
         for (int c = 0; c < 12; ++c) poses[(size_t)k * 12 + c] = 0.0;
 }
 
+// zero-fill of a list of buffers in one launch (ssba_finalize): work-group r clears range r
+__global__ __launch_bounds__(256) void k_zero_ranges(const ZeroRange *ranges) {
+    const ZeroRange r = ranges[blockIdx.x];
+    double2 *q = reinterpret_cast<double2 *>(r.ptr);
+    const uint64_t n16 = r.bytes / 16;
+    for (uint64_t i = threadIdx.x; i < n16; i += 256) q[i] = make_double2(0.0, 0.0);
+    unsigned char *tail = reinterpret_cast<unsigned char *>(r.ptr) + n16 * 16;
+    if (threadIdx.x < (r.bytes & 15)) tail[threadIdx.x] = 0;
+}
+void launch_zero_ranges(hipStream_t stream, const ZeroRange *ranges, int n) {
+    if (n > 0) hipLaunchKernelGGL(k_zero_ranges, dim3(n), dim3(256), 0, stream, ranges);
+}
+
 // ----------------------------------------------------------------- launchers ---
 int configure_schur() {
     return hipFuncSetAttribute((const void *)k_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,

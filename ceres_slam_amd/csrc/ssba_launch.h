@@ -99,6 +99,8 @@ struct Launcher {
 
 int upload_pair_table(hipStream_t s);
 int upload_bcr_tables(hipStream_t s);
+struct ZeroRange { void *ptr; uint64_t bytes; };
+void launch_zero_ranges(hipStream_t stream, const ZeroRange *ranges, int n);       // one work-group per range (<= 1 MiB each)
 int configure_kernels();
 int configure_schur();
 int configure_dense();
