@@ -168,6 +168,27 @@ def roofline_of(work, avg_ms):
     return r
 
 
+def _rccl_first_use(local_rank):
+    """On this pool RCCL warns at start-up ('Missing "iommu=pt" ... can lead to system instability or hang') and the FIRST
+    communicator set-up on a fresh box occasionally does hang (seen on a one-GPU box: about one box in ten; the next
+    process on the same box is fine).  A child process with a time limit takes that first use -- a world-of-one
+    communicator through libssba.so on this rank's GPU -- before this process touches RCCL; whatever happens to it, the
+    bench goes on."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ceres_slam_amd import sharding, synth\n"
+            "from ceres_slam_amd.solver import StereoBA\n"
+            "p = synth.make_problem(4, 80, track_len=4, seed=1)\n"
+            "ba = StereoBA(p.camera, p.poses_init.copy(), p.points_init.copy(), p.obs_pose, p.obs_point, p.obs_uvd, p.stiffness(),\n"
+            "              device=%d, world_size=1, rank=0)\n"
+            "sharding.attach_rccl_exchange(ba, None)\n"
+            "ba.close()\n") % (os.path.dirname(os.path.abspath(__file__)), local_rank)
+    try:
+        subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] local rank {local_rank}: RCCL's first communicator set-up on this box hung for 120 s (child process killed)", file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +222,8 @@ def main():
     # boxes with a single GPU (all ranks share cuda:0, collectives staged through the host)
     backend = os.environ.get("SSBA_BENCH_BACKEND", "nccl")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    if world > 1 and backend == "nccl":
+        _rccl_first_use(local_rank)
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
