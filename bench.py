@@ -216,14 +216,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the stereo-BA path is HIP-only (no CPU fallback)")
     # one rank per GPU; SSBA_BENCH_BACKEND=gloo + fewer devices than ranks is a rehearsal mode for
     # boxes with a single GPU (all ranks share cuda:0, collectives staged through the host)
     backend = os.environ.get("SSBA_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)       # (counting devices does not initialise the GPU)
     if world > 1 and backend == "nccl":
-        _rccl_first_use(local_rank)
+        _rccl_first_use(local_rank)       # a child process, started before this one initialises the GPU
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the stereo-BA path is HIP-only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         if backend == "nccl":
