@@ -315,11 +315,11 @@ def main():
             done += k
 
     ba.solve_begin(opts, ignore_convergence=True)
-    # set-up, not measurement: the two hipGraphs the production path replays (eight iterations per launch, and the single
-    # iteration for the remainder) are captured here, whatever --warmup is (a warm-up shorter than eight iterations would
+    # set-up, not measurement: the two hipGraphs the production path replays (ten iterations per launch, and the single
+    # iteration for the remainder) are captured here, whatever --warmup is (a warm-up shorter than ten iterations would
     # leave the capture + instantiation of the batched graph, ~1.5 ms, inside the K timed steps)
     if world == 1:
-        ba.step(9)
+        ba.step(11)
         ba.synchronize()
         ba.restart()
     run(args.warmup, False)

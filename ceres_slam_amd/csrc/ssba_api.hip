@@ -105,7 +105,7 @@ struct ssba_problem {
     // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
-    hipGraph_t graph2 = nullptr;            // GRAPH_ITERS iterations per replay (ssba_solve_step(n >= GRAPH_ITERS)): 1/8 of the replay gaps
+    hipGraph_t graph2 = nullptr;            // GRAPH_ITERS iterations per replay (ssba_solve_step(n >= GRAPH_ITERS)): a tenth of the replay gaps
     hipGraphExec_t gexec2 = nullptr;
     // multi-rank: the kernel runs between the exchange points are captured as separate graphs
     hipGraph_t seg_graph[3] = {nullptr, nullptr, nullptr};
@@ -1683,7 +1683,7 @@ static int enqueue_front(ssba_problem *p);
 // 7/8 of the ~9 us between replays.  (ssba_solve polls the state one replay behind and keeps single iterations: idle
 // iterations after termination would cost what the batches save.)  Returns SSBA_ERR_STATE when this handle does not
 // replay graphs (the caller falls back to single iterations).
-constexpr int GRAPH_ITERS = 8;
+constexpr int GRAPH_ITERS = 10;
 static int enqueue_batch(ssba_problem *p) {
     if (p->d.constrained || !p->use_graph || p->xfn || p->launcher.timing) return SSBA_ERR_STATE;
     hipStream_t s = p->launcher.stream;
