@@ -194,6 +194,14 @@ def test_stepwise_api_and_restart_reproduce_the_blocking_solve(c1_problem):
     s2 = ba2.solve_end()
     assert s2.num_iterations == s.num_iterations and s2.final_cost == s.final_cost
     assert np.array_equal(ba.poses, ba2.poses)
+    # any split of the steps (eager launches, single-iteration replays, ten-iteration replays) is the same arithmetic
+    ba4 = StereoBA.from_synth(c1_problem)
+    ba4.solve_begin(o)
+    for k in (3, 10, 11, 1, 15):
+        ba4.step(k)
+    s4 = ba4.solve_end()
+    assert s4.num_iterations == s.num_iterations and s4.final_cost == s.final_cost
+    assert np.array_equal(ba.poses, ba4.poses)
     # deterministic: a second run gives bit-identical results (no float atomics anywhere)
     ba3 = StereoBA.from_synth(c1_problem)
     s3, log3 = ba3.solve(o)
