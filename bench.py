@@ -10,10 +10,13 @@ Contract (one JSON line on rank 0):
     solve repeatedly: whenever the solve has done as many iterations as the converging
     solve needs (measured in warm-up) the parameters are reset on the device and the
     solve restarts, so every timed iteration does the full work of a live iteration;
-  * N > 1 (one rank per GPU under torch.distributed.run): weak scaling -- every rank owns
-    one C2-sized segment of an N-times longer trajectory (its landmarks and their
-    observations; poses replicated); the reduced pose system is all-reduced over RCCL
-    every iteration.  `value` = N x joint-problem iterations/s (C2-shard-iterations/s).
+  * N > 1: `python bench.py --gpus N` starts its own N ranks as child processes (torch.distributed.run, one per GPU); under
+    a launcher (WORLD_SIZE set) it is one of the ranks.  Landmarks are sharded, poses replicated; every rank eliminates
+    its chain of the reduced system and only the separator blocks are summed over RCCL (all-reduce of the whole reduced
+    system with SSBA_NO_PARTITION=1).  Workload: N = 2, 4 -> N x C2 (one C2-sized trajectory segment per rank); N = 8 ->
+    BASELINE.json configs[3] exactly (C4 = 10 000 poses / 1 000 000 landmarks), with the 8 x C2 weak-scaling figure as the
+    secondary key `weak_scaling_NxC2`.  `value` = joint-problem iterations/s x (landmarks / 100 000), i.e. C2-sized units
+    of work per second; `config.joint_iters_per_sec` is the plain rate of the joint problem.
   * `roofline`: the dominant kernel's algorithmic bytes or flops per launch / its average
     duration measured with HIP events on the library's stream during the timed region;
   * `cpu_baseline`: the CPU oracle (a port with Ceres-equivalent semantics, NOT Ceres --
@@ -168,81 +171,65 @@ def roofline_of(work, avg_ms):
     return r
 
 
-def _rccl_first_use(local_rank):
-    """On this pool RCCL warns at start-up ('Missing "iommu=pt" ... can lead to system instability or hang') and the FIRST
-    communicator set-up on a fresh box occasionally does hang (seen on a one-GPU box: about one box in ten; the next
-    process on the same box is fine).  A child process with a time limit takes that first use -- a world-of-one
-    communicator through libssba.so on this rank's GPU -- before this process touches RCCL; whatever happens to it, the
-    bench goes on."""
+def launch_ranks(args):
+    """`python bench.py --gpus N` typed without a launcher: start the N ranks as CHILD processes (torch.distributed.run, one
+    rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU call, relay rank 0's JSON line and the
+    exit code.  Nothing else happens in the parent."""
+    import socket
     import subprocess
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from ceres_slam_amd import sharding, synth\n"
-            "from ceres_slam_amd.solver import StereoBA\n"
-            "p = synth.make_problem(4, 80, track_len=4, seed=1)\n"
-            "ba = StereoBA(p.camera, p.poses_init.copy(), p.points_init.copy(), p.obs_pose, p.obs_point, p.obs_uvd, p.stiffness(),\n"
-            "              device=%d, world_size=1, rank=0)\n"
-            "sharding.attach_rccl_exchange(ba, None)\n"
-            "ba.close()\n") % (os.path.dirname(os.path.abspath(__file__)), local_rank)
-    try:
-        subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=120)
-    except subprocess.TimeoutExpired:
-        print(f"[bench] local rank {local_rank}: RCCL's first communicator set-up on this box hung for 120 s (child process killed)", file=sys.stderr)
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="C2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=1000, help="iteration cap of the CPU-oracle sample (it converges in ~80)")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP-event bracketing (use under rocprofv3)")
-    ap.add_argument("--shared-free", type=int, default=0, help="C3 only: free shared blocks (bit 0 light, 1 Phong, 2 texture)")
-    ap.add_argument("--bounds", action="store_true", help="C3 only: the driver's bounds on the Phong / texture blocks")
-    ap.add_argument("--dogleg", type=int, default=-1, help="-1 LM (dataset_vo), 0 TRADITIONAL_DOGLEG, 1 SUBSPACE_DOGLEG")
-    args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from ceres_slam_amd import capi, synth
-    from ceres_slam_amd.solver import StereoBA
-    from ceres_slam_amd import sharding
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-    # one rank per GPU; SSBA_BENCH_BACKEND=gloo + fewer devices than ranks is a rehearsal mode for
-    # boxes with a single GPU (all ranks share cuda:0, collectives staged through the host)
-    backend = os.environ.get("SSBA_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)       # (counting devices does not initialise the GPU)
-    if world > 1 and backend == "nccl":
-        _rccl_first_use(local_rank)       # a child process, started before this one initialises the GPU
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the stereo-BA path is HIP-only (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what this pool's driver supports (RCCL, tensor sharing)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out.strip()
         else:
-            dist.init_process_group(backend)
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    raise SystemExit(rc if rc or line else 1)
 
-    phong = args.config == "C3"           # BASELINE.json configs[2]: C2 + Phong lighting residual blocks
-    robust = args.config == "C5"          # BASELINE.json configs[4]: Huber loss, 30 % outlier observations (C2 shape per GPU)
+
+def host_description():
+    """nproc and CPU model of the box (the CPU baseline is only meaningful with both)."""
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return {"nproc": os.cpu_count() or 1, "usable_cpus": usable, "cpu_model": model}
+
+
+def measure(args, name, P, L, ctx, kernel_timing, phong=False, robust=False):
+    """One workload: build the (sharded) problem, solve it once to convergence, then time `args.steps` iterations of the
+    production path between barriers.  Returns everything the bench line reports for it (rank 0 decides what to print)."""
+    import torch
+    from ceres_slam_amd import capi, sharding, synth
+    from ceres_slam_amd.solver import StereoBA
+    world, rank, local_rank, dist, backend = ctx["world"], ctx["rank"], ctx["local_rank"], ctx["dist"], ctx["backend"]
     huber_a = 1.345 if robust else 0.0
-    P1, L1 = synth.CONFIGS["C2" if (phong or robust) else args.config]
     lighting = None
     if phong:
         if world > 1 and args.shared_free and (args.bounds or args.dogleg >= 0):
             raise SystemExit("config C3 with FREE shared blocks shards with LM and without bounds only")
-        prob, ph = synth.make_phong_problem(P1 * world, L1 * world)
+        prob, ph = synth.make_phong_problem(P, L)
         lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
-        prob = synth.make_problem(P1 * world, L1 * world, outlier_fraction=0.3 if robust else 0.0)
+        prob = synth.make_problem(P, L, outlier_fraction=0.3 if robust else 0.0)
     partition = None
     if world > 1:
         # landmark ranges cut at super-block boundaries -> partitioned reduced solve (only the separator system is
@@ -265,11 +252,12 @@ def main():
                   prob.stiffness(), device=local_rank, world_size=world, rank=rank, lighting=lighting,
                   shared_free=args.shared_free if phong else 0, use_bounds=bool(phong and args.bounds), partition=partition,
                   huber_a=huber_a)
-    exchange = "none"
+    exchange, rccl_ranks, rccl_note = "none", 0, None
     if world > 1:
         # native exchange: libssba.so enqueues ncclAllReduce (RCCL over xGMI) itself on its stream; torch.distributed only
         # carries the 128-byte unique id.  SSBA_BENCH_EXCHANGE=torch (or a gloo rehearsal) routes the collectives through
-        # torch.distributed instead; so does a failed RCCL set-up on any rank.
+        # torch.distributed instead; so does a failed or timed-out RCCL set-up on any rank (ssba_set_rccl is time-limited
+        # and says where it sat: the text goes to stderr and into the bench line)
         want_native = backend == "nccl" and os.environ.get("SSBA_BENCH_EXCHANGE", "rccl") != "torch"
         ok = 0
         if want_native:
@@ -277,12 +265,14 @@ def main():
                 sharding.attach_rccl_exchange(ba, dist)
                 ok = 1
             except Exception as e:      # noqa: BLE001 -- any failure falls back, on every rank
+                rccl_note = f"rank {rank}: {e}"
                 print(f"[bench] rank {rank}: native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag.item())
         if ok:
             exchange = "rccl (native, in libssba.so)"
+            rccl_ranks = ba.rccl_ranks()
         else:
             ba.set_exchange(None)
             sharding.attach_torch_exchange(ba, dist)      # library kernels + collectives on one dedicated torch stream
@@ -310,16 +300,17 @@ def main():
         while done < n_steps:
             if done and done % period == 0:
                 ba.restart()
-            k = min(n_steps - done, period - done % period)      # up to the next restart in one call (graph replays of two iterations)
+            k = min(n_steps - done, period - done % period)      # up to the next restart in one call (graph replays of ten iterations)
             ba.step(k)
             done += k
 
     ba.solve_begin(opts, ignore_convergence=True)
     # set-up, not measurement: the two hipGraphs the production path replays (ten iterations per launch, and the single
     # iteration for the remainder) are captured here, whatever --warmup is (a warm-up shorter than ten iterations would
-    # leave the capture + instantiation of the batched graph, ~1.5 ms, inside the K timed steps)
+    # leave the capture + instantiation of the batched graph, ~1.5 ms, inside the K timed steps): ten iterations capture
+    # the batch, the next seven run the six eager iterations a fresh handle starts with and capture the single one
     if world == 1:
-        ba.step(11)
+        ba.step(17)
         ba.synchronize()
         ba.restart()
     run(args.warmup, False)
@@ -330,7 +321,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(args.steps, False)          # production path: one hipGraph replay per iteration
+    run(args.steps, False)          # production path: hipGraph replays
     ba.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -341,7 +332,7 @@ def main():
     # events on the library's stream (per-kernel durations for the roofline; agrees with
     # rocprofv3 --kernel-trace of this command)
     dt_instr = None
-    if not args.no_kernel_timing:
+    if kernel_timing:
         ba.restart()
         ba.synchronize()
         t1 = time.perf_counter()
@@ -350,90 +341,175 @@ def main():
         dt_instr = time.perf_counter() - t1
     ktimes = ba.kernel_times()
     ba.solve_end()
+    xsize = int(ba.exchange_size()) if world > 1 else 0
+    ba.close()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    return dict(name=name, prob=prob, lighting=lighting, huber_a=huber_a, stats=stats, dt=dt, dt_instr=dt_instr, ktimes=ktimes,
+                period=period, final_cost=final_cost, solve_iterations=int(s_conv.num_iterations), solve_wall_s=solve_wall_s,
+                solve_device_s=solve_device_s, exchange=exchange, rccl_ranks=rccl_ranks, rccl_note=rccl_note,
+                partitioned=partition is not None, exchange_doubles=xsize, poses=P, landmarks=L)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default=None, help="C2 (default at N = 1), C3, C4, C5; default at N > 1: N x C2 for N = 2, 4 and "
+                                                   "C4 exactly (10 000 poses / 1 M landmarks, BASELINE configs[3]) at N = 8")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=1000, help="iteration cap of the CPU-oracle sample (it converges in ~80)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP-event bracketing (use under rocprofv3)")
+    ap.add_argument("--no-weak-secondary", action="store_true", help="N = 8: skip the secondary 8 x C2 weak-scaling measurement")
+    ap.add_argument("--shared-free", type=int, default=0, help="C3 only: free shared blocks (bit 0 light, 1 Phong, 2 texture)")
+    ap.add_argument("--bounds", action="store_true", help="C3 only: the driver's bounds on the Phong / texture blocks")
+    ap.add_argument("--dogleg", type=int, default=-1, help="-1 LM (dataset_vo), 0 TRADITIONAL_DOGLEG, 1 SUBSPACE_DOGLEG")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)         # children; never returns
+
+    import torch
+    import torch.distributed as dist
+    from ceres_slam_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    # one rank per GPU; SSBA_BENCH_BACKEND=gloo + fewer devices than ranks is a rehearsal mode for
+    # boxes with a single GPU (all ranks share cuda:0, collectives staged through the host)
+    backend = os.environ.get("SSBA_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)       # (counting devices does not initialise the GPU)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the stereo-BA path is HIP-only (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    ctx = dict(world=world, rank=rank, local_rank=local_rank, dist=dist, backend=backend)
+
+    cfg = args.config or ("C2" if world < 8 else "C4")
+    phong = cfg == "C3"                   # BASELINE.json configs[2]: C2 + Phong lighting residual blocks
+    robust = cfg == "C5"                  # BASELINE.json configs[4]: Huber loss, 30 % outlier observations (C2 shape per GPU)
+    P1, L1 = synth.CONFIGS["C2" if (phong or robust) else cfg]
+    C2P, C2L = synth.CONFIGS["C2"]
+    # the joint problem: C4 is a fixed size (strong-scaled over the ranks); the C2-shaped configurations grow with the ranks
+    P, L = (P1, L1) if cfg == "C4" else (P1 * world, L1 * world)
+    m = measure(args, cfg, P, L, ctx, kernel_timing=not args.no_kernel_timing, phong=phong, robust=robust)
+    weak = None
+    if world == 8 and args.config is None and not args.no_weak_secondary:
+        weak = measure(args, "C2", C2P * world, C2L * world, ctx, kernel_timing=False)
 
     if rank == 0:
-        ms = 1e3 * dt / args.steps
-        joint_ips = args.steps / dt
+        print(json.dumps(bench_line(args, m, weak, world, cfg)), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_line(args, m, weak, world, cfg):
+    from ceres_slam_amd import synth
+    C2L = synth.CONFIGS["C2"][1]
+    stats, ktimes, prob, dt = m["stats"], m["ktimes"], m["prob"], m["dt"]
+    phong, robust = cfg == "C3", cfg == "C5"
+    ms = 1e3 * dt / args.steps
+    joint_ips = args.steps / dt
+    # `value` counts C2-sized units of work: one iteration of a joint problem with k x 100 000 landmarks is k units
+    # (N x C2 at N ranks: N units; C4: 10 units)
+    units = m["landmarks"] / C2L
+    out = {
+        "metric": "gauss_newton_iters_per_sec",
+        "value": joint_ips * units,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms,
+        "ms_per_step_instrumented": (1e3 * m["dt_instr"] / args.steps) if m["dt_instr"] else None,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "value_definition": "joint-problem iterations/s x (landmarks of the joint problem / 100 000): C2-sized units of work per "
+                            "second, so that N = 1 (C2), N x C2 and C4 (10 units per iteration) are one scale; joint_iters_per_sec "
+                            "is the plain rate of the joint problem",
+        "config": {"workload": f"{cfg}: {m['poses']} poses / {m['landmarks']} landmarks / "
+                               f"{prob.num_obs} stereo observations, "
+                               + ("stereo + Phong intensity + normal residual blocks, 6-D landmark blocks "
+                                  f"(position + unit normal), shared_free={args.shared_free}, bounds={bool(args.bounds)}, "
+                                  f"strategy={'LM' if args.dogleg < 0 else 'DOGLEG/%d' % args.dogleg}"
+                                  if phong else ("reprojection-only LM (Ceres dataset_vo options)"
+                                                 + (", HuberLoss(1.345) on every block, 30 % outlier observations" if robust else "")))
+                               + f", {world} shard(s)",
+                   "poses": m["poses"], "landmarks": m["landmarks"], "observations": int(prob.num_obs),
+                   "exchange": m["exchange"], "rccl_ranks": m["rccl_ranks"],
+                   "reduced_solve": ("partitioned: chain elimination per rank + separator exchange" if m["partitioned"]
+                                     else ("replicated after an all-reduce of the reduced system" if world > 1 else "single GPU")),
+                   "exchange_doubles_per_iteration": m["exchange_doubles"],
+                   "restart_period_iters": m["period"], "joint_iters_per_sec": joint_ips, "c2_units_per_iteration": units,
+                   "converged_final_cost": m["final_cost"],
+                   # one blocking ssba_solve from host buffers: upload + loop + write-back (PCIe-inclusive)
+                   "solve_iterations": m["solve_iterations"], "solve_wall_s_incl_pcie": m["solve_wall_s"],
+                   "solve_device_s": m["solve_device_s"]},
+        "stats": stats,
+    }
+    if m["rccl_note"]:
+        out["config"]["rccl_set_up_failure"] = m["rccl_note"]
+    if weak is not None:
+        w_ips = args.steps / weak["dt"]
+        out["weak_scaling_NxC2"] = {"workload": f"{world} x C2: {weak['poses']} poses / {weak['landmarks']} landmarks / {weak['prob'].num_obs} "
+                                                "observations (one C2-sized segment per rank)",
+                                    "joint_iters_per_sec": w_ips, "ms_per_step": 1e3 * weak["dt"] / args.steps,
+                                    "value": w_ips * weak["landmarks"] / C2L, "exchange": weak["exchange"], "rccl_ranks": weak["rccl_ranks"],
+                                    "exchange_doubles_per_iteration": weak["exchange_doubles"]}
+    if any(v[0] for v in ktimes.values()):
         work = algorithmic_work(stats, phong)
         per_kernel = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in ktimes.items()}   # avg ms
         iter_kernel_ms = {k: v[1] / args.steps for k, v in ktimes.items()}
-        if not any(v[0] for v in ktimes.values()):
-            print(json.dumps({"metric": "gauss_newton_iters_per_sec", "value": joint_ips * world, "unit": "iters/s",
-                              "ms_per_step": ms, "note": "kernel timing disabled"}))
-            return
         dom = max((k for k in iter_kernel_ms if k in work), key=lambda k: iter_kernel_ms[k])
         roof = roofline_of(work[dom], per_kernel[dom])
         roof["kernel"] = dom
         roof_all = {k: roofline_of(work[k], per_kernel[k]) for k in work if per_kernel.get(k)}
-        traffic, traffic_src = pmc_traffic(args.config) if world == 1 else ({}, None)
+        traffic, traffic_src = pmc_traffic(cfg) if world == 1 else ({}, None)
         for k, r in roof_all.items():
             r["traffic"] = traffic.get(k)
             r["algorithmic_bytes"] = work[k]["bytes"]
         roof["traffic"] = traffic.get(dom)
         roof["traffic_source"] = f"{traffic_src} (rocprofv3 --pmc passes of the same command; replayed, not measured in this run)" if traffic_src else None
         roof["algorithmic_bytes"] = work[dom]["bytes"]
-        wi = whole_iteration_work(stats)
-        wi["ms"] = ms
-        wi["achieved_GBs"] = wi["bytes"] / (ms * 1e-3) / 1e9
-        wi["achieved_TFLOPs"] = wi["flops"] / (ms * 1e-3) / 1e12
-        wi["frac_hbm"] = wi["achieved_GBs"] / HBM_PEAK_GBS
-        wi["frac_fp64"] = wi["achieved_TFLOPs"] / FP64_PEAK_TFLOPS
-        wi["floor_us_at_hbm_peak"] = wi["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
-        out = {
-            "metric": "gauss_newton_iters_per_sec",
-            "value": joint_ips * world,
-            "unit": "iters/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms,
-            "ms_per_step_instrumented": (1e3 * dt_instr / args.steps) if dt_instr else None,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config}: {P1 * world} poses / {L1 * world} landmarks / "
-                                   f"{prob.num_obs} stereo observations, "
-                                   + ("stereo + Phong intensity + normal residual blocks, 6-D landmark blocks "
-                                      f"(position + unit normal), shared_free={args.shared_free}, bounds={bool(args.bounds)}, "
-                                      f"strategy={'LM' if args.dogleg < 0 else 'DOGLEG/%d' % args.dogleg}"
-                                      if phong else ("reprojection-only LM (Ceres dataset_vo options)"
-                                                     + (", HuberLoss(1.345) on every block, 30 % outlier observations" if robust else "")))
-                                   + f", {world} shard(s)",
-                       "poses": P1 * world, "landmarks": L1 * world, "observations": int(prob.num_obs),
-                       "exchange": exchange,
-                       "reduced_solve": ("partitioned: chain elimination per rank + separator exchange" if partition is not None
-                                         else ("replicated after an all-reduce of the reduced system" if world > 1 else "single GPU")),
-                       "exchange_doubles_per_iteration": int(ba.exchange_size()) if world > 1 else 0,
-                       "restart_period_iters": period, "joint_iters_per_sec": joint_ips,
-                       "converged_final_cost": final_cost,
-                       # one blocking ssba_solve from host buffers: upload + loop + write-back (PCIe-inclusive)
-                       "solve_iterations": int(s_conv.num_iterations), "solve_wall_s_incl_pcie": solve_wall_s,
-                       "solve_device_s": solve_device_s},
-            "roofline": roof,
-            "roofline_by_kernel": roof_all,
-            "roofline_whole_iteration": wi,
-            "peaks": measured_peaks(),
-            "kernel_ms_per_iter": {k: round(v, 5) for k, v in iter_kernel_ms.items()},
-            "stats": stats,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, final_cost, lighting, args, huber_a)
-            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        out["roofline"] = roof
+        out["roofline_by_kernel"] = roof_all
+        out["kernel_ms_per_iter"] = {k: round(v, 5) for k, v in iter_kernel_ms.items()}
+    else:
+        out["note"] = "kernel timing disabled"
+    wi = whole_iteration_work(stats)
+    wi["ms"] = ms
+    wi["achieved_GBs"] = wi["bytes"] / (ms * 1e-3) / 1e9
+    wi["achieved_TFLOPs"] = wi["flops"] / (ms * 1e-3) / 1e12
+    wi["frac_hbm"] = wi["achieved_GBs"] / HBM_PEAK_GBS
+    wi["frac_fp64"] = wi["achieved_TFLOPs"] / FP64_PEAK_TFLOPS
+    wi["floor_us_at_hbm_peak"] = wi["bytes"] / (HBM_PEAK_GBS * 1e9) * 1e6
+    if world == 1:
+        out["roofline_whole_iteration"] = wi
+    out["peaks"] = measured_peaks()
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, m["final_cost"], m["lighting"], args, m["huber_a"])
+        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None, huber_a=0.0):
     """CPU oracle = port with Ceres-equivalent semantics (kind "port"); bounded sample."""
     from oracle import oracle as orc
-    cores = min(os.cpu_count() or 1, 16)
+    host = host_description()
+    cores = min(host["usable_cpus"], 16)
     if lighting is None:
         op = orc.OracleProblem.from_synth(prob, huber_a=huber_a)
     else:
@@ -465,10 +541,10 @@ def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None, huber_a=
             return {"value": m / el, "unit": "iters/s", "cores": threads, "ms_per_iter": 1e3 * el / m, "iterations": m}
         variants["jet_autodiff_jacobians"] = sample(cores, True)
         variants["closed_form_8_threads"] = sample(min(8, cores), False)
-    return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port", "variants": variants,
+    return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port", "host": host, "variants": variants,
             "sample": f"{n} trust-region iterations (termination {int(s.termination_type)}) of the same "
                       f"{prob.num_obs}-observation solve: CPU restatement with Ceres-equivalent semantics, NOT Ceres "
-                      f"(OpenMP, {cores} threads, analytic Jacobians, Schur + band Cholesky); {dt:.1f} s",
+                      f"(OpenMP, {cores} threads on a {host['nproc']}-CPU {host['cpu_model']}, analytic Jacobians, Schur + band Cholesky); {dt:.1f} s",
             "ms_per_iter": 1e3 * dt / n, "final_cost": float(s.final_cost), "iterations": int(s.num_iterations),
             "gpu_final_cost": gpu_final_cost,
             "final_cost_rel_diff_gpu_vs_cpu": abs(gpu_final_cost - float(s.final_cost)) / float(s.final_cost)}

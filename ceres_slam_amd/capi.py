@@ -22,7 +22,7 @@ _i32p = C.POINTER(C.c_int32)
 
 SSBA_OK = 0
 STATUS = {0: "SSBA_OK", -1: "SSBA_ERR_INVALID_ARGUMENT", -2: "SSBA_ERR_HIP", -3: "SSBA_ERR_NUMERICAL_FAILURE",
-          -4: "SSBA_ERR_NOT_FINALIZED", -5: "SSBA_ERR_NO_DEVICE", -6: "SSBA_ERR_UNSUPPORTED", -7: "SSBA_ERR_STATE"}
+          -4: "SSBA_ERR_NOT_FINALIZED", -5: "SSBA_ERR_NO_DEVICE", -6: "SSBA_ERR_UNSUPPORTED", -7: "SSBA_ERR_STATE", -8: "SSBA_ERR_TIMEOUT"}
 
 #: every symbol include/ssba.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -36,6 +36,7 @@ SYMBOLS = [
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant", "ssba_release_cached_memory",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation", "ssba_add_relative_pose",
     "ssba_pose_covariance", "ssba_rccl_unique_id", "ssba_set_rccl", "ssba_frontend_vo",
+    "ssba_rccl_describe", "ssba_rccl_ranks",
 ]
 
 
@@ -126,6 +127,8 @@ def load():
                                    _dp, _dp, C.POINTER(C.c_uint8), _u32p, _u32p, _dp]
     L.ssba_rccl_unique_id.argtypes = [C.c_void_p, C.c_uint64]
     L.ssba_set_rccl.argtypes = [H, C.c_void_p, C.c_uint64]
+    L.ssba_rccl_describe.argtypes = [C.c_char_p, C.c_uint64]
+    L.ssba_rccl_ranks.argtypes = [H, C.POINTER(C.c_int)]
     L.ssba_exchange_size.argtypes = [H, C.POINTER(C.c_uint64)]
     L.ssba_set_kernel_timing.argtypes = [H, C.c_int]
     L.ssba_kernel_times.argtypes = [H, C.POINTER(KernelTime), C.c_int32, _i32p]

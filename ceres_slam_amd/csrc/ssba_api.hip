@@ -10,7 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -212,6 +215,7 @@ static void drop_graph(ssba_problem *p) {
         if (p->seg_exec[i]) { hipGraphExecDestroy(p->seg_exec[i]); p->seg_exec[i] = nullptr; }
         if (p->seg_graph[i]) { hipGraphDestroy(p->seg_graph[i]); p->seg_graph[i] = nullptr; }
     }
+    p->eager_iters = 0;
 }
 
 static void free_device(ssba_problem *p) {
@@ -293,6 +297,7 @@ const char *ssba_status_string(int s) {
         case SSBA_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
         case SSBA_ERR_UNSUPPORTED: return "problem structure not supported by this build";
         case SSBA_ERR_STATE: return "call sequence error";
+        case SSBA_ERR_TIMEOUT: return "a collective-library set-up call did not return in time (see ssba_last_error)";
     }
     return "unknown status";
 }
@@ -570,7 +575,10 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     bool ok = false;
+    bool preloaded = false;      // the copy was mapped by the process already (PyTorch's), not loaded by this library
 };
 RcclApi *rccl_api() {
     static RcclApi api = [] {
@@ -579,7 +587,7 @@ RcclApi *rccl_api() {
         // is loaded from the ROCm installation: two RCCL instances in one process share no state
         for (const char *name : {"librccl.so", "librccl.so.1"}) {
             a.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-            if (a.lib) break;
+            if (a.lib) { a.preloaded = true; break; }
         }
         for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             if (a.lib) break;
@@ -591,6 +599,8 @@ RcclApi *rccl_api() {
         a.AllReduce = (decltype(a.AllReduce))dlsym(a.lib, "ncclAllReduce");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.lib, "ncclCommDestroy");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.lib, "ncclGetErrorString");
+        a.GetVersion = (decltype(a.GetVersion))dlsym(a.lib, "ncclGetVersion");
+        a.CommCount = (decltype(a.CommCount))dlsym(a.lib, "ncclCommCount");
         a.ok = a.GetUniqueId && a.CommInitRank && a.AllReduce && a.CommDestroy && a.GetErrorString;
         return a;
     }();
@@ -613,14 +623,77 @@ static void rccl_release(ssba_problem *p) {
     if (p->xfn == rccl_exchange) { p->xfn = nullptr; p->xctx = nullptr; }
 }
 
+// RCCL's set-up calls block without a time limit of their own, and a hang there (seen on this pool: DESIGN.md section 6) would
+// hang the caller.  Both run on a helper thread and the caller waits at most SSBA_RCCL_TIMEOUT_S seconds (default 180); on
+// expiry the thread is left behind (it cannot be cancelled inside the driver), the call returns SSBA_ERR_TIMEOUT and
+// ssba_last_error() holds a record of where it sat: the phase, the librccl.so file that was mapped and its version, the
+// world, HSA_ENABLE_IPC_MODE_LEGACY and the NCCL_DEBUG_FILE to read.  The caller can then fall back to another exchange.
+extern "C++" {
+namespace {
+std::string rccl_describe() {
+    RcclApi *a = rccl_api();
+    std::string out = "librccl: ";
+    Dl_info info;
+    if (a->ok && dladdr((void *)a->CommInitRank, &info) && info.dli_fname) out += info.dli_fname; else out += "(not loaded)";
+    int v = 0;
+    if (a->ok && a->GetVersion && a->GetVersion(&v) == ncclSuccess) out += " version " + std::to_string(v);
+    out += a->preloaded ? " (already mapped by the process)" : " (loaded by libssba.so)";
+    const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY"), *dbg = getenv("NCCL_DEBUG"), *dbgf = getenv("NCCL_DEBUG_FILE");
+    out += std::string("; HSA_ENABLE_IPC_MODE_LEGACY=") + (ipc ? ipc : "(unset)") + "; NCCL_DEBUG=" + (dbg ? dbg : "(unset)") +
+           "; NCCL_DEBUG_FILE=" + (dbgf ? dbgf : "(unset)");
+    return out;
+}
+double rccl_timeout_s() {
+    const char *e = getenv("SSBA_RCCL_TIMEOUT_S");
+    const double t = e ? atof(e) : 180.0;
+    return t > 0.0 ? t : 180.0;
+}
+struct RcclJob {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t result = ncclSuccess;
+    ncclUniqueId id;
+    ncclComm_t comm = nullptr;
+};
+// runs fn(job) on a helper thread; false = not finished within the time limit (the thread keeps the job alive)
+template <class F>
+bool rccl_run_limited(std::shared_ptr<RcclJob> job, F fn, double *elapsed_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::thread([job, fn] {
+        const ncclResult_t r = fn(job.get());
+        std::lock_guard<std::mutex> lock(job->mu);
+        job->result = r;
+        job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lock(job->mu);
+    const bool ok = job->cv.wait_for(lock, std::chrono::duration<double>(rccl_timeout_s()), [&] { return job->done; });
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return ok;
+}
+}  // namespace
+}  // extern "C++"
+
+int ssba_rccl_describe(char *buf, uint64_t size) {
+    if (!buf || size == 0) return SSBA_ERR_INVALID_ARGUMENT;
+    snprintf(buf, (size_t)size, "%s", rccl_describe().c_str());
+    return SSBA_OK;
+}
+
 int ssba_rccl_unique_id(void *out, uint64_t size) {
     if (!out || size < sizeof(ncclUniqueId)) return SSBA_ERR_INVALID_ARGUMENT;
     RcclApi *a = rccl_api();
     if (!a->ok) { set_error("librccl.so could not be loaded"); return SSBA_ERR_UNSUPPORTED; }
-    ncclUniqueId id;
-    const ncclResult_t r = a->GetUniqueId(&id);
-    if (r != ncclSuccess) { set_error(std::string("ncclGetUniqueId: ") + a->GetErrorString(r)); return SSBA_ERR_HIP; }
-    memcpy(out, &id, sizeof id);
+    auto job = std::make_shared<RcclJob>();
+    double el = 0.0;
+    if (!rccl_run_limited(job, [a](RcclJob *j) { return a->GetUniqueId(&j->id); }, &el)) {
+        char t[64]; snprintf(t, sizeof t, "%.0f", el);
+        set_error(std::string("ncclGetUniqueId did not return within ") + t + " s (phase: bootstrap root set-up); " + rccl_describe());
+        return SSBA_ERR_TIMEOUT;
+    }
+    if (job->result != ncclSuccess) { set_error(std::string("ncclGetUniqueId: ") + a->GetErrorString(job->result) + "; " + rccl_describe()); return SSBA_ERR_HIP; }
+    memcpy(out, &job->id, sizeof job->id);
     return SSBA_OK;
 }
 
@@ -631,12 +704,32 @@ int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size) {
     if (!a->ok) { set_error("librccl.so could not be loaded"); return SSBA_ERR_UNSUPPORTED; }
     HIPCHECK(hipSetDevice(p->device));
     rccl_release(p);
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof id);
-    const ncclResult_t r = a->CommInitRank(&p->rccl_comm, p->world_size, id, p->rank);
-    if (r != ncclSuccess) { p->rccl_comm = nullptr; set_error(std::string("ncclCommInitRank: ") + a->GetErrorString(r)); return SSBA_ERR_HIP; }
+    auto job = std::make_shared<RcclJob>();
+    memcpy(&job->id, unique_id, sizeof job->id);
+    const int device = p->device, world = p->world_size, rank = p->rank;
+    double el = 0.0;
+    if (!rccl_run_limited(job, [a, device, world, rank](RcclJob *j) {
+            if (hipSetDevice(device) != hipSuccess) return ncclUnhandledCudaError;       // the current device is per thread
+            return a->CommInitRank(&j->comm, world, j->id, rank);
+        }, &el)) {
+        char t[160];
+        snprintf(t, sizeof t, "ncclCommInitRank(world %d, rank %d, device %d) did not return within %.0f s; ", world, rank, device, el);
+        set_error(std::string(t) + rccl_describe());
+        return SSBA_ERR_TIMEOUT;
+    }
+    if (job->result != ncclSuccess) { set_error(std::string("ncclCommInitRank: ") + a->GetErrorString(job->result) + "; " + rccl_describe()); return SSBA_ERR_HIP; }
+    p->rccl_comm = job->comm;
     p->xfn = rccl_exchange;
     p->xctx = p;
+    return SSBA_OK;
+}
+
+int ssba_rccl_ranks(ssba_problem *p, int *count) {
+    if (!p || !count) return SSBA_ERR_INVALID_ARGUMENT;
+    *count = 0;
+    if (!p->rccl_comm) return SSBA_OK;
+    RcclApi *a = rccl_api();
+    if (!a->CommCount || a->CommCount(p->rccl_comm, count) != ncclSuccess) { set_error("ncclCommCount failed"); return SSBA_ERR_HIP; }
     return SSBA_OK;
 }
 
@@ -1859,8 +1952,8 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
         return SSBA_ERR_UNSUPPORTED;
     }
-    if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
-        drop_graph(p);   // other kernel sequence
+    if (p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
+        drop_graph(p);   // other kernel sequence: every captured graph (single iteration, batch, segments) goes
     HIPCHECK(hipSetDevice(p->device));
     p->opt = *o;
     p->ignore_convergence = ignore_convergence;
@@ -2100,7 +2193,7 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
         set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
         return SSBA_ERR_UNSUPPORTED;
     }
-    if ((p->gexec || p->seg_exec[0] || p->seg_exec[1]) && p->opt.trust_region_strategy_type != opt.trust_region_strategy_type)
+    if (p->opt.trust_region_strategy_type != opt.trust_region_strategy_type)
         drop_graph(p);   // other kernel sequence (as in ssba_solve_begin)
     p->opt = opt;
     p->ignore_convergence = 1;

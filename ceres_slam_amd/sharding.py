@@ -139,7 +139,14 @@ def attach_rccl_exchange(ba, dist=None, group=None):
     torch.distributed backend; None for a single rank), once."""
     world = 1 if dist is None else dist.get_world_size(group)
     rank = 0 if dist is None else dist.get_rank(group)
-    ids = [ba.rccl_unique_id() if rank == 0 else None]
+    ids, err = [None], None
+    if rank == 0:
+        try:
+            ids[0] = ba.rccl_unique_id()
+        except Exception as e:      # noqa: BLE001 -- the other ranks sit in the broadcast below: they must get an answer
+            err = e
     if world > 1:
         dist.broadcast_object_list(ids, src=0, group=group)
+    if ids[0] is None:              # every rank leaves through the same sequence of collectives
+        raise err if err is not None else RuntimeError("rank 0 could not create the RCCL unique id")
     ba.set_rccl(ids[0])

@@ -212,6 +212,19 @@ class StereoBA:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         capi.check(self.lib.ssba_set_rccl(self.h, buf, 128), "ssba_set_rccl")
 
+    @staticmethod
+    def rccl_describe() -> str:
+        """Which librccl.so file this process uses, its version, the IPC / debug environment (ssba_rccl_describe)."""
+        buf = C.create_string_buffer(1024)
+        capi.check(capi.load().ssba_rccl_describe(buf, 1024), "ssba_rccl_describe")
+        return buf.value.decode(errors="replace")
+
+    def rccl_ranks(self) -> int:
+        """ncclCommCount of the handle's communicator; 0 when the exchange is not the native one."""
+        n = C.c_int()
+        capi.check(self.lib.ssba_rccl_ranks(self.h, C.byref(n)), "ssba_rccl_ranks")
+        return n.value
+
     def exchange_size(self) -> int:
         n = C.c_uint64()
         capi.check(self.lib.ssba_exchange_size(self.h, C.byref(n)), "ssba_exchange_size")

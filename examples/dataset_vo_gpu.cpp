@@ -30,6 +30,7 @@
 #include <unistd.h>
 
 #include <cmath>
+#include <sstream>
 #include <cstdint>
 #include <iostream>
 
@@ -128,7 +129,17 @@ int main(int argc, char **argv) {
             close(a[0]); close(b[1]);
             id_w.push_back(a[1]); pts_r.push_back(b[0]); peers.push_back(pid);
         }
-        if (gpus > 1) setenv("HIP_VISIBLE_DEVICES", std::to_string(g_rank).c_str(), 1);
+        if (gpus > 1) {     // rank r takes the r-th entry of a device list the caller set, or device r
+            std::string pick = std::to_string(g_rank);
+            if (const char *vis = getenv("HIP_VISIBLE_DEVICES")) {
+                std::vector<std::string> ids;
+                std::stringstream ss(vis);
+                for (std::string t; std::getline(ss, t, ',');) if (!t.empty()) ids.push_back(t);
+                if ((int)ids.size() < gpus) { std::cerr << "HIP_VISIBLE_DEVICES lists fewer than --gpus devices" << std::endl; return EXIT_FAILURE; }
+                pick = ids[g_rank];
+            }
+            setenv("HIP_VISIBLE_DEVICES", pick.c_str(), 1);
+        }
         if (g_rank == 0) {
             if (ssba_rccl_unique_id(g_rccl_id, sizeof g_rccl_id)) { std::cerr << "ssba_rccl_unique_id: " << ssba_last_error() << std::endl; return EXIT_FAILURE; }
             for (int fd : id_w)

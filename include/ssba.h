@@ -51,7 +51,8 @@ typedef enum {
     SSBA_ERR_NOT_FINALIZED = -4,
     SSBA_ERR_NO_DEVICE = -5,        /* no usable gfx950 device: no CPU fallback exists  */
     SSBA_ERR_UNSUPPORTED = -6,      /* structure outside this build's envelope          */
-    SSBA_ERR_STATE = -7             /* call sequence error                              */
+    SSBA_ERR_STATE = -7,            /* call sequence error                              */
+    SSBA_ERR_TIMEOUT = -8           /* an RCCL set-up call did not return in time       */
 } ssba_status;
 
 /* StereoCamera<double> intrinsics (include/ceres_slam/stereo_camera.hpp:159-163) */
@@ -200,6 +201,13 @@ int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, u
 #define SSBA_RCCL_UNIQUE_ID_BYTES 128
 int ssba_rccl_unique_id(void *out, uint64_t size);
 int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size);
+/* Both set-up calls above are time-limited (RCCL's own calls are not): after SSBA_RCCL_TIMEOUT_S seconds (environment,
+ * default 180) they return SSBA_ERR_TIMEOUT and ssba_last_error() says which RCCL call did not return, which librccl.so
+ * file the process had mapped (PyTorch ships its own copy) and its version, and the IPC / debug environment; the caller
+ * can fall back to ssba_set_exchange.  ssba_rccl_describe writes that description of the loaded library at any time;
+ * ssba_rccl_ranks returns ncclCommCount of the handle's communicator (0 without one). */
+int ssba_rccl_describe(char *buf, uint64_t size);
+int ssba_rccl_ranks(ssba_problem *p, int *count);
 /* number of doubles in the per-iteration reduced-system exchange */
 int ssba_exchange_size(ssba_problem *p, uint64_t *count);
 

@@ -231,6 +231,31 @@ def test_handle_reuse_with_other_options_recaptures_the_graph():
     assert s4.final_cost == pytest.approx(s5.final_cost, rel=1e-6)
 
 
+def test_batched_graph_is_dropped_when_the_strategy_changes():
+    """ssba_solve_step(n >= 10) as the FIRST call of a handle captures only the ten-iteration graph (the single-iteration
+    one stays empty); a following solve with another trust-region strategy on the same handle must not replay it (it used
+    to: the LM kernel sequence ran under DOGLEG options)."""
+    prob = synth.make_problem(14, 400, track_len=6, seed=10)
+    ba = StereoBA.from_synth(prob)
+    logs = {}
+    for name, kw in (("lm", {}), ("dogleg", dict(trust_region_strategy_type=1, dogleg_type=1)), ("lm2", {})):
+        ba.poses[:] = prob.poses_init
+        ba.points[:] = prob.points_init
+        ba.solve_begin(capi.default_options(**dict(DRIVER, **kw)))
+        ba.step(10)
+        ba.step(10)
+        ba.solve_end()
+        logs[name] = ba.iteration_log()
+        op = orc.OracleProblem.from_synth(prob)
+        s2, log2 = op.solve(orc.driver_options(num_threads=2, **kw))
+        n = min(len(logs[name]["cost"]), len(log2["cost"]))
+        assert n >= 5
+        assert logs[name]["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+        np.testing.assert_allclose(logs[name]["cost"][:n], log2["cost"][:n], rtol=1e-8)
+        np.testing.assert_allclose(logs[name]["trust_region_radius"][:n], log2["trust_region_radius"][:n], rtol=1e-6)
+    assert logs["lm"]["cost"].tolist() == logs["lm2"]["cost"].tolist()
+
+
 @pytest.mark.parametrize("dogleg_type", [0, 1])
 @pytest.mark.parametrize("huber_a", [0.0, 1.345])
 @pytest.mark.parametrize("size", [(16, 500, 8), (50, 2000, 12)])

@@ -240,13 +240,16 @@ def test_cpp_driver_with_the_native_rccl_exchange(tmp_path):
     r0 = subprocess.run([exe, ds, ip, im], capture_output=True, text=True, timeout=120)
     assert r0.returncode == 0, r0.stderr
     poses0 = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
-    try:
-        r1 = subprocess.run([exe, ds, ip, im, "--gpus", "1"], capture_output=True, text=True, timeout=150)
-    except subprocess.TimeoutExpired:
-        # on this pool RCCL warns at start-up ('Missing "iommu=pt" ... can lead to system instability or hang') and about one
-        # fresh box in ten hangs inside the first communicator set-up: a property of the box, reported as a skip
-        pytest.skip("RCCL did not finish its communicator set-up within 150 s on this box (RCCL: missing iommu=pt)")
-    assert r1.returncode == 0, r1.stderr
+    from rccl_record import library_timed_out, run
+    rc, out1, err1, record, rec_dir = run([exe, ds, ip, im, "--gpus", "1"], "cpp_driver")
+    if rc != 0 and library_timed_out(err1):
+        # the library's own time limit fired inside the RCCL call it names: an expected failure with its record, not a skip
+        pytest.xfail(f"RCCL set-up hang, diagnosed by the library's own time limit (record kept in {rec_dir}):\n{record}")
+    assert rc == 0, f"record in {rec_dir}:\n{record}"
+
+    class _R:
+        stdout = out1
+    r1 = _R()
     report = lambda r: [l for l in r.stdout.splitlines() if l.startswith("Ceres Solver Report")]       # (RCCL prints a banner)
     assert report(r1) == report(r0) and len(report(r0)) == 1
     assert np.array_equal(synth.read_pose_csv(str(tmp_path / "sim_poses.csv")), poses0)

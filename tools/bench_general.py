@@ -13,6 +13,20 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+TRACE = None
+
+
+def _trace(msg):
+    """--trace FILE: progress marks + the process's memory map (so that the raw addresses of a native stack dump -- e.g. the
+    one rocprofv3's signal handler prints -- can be resolved to library + offset afterwards)."""
+    if not TRACE:
+        return
+    with open(TRACE, "a") as fh:
+        fh.write(f"[{time.time():.3f}] {msg}\n")
+    with open(TRACE + ".maps", "w") as fh:
+        fh.write(open("/proc/self/maps").read())
+
+
 def run_case(name, prob, steps, force_dense):
     from ceres_slam_amd import capi
     from ceres_slam_amd.solver import StereoBA
@@ -24,13 +38,17 @@ def run_case(name, prob, steps, force_dense):
         os.environ.pop("SSBA_FORCE_DENSE", None)
     st = ba.stats()
     opts = capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1)
+    _trace("finalized " + name)
     s, _ = ba.solve(opts)
+    _trace(f"solved {name}: {int(s.num_iterations)} iterations")
     period = max(int(s.num_iterations) - 1, 1)
     ba.poses[:] = prob.poses_init
     ba.points[:] = prob.points_init
     ba.solve_begin(opts, ignore_convergence=True)
+    _trace("solve_begin done")
     ba.step(3)
     ba.synchronize()
+    _trace("three steps done")
     ba.restart()
     def loop():
         ba.synchronize()
@@ -59,8 +77,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--case", default="", help="run only the cases whose name contains this")
+    ap.add_argument("--trace", default="", help="file for progress marks; FILE.maps gets /proc/self/maps at each mark")
     args = ap.parse_args()
-    global run_case
+    global run_case, TRACE
+    TRACE = args.trace
     _run = run_case
 
     def run_case(name, make, steps, force):       # problems are built lazily: a filtered-out case costs nothing
