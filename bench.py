@@ -182,6 +182,9 @@ def launch_ranks(args):
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what this pool's driver supports (RCCL, tensor sharing)
+    # one node by contract: RCCL's bootstrap and socket transport stay on the loopback interface instead of whatever external
+    # interface the container happens to have (the NCCL_DEBUG record of this pool shows it picking the container's veth)
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)

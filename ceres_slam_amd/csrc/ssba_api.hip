@@ -1490,6 +1490,16 @@ int ssba_finalize(ssba_problem *p) {
             int k = 0;
             while (d.lev[k].n > pcr_max) ++k;
             TRY(make_pcr(d.pcr, k, d.lev[k].n, d.nb ? 1 : 0, 0, 0));
+            if (!d.nb) {        // one launch per step (PcrFused): ping-pong buffers of the assembled blocks and the Gram products
+                const size_t n = (size_t)d.pcr.n;
+                for (int q = 0; q < 2; ++q) {
+                    TRY(dzero(p, &d.pcrf.Dpp[q], n * blk)); TRY(dzero(p, &d.pcrf.rpp[q], n * BD));
+                    TRY(dzero(p, &d.pcrf.GLL[q], n * blk)); TRY(dzero(p, &d.pcrf.GUU[q], n * blk));
+                    TRY(dzero(p, &d.pcrf.GUL[q], n * blk)); TRY(dzero(p, &d.pcrf.GULT[q], n * blk));
+                    TRY(dzero(p, &d.pcrf.gL[q], n * BD)); TRY(dzero(p, &d.pcrf.gU[q], n * BD));
+                }
+                d.pcrf.on = 1;
+            }
         }
     }
     if (part) {

@@ -782,6 +782,11 @@ static bool bcr_fused_solve(const Dev &d) {
     const char *nf = getenv("SSBA_NO_FUSED_SOLVE");
     return !d.part && d.pcr.level >= 0 && !bcr_border_rides(d) && d.nb == 0 && !bcr_legacy() && !(nf && nf[0] == '1');
 }
+// the fused plan (PcrFused buffers allocated: single GPU, no border columns); SSBA_NO_PCR_FUSED=1 keeps factor + reduce launches (A/B, tests)
+static bool bcr_fused_steps(const Dev &d) {
+    const char *e = getenv("SSBA_NO_PCR_FUSED");        // read per call: tests switch it between handles
+    return d.pcrf.on && !d.part && !d.pcr.keep && d.nb == 0 && !bcr_legacy() && !(e && e[0] == '1');
+}
 bool bcr_updates_poses(const Dev &d) { return bcr_fused_solve(d) && d.pcr.level == 0 && d.n_pf == 0; }
 
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
@@ -799,13 +804,21 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
             launch_factor(L, d, nn / 2, l, 0, 0, true);
             launch_reduce(L, d, (nn + 1) / 2, 2, l, 0);
         }
+        const bool fsolve = bcr_fused_solve(d);
+        const int solve = fsolve ? (fuse_update && bcr_updates_poses(d) ? 2 : 1) : 0;
+        if (bcr_fused_steps(d)) {
+            // one launch per step: the factorisation of a block also forms the Gram products the next step assembles its
+            // operands from (ssba_bcr_mfma.hip, PcrFused) -- steps + 1 launches instead of 2 x steps + 1
+            for (int q = 0; q < d.pcr.steps; ++q) launch_pcr_fused_step(L, d, n, q);
+            launch_pcr_fused_top(L, d, n, d.pcr.steps, solve);
+        } else {
         for (int q = 0; q < d.pcr.steps; ++q) {
             launch_factor(L, d, n, q, 0, 2, true, ride);
             launch_reduce(L, d, n, 2, q, 2, ride);
         }
         // the decoupled last step solves its blocks itself (matrix-core kernels, no border columns): no k_bcr_backsub launch
-        const bool fsolve = bcr_fused_solve(d);
-        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride, fsolve ? (fuse_update && bcr_updates_poses(d) ? 2 : 1) : 0);
+        launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride, solve);
+        }
         if (!fsolve) LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
         for (int l = k - 1; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);

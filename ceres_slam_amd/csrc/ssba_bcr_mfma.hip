@@ -86,6 +86,11 @@ struct FactorOps {
     double *oD, *oYL, *oYU, *orr, *saveU, *oYB, *xsol;
     int f0;                                 // first free pose of the block (solve + pose update)
     bool hasL, hasU, trL, trU;
+    // fused steps (PcrFused): D = Dg - GA - GB, r = rin - ga - gb (null: nothing to subtract), couplings = sgn x [Lg | Ug];
+    // nD / nr: where the assembled D (upper tiles) / r go for the next step; the Gram products of this block
+    const double *GA, *GB, *ga, *gb;
+    double sgn;
+    double *nD, *nr, *oGLL, *oGUU, *oGUL, *oGULT, *ogL, *ogU;
 };
 
 // operands and destinations of one block: mirrors k_bcr_factor (ssba_bcr.hip).  false: this block has nothing to do.
@@ -95,6 +100,7 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
     o.trL = o.trU = false;
     o.saveU = nullptr;
     o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
+    o.GA = o.GB = o.ga = o.gb = nullptr; o.sgn = 1.0; o.nD = o.nr = nullptr;
     if (which >= 2) {
         const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
         const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
@@ -146,6 +152,49 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
     return true;
 }
 
+// Operands of block bx in step `lev` (stride 1 << lev) of the fused plan, or of its decoupled last step (top).  Step 0 reads
+// the level's own D / L / r; step q >= 1 assembles them from what step q - 1 left (see PcrFused).
+static __device__ __forceinline__ void fused_ops(const Dev &d, int lev, int top, int bx, FactorOps &o) {
+    const PcrPlan &P = d.pcr;
+    const PcrFused &F = d.pcrf;
+    const BcrLevel &B = d.lev[P.level];
+    const size_t blk = (size_t)BD * BD;
+    const int s = 1 << lev, h = s >> 1, last = B.n - 1, e = bx;
+    o.saveU = nullptr; o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
+    o.oYL = o.oYU = nullptr;
+    o.GA = o.GB = o.ga = o.gb = nullptr;
+    o.nD = o.nr = nullptr;
+    o.hasL = !top && e - s >= 0;
+    o.hasU = !top && e + s <= last;
+    if (lev == 0) {
+        o.Dg = B.D + e * blk; o.rin = B.r + (size_t)e * BD;
+        o.Lg = B.L + e * blk; o.Ug = B.L + (size_t)(o.hasU ? e + 1 : e) * blk;
+        o.trL = o.trU = (e & 1) == 0;       // even coupling blocks of a level are stored transposed (ssba_bcr.hip)
+        o.sgn = 1.0;
+    } else {
+        const int set = (lev - 1) & 1, prev = e - h, next = e + h;
+        o.Dg = lev == 1 ? B.D + e * blk : F.Dpp[(lev - 1) & 1] + e * blk;
+        o.rin = lev == 1 ? B.r + (size_t)e * BD : F.rpp[(lev - 1) & 1] + (size_t)e * BD;
+        if (prev >= 0) { o.GA = F.GUU[set] + prev * blk; o.ga = F.gU[set] + (size_t)prev * BD; }
+        if (next <= last) { o.GB = F.GLL[set] + next * blk; o.gb = F.gL[set] + (size_t)next * BD; }
+        o.Lg = F.GUL[set] + (size_t)(o.hasL ? prev : e) * blk;
+        o.Ug = F.GULT[set] + (size_t)(o.hasU ? next : e) * blk;
+        o.trL = o.trU = false;
+        o.sgn = -1.0;
+        if (!top) { o.nD = F.Dpp[lev & 1] + e * blk; o.nr = F.rpp[lev & 1] + (size_t)e * BD; }
+    }
+    o.oD = top ? B.D + e * blk : nullptr;
+    o.orr = top ? B.r + (size_t)e * BD : nullptr;
+    if (top) {
+        o.xsol = d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[e] * BD;
+        o.f0 = (d.chain0 + B.pos[e]) * SBP;
+    }
+    const int oset = lev & 1;
+    o.oGLL = F.GLL[oset] + e * blk; o.oGUU = F.GUU[oset] + e * blk;
+    o.oGUL = F.GUL[oset] + e * blk; o.oGULT = F.GULT[oset] + e * blk;
+    o.ogL = F.gL[oset] + (size_t)e * BD; o.ogU = F.gU[oset] + (size_t)e * BD;
+}
+
 struct FactorLds {
     // every block row has its own slots: nothing is overwritten during a factorisation, so the hand-offs below need
     // no write-after-read protection
@@ -188,34 +237,53 @@ struct FactorLds {
 // 0 .. 11 with them, 9 .. 11 for decoupled blocks with border columns)
 // solve (decoupled blocks without border columns, NRW = 0): the workgroup also solves  G^T x = yr  -- the block's part of
 // the solution -- from an LDS copy of G, which is what k_bcr_backsub did in a launch of its own.
-template <int NRW>
-__global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt, int solve) {
+// MODE 0: operands and destinations of the classic plans (factor_ops).
+// MODE 1: the decoupled last step of the fused plan: D and r are assembled from the previous step's Gram products on load.
+// MODE 2: a step of the fused plan (PcrFused): 8 waves -- waves 0..3 run the D stream as always, waves 4..7 carry ALL nine
+//         column tiles of [L | U^T] (every workgroup of a block repeats the whole factorisation: the products that follow
+//         need every column, and a cross-workgroup exchange would cost more than the repetition) -- then [YL | yr] and
+//         [YU | yr] are staged in LDS and the workgroups of the block share the 55 Gram tiles (gram_phase).
+struct GramJob;
+static __device__ __forceinline__ void gram_phase(const FactorOps &o, double *sAL, double *sAU, double *scr, int W, int NW, int lane);
+constexpr int MF_THREADS2 = 512;
+// ROLE 0: every wave runs both streams (MODE 0, 1).  MODE 2 instantiates the body twice -- ROLE 1: the D stream only (waves
+// 0..3), ROLE 2: right-hand-side tiles only (waves 4..7) -- so that neither role carries the other's register arrays
+// (one body with run-time roles needed 538 spilled registers at the 256 a wave of a 512-lane workgroup may use).
+template <int NRW, int MODE, int ROLE>
+static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, double *mf_solve_lds, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt, int solve) {
+    constexpr bool HAS_D = ROLE != 2, HAS_R = ROLE != 1;
     State &st = *d.st;
     const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested once the operand reads are in flight
-    __shared__ FactorLds S;
     FactorOps o;
     int bx, by;
     xcd_map((int)blockIdx.x, nblocks, ns, bx, by);
-    if (!factor_ops(d, lev, top, which, bx, by == 0 && !dead, nrt > NRT, o)) return;
+    if (MODE) fused_ops(d, lev, top, bx, o);
+    else if (!factor_ops(d, lev, top, which, bx, by == 0 && !dead, nrt > NRT, o)) return;
     const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr bool rwave = HAS_R;       // this wave carries right-hand-side tiles
     const bool storeG = by == 0;
     // this workgroup's share of the nine right-hand-side column tiles, dealt to waves 1, 2, 3, 0, 1, ... (wave 0 owns the
     // longest column of [D | r] and two diagonal tiles: it comes last)
-    const int rfirst = rlo + (by * (nrt - rlo)) / ns, rcnt = rlo + ((by + 1) * (nrt - rlo)) / ns - rfirst;
+    const int rfirst = MODE == 2 ? 0 : rlo + (by * (nrt - rlo)) / ns;
+    const int rcnt = MODE == 2 ? NRT : rlo + ((by + 1) * (nrt - rlo)) / ns - rfirst;
     constexpr int NRA = NRW > 0 ? NRW : 1;        // array extents (NRW = 0: the decoupled last step has no right-hand-side tiles)
     int rcol[NRA];
     bool ract[NRA];
 #pragma unroll
     for (int q = 0; q < NRW; ++q) {
-        const int idx = ((w + 3) & 3) + 4 * q;
+        const int idx = (MODE == 2 ? (w & 3) : ((w + 3) & 3)) + 4 * q;
         rcol[q] = rfirst + idx;
-        ract[q] = idx < rcnt && ((rcol[q] <= 4 && o.hasL) || (rcol[q] >= 4 && rcol[q] < NRT && o.hasU) || (rcol[q] >= NRT && o.Bg));
+        ract[q] = rwave && idx < rcnt && ((rcol[q] <= 4 && o.hasL) || (rcol[q] >= 4 && rcol[q] < NRT && o.hasU) || (rcol[q] >= NRT && o.Bg));
     }
-    const int dj = w == 0 ? 4 : w;          // column tile of [D | r] this wave owns (wave 0 also owns tile (0, 0))
+    const int dj = !HAS_D ? -1 : w == 0 ? 4 : w;          // column tile of [D | r] this wave owns (wave 0 also owns tile (0, 0)); -1: none
     if (t == 0) { S.bad = 0; S.seqPQ = 0; }
     if (t < 4) S.seqA[t] = 0;
     if (t < 8) S.rc[72 + t] = 1.0;
+    // mf_solve_lds: solve: G (BD x BD) | yr (BD) | x;  MODE 2: [YL | yr] and [YU | yr], 72 x 80 each
+    if (MODE == 2) {        // columns 72..79 of both staged operands: yr goes into column 72 later, the rest stays zero
+        for (int i = t; i < 2 * BD * 8; i += MF_THREADS2) mf_solve_lds[(i >> 3) * 80 + BD + (i & 7)] = 0.0;
+    }
     // the only workgroup barrier before the end of the factorisation: the hand-off words are initialised.  It sits BEFORE
     // the loads so that wave 0 can start on the first diagonal tile as soon as ITS data is there, without waiting for the
     // other waves' right-hand-side tiles.
@@ -226,26 +294,66 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     //      tile, compile-time row offsets, every load issued before the first is waited for ----------------------
     mf_d4 dt[NDT], d00, rt[NRA][NDT];
     {
-        const int colD = 16 * dj + j;
-        const double *pD = o.Dg + g * BD + min(colD, BD - 1), *pr = o.rin + g;
-        double rv[NDT][4];
+        const int colD = 16 * max(dj, 0) + j;
+        const int offD = g * BD + min(colD, BD - 1);
+        double rv[MODE ? 1 : NDT][4];
+        if (HAS_D && !MODE) {
+            const double *pD = o.Dg + offD, *pr = o.rin + g;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;      // first: the first diagonal tile waits for nothing else
+            for (int q = 0; q < 4; ++q) d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;      // first: the first diagonal tile waits for nothing else
 #pragma unroll
-        for (int k = 0; k < NDT; ++k)
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool in = k < 4 || q < 2;           // rows 72..79 are padding
+                    dt[k][q] = (in && k <= dj) ? pD[(16 * k + 4 * q) * BD] : 0.0;
+                    rv[k][q] = (in && w == 0) ? pr[16 * k + 4 * q] : 0.0;
+                }
+        }
+        if (HAS_D && MODE) {
+            // fused plan: [D | r] = [Dg - GA - GB | rin - ga - gb], the three reads of an entry issued together.  A lane of
+            // column 72 (wave 0's tile column 4) reads the right-hand-side vectors instead of the blocks -- same loop, its own
+            // base pointers and row stride -- and the lanes beyond it read nothing: no separate arrays for r.
+            const bool isD = colD < BD, isR = colD == BD;
+            const long rstride = isD ? BD : 1, off0 = isD ? offD : g;
+            const double *b0 = isD ? o.Dg : o.rin, *b1 = isD ? o.GA : o.ga, *b2 = isD ? o.GB : o.gb;
+            const bool act = isD || isR;
+            mf_d4 x1[NDT], x2[NDT], y1, y2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool in = k < 4 || q < 2;           // rows 72..79 are padding
-                dt[k][q] = (in && k <= dj) ? pD[(16 * k + 4 * q) * BD] : 0.0;
-                rv[k][q] = (in && w == 0) ? pr[16 * k + 4 * q] : 0.0;
+                d00[q] = (w == 0) ? o.Dg[(4 * q + g) * BD + j] : 0.0;
+                y1[q] = (w == 0 && o.GA) ? o.GA[(4 * q + g) * BD + j] : 0.0;
+                y2[q] = (w == 0 && o.GB) ? o.GB[(4 * q + g) * BD + j] : 0.0;
             }
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool in = (k < 4 || q < 2) && k <= dj && act;
+                    const long off = off0 + (16 * k + 4 * q) * rstride;
+                    dt[k][q] = in ? b0[off] : 0.0;
+                    x1[k][q] = (in && b1) ? b1[off] : 0.0;
+                    x2[k][q] = (in && b2) ? b2[off] : 0.0;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d00[q] = d00[q] - y1[q] - y2[q];
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dt[k][q] = dt[k][q] - x1[k][q] - x2[k][q];
+        }
+        if (!HAS_D) {
+            d00 = mf_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < NDT; ++k) dt[k] = mf_d4{0.0, 0.0, 0.0, 0.0};
+        }
         bool rok[NRA];
 #pragma unroll
         for (int q = 0; q < NRW; ++q) {
             const int col = 16 * rcol[q] + j;
             const bool isL = col < BD, isB = rcol[q] >= NRT;
             const int cc = isL ? col : col - BD;
-            const bool tr = o.trL;                       // trL == trU (ssba_bcr.hip: even blocks of level 0)
+            const bool tr = isL ? o.trL : o.trU;
             const double *base = isL ? o.Lg : o.Ug;
             rok[q] = ract[q] && (isB || (isL ? o.hasL : o.hasU));
             if (!ract[q]) {
@@ -273,11 +381,33 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
         }
         if (dead) return;
         // masks: column 72 of [D | r] is the right-hand side, the columns after it are zero; absent couplings are zero
-        if (dj == 4) {
+        if (!MODE && dj == 4) {
 #pragma unroll
             for (int k = 0; k < NDT; ++k)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dt[k][q] = colD < BD ? dt[k][q] : colD == BD ? rv[k][q] : 0.0;
+        }
+        if (HAS_D && MODE && o.nD && by == 0) {      // the assembled block (upper tiles) and right-hand side, for the next step
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!((k < 4 || q < 2) && k <= dj)) continue;
+                    if (colD < BD) o.nD[offD + (16 * k + 4 * q) * BD] = dt[k][q];
+                    else if (colD == BD) o.nr[g + 16 * k + 4 * q] = dt[k][q];
+                }
+            if (w == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o.nD[(4 * q + g) * BD + j] = d00[q];
+            }
+        }
+        if (HAS_R && MODE && o.sgn < 0.0) {
+#pragma unroll
+            for (int q = 0; q < NRW; ++q)
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = -rt[q][k][qq];
         }
 #pragma unroll
         for (int q = 0; q < NRW; ++q) {
@@ -476,19 +606,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     };
 
     MF_STAMP(1);
-    if (w == 0) factor_tile(d00, 0, 4);
+    if (HAS_D && w == 0) factor_tile(d00, 0, 4);
 #pragma unroll
     for (int k = 0; k < NDT; ++k) {
         MF_STAMP(2 + 4 * k);
-        if (dj > k) d_panel(k);
+        if (HAS_D && dj > k) d_panel(k);
         MF_STAMP(3 + 4 * k);
-        if (k + 1 < NDT && dj == k + 1) factor_tile(dt[k + 1], k + 1, k + 1 < 4 ? 4 : 2);   // the next diagonal tile is this wave's
+        if (HAS_D && k + 1 < NDT && dj == k + 1) factor_tile(dt[k + 1], k + 1, k + 1 < 4 ? 4 : 2);   // the next diagonal tile is this wave's
         MF_STAMP(4 + 4 * k);
-        if (dj > k + 1) d_update(k);
-        if (k >= 1) r_step(k - 1);
+        if (HAS_D && dj > k + 1) d_update(k);
+        if (k >= 1 && rwave) r_step(k - 1);
         MF_STAMP(5 + 4 * k);
     }
-    r_step(NDT - 1);
+    if (rwave) r_step(NDT - 1);
     MF_STAMP(30);
     __syncthreads();
     if (t < BD) {
@@ -501,6 +631,36 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     __syncthreads();
     if (S.bad) {
         if (t == 0) st.step_failed = 1;
+        return;
+    }
+    if (MODE == 2) {
+        // ---- [YL | yr] and [YU | yr] into LDS (rows scaled by 1/sqrt(d)), then this workgroup's share of the Gram tiles ----
+        double *sAL = mf_solve_lds, *sAU = mf_solve_lds + BD * 80;
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) {
+            if (!ract[q]) continue;
+            const int col = 16 * rcol[q] + j;
+            double *pp = col < BD ? sAL + g * 80 + col : sAU + g * 80 + (col - BD);
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (k < 4 || qq < 2) pp[(16 * k + 4 * qq) * 80] = rt[q][k][qq] * S.rs[16 * k + 4 * qq + g];
+        }
+        if (HAS_D && w == 0 && j == 8) {         // yr = column 72 of [D | r] (this wave's column tile 4)
+#pragma unroll
+            for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (k < 4 || qq < 2) {
+                        const int row = 16 * k + 4 * qq + g;
+                        const double v = dt[k][qq] * S.rs[row];
+                        sAL[row * 80 + BD] = v;
+                        sAU[row * 80 + BD] = v;
+                    }
+        }
+        __syncthreads();        // (the hand-off slots of the factorisation are dead from here on: S.A is the transposition scratch)
+        gram_phase(o, sAL, sAU, &S.A[0][0][0][0] + w * (16 * 17), MODE == 2 ? 8 * by + w : 0, 8 * ns, lane);
         return;
     }
 
@@ -532,7 +692,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
             for (int qq = 0; qq < 4; ++qq)
                 if (k < 4 || qq < 2) pp[(16 * k + 4 * qq) * BD] = rt[q][k][qq] * rsv[k][qq];
     }
-    extern __shared__ __align__(16) double mf_solve_lds[];        // solve: G (BD x BD) | yr (BD)
     const bool do_solve = NRW == 0 && solve && o.xsol;
     if (storeG) {
         // G = U^T: column c of U is row c of G; lane (g, j) of tile (k, c) holds U[16 k + 4 q + g][16 c + j]
@@ -632,6 +791,18 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, in
     MF_STAMP(31);
 }
 
+template <int NRW, int MODE>
+__global__ __launch_bounds__(MODE == 2 ? MF_THREADS2 : MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt, int solve) {
+    __shared__ FactorLds S;
+    extern __shared__ __align__(16) double mf_dyn_lds[];
+    if (MODE == 2) {
+        if (threadIdx.x < MF_THREADS) factor_body<0, 2, 1>(d, S, mf_dyn_lds, lev, top, which, nblocks, ns, rlo, nrt, solve);
+        else factor_body<NRW, 2, 2>(d, S, mf_dyn_lds, lev, top, which, nblocks, ns, rlo, nrt, solve);
+    } else {
+        factor_body<NRW, MODE, 0>(d, S, mf_dyn_lds, lev, top, which, nblocks, ns, rlo, nrt, solve);
+    }
+}
+
 // ---- reduce ---------------------------------------------------------------------------------------------------
 constexpr int RS = 80;                      // LDS row stride of a staged operand (columns 72..79: yr | zeros)
 constexpr int RED_OPERAND_DOUBLES = 3 * BD * RS;
@@ -683,6 +854,85 @@ static __device__ __forceinline__ mf_d4 tn_mma(const TnOps &O, mf_d4 acc) {
 // keeps the operand reads issued above it ahead of the matrix instructions below it (memory clobber for the compiler's
 // middle end, a scheduling barrier for the machine scheduler, which would otherwise sink the reads again)
 #define MF_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+// Gram products of one block's own factor outputs (fused plan, see PcrFused): units 0..14 the upper tiles of
+// GLL = [YL | yr]^T [YL | yr] (column 72 = YL^T yr), 15..29 the same for YU, 30..54 the tiles of GUL = YU^T YL, which is
+// stored in both orientations.  Wave W of the NW waves that share the block takes the units W, W + NW, ...; operand reads
+// run one unit ahead of the matrix instructions.
+static __device__ __forceinline__ void gram_phase(const FactorOps &o, double *sAL, double *sAU, double *scr, int W, int NW, int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    constexpr int NUMAX = 7;        // 55 units over at least 8 waves
+    int ti[NUMAX], tj[NUMAX], kind[NUMAX];
+    bool have[NUMAX];
+#pragma unroll
+    for (int i = 0; i < NUMAX; ++i) {
+        const int u = W + i * NW;
+        kind[i] = u < 15 ? 0 : u < 30 ? 1 : 2;
+        have[i] = u < 55 && (kind[i] == 0 ? o.hasL : kind[i] == 1 ? o.hasU : (o.hasL && o.hasU));
+        if (kind[i] == 2) {
+            const int c = min(u - 30, 24);
+            ti[i] = c / 5;
+            tj[i] = c - 5 * ti[i];
+        } else {
+            const int n = u - 15 * kind[i];       // n -> (ti, tj): rows of the upper triangle start at 0, 5, 9, 12, 14
+            const int a = n >= 14 ? 4 : n >= 12 ? 3 : n >= 9 ? 2 : n >= 5 ? 1 : 0;
+            const int st0 = a == 4 ? 14 : a == 3 ? 12 : a == 2 ? 9 : a == 1 ? 5 : 0;
+            ti[i] = a;
+            tj[i] = min(a + (n - st0), NDT - 1);
+        }
+    }
+    auto load = [&](TnOps &O, int i) {
+        const double *sa = kind[i] == 0 ? sAL : sAU, *sb = kind[i] == 1 ? sAU : sAL;
+        tn_load(O, sa, sb, ti[i], tj[i], g, j);
+    };
+    auto store = [&](const mf_d4 &v, int i) {
+        const int r0 = 16 * ti[i] + g, c0 = 16 * tj[i] + j;
+        if (kind[i] < 2) {
+            double *dst = kind[i] == 0 ? o.oGLL : o.oGUU, *gv = kind[i] == 0 ? o.ogL : o.ogU;
+            if (c0 < BD) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + 4 * q < BD) dst[(r0 + 4 * q) * BD + c0] = v[q];
+            } else if (c0 == BD) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (r0 + 4 * q < BD) gv[r0 + 4 * q] = v[q];
+            }
+            return;
+        }
+        if (c0 < BD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + 4 * q < BD) o.oGUL[(r0 + 4 * q) * BD + c0] = v[q];
+        }
+        // the transposed copy leaves through a per-wave LDS tile, as full row segments
+#pragma unroll
+        for (int q = 0; q < 4; ++q) scr[j * 17 + 4 * q + g] = v[q];
+        MF_FENCE();
+        mf_d4 r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = scr[(4 * q + g) * 17 + j];
+        MF_FENCE();
+        const int r1 = 16 * tj[i] + g, c1 = 16 * ti[i] + j;
+        if (c1 < BD) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r1 + 4 * q < BD) o.oGULT[(r1 + 4 * q) * BD + c1] = r[q];
+        }
+    };
+    TnOps Oa, Ob;
+    if (have[0]) load(Oa, 0);
+#pragma unroll
+    for (int i = 0; i < NUMAX; ++i) {
+        MF_FENCE();
+        if (i + 1 < NUMAX && have[i + 1]) load((i & 1) ? Oa : Ob, i + 1);
+        MF_FENCE();
+        if (have[i]) {
+            const mf_d4 acc = tn_mma((i & 1) ? Ob : Oa, mf_d4{0.0, 0.0, 0.0, 0.0});
+            store(acc, i);
+        }
+    }
+}
 
 // One block's reduction as a job of three staged operands -- A0 = YU(prev) | yr(prev), A1 = YL(next) | yr(next),
 // A2 = YL(prev) -- and 55 units of 18 instructions: the 15 upper tiles of  D' = D - A0^T A0 - A1^T A1  (two units
@@ -1050,10 +1300,23 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
     const int per_wg = (nrt - rlo + ns - 1) / ns;
     const int grid = xcd_grid(nblocks, ns);
     const size_t sh_solve = (size_t)(BD * BD + 2 * BD) * sizeof(double);
-    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<0>, dim3(grid), dim3(MF_THREADS), solve ? sh_solve : 0, d, lev, top, which, nblocks, ns, rlo, nrt, solve);
-    else if (per_wg <= 3) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<1>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
-    else if (per_wg <= 7) LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<2>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
-    else LAUNCH(KC_BCR_FACTOR, k_bcr_factor_mf<3>, dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
+    if (!coupled && !ride) LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<0, 0>), dim3(grid), dim3(MF_THREADS), solve ? sh_solve : 0, d, lev, top, which, nblocks, ns, rlo, nrt, solve);
+    else if (per_wg <= 3) LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<1, 0>), dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
+    else if (per_wg <= 7) LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<2, 0>), dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
+    else LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 0>), dim3(grid), dim3(MF_THREADS), 0, d, lev, top, which, nblocks, ns, rlo, nrt, 0);
+}
+
+// Fused plan (PcrFused): step q = factorisation of every block at stride 2^q + the Gram products the next step assembles its
+// operands from, ONE launch; the workgroups of a block (3 up to 85 blocks, 2 up to 128) repeat the factorisation and share
+// the Gram tiles.  The decoupled last step assembles its blocks the same way, solves them and (solve = 2) updates the poses.
+constexpr size_t FUSED_LDS = (size_t)2 * BD * 80 * sizeof(double);
+void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q) {
+    const int ns = n <= 85 ? 3 : n <= 128 ? 2 : 1;
+    LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 2>), dim3(xcd_grid(n, ns)), dim3(MF_THREADS2), FUSED_LDS, d, q, 0, 2, n, ns, 0, NRT, 0);
+}
+void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve) {
+    const size_t sh_solve = (size_t)(BD * BD + 2 * BD) * sizeof(double);
+    LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<0, 1>), dim3(xcd_grid(n, 1)), dim3(MF_THREADS), solve ? sh_solve : 0, d, steps, 1, 2, n, 1, 0, NRT, solve);
 }
 
 // ny_legacy: 2, or 3 with the coupling to a pinned last block (the grid.y of k_bcr_reduce)
@@ -1076,7 +1339,9 @@ void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny_legacy,
 
 int configure_bcr_mf() {
     if (hipFuncSetAttribute((const void *)k_bcr_reduce_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RED_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
-    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BD * BD + 2 * BD) * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BD * BD + 2 * BD) * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((BD * BD + 2 * BD) * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_bcr_factor_mf<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS) != hipSuccess) return -1;
     return 0;
 }
 

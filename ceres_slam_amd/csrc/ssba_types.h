@@ -112,6 +112,20 @@ struct PcrPlan {
 };
 constexpr int PCR_MAX_BLOCKS = 128;
 
+// One launch per step of the parallel cyclic reduction (ssba_bcr_mfma.hip, k_bcr_factor_mf<.., FUSED>): the products the
+// next step needs are Gram products of ONE block's own factor outputs,
+//     GUU(b) = YU(b)^T YU(b) -> D'(b + s),   GLL(b) = YL(b)^T YL(b) -> D'(b - s),   GUL(b) = YU(b)^T YL(b) -> the couplings
+//     S'[b + s, b - s] = -GUL(b) and S'[b - s, b + s] = -GUL(b)^T,
+// so the block that has just factored itself forms them from LDS (no reduce launch, no staging of three neighbours'
+// operands from HBM) and the NEXT step's load phase assembles  D(e) - GUU(e - s) - GLL(e + s)  on the way into the
+// registers.  Everything ping-pongs by step parity (a step reads what the previous one wrote).
+struct PcrFused {
+    int on;
+    double *Dpp[2], *rpp[2];                    // assembled D (upper tiles) and r of a step: n x BD x BD, n x BD
+    double *GLL[2], *GUU[2], *GUL[2], *GULT[2]; // n x BD x BD each (GLL / GUU: upper tiles)
+    double *gL[2], *gU[2];                      // YL^T yr, YU^T yr: n x BD
+};
+
 struct Dev {
     // camera, stiffness, loss
     double fu, fv, cu, cv, b;
@@ -152,6 +166,7 @@ struct Dev {
     int n_levels;
     BcrLevel lev[MAX_LEVELS];
     PcrPlan pcr;
+    PcrFused pcrf;                   // the fused-step buffers of `pcr` (single GPU, no border columns)
     // partitioned solve (one rank per contiguous chain of super-blocks): this rank's chain is
     // super-blocks [chain0, chain1]; the end it shares with a neighbouring rank is pinned (pin0: rank > 0, pin1:
     // rank < world - 1), the world - 1 shared blocks of all ranks form the separator system

@@ -50,6 +50,7 @@ def run(cmd, tag, inner_timeout_s=100, outer_timeout_s=240, env_extra=None):
     env.update({"NCCL_DEBUG": "INFO", "NCCL_DEBUG_FILE": os.path.join(rec_dir, "nccl_%h_%p.log"), "PYTHONFAULTHANDLER": "1",
                 "SSBA_RCCL_TIMEOUT_S": str(inner_timeout_s)})
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_SOCKET_IFNAME", "lo")      # single node: bootstrap over loopback, not the container's external interface
     env.update(env_extra or {})
     t0 = time.time()
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)

@@ -119,6 +119,23 @@ def test_parallel_and_plain_cyclic_reduction_agree(monkeypatch):
     assert np.abs(ba.poses - ba2.poses).max() < 1e-9
 
 
+@pytest.mark.parametrize("num_poses", [14, 26, 300, 1600])
+def test_fused_and_two_launch_steps_of_the_parallel_plan_agree(monkeypatch, num_poses):
+    """One launch per step of the parallel cyclic reduction (the factorisation of a block also forms the Gram products the
+    next step assembles its operands from: ssba_bcr_mfma.hip, PcrFused) against factor + reduce launches per step
+    (SSBA_NO_PCR_FUSED=1): 2, 3, 25 super-blocks, and 67 below a plain level; both against the oracle."""
+    prob = synth.make_problem(num_poses, 30 * num_poses, track_len=12, seed=3)
+    ba, s, log, op, s0, log0 = _solve_both(prob)
+    _assert_same_solve(ba, s, log, op, s0, log0)
+    monkeypatch.setenv("SSBA_NO_PCR_FUSED", "1")
+    ba2 = StereoBA.from_synth(prob)
+    s2, log2 = ba2.solve(capi.default_options(**DRIVER))
+    assert s.num_iterations == s2.num_iterations
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-10)
+    assert np.abs(ba.poses - ba2.poses).max() < 1e-9
+
+
 def test_full_3x3_stiffness_matrix():
     # the sun driver builds full covariances (tests/dataset_vo_sun.cpp:57-59); the stereo functor
     # takes any 3x3 stiffness (stereo_reprojection_error.hpp:49-50)

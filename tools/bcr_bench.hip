@@ -86,6 +86,16 @@ int main(int argc, char **argv) {
         CHK(hipMemcpy(d.pcr.LbufT, hLbT.data(), n * blk * 8, hipMemcpyHostToDevice));
     };
     upload();
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    d.x0 = dalloc<double>((size_t)n * BD);
+    d.nfree = n * SBP;
+    {
+        std::vector<int> pos(n);
+        for (int i = 0; i < n; ++i) pos[i] = i;
+        int *dpos = dalloc<int>(n);
+        CHK(hipMemcpy(dpos, pos.data(), n * sizeof(int), hipMemcpyHostToDevice));
+        d.lev[0].pos = dpos;
+    }
     if (configure_bcr_mf()) { printf("configure failed\n"); return 1; }
     Launcher L;
     CHK(hipStreamCreate(&L.stream));
@@ -193,6 +203,86 @@ int main(int argc, char **argv) {
             er = fmax(er, maxrel(&orr[b * BD], yv.data(), BD));
         }
         printf("factor top: max abs err G %.2e, rel err yr %.2e\n", eG, er);
+        upload();
+    }
+    // ---- whole chains: factor + reduce per step (classic) against one launch per step (fused plan, PcrFused) ----
+    {
+        const double cpl = 0.04;        // weak couplings: the block-tridiagonal matrix stays positive definite
+        std::vector<double> cL(n * blk);
+        for (auto &v : cL) v = cpl * nd(rng);
+        for (int q = 0; q < 2; ++q) {
+            d.pcrf.Dpp[q] = dalloc<double>(n * blk); d.pcrf.rpp[q] = dalloc<double>(n * BD);
+            d.pcrf.GLL[q] = dalloc<double>(n * blk); d.pcrf.GUU[q] = dalloc<double>(n * blk);
+            d.pcrf.GUL[q] = dalloc<double>(n * blk); d.pcrf.GULT[q] = dalloc<double>(n * blk);
+            d.pcrf.gL[q] = dalloc<double>(n * BD); d.pcrf.gU[q] = dalloc<double>(n * BD);
+        }
+        d.pcrf.on = 1;
+        auto upload2 = [&] {
+            CHK(hipMemcpy(d.lev[0].D, hD.data(), n * blk * 8, hipMemcpyHostToDevice));
+            CHK(hipMemcpy(d.lev[0].L, cL.data(), n * blk * 8, hipMemcpyHostToDevice));
+            CHK(hipMemcpy(d.lev[0].r, hr.data(), n * BD * 8, hipMemcpyHostToDevice));
+            CHK(hipMemset(d.st, 0, sizeof(State)));
+        };
+        auto chain = [&](bool fused) {
+            for (int q = 0; q < d.pcr.steps; ++q) {
+                if (fused) launch_pcr_fused_step(L, d, n, q);
+                else { launch_bcr_factor_mf(L, d, n, q, 0, 2, true); launch_bcr_reduce_mf(L, d, n, 2, q, 2); }
+            }
+            if (fused) launch_pcr_fused_top(L, d, n, d.pcr.steps, 1);
+            else launch_bcr_factor_mf(L, d, n, d.pcr.steps, 1, 2, false, false, 1);
+        };
+        std::vector<double> xc((size_t)n * BD), xf((size_t)n * BD);
+        State hst;
+        upload2(); chain(false); CHK(hipStreamSynchronize(L.stream));
+        CHK(hipMemcpy(xc.data(), d.x0, xc.size() * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(&hst, d.st, sizeof hst, hipMemcpyDeviceToHost));
+        printf("classic chain: step_failed %d\n", hst.step_failed);
+        upload2(); chain(true); CHK(hipStreamSynchronize(L.stream));
+        CHK(hipMemcpy(xf.data(), d.x0, xf.size() * 8, hipMemcpyDeviceToHost));
+        CHK(hipMemcpy(&hst, d.st, sizeof hst, hipMemcpyDeviceToHost));
+        printf("fused chain:   step_failed %d\n", hst.step_failed);
+        printf("solution, fused against classic: max rel diff %.2e\n", maxrel(xf.data(), xc.data(), xf.size()));
+        if (n <= 16) {      // dense host solve of the block-tridiagonal system
+            const int N = n * BD;
+            std::vector<double> A((size_t)N * N, 0.0), x(hr.begin(), hr.begin() + N);
+            for (int b = 0; b < n; ++b)
+                for (int i = 0; i < BD; ++i)
+                    for (int j = 0; j < BD; ++j) {
+                        A[(size_t)(b * BD + i) * N + b * BD + j] = hD[b * blk + i * BD + j];
+                        if (b > 0) {        // S[b, b-1]: stored transposed for even b
+                            const double v = (b & 1) == 0 ? cL[b * blk + j * BD + i] : cL[b * blk + i * BD + j];
+                            A[(size_t)(b * BD + i) * N + (b - 1) * BD + j] = v;
+                            A[(size_t)((b - 1) * BD + j) * N + b * BD + i] = v;
+                        }
+                    }
+            for (int j = 0; j < N; ++j) {       // in-place Cholesky (lower) + two triangular solves
+                double sdiag = A[(size_t)j * N + j];
+                for (int k = 0; k < j; ++k) sdiag -= A[(size_t)j * N + k] * A[(size_t)j * N + k];
+                const double gjj = sqrt(sdiag);
+                A[(size_t)j * N + j] = gjj;
+                for (int i = j + 1; i < N; ++i) {
+                    double v = A[(size_t)i * N + j];
+                    for (int k = 0; k < j; ++k) v -= A[(size_t)i * N + k] * A[(size_t)j * N + k];
+                    A[(size_t)i * N + j] = v / gjj;
+                }
+            }
+            for (int i = 0; i < N; ++i) { double v = x[i]; for (int k = 0; k < i; ++k) v -= A[(size_t)i * N + k] * x[k]; x[i] = v / A[(size_t)i * N + i]; }
+            for (int i = N - 1; i >= 0; --i) { double v = x[i]; for (int k = i + 1; k < N; ++k) v -= A[(size_t)k * N + i] * x[k]; x[i] = v / A[(size_t)i * N + i]; }
+            printf("solution against a dense host solve: classic %.2e, fused %.2e (max rel)\n", maxrel(xc.data(), x.data(), N), maxrel(xf.data(), x.data(), N));
+        }
+        hipEvent_t a, b2;
+        CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b2));
+        for (int fused = 0; fused < 2; ++fused) {
+            upload2(); chain(fused); CHK(hipStreamSynchronize(L.stream));
+            const int reps = 20;
+            CHK(hipEventRecord(a, L.stream));
+            for (int i = 0; i < reps; ++i) chain(fused);        // (the data degrade from repetition to repetition; the work does not)
+            CHK(hipEventRecord(b2, L.stream));
+            CHK(hipEventSynchronize(b2));
+            float ms;
+            CHK(hipEventElapsedTime(&ms, a, b2));
+            printf("%s chain (%d steps + top, eager launches): %.1f us\n", fused ? "fused  " : "classic", d.pcr.steps, 1000.0 * ms / reps);
+        }
         upload();
     }
     // ---- timing ----
