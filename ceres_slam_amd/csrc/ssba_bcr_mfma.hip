@@ -56,8 +56,11 @@ static __device__ __forceinline__ double mf_rsqrt(double a) {
 
 #ifdef SSBA_STAMPS
 #define MF_STAMP(i) do { if (bx == 3 && by == 0 && (threadIdx.x & 63) == 0) d.dbg[(threadIdx.x >> 6) * 64 + (i)] = clock64(); } while (0)
+// phases of EVERY workgroup (its thread 0) on the chip-wide 100 MHz clock: 0 entry, 1 loaded, 2 factored, 3 staged, 4 done
+#define MF_WG_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 500) d.dbg[4096 + 8 * (int)blockIdx.x + (k)] = wall_clock64(); } while (0)
 #else
 #define MF_STAMP(i) do { } while (0)
+#define MF_WG_STAMP(k) do { } while (0)
 #endif
 
 // XCD-aware placement: workgroups go to the eight XCDs round-robin by linear id (id % 8), and each XCD has its own L2.
@@ -204,6 +207,7 @@ struct FactorLds {
     // hand-offs between the four waves (LDS words, monotonic): no workgroup barrier inside the factorisation
     int seqPQ;                              // sub-steps published so far: 4 k + r + 1
     int seqA[4];                            // per column tile - 1: block rows whose panel is published (k + 1)
+    int seqY[8];                            // fused steps: per block row, the waves whose rows of [YL | YU | yr] are in LDS (5 = all)
     int bad;
 };
 
@@ -232,6 +236,10 @@ struct FactorLds {
         __builtin_amdgcn_sched_barrier(0);                                                                               \
     } while (0)
 
+// keeps the operand reads issued above it ahead of the matrix instructions below it (memory clobber for the compiler's
+// middle end, a scheduling barrier for the machine scheduler, which would otherwise sink the reads again)
+#define MF_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
 // NRW: column tiles of [L | U^T] per wave (1: three workgroups per block, 2: two, 3: one, 0: none -- blocks without couplings)
 // rlo .. nrt: the column tiles of the right-hand sides [L | U^T | B] this launch carries (0 .. 9 without border columns,
 // 0 .. 11 with them, 9 .. 11 for decoupled blocks with border columns)
@@ -242,9 +250,11 @@ struct FactorLds {
 // MODE 2: a step of the fused plan (PcrFused): 8 waves -- waves 0..3 run the D stream as always, waves 4..7 carry ALL nine
 //         column tiles of [L | U^T] (every workgroup of a block repeats the whole factorisation: the products that follow
 //         need every column, and a cross-workgroup exchange would cost more than the repetition) -- then [YL | yr] and
-//         [YU | yr] are staged in LDS and the workgroups of the block share the 55 Gram tiles (gram_phase).
-struct GramJob;
-static __device__ __forceinline__ void gram_phase(const FactorOps &o, double *sAL, double *sAU, double *scr, int W, int NW, int lane);
+//         [YU | yr] go to LDS block row by block row AS THEY BECOME FINAL, and every wave but the first adds the contribution of
+//         a finished block row to its share of the 55 Gram tiles (16 rows = four instructions per tile) in the time it would
+//         otherwise spend waiting for the pivot chain: when the last block row is done, so are the products.
+static __device__ __forceinline__ void gram_tile(int u, int &kind, int &ti, int &tj);
+static __device__ __forceinline__ void gram_store(const FactorOps &o, int kind, int ti, int tj, const double (&v)[4], double *scr, int lane);
 constexpr int MF_THREADS2 = 512;
 // ROLE 0: every wave runs both streams (MODE 0, 1).  MODE 2 instantiates the body twice -- ROLE 1: the D stream only (waves
 // 0..3), ROLE 2: right-hand-side tiles only (waves 4..7) -- so that neither role carries the other's register arrays
@@ -279,7 +289,7 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
     const int dj = !HAS_D ? -1 : w == 0 ? 4 : w;          // column tile of [D | r] this wave owns (wave 0 also owns tile (0, 0)); -1: none
     if (t == 0) { S.bad = 0; S.seqPQ = 0; }
     if (t < 4) S.seqA[t] = 0;
-    if (t < 8) S.rc[72 + t] = 1.0;
+    if (t < 8) { S.rc[72 + t] = 1.0; S.seqY[t] = 0; }
     // mf_solve_lds: solve: G (BD x BD) | yr (BD) | x;  MODE 2: [YL | yr] and [YU | yr], 72 x 80 each
     if (MODE == 2) {        // columns 72..79 of both staged operands: yr goes into column 72 later, the rest stays zero
         for (int i = t; i < 2 * BD * 8; i += MF_THREADS2) mf_solve_lds[(i >> 3) * 80 + BD + (i & 7)] = 0.0;
@@ -563,6 +573,89 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
             for (int s = 0; s < 4; ++s) dt[i] = mf(S.A[k][i - 1][s][lane], dt[k][s], dt[i]);
         }
     };
+    // ---- fused steps: [YL | yr] and [YU | yr] (72 x 80 each, rows scaled by 1 / sqrt(pivot)) are published block row by block
+    //      row; S.seqY[k] counts the waves that have written their part of block row k (the four right-hand-side waves and
+    //      wave 0 for yr).  Every wave but wave 0 owns up to NG of the 55 Gram tiles and adds the contribution of the block
+    //      rows in order as they complete: without blocking wherever it still has substitution work, blocking at the end. ----
+    double *sAL = mf_solve_lds, *sAU = mf_solve_lds + BD * 80;
+    // Who takes which tile.  Workgroup `by` of the ns that share the block owns the tiles u = by, by + ns, ... (18 or 19 of
+    // the 55 at ns = 3); its m-th tile goes to D wave 1 (m < 6), 2 (m < 11) or 3 (m < 15) -- they are done with the pivot
+    // chain early and add block rows while the right-hand-side waves, which the matrix pipe of the CU is busy with, still
+    // work on them -- and the few beyond that to the right-hand-side waves, which form them after their last block row.
+    constexpr int NG = MODE == 2 ? (ROLE == 1 ? 6 : 4) : 1;
+    int gti[NG], gtj[NG], gkind[NG];
+    bool ghave[NG];
+    mf_d4 gacc[NG];
+    int grow = 0;           // next block row to add
+    if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            int m;
+            if (ROLE == 1) m = w == 1 ? i : w == 2 ? 6 + i : w == 3 ? 11 + i : 1000;
+            else m = 15 + ((w + 3) & 3) + 4 * i;               // waves 5, 6, 7, 4 (wave 4 carries three column tiles: it comes last)
+            const bool mine = ROLE == 1 ? (w == 1 ? i < 6 : w == 2 ? i < 5 : w == 3 ? i < 4 : false) : true;
+            const int u = by + m * ns;
+            gram_tile(min(max(u, 0), 54), gkind[i], gti[i], gtj[i]);
+            ghave[i] = mine && u < 55 && (gkind[i] == 0 ? o.hasL : gkind[i] == 1 ? o.hasU : (o.hasL && o.hasU));
+            gacc[i] = mf_d4{0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    auto y_post = [&](int k) {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0) __hip_atomic_fetch_add(&S.seqY[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto y_rows = [&](int k) {          // right-hand-side waves: block row k of the wave's column tiles
+        double rsk[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) rsk[qq] = (k < 4 || qq < 2) ? sqrt(S.rc[16 * k + 4 * qq + g]) : 0.0;
+#pragma unroll
+        for (int q = 0; q < NRW; ++q) {
+            if (!ract[q]) continue;
+            const int col = 16 * rcol[q] + j;
+            double *pp = col < BD ? sAL + g * 80 + col : sAU + g * 80 + (col - BD);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (k < 4 || qq < 2) pp[(16 * k + 4 * qq) * 80] = rt[q][k][qq] * rsk[qq];
+        }
+        y_post(k);
+    };
+    auto yr_rows = [&](int k) {         // wave 0: block row k of yr = column 72 of [D | r] (lanes j == 8 of its column tile 4)
+        if (j == 8) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (k < 4 || qq < 2) {
+                    const int row = 16 * k + 4 * qq + g;
+                    const double v = dt[k][qq] * sqrt(S.rc[row]);
+                    sAL[row * 80 + BD] = v;
+                    sAU[row * 80 + BD] = v;
+                }
+        }
+        y_post(k);
+    };
+    auto gram_rows = [&](int k) {       // k at run time: the contribution of block row k to this wave's tiles
+        const int off = (16 * k + g) * 80 + j;
+        double a[NG][4], b[NG][4];
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (!ghave[i]) continue;
+            const double *sa = (gkind[i] == 0 ? sAL : sAU) + off + 16 * gti[i], *sb = (gkind[i] == 1 ? sAU : sAL) + off + 16 * gtj[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {       // (the last block row has eight rows)
+                a[i][q] = (q < 2 || k < 4) ? sa[4 * q * 80] : 0.0;
+                b[i][q] = (q < 2 || k < 4) ? sb[4 * q * 80] : 0.0;
+            }
+        }
+        MF_FENCE();
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            if (!ghave[i]) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < 2 || k < 4) gacc[i] = mf(a[i][q], b[i][q], gacc[i]);
+        }
+    };
     auto r_step = [&](int k) {
         const int nsub = k < 4 ? 4 : 2;
         MF_WAIT_GE(S.seqPQ, 4 * k + nsub);          // this stream lags: the whole diagonal tile is normally long done
@@ -584,6 +677,7 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
                     if (r + 1 < nsub) rt[q][k] = mf(Qv, yq[q][0], rt[q][k]);
                 }
         }
+        if (MODE == 2) y_rows(k);       // block row k of this wave's columns of [YL | YU] is final: into LDS for the Gram products
         // the panels of block row k (this stream lags, they are normally all there): one pass over the flags, then all
         // A operands in one batch of LDS reads
 #pragma unroll
@@ -606,13 +700,16 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
     };
 
     MF_STAMP(1);
+    MF_WG_STAMP(1);
     if (HAS_D && w == 0) factor_tile(d00, 0, 4);
 #pragma unroll
     for (int k = 0; k < NDT; ++k) {
         MF_STAMP(2 + 4 * k);
         if (HAS_D && dj > k) d_panel(k);
+        if (MODE == 2 && HAS_D && w == 0 && k < NDT - 1) yr_rows(k);        // (wave 0 owns column tile 4: its panel of block row k is final)
         MF_STAMP(3 + 4 * k);
         if (HAS_D && k + 1 < NDT && dj == k + 1) factor_tile(dt[k + 1], k + 1, k + 1 < 4 ? 4 : 2);   // the next diagonal tile is this wave's
+        if (MODE == 2 && HAS_D && w == 0 && k + 1 == NDT - 1) yr_rows(NDT - 1);
         MF_STAMP(4 + 4 * k);
         if (HAS_D && dj > k + 1) d_update(k);
         if (k >= 1 && rwave) r_step(k - 1);
@@ -620,6 +717,13 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
     }
     if (rwave) r_step(NDT - 1);
     MF_STAMP(30);
+    MF_WG_STAMP(2);
+    if (MODE == 2 && (HAS_R || w > 0)) {       // what is left of the Gram products: block rows in order, as they complete
+        for (; grow < NDT; ++grow) {
+            MF_WAIT_GE(S.seqY[grow], 5);
+            gram_rows(grow);
+        }
+    }
     __syncthreads();
     if (t < BD) {
         // 1 / pivot: a non-positive or non-finite pivot shows here (negative, infinite or NaN reciprocal): Cholesky breakdown,
@@ -634,36 +738,20 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
         return;
     }
     if (MODE == 2) {
-        // ---- [YL | yr] and [YU | yr] into LDS (rows scaled by 1/sqrt(d)), then this workgroup's share of the Gram tiles ----
-        double *sAL = mf_solve_lds, *sAU = mf_solve_lds + BD * 80;
+        // ---- the Gram tiles of this wave (the hand-off slots of the factorisation are dead: S.A is the transposition scratch) ----
+        MF_STAMP(32);
+        MF_WG_STAMP(3);
+        double *scr = &S.A[0][0][0][0] + w * (16 * 17);
 #pragma unroll
-        for (int q = 0; q < NRW; ++q) {
-            if (!ract[q]) continue;
-            const int col = 16 * rcol[q] + j;
-            double *pp = col < BD ? sAL + g * 80 + col : sAU + g * 80 + (col - BD);
-#pragma unroll
-            for (int k = 0; k < NDT; ++k)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    if (k < 4 || qq < 2) pp[(16 * k + 4 * qq) * 80] = rt[q][k][qq] * S.rs[16 * k + 4 * qq + g];
+        for (int i = 0; i < NG; ++i) {
+            if (!ghave[i]) continue;
+            const double v[4] = {gacc[i][0], gacc[i][1], gacc[i][2], gacc[i][3]};
+            gram_store(o, gkind[i], gti[i], gtj[i], v, scr, lane);
         }
-        if (HAS_D && w == 0 && j == 8) {         // yr = column 72 of [D | r] (this wave's column tile 4)
-#pragma unroll
-            for (int k = 0; k < NDT; ++k)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq)
-                    if (k < 4 || qq < 2) {
-                        const int row = 16 * k + 4 * qq + g;
-                        const double v = dt[k][qq] * S.rs[row];
-                        sAL[row * 80 + BD] = v;
-                        sAU[row * 80 + BD] = v;
-                    }
-        }
-        __syncthreads();        // (the hand-off slots of the factorisation are dead from here on: S.A is the transposition scratch)
-        gram_phase(o, sAL, sAU, &S.A[0][0][0][0] + w * (16 * 17), MODE == 2 ? 8 * by + w : 0, 8 * ns, lane);
+        MF_STAMP(33);
+        MF_WG_STAMP(4);
         return;
     }
-
     // ---- store: rows scaled by 1/sqrt(d) ---------------------------------------------------------------------
     double rsv[NDT][4];
 #pragma unroll
@@ -795,6 +883,9 @@ template <int NRW, int MODE>
 __global__ __launch_bounds__(MODE == 2 ? MF_THREADS2 : MF_THREADS) void k_bcr_factor_mf(Dev d, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt, int solve) {
     __shared__ FactorLds S;
     extern __shared__ __align__(16) double mf_dyn_lds[];
+#ifdef SSBA_STAMPS
+    if (threadIdx.x == 0) d.dbg[4096 + 8 * (int)blockIdx.x] = wall_clock64();       // entry of the workgroup on the chip-wide 100 MHz clock
+#endif
     if (MODE == 2) {
         if (threadIdx.x < MF_THREADS) factor_body<0, 2, 1>(d, S, mf_dyn_lds, lev, top, which, nblocks, ns, rlo, nrt, solve);
         else factor_body<NRW, 2, 2>(d, S, mf_dyn_lds, lev, top, which, nblocks, ns, rlo, nrt, solve);
@@ -853,84 +944,58 @@ static __device__ __forceinline__ mf_d4 tn_mma(const TnOps &O, mf_d4 acc) {
 }
 // keeps the operand reads issued above it ahead of the matrix instructions below it (memory clobber for the compiler's
 // middle end, a scheduling barrier for the machine scheduler, which would otherwise sink the reads again)
-#define MF_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
 // Gram products of one block's own factor outputs (fused plan, see PcrFused): units 0..14 the upper tiles of
 // GLL = [YL | yr]^T [YL | yr] (column 72 = YL^T yr), 15..29 the same for YU, 30..54 the tiles of GUL = YU^T YL, which is
-// stored in both orientations.  Wave W of the NW waves that share the block takes the units W, W + NW, ...; operand reads
-// run one unit ahead of the matrix instructions.
-static __device__ __forceinline__ void gram_phase(const FactorOps &o, double *sAL, double *sAU, double *scr, int W, int NW, int lane) {
-    const int g = lane >> 4, j = lane & 15;
-    constexpr int NUMAX = 7;        // 55 units over at least 8 waves
-    int ti[NUMAX], tj[NUMAX], kind[NUMAX];
-    bool have[NUMAX];
-#pragma unroll
-    for (int i = 0; i < NUMAX; ++i) {
-        const int u = W + i * NW;
-        kind[i] = u < 15 ? 0 : u < 30 ? 1 : 2;
-        have[i] = u < 55 && (kind[i] == 0 ? o.hasL : kind[i] == 1 ? o.hasU : (o.hasL && o.hasU));
-        if (kind[i] == 2) {
-            const int c = min(u - 30, 24);
-            ti[i] = c / 5;
-            tj[i] = c - 5 * ti[i];
-        } else {
-            const int n = u - 15 * kind[i];       // n -> (ti, tj): rows of the upper triangle start at 0, 5, 9, 12, 14
-            const int a = n >= 14 ? 4 : n >= 12 ? 3 : n >= 9 ? 2 : n >= 5 ? 1 : 0;
-            const int st0 = a == 4 ? 14 : a == 3 ? 12 : a == 2 ? 9 : a == 1 ? 5 : 0;
-            ti[i] = a;
-            tj[i] = min(a + (n - st0), NDT - 1);
-        }
+// stored in both orientations.  u -> (kind, tile row, tile column).
+static __device__ __forceinline__ void gram_tile(int u, int &kind, int &ti, int &tj) {
+    kind = u < 15 ? 0 : u < 30 ? 1 : 2;
+    if (kind == 2) {
+        const int c = u - 30;
+        ti = c / 5;
+        tj = c - 5 * ti;
+    } else {
+        const int n = u - 15 * kind;       // n -> (ti, tj): rows of the upper triangle start at 0, 5, 9, 12, 14
+        const int a = n >= 14 ? 4 : n >= 12 ? 3 : n >= 9 ? 2 : n >= 5 ? 1 : 0;
+        const int st0 = a == 4 ? 14 : a == 3 ? 12 : a == 2 ? 9 : a == 1 ? 5 : 0;
+        ti = a;
+        tj = min(a + (n - st0), NDT - 1);
     }
-    auto load = [&](TnOps &O, int i) {
-        const double *sa = kind[i] == 0 ? sAL : sAU, *sb = kind[i] == 1 ? sAU : sAL;
-        tn_load(O, sa, sb, ti[i], tj[i], g, j);
-    };
-    auto store = [&](const mf_d4 &v, int i) {
-        const int r0 = 16 * ti[i] + g, c0 = 16 * tj[i] + j;
-        if (kind[i] < 2) {
-            double *dst = kind[i] == 0 ? o.oGLL : o.oGUU, *gv = kind[i] == 0 ? o.ogL : o.ogU;
-            if (c0 < BD) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (r0 + 4 * q < BD) dst[(r0 + 4 * q) * BD + c0] = v[q];
-            } else if (c0 == BD) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (r0 + 4 * q < BD) gv[r0 + 4 * q] = v[q];
-            }
-            return;
-        }
+}
+static __device__ __forceinline__ void gram_store(const FactorOps &o, int kind, int ti, int tj, const double (&v)[4], double *scr, int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    const int r0 = 16 * ti + g, c0 = 16 * tj + j;
+    if (kind < 2) {
+        double *dst = kind == 0 ? o.oGLL : o.oGUU, *gv = kind == 0 ? o.ogL : o.ogU;
         if (c0 < BD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (r0 + 4 * q < BD) o.oGUL[(r0 + 4 * q) * BD + c0] = v[q];
-        }
-        // the transposed copy leaves through a per-wave LDS tile, as full row segments
-#pragma unroll
-        for (int q = 0; q < 4; ++q) scr[j * 17 + 4 * q + g] = v[q];
-        MF_FENCE();
-        mf_d4 r;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = scr[(4 * q + g) * 17 + j];
-        MF_FENCE();
-        const int r1 = 16 * tj[i] + g, c1 = 16 * ti[i] + j;
-        if (c1 < BD) {
+                if (r0 + 4 * q < BD) dst[(r0 + 4 * q) * BD + c0] = v[q];
+        } else if (c0 == BD) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (r1 + 4 * q < BD) o.oGULT[(r1 + 4 * q) * BD + c1] = r[q];
+                if (r0 + 4 * q < BD) gv[r0 + 4 * q] = v[q];
         }
-    };
-    TnOps Oa, Ob;
-    if (have[0]) load(Oa, 0);
+        return;
+    }
+    if (c0 < BD) {
 #pragma unroll
-    for (int i = 0; i < NUMAX; ++i) {
-        MF_FENCE();
-        if (i + 1 < NUMAX && have[i + 1]) load((i & 1) ? Oa : Ob, i + 1);
-        MF_FENCE();
-        if (have[i]) {
-            const mf_d4 acc = tn_mma((i & 1) ? Ob : Oa, mf_d4{0.0, 0.0, 0.0, 0.0});
-            store(acc, i);
-        }
+        for (int q = 0; q < 4; ++q)
+            if (r0 + 4 * q < BD) o.oGUL[(r0 + 4 * q) * BD + c0] = v[q];
+    }
+    // the transposed copy leaves through a per-wave LDS tile, as full row segments
+#pragma unroll
+    for (int q = 0; q < 4; ++q) scr[j * 17 + 4 * q + g] = v[q];
+    MF_FENCE();
+    double r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = scr[(4 * q + g) * 17 + j];
+    MF_FENCE();
+    const int r1 = 16 * tj + g, c1 = 16 * ti + j;
+    if (c1 < BD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (r1 + 4 * q < BD) o.oGULT[(r1 + 4 * q) * BD + c1] = r[q];
     }
 }
 
@@ -1311,7 +1376,9 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
 // the Gram tiles.  The decoupled last step assembles its blocks the same way, solves them and (solve = 2) updates the poses.
 constexpr size_t FUSED_LDS = (size_t)2 * BD * 80 * sizeof(double);
 void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q) {
-    const int ns = n <= 85 ? 3 : n <= 128 ? 2 : 1;
+    int ns = n <= 85 ? 3 : 2;         // (a plan has at most PCR_MAX_BLOCKS = 128 blocks; the kernel's tile share assumes ns >= 2)
+    static const int ns_env = [] { const char *e = getenv("SSBA_FUSED_NS"); return e ? atoi(e) : 0; }();      // 2 or 3: experiments
+    if (ns_env == 2 || (ns_env == 3 && n <= 85)) ns = ns_env;
     LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 2>), dim3(xcd_grid(n, ns)), dim3(MF_THREADS2), FUSED_LDS, d, q, 0, 2, n, ns, 0, NRT, 0);
 }
 void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve) {

@@ -154,6 +154,8 @@ int main(int argc, char **argv) {
     bool ok = true;
     for (uint k1 = 0; k1 + window_size <= dataset.num_states && ok; ++k1)             // :317-327
         ok = solveWindow(dataset, k1, k1 + window_size, use_light, multi_stage);
+    for (int a = 1; a < argc; ++a)          // --refprecision: the reference's four significant digits (utils/utils.hpp:34) instead of 17
+        if (std::string(argv[a]) == "--refprecision") dataset.csv_precision = ceres_slam::DatasetProblemPhong::kReferenceCsvPrecision;
     dataset.write_csv(filename);
     return ok ? EXIT_SUCCESS : EXIT_FAILURE;
 }

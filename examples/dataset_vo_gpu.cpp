@@ -201,6 +201,8 @@ int main(int argc, char **argv) {
             if (!ok || !WIFEXITED(status) || WEXITSTATUS(status) != 0) usable = false;
         }
     }
+    for (int a = 1; a < argc; ++a)          // --refprecision: the reference's four significant digits (utils/utils.hpp:34) instead of 17
+        if (std::string(argv[a]) == "--refprecision") dataset.csv_precision = ceres_slam::DatasetProblem::kReferenceCsvPrecision;
     dataset.write_csv(filename);
     return usable ? EXIT_SUCCESS : EXIT_FAILURE;
 }

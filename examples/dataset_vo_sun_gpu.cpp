@@ -113,6 +113,8 @@ int main(int argc, char **argv) {
     }
     ceres_slam::DatasetProblemSun dataset;
     if (!dataset.read_csv(argv[1], argv[2], argv[3])) return EXIT_FAILURE;
+    for (int a = 4; a < argc; ++a)          // --refprecision: the reference's four significant digits (utils/utils.hpp:34) instead of 17
+        if (std::string(argv[a]) == "--refprecision") dataset.csv_precision = ceres_slam::DatasetProblemSun::kReferenceCsvPrecision;
     if (window_size == 0 || window_size > dataset.num_states) window_size = dataset.num_states;      // 0 = full batch (:259-262)
 
     auto run_pass = [&](bool use_sun) {                                             // :267-283 / :295-311

@@ -198,14 +198,19 @@ class DatasetProblem {
         return true;
     }
 
+    //! Significant digits write_csv prints.  17 (the default) round-trips a double; kReferenceCsvPrecision = 4 is what the
+    //! reference writes (Eigen::IOFormat(4, ...), utils/utils.hpp:34) -- set it for byte-compatible output files.
+    static constexpr int kReferenceCsvPrecision = 4;
+    int csv_precision = 17;
+
     //! Write result to `<stem>_poses.csv` and `<stem>_map.csv` (dataset_problem.cpp:121-165)
     bool write_csv(const std::string &filename) const {
         const std::string stem = detail::stem(filename);
         std::ofstream pose_file(stem + "_poses.csv"), map_file(stem + "_map.csv");
         if (!pose_file.is_open() || !map_file.is_open()) { std::cerr << "Error: Couldn't open output files for " << stem << std::endl; return false; }
         pose_file << "T_00, T_01, T_02, T_03,T_10, T_11, T_12, T_13,T_20, T_21, T_22, T_23,T_30, T_31, T_32, T_33" << std::endl;
-        for (const SE3 &T : poses) pose_file << T.str() << std::endl;
-        map_file.precision(17);
+        for (const SE3 &T : poses) pose_file << T.str(csv_precision) << std::endl;
+        map_file.precision(csv_precision);
         map_file << "point_id, x, y, z" << std::endl;
         for (uint j = 0; j < map_points.size(); ++j)
             if (initialized_point[j]) map_file << j << "," << map_points[j](0) << "," << map_points[j](1) << "," << map_points[j](2) << std::endl;

@@ -166,14 +166,19 @@ class DatasetProblemPhong {
         return true;
     }
 
-    //! `<stem>_poses.csv`, `_map.csv`, `_lights.csv` (dataset_problem_phong.cpp:175-235), full precision
+    //! Significant digits write_csv prints: 17 round-trips a double, kReferenceCsvPrecision = 4 is the reference's
+    //! Eigen::IOFormat(4, ...) (utils/utils.hpp:34) for byte-compatible output files.
+    static constexpr int kReferenceCsvPrecision = 4;
+    int csv_precision = 17;
+
+    //! `<stem>_poses.csv`, `_map.csv`, `_lights.csv` (dataset_problem_phong.cpp:175-235)
     bool write_csv(const std::string &filename) const {
         const std::string stem = detail::stem(filename);
         std::ofstream pose_file(stem + "_poses.csv"), map_file(stem + "_map.csv"), light_file(stem + "_lights.csv");
         if (!pose_file.is_open() || !map_file.is_open() || !light_file.is_open()) return false;
-        map_file.precision(17); light_file.precision(17);
+        map_file.precision(csv_precision); light_file.precision(csv_precision);
         pose_file << "T_00, T_01, T_02, T_03,T_10, T_11, T_12, T_13,T_20, T_21, T_22, T_23,T_30, T_31, T_32, T_33" << std::endl;
-        for (const SE3 &T : poses) pose_file << T.str() << std::endl;
+        for (const SE3 &T : poses) pose_file << T.str(csv_precision) << std::endl;
         map_file << "point_id, x, y, z, nx, ny, nz, ka, ks, exponent, kd" << std::endl;
         for (uint j = 0; j < num_vertices; ++j) {
             if (!initialized_vertex[j]) continue;

@@ -171,12 +171,17 @@ class DatasetProblemSun {
         return true;
     }
 
+    //! Significant digits write_csv prints: 17 round-trips a double, kReferenceCsvPrecision = 4 is the reference's
+    //! Eigen::IOFormat(4, ...) (utils/utils.hpp:34) for byte-compatible output files.
+    static constexpr int kReferenceCsvPrecision = 4;
+    int csv_precision = 17;
+
     //! Write result to a CSV file: <filename>_poses.csv (dataset_problem_sun.cpp:172-232)
     bool write_csv(const std::string &filename) const {
         std::cout << "Outputting to file:\n\t" << filename + "_poses.csv" << std::endl;
         std::ofstream po(filename + "_poses.csv");
         if (!po.is_open()) return false;
-        po.precision(17);
+        po.precision(csv_precision);
         po << "T_00, T_01, T_02, T_03,T_10, T_11, T_12, T_13,T_20, T_21, T_22, T_23,T_30, T_31, T_32, T_33" << std::endl;
         for (uint k = 0; k < num_states; ++k) {
             const double *T = poses[k].data();

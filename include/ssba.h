@@ -61,9 +61,10 @@ typedef struct { double fu, fv, cu, cv, b; } ssba_camera;
 /* The ceres::Solver::Options fields the reference drivers set
  * (tests/dataset_vo.cpp:65-74, tests/dataset_ba_phong.cpp:79-88) plus the Ceres 1.x
  * defaults that shape the trust-region loop.  Unlisted Ceres options keep their
- * defaults.  trust_region_strategy_type / linear_solver_type: this build
- * implements LEVENBERG_MARQUARDT with an exact Schur-complement solve (what
- * dataset_vo.cpp runs; DOGLEG is SURVEY.md 8(f) row N1). */
+ * defaults.  trust_region_strategy_type: LEVENBERG_MARQUARDT (what dataset_vo.cpp runs)
+ * and DOGLEG with dogleg_type TRADITIONAL_DOGLEG / SUBSPACE_DOGLEG (dataset_ba_phong.cpp:85-86,
+ * dataset_vo_sun.cpp:142-143), both on an exact Schur-complement solve.  linear_solver_type
+ * has no field: every solve is the reduced-camera-system solve Ceres' SPARSE_SCHUR performs. */
 typedef struct {
     int32_t max_num_iterations;                 /* 50; drivers: 1000                   */
     int32_t use_nonmonotonic_steps;             /* 0;  drivers: 1                      */
@@ -288,8 +289,10 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
  *                             evaluation; such solves are not captured in a hipGraph).
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
  * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  ssba_set_huber_loss keeps its meaning
- * (the loss sits on the stereo residual blocks; lighting blocks take a NULL loss, :113,186).  Not
- * available together with lighting terms yet (SSBA_ERR_UNSUPPORTED): landmark sharding. */
+ * (the loss sits on the stereo residual blocks; lighting blocks take a NULL loss, :113,186).  Lighting
+ * terms shard by landmarks like the stereo terms (ssba_set_distributed); with FREE shared blocks the
+ * border sums are exchanged in the all-reduce mode only -- the partitioned reduced solve, bounds and
+ * DOGLEG with free shared blocks on more than one rank return SSBA_ERR_UNSUPPORTED. */
 #define SSBA_MAX_MATERIALS 15
 enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };
 int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);

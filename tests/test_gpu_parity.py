@@ -225,6 +225,19 @@ def test_cpp_driver_through_ceres_shim_matches_oracle(tmp_path):
     assert "Termination: CONVERGENCE" in report
     poses = synth.read_pose_csv(str(tmp_path / "sim_poses.csv"))
     assert np.abs(poses - op.poses).max() < 1e-6
+    # --refprecision: the reference's output format, four significant digits (Eigen::IOFormat(4, ...), utils/utils.hpp:34)
+    full_p = open(tmp_path / "sim_poses.csv").read().splitlines()
+    full_m = open(tmp_path / "sim_map.csv").read().splitlines()
+    r = subprocess.run([exe, ds, ip, im, "--refprecision"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for name, full in (("sim_poses.csv", full_p), ("sim_map.csv", full_m)):
+        short = open(tmp_path / name).read().splitlines()
+        assert short[0] == full[0] and len(short) == len(full)
+        for a, b in zip(short[1:], full[1:]):
+            ta, tb = a.split(","), b.split(",")
+            first = 1 if name == "sim_map.csv" else 0         # the point id is an integer
+            assert ta[:first] == tb[:first]
+            assert ta[first:] == ["%.4g" % float(x) for x in tb[first:]]
 
 
 def test_cpp_driver_with_the_native_rccl_exchange(tmp_path):

@@ -270,19 +270,70 @@ int main(int argc, char **argv) {
             for (int i = N - 1; i >= 0; --i) { double v = x[i]; for (int k = i + 1; k < N; ++k) v -= A[(size_t)k * N + i] * x[k]; x[i] = v / A[(size_t)i * N + i]; }
             printf("solution against a dense host solve: classic %.2e, fused %.2e (max rel)\n", maxrel(xc.data(), x.data(), N), maxrel(xf.data(), x.data(), N));
         }
-        hipEvent_t a, b2;
-        CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b2));
+        // per-launch times on VALID data (a chain leaves G in place of D: every run starts from a fresh upload)
         for (int fused = 0; fused < 2; ++fused) {
-            upload2(); chain(fused); CHK(hipStreamSynchronize(L.stream));
-            const int reps = 20;
-            CHK(hipEventRecord(a, L.stream));
-            for (int i = 0; i < reps; ++i) chain(fused);        // (the data degrade from repetition to repetition; the work does not)
-            CHK(hipEventRecord(b2, L.stream));
-            CHK(hipEventSynchronize(b2));
-            float ms;
-            CHK(hipEventElapsedTime(&ms, a, b2));
-            printf("%s chain (%d steps + top, eager launches): %.1f us\n", fused ? "fused  " : "classic", d.pcr.steps, 1000.0 * ms / reps);
+            std::vector<hipEvent_t> ev;
+            auto mark = [&] { hipEvent_t e; CHK(hipEventCreate(&e)); CHK(hipEventRecord(e, L.stream)); ev.push_back(e); };
+            double best_total = 1e30;
+            std::vector<float> best;
+            for (int rep = 0; rep < 5; ++rep) {
+                upload2();
+                CHK(hipStreamSynchronize(L.stream));
+                ev.clear();
+                mark();
+                for (int q = 0; q < d.pcr.steps; ++q) {
+                    if (fused) { launch_pcr_fused_step(L, d, n, q); mark(); }
+                    else { launch_bcr_factor_mf(L, d, n, q, 0, 2, true); mark(); launch_bcr_reduce_mf(L, d, n, 2, q, 2); mark(); }
+                }
+                if (fused) launch_pcr_fused_top(L, d, n, d.pcr.steps, 1);
+                else launch_bcr_factor_mf(L, d, n, d.pcr.steps, 1, 2, false, false, 1);
+                mark();
+                CHK(hipStreamSynchronize(L.stream));
+                std::vector<float> ms(ev.size() - 1);
+                float tot;
+                CHK(hipEventElapsedTime(&tot, ev.front(), ev.back()));
+                for (size_t i = 0; i + 1 < ev.size(); ++i) CHK(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+                if (tot < best_total) { best_total = tot; best = ms; }
+                for (auto e : ev) CHK(hipEventDestroy(e));
+            }
+            printf("%s chain, eager with an event after every launch: %.1f us total; per launch:", fused ? "fused  " : "classic", 1000.0 * best_total);
+            for (float v : best) printf(" %.1f", 1000.0 * v);
+            printf("\n");
+            CHK(hipMemcpy(&hst, d.st, sizeof hst, hipMemcpyDeviceToHost));
+            if (hst.step_failed) printf("  (step_failed set!)\n");
         }
+#ifdef SSBA_STAMPS
+        {
+            upload2();
+            for (int q = 0; q < 3 && q < d.pcr.steps; ++q) launch_pcr_fused_step(L, d, n, q);
+            CHK(hipStreamSynchronize(L.stream));
+            CHK(hipMemset(d.dbg, 0, 8192 * 8));
+            launch_pcr_fused_step(L, d, n, 3);
+            CHK(hipStreamSynchronize(L.stream));
+            std::vector<unsigned long long> stp(8192);
+            CHK(hipMemcpy(stp.data(), d.dbg, 8192 * 8, hipMemcpyDeviceToHost));
+            {
+                const int nwg = n * (n <= 85 ? 3 : n <= 128 ? 2 : 1);
+                unsigned long long lo = ~0ull;
+                for (int g = 0; g < nwg; ++g) lo = std::min(lo, stp[4096 + 8 * g]);
+                printf("fused step 3, every workgroup (thread 0) on the 100 MHz clock, us since the first entry: entry loaded factored staged done\n");
+                std::vector<std::pair<double, int>> order;
+                for (int g = 0; g < nwg; ++g) order.push_back({(stp[4096 + 8 * g + 4] - lo) / 100.0, g});
+                std::sort(order.begin(), order.end());
+                for (int i = 0; i < nwg; i += (i < 8 || i >= nwg - 24) ? 1 : 16) {
+                    const int g = order[i].second;
+                    printf("  wg %3d (xcd slot %d):", g, g & 7);
+                    for (int k = 0; k < 5; ++k) printf(" %6.2f", (double)(long long)(stp[4096 + 8 * g + k] - lo) / 100.0);
+                    printf("\n");
+                }
+            }
+            for (int w = 0; w < 8; ++w) {
+                printf("fused step 3, wave %d stamps (cycles since wave 0's first):", w);
+                for (int i = 0; i < 40; ++i) if (stp[w * 64 + i]) printf(" [%d]%lld", i, (long long)(stp[w * 64 + i] - stp[0]));
+                printf("\n");
+            }
+        }
+#endif
         upload();
     }
     // ---- timing ----

@@ -56,6 +56,9 @@ def run_case(name, prob, steps, force_dense):
         for i in range(steps):
             if i and i % period == 0:
                 ba.restart()
+            if TRACE:
+                with open(TRACE, "a") as fh:
+                    fh.write(f"step {i}\n")
             ba.step(1)
         ba.synchronize()
         return time.perf_counter() - t0

@@ -34,6 +34,13 @@ __global__ void k_bypointer(const Big *d, int *state, int use_state) {
     if (use_state) { if (threadIdx.x == 0) state[0] = state[0] + 1; }
 }
 
+// clock64() against wall time: spins until the counter has advanced by `cycles`
+__global__ void k_spin(long long cycles, long long *out) {
+    const long long t0 = clock64(), w0 = wall_clock64();
+    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(1);
+    if (threadIdx.x == 0) { out[0] = clock64() - t0; out[1] = wall_clock64() - w0; }
+}
+
 template <class F>
 static double time_chain(hipStream_t s, int n, int reps, F enqueue) {
     hipGraph_t g;
@@ -65,6 +72,23 @@ int main(int argc, char **argv) {
     Big *dbig;
     CK(hipMalloc(&dbig, sizeof(Big)));
     CK(hipMemcpy(dbig, &h, sizeof(Big), hipMemcpyHostToDevice));
+    {
+        long long *out;
+        CK(hipMalloc(&out, 16));
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(a, s));
+            hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, 2000000LL, out);
+            CK(hipEventRecord(b, s));
+            CK(hipEventSynchronize(b));
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            long long h[2];
+            CK(hipMemcpy(h, out, 16, hipMemcpyDeviceToHost));
+            printf("clock64: %lld ticks in %.1f us by events (%.1f per us); wall_clock64: %lld ticks (%.1f per us)\n", h[0], 1000.0 * ms, h[0] / (1000.0 * ms), h[1], h[1] / (1000.0 * ms));
+        }
+    }
     printf("chain of %d dependent launches per graph, %d replays, grid %d x 64 lanes; microseconds per launch\n", n, reps, grid);
     for (int use_state = 0; use_state < 2; ++use_state) {
         const char *sfx = use_state ? "+state" : "";
