@@ -68,13 +68,20 @@ static __device__ __forceinline__ double mf_rsqrt(double a) {
 // XCD.  The n x ny (block, part) pairs are listed grouped by block % 8 and XCD c takes a contiguous run of that list
 // (its ids c, c + 8, ...): exactly n x ny ids, no padding workgroups.  id -> (block e, part y).
 static __device__ __forceinline__ void xcd_map(int id, int n, int ny, int &e, int &y) {
+    // (no divisions: this runs in the prologue of every launch, in front of the first load)
     const int N = n * ny, c = id & 7;
-    int idx = id >> 3;
-    for (int k = 0; k < c; ++k) idx += (N - k + 7) >> 3;      // ids of the XCDs before c
+    const int q = (N + 7) >> 3, r = (N + 7) & 7;                // ids of XCD k: (N - k + 7) >> 3 = q for k <= r, q - 1 beyond
+    int idx = (id >> 3) + c * q - max(0, c - (r + 1));          // + the ids of the XCDs before c
     e = 0; y = 0;
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int sk = ((n - k + 7) >> 3) * ny;                 // pairs of the blocks with e % 8 == k
-        if (idx < sk) { const int bq = idx / ny; y = idx - bq * ny; e = k + 8 * bq; return; }
+        if (idx < sk) {
+            const int bq = ny == 1 ? idx : ny == 2 ? (idx >> 1) : ny == 3 ? ((idx * 0xAAAB) >> 17) : ((idx * 0x4000) >> 16);     // idx / ny, idx < 2^15, ny <= 4
+            y = idx - bq * ny;
+            e = k + 8 * bq;
+            return;
+        }
         idx -= sk;
     }
 }
@@ -263,12 +270,12 @@ template <int NRW, int MODE, int ROLE>
 static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, double *mf_solve_lds, int lev, int top, int which, int nblocks, int ns, int rlo, int nrt, int solve) {
     constexpr bool HAS_D = ROLE != 2, HAS_R = ROLE != 1;
     State &st = *d.st;
-    const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested once the operand reads are in flight
+    const StateFlags sf = state_flags_vmem(d.st);       // tested once the operand reads are in flight (ssba_device.h)
     FactorOps o;
     int bx, by;
     xcd_map((int)blockIdx.x, nblocks, ns, bx, by);
     if (MODE) fused_ops(d, lev, top, bx, o);
-    else if (!factor_ops(d, lev, top, which, bx, by == 0 && !dead, nrt > NRT, o)) return;
+    else if (!factor_ops(d, lev, top, which, bx, by == 0, nrt > NRT, o)) return;
     const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr bool rwave = HAS_R;       // this wave carries right-hand-side tiles
@@ -389,7 +396,7 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
                     for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = (k < 4 || qq < 2) ? pp[(16 * k + 4 * qq) * BD] : 0.0;
             }
         }
-        if (dead) return;
+        if (sf.dead()) return;
         // masks: column 72 of [D | r] is the right-hand side, the columns after it are zero; absent couplings are zero
         if (!MODE && dj == 4) {
 #pragma unroll
@@ -1023,7 +1030,7 @@ constexpr int BRS = 40;                     // LDS row stride of a staged yB: tw
 #endif
 // wg / nwg: this workgroup's index among the workgroups of the job.  dead: the solver state says "nothing to do"
 // (read by the caller; tested here, after the operand reads are in flight).
-static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *lds, int wg, int nwg, int dead, unsigned long long *dbg, bool stamp_here) {
+static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *lds, int wg, int nwg, const StateFlags &sf, unsigned long long *dbg, bool stamp_here) {
     double *sA0 = lds, *sA1 = lds + BD * RS, *sA2 = lds + 2 * BD * RS;
     const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15, w = t >> 6;
     const int W = 4 * wg + w, NW = 4 * nwg;     // wave index among the job's waves
@@ -1032,7 +1039,7 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
     stage_issue(R0, (J.sym || J.cpl) ? J.a0 : nullptr, J.sym ? J.ya0 : nullptr);
     stage_issue(R1, J.sym ? J.a1 : nullptr, J.sym ? J.ya1 : nullptr);
     stage_issue(R2, J.cpl ? J.a2 : nullptr, nullptr);
-    if (dead) return;
+    if (sf.dead()) return;
     // units of this wave: symmetric tiles n = W, W + NW (< 15); coupling tiles: the first ones go to the waves with
     // a single symmetric tile so that nobody gets more than five units
     constexpr int NSYM = 2, NCPL = 4;
@@ -1252,8 +1259,7 @@ static __device__ __forceinline__ void reduce_job(const ReduceJob &J, double *ld
 // reduction (which >= 2): D', r' in place, L' (+ its transpose) into the plan's buffers.  Plain levels (which = 0):
 // D', r', L' of the next level.  Same operand rules as k_bcr_reduce (ssba_bcr.hip).
 __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, int which, int nblocks, int ny, int ride, int x_lo) {
-    const State &st = *d.st;
-    const int dead = st.terminated | st.step_failed | st.dl_reuse;     // tested after the operand reads have been issued
+    const StateFlags sf = state_flags_vmem(d.st);       // tested after the operand reads have been issued (ssba_device.h)
     extern __shared__ __align__(16) double lds[];
     int bx, y;
     if ((int)blockIdx.x < nblocks * ny) xcd_map((int)blockIdx.x, nblocks, ny, bx, y);
@@ -1306,7 +1312,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
         const int m = bx, e = 2 * m, t = threadIdx.x;
         if (L.pin && m == L.n / 2) {
             // pinned end of a partitioned chain: carried over unchanged (see k_bcr_reduce)
-            if (dead) return;
+            if (sf.dead()) return;
             const int src = L.n - 1;
             if (y == 0) {
                 const double2 *s2 = reinterpret_cast<const double2 *>(L.D + (size_t)src * BD * BD);
@@ -1346,7 +1352,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_bcr_reduce_mf(Dev d, int lev, in
             J.bout = N.B + (size_t)m * BD * NBP;
         }
     }
-    reduce_job(J, lds, wg, nwg, dead, d.dbg, bx == 5);
+    reduce_job(J, lds, wg, nwg, sf, d.dbg, bx == 5);
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------

@@ -10,6 +10,26 @@
 namespace ssba {
 
 // ------------------------------------------------------------------ helpers ---
+// The words of the solver state every kernel tests first ("terminated", "step failed", "reuse the dogleg data") were
+// written by the previous launch, usually on another XCD: a cold read of a microsecond or two.  Through the scalar path
+// that latency sits in front of everything, because scalar loads return out of order and the first `s_waitcnt lgkmcnt(0)`
+// -- the one for the kernel arguments the addresses are computed from -- waits for the state words too.  Through the
+// VECTOR path the read has its own counter (vmcnt, in order): issued first, it is waited for where its value is used, with
+// the operand loads of the kernel already in flight behind it.  mbcnt(0, 0) is zero in every lane but opaque to the
+// compiler, which therefore emits a per-lane global_load.
+static __device__ __forceinline__ int state_word_vmem(const int *p) { return p[__builtin_amdgcn_mbcnt_lo(0u, 0u)]; }
+struct StateFlags {
+    int terminated, step_failed, dl_reuse;
+    __device__ __forceinline__ int dead() const { return terminated | step_failed | dl_reuse; }
+};
+static __device__ __forceinline__ StateFlags state_flags_vmem(const State *st) {
+    StateFlags f;
+    f.terminated = state_word_vmem(&st->terminated);
+    f.step_failed = state_word_vmem(&st->step_failed);
+    f.dl_reuse = state_word_vmem(&st->dl_reuse);
+    return f;
+}
+
 static __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
