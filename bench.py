@@ -57,6 +57,8 @@ def algorithmic_work(stats, phong=False):
     odd = [n // 2 for n in lv[:-1]] + [1]            # blocks factored per factor / backsub launch
     nxt = lv[1:]                                     # blocks produced per reduce launch
     bsub = list(odd)
+    fused = bool(stats.get("pcr_fused", 0)) and os.environ.get("SSBA_NO_PCR_FUSED") != "1"
+    fused_launches = 0
     if stats.get("pcr_blocks", 0):
         # plain levels down to the first one with <= 128 blocks, then parallel cyclic reduction of those n blocks:
         # ceil(log2 n) steps over ALL n blocks + one decoupled factor / solve, no back-substitution sweep there
@@ -71,6 +73,15 @@ def algorithmic_work(stats, phong=False):
         # the one after) + the coupling and its transpose
         fact_blocks = 6 * sum(m // 2 for m in lv[:k]) + 5 * n * steps + 2 * n
         red_blocks = 5 * sum(lv[1:k + 1]) + 7 * n * steps
+        if fused:
+            # one launch per step (PcrFused): D + two Gram blocks + two couplings in, assembled D + four Gram blocks out =
+            # 10 block moves per block and step; the decoupled last step 3 in + 1 out; no reduce launches in the plan.
+            # Per block and step: Cholesky + 145 right-hand-side columns + the Gram products YL^T YL, YU^T YU (symmetric:
+            # bd^3 each) and YU^T YL (2 bd^3).  (The workgroups of a block repeat the factorisation: not algorithmic work.)
+            fact_blocks = 6 * sum(m // 2 for m in lv[:k]) + 10 * n * steps + 4 * n
+            red_blocks = 5 * sum(lv[1:k + 1])
+            nxt = lv[1:k + 1]
+            fused_launches = steps
     else:
         fact_blocks, red_blocks = 6 * sum(odd), 5 * sum(nxt)
     bd = 72
@@ -99,7 +110,8 @@ def algorithmic_work(stats, phong=False):
         # slabs in (23 KB per window) + S blocks out
         "k_assemble_reduced": dict(bytes=23040 * stats["num_windows"] + B * 288 * 2, flops=0),
         # per block: Cholesky bd^3/3 + two triangular solves with 2*bd+1 right-hand sides; 3 blocks in, 3 out
-        "k_bcr_factor": dict(bytes=blk * fact_blocks / len(odd), flops=(bd ** 3 / 3 + bd * bd * (2 * bd + 1)) * sum(odd) / len(odd)),
+        "k_bcr_factor": dict(bytes=blk * fact_blocks / len(odd),
+                             flops=((bd ** 3 / 3 + bd * bd * (2 * bd + 1)) * sum(odd) + 4 * bd ** 3 * stats.get("pcr_blocks", 0) * fused_launches) / len(odd)),
         # per new block: three bd^3 products (2 flop per FMA), 3 blocks in, 2 out
         "k_bcr_reduce": dict(bytes=blk * red_blocks / max(len(nxt), 1), flops=3 * 2 * bd ** 3 * sum(nxt) / max(len(nxt), 1)),
         # per block: two mat-vecs + one triangular solve; 3 blocks in
@@ -133,9 +145,9 @@ def measured_peaks():
         return out
     txt = open(paths[-1]).read()
     out["source"] = os.path.relpath(paths[-1], ROOT)
-    m = re.search(r"HBM copy[^:]*: ([0-9.]+) GB/s", txt)
-    if m:
-        out["hbm_copy_measured_GBs"] = float(m.group(1))
+    rates = [float(x) for x in re.findall(r"HBM copy[^:\n]*: ([0-9.]+) GB/s", txt)]
+    if rates:
+        out["hbm_copy_measured_GBs"] = max(rates)       # the best copy kernel of the calibration (several shapes)
     m = re.search(r"fp64 MFMA 16x16x4 throughput, 1 wave\(s\)/SIMD, 4 indep acc: ([0-9.]+) TFLOP/s", txt)
     if m:
         out["fp64_mfma_measured_TFLOPs"] = float(m.group(1))

@@ -1625,6 +1625,7 @@ int ssba_finalize(ssba_problem *p) {
     p->stats.pose_bandwidth = bandwidth;
     p->stats.general_structure = dense ? 1u : nborder ? 2u : 0u;      // 2: windowed layout + closure border
     p->stats.pcr_blocks = d.pcr.level >= 0 ? (uint32_t)d.pcr.n : 0u;
+    p->stats.pcr_fused = d.pcrf.on ? 1u : 0u;
     if (dense) {      // the dense reduced system: its non-zero blocks and the real co-visibility span
         p->stats.num_reduced_blocks = (uint32_t)dn_blk_a.size();
         for (size_t i = 0; i < dn_blk_a.size(); ++i) p->stats.pose_bandwidth = std::max(p->stats.pose_bandwidth, dn_blk_b[i] - dn_blk_a[i]);

@@ -233,6 +233,8 @@ typedef struct {
     uint64_t device_bytes;         /* device memory held by the handle                  */
     uint32_t general_structure;    /* 1: tracks > SSBA_MAX_TRACK or span > 12 poses -> dense reduced system; 2: windowed layout + closure border */
     uint32_t pcr_blocks;           /* blocks handed to the parallel cyclic reduction (<= 128), 0 = plain BCR */
+    uint32_t pcr_fused;            /* 1: one launch per step of that reduction (no border columns, single GPU; SSBA_NO_PCR_FUSED=1 in the environment of a solve keeps factor + reduce launches) */
+    uint32_t reserved_;
 } ssba_stats;
 int ssba_get_stats(ssba_problem *p, ssba_stats *st);
 
