@@ -1521,6 +1521,13 @@ int ssba_finalize(ssba_problem *p) {
         for (int i = 0; i < d.n_sep; ++i) pos[i] = i;
         TRY(upload_pos(pos, &d.slev[0].pos));
         TRY(make_pcr(d.spcr, 0, d.n_sep, 0, 0, 0));
+        for (int q = 0; q < 2; ++q) {       // one launch per step of the separator solve (PcrFused)
+            TRY(dzero(p, &d.spcrf.Dpp[q], ns * blk)); TRY(dzero(p, &d.spcrf.rpp[q], ns * BD));
+            TRY(dzero(p, &d.spcrf.GLL[q], ns * blk)); TRY(dzero(p, &d.spcrf.GUU[q], ns * blk));
+            TRY(dzero(p, &d.spcrf.GUL[q], ns * blk)); TRY(dzero(p, &d.spcrf.GULT[q], ns * blk));
+            TRY(dzero(p, &d.spcrf.gL[q], ns * BD)); TRY(dzero(p, &d.spcrf.gU[q], ns * BD));
+        }
+        d.spcrf.on = 1;
     }
     std::vector<uint32_t> dn_blk_rf_start, dn_blk_rf;
     if (!pfs.empty()) {

@@ -858,12 +858,19 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
 void launch_bcr_separators(Launcher &L, const Dev &d) {
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int ns = d.n_sep;
+    const char *fe = getenv("SSBA_NO_PCR_FUSED");
+    if (d.spcrf.on && !bcr_legacy() && !(fe && fe[0] == '1')) {
+        // one launch per step, the decoupled last step solves its blocks itself: steps + 1 launches instead of 2 steps + 2
+        for (int q = 0; q < d.spcr.steps; ++q) launch_pcr_fused_step(L, d, ns, q, 3);
+        launch_pcr_fused_top(L, d, ns, d.spcr.steps, 1, 3);
+    } else {
     for (int q = 0; q < d.spcr.steps; ++q) {
         launch_factor(L, d, ns, q, 0, 3, true);
         launch_reduce(L, d, ns, 2, q, 3);
     }
     launch_factor(L, d, ns, d.spcr.steps, 1, 3, false);
     LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(ns), dim3(BS_THREADS), sh_backsub, d, 0, 1, 3);
+    }
     launch_sep_scatter(L, d);       // x0 at the separator poses <- separator solution
     LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.pcr.n), dim3(BS_THREADS), sh_backsub, d, d.pcr.level, 1, 2);
     for (int l = d.pcr.level - 1; l >= 0; --l)

@@ -164,10 +164,11 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
 
 // Operands of block bx in step `lev` (stride 1 << lev) of the fused plan, or of its decoupled last step (top).  Step 0 reads
 // the level's own D / L / r; step q >= 1 assembles them from what step q - 1 left (see PcrFused).
-static __device__ __forceinline__ void fused_ops(const Dev &d, int lev, int top, int bx, FactorOps &o) {
-    const PcrPlan &P = d.pcr;
-    const PcrFused &F = d.pcrf;
-    const BcrLevel &B = d.lev[P.level];
+// which = 2: the plan of the chain (d.pcr), 3: the separator system of a partitioned solve (d.spcr, solution into d.xsep)
+static __device__ __forceinline__ void fused_ops(const Dev &d, int which, int lev, int top, int bx, FactorOps &o) {
+    const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+    const PcrFused &F = which == 3 ? d.spcrf : d.pcrf;
+    const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[P.level];
     const size_t blk = (size_t)BD * BD;
     const int s = 1 << lev, h = s >> 1, last = B.n - 1, e = bx;
     o.saveU = nullptr; o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
@@ -196,7 +197,7 @@ static __device__ __forceinline__ void fused_ops(const Dev &d, int lev, int top,
     o.oD = top ? B.D + e * blk : nullptr;
     o.orr = top ? B.r + (size_t)e * BD : nullptr;
     if (top) {
-        o.xsol = d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[e] * BD;
+        o.xsol = which == 3 ? d.xsep + (size_t)B.pos[e] * BD : d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[e] * BD;
         o.f0 = (d.chain0 + B.pos[e]) * SBP;
     }
     const int oset = lev & 1;
@@ -274,7 +275,7 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
     FactorOps o;
     int bx, by;
     xcd_map((int)blockIdx.x, nblocks, ns, bx, by);
-    if (MODE) fused_ops(d, lev, top, bx, o);
+    if (MODE) fused_ops(d, which, lev, top, bx, o);
     else if (!factor_ops(d, lev, top, which, bx, by == 0, nrt > NRT, o)) return;
     const int t = threadIdx.x, lane = t & 63, g = lane >> 4, j = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1381,15 +1382,15 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
 // operands from, ONE launch; the workgroups of a block (3 up to 85 blocks, 2 up to 128) repeat the factorisation and share
 // the Gram tiles.  The decoupled last step assembles its blocks the same way, solves them and (solve = 2) updates the poses.
 constexpr size_t FUSED_LDS = (size_t)2 * BD * 80 * sizeof(double);
-void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q) {
+void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q, int which) {
     int ns = n <= 85 ? 3 : 2;         // (a plan has at most PCR_MAX_BLOCKS = 128 blocks; the kernel's tile share assumes ns >= 2)
     static const int ns_env = [] { const char *e = getenv("SSBA_FUSED_NS"); return e ? atoi(e) : 0; }();      // 2 or 3: experiments
     if (ns_env == 2 || (ns_env == 3 && n <= 85)) ns = ns_env;
-    LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 2>), dim3(xcd_grid(n, ns)), dim3(MF_THREADS2), FUSED_LDS, d, q, 0, 2, n, ns, 0, NRT, 0);
+    LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 2>), dim3(xcd_grid(n, ns)), dim3(MF_THREADS2), FUSED_LDS, d, q, 0, which, n, ns, 0, NRT, 0);
 }
-void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve) {
+void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve, int which) {
     const size_t sh_solve = (size_t)(BD * BD + 2 * BD) * sizeof(double);
-    LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<0, 1>), dim3(xcd_grid(n, 1)), dim3(MF_THREADS), solve ? sh_solve : 0, d, steps, 1, 2, n, 1, 0, NRT, solve);
+    LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<0, 1>), dim3(xcd_grid(n, 1)), dim3(MF_THREADS), solve ? sh_solve : 0, d, steps, 1, which, n, 1, 0, NRT, solve);
 }
 
 // ny_legacy: 2, or 3 with the coupling to a pinned last block (the grid.y of k_bcr_reduce)

@@ -108,8 +108,8 @@ int configure_dense();
 int configure_bcr_mf();
 void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int top, int which, bool coupled, bool ride = false, int solve = 0);
 void launch_bcr_reduce_mf(Launcher &L, const Dev &d, int nblocks, int ny, int lev, int which, bool ride = false);
-void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q);            // one launch per step of the fused plan (PcrFused)
-void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve);
+void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q, int which = 2);        // one launch per step of the fused plan (PcrFused); which = 3: the separator system
+void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve, int which = 2);
 void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
 void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false, bool skip_reduce = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)

@@ -28,7 +28,7 @@ constexpr int SBP = 12;                 // poses per super-block of the reduced 
 constexpr int BD = 6 * SBP;             // 72 rows per super-block
 constexpr int LMG = 64;                 // landmarks per ELL group (= wavefront)
 constexpr int SLAB_DOUBLES = NPAIR * 36 + TW * 6;   // per Schur work item
-constexpr int MAX_LEVELS = 24;
+constexpr int MAX_LEVELS = 18;          // plain levels below a parallel top of <= 128 blocks: 2^17 x 128 super-blocks
 constexpr int MAX_SLEVELS = 1;          // the separator system of a partitioned (multi-rank) solve: one level, parallel cyclic reduction
 constexpr int MAX_SEP = 65;             // separators = ranks - 1
 constexpr int NSCAL = 16;
@@ -174,6 +174,7 @@ struct Dev {
     int sep_sb[MAX_SEP];             // separator s = super-block sep_sb[s], shared by the ranks s and s + 1
     BcrLevel slev[MAX_SLEVELS];      // slev[0]: the separator system (n_sep blocks) inside the exchange vector
     PcrPlan spcr;                    // its parallel cyclic reduction (replicated on every rank)
+    PcrFused spcrf;                  // ... one launch per step (the separator plan has no pinned ends)
     double *sepv;                    // [Dsep | Lsep | rhs | gp | hdiag | scal]: the (small) exchange vector
     uint64_t soff_D, soff_L, soff_rhs, soff_gp, soff_hdiag, soff_scal, sepv_count;
     double *xsep;                    // n_sep * BD separator solution
@@ -252,6 +253,9 @@ struct Dev {
     double *dn_S;                                   // (dn_pad + DN_BS) x dn_pad, row-major, lower triangle; row dn_pad holds the
                                                     // right-hand side, so the factorisation leaves L^-1 rhs there
 };
+// Every kernel takes Dev by value: explicit kernel arguments are limited to 4 KB, and the hidden arguments of the code
+// object (256 B) and the handful of scalars beside Dev have to fit next to it.
+static_assert(sizeof(Dev) <= 4096 - 256 - 128, "Dev no longer fits the kernel-argument segment next to the scalars and hidden arguments");
 constexpr int DN_BS = 64;                           // block size of the dense Cholesky
 constexpr int NLS = 6;        // per block: cost, phi', |dx_l|^2, nonfinite, max|delta_l|, g_l . delta_l
 constexpr int NLS_OUT = 8;    // cost, phi', |dx_l|^2, nonfinite_l, max|delta|, g . delta, valid, x_cost
