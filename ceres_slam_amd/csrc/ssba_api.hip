@@ -103,6 +103,8 @@ struct ssba_problem {
     ssba_exchange_fn xfn = nullptr;
     void *xctx = nullptr;
     int world_size = 1, rank = 0;
+    State *ls_ring = nullptr;              // bounds: pinned copies of the state, one iteration behind (ssba_solve_step)
+    hipEvent_t ls_ev[2] = {nullptr, nullptr};
     ncclComm_t rccl_comm = nullptr;        // native exchange (ssba_set_rccl): all-reduces enqueued on the solver's stream
     std::vector<uint32_t> sep_sb;          // partitioned solve: separator super-blocks (world_size + 1 entries)
     // one trust-region iteration captured as a hipGraph (single-GPU, un-instrumented path)
@@ -366,6 +368,8 @@ int ssba_destroy(ssba_problem *p) {
     rccl_release(p);
     if (p->ev_begin) hipEventDestroy(p->ev_begin);
     if (p->ev_end) hipEventDestroy(p->ev_end);
+    if (p->ls_ring) pool_host_free(p->ls_ring);
+    for (hipEvent_t e : p->ls_ev) if (e) hipEventDestroy(e);
     if (p->own_stream) { hipStreamSynchronize(p->own_stream); pool_stream_release(p->own_stream); }
     delete p;
     return SSBA_OK;
@@ -1760,10 +1764,9 @@ static int ensure_log(ssba_problem *p, int capacity) {
 static int enqueue_kernels(ssba_problem *p);
 constexpr int LAZY_GRAPH_ITERS = 6;
 
-static int enqueue_constrained_iteration(ssba_problem *p);
+static int finish_pending_search(ssba_problem *p);
 
 static int enqueue_iteration(ssba_problem *p) {
-    if (p->d.constrained) return enqueue_constrained_iteration(p);   // host-driven line search: two graph segments around the host's read
     // The kernel sequence of an iteration is fixed (all control flow is on the device), so on
     // the plain single-GPU path it is captured once and replayed: ~45 launches become one.
     if (p->use_graph && !p->xfn && !p->launcher.timing) {
@@ -1796,7 +1799,7 @@ static int enqueue_front(ssba_problem *p);
 // replay graphs (the caller falls back to single iterations).
 constexpr int GRAPH_ITERS = 10;
 static int enqueue_batch(ssba_problem *p) {
-    if (p->d.constrained || !p->use_graph || p->xfn || p->launcher.timing) return SSBA_ERR_STATE;
+    if (!p->use_graph || p->xfn || p->launcher.timing) return SSBA_ERR_STATE;
     hipStream_t s = p->launcher.stream;
     if (!p->gexec2) {
         HIPCHECK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
@@ -1824,35 +1827,33 @@ static int enqueue_kernels(ssba_problem *p) {
     // single GPU, LM: the decision kernel forms the evaluation sums itself (no exchange sits between them)
     const bool fuse = !p->xfn && !p->d.constrained && p->opt.trust_region_strategy_type != 1;
     const bool fuse_upd = fuse_all_launches(p) && !p->d.dense && bcr_updates_poses(p->d);       // the reduced solve updated the poses, one partial per block
+    // bounds [trust_region_minimizer.cc DoLineSearch]: the Armijo test of the full step runs on the device; when it fails
+    // (rare) the state is parked and the host drives the search at its next look at the state (finish_pending_search)
+    if (p->d.constrained) launch_ph_ls_fast(p->launcher, p->d);
     if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p), fuse_upd ? p->d.pcr.n : -1); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
 }
 
-// Bounds-constrained problems [Ceres 1.x trust_region_minimizer.cc]: after the trust-region step the
-// minimiser runs a projected Armijo line search along it.  The device evaluates the line-search function,
-// the host drives the search (one synchronisation per evaluation), then the usual accept / reject logic
-// judges the (possibly shortened) step.
-static int enqueue_constrained_iteration(ssba_problem *p) {
+// Bounds-constrained problems [Ceres 1.x trust_region_minimizer.cc]: after the trust-region step the minimiser runs a
+// projected Armijo line search along it.  Its first sample -- the full step -- is tested on the device (k_ph_ls_fast); only
+// a rejected full step comes here: the stream is idle, the state parked (terminated, LS_PENDING), the iteration's front
+// part done.  The device evaluates the line-search function, the host drives the search (one synchronisation per
+// evaluation, ssba_linesearch.h), then the usual accept / reject logic judges the shortened step and the solver goes on.
+static int finish_pending_search(ssba_problem *p) {
+    ApiTimer api_timer("line search finished by the host");
     Dev &d = p->d;
     Launcher &L = p->launcher;
-    // The common case -- the full step satisfies the Armijo condition at once -- is two graph replays around one
-    // host read: [linearise .. solve .. candidate + first line-search evaluation] and [accept / reject + commit].
-    // Only the extra evaluations of a search that has to shorten the step are launched one by one.
-    int rc_front = SSBA_OK;
-    int rc = run_segment(p, 0, [&] {
-        rc_front = enqueue_front(p);
-        launch_ph_ls_probe(L, d, -1.0, 0);     // first evaluation at step 1: the candidate of the update kernels is that trial point
-    });
-    if (rc_front) return rc_front;
-    if (rc) return rc;
+    int rc;
     auto fetch = [&]() -> int {
         HIPCHECK(hipMemcpyAsync(p->h_ls, d.ls_out, NLS_OUT * sizeof(double), hipMemcpyDeviceToHost, L.stream));
         HIPCHECK(hipMemcpyAsync(p->h_state, d.st, sizeof(State), hipMemcpyDeviceToHost, L.stream));
         HIPCHECK(hipStreamSynchronize(L.stream));
         return SSBA_OK;
     };
+    launch_ls_resume(L, d);                 // the evaluation kernels test `terminated`
+    launch_ph_ls_probe(L, d, -1.0, 0);      // the full step again, with phi'(1) this time (the candidate of the update kernels is that trial point)
     if ((rc = fetch())) return rc;
     if (!p->h_state->terminated && p->h_ls[6] != 0.0) {
         Armijo a;
@@ -1871,11 +1872,13 @@ static int enqueue_constrained_iteration(ssba_problem *p) {
         if (want != at) launch_ph_ls_probe(L, d, want, 1);
         if (want != 1.0 || at != 1.0) launch_ph_ls_accept(L, d);
     }
-    if ((rc = run_segment(p, 2, [&] { launch_decide_commit(L, d); }))) return rc;
+    launch_decide_commit(L, d);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
 }
+// the state as the host last saw it says "a line search waits for the host"
+static bool search_pending(const ssba_problem *p) { return p->h_state->terminated && p->h_state->termination_type == LS_PENDING; }
 
 static int enqueue_front(ssba_problem *p) {
     Dev &d = p->d;
@@ -2004,9 +2007,9 @@ int ssba_solve_restart(ssba_problem *p) {
     return reset_solver(p);
 }
 
-int ssba_solve_step(ssba_problem *p, int n) {
-    if (!p || n < 0) return SSBA_ERR_INVALID_ARGUMENT;
-    if (!p->began) return SSBA_ERR_STATE;
+static int fetch_state(ssba_problem *p);
+
+static int enqueue_n(ssba_problem *p, int n) {
     int i = 0;
     for (; i + GRAPH_ITERS <= n; i += GRAPH_ITERS) {         // batches where the handle replays graphs
         const int rc = enqueue_batch(p);
@@ -2016,6 +2019,52 @@ int ssba_solve_step(ssba_problem *p, int n) {
     for (; i < n; ++i) {
         int rc = enqueue_iteration(p);
         if (rc) return rc;
+    }
+    return SSBA_OK;
+}
+
+int ssba_solve_step(ssba_problem *p, int n) {
+    if (!p || n < 0) return SSBA_ERR_INVALID_ARGUMENT;
+    if (!p->began) return SSBA_ERR_STATE;
+    if (!p->d.constrained) return enqueue_n(p, n);
+    // Bounds: an iteration whose full step fails the device-side Armijo test parks the solver, and everything enqueued
+    // behind it does nothing.  So the host stays ONE iteration ahead and looks at the state of the iteration before (as
+    // ssba_solve does): a parked search costs one idle iteration, is finished on the host, and the count goes on.
+    hipStream_t st = p->launcher.stream;
+    if (!p->ls_ring) {
+        HIPCHECK(pool_host_malloc((void **)&p->ls_ring, 2 * sizeof(State)));
+        HIPCHECK(hipEventCreateWithFlags(&p->ls_ev[0], hipEventDisableTiming));
+        HIPCHECK(hipEventCreateWithFlags(&p->ls_ev[1], hipEventDisableTiming));
+    }
+    int rc = fetch_state(p);
+    if (rc) return rc;
+    if (search_pending(p) && (rc = finish_pending_search(p))) return rc;
+    int judged = 0;                 // iterations of this call that reached their accept / reject decision
+    long it = 0;
+    bool outstanding = false;       // an enqueued iteration whose state has not been looked at
+    while (judged < n || outstanding) {
+        const bool more = judged + (outstanding ? 1 : 0) < n;
+        int slot = -1;
+        if (more) {
+            if ((rc = enqueue_iteration(p))) return rc;
+            slot = (int)(it++ & 1);
+            HIPCHECK(hipMemcpyAsync(&p->ls_ring[slot], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipEventRecord(p->ls_ev[slot], st));
+        }
+        if (outstanding) {          // the iteration before the one just enqueued
+            const int prev = more ? slot ^ 1 : (int)((it - 1) & 1);
+            HIPCHECK(hipEventSynchronize(p->ls_ev[prev]));
+            if (p->ls_ring[prev].terminated && p->ls_ring[prev].termination_type == LS_PENDING) {
+                // parked: the iteration enqueued behind it (if any) did nothing and does not count
+                if ((rc = fetch_state(p))) return rc;
+                if (search_pending(p) && (rc = finish_pending_search(p))) return rc;
+                ++judged;
+                outstanding = false;
+                continue;
+            }
+            ++judged;
+        }
+        outstanding = more;
     }
     return SSBA_OK;
 }
@@ -2038,9 +2087,14 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
     if (!p) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->began) return SSBA_ERR_STATE;
     hipStream_t st = p->launcher.stream;
-    HIPCHECK(hipEventRecord(p->ev_end, st));
     int rc = fetch_state(p);
     if (rc) return rc;
+    if (search_pending(p)) {        // (a stepwise caller stopped on a parked line search)
+        if ((rc = finish_pending_search(p))) return rc;
+        if ((rc = fetch_state(p))) return rc;
+    }
+    HIPCHECK(hipEventRecord(p->ev_end, st));
+    HIPCHECK(hipStreamSynchronize(st));
     p->launcher.collect();
     const State &S = *p->h_state;
     const int n = std::min(S.log_count, p->d.log.capacity);
@@ -2116,7 +2170,7 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
         set_error("pinned host allocation failed");
         return SSBA_ERR_HIP;
     }
-    const long max_enqueue = (long)o->max_num_iterations + 3;
+    long max_enqueue = (long)o->max_num_iterations + 3;
     bool done = false;
     for (long it = 0; it < max_enqueue && !done; ++it) {
         rc = enqueue_iteration(p);      // (one iteration per replay here: the host polls one round behind, and idle iterations
@@ -2128,6 +2182,19 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
         if (it >= 1) {
             const int prev = (int)((it - 1) & 1);
             hipEventSynchronize(ev[prev]);
+            if (ring[prev].terminated && ring[prev].termination_type == LS_PENDING) {
+                // bounds: the full step of an iteration failed the device-side Armijo test; what was enqueued behind it has
+                // done nothing.  Drain, let the host drive the search, go on.
+                if ((rc = fetch_state(p))) break;
+                if (search_pending(p) && (rc = finish_pending_search(p))) break;
+                // (the ring slot of this round was filled before the search finished: refill both)
+                hipMemcpyAsync(&ring[0], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st);
+                hipMemcpyAsync(&ring[1], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st);
+                hipEventRecord(ev[0], st);
+                hipEventRecord(ev[1], st);
+                max_enqueue += 2;       // the parked iteration's successor(s) did nothing: they do not count
+                continue;
+            }
             if (ring[prev].terminated) done = true;
             if (o->minimizer_progress_to_stdout)
                 printf("iter %4d cost %.6e radius %.3e\n", ring[prev].iteration, ring[prev].x_cost, ring[prev].radius);

@@ -534,7 +534,7 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
             const double y = yd[0];
             dt[k][r] = y;
             const double a = -y * rcr;
-            S.A[k][dj - 1][r][lane] = a;
+            S.A[k][max(dj, 1) - 1][r][lane] = a;       // (dj >= 1 wherever this runs)
             if (r < 3) dt[k] = mf(Qv, y, dt[k]);      // the next sub-step waits for this one: issued before the update of (dj, dj)
 #pragma unroll
             for (int i = 1; i < NDT; ++i)

@@ -1627,6 +1627,7 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.dl_reuse = 0; st.mu = 1e-8; st.alpha = 0.0; st.dl_step_norm = 0.0; st.grad_norm = 0.0; st.gn_norm = 0.0;
     st.g_dot_gn = 0.0; st.beta = 1.0; st.gamma = 0.0;
     st.ls_alpha = 1.0;
+    st.ls_pending = 0;
     st.sub_one_dim = 0; st.sub_g[0] = st.sub_g[1] = 0.0; st.sub_B[0] = st.sub_B[1] = st.sub_B[2] = 0.0;
     st.sub_e[0][0] = st.sub_e[0][1] = st.sub_e[1][0] = st.sub_e[1][1] = 0.0;
 }

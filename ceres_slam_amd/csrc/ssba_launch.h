@@ -141,6 +141,8 @@ void launch_ph_dogleg_eval(Launcher &L, const Dev &d);
 void launch_pose_update(Launcher &L, const Dev &d);
 void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved);
 void launch_ph_ls_accept(Launcher &L, const Dev &d);
+void launch_ph_ls_fast(Launcher &L, const Dev &d);          // bounds: the Armijo test of the full step on the device (parks the solver when it fails)
+void launch_ls_resume(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();
 void launch_border_solve(Launcher &L, const Dev &d);

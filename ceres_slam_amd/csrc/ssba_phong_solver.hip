@@ -1466,6 +1466,81 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_ls_probe(Dev d
     }
 }
 
+// ---- the common case of the projected line search without the host ----------------------------------------------
+// [line_search.cc ArmijoLineSearch::DoSearch] The first sample is the full step, and it is accepted iff
+//     phi(1) <= phi(0) + 1e-4 phi'(0),    phi(1) = the candidate cost the evaluation kernel has just formed,
+//     phi'(0) = g . delta (every block: landmarks, poses, shared blocks).
+// phi'(1), which Ceres also evaluates there, is only USED by the interpolation of a rejected sample.  So the accepted full
+// step needs no probe at all: k_ph_ls_dir forms the landmark part of g . delta and max|delta| (the search's
+// min_step_size test), k_ph_ls_fast adds the pose / border parts and decides.  A rejected full step parks the solver
+// (terminated with LS_PENDING) until the host has driven the search (ssba_api.hip: finish_pending_search) -- exactly the
+// evaluations Ceres makes, starting with phi'(1).
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_dir(Dev d) {
+    const State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = d.lm_mask[l];
+    double dmax = 0.0, gd = 0.0;
+    if (mask && !st.step_failed) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double dl = d.dlm[(size_t)c * d.Lpad + l];
+            dmax = fmax(dmax, fabs(dl));
+            gd += d.gl[(size_t)c * d.Lpad + l] * dl;
+        }
+    }
+    const double f2 = block_max(dmax, sm), g2 = block_sum(gd, sm);
+    if (threadIdx.x == 0) {
+        double *o = d.part_ls + (size_t)blockIdx.x * NLS;
+        o[4] = f2; o[5] = g2;
+    }
+}
+__global__ __launch_bounds__(256) void k_ph_ls_fast(Dev d) {
+    State &st = *d.st;
+    if (st.terminated) return;
+    __shared__ double sm[4];
+    double lmax = 0.0, lgd = 0.0;
+    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+        const double *o = d.part_ls + (size_t)i * NLS;
+        lmax = fmax(lmax, o[4]); lgd += o[5];
+    }
+    double pmax = 0.0, pgd = 0.0, pbad = 0.0;
+    for (int i = threadIdx.x; i < d.nfree * 6; i += 256) {
+        const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
+        const double dpc = st.opt.strategy ? st.beta * d.x0[i] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[i];
+        pmax = fmax(pmax, fabs(dpc));
+        pgd += d.xv[d.off_gp + i] * dpc;
+    }
+    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) pbad += d.part_pose[i * NPP + 1];
+    lmax = block_max(lmax, sm); lgd = block_sum(lgd, sm);
+    pmax = block_max(pmax, sm); pgd = block_sum(pgd, sm); pbad = block_sum(pbad, sm);
+    if (threadIdx.x != 0) return;
+    double bmax = 0.0, bgd = 0.0;
+    for (int c = 0; c < d.nb; ++c) {
+        const double v = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
+        bmax = fmax(bmax, fabs(v));
+        bgd += d.bsys[BS_G + c] * v;
+    }
+    // ComputeTrustRegionStep: the search only runs on a valid step (as k_ph_ls_reduce's ls_out[6])
+    const bool valid = !st.step_failed && (d.scal2[3] + pbad) == 0.0 && d.scal2[1] > 0.0;
+    if (!valid) return;
+    const double phi0 = st.x_cost, dphi0 = lgd + pgd + bgd, phi1 = d.scal2[0];
+    const bool value_ok = isfinite(phi1);
+    if (value_ok && !(phi1 > phi0 + 1e-4 * dphi0 * 1.0)) return;       // the full step satisfies the Armijo condition: nothing to search
+    st.ls_pending = 1;
+    st.terminated = 1;
+    st.termination_type = LS_PENDING;
+}
+__global__ void k_ls_resume(Dev d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    State &st = *d.st;
+    if (!st.ls_pending) return;
+    st.ls_pending = 0;
+    st.terminated = 0;
+    st.termination_type = 1;
+}
+
 // one block: totals of the probe plus the pose / border parts of max|delta| and g . delta, and the
 // validity of the trust-region step (as k_decide will judge it)
 __global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d) {
@@ -1621,6 +1696,14 @@ void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
     }
     LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d);
+}
+// the device-side test of the full step (the common case); a rejected one leaves the state parked for the host
+void launch_ph_ls_fast(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, (d.dense ? k_ph_ls_dir<true> : k_ph_ls_dir<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(256), 0, d);
+}
+void launch_ls_resume(Launcher &L, const Dev &d) {
+    hipLaunchKernelGGL(k_ls_resume, dim3(1), dim3(64), 0, L.stream, d);
 }
 void launch_ph_ls_accept(Launcher &L, const Dev &d) {
     hipLaunchKernelGGL(k_ph_ls_accept, dim3(1), dim3(64), 0, L.stream, d);

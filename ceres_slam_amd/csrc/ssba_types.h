@@ -73,7 +73,11 @@ struct State {
     int sub_one_dim, sub_pad_;
     double sub_e[2][2], sub_g[2], sub_B[3];
     double ls_alpha;          // projected line search (bounds): the candidate is Plus(x, ls_alpha * delta)
+    // bounds: the full step failed the Armijo test on the device (k_ph_ls_fast), the search needs evaluations the host has to
+    // drive: terminated = 1 with termination_type = LS_PENDING parks every kernel until ssba_api.hip has finished the search
+    int ls_pending, pad3_;
 };
+constexpr int LS_PENDING = 3;   // State::termination_type while a projected line search waits for the host (never reported)
 
 struct IterLog {   // device arrays, capacity entries
     int capacity;
