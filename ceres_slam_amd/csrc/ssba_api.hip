@@ -1484,26 +1484,29 @@ int ssba_finalize(ssba_problem *p) {
         }
         return SSBA_OK;
     };
+    auto make_fused = [&](PcrFused &F, size_t n, bool pins) -> int {      // one launch per step (PcrFused): ping-pong buffers of the assembled blocks and the Gram products
+        for (int q = 0; q < 2; ++q) {
+            TRY(dzero(p, &F.Dpp[q], n * blk)); TRY(dzero(p, &F.rpp[q], n * BD));
+            TRY(dzero(p, &F.GLL[q], n * blk)); TRY(dzero(p, &F.GUU[q], n * blk));
+            TRY(dzero(p, &F.GUL[q], n * blk)); TRY(dzero(p, &F.GULT[q], n * blk));
+            TRY(dzero(p, &F.gL[q], n * BD)); TRY(dzero(p, &F.gU[q], n * BD));
+        }
+        if (pins) { TRY(dzero(p, &F.Lkeep, n * blk)); TRY(dzero(p, &F.Ukeep, n * blk)); }
+        F.on = 1;
+        return SSBA_OK;
+    };
     {
         const char *e = getenv("SSBA_NO_PCR");
         // with free shared blocks the border columns follow through the kept factors of every step (ssba_border.hip);
         // that variant covers plans that are parallel from level 0 on
         if (part) {
             TRY(make_pcr(d.pcr, d.n_levels - 1, d.lev[d.n_levels - 1].n, 0, d.pin0, d.pin1));
+            if (!d.nb) TRY(make_fused(d.pcrf, (size_t)d.pcr.n, true));
         } else if ((!d.nb || d.lev[0].n <= pcr_max) && p->world_size == 1 && !dense && !(e && e[0] == '1')) {
             int k = 0;
             while (d.lev[k].n > pcr_max) ++k;
             TRY(make_pcr(d.pcr, k, d.lev[k].n, d.nb ? 1 : 0, 0, 0));
-            if (!d.nb) {        // one launch per step (PcrFused): ping-pong buffers of the assembled blocks and the Gram products
-                const size_t n = (size_t)d.pcr.n;
-                for (int q = 0; q < 2; ++q) {
-                    TRY(dzero(p, &d.pcrf.Dpp[q], n * blk)); TRY(dzero(p, &d.pcrf.rpp[q], n * BD));
-                    TRY(dzero(p, &d.pcrf.GLL[q], n * blk)); TRY(dzero(p, &d.pcrf.GUU[q], n * blk));
-                    TRY(dzero(p, &d.pcrf.GUL[q], n * blk)); TRY(dzero(p, &d.pcrf.GULT[q], n * blk));
-                    TRY(dzero(p, &d.pcrf.gL[q], n * BD)); TRY(dzero(p, &d.pcrf.gU[q], n * BD));
-                }
-                d.pcrf.on = 1;
-            }
+            if (!d.nb) TRY(make_fused(d.pcrf, (size_t)d.pcr.n, false));
         }
     }
     if (part) {
@@ -1525,13 +1528,7 @@ int ssba_finalize(ssba_problem *p) {
         for (int i = 0; i < d.n_sep; ++i) pos[i] = i;
         TRY(upload_pos(pos, &d.slev[0].pos));
         TRY(make_pcr(d.spcr, 0, d.n_sep, 0, 0, 0));
-        for (int q = 0; q < 2; ++q) {       // one launch per step of the separator solve (PcrFused)
-            TRY(dzero(p, &d.spcrf.Dpp[q], ns * blk)); TRY(dzero(p, &d.spcrf.rpp[q], ns * BD));
-            TRY(dzero(p, &d.spcrf.GLL[q], ns * blk)); TRY(dzero(p, &d.spcrf.GUU[q], ns * blk));
-            TRY(dzero(p, &d.spcrf.GUL[q], ns * blk)); TRY(dzero(p, &d.spcrf.GULT[q], ns * blk));
-            TRY(dzero(p, &d.spcrf.gL[q], ns * BD)); TRY(dzero(p, &d.spcrf.gU[q], ns * BD));
-        }
-        d.spcrf.on = 1;
+        TRY(make_fused(d.spcrf, (size_t)ns, false));        // one launch per step of the separator solve
     }
     std::vector<uint32_t> dn_blk_rf_start, dn_blk_rf;
     if (!pfs.empty()) {

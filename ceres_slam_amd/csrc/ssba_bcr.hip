@@ -846,6 +846,14 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
         launch_factor(L, d, n_odd(d.lev[l], d.lev[l].pin), l, 0, 0, true);
         launch_reduce(L, d, d.lev[l + 1].n, 2, l, 0);
     }
+    const char *fe = getenv("SSBA_NO_PCR_FUSED");
+    if (d.pcrf.on && !bcr_legacy() && !(fe && fe[0] == '1')) {
+        // one launch per step, with the couplings to the pinned ends kept (PcrFused::Lkeep / Ukeep); the last launch
+        // factors the interior blocks with those couplings as right-hand sides and leaves the pinned rows in place
+        for (int q = 0; q < d.pcr.steps; ++q) launch_pcr_fused_step(L, d, n, q, 2);
+        launch_pcr_fused_top(L, d, n, d.pcr.steps, 0, 2);
+        return;
+    }
     for (int q = 0; q < d.pcr.steps; ++q) {
         launch_factor(L, d, n, q, 0, 2, true);
         launch_reduce(L, d, n, d.pcr.pin1 ? 3 : 2, q, 2);

@@ -99,8 +99,12 @@ struct FactorOps {
     // fused steps (PcrFused): D = Dg - GA - GB, r = rin - ga - gb (null: nothing to subtract), couplings = sgn x [Lg | Ug];
     // nD / nr: where the assembled D (upper tiles) / r go for the next step; the Gram products of this block
     const double *GA, *GB, *ga, *gb;
-    double sgn;
+    double sgnL, sgnU;
     double *nD, *nr, *oGLL, *oGUU, *oGUL, *oGULT, *ogL, *ogU;
+    // chains with pinned ends: saveL (like saveU) keeps a coupling that will not be folded again; a pinned block is only
+    // assembled (and, the last one, tracks its coupling to the first); which Gram products somebody will read
+    double *saveL;
+    bool pinned, gLL, gUU, gUL;
 };
 
 // operands and destinations of one block: mirrors k_bcr_factor (ssba_bcr.hip).  false: this block has nothing to do.
@@ -110,7 +114,8 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
     o.trL = o.trU = false;
     o.saveU = nullptr;
     o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
-    o.GA = o.GB = o.ga = o.gb = nullptr; o.sgn = 1.0; o.nD = o.nr = nullptr;
+    o.GA = o.GB = o.ga = o.gb = nullptr; o.sgnL = o.sgnU = 1.0; o.nD = o.nr = nullptr;
+    o.saveL = nullptr; o.pinned = false; o.gLL = o.gUU = o.gUL = false;
     if (which >= 2) {
         const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
         const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[d.pcr.level];
@@ -164,41 +169,73 @@ static __device__ __forceinline__ bool factor_ops(const Dev &d, int lev, int top
 
 // Operands of block bx in step `lev` (stride 1 << lev) of the fused plan, or of its decoupled last step (top).  Step 0 reads
 // the level's own D / L / r; step q >= 1 assembles them from what step q - 1 left (see PcrFused).
-// which = 2: the plan of the chain (d.pcr), 3: the separator system of a partitioned solve (d.spcr, solution into d.xsep)
+// which = 2: the plan of the chain (d.pcr), 3: the separator system of a partitioned solve (d.spcr, solution into d.xsep).
+// Chains with pinned ends (P.pin0 / P.pin1, see PcrPlan): a pinned block is never factored -- it folds its neighbours like
+// every block (it is assembled) -- and never folded: a block whose neighbour at the current stride is pinned, or beyond the
+// chain, KEEPS its coupling to the pinned block from then on (PcrFused::Lkeep / Ukeep).
 static __device__ __forceinline__ void fused_ops(const Dev &d, int which, int lev, int top, int bx, FactorOps &o) {
     const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
     const PcrFused &F = which == 3 ? d.spcrf : d.pcrf;
     const BcrLevel &B = which == 3 ? d.slev[0] : d.lev[P.level];
     const size_t blk = (size_t)BD * BD;
     const int s = 1 << lev, h = s >> 1, last = B.n - 1, e = bx;
-    o.saveU = nullptr; o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
+    const int lo = P.pin0 ? 1 : 0, hi = P.pin1 ? last - 1 : last;          // the blocks that are factored (and folded by others)
+    o.saveU = o.saveL = nullptr; o.Bg = nullptr; o.oYB = nullptr; o.xsol = nullptr;
     o.oYL = o.oYU = nullptr;
     o.GA = o.GB = o.ga = o.gb = nullptr;
     o.nD = o.nr = nullptr;
-    o.hasL = !top && e - s >= 0;
-    o.hasU = !top && e + s <= last;
+    o.pinned = e < lo || e > hi;
+    const bool pinned_chain = P.pin0 || P.pin1;
+    // couplings of this block at this stride: to e -/+ s, or the kept one to the pinned end; the decoupled last step of a
+    // pinned chain still carries the kept ones
+    // (in the decoupled last step s >= n: only kept couplings are left)
+    o.hasL = e >= 1 && (e - s >= 0 || P.pin0);
+    o.hasU = e <= last - 1 && (e + s <= last || P.pin1);
+    if (o.pinned) {     // no right-hand sides, except that the pinned last block tracks its coupling to the pinned first one
+        o.hasU = false;
+        o.hasL = e == last && e >= 1 && P.pin0 && P.pin1;
+    }
+    o.trL = o.trU = false;
+    o.sgnL = o.sgnU = 1.0;
+    o.Lg = B.L + e * blk; o.Ug = B.L + e * blk;         // (never read without hasL / hasU)
     if (lev == 0) {
         o.Dg = B.D + e * blk; o.rin = B.r + (size_t)e * BD;
-        o.Lg = B.L + e * blk; o.Ug = B.L + (size_t)(o.hasU ? e + 1 : e) * blk;
+        o.Lg = B.L + e * blk; o.Ug = B.L + (size_t)(e < last ? e + 1 : e) * blk;
         o.trL = o.trU = (e & 1) == 0;       // even coupling blocks of a level are stored transposed (ssba_bcr.hip)
-        o.sgn = 1.0;
     } else {
         const int set = (lev - 1) & 1, prev = e - h, next = e + h;
         o.Dg = lev == 1 ? B.D + e * blk : F.Dpp[(lev - 1) & 1] + e * blk;
         o.rin = lev == 1 ? B.r + (size_t)e * BD : F.rpp[(lev - 1) & 1] + (size_t)e * BD;
-        if (prev >= 0) { o.GA = F.GUU[set] + prev * blk; o.ga = F.gU[set] + (size_t)prev * BD; }
-        if (next <= last) { o.GB = F.GLL[set] + next * blk; o.gb = F.gL[set] + (size_t)next * BD; }
-        o.Lg = F.GUL[set] + (size_t)(o.hasL ? prev : e) * blk;
-        o.Ug = F.GULT[set] + (size_t)(o.hasU ? next : e) * blk;
-        o.trL = o.trU = false;
-        o.sgn = -1.0;
+        if (prev >= lo) { o.GA = F.GUU[set] + prev * blk; o.ga = F.gU[set] + (size_t)prev * BD; }
+        if (next <= hi) { o.GB = F.GLL[set] + next * blk; o.gb = F.gL[set] + (size_t)next * BD; }
+        // the coupling was renewed by the last step iff the neighbour at half the stride was folded; else it is a kept one
+        if (o.hasL) { if (prev >= lo) { o.Lg = F.GUL[set] + prev * blk; o.sgnL = -1.0; } else o.Lg = F.Lkeep + e * blk; }
+        if (o.hasU) { if (next <= hi) { o.Ug = F.GULT[set] + next * blk; o.sgnU = -1.0; } else o.Ug = F.Ukeep + e * blk; }
         if (!top) { o.nD = F.Dpp[lev & 1] + e * blk; o.nr = F.rpp[lev & 1] + (size_t)e * BD; }
     }
+    if (pinned_chain && !top) {
+        // save a coupling when the NEXT step will find it kept (its half-stride neighbour, e -/+ s, pinned or outside) and this
+        // step did not read it from the keep buffer already
+        if (o.hasL && e - s < lo && o.Lg != F.Lkeep + e * blk) o.saveL = F.Lkeep + e * blk;
+        if (o.hasU && e + s > hi && o.Ug != F.Ukeep + e * blk) o.saveU = F.Ukeep + e * blk;
+    }
+    // the Gram products somebody reads: the next step's block e - s / e + s assembles from them (a kept coupling feeds nobody's D)
+    o.gLL = o.hasL && e - s >= 0 && !top;
+    o.gUU = o.hasU && e + s <= last && !top;
+    o.gUL = o.hasL && o.hasU && !top;
     o.oD = top ? B.D + e * blk : nullptr;
     o.orr = top ? B.r + (size_t)e * BD : nullptr;
     if (top) {
         o.xsol = which == 3 ? d.xsep + (size_t)B.pos[e] * BD : d.x0 + (size_t)d.chain0 * BD + (size_t)B.pos[e] * BD;
         o.f0 = (d.chain0 + B.pos[e]) * SBP;
+        if (pinned_chain) {         // the factor outputs k_bcr_backsub reads after the separator solve; the pinned rows in place
+            o.xsol = nullptr;
+            o.oYL = o.hasL ? P.YL + e * blk : nullptr;
+            o.oYU = o.hasU ? P.YU + e * blk : nullptr;
+            if (o.pinned) { o.nD = B.D + e * blk; o.nr = B.r + (size_t)e * BD; }
+            // S[last, first], for k_sep_pack: the pinned last block's coupling to the pinned first one
+            if (o.pinned && e == last && P.pin0 && P.pin1) o.saveL = P.Lbuf + e * blk;
+        }
     }
     const int oset = lev & 1;
     o.oGLL = F.GLL[oset] + e * blk; o.oGUU = F.GUU[oset] + e * blk;
@@ -411,21 +448,26 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (!((k < 4 || q < 2) && k <= dj)) continue;
-                    if (colD < BD) o.nD[offD + (16 * k + 4 * q) * BD] = dt[k][q];
-                    else if (colD == BD) o.nr[g + 16 * k + 4 * q] = dt[k][q];
+                    if (colD < BD) {
+                        o.nD[offD + (16 * k + 4 * q) * BD] = dt[k][q];
+                        // (a pinned block of a partitioned chain in its final form: k_sep_pack copies the whole block)
+                        if (MODE == 1 && o.pinned && k < dj) o.nD[(size_t)colD * BD + 16 * k + 4 * q + g] = dt[k][q];
+                    } else if (colD == BD) o.nr[g + 16 * k + 4 * q] = dt[k][q];
                 }
             if (w == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o.nD[(4 * q + g) * BD + j] = d00[q];
             }
         }
-        if (HAS_R && MODE && o.sgn < 0.0) {
+        if (HAS_R && MODE) {        // couplings read from the Gram products carry a minus sign, kept ones and the level's own do not
 #pragma unroll
-            for (int q = 0; q < NRW; ++q)
+            for (int q = 0; q < NRW; ++q) {
+                const double sg = (16 * rcol[q] + j < BD) ? o.sgnL : o.sgnU;
 #pragma unroll
                 for (int k = 0; k < NDT; ++k)
 #pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = -rt[q][k][qq];
+                    for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] *= sg;
+            }
         }
 #pragma unroll
         for (int q = 0; q < NRW; ++q) {
@@ -437,7 +479,8 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
                     for (int qq = 0; qq < 4; ++qq) rt[q][k][qq] = 0.0;
             }
             const int col = 16 * rcol[q] + j;
-            if (o.saveU && rok[q] && col >= BD && rcol[q] < NRT) {
+            const bool saver = MODE != 2 || by == 0;       // (the workgroups of a fused step all hold every tile)
+            if (o.saveU && rok[q] && col >= BD && rcol[q] < NRT && saver) {
                 double *ps = o.saveU + g * BD + col - BD;
 #pragma unroll
                 for (int k = 0; k < NDT; ++k)
@@ -445,7 +488,16 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
                     for (int qq = 0; qq < 4; ++qq)
                         if (k < 4 || qq < 2) ps[(16 * k + 4 * qq) * BD] = rt[q][k][qq];
             }
+            if (MODE && o.saveL && rok[q] && col < BD && saver) {
+                double *ps = o.saveL + g * BD + col;
+#pragma unroll
+                for (int k = 0; k < NDT; ++k)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        if (k < 4 || qq < 2) ps[(16 * k + 4 * qq) * BD] = rt[q][k][qq];
+            }
         }
+        if (MODE && o.pinned) return;       // a pinned end of a partitioned chain: assembled (and its coupling tracked), never factored
     }
 
     // lane masks of the sub-step operands (all-ones / zero words): bit selects instead of branches
@@ -604,7 +656,7 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
             const bool mine = ROLE == 1 ? (w == 1 ? i < 6 : w == 2 ? i < 5 : w == 3 ? i < 4 : false) : true;
             const int u = by + m * ns;
             gram_tile(min(max(u, 0), 54), gkind[i], gti[i], gtj[i]);
-            ghave[i] = mine && u < 55 && (gkind[i] == 0 ? o.hasL : gkind[i] == 1 ? o.hasU : (o.hasL && o.hasU));
+            ghave[i] = mine && u < 55 && (gkind[i] == 0 ? o.gLL : gkind[i] == 1 ? o.gUU : o.gUL);
             gacc[i] = mf_d4{0.0, 0.0, 0.0, 0.0};
         }
     }
@@ -1390,6 +1442,11 @@ void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q, int which) {
 }
 void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve, int which) {
     const size_t sh_solve = (size_t)(BD * BD + 2 * BD) * sizeof(double);
+    const PcrPlan &P = which == 3 ? d.spcr : d.pcr;
+    if (P.pin0 || P.pin1) {     // a chain with pinned ends: its blocks keep their couplings to those (right-hand-side tiles), nothing is solved yet
+        LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 1>), dim3(xcd_grid(n, 1)), dim3(MF_THREADS), 0, d, steps, 1, which, n, 1, 0, NRT, 0);
+        return;
+    }
     LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<0, 1>), dim3(xcd_grid(n, 1)), dim3(MF_THREADS), solve ? sh_solve : 0, d, steps, 1, which, n, 1, 0, NRT, solve);
 }
 

@@ -128,6 +128,9 @@ struct PcrFused {
     double *Dpp[2], *rpp[2];                    // assembled D (upper tiles) and r of a step: n x BD x BD, n x BD
     double *GLL[2], *GUU[2], *GUL[2], *GULT[2]; // n x BD x BD each (GLL / GUU: upper tiles)
     double *gL[2], *gU[2];                      // YL^T yr, YU^T yr: n x BD
+    // chains with pinned ends (partitioned solve): a coupling that points at a pinned block is never folded again; the
+    // block that holds it saves it once (canonical orientation: rows of the block) and reads it back in every later step
+    double *Lkeep, *Ukeep;                      // n x BD x BD each, or null
 };
 
 struct Dev {

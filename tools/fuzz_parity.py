@@ -27,6 +27,41 @@ def horizon(log_a, log_b, n):
     return m
 
 
+#: bookkeeping of a sweep: comparison horizons per configuration class, and which side met a factorisation breakdown first
+SUMMARY = {"classes": {}, "breakdown_first": {"gpu": 0, "oracle": 0}}
+MIN_HORIZON = 4         # a case compared over fewer iterations counts as "uncompared", not as "ok"
+
+
+def record(cls, nall, ok):
+    c = SUMMARY["classes"].setdefault(cls, {"cases": 0, "uncompared": 0, "mismatch": 0, "horizons": []})
+    c["cases"] += 1
+    c["horizons"].append(int(nall))
+    if not ok:
+        c["mismatch"] += 1
+    elif nall < MIN_HORIZON:
+        c["uncompared"] += 1
+
+
+def print_summary():
+    """Per class: cases, mismatches, cases whose comparison horizon is below MIN_HORIZON (the oracle disagrees with itself
+    that early: nothing was compared beyond the first iterations -- reported, not counted as agreement), median horizon.
+    Returns non-zero when a class is mostly uncompared or when factorisation breakdowns only ever hit the GPU side first."""
+    rc = 0
+    print("class                      cases  mismatches  uncompared(<%d it)  median horizon" % MIN_HORIZON)
+    for cls, c in sorted(SUMMARY["classes"].items()):
+        med = int(np.median(c["horizons"])) if c["horizons"] else 0
+        print(f"{cls:26s} {c['cases']:5d} {c['mismatch']:11d} {c['uncompared']:18d} {med:15d}")
+        if c["cases"] >= 8 and c["uncompared"] > c["cases"] // 2:
+            print(f"  -> class '{cls}': more than half of the cases uncompared")
+            rc = 1
+    b = SUMMARY["breakdown_first"]
+    print(f"factorisation breakdown at a radius > 1e9, first on the GPU side: {b['gpu']}, first on the oracle side: {b['oracle']}")
+    if b["gpu"] >= 3 and b["oracle"] == 0:
+        print("  -> breakdowns only on the GPU side")
+        rc = 1
+    return rc
+
+
 def solver_breakdown(log_gpu, log_orc, n):
     """First iteration at which exactly one side reports an INVALID step (no step at all: step_norm = 0, cost_change = 0,
     unsuccessful -- the factorisation of the reduced system met a non-positive pivot).  With trust-region radii of 1e10 and more
@@ -38,6 +73,7 @@ def solver_breakdown(log_gpu, log_orc, n):
         bad = [int(lg["step_is_successful"][i]) == 0 and float(lg["step_norm"][i]) == 0.0 and float(lg["cost_change"][i]) == 0.0
                and float(lg["trust_region_radius"][i]) > 1e9 for lg in (log_gpu, log_orc)]
         if bad[0] != bad[1]:
+            SUMMARY["breakdown_first"]["gpu" if bad[0] else "oracle"] += 1
             return i
     return m
 
@@ -92,6 +128,7 @@ def lighting_case(rng, c, P, L, T, seed):
     print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} lighting M={M} light={light_type} free={shared_free} bounds={int(bounds)} dogleg={dog:2d} "
           f"iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     ba.close()
+    record(f"lighting {'dogleg' if dog >= 0 else 'LM'}{' bounds' if bounds else ''}", nall, ok)
     return 0 if ok else 1
 
 
@@ -142,9 +179,10 @@ def mid_size(cases, seed0):
         print(f"mid {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} closure={closure} const={int(pose_const.sum()):2d} "
               f"general={int(ba.stats().general_structure)} sb={int(ba.stats().num_superblocks)} iters={int(s.num_iterations):2d}/{int(s2.num_iterations):2d} "
               f"horizon={nall:2d} trace={trace:.1e} dpose={dpose:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+        record(f"mid {'general' if int(ba.stats().general_structure) == 1 else 'border' if int(ba.stats().general_structure) == 2 else 'windowed'}", nall, ok)
         ba.close()
     print("mismatches:", bad)
-    return 1 if bad else 0
+    return 1 if (bad or print_summary()) else 0
 
 
 def main():
@@ -203,9 +241,10 @@ def main():
         print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} dogleg={dog:2d} const={int(pose_const.sum()):2d} "
               f"general={int(ba.stats().general_structure)} iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} "
               f"{'ok' if ok else 'MISMATCH'}", flush=True)
+        record(f"stereo {'dogleg' if dog >= 0 else 'LM'}", nall, ok)
         ba.close()
     print("mismatches:", bad)
-    return 1 if bad else 0
+    return 1 if (bad or print_summary()) else 0
 
 
 if __name__ == "__main__":
