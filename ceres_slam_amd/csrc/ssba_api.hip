@@ -955,9 +955,15 @@ int ssba_finalize(ssba_problem *p) {
     }
     const int nborder = nfree - nchain;
     if (dense) {
-        if (p->world_size > 1 || nfree > 4096) {
-            set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system, "
-                      "which is limited to single-GPU problems with <= 4096 free poses in this build");
+        // the reduced system of the general path is stored as a dense lower triangle + right-hand-side rows; only its
+        // structurally non-zero tiles are ever touched (symbolic factorisation below), so its size is bounded by memory,
+        // not by time: SSBA_DENSE_MAX_GB (default 160 of the 288 GB of an MI355X; 10 000 free poses = 28.8 GB)
+        const double dn_gb = (double)(6.0 * nfree + 2 * DN_BS) * (6.0 * nfree + DN_BS) * 8.0 / 1e9;
+        const char *mg = getenv("SSBA_DENSE_MAX_GB");
+        const double dn_cap = mg ? atof(mg) : 160.0;
+        if (p->world_size > 1 || dn_gb > dn_cap || (6 * (long)nfree + DN_BS) / DN_BS >= 65535) {
+            set_error("problem structure (tracks > SSBA_MAX_TRACK or co-visibility span > 12 poses) needs the dense reduced system: "
+                      "single GPU only, and its array must fit SSBA_DENSE_MAX_GB (default 160)");
             return SSBA_ERR_UNSUPPORTED;
         }
         std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) { return a.j < b.j; });
@@ -1022,7 +1028,7 @@ int ssba_finalize(ssba_problem *p) {
     // general path: landmark-major observation arrays + the pose-major index list into them
     std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs, dn_zpos;
     std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
-    std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b, dn_pose_mat_start;
+    std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b, dn_pose_mat_start, dn_ztile;
     DensePlan dplan;
     if (dense) {
         dn_lm_start.assign(Lpad + 1, 0);
@@ -1132,6 +1138,12 @@ int ssba_finalize(ssba_problem *p) {
             dplan.col_start.push_back((uint32_t)dplan.cols.size());
         }
         dplan.nbk = nbk;
+        // every tile the factorisation touches: the diagonal and the non-zero block rows of each block column (the
+        // right-hand-side block row nbk among them)
+        for (int j = 0; j < nbk; ++j) {
+            dn_ztile.push_back(((uint32_t)j << 16) | (uint32_t)j);
+            for (uint32_t x = dplan.row_start[j]; x < dplan.row_start[j + 1]; ++x) dn_ztile.push_back((dplan.rows[x] << 16) | (uint32_t)j);
+        }
     }
     // ELL slots and the pose-major reference list (landmark*16 + slot) in one pass: a landmark's poses and its window's
     // pose list are both ascending (one merge per landmark), and landmarks are visited in device order, so counting
@@ -1578,6 +1590,8 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.dn_rows, dplan.rows)); TRY(dupload(p, &d.dn_ti, dplan.ti)); TRY(dupload(p, &d.dn_tk, dplan.tk));
         TRY(dupload(p, &d.dn_cols, dplan.cols));
         TRY(dupload(p, &d.dn_row_start, dplan.row_start));
+        TRY(dupload(p, &d.dn_ztile, dn_ztile));
+        d.dn_nztile = (int)dn_ztile.size();
         p->launcher.dense = dplan;
         TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));

@@ -567,6 +567,18 @@ __global__ __launch_bounds__(256) void k_dn_border_rows(Dev d, int store) {
     }
 }
 
+// zero-fill of the structurally non-zero tiles (the factorisation works in place, so they hold the last factor); every
+// other tile of the dense array is never written and keeps the zeros it was allocated with
+__global__ __launch_bounds__(256) void k_dn_zero_tiles(Dev d) {
+    const uint32_t t = d.dn_ztile[blockIdx.x];
+    const size_t lda = (size_t)d.dn_pad;
+    double *T = d.dn_S + ((size_t)(t >> 16) * DN_BS) * lda + (size_t)(t & 0xFFFFu) * DN_BS;
+    for (int i = threadIdx.x; i < DN_BS * DN_BS / 2; i += 256) {
+        const int row = i / (DN_BS / 2), c2 = i - row * (DN_BS / 2);
+        *reinterpret_cast<double2 *>(T + (size_t)row * lda + 2 * c2) = make_double2(0.0, 0.0);
+    }
+}
+
 // ----------------------------------------------------------------- launchers ---
 constexpr size_t DN_SYRK_LDS = (size_t)2 * DN_BS * DN_LS * sizeof(double);                       // 69 632 B
 constexpr size_t DN_TRSM_LDS = (size_t)(2 * DN_BS * DN_LS + DN_BS * 20) * sizeof(double);       // 79 872 B
@@ -575,7 +587,7 @@ int configure_dense() {
     return hipFuncSetAttribute((const void *)k_dn_trsm_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_TRSM_LDS) == hipSuccess ? 0 : -1;
 }
 void launch_dense_schur(Launcher &L, const Dev &d) {
-    if (d.dn_pad > 0) hipMemsetAsync(d.dn_S, 0, (size_t)(d.dn_pad + DN_BS) * d.dn_pad * sizeof(double), L.stream);
+    LAUNCH(KC_SMALL, k_dn_zero_tiles, dim3(d.dn_nztile), dim3(256), 0, d);
     if (d.phong) {       // 6-D landmark blocks: C^-1 first, W / Y are 6x6 (ssba_phong_solver.hip)
         launch_ph_dense_wy(L, d);
         LAUNCH(KC_SCHUR, (k_dn_schur<6, 64, 2>), dim3(d.dn_nblk), dim3(64), 0, d);

@@ -257,6 +257,8 @@ struct Dev {
     // block-level (DN_BS) symbolic factorisation: non-zero block rows below the diagonal of every block column
     // (the rhs row last), the tile pairs of every trailing update, and the non-zero block columns of every block row
     const uint32_t *dn_rows, *dn_ti, *dn_tk, *dn_cols, *dn_row_start;
+    const uint32_t *dn_ztile;                       // the structurally non-zero DN_BS tiles of the factor (row << 16 | column), right-hand-side row included:
+    int dn_nztile;                                  // what an iteration zero-fills instead of the whole dense array
     double *dn_S;                                   // (dn_pad + DN_BS) x dn_pad, row-major, lower triangle; row dn_pad holds the
                                                     // right-hand side, so the factorisation leaves L^-1 rhs there
 };

@@ -55,6 +55,20 @@ def test_c5_shape_full_size_huber_outliers_matches_cpu_oracle():
     _compare(s, log, s2, log2, ba, op)
 
 
+def test_general_path_beyond_4096_poses_matches_cpu_oracle():
+    """Long tracks (the general-structure path, ssba_dense.hip) on 5 000 poses: the dense array of the reduced system
+    (7 GB) is bounded by memory, not by a pose count -- an iteration zero-fills and factors only its structurally
+    non-zero tiles (r02 stopped at 4 096 free poses)."""
+    K = 5
+    prob = synth.make_problem(5000, 40000, track_len=16, seed=31)
+    ba = StereoBA.from_synth(prob)
+    assert ba.stats().general_structure == 1 and ba.stats().num_free_poses == 4999
+    s, log = ba.solve(capi.default_options(max_num_iterations=K, use_nonmonotonic_steps=1))
+    op = orc.OracleProblem.from_synth(prob)
+    s2, log2 = op.solve(orc.driver_options(num_threads=16, max_num_iterations=K))
+    _compare(s, log, s2, log2, ba, op)
+
+
 def test_c4_full_size_single_gpu_and_four_rank_partitioned(tmp_path):
     """configs[3]: 10 000 poses / 1 000 000 landmarks / 12 M observations.  (i) one GPU against the oracle's first
     iterations; (ii) the landmarks sharded over four ranks (all on the one device here, gloo exchange) with the
