@@ -944,7 +944,12 @@ __global__ __launch_bounds__(MODE == 2 ? MF_THREADS2 : MF_THREADS) void k_bcr_fa
     __shared__ FactorLds S;
     extern __shared__ __align__(16) double mf_dyn_lds[];
 #ifdef SSBA_STAMPS
-    if (threadIdx.x == 0) d.dbg[4096 + 8 * (int)blockIdx.x] = wall_clock64();       // entry of the workgroup on the chip-wide 100 MHz clock
+    if (threadIdx.x == 0 && blockIdx.x < 500) {
+        d.dbg[4096 + 8 * (int)blockIdx.x] = wall_clock64();       // entry of the workgroup on the chip-wide 100 MHz clock
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        d.dbg[4096 + 8 * (int)blockIdx.x + 5] = 1000 + (xcc & 0xf);      // the XCD it runs on
+    }
 #endif
     if (MODE == 2) {
         if (threadIdx.x < MF_THREADS) factor_body<0, 2, 1>(d, S, mf_dyn_lds, lev, top, which, nblocks, ns, rlo, nrt, solve);

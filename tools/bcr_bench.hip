@@ -310,8 +310,21 @@ int main(int argc, char **argv) {
             CHK(hipMemset(d.dbg, 0, 8192 * 8));
             launch_pcr_fused_step(L, d, n, 3);
             CHK(hipStreamSynchronize(L.stream));
-            std::vector<unsigned long long> stp(8192);
+            std::vector<unsigned long long> stp(8192), stq(8192);
             CHK(hipMemcpy(stp.data(), d.dbg, 8192 * 8, hipMemcpyDeviceToHost));
+            {   // is the workgroup -> XCD placement the same from launch to launch?  (slot 5 of the per-workgroup stamps)
+                launch_pcr_fused_step(L, d, n, 4);
+                CHK(hipStreamSynchronize(L.stream));
+                CHK(hipMemcpy(stq.data(), d.dbg, 8192 * 8, hipMemcpyDeviceToHost));
+                const int nwg = n * (n <= 85 ? 3 : 2);
+                int same = 0, rr = 0;
+                for (int g = 0; g < nwg; ++g) {
+                    same += stp[4096 + 8 * g + 5] == stq[4096 + 8 * g + 5];
+                    rr += (int)(stp[4096 + 8 * g + 5] - 1000) == ((int)(stp[4096 + 5] - 1000) + g) % 8;
+                }
+                printf("XCD placement: %d of %d workgroups on the same XCD in two consecutive launches; %d of %d follow (xcd of workgroup 0 + id) %% 8; "
+                       "workgroup 0 on XCD %d then %d\n", same, nwg, rr, nwg, (int)(stp[4096 + 5] - 1000), (int)(stq[4096 + 5] - 1000));
+            }
             {
                 const int nwg = n * (n <= 85 ? 3 : n <= 128 ? 2 : 1);
                 unsigned long long lo = ~0ull;
