@@ -287,8 +287,10 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
  *                             kd in [0,1], alpha >= 1); +-INFINITY = no bound.  With a bound on a free
  *                             block the problem is constrained and the minimiser does what Ceres 1.x
  *                             does: Plus projects onto the box and every trust-region step goes through
- *                             a projected Armijo line search (host-driven, one synchronisation per
- *                             evaluation; such solves are not captured in a hipGraph).
+ *                             a projected Armijo line search.  The test of the full step runs on the device
+ *                             (the iteration is one hipGraph); a step that has to be shortened parks the solver
+ *                             until the host -- inside ssba_solve / ssba_solve_step / ssba_solve_end -- has driven
+ *                             the search (one synchronisation per evaluation).
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
  * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  ssba_set_huber_loss keeps its meaning
  * (the loss sits on the stereo residual blocks; lighting blocks take a NULL loss, :113,186).  Lighting
