@@ -1440,9 +1440,7 @@ void launch_bcr_factor_mf(Launcher &L, const Dev &d, int nblocks, int lev, int t
 // the Gram tiles.  The decoupled last step assembles its blocks the same way, solves them and (solve = 2) updates the poses.
 constexpr size_t FUSED_LDS = (size_t)2 * BD * 80 * sizeof(double);
 void launch_pcr_fused_step(Launcher &L, const Dev &d, int n, int q, int which) {
-    int ns = n <= 85 ? 3 : 2;         // (a plan has at most PCR_MAX_BLOCKS = 128 blocks; the kernel's tile share assumes ns >= 2)
-    static const int ns_env = [] { const char *e = getenv("SSBA_FUSED_NS"); return e ? atoi(e) : 0; }();      // 2 or 3: experiments
-    if (ns_env == 2 || (ns_env == 3 && n <= 85)) ns = ns_env;
+    const int ns = n <= 85 ? 3 : 2;         // (a plan has at most PCR_MAX_BLOCKS = 128 blocks; the kernel's tile share assumes ns >= 2; 2 at C2: 0.372 against 0.364 ms)
     LAUNCH(KC_BCR_FACTOR, (k_bcr_factor_mf<3, 2>), dim3(xcd_grid(n, ns)), dim3(MF_THREADS2), FUSED_LDS, d, q, 0, which, n, ns, 0, NRT, 0);
 }
 void launch_pcr_fused_top(Launcher &L, const Dev &d, int n, int steps, int solve, int which) {

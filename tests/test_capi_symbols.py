@@ -69,3 +69,13 @@ def test_brief_report_format():
 def test_reference_style_cpp_driver_compiles_against_the_shim():
     exe = build.build_examples()
     assert os.path.exists(exe)
+
+
+def test_rccl_describe_names_the_library_without_a_gpu():
+    """ssba_rccl_describe: which librccl.so file the process would use, its version and the IPC / debug environment -- the
+    text a set-up time-out carries (include/ssba.h); loading the library needs no device."""
+    from ceres_slam_amd.solver import StereoBA
+    text = StereoBA.rccl_describe()
+    assert text.startswith("librccl: ") and "HSA_ENABLE_IPC_MODE_LEGACY=" in text
+    if "(not loaded)" not in text:
+        assert "version" in text and "librccl" in text.split(";")[0]

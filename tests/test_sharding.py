@@ -302,3 +302,33 @@ def test_bench_two_rank_rehearsal_on_one_device():
     assert b["config"]["exchange"] == "torch.distributed (gloo)" and b["config"]["rccl_ranks"] == 0
     assert b["value"] == pytest.approx(2 * b["config"]["joint_iters_per_sec"])
     assert b["ms_per_step"] > 0
+
+
+_RCCL_TIMEOUT = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+from ceres_slam_amd import capi
+from ceres_slam_amd.solver import StereoBA
+print("DESCRIBE", StereoBA.rccl_describe())
+try:
+    StereoBA.rccl_unique_id()
+    print("RESULT no timeout")
+except capi.SsbaError as e:
+    print("RESULT", e.status, str(e))
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_set_up_time_limit_leaves_a_record():
+    """SSBA_RCCL_TIMEOUT_S: with a limit no RCCL call can meet (100 microseconds) ssba_rccl_unique_id must come back with
+    SSBA_ERR_TIMEOUT and say which call it was waiting for and which librccl.so the process uses -- the record a real
+    set-up hang would leave (the helper thread finishes in the background; the child process ends before it matters)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSBA_RCCL_TIMEOUT_S="0.0001")
+    r = subprocess.run([sys.executable, "-c", _RCCL_TIMEOUT, root], capture_output=True, text=True, timeout=240, env=env)
+    out = r.stdout
+    assert "DESCRIBE librccl: " in out and "version" in out, out + r.stderr[-2000:]
+    line = [ln for ln in out.splitlines() if ln.startswith("RESULT")][0]
+    assert "-8" in line and "SSBA_ERR_TIMEOUT" in line, line
+    assert "ncclGetUniqueId did not return within" in line and "librccl: /" in line and "HSA_ENABLE_IPC_MODE_LEGACY=" in line, line
