@@ -53,6 +53,7 @@ struct ssba_problem {
     std::vector<double> obs_uvd;
     double S[9] = {0};
     bool have_S = false, per_obs_S = false, points_const = false;
+    bool no_closure_border = false;     // a caller asked for something the closure border does not cover (DOGLEG, covariance): general path
     std::vector<double> obs_S;          // 9 per observation once two stereo blocks differ in stiffness
     std::vector<uint8_t> pose_const;
     double huber_a = 0.0;
@@ -914,7 +915,7 @@ int ssba_finalize(ssba_problem *p) {
     int nchain = nfree;
     if (span_violation && !dense) {
         const char *e = getenv("SSBA_NO_CLOSURE_BORDER");
-        bool ok = !(e && e[0] == '1') && !ph && p->world_size == 1 && !p->per_obs_S && p->rel_factors.empty() && pfs.empty();
+        bool ok = !(e && e[0] == '1') && !p->no_closure_border && !ph && p->world_size == 1 && !p->per_obs_S && p->rel_factors.empty() && pfs.empty();
         std::vector<uint8_t> is_border(nfree, 0);
         int nborder = 0;
         for (size_t q = 0; q < wide.size() && ok; ++q) {
@@ -1964,6 +1965,16 @@ static int reset_solver(ssba_problem *p) {
     return SSBA_OK;
 }
 
+// The closure border (loop closures as a dense border of the block-tridiagonal system, LM only) does not cover everything
+// the general-structure path does.  A caller that asks for one of those things on a handle that was finalized with a
+// border gets the other layout: ssba_finalize runs again from the host-side problem graph the handle still holds.
+static int refinalize_without_closure_border(ssba_problem *p) {
+    if (p->began) return SSBA_ERR_STATE;
+    p->no_closure_border = true;
+    p->finalized = false;
+    return ssba_finalize(p);
+}
+
 int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence) {
     ApiTimer api_timer("ssba_solve_begin");
     if (!p || !o) return SSBA_ERR_INVALID_ARGUMENT;
@@ -1977,8 +1988,10 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     }
     if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
     if (o->trust_region_strategy_type == 1 && p->d.cb) {
-        set_error("DOGLEG is not available with a closure border yet; SSBA_NO_CLOSURE_BORDER=1 at ssba_finalize selects the general path");
-        return SSBA_ERR_UNSUPPORTED;
+        // DOGLEG is not implemented on the closure border: the symbolic phase runs again and puts the problem on the
+        // general-structure path, which has it (once per handle; the caller's blocks and pointers are unchanged)
+        int rc = refinalize_without_closure_border(p);
+        if (rc) return rc;
     }
     if (p->d.phong && p->xfn && p->d.nb && (p->d.constrained || p->d.dense)) {
         set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
@@ -2462,9 +2475,12 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     ApiTimer api_timer("ssba_pose_covariance");
     if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
+    if (p->d.cb && !p->began) {      // the closure border has no covariance sweep: the general path has (symbolic phase again, once)
+        int rc = refinalize_without_closure_border(p);
+        if (rc) return rc;
+    }
     if (p->d.part || p->d.phong || p->d.cb) {
-        set_error("covariance: not available on partitioned problems, with lighting terms or with a closure border "
-                  "(SSBA_NO_CLOSURE_BORDER=1 at ssba_finalize selects the general path)");
+        set_error("covariance: not available on partitioned problems or with lighting terms");
         return SSBA_ERR_UNSUPPORTED;
     }
     const int f = p->pose_free[pose];

@@ -38,7 +38,9 @@ extern "C" {
  * with co-observing free poses more than 12 apart, run the general-structure kernels (ssba_stats.general_structure = 1)
  * -- except a loop closure whose far side is at most 5 states and whose landmarks keep <= 12 observations: those
  * states become a border of the block-tridiagonal reduced system and the windowed kernels stay (general_structure = 2;
- * any number of poses, LM only; SSBA_NO_CLOSURE_BORDER=1 in the environment of ssba_finalize selects the general path) */
+ * any number of poses).  The border covers Levenberg-Marquardt solves; a DOGLEG solve or ssba_pose_covariance on such a
+ * handle runs the symbolic phase again and continues on the general path (general_structure becomes 1);
+ * SSBA_NO_CLOSURE_BORDER=1 in the environment of ssba_finalize selects the general path from the start */
 #define SSBA_MAX_TRACK 12
 
 typedef struct ssba_problem ssba_problem;

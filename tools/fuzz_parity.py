@@ -2,6 +2,10 @@
 constant poses, Huber loss, trust-region strategy; every fourth case with lighting terms (point / directional light,
 1-5 materials, shared blocks constant or free, with or without bounds) -- solved by the HIP path and by the CPU oracle;
 compares the cost trace, the accept / reject sequence and the final cost.
+Per case: the verdict comes from the strict criterion over the horizon on which the oracle agrees with itself to 1e-9
+(decisions equal, cost trace 1e-6 / 1e-4 with lighting terms, end point 1e-6); beside it a conditioned count says over how
+many iterations the HIP run stays within the oracle's own sensitivity (conditioned_agreement).  The summary counts a case
+as uncompared when the longer of the two has fewer than MIN_HORIZON iterations.
 usage: python tools/fuzz_parity.py [cases] [seed]  |  python tools/fuzz_parity.py mid [cases] [seed]  (mid_size below)"""
 import os
 import sys
@@ -25,6 +29,37 @@ def horizon(log_a, log_b, n):
         if (log_a["step_is_successful"][i] or i == 0) and abs(log_a["cost"][i] - log_b["cost"][i]) > 1e-9 * abs(log_b["cost"][i]):
             return max(i, 1)
     return m
+
+
+def conditioned_agreement(log, ref, probes, nmax, amp=30.0, spread_max=1e-5):
+    """Comparison relative to the problem's own conditioning.  `probes` are re-runs of the ORACLE that differ from `ref` by
+    something a correct implementation may differ by (summation order: another thread count; an input perturbation of
+    1e-14).  Where all oracle runs take the same accept / reject decisions and their accepted-iterate costs stay within
+    `spread_max` of each other, the HIP run must take the same decisions and stay within amp x that spread (floor 1e-9) of
+    `ref`; the count stops at the first iteration where it does not (the HIP path's rounding differs from the oracle's by
+    more than a thread count does, so past the strict horizon this is a measure, not a verdict).  (SUBSPACE_DOGLEG on lighting problems amplifies 1e-14 to ~1e-8 in its FIRST iteration -- the Gauss-Newton
+    solve with mu = 1e-8 -- and keeps that level: the strict 1e-9 horizon ends at iteration 1 there although the runs
+    agree to 1e-8 over the whole solve.)  Returns (iterations in agreement, worst deviation / allowance over them)."""
+    m = min([nmax, len(log["cost"]), len(ref["cost"])] + [len(p["cost"]) for p in probes])
+    worst, n = 0.0, 0
+    for i in range(m):
+        flags = {int(p["step_is_successful"][i]) for p in probes} | {int(ref["step_is_successful"][i])}
+        if len(flags) > 1:
+            break
+        c = float(ref["cost"][i])
+        spread = max([abs(float(p["cost"][i]) - c) / abs(c) for p in probes] + [0.0])
+        accepted = bool(ref["step_is_successful"][i]) or i == 0
+        if accepted and spread > spread_max:
+            break
+        if int(log["step_is_successful"][i]) != int(ref["step_is_successful"][i]):
+            break
+        if accepted:
+            ratio = abs(float(log["cost"][i]) - c) / abs(c) / max(1e-8, amp * spread)
+            if ratio > 1.0:
+                break
+            worst = max(worst, ratio)
+        n = i + 1
+    return n, worst
 
 
 #: bookkeeping of a sweep: comparison horizons per configuration class, and which side met a factorisation breakdown first
@@ -121,14 +156,16 @@ def lighting_case(rng, c, P, L, T, seed):
     fin = abs(log["cost"][:nall].min() - log2["cost"][:nall].min()) / abs(log2["cost"][:nall].min())
     # the lighting model clamps the colour to [0, 1] (phong.hpp:33, utils.hpp:16-25): a far-off trial step can sit on a
     # clamp, where the last bits decide a finite jump of the cost -- the traces may part by ~1e-5 there and meet again
+    n2, worst2 = conditioned_agreement(log, log2, [log_b, log_c], min(len(log["cost"]), len(log2["cost"])))
     ok = acc_ok and trace < 1e-4 and fin < 1e-6
     if os.environ.get("FUZZ_ONLY") is not None:
         for i in range(min(len(log["cost"]), len(log2["cost"]))):
             print(f"   it {i}: hip {log['cost'][i]:.12e} {int(log['step_is_successful'][i])}  oracle {log2['cost'][i]:.12e} {int(log2['step_is_successful'][i])}  oracle(1 thr) {log_b['cost'][i]:.12e}  oracle(perturbed) {log_c['cost'][i] if i < len(log_c['cost']) else float('nan'):.12e}")
     print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} lighting M={M} light={light_type} free={shared_free} bounds={int(bounds)} dogleg={dog:2d} "
-          f"iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} "
+          f"conditioned: {n2:3d} it, {worst2:.2f} of the allowance {'ok' if ok else 'MISMATCH'}", flush=True)
     ba.close()
-    record(f"lighting {'dogleg' if dog >= 0 else 'LM'}{' bounds' if bounds else ''}", nall, ok)
+    record(f"lighting {'dogleg' if dog >= 0 else 'LM'}{' bounds' if bounds else ''}", max(nall, n2), ok)
     return 0 if ok else 1
 
 
@@ -236,12 +273,13 @@ def main():
         # end points at a fixed iteration count: the best cost over the iterations both runs have (a converged run's stop
         # iteration is rounding-sensitive in a flat tail; its path is not)
         fin = abs(log["cost"][:nall].min() - log2["cost"][:nall].min()) / abs(log2["cost"][:nall].min())
+        n2, worst2 = conditioned_agreement(log, log2, [log_b], min(len(log["cost"]), len(log2["cost"])))
         ok = acc_ok and trace < 1e-6 and fin < 1e-6
         bad += not ok
         print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} dogleg={dog:2d} const={int(pose_const.sum()):2d} "
               f"general={int(ba.stats().general_structure)} iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} "
-              f"{'ok' if ok else 'MISMATCH'}", flush=True)
-        record(f"stereo {'dogleg' if dog >= 0 else 'LM'}", nall, ok)
+              f"conditioned: {n2:3d} it, {worst2:.2f} of the allowance {'ok' if ok else 'MISMATCH'}", flush=True)
+        record(f"stereo {'dogleg' if dog >= 0 else 'LM'}", max(nall, n2), ok)
         ba.close()
     print("mismatches:", bad)
     return 1 if (bad or print_summary()) else 0
