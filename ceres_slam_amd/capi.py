@@ -64,7 +64,9 @@ class Summary(C.Structure):
     _fields_ = [("termination_type", C.c_int32), ("num_iterations", C.c_int32),
                 ("num_successful_steps", C.c_int32), ("num_unsuccessful_steps", C.c_int32),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double),
-                ("total_time_s", C.c_double), ("device_time_s", C.c_double)]
+                ("total_time_s", C.c_double), ("device_time_s", C.c_double),
+                ("num_line_search_steps", C.c_int32), ("num_line_searches_on_device", C.c_int32),
+                ("num_line_searches_by_host", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class KernelTime(C.Structure):

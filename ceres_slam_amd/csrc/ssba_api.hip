@@ -77,7 +77,7 @@ struct ssba_problem {
     struct RelFactor { uint32_t pose1, pose2; double T_ref[12], S[36], huber; };
     std::vector<RelFactor> rel_factors;
     double *h_ls = nullptr;                // pinned: line-search scalars + state
-    int num_line_search_steps = 0;
+    int num_line_search_steps = 0, num_line_searches_by_host = 0;      // evaluations / searches driven by the host (the device counts its own in the state)
     std::vector<double> ph_intensity, ph_nobs;
     double ph_int_stiff = 0.0, ph_Sn[9] = {0};
     bool lighting() const { return !ph_intensity.empty(); }
@@ -1388,7 +1388,7 @@ int ssba_finalize(ssba_problem *p) {
             TRY(dzero(p, &d.part_g, (size_t)d.n_gram * (NBP * NBP + NBP)));
         }
         TRY(dzero(p, &d.part_ls, (size_t)(Lpad / 256) * NLS));
-        TRY(dzero(p, &d.ls_out, (size_t)NLS_OUT));
+        TRY(dzero(p, &d.ls_out, (size_t)NLS_OUT + NLS_MACH));
     }
     TRY(dzero(p, &d.hpp, (size_t)P * 21)); TRY(dzero(p, &d.gp, (size_t)P * 6));
     TRY(dzero(p, &d.sp, (size_t)d.nf_pad * 6));
@@ -1865,7 +1865,8 @@ static int finish_pending_search(ssba_problem *p) {
         return SSBA_OK;
     };
     launch_ls_resume(L, d);                 // the evaluation kernels test `terminated`
-    launch_ph_ls_probe(L, d, -1.0, 0);      // the full step again, with phi'(1) this time (the candidate of the update kernels is that trial point)
+    launch_ph_ls_probe(L, d, 1.0, 1);       // the full step again, with phi'(1) this time (rounds of the device-side search may have moved the candidate)
+    ++p->num_line_searches_by_host;
     if ((rc = fetch())) return rc;
     if (!p->h_state->terminated && p->h_ls[6] != 0.0) {
         Armijo a;
@@ -1999,6 +2000,13 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     }
     if (p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
         drop_graph(p);   // other kernel sequence: every captured graph (single iteration, batch, segments) goes
+    if (p->d.constrained) {
+        // bounds: evaluations of the projected line search enqueued with every iteration (device-side search); a search
+        // that needs more is finished by the host.  SSBA_LS_ROUNDS in the environment of a solve (0: host only -- A/B, tests)
+        int rounds = 3;
+        if (const char *e = getenv("SSBA_LS_ROUNDS")) rounds = std::min(20, std::max(0, atoi(e)));
+        if (rounds != p->d.ls_rounds) { p->d.ls_rounds = rounds; drop_graph(p); }
+    }
     HIPCHECK(hipSetDevice(p->device));
     p->opt = *o;
     p->ignore_convergence = ignore_convergence;
@@ -2008,7 +2016,7 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     int rc = ensure_log(p, cap);
     if (rc) return rc;
     p->t_begin = std::chrono::steady_clock::now();
-    p->num_line_search_steps = 0;
+    p->num_line_search_steps = p->num_line_searches_by_host = 0;
     rc = upload_params(p);
     if (rc) return rc;
     hipStream_t s = p->launcher.stream;
@@ -2163,6 +2171,9 @@ int ssba_solve_end(ssba_problem *p, ssba_summary *s) {
         s->num_iterations = n;
         s->num_successful_steps = S.num_successful;
         s->num_unsuccessful_steps = S.num_unsuccessful;
+        s->num_line_search_steps = S.ls_steps + p->num_line_search_steps;
+        s->num_line_searches_on_device = S.ls_searches;
+        s->num_line_searches_by_host = p->num_line_searches_by_host;
         s->initial_cost = S.initial_cost;
         // solver.cc SetSummaryFinalCost: minimum over the recorded iteration costs
         double fc = S.initial_cost;

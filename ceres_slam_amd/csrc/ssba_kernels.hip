@@ -762,7 +762,8 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
 
 // candidate poses = Plus(x, delta_p)  [Evaluator::Plus with SE3Perturbation]
 // fuse_best: also does k_best's share for the poses (x -> best when the k_check of this iteration saw the cost improve;
-// like k_best, before the termination test -- the improving iterate may be the converged one)
+// like k_best, before the termination test -- the improving iterate may be the converged one); -1: the trial point of a
+// device-side line-search round (bounds), a no-op unless a search is under way
 __global__ __launch_bounds__(256) void k_pose_update(Dev d, int fuse_best) {
     const State &st = *d.st;
     __shared__ double sm[4];
@@ -775,11 +776,11 @@ __global__ __launch_bounds__(256) void k_pose_update(Dev d, int fuse_best) {
 #pragma unroll
         for (int c = 0; c < 12; ++c) Tk[c] = d.poses[(size_t)k * 12 + c];
     }
-    if (fuse_best && st.copy_best == st.check_count && k < d.P) {
+    if (fuse_best > 0 && st.copy_best == st.check_count && k < d.P) {
 #pragma unroll
         for (int c = 0; c < 12; ++c) d.best_poses[(size_t)k * 12 + c] = Tk[c];
     }
-    if (st.terminated) return;
+    if (st.terminated || (fuse_best < 0 && !st.ls_active)) return;       // fuse_best < 0: a round of the device-side line search
     double dn = 0.0, nonfinite = 0.0, pf_cc = 0.0, pf_mcc = 0.0;
     if (k < d.P) {
         const int f = fk;
@@ -1627,7 +1628,7 @@ __global__ void k_reset_state(Dev d, Options opt) {
     st.dl_reuse = 0; st.mu = 1e-8; st.alpha = 0.0; st.dl_step_norm = 0.0; st.grad_norm = 0.0; st.gn_norm = 0.0;
     st.g_dot_gn = 0.0; st.beta = 1.0; st.gamma = 0.0;
     st.ls_alpha = 1.0;
-    st.ls_pending = 0;
+    st.ls_pending = st.ls_active = st.ls_steps = st.ls_searches = 0;
     st.sub_one_dim = 0; st.sub_g[0] = st.sub_g[1] = 0.0; st.sub_B[0] = st.sub_B[1] = st.sub_B[2] = 0.0;
     st.sub_e[0][0] = st.sub_e[0][1] = st.sub_e[1][0] = st.sub_e[1][1] = 0.0;
 }
@@ -1864,8 +1865,8 @@ void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses) {
     LAUNCH(KC_SMALL, k_mask_unowned_poses, dim3((d.P + 255) / 256), dim3(256), 0, d, poses);
 }
 
-void launch_pose_update(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, 0);
+void launch_pose_update(Launcher &L, const Dev &d, int ls_round) {
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, ls_round ? -1 : 0);
 }
 
 void launch_dogleg_eval(Launcher &L, const Dev &d) {

@@ -138,10 +138,10 @@ void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur = false);
 void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best = 0);
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d);
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d);
-void launch_pose_update(Launcher &L, const Dev &d);
+void launch_pose_update(Launcher &L, const Dev &d, int ls_round = 0);
 void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved);
 void launch_ph_ls_accept(Launcher &L, const Dev &d);
-void launch_ph_ls_fast(Launcher &L, const Dev &d);          // bounds: the Armijo test of the full step on the device (parks the solver when it fails)
+void launch_ph_ls_fast(Launcher &L, const Dev &d);          // bounds: the Armijo test of the full step on the device, then d.ls_rounds blindly enqueued rounds of the search (no-ops unless the test failed); what they cannot finish parks the solver for the host
 void launch_ls_resume(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();

@@ -19,6 +19,7 @@
 
 #include "ssba_device.h"
 #include "ssba_launch.h"
+#include "ssba_linesearch.h"
 #include "ssba_phong_device.h"
 #include "ssba_types.h"
 #include "ssba_check.h"
@@ -1143,9 +1144,9 @@ template <bool DN> __global__ __launch_bounds__(BP_THREADS) void k_ph_border_pos
 
 // candidate shared blocks = Plus(x_b, delta_b): Euclidean, UnitVectorPerturbation on a directional
 // light (dataset_ba_phong.cpp:201-204); its |dx|^2 and non-finite flag join the pose partials
-__global__ void k_ph_border_update(Dev d) {
+__global__ void k_ph_border_update(Dev d, int ls_round) {
     const State &st = *d.st;
-    if (st.terminated || threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (st.terminated || threadIdx.x != 0 || blockIdx.x != 0 || (ls_round && !st.ls_active)) return;
     double dn = 0.0, bad = 0.0;
     for (int i = 0; i < d.nsh; ++i) d.cand_sh[i] = d.sh[i];
     if (!st.step_failed && d.nb) {
@@ -1381,16 +1382,17 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_eval(De
 // ------------------------------------------------------------------ projected line search ---
 // [Ceres 1.x TrustRegionMinimizer::DoLineSearch] phi(a) = cost(Plus(x, a * delta)) and
 // phi'(a) = delta . gradient(Plus(x, a * delta)) = sum_obs r . (J delta), r and J evaluated at the
-// trial point; the scalar Armijo logic runs on the host (ssba_linesearch.h).
+// trial point; the scalar Armijo logic (ssba_linesearch.h) runs in k_ph_ls_reduce for the rounds enqueued with the
+// iteration, and on the host for what those cannot finish.
 __global__ void k_ls_set_alpha(Dev d, double alpha) {
     if (threadIdx.x == 0 && blockIdx.x == 0) d.st->ls_alpha = alpha;
 }
 
 // per landmark: trial point for st.ls_alpha (candidate poses / shared blocks are already in place),
 // its cost, phi', |dx_l|^2, and the alpha-independent max|delta_l| and g_l . delta_l
-template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_ls_probe(Dev d) {
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_ls_probe(Dev d, int ls_round) {
     const State &st = *d.st;
-    if (st.terminated) return;
+    if (st.terminated || (ls_round && !st.ls_active)) return;
     __shared__ double sm[4];
     const int l = blockIdx.x * 256 + threadIdx.x;
     const uint32_t mask = d.lm_mask[l];
@@ -1475,6 +1477,12 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_ls_probe(Dev d
 // min_step_size test), k_ph_ls_fast adds the pose / border parts and decides.  A rejected full step parks the solver
 // (terminated with LS_PENDING) until the host has driven the search (ssba_api.hip: finish_pending_search) -- exactly the
 // evaluations Ceres makes, starting with phi'(1).
+__device__ inline void ls_park(State &st) {
+    st.ls_active = 0;
+    st.ls_pending = 1;
+    st.terminated = 1;
+    st.termination_type = LS_PENDING;
+}
 template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_dir(Dev d) {
     const State &st = *d.st;
     if (st.terminated) return;
@@ -1527,10 +1535,9 @@ __global__ __launch_bounds__(256) void k_ph_ls_fast(Dev d) {
     if (!valid) return;
     const double phi0 = st.x_cost, dphi0 = lgd + pgd + bgd, phi1 = d.scal2[0];
     const bool value_ok = isfinite(phi1);
-    if (value_ok && !(phi1 > phi0 + 1e-4 * dphi0 * 1.0)) return;       // the full step satisfies the Armijo condition: nothing to search
-    st.ls_pending = 1;
-    st.terminated = 1;
-    st.termination_type = LS_PENDING;
+    if (value_ok && !(phi1 > phi0 + 1e-4 * dphi0 * 1.0)) { st.ls_steps += 1; return; }       // the full step satisfies the Armijo condition: nothing to search (one evaluation in Ceres' count)
+    if (d.ls_rounds > 0) { st.ls_active = 1; return; }                // the search rounds behind this launch wake up
+    ls_park(st);
 }
 __global__ void k_ls_resume(Dev d) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1543,9 +1550,14 @@ __global__ void k_ls_resume(Dev d) {
 
 // one block: totals of the probe plus the pose / border parts of max|delta| and g . delta, and the
 // validity of the trust-region step (as k_decide will judge it)
-__global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d) {
-    const State &st = *d.st;
-    if (st.terminated) return;
+// ls_round: a round of the device-side search -- lane 0 then feeds the evaluation to the Armijo state machine: the search
+// ends (accepted sample: its sums replace the evaluation kernel's for k_decide, as k_ph_ls_accept does for the host), goes
+// on (st.ls_alpha = the next step: the following round evaluates it) or is handed to the host (`last` round and still not
+// done, or a failed search that would have to restore the full step: the host starts that search again from the top --
+// the evaluations are deterministic, it takes the same path)
+__global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d, int ls_round, int last) {
+    State &st = *d.st;
+    if (st.terminated || (ls_round && !st.ls_active)) return;
     __shared__ double sm[4];
     double acc[NLS] = {0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
@@ -1576,6 +1588,24 @@ __global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d) {
     // ComputeTrustRegionStep: valid iff the solve succeeded, the step is finite and model_cost_change > 0
     d.ls_out[6] = (!st.step_failed && (d.scal2[3] + qbad) == 0.0 && d.scal2[1] > 0.0) ? 1.0 : 0.0;
     d.ls_out[7] = st.x_cost;
+    if (!ls_round) return;
+    static_assert(sizeof(Armijo) <= NLS_MACH * sizeof(double), "the search state lives behind ls_out");
+    Armijo &a = *reinterpret_cast<Armijo *>(d.ls_out + NLS_OUT);
+    if (st.ls_active == 1) {
+        a.begin(st.x_cost, d.ls_out[5], d.ls_out[4]);
+        st.ls_active = 2;
+    }
+    a.feed(cost, dphi);
+    if (a.done && (a.success || st.ls_alpha == 1.0)) {
+        if (st.ls_alpha != 1.0) { d.scal2[0] = cost; d.scal2[2] = dn; d.scal2[3] = bad; }
+        st.ls_active = 0;
+        st.ls_steps += a.num_feeds;
+        st.ls_searches += 1;
+    } else if (a.done || last) {
+        ls_park(st);
+    } else {
+        st.ls_alpha = a.current.x;
+    }
 }
 
 // the accepted trial point becomes the candidate k_decide judges; the model cost change of the
@@ -1676,7 +1706,7 @@ void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur) {
     }
 }
 void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best) {
-    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
+    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
     LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_backsub_eval<true> : k_ph_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, fuse_best);
 }
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
@@ -1684,7 +1714,7 @@ void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
     LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_gn<true> : k_ph_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {
-    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
+    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
     LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_eval<true> : k_ph_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 // one evaluation of the line-search function at step `alpha` (alpha < 0: keep the current one)
@@ -1692,15 +1722,25 @@ void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
     if (alpha >= 0.0) hipLaunchKernelGGL(k_ls_set_alpha, dim3(1), dim3(64), 0, L.stream, d, alpha);
     if (moved) {
         launch_pose_update(L, d);
-        if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d);
+        if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
     }
-    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 0);
+    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d, 0, 0);
 }
-// the device-side test of the full step (the common case); a rejected one leaves the state parked for the host
+// the device-side test of the full step (the common case) and the search rounds behind it
 void launch_ph_ls_fast(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, (d.dense ? k_ph_ls_dir<true> : k_ph_ls_dir<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(256), 0, d);
+    // the search itself, enqueued blindly like the trust-region loop: round 0 evaluates phi and phi' at the full step (the
+    // candidate of the update kernels is that trial point), every further round moves the candidate to st.ls_alpha first
+    for (int r = 0; r < d.ls_rounds; ++r) {
+        if (r) {
+            launch_pose_update(L, d, 1);
+            if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 1);
+        }
+        LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 1);
+        LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d, 1, r == d.ls_rounds - 1 ? 1 : 0);
+    }
 }
 void launch_ls_resume(Launcher &L, const Dev &d) {
     hipLaunchKernelGGL(k_ls_resume, dim3(1), dim3(64), 0, L.stream, d);

@@ -73,9 +73,13 @@ struct State {
     int sub_one_dim, sub_pad_;
     double sub_e[2][2], sub_g[2], sub_B[3];
     double ls_alpha;          // projected line search (bounds): the candidate is Plus(x, ls_alpha * delta)
-    // bounds: the full step failed the Armijo test on the device (k_ph_ls_fast), the search needs evaluations the host has to
-    // drive: terminated = 1 with termination_type = LS_PENDING parks every kernel until ssba_api.hip has finished the search
-    int ls_pending, pad3_;
+    // bounds: the full step failed the Armijo test on the device (k_ph_ls_fast).  ls_active: the device-side search is under
+    // way (1: its first evaluation, phi and phi' at the full step, is still to come; 2: running) -- the blindly enqueued
+    // search rounds of the iteration are no-ops without it.  A search that needs more rounds than were enqueued (or whose
+    // failure has to restore the full step) is handed to the host: terminated = 1 with termination_type = LS_PENDING parks
+    // every kernel until ssba_api.hip has run the search (finish_pending_search).  ls_steps / ls_searches: evaluations /
+    // searches completed on the device.
+    int ls_pending, ls_active, ls_steps, ls_searches;
 };
 constexpr int LS_PENDING = 3;   // State::termination_type while a projected line search waits for the host (never reported)
 
@@ -229,10 +233,10 @@ struct Dev {
     double *bsys;
     // bounds on the shared blocks (SetParameterLower/UpperBound): [ka, ks, alpha, kd]; projected Plus +
     // Armijo line search when constrained
-    int constrained, pad2_;
+    int constrained, ls_rounds;                     // ls_rounds: search evaluations enqueued per iteration for the device-side Armijo search
     double blo[4], bhi[4];
     double *part_ls;                                // n_lm_blocks * NLS line-search partials
-    double *ls_out;                                 // NLS_OUT scalars the host reads per probe
+    double *ls_out;                                 // NLS_OUT scalars the host reads per probe, then NLS_MACH doubles holding the device-side search's state (ssba_linesearch.h: Armijo)
     // unary pose residual blocks (pose prior, sun sensor), sorted by pose
     int n_pf, pos_const;                            // pos_const: every position block constant (--multistage stage 2; lighting problems)
     const uint32_t *pf_start;                       // P+1
@@ -267,6 +271,7 @@ struct Dev {
 static_assert(sizeof(Dev) <= 4096 - 256 - 128, "Dev no longer fits the kernel-argument segment next to the scalars and hidden arguments");
 constexpr int DN_BS = 64;                           // block size of the dense Cholesky
 constexpr int NLS = 6;        // per block: cost, phi', |dx_l|^2, nonfinite, max|delta_l|, g_l . delta_l
+constexpr int NLS_MACH = 24;
 constexpr int NLS_OUT = 8;    // cost, phi', |dx_l|^2, nonfinite_l, max|delta|, g . delta, valid, x_cost
 constexpr int BS_SBB = 0, BS_RHS = NBP * NBP, BS_G = BS_RHS + NBP, BS_H = BS_G + NBP, BS_S = BS_H + NBP,
               BS_DB = BS_S + NBP, BS_VB = BS_DB + NBP, BS_COUNT = BS_VB + NBP;   // VB: dogleg v_b = s^2 g / D^2

@@ -202,6 +202,42 @@ def test_bounded_solve_matches_oracle(light_type, init, strategy):
         np.testing.assert_allclose(ba.texture, op.texture, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 1)])
+def test_line_search_on_the_device_is_the_search_the_host_drives(strategy, monkeypatch):
+    """The Armijo state machine (csrc/ssba_linesearch.h) runs in k_ph_ls_reduce for the evaluations enqueued with every
+    iteration (SSBA_LS_ROUNDS, default 3); SSBA_LS_ROUNDS=0 leaves every search to the host (the r02 path), 1 makes the
+    hand-over of a search that needs more evaluations than were enqueued the common case.  Same code, same evaluations:
+    the solves must agree bit for bit, and the evaluation count must be the oracle's (Summary::num_line_search_steps)."""
+    prob, ph = synth.make_phong_problem(50, 2000)
+    d = ph.as_oracle_dict("reference")
+    kw = dict(max_num_iterations=25, use_nonmonotonic_steps=1, trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    runs = {}
+    for rounds in ("3", "0", "1", "20"):
+        monkeypatch.setenv("SSBA_LS_ROUNDS", rounds)
+        ba = StereoBA.from_synth(prob, lighting=d, shared_free=7, use_bounds=True)
+        s, log = ba.solve(capi.default_options(**kw))
+        runs[rounds] = (s, log, ba.poses.copy(), ba.texture.copy())
+    s3, log3 = runs["3"][:2]
+    assert s3.num_line_searches_on_device > 0 and runs["0"][0].num_line_searches_on_device == 0
+    assert runs["0"][0].num_line_searches_by_host == s3.num_line_searches_on_device + s3.num_line_searches_by_host
+    assert runs["1"][0].num_line_searches_by_host > 0 and runs["20"][0].num_line_searches_by_host == 0
+    for rounds in ("0", "1", "20"):
+        s, log, poses, tex = runs[rounds]
+        assert s.num_iterations == s3.num_iterations and s.num_line_search_steps == s3.num_line_search_steps
+        assert log["step_is_successful"].tolist() == log3["step_is_successful"].tolist()
+        # bit for bit: the state machine uses no libm beyond sqrt and contracts no a * b + c (ssba_linesearch.h)
+        np.testing.assert_array_equal(log["cost"], log3["cost"])
+        np.testing.assert_array_equal(poses, runs["3"][2])
+        np.testing.assert_array_equal(tex, runs["3"][3])
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s2, log2 = op.solve(orc.driver_options(num_threads=4, **kw))
+    n = 12
+    assert log3["step_is_successful"][:n].tolist() == log2["step_is_successful"][:n].tolist()
+    if len(log3["cost"]) == len(log2["cost"]) and log3["step_is_successful"].tolist() == log2["step_is_successful"].tolist():
+        assert s3.num_line_search_steps == s2.num_line_search_steps
+
+
 def test_infeasible_start_is_projected_on_the_device():
     prob, ph = synth.make_phong_problem(20, 600, track_len=8, seed=2)
     d = ph.as_oracle_dict("perturbed")
