@@ -147,6 +147,7 @@ class SolverSummary:
         self.termination_type = NO_CONVERGENCE
         self.num_successful_steps = 0
         self.num_unsuccessful_steps = 0
+        self.num_line_search_steps = 0
         self.initial_cost = 0.0
         self.final_cost = 0.0
         self.total_time_in_seconds = 0.0
@@ -312,6 +313,7 @@ def Solve(options: SolverOptions, problem: Problem, summary: SolverSummary, devi
     summary.termination_type = s.termination_type
     summary.num_successful_steps = s.num_successful_steps
     summary.num_unsuccessful_steps = s.num_unsuccessful_steps
+    summary.num_line_search_steps = s.num_line_search_steps
     summary.initial_cost, summary.final_cost = s.initial_cost, s.final_cost
     summary.total_time_in_seconds, summary.device_time_in_seconds = s.total_time_s, s.device_time_s
     names = ("cost", "cost_change", "gradient_max_norm", "step_norm", "relative_decrease", "trust_region_radius")

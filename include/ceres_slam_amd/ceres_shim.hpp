@@ -210,6 +210,7 @@ class Solver {
     struct Summary {
         TerminationType termination_type = NO_CONVERGENCE;
         int num_successful_steps = 0, num_unsuccessful_steps = 0;
+        int num_line_search_steps = 0;      // bounds: evaluations of the projected line search (device + host)
         double initial_cost = 0, final_cost = 0, total_time_in_seconds = 0;
         std::string message;
         bool IsSolutionUsable() const { return termination_type == CONVERGENCE || termination_type == NO_CONVERGENCE; }
@@ -620,6 +621,7 @@ inline void Solve(const Solver::Options &options, Problem *problem, Solver::Summ
     summary->termination_type = (TerminationType)s.termination_type;
     summary->num_successful_steps = s.num_successful_steps;
     summary->num_unsuccessful_steps = s.num_unsuccessful_steps;
+    summary->num_line_search_steps = s.num_line_search_steps;
     summary->initial_cost = s.initial_cost;
     summary->final_cost = s.final_cost;
     summary->total_time_in_seconds = s.total_time_s;

@@ -29,9 +29,9 @@ def test_every_header_symbol_is_exported():
 
 
 def test_struct_layouts_match_header_sizes():
-    # ssba_options: 8 int32 + 9 double + 2 int32 ; ssba_summary: 4 int32 + 4 double
+    # ssba_options: 8 int32 + 9 double + 2 int32 ; ssba_summary: 4 int32 + 4 double + 4 int32 (line-search counters)
     assert ctypes.sizeof(capi.Options) == 8 * 4 + 9 * 8 + 2 * 4
-    assert ctypes.sizeof(capi.Summary) == 4 * 4 + 4 * 8
+    assert ctypes.sizeof(capi.Summary) == 4 * 4 + 4 * 8 + 4 * 4
     assert ctypes.sizeof(capi.KernelTime) == 48 + 8 + 8
     assert ctypes.sizeof(capi.Camera) == 40
 
