@@ -322,16 +322,27 @@ static __device__ int poly_roots_real(const double *coef_in, int ncoef, double *
         return 2;
     }
     if (deg > 4) return -1;
-    double m[5], bound = 0.0;
+    // (ONE lane of a work-group runs this; the arrays are indexed at run time: LDS, not scratch memory)
+    __shared__ double m[5], zr[4], zi[4];
+    double bound = 0.0, fuji = 0.0;
     for (int i = 0; i <= deg; ++i) {
         m[i] = c[i] / c[0];
         if (!isfinite(m[i])) return -1;
         if (i && fabs(m[i]) > bound) bound = fabs(m[i]);
+        // Fujiwara: every root has |z| <= 2 max_k |m_k|^(1/k); the k-th roots bounded from above with square roots alone
+        // (as ssba_linesearch.h: ls_root_radius).  Cauchy's 1 + max |m_k| is ~lambda^4 for roots ~lambda here: the start
+        // circle was 1e10 x too wide and the iteration spent ~40 sweeps (60-90 us on this one lane) contracting it
+        if (i) {
+            double x = fabs(m[i]);
+            const int nsq = x >= 1.0 ? (i >= 4 ? 2 : i >= 2 ? 1 : 0) : (i >= 3 ? 2 : i >= 2 ? 1 : 0);
+            for (int j = 0; j < nsq; ++j) x = sqrt(x);
+            fuji = fmax(fuji, x);
+        }
     }
-    double zr[4], zi[4];
+    const double radius = fuji > 0.0 ? fmin(1.0 + bound, 2.0 * fuji) : 1.0;
     for (int i = 0; i < deg; ++i) {
         const double ang = 2.0 * 3.14159265358979323846 * i / deg + 0.4;
-        zr[i] = (1.0 + bound) * cos(ang); zi[i] = (1.0 + bound) * sin(ang);
+        zr[i] = radius * cos(ang); zi[i] = radius * sin(ang);
     }
     int polished = 0;
     for (int it = 0; it < 500; ++it) {

@@ -17,6 +17,13 @@ namespace ssba {
 
 #define SSBA_HD __host__ __device__
 #define SSBA_NO_CONTRACT _Pragma("clang fp contract(off)")
+// arrays that are indexed at run time: in LDS on the device (ONE lane of a work-group runs this code; registers cannot be
+// indexed, so the arrays would live in scratch memory behind ~1 us loads), on the stack on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SSBA_WORK __shared__
+#else
+#define SSBA_WORK
+#endif
 
 struct LsSample { double x, value, gradient; int value_ok, gradient_ok; };
 
@@ -68,6 +75,23 @@ SSBA_HD inline double ls_poly_eval(const double *c, int n, double x) {
     return v;
 }
 
+// Radius of a disc that holds every root of the monic polynomial m[0] = 1, m[1..deg] (Fujiwara: |z| <= 2 max_k |m_k|^(1/k)),
+// with the k-th roots bounded from above through square roots alone (x >= 1: the largest power of two <= k, x < 1: the
+// smallest one >= k) -- the start circle of the Aberth iteration.  Cauchy's 1 + max |m_k| can be 1e10 x the roots here
+// (the dogleg's quartic has m_4 ~ lambda^4 for roots ~ lambda), which costs ~40 sweeps of slow contraction on one lane.
+SSBA_HD inline double ls_root_radius(const double *m, int deg) {
+    SSBA_NO_CONTRACT
+    double R = 0.0, cauchy = 0.0;
+    for (int k = 1; k <= deg; ++k) {
+        double x = fabs(m[k]);
+        cauchy = fmax(cauchy, x);
+        const int nsq = x >= 1.0 ? (k >= 4 ? 2 : k >= 2 ? 1 : 0) : (k >= 5 ? 3 : k >= 3 ? 2 : k >= 2 ? 1 : 0);
+        for (int j = 0; j < nsq; ++j) x = sqrt(x);
+        R = fmax(R, x);
+    }
+    return R > 0.0 ? fmin(1.0 + cauchy, 2.0 * R) : 1.0;
+}
+
 // real parts of all roots (FindPolynomialRoots(p, &real, NULL)); degree <= 5 after dropping leading zeros
 SSBA_HD inline int ls_poly_roots_real(const double *coef_in, int ncoef, double *re) {
     SSBA_NO_CONTRACT
@@ -90,17 +114,17 @@ SSBA_HD inline int ls_poly_roots_real(const double *coef_in, int ncoef, double *
         return 2;
     }
     if (deg > 6) return -1;
-    double m[8], bound = 0.0;
+    SSBA_WORK double m[8];
     for (int i = 0; i <= deg; ++i) {
         m[i] = c[i] / c[0];
         if (!ls_finite(m[i])) return -1;
-        if (i && fabs(m[i]) > bound) bound = fabs(m[i]);
     }
-    LsCx z[8];
+    const double radius = ls_root_radius(m, deg);
+    SSBA_WORK LsCx z[8];
     for (int i = 0; i < deg; ++i) {
         double c, sn;
         ls_start_dir(deg, i, &c, &sn);
-        z[i] = cx((1.0 + bound) * c, (1.0 + bound) * sn);
+        z[i] = cx(radius * c, radius * sn);
     }
     int polished = 0;
     for (int it = 0; it < 500; ++it) {     // Aberth-Ehrlich (Ceres: eigenvalues of the companion matrix)
@@ -132,7 +156,7 @@ SSBA_HD inline double ls_minimize(const LsSample *smp, int ns, double x_min, dou
     int nc = 0;
     for (int i = 0; i < ns; ++i) nc += (smp[i].value_ok ? 1 : 0) + (smp[i].gradient_ok ? 1 : 0);
     const int deg = nc - 1;
-    double A[6][7];
+    SSBA_WORK double A[6][7];
     int row = 0;
     for (int i = 0; i < ns; ++i) {
         if (smp[i].value_ok) {
@@ -146,7 +170,7 @@ SSBA_HD inline double ls_minimize(const LsSample *smp, int ns, double x_min, dou
             ++row;
         }
     }
-    int perm[6];
+    SSBA_WORK int perm[6];
     for (int i = 0; i < nc; ++i) perm[i] = i;
     for (int k = 0; k < nc; ++k) {
         int pr = k, pc = k;
@@ -163,7 +187,8 @@ SSBA_HD inline double ls_minimize(const LsSample *smp, int ns, double x_min, dou
             for (int j = k; j <= nc; ++j) A[i][j] -= f * A[k][j];
         }
     }
-    double y[6], coef[6];
+    SSBA_WORK double y[6];
+    SSBA_WORK double coef[6];
     for (int i = nc - 1; i >= 0; --i) {
         double v = A[i][nc];
         for (int j = i + 1; j < nc; ++j) v -= A[i][j] * y[j];
@@ -174,7 +199,8 @@ SSBA_HD inline double ls_minimize(const LsSample *smp, int ns, double x_min, dou
     if ((v = ls_poly_eval(coef, nc, x_min)) < best_v) { best_v = v; best_x = x_min; }
     if ((v = ls_poly_eval(coef, nc, x_max)) < best_v) { best_v = v; best_x = x_max; }
     if (nc > 2) {
-        double der[6], roots[8];
+        SSBA_WORK double der[6];
+        SSBA_WORK double roots[8];
         for (int i = 0; i < nc - 1; ++i) der[i] = (nc - 1 - i) * coef[i];
         const int nr = ls_poly_roots_real(der, nc - 1, roots);
         for (int i = 0; i < nr; ++i) {
@@ -223,7 +249,7 @@ struct Armijo {
         if (!current.value_ok) {
             step = fmin(fmax(current.x * 0.5, lo), hi);
         } else {
-            LsSample smp[3];
+            SSBA_WORK LsSample smp[3];
             int ns = 0;
             smp[ns++] = initial;
             smp[ns++] = current;

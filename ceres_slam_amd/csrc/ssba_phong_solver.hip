@@ -1144,33 +1144,53 @@ template <bool DN> __global__ __launch_bounds__(BP_THREADS) void k_ph_border_pos
 
 // candidate shared blocks = Plus(x_b, delta_b): Euclidean, UnitVectorPerturbation on a directional
 // light (dataset_ba_phong.cpp:201-204); its |dx|^2 and non-finite flag join the pose partials
-__global__ void k_ph_border_update(Dev d, int ls_round) {
+// (one lane per entry of the shared blocks [light 3 | phong 3 M | texture M], nsh <= 63: the serial version spent 18 us in
+// chains of dependent loads; |dx|^2 is still summed in index order)
+__global__ __launch_bounds__(64) void k_ph_border_update(Dev d, int ls_round) {
     const State &st = *d.st;
-    if (st.terminated || threadIdx.x != 0 || blockIdx.x != 0 || (ls_round && !st.ls_active)) return;
-    double dn = 0.0, bad = 0.0;
-    for (int i = 0; i < d.nsh; ++i) d.cand_sh[i] = d.sh[i];
-    if (!st.step_failed && d.nb) {
-        double db[NBP];   // LM: beta = 1, gamma = 0; dogleg: beta * delta_gn + gamma * v
-        for (int c = 0; c < d.nb; ++c) {
-            db[c] = st.ls_alpha * (st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c]);
-            if (!isfinite(db[c])) bad = 1.0;
+    if (st.terminated || blockIdx.x != 0 || (ls_round && !st.ls_active)) return;
+    __shared__ double sdf[64];
+    const int i = threadIdx.x, M3 = 3 * d.M;
+    const bool in = i < d.nsh;
+    const double old = in ? d.sh[i] : 0.0;
+    double nw = old, bad = 0.0;
+    const bool moved = !st.step_failed && d.nb;
+    if (moved) {
+        int col = -1;       // border column of this entry (-1: its block is constant)
+        if (i < 3) col = d.b_light >= 0 ? d.b_light + i : -1;
+        else if (i < 3 + M3) col = d.b_phong >= 0 ? d.b_phong + (i - 3) : -1;
+        else if (in) col = d.b_tex >= 0 ? d.b_tex + (i - 3 - M3) : -1;
+        double db = 0.0;    // LM: beta = 1, gamma = 0; dogleg: beta * delta_gn + gamma * v
+        if (col >= 0) {
+            db = st.ls_alpha * (st.beta * d.bsys[BS_DB + col] + st.gamma * d.bsys[BS_VB + col]);
+            if (!isfinite(db)) bad = 1.0;
         }
-        if (d.b_light >= 0) {
-            if (d.light_type == 1) unit_plus(d.sh, db + d.b_light, d.cand_sh);
-            else for (int c = 0; c < 3; ++c) d.cand_sh[c] = d.sh[c] + db[d.b_light + c];
+        const double x3[3] = {__shfl(old, 0, 64), __shfl(old, 1, 64), __shfl(old, 2, 64)};
+        const double d3[3] = {__shfl(db, 0, 64), __shfl(db, 1, 64), __shfl(db, 2, 64)};
+        if (col >= 0) {
+            if (i < 3 && d.light_type == 1) {
+                double o3[3];
+                unit_plus(x3, d3, o3);
+                nw = o3[i];
+            } else {
+                nw = old + db;
+            }
+            if (d.constrained && i >= 3) {   // ParameterBlock::Plus projects onto the box constraints
+                const int bi = i < 3 + M3 ? (i - 3) % 3 : 3;
+                nw = fmin(fmax(nw, d.blo[bi]), d.bhi[bi]);
+            }
         }
-        if (d.b_phong >= 0) for (int c = 0; c < 3 * d.M; ++c) d.cand_sh[3 + c] = d.sh[3 + c] + db[d.b_phong + c];
-        if (d.b_tex >= 0) for (int c = 0; c < d.M; ++c) d.cand_sh[3 + 3 * d.M + c] = d.sh[3 + 3 * d.M + c] + db[d.b_tex + c];
-        if (d.constrained) {   // ParameterBlock::Plus projects onto the box constraints
-            if (d.b_phong >= 0)
-                for (int c = 0; c < 3 * d.M; ++c) d.cand_sh[3 + c] = fmin(fmax(d.cand_sh[3 + c], d.blo[c % 3]), d.bhi[c % 3]);
-            if (d.b_tex >= 0)
-                for (int c = 0; c < d.M; ++c) d.cand_sh[3 + 3 * d.M + c] = fmin(fmax(d.cand_sh[3 + 3 * d.M + c], d.blo[3]), d.bhi[3]);
-        }
-        for (int i = 0; i < d.nsh; ++i) { const double df = d.cand_sh[i] - d.sh[i]; dn += df * df; }
     }
+    if (in) d.cand_sh[i] = nw;
+    sdf[i] = (nw - old) * (nw - old);
+    const bool any_bad = __ballot(bad != 0.0) != 0ull;
+    __syncthreads();
+    if (i != 0) return;
+    double dn = 0.0;
+    if (moved)
+        for (int k = 0; k < d.nsh; ++k) dn += sdf[k];
     d.part_pose[d.n_pose_blocks * NPP] = dn;
-    d.part_pose[d.n_pose_blocks * NPP + 1] = bad;
+    d.part_pose[d.n_pose_blocks * NPP + 1] = any_bad ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------------ dogleg (config 3) ---
@@ -1504,23 +1524,24 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_dir(Dev d) {
         o[4] = f2; o[5] = g2;
     }
 }
-__global__ __launch_bounds__(256) void k_ph_ls_fast(Dev d) {
+// (1024 lanes: the loops below are chains of cold loads, six trips instead of 24 -- 29 us -> see profiles/README.md)
+__global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d) {
     State &st = *d.st;
     if (st.terminated) return;
-    __shared__ double sm[4];
+    __shared__ double sm[16];
     double lmax = 0.0, lgd = 0.0;
-    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
         const double *o = d.part_ls + (size_t)i * NLS;
         lmax = fmax(lmax, o[4]); lgd += o[5];
     }
     double pmax = 0.0, pgd = 0.0, pbad = 0.0;
-    for (int i = threadIdx.x; i < d.nfree * 6; i += 256) {
+    for (int i = threadIdx.x; i < d.nfree * 6; i += 1024) {
         const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
         const double dpc = st.opt.strategy ? st.beta * d.x0[i] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[i];
         pmax = fmax(pmax, fabs(dpc));
         pgd += d.xv[d.off_gp + i] * dpc;
     }
-    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) pbad += d.part_pose[i * NPP + 1];
+    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
     lmax = block_max(lmax, sm); lgd = block_sum(lgd, sm);
     pmax = block_max(pmax, sm); pgd = block_sum(pgd, sm); pbad = block_sum(pbad, sm);
     if (threadIdx.x != 0) return;
@@ -1555,23 +1576,23 @@ __global__ void k_ls_resume(Dev d) {
 // on (st.ls_alpha = the next step: the following round evaluates it) or is handed to the host (`last` round and still not
 // done, or a failed search that would have to restore the full step: the host starts that search again from the top --
 // the evaluations are deterministic, it takes the same path)
-__global__ __launch_bounds__(256) void k_ph_ls_reduce(Dev d, int ls_round, int last) {
+__global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int last) {
     State &st = *d.st;
     if (st.terminated || (ls_round && !st.ls_active)) return;
-    __shared__ double sm[4];
+    __shared__ double sm[16];
     double acc[NLS] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 256) {
+    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
         const double *o = d.part_ls + (size_t)i * NLS;
         acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; acc[4] = fmax(acc[4], o[4]); acc[5] += o[5];
     }
     double pmax = 0.0, pgd = 0.0, pbad = 0.0;
-    for (int i = threadIdx.x; i < d.nfree * 6; i += 256) {
+    for (int i = threadIdx.x; i < d.nfree * 6; i += 1024) {
         const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
         const double dpc = st.opt.strategy ? st.beta * d.x0[i] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[i];
         pmax = fmax(pmax, fabs(dpc));
         pgd += d.xv[d.off_gp + i] * dpc;
     }
-    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 256) pbad += d.part_pose[i * NPP + 1];
+    for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
     const double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
     const double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
     const double qmax = block_max(pmax, sm), qgd = block_sum(pgd, sm), qbad = block_sum(pbad, sm);
@@ -1725,12 +1746,12 @@ void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
         if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
     }
     LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 0);
-    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d, 0, 0);
+    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 0, 0);
 }
 // the device-side test of the full step (the common case) and the search rounds behind it
 void launch_ph_ls_fast(Launcher &L, const Dev &d) {
     LAUNCH(KC_SMALL, (d.dense ? k_ph_ls_dir<true> : k_ph_ls_dir<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(256), 0, d);
+    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(1024), 0, d);
     // the search itself, enqueued blindly like the trust-region loop: round 0 evaluates phi and phi' at the full step (the
     // candidate of the update kernels is that trial point), every further round moves the candidate to st.ls_alpha first
     for (int r = 0; r < d.ls_rounds; ++r) {
@@ -1739,7 +1760,7 @@ void launch_ph_ls_fast(Launcher &L, const Dev &d) {
             if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 1);
         }
         LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 1);
-        LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(256), 0, d, 1, r == d.ls_rounds - 1 ? 1 : 0);
+        LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 1, r == d.ls_rounds - 1 ? 1 : 0);
     }
 }
 void launch_ls_resume(Launcher &L, const Dev &d) {
