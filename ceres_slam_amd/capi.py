@@ -36,7 +36,7 @@ SYMBOLS = [
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant", "ssba_release_cached_memory",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation", "ssba_add_relative_pose",
     "ssba_pose_covariance", "ssba_rccl_unique_id", "ssba_set_rccl", "ssba_frontend_vo",
-    "ssba_rccl_describe", "ssba_rccl_ranks",
+    "ssba_rccl_describe", "ssba_rccl_ranks", "ssba_armijo_trace",
 ]
 
 
@@ -138,6 +138,7 @@ def load():
     L.ssba_get_stats.argtypes = [H, C.POINTER(Stats)]
     L.ssba_evaluate.argtypes = [H, _dp, _dp, _dp, _dp, _dp]
     L.ssba_lm_step.argtypes = [H, C.POINTER(Options), C.c_double, _dp, _dp, _dp, _dp, _dp]
+    L.ssba_armijo_trace.argtypes = [_dp, _dp, C.c_int32, C.c_double, C.c_double, C.c_double, _dp, _dp, C.c_int32, C.c_int32]
     L.ssba_phong_evaluate.argtypes = [C.c_int, C.c_int, C.c_uint64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp,
                                       _dp, _dp, _dp, _dp, _dp]
     L.ssba_add_normal_blocks.argtypes = [H, _dp, C.c_uint32]

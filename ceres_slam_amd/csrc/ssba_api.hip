@@ -2386,6 +2386,57 @@ int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, doubl
     return SSBA_OK;
 }
 
+// test hook: the line-search state machine on a recorded sequence of evaluations, on the host or in a one-lane kernel
+namespace {
+struct ArmijoTraceOut { int count; double optimal; };
+__host__ __device__ inline void armijo_replay(const double *values, const double *gradients, int n, double c0, double g0, double dmax,
+                                              double *steps_out, ArmijoTraceOut *out) {
+    ssba::Armijo a;
+    a.begin(c0, g0, dmax);
+    int k = 0;
+    while (!a.done && k < n) {
+        steps_out[k] = a.current.x;
+        a.feed(values[k], gradients[k]);
+        ++k;
+    }
+    out->count = k;
+    out->optimal = a.success ? a.optimal_step : -1.0;
+}
+__global__ void k_armijo_replay(const double *values, const double *gradients, int n, double c0, double g0, double dmax, double *steps_out,
+                                ArmijoTraceOut *out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) armijo_replay(values, gradients, n, c0, g0, dmax, steps_out, out);
+}
+}  // namespace
+int ssba_armijo_trace(const double *values, const double *gradients, int32_t n, double initial_cost, double initial_gradient,
+                      double dir_max_norm, double *steps_out, double *optimal_step, int32_t on_device, int32_t device) {
+    if (!values || !gradients || !steps_out || !optimal_step || n < 0) return SSBA_ERR_INVALID_ARGUMENT;
+    ArmijoTraceOut out{0, -1.0};
+    if (!on_device) {
+        armijo_replay(values, gradients, n, initial_cost, initial_gradient, dir_max_norm, steps_out, &out);
+    } else {
+        HIPCHECK(hipSetDevice(device < 0 ? 0 : device));
+        double *dv = nullptr, *dg = nullptr, *ds = nullptr;
+        ArmijoTraceOut *dout = nullptr;
+        const size_t bytes = (size_t)(n > 0 ? n : 1) * sizeof(double);
+        hipError_t e = hipMalloc(&dv, bytes);
+        if (e == hipSuccess) e = hipMalloc(&dg, bytes);
+        if (e == hipSuccess) e = hipMalloc(&ds, bytes);
+        if (e == hipSuccess) e = hipMalloc(&dout, sizeof out);
+        if (e == hipSuccess) e = hipMemcpy(dv, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dg, gradients, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_armijo_replay, dim3(1), dim3(64), 0, 0, dv, dg, (int)n, initial_cost, initial_gradient, dir_max_norm, ds, dout);
+            e = hipDeviceSynchronize();
+        }
+        if (e == hipSuccess) e = hipMemcpy(steps_out, ds, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&out, dout, sizeof out, hipMemcpyDeviceToHost);
+        hipFree(dv); hipFree(dg); hipFree(ds); hipFree(dout);
+        if (e != hipSuccess) { set_error(std::string("ssba_armijo_trace: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
+    }
+    *optimal_step = out.optimal;
+    return out.count;
+}
+
 int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S, double *rhs,
                  double *delta_p, double *delta_l, double *model_cost_change) {
     if (!p || !(radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;

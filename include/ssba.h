@@ -263,6 +263,15 @@ int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, doubl
  * model cost change.  Any output may be NULL. */
 int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S,
                  double *rhs, double *delta_p, double *delta_l, double *model_cost_change);
+/* The scalar state machine of the projected line search [Ceres 1.x line_search.cc ArmijoLineSearch::DoSearch, CUBIC
+ * interpolation; bounds: tests/dataset_ba_phong.cpp:143-181] replayed on a given sequence of evaluations: phi(0),
+ * phi'(0), max |direction|, then values[k] / gradients[k] = phi, phi' at the k-th step it asks for (steps_out[k], capacity
+ * n).  on_device = 0 runs it on the host (no GPU needed), 1 in a one-lane kernel on `device` -- the solver uses both (the
+ * search rounds enqueued with an iteration, and the searches handed back to the host) and they must agree bit for bit.
+ * Returns the number of steps asked for (<= n), a negative status on error; *optimal_step = the accepted step or -1. */
+int ssba_armijo_trace(const double *values, const double *gradients, int32_t n, double initial_cost,
+                      double initial_gradient, double dir_max_norm, double *steps_out, double *optimal_step,
+                      int32_t on_device, int32_t device);
 
 /* ---- config 3: lighting terms on the same graph (tests/dataset_ba_phong.cpp:101-204) ---- */
 /* The Phong driver adds, for every stereo observation (pose k, vertex j), an intensity residual

@@ -238,6 +238,19 @@ def test_line_search_on_the_device_is_the_search_the_host_drives(strategy, monke
         assert s3.num_line_search_steps == s2.num_line_search_steps
 
 
+def test_armijo_state_machine_gives_the_same_bits_on_the_device_and_on_the_host():
+    """csrc/ssba_linesearch.h in a one-lane kernel against the same header on the host (ssba_armijo_trace): every step the
+    search asks for, through cubic and quintic interpolations and the Aberth root finder, bit for bit."""
+    from test_oracle_bounds import _product_trace, _search_cases
+    long_searches = 0
+    for phi, dphi in _search_cases(60, seed=17):
+        host, host_opt = _product_trace(phi, dphi, on_device=0)
+        dev, dev_opt = _product_trace(phi, dphi, on_device=1)
+        assert dev == host and dev_opt == host_opt
+        long_searches += len(host) >= 3
+    assert long_searches >= 15
+
+
 def test_infeasible_start_is_projected_on_the_device():
     prob, ph = synth.make_phong_problem(20, 600, track_len=8, seed=2)
     d = ph.as_oracle_dict("perturbed")

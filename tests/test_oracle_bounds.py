@@ -77,6 +77,61 @@ def test_armijo_state_machine_matches_numpy_restatement(case):
         assert len(steps) >= 2            # the interpolation was exercised
 
 
+def _search_cases(count, seed=5):
+    """line-search functions that need several interpolations: phi(a) = sum_k c_k (a - m_k)^2k-ish polynomials + an exponential wall"""
+    rng = np.random.default_rng(seed)
+    for _ in range(count):
+        m = rng.uniform(0.002, 0.3)
+        w, q, e = rng.uniform(0.0, 60.0), rng.uniform(0.0, 400.0), rng.uniform(0.0, 6.0)
+        phi = lambda a, m=m, w=w, q=q, e=e: (a - m) ** 2 * (1 + w * a * a + q * a ** 4) + 1e-3 * np.expm1(e * a) + 2.0
+        dphi = lambda a, phi=phi: (phi(a + 1e-7) - phi(a - 1e-7)) / 2e-7
+        yield phi, dphi
+
+
+def _product_trace(phi, dphi, on_device=0, capacity=24):
+    """the product's state machine (csrc/ssba_linesearch.h through ssba_armijo_trace), fed by evaluating phi at what it asks
+    for.  The hook replays a recorded sequence, so it is called with the evaluations so far plus one dummy (never accepted):
+    either the machine stops before the dummy -- done -- or steps_out names the step it wants next."""
+    from ceres_slam_amd import capi
+    lib = capi.load()
+    dp = C.POINTER(C.c_double)
+    steps = []
+    while len(steps) < capacity:
+        vals = np.array([phi(x) for x in steps] + [1e300])
+        grads = np.array([dphi(x) for x in steps] + [0.0])
+        out, optimal = np.zeros(capacity + 1), C.c_double()
+        n = lib.ssba_armijo_trace(vals.ctypes.data_as(dp), grads.ctypes.data_as(dp), len(steps) + 1, phi(0.0), dphi(0.0), 1.0,
+                                  out.ctypes.data_as(dp), C.byref(optimal), on_device, 0)
+        assert n >= 0
+        if n == len(steps):
+            return steps, optimal.value
+        steps.append(float(out[len(steps)]))
+    return steps, -1.0
+
+
+def test_product_armijo_state_machine_matches_the_oracle_and_numpy():
+    """csrc/ssba_linesearch.h -- the code the device runs inside k_ph_ls_reduce and the host runs for the searches handed
+    back -- on the host (no GPU): the steps it asks for against the numpy restatement above and the oracle's C machine."""
+    lib = orc.lib()
+    dp = C.POINTER(C.c_double)
+    lib.orc_armijo_trace.argtypes = [dp, dp, C.c_int, C.c_double, C.c_double, C.c_double, dp, dp]
+    searched = 0
+    for phi, dphi in _search_cases(40):
+        steps, opt = _np_armijo(phi, dphi)
+        mine, mine_opt = _product_trace(phi, dphi)
+        assert len(mine) == len(steps)
+        np.testing.assert_allclose(mine, steps, rtol=1e-6)      # (numpy solves the 6 x 6 interpolation system with partial pivoting)
+        assert mine_opt == pytest.approx(opt, rel=1e-6)
+        vals, grads = np.array([phi(x) for x in mine]), np.array([dphi(x) for x in mine])
+        out, optimal = np.zeros(len(mine) + 2), C.c_double()
+        n = lib.orc_armijo_trace(vals.ctypes.data_as(dp), grads.ctypes.data_as(dp), len(mine), phi(0.0), dphi(0.0), 1.0,
+                                 out.ctypes.data_as(dp), C.byref(optimal))
+        assert n == len(mine)
+        np.testing.assert_allclose(out[:n], mine, rtol=1e-9)
+        searched += len(mine) >= 3
+    assert searched >= 10                 # cubic AND quintic interpolation were exercised
+
+
 def _oracle(prob, ph, init, **kw):
     return orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
                              prob.stiffness(), lighting=ph.as_oracle_dict(init), shared_free=7, **kw)
