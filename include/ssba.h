@@ -304,10 +304,11 @@ int ssba_armijo_trace(const double *values, const double *gradients, int32_t n, 
  *                             kd in [0,1], alpha >= 1); +-INFINITY = no bound.  With a bound on a free
  *                             block the problem is constrained and the minimiser does what Ceres 1.x
  *                             does: Plus projects onto the box and every trust-region step goes through
- *                             a projected Armijo line search.  The test of the full step runs on the device
- *                             (the iteration is one hipGraph); a step that has to be shortened parks the solver
- *                             until the host -- inside ssba_solve / ssba_solve_step / ssba_solve_end -- has driven
- *                             the search (one synchronisation per evaluation).
+ *                             a projected Armijo line search.  The search runs on the device inside the
+ *                             iteration's hipGraph: the test of the full step, then up to SSBA_LS_ROUNDS
+ *                             (environment, default 3) further evaluations; a search that needs more parks the
+ *                             solver until the host -- inside ssba_solve / ssba_solve_step / ssba_solve_end --
+ *                             has run it (same state machine, same bits: csrc/ssba_linesearch.h).
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:
  * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  ssba_set_huber_loss keeps its meaning
  * (the loss sits on the stereo residual blocks; lighting blocks take a NULL loss, :113,186).  Lighting

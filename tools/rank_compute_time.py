@@ -7,7 +7,7 @@ iterates are meaningless, but every kernel does its normal work on its normal si
 exactly the collective time; what is measured is the GPU + launch time per iteration that each rank pays:
   * "partitioned": chain elimination with pinned shared ends + separator system (ssba_set_partition),
   * "all-reduce":  the whole N x 84 super-block system solved by every rank.
-usage: python tools/rank_compute_time.py [N ...]"""
+usage: python tools/rank_compute_time.py [--partitioned-only] [N ...]   (--partitioned-only: for a kernel trace of that mode alone)"""
 import json
 import os
 import sys
@@ -52,7 +52,8 @@ def measure(world, rank, partitioned, steps=60):
 
 
 if __name__ == "__main__":
-    worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+    part_only = "--partitioned-only" in sys.argv
+    worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 2, 4, 8]
     rows = []
     for w in worlds:
         r = w // 2            # a middle rank: two shared separators
@@ -60,8 +61,8 @@ if __name__ == "__main__":
             ms, nx = measure(1, 0, False)
             rows.append(dict(world=1, mode="single GPU", ms_per_iteration=ms, exchange_doubles=0))
         else:
-            for part in (True, False):
+            for part in ((True,) if part_only else (True, False)):
                 ms, nx = measure(w, r, part)
                 rows.append(dict(world=w, rank=r, mode="partitioned" if part else "all-reduce", ms_per_iteration=ms, exchange_doubles=int(nx)))
-        print(json.dumps(rows[-1] if w == 1 else rows[-2:]), flush=True)
+        print(json.dumps(rows[-1] if (w == 1 or part_only) else rows[-2:]), flush=True)
     print(json.dumps({"rank_compute_time": rows}))
