@@ -43,6 +43,32 @@ def test_c3_full_size_lighting_solve_matches_cpu_oracle():
     assert np.abs(np.linalg.norm(ba.normals, axis=1) - 1).max() < 1e-12
 
 
+def test_c3_full_size_in_the_phong_drivers_own_configuration():
+    """configs[2] the way tests/dataset_ba_phong.cpp:84-87,143-181 configures it: SUBSPACE_DOGLEG, non-monotonic steps, light /
+    material / texture blocks free, bounds on the material and texture blocks (projected Plus + Armijo line search -- on the
+    device, csrc/ssba_linesearch.h), the reference's initial material values."""
+    K = 10
+    prob, ph = synth.make_phong_problem(*synth.CONFIGS["C2"])
+    d = ph.as_oracle_dict("reference")
+    kw = dict(max_num_iterations=K, use_nonmonotonic_steps=1, trust_region_strategy_type=1, dogleg_type=1)
+    ba = StereoBA.from_synth(prob, lighting=d, shared_free=7, use_bounds=True)
+    s, log = ba.solve(capi.default_options(**kw))
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d, shared_free=7, use_bounds=True)
+    s2, log2 = op.solve(orc.driver_options(num_threads=16, **kw))
+    assert s.num_iterations == s2.num_iterations
+    assert log["step_is_successful"].tolist() == log2["step_is_successful"].tolist()
+    ok = np.asarray(log2["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log["cost"][ok], log2["cost"][ok], rtol=1e-6)
+    assert s.final_cost == pytest.approx(s2.final_cost, rel=1e-6)
+    assert s.num_line_search_steps == s2.num_line_search_steps and s.num_line_searches_on_device > 0
+    assert np.abs(ba.poses - op.poses).max() < 1e-5
+    assert np.all(ba.phong[:, :2] >= 0) and np.all(ba.phong[:, :2] <= 1) and np.all(ba.phong[:, 2] >= 1)
+    assert np.all(ba.texture >= 0) and np.all(ba.texture <= 1)
+    np.testing.assert_allclose(ba.texture, op.texture, rtol=1e-5, atol=1e-7)
+
+
 def test_c5_shape_full_size_huber_outliers_matches_cpu_oracle():
     """configs[4]'s problem on one GPU: C2 with 30 % of the observations replaced by outliers, HuberLoss(1.345) on
     every stereo block."""
