@@ -1350,6 +1350,7 @@ int ssba_finalize(ssba_problem *p) {
         d.pos_const = p->points_const ? 1 : 0;
         d.light_type = p->ph_light_type;
         d.M = (int)p->M;
+        static_assert(3 + 4 * SSBA_MAX_MATERIALS <= 64, "k_ph_border_update gives every entry of the shared blocks a lane of one wave");
         d.nsh = 3 + 4 * (int)p->M;
         d.b_light = d.b_phong = d.b_tex = -1;
         if (!(p->shared_const & 1u)) { d.b_light = d.nb; d.nb += 3; }
