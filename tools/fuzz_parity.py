@@ -90,9 +90,12 @@ def print_summary():
             print(f"  -> class '{cls}': more than half of the cases uncompared")
             rc = 1
     b = SUMMARY["breakdown_first"]
-    print(f"factorisation breakdown at a radius > 1e9, first on the GPU side: {b['gpu']}, first on the oracle side: {b['oracle']}")
-    if b["gpu"] >= 3 and b["oracle"] == 0:
-        print("  -> breakdowns only on the GPU side")
+    total = sum(c["cases"] for c in SUMMARY["classes"].values())
+    print(f"factorisation breakdown at a radius > 1e9, first on the GPU side: {b['gpu']}, first on the oracle side: {b['oracle']} (of {total} cases)")
+    # both sides then reject the step, halve the radius and go on (Ceres: LINEAR_SOLVER_FAILURE); which elimination order meets
+    # the non-positive pivot first is a property of the order.  More than 1 % of the cases on ONE side would be a finding.
+    if b["gpu"] > max(3, total // 100) and b["oracle"] == 0:
+        print("  -> breakdowns only on the GPU side, in more than 1 % of the cases")
         rc = 1
     return rc
 
@@ -106,7 +109,7 @@ def solver_breakdown(log_gpu, log_orc, n):
     m = min(n, len(log_gpu["cost"]), len(log_orc["cost"]))
     for i in range(1, m):
         bad = [int(lg["step_is_successful"][i]) == 0 and float(lg["step_norm"][i]) == 0.0 and float(lg["cost_change"][i]) == 0.0
-               and float(lg["trust_region_radius"][i]) > 1e9 for lg in (log_gpu, log_orc)]
+               and float(lg["trust_region_radius"][i - 1]) > 1e9 for lg in (log_gpu, log_orc)]      # (entry i holds the radius AFTER iteration i: the step was computed with entry i - 1's)
         if bad[0] != bad[1]:
             SUMMARY["breakdown_first"]["gpu" if bad[0] else "oracle"] += 1
             return i
@@ -161,6 +164,7 @@ def lighting_case(rng, c, P, L, T, seed):
     if os.environ.get("FUZZ_ONLY") is not None:
         for i in range(min(len(log["cost"]), len(log2["cost"]))):
             print(f"   it {i}: hip {log['cost'][i]:.12e} {int(log['step_is_successful'][i])}  oracle {log2['cost'][i]:.12e} {int(log2['step_is_successful'][i])}  oracle(1 thr) {log_b['cost'][i]:.12e}  oracle(perturbed) {log_c['cost'][i] if i < len(log_c['cost']) else float('nan'):.12e}")
+            print("        " + "  ".join(f"{k}: hip {float(log[k][i]):.6e} oracle {float(log2[k][i]):.6e}" for k in ("cost_change", "step_norm", "relative_decrease", "trust_region_radius", "gradient_max_norm")))
     print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} lighting M={M} light={light_type} free={shared_free} bounds={int(bounds)} dogleg={dog:2d} "
           f"iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} "
           f"conditioned: {n2:3d} it, {worst2:.2f} of the allowance {'ok' if ok else 'MISMATCH'}", flush=True)
