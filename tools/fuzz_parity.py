@@ -35,9 +35,10 @@ def conditioned_agreement(log, ref, probes, nmax, amp=30.0, spread_max=1e-5):
     """Comparison relative to the problem's own conditioning.  `probes` are re-runs of the ORACLE that differ from `ref` by
     something a correct implementation may differ by (summation order: another thread count; an input perturbation of
     1e-14).  Where all oracle runs take the same accept / reject decisions and their accepted-iterate costs stay within
-    `spread_max` of each other, the HIP run must take the same decisions and stay within amp x that spread (floor 1e-9) of
+    `spread_max` of each other, the HIP run must take the same decisions and stay within amp x that spread (floor 1e-8) of
     `ref`; the count stops at the first iteration where it does not (the HIP path's rounding differs from the oracle's by
-    more than a thread count does, so past the strict horizon this is a measure, not a verdict).  (SUBSPACE_DOGLEG on lighting problems amplifies 1e-14 to ~1e-8 in its FIRST iteration -- the Gauss-Newton
+    more than a thread count does, so past the strict horizon this is a measure, not a verdict).  (SUBSPACE_DOGLEG on
+    lighting problems amplifies 1e-14 to ~1e-8 in its FIRST iteration -- the Gauss-Newton
     solve with mu = 1e-8 -- and keeps that level: the strict 1e-9 horizon ends at iteration 1 there although the runs
     agree to 1e-8 over the whole solve.)  Returns (iterations in agreement, worst deviation / allowance over them)."""
     m = min([nmax, len(log["cost"]), len(ref["cost"])] + [len(p["cost"]) for p in probes])
