@@ -364,6 +364,8 @@ def measure(args, name, P, L, ctx, kernel_timing, phong=False, robust=False):
         dt = float(tmax.item())
     return dict(name=name, prob=prob, lighting=lighting, huber_a=huber_a, stats=stats, dt=dt, dt_instr=dt_instr, ktimes=ktimes,
                 period=period, final_cost=final_cost, solve_iterations=int(s_conv.num_iterations), solve_wall_s=solve_wall_s,
+                line_search=dict(evaluations=int(s_conv.num_line_search_steps), searches_on_device=int(s_conv.num_line_searches_on_device),
+                                 searches_by_host=int(s_conv.num_line_searches_by_host)),
                 solve_device_s=solve_device_s, exchange=exchange, rccl_ranks=rccl_ranks, rccl_note=rccl_note,
                 partitioned=partition is not None, exchange_doubles=xsize, poses=P, landmarks=L)
 
@@ -475,6 +477,8 @@ def bench_line(args, m, weak, world, cfg):
                    "solve_device_s": m["solve_device_s"]},
         "stats": stats,
     }
+    if m["line_search"]["evaluations"]:       # bounds: the projected line search of the converged solve above
+        out["config"]["line_search"] = m["line_search"]
     if m["rccl_note"]:
         out["config"]["rccl_set_up_failure"] = m["rccl_note"]
     if weak is not None:
