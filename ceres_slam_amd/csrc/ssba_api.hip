@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <string>
 #include <vector>
@@ -1154,33 +1155,70 @@ int ssba_finalize(ssba_problem *p) {
     const uint32_t Mm = ph ? p->M : 0;
     if (!dense) {
         for (uint32_t k = 0; k < P; ++k) pose_obs_start[k + 1] = pose_obs_start[k] + pose_cnt[k];
-        std::vector<uint32_t> at(pose_obs_start.begin(), pose_obs_start.end() - 1);
         const uint32_t *lmo = lm_obs_by_pose.empty() ? lm_obs.data() : lm_obs_by_pose.data();
-        for (uint32_t l = 0; l < Lact; ++l) {
-            const uint32_t j = order[l].j, w = lm_win[l];
-            p->user_of_dev[l] = j;
-            if (ph) lm_mat[l] = p->ph_mat_of_point[j];
-            const uint32_t *wp = &win_pose[(size_t)w * TW];
-            const size_t base = (size_t)(l / LMG) * (TW * LMG) + (l % LMG);
-            int s = 0;
-            uint32_t mask = 0;
-            for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
-                const uint32_t i = lmo[e], k = lm_pose_sorted[e];
-                while (wp[s] != k) ++s;
-                const size_t oi = base + (size_t)s * LMG;
-                ou[oi] = p->obs_uvd[3 * (size_t)i];
-                ov[oi] = p->obs_uvd[3 * (size_t)i + 1];
-                od[oi] = p->obs_uvd[3 * (size_t)i + 2];
-                if (ph) {
-                    oint[oi] = p->ph_intensity[i];
-                    onx[oi] = p->ph_nobs[3 * (size_t)i];
-                    ony[oi] = p->ph_nobs[3 * (size_t)i + 1];
-                    onz[oi] = p->ph_nobs[3 * (size_t)i + 2];
+        // landmarks [l0, l1) in device order; at[k] = where the next reference of pose k goes
+        auto fill = [&](uint32_t l0, uint32_t l1, uint32_t *at) {
+            for (uint32_t l = l0; l < l1; ++l) {
+                const uint32_t j = order[l].j, w = lm_win[l];
+                p->user_of_dev[l] = j;
+                if (ph) lm_mat[l] = p->ph_mat_of_point[j];
+                const uint32_t *wp = &win_pose[(size_t)w * TW];
+                const size_t base = (size_t)(l / LMG) * (TW * LMG) + (l % LMG);
+                int s = 0;
+                uint32_t mask = 0;
+                for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) {
+                    const uint32_t i = lmo[e], k = lm_pose_sorted[e];
+                    while (wp[s] != k) ++s;
+                    const size_t oi = base + (size_t)s * LMG;
+                    ou[oi] = p->obs_uvd[3 * (size_t)i];
+                    ov[oi] = p->obs_uvd[3 * (size_t)i + 1];
+                    od[oi] = p->obs_uvd[3 * (size_t)i + 2];
+                    if (ph) {
+                        oint[oi] = p->ph_intensity[i];
+                        onx[oi] = p->ph_nobs[3 * (size_t)i];
+                        ony[oi] = p->ph_nobs[3 * (size_t)i + 1];
+                        onz[oi] = p->ph_nobs[3 * (size_t)i + 2];
+                    }
+                    mask |= 1u << s;
+                    pose_obs_ref[at[k]++] = l * 16u + (uint32_t)s;
                 }
-                mask |= 1u << s;
-                pose_obs_ref[at[k]++] = l * 16u + (uint32_t)s;
+                lm_mask[l] = mask;
             }
-            lm_mask[l] = mask;
+        };
+        // Large problems: the landmark range is cut into one piece per host thread.  A first pass counts every piece's
+        // references per pose, a prefix over the pieces gives each its own write positions -- the lists come out exactly as
+        // the single pass leaves them (12 M observations at C4: 121 ms of a 330 ms ssba_finalize on one thread).
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = (N >= 400000 && hw > 1) ? (int)std::min<unsigned>(hw, 16u) : 1;
+        if (nt == 1) {
+            std::vector<uint32_t> at(pose_obs_start.begin(), pose_obs_start.end() - 1);
+            fill(0, Lact, at.data());
+        } else {
+            std::vector<std::vector<uint32_t>> at((size_t)nt, std::vector<uint32_t>(P, 0));
+            auto piece = [&](int t) { return (uint32_t)((uint64_t)Lact * (uint64_t)t / (uint64_t)nt); };
+            auto run = [&](auto &&fn) {         // pieces 1 .. nt - 1 on threads of their own (or here, if none can be started)
+                std::vector<std::thread> th;
+                int started = 1;
+                try {
+                    for (; started < nt; ++started) th.emplace_back(fn, started);
+                } catch (const std::system_error &) {
+                }
+                fn(0);
+                for (int t = started; t < nt; ++t) fn(t);
+                for (auto &x : th) x.join();
+            };
+            run([&](int t) {
+                uint32_t *c = at[(size_t)t].data();
+                for (uint32_t l = piece(t); l < piece(t + 1); ++l) {
+                    const uint32_t j = order[l].j;
+                    for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) ++c[lm_pose_sorted[e]];
+                }
+            });
+            for (uint32_t k = 0; k < P; ++k) {
+                uint32_t pos = pose_obs_start[k];
+                for (int t = 0; t < nt; ++t) { const uint32_t c = at[(size_t)t][k]; at[(size_t)t][k] = pos; pos += c; }
+            }
+            run([&](int t) { fill(piece(t), piece(t + 1), at[(size_t)t].data()); });
         }
     }
     for (uint32_t k = 0; k < P && ph && !dense; ++k) {
