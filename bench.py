@@ -16,7 +16,11 @@ Contract (one JSON line on rank 0):
     system with SSBA_NO_PARTITION=1).  Workload: N = 2, 4 -> N x C2 (one C2-sized trajectory segment per rank); N = 8 ->
     BASELINE.json configs[3] exactly (C4 = 10 000 poses / 1 000 000 landmarks), with the 8 x C2 weak-scaling figure as the
     secondary key `weak_scaling_NxC2`.  `value` = joint-problem iterations/s x (landmarks / 100 000), i.e. C2-sized units
-    of work per second; `config.joint_iters_per_sec` is the plain rate of the joint problem.
+    of work per second; `config.joint_iters_per_sec` is the plain rate of the joint problem.  Every N > 1 line also carries
+    `speedup_vs_1gpu_same_problem` (rank 0 measures the SAME joint problem on one GPU while the others wait: a larger
+    problem scores more units per second on one GPU already, so value(N) / value(1) is not a scaling factor) and
+    `strong_scaling_C2` (BASELINE.json's literal metric problem, 1 000 / 100 000, cut into N shards); `scaling` says
+    "strong" for C4 and "weak" for N x C2.
   * `roofline`: the dominant kernel's algorithmic bytes or flops per launch / its average
     duration measured with HIP events on the library's stream during the timed region;
   * `cpu_baseline`: the CPU oracle (a port with Ceres-equivalent semantics, NOT Ceres --
@@ -381,6 +385,10 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iteration cap of the CPU-oracle sample (it converges in ~80)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="no HIP-event bracketing (use under rocprofv3)")
     ap.add_argument("--no-weak-secondary", action="store_true", help="N = 8: skip the secondary 8 x C2 weak-scaling measurement")
+    ap.add_argument("--strong", action="store_true", help="N > 1 with --config: also measure C2 itself (1 000 / 100 000) sharded over the N ranks "
+                                                          "(secondary key strong_scaling_C2; measured by default when --config is not given)")
+    ap.add_argument("--no-strong-secondary", action="store_true", help="N > 1: skip the strong-scaled C2 measurement")
+    ap.add_argument("--no-single-reference", action="store_true", help="N > 1: skip rank 0's one-GPU measurement of the same joint problem")
     ap.add_argument("--shared-free", type=int, default=0, help="C3 only: free shared blocks (bit 0 light, 1 Phong, 2 texture)")
     ap.add_argument("--bounds", action="store_true", help="C3 only: the driver's bounds on the Phong / texture blocks")
     ap.add_argument("--dogleg", type=int, default=-1, help="-1 LM (dataset_vo), 0 TRADITIONAL_DOGLEG, 1 SUBSPACE_DOGLEG")
@@ -420,17 +428,29 @@ def main():
     # the joint problem: C4 is a fixed size (strong-scaled over the ranks); the C2-shaped configurations grow with the ranks
     P, L = (P1, L1) if cfg == "C4" else (P1 * world, L1 * world)
     m = measure(args, cfg, P, L, ctx, kernel_timing=not args.no_kernel_timing, phong=phong, robust=robust)
-    weak = None
+    weak = strong = single = single_c2 = None
     if world == 8 and args.config is None and not args.no_weak_secondary:
         weak = measure(args, "C2", C2P * world, C2L * world, ctx, kernel_timing=False)
+    if world > 1 and (args.strong or args.config is None) and not args.no_strong_secondary and cfg != "C3":
+        # BASELINE.json's literal metric problem (1 000 poses / 100 000 landmarks) sharded over the N ranks: strong scaling of C2
+        strong = measure(args, "C2", C2P, C2L, ctx, kernel_timing=False, robust=robust)
+    if world > 1 and not args.no_single_reference:
+        # the SAME joint problem on ONE GPU, measured by rank 0 while the other ranks wait at the barrier: the honest
+        # denominator of a scaling factor (a larger problem scores more C2-units per second on one GPU already)
+        ctx1 = dict(ctx, world=1, rank=0)
+        if rank == 0:
+            single = measure(args, cfg, P, L, ctx1, kernel_timing=False, phong=phong, robust=robust)
+            if strong is not None:
+                single_c2 = single if (P, L) == (C2P, C2L) else measure(args, "C2", C2P, C2L, ctx1, kernel_timing=False, robust=robust)
+        dist.barrier()
 
     if rank == 0:
-        print(json.dumps(bench_line(args, m, weak, world, cfg)), flush=True)
+        print(json.dumps(bench_line(args, m, weak, world, cfg, strong=strong, single=single, single_c2=single_c2)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def bench_line(args, m, weak, world, cfg):
+def bench_line(args, m, weak, world, cfg, strong=None, single=None, single_c2=None):
     from ceres_slam_amd import synth
     C2L = synth.CONFIGS["C2"][1]
     stats, ktimes, prob, dt = m["stats"], m["ktimes"], m["prob"], m["dt"]
@@ -443,14 +463,16 @@ def bench_line(args, m, weak, world, cfg):
     out = {
         "metric": "gauss_newton_iters_per_sec",
         "value": joint_ips * units,
-        "unit": "iters/s",
+        # one C2-sized unit per iteration: plain iterations/s; a larger joint problem: C2-units/s (see value_definition)
+        "unit": "iters/s" if units == 1 else "C2-units/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms,
         "ms_per_step_instrumented": (1e3 * m["dt_instr"] / args.steps) if m["dt_instr"] else None,
         "higher_is_better": True,
-        "scaling": "weak",
+        # C4 is one fixed problem cut into N shards (strong); the C2-shaped workloads grow with the ranks (weak)
+        "scaling": "strong" if (cfg == "C4" and world > 1) else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -488,6 +510,22 @@ def bench_line(args, m, weak, world, cfg):
                                     "joint_iters_per_sec": w_ips, "ms_per_step": 1e3 * weak["dt"] / args.steps,
                                     "value": w_ips * weak["landmarks"] / C2L, "exchange": weak["exchange"], "rccl_ranks": weak["rccl_ranks"],
                                     "exchange_doubles_per_iteration": weak["exchange_doubles"]}
+    if single is not None:
+        s_ips = args.steps / single["dt"]
+        out["speedup_vs_1gpu_same_problem"] = joint_ips / s_ips
+        out["single_gpu_same_problem"] = {"joint_iters_per_sec": s_ips, "ms_per_step": 1e3 * single["dt"] / args.steps,
+                                          "value": s_ips * units, "measured_by": "rank 0 on its own GPU, the other ranks waiting at a barrier"}
+    if strong is not None:
+        g_ips = args.steps / strong["dt"]
+        out["strong_scaling_C2"] = {"workload": f"C2 itself: {strong['poses']} poses / {strong['landmarks']} landmarks / {strong['prob'].num_obs} "
+                                                f"observations cut into {world} landmark shards (BASELINE.json's metric problem)",
+                                    "iters_per_sec": g_ips, "ms_per_step": 1e3 * strong["dt"] / args.steps, "scaling": "strong",
+                                    "exchange": strong["exchange"], "partitioned": strong["partitioned"],
+                                    "exchange_doubles_per_iteration": strong["exchange_doubles"]}
+        if single_c2 is not None:
+            c_ips = args.steps / single_c2["dt"]
+            out["strong_scaling_C2"]["single_gpu_iters_per_sec"] = c_ips
+            out["strong_scaling_C2"]["speedup_vs_1gpu_same_problem"] = g_ips / c_ips
     if any(v[0] for v in ktimes.values()):
         work = algorithmic_work(stats, phong)
         per_kernel = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in ktimes.items()}   # avg ms
@@ -520,7 +558,8 @@ def bench_line(args, m, weak, world, cfg):
     out["peaks"] = measured_peaks()
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters, m["final_cost"], m["lighting"], args, m["huber_a"])
-        out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        # both sides in plain iterations/s of the SAME problem (`value` counts C2-sized units: ten per iteration at C4)
+        out["gpu_over_cpu"] = joint_ips / out["cpu_baseline"]["value"]
     return out
 
 

@@ -13,8 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libssba.so")
 SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_bcr_mfma.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip", "ssba_pool.hip"]
-HEADERS = ["ssba_types.h", "ssba_pool.h", "ssba_launch.h", "ssba_device.h", "ssba_phong_device.h", "ssba_linesearch.h", "ssba_posefactor_device.h", os.path.join("..", "..", "include", "ssba.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *os.environ.get("SSBA_EXTRA_FLAGS", "").split(),
+HEADERS = ["ssba_types.h", "ssba_pool.h", "ssba_launch.h", "ssba_device.h", "ssba_phong_device.h", "ssba_linesearch.h", "ssba_posefactor_device.h", "libssba.map", os.path.join("..", "..", "include", "ssba.h")]
+# -fvisibility=hidden + the version script below: the dynamic symbol table of libssba.so holds the entry points of
+# include/ssba.h (SSBA_API) and nothing else -- no unprefixed helpers, no ssba:: C++ symbols next to torch's RCCL or user code
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wall", "-Wno-unused-function", *os.environ.get("SSBA_EXTRA_FLAGS", "").split(),
          "-Wno-unused-value", "-Wno-unused-variable", "-Wno-unused-result"]
 
 
@@ -50,7 +52,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out.decode(errors="replace"))
         if verbose and out:
             print(out.decode(errors="replace"), file=sys.stderr)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "libssba.map"), "-o", LIB, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))

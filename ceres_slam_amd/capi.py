@@ -36,7 +36,7 @@ SYMBOLS = [
     "ssba_add_lighting_observations", "ssba_border_system", "ssba_set_shared_block_bounds", "ssba_set_point_blocks_constant", "ssba_release_cached_memory",
     "ssba_set_partition", "ssba_ransac_samples", "ssba_frontend_ransac", "ssba_add_pose_prior", "ssba_add_sun_observation", "ssba_add_relative_pose",
     "ssba_pose_covariance", "ssba_rccl_unique_id", "ssba_set_rccl", "ssba_frontend_vo",
-    "ssba_rccl_describe", "ssba_rccl_ranks", "ssba_armijo_trace",
+    "ssba_rccl_describe", "ssba_rccl_ranks", "ssba_armijo_trace", "ssba_debug_stamps",
 ]
 
 

@@ -661,20 +661,31 @@ struct RcclJob {
     ncclResult_t result = ncclSuccess;
     ncclUniqueId id;
     ncclComm_t comm = nullptr;
+    bool abandoned = false;                             // the caller gave up waiting: a communicator that completes late is the thread's to destroy
+    ncclResult_t (*destroy)(ncclComm_t) = nullptr;
 };
-// runs fn(job) on a helper thread; false = not finished within the time limit (the thread keeps the job alive)
+// runs fn(job) on a helper thread; false = not finished within the time limit.  The thread keeps the job alive; a call that
+// completes after the caller gave up destroys its own communicator (nothing is leaked, nobody will ever use it).  A process
+// whose RCCL set-up timed out still has a thread inside RCCL: it should finish its work and leave (bench.py falls back to
+// torch.distributed for the run and exits normally; process teardown while that thread is mid-call is RCCL's to survive).
 template <class F>
 bool rccl_run_limited(std::shared_ptr<RcclJob> job, F fn, double *elapsed_s) {
     const auto t0 = std::chrono::steady_clock::now();
     std::thread([job, fn] {
         const ncclResult_t r = fn(job.get());
-        std::lock_guard<std::mutex> lock(job->mu);
-        job->result = r;
-        job->done = true;
-        job->cv.notify_all();
+        ncclComm_t late = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(job->mu);
+            job->result = r;
+            job->done = true;
+            if (job->abandoned) { late = job->comm; job->comm = nullptr; }
+            job->cv.notify_all();
+        }
+        if (late && job->destroy) job->destroy(late);
     }).detach();
     std::unique_lock<std::mutex> lock(job->mu);
     const bool ok = job->cv.wait_for(lock, std::chrono::duration<double>(rccl_timeout_s()), [&] { return job->done; });
+    if (!ok) job->abandoned = true;
     *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return ok;
 }
@@ -712,6 +723,7 @@ int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size) {
     rccl_release(p);
     auto job = std::make_shared<RcclJob>();
     memcpy(&job->id, unique_id, sizeof job->id);
+    job->destroy = a->CommDestroy;
     const int device = p->device, world = p->world_size, rank = p->rank;
     double el = 0.0;
     if (!rccl_run_limited(job, [a, device, world, rank](RcclJob *j) {
@@ -2008,11 +2020,32 @@ static int reset_solver(ssba_problem *p) {
 // The closure border (loop closures as a dense border of the block-tridiagonal system, LM only) does not cover everything
 // the general-structure path does.  A caller that asks for one of those things on a handle that was finalized with a
 // border gets the other layout: ssba_finalize runs again from the host-side problem graph the handle still holds.
-static int refinalize_without_closure_border(ssba_problem *p) {
-    if (p->began) return SSBA_ERR_STATE;
+static int refinalize_without_closure_border(ssba_problem *p, const char *what) {
+    if (p->began) {
+        set_error(std::string(what) + ": not available on the closure border of this handle once a solve has begun (the loop closure was "
+                  "folded into a border of the chain at ssba_finalize; ask before the first solve, or set SSBA_NO_CLOSURE_BORDER=1)");
+        return SSBA_ERR_STATE;
+    }
+    // the general layout must fit BEFORE anything of the working layout is torn down (same test as ssba_finalize)
+    const double nf = (double)p->free_pose.size();
+    const double dn_gb = (6.0 * nf + 2 * DN_BS) * (6.0 * nf + DN_BS) * 8.0 / 1e9;
+    const char *mg = getenv("SSBA_DENSE_MAX_GB");
+    const double dn_cap = mg ? atof(mg) : 160.0;
+    if (dn_gb > dn_cap || (6 * (long)p->free_pose.size() + DN_BS) / DN_BS >= 65535) {
+        char buf[320];
+        snprintf(buf, sizeof buf, "%s: not available on the closure border, and the general layout it would need holds a %.1f GB reduced "
+                 "system (SSBA_DENSE_MAX_GB = %.0f): the handle keeps its closure-border layout (LM solves still work)", what, dn_gb, dn_cap);
+        set_error(buf);
+        return SSBA_ERR_UNSUPPORTED;
+    }
     p->no_closure_border = true;
     p->finalized = false;
-    return ssba_finalize(p);
+    const int rc = ssba_finalize(p);
+    if (rc) {       // (an allocation failed after the old layout was freed): a later ssba_finalize builds the border layout again
+        p->no_closure_border = false;
+        p->finalized = false;
+    }
+    return rc;
 }
 
 int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence) {
@@ -2030,7 +2063,7 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (o->trust_region_strategy_type == 1 && p->d.cb) {
         // DOGLEG is not implemented on the closure border: the symbolic phase runs again and puts the problem on the
         // general-structure path, which has it (once per handle; the caller's blocks and pointers are unchanged)
-        int rc = refinalize_without_closure_border(p);
+        int rc = refinalize_without_closure_border(p, "DOGLEG");
         if (rc) return rc;
     }
     if (p->d.phong && p->xfn && p->d.nb && (p->d.constrained || p->d.dense)) {
@@ -2266,7 +2299,7 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
                 hipMemcpyAsync(&ring[1], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st);
                 hipEventRecord(ev[0], st);
                 hipEventRecord(ev[1], st);
-                max_enqueue += 2;       // the parked iteration's successor(s) did nothing: they do not count
+                max_enqueue += 1;       // the one iteration enqueued behind the parked one did nothing; the parked one is judged now and counts
                 continue;
             }
             if (ring[prev].terminated) done = true;
@@ -2576,11 +2609,11 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     ApiTimer api_timer("ssba_pose_covariance");
     if (!p || !cov || pose >= p->P) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
-    if (p->d.cb && !p->began) {      // the closure border has no covariance sweep: the general path has (symbolic phase again, once)
-        int rc = refinalize_without_closure_border(p);
+    if (p->d.cb) {      // the closure border has no covariance sweep: the general path has (symbolic phase again, once)
+        int rc = refinalize_without_closure_border(p, "covariance");
         if (rc) return rc;
     }
-    if (p->d.part || p->d.phong || p->d.cb) {
+    if (p->d.part || p->d.phong) {
         set_error("covariance: not available on partitioned problems or with lighting terms");
         return SSBA_ERR_UNSUPPORTED;
     }

@@ -33,6 +33,14 @@
 extern "C" {
 #endif
 
+/* libssba.so is built with -fvisibility=hidden and a linker version script: the entry points declared in this header are
+ * the ONLY dynamic symbols it defines (tests/test_capi_symbols.py compares `nm -D --defined-only` with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#define SSBA_API __attribute__((visibility("default")))
+#else
+#define SSBA_API
+#endif
+
 #define SSBA_VERSION 1
 /* longest landmark track (observations of one landmark) of the windowed layout; problems with longer tracks, or
  * with co-observing free poses more than 12 apart, run the general-structure kernels (ssba_stats.general_structure = 1)
@@ -119,76 +127,76 @@ typedef struct {
 /* replaces: ceres::Problem problem; + the shared StereoCamera captured by every
  * functor (tests/dataset_vo.cpp:26, stereo_reprojection_error.hpp:73).
  * device < 0 selects the current HIP device. */
-int ssba_create(const ssba_camera *camera, int device, ssba_problem **out);
-int ssba_destroy(ssba_problem *p);
+SSBA_API int ssba_create(const ssba_camera *camera, int device, ssba_problem **out);
+SSBA_API int ssba_destroy(ssba_problem *p);
 
 /* ---- problem building ------------------------------------------------------------- */
 /* replaces: the pose blocks passed to AddResidualBlock + SetParameterization(pose,
  * SE3Perturbation) (tests/dataset_vo.cpp:51-58; include/ceres_slam/perturbations.hpp:45-76).
  * `poses` is num*12 doubles, caller-owned, updated in place by a solve. */
-int ssba_add_pose_blocks(ssba_problem *p, double *poses, uint32_t num);
+SSBA_API int ssba_add_pose_blocks(ssba_problem *p, double *poses, uint32_t num);
 /* replaces: the point blocks passed to AddResidualBlock (tests/dataset_vo.cpp:53);
  * `points` is num*3 doubles, caller-owned, updated in place. */
-int ssba_add_point_blocks(ssba_problem *p, double *points, uint32_t num);
+SSBA_API int ssba_add_point_blocks(ssba_problem *p, double *points, uint32_t num);
 /* replaces: StereoReprojectionErrorAutomatic::Create(camera, obs, stiffness) +
  * problem.AddResidualBlock(cost, NULL, pose_k, point_j) for every observation
  * (include/ceres_slam/stereo_reprojection_error.hpp:59-69; tests/dataset_vo.cpp:39-56).
  * uvd is num*3 (u_l, v_l, d); stiffness is the shared 3x3 row-major Sigma^{-1/2}
  * (tests/dataset_vo.cpp:29-32).  May be called several times; order is kept. */
-int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index,
+SSBA_API int ssba_add_stereo_observations(ssba_problem *p, const uint32_t *pose_index,
                                  const uint32_t *point_index, const double *uvd,
                                  uint64_t num, const double stiffness[9]);
 /* replaces: problem.SetParameterBlockConstant / SetParameterBlockVariable(pose)
  * (tests/dataset_vo.cpp:62; tests/dataset_ba_phong.cpp:76,219-243) */
-int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant);
+SSBA_API int ssba_set_pose_constant(ssba_problem *p, uint32_t pose, int is_constant);
 /* replaces: passing `new ceres::HuberLoss(a)` instead of NULL to AddResidualBlock
  * (call-site shape tests/dataset_vo_sun.cpp:89-95); a <= 0 restores the NULL loss */
-int ssba_set_huber_loss(ssba_problem *p, double a);
+SSBA_API int ssba_set_huber_loss(ssba_problem *p, double a);
 /* Uploads the problem graph and builds the device-side structure (once per graph). */
-int ssba_finalize(ssba_problem *p);
+SSBA_API int ssba_finalize(ssba_problem *p);
 
 /* ---- solving ---------------------------------------------------------------------- */
 /* Ceres 1.x defaults */
-void ssba_default_options(ssba_options *o);
+SSBA_API void ssba_default_options(ssba_options *o);
 /* replaces: ceres::Solve(options, &problem, &summary) (tests/dataset_vo.cpp:81).
  * Blocking.  Re-uploads the caller's current parameter values first. */
-int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s);
+SSBA_API int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s);
 /* replaces: summary.BriefReport() (tests/dataset_vo.cpp:82) */
-int ssba_brief_report(const ssba_summary *s, char *buf, size_t buf_len);
+SSBA_API int ssba_brief_report(const ssba_summary *s, char *buf, size_t buf_len);
 
 /* Stepwise form of ssba_solve for the bench harness and for multi-GPU drivers:
  * begin (upload + iteration 0), `step` enqueues n trust-region iterations on the
  * stream without host synchronisation, end synchronises and writes back.
  * With ignore_convergence != 0 the convergence tests are skipped so that exactly n
  * iterations of full work are executed (bench.py's timed region). */
-int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence);
-int ssba_solve_step(ssba_problem *p, int n);
-int ssba_solve_end(ssba_problem *p, ssba_summary *s);
+SSBA_API int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_convergence);
+SSBA_API int ssba_solve_step(ssba_problem *p, int n);
+SSBA_API int ssba_solve_end(ssba_problem *p, ssba_summary *s);
 /* restores the parameter values uploaded by ssba_solve_begin and restarts the
  * trust-region state (device-to-device, asynchronous) */
-int ssba_solve_restart(ssba_problem *p);
-int ssba_synchronize(ssba_problem *p);
+SSBA_API int ssba_solve_restart(ssba_problem *p);
+SSBA_API int ssba_synchronize(ssba_problem *p);
 
 /* Per-iteration log of the last solve (the columns of Ceres's progress table).
  * Arrays of `capacity` entries or NULL; returns the number of recorded iterations. */
-int ssba_iteration_log(ssba_problem *p, int32_t capacity, double *cost, double *cost_change,
+SSBA_API int ssba_iteration_log(ssba_problem *p, int32_t capacity, double *cost, double *cost_change,
                        double *gradient_max_norm, double *step_norm, double *relative_decrease,
                        double *trust_region_radius, int32_t *step_is_successful);
 
 /* ---- streams, multi-GPU exchange, instrumentation ---------------------------------- */
 /* Run on a caller-provided hipStream_t (e.g. torch's current stream). */
-int ssba_set_stream(ssba_problem *p, void *hip_stream);
+SSBA_API int ssba_set_stream(ssba_problem *p, void *hip_stream);
 /* Landmark sharding: every rank adds ALL pose blocks and only ITS landmarks and
  * observations.  The library calls `fn` at the two exchange points of an iteration
  * with a device buffer of `count` doubles that must be reduced in place over all
  * ranks (op 0 = sum, 1 = max) on the stream given to ssba_set_stream -- e.g. a
  * torch.distributed all_reduce over RCCL.  fn == NULL (default) = single GPU. */
 typedef int (*ssba_exchange_fn)(void *ctx, void *device_buffer, uint64_t count, int op);
-int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx);
+SSBA_API int ssba_set_exchange(ssba_problem *p, ssba_exchange_fn fn, void *ctx);
 /* Declares (before ssba_finalize) that the landmarks are sharded over `world_size` ranks:
  * every non-constant pose is then kept in the reduced system even if THIS rank holds no
  * observation of it, so that all ranks agree on the layout of the exchanged system. */
-int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
+SSBA_API int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
 /* Partitioned reduced solve (after ssba_set_distributed, before ssba_finalize).  The free poses are
  * grouped into super-blocks of 12 (free-pose index / 12); separator_superblocks (world_size + 1 ascending
  * entries, first = 0, last = the last super-block) says that rank r's landmarks only observe poses of the
@@ -200,7 +208,7 @@ int ssba_set_distributed(ssba_problem *p, int world_size, int rank);
  * the other ranks' chains.  At the end of the solve the poses are gathered (one more exchange), so every
  * rank returns the complete trajectory.  Without this call the ranks sum the whole reduced system and
  * each solves all of it (works for any sharding).  num = 0 clears the partition. */
-int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, uint32_t num);
+SSBA_API int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, uint32_t num);
 /* Native exchange: the library itself enqueues ncclAllReduce (RCCL over xGMI) on the solver's stream at the exchange
  * points -- one process per GPU, no host language in the loop (this is what a sharded
  * tests/dataset_vo.cpp:22-85 links against).  Rank 0 calls ssba_rccl_unique_id (128 bytes) and hands the bytes to the
@@ -208,17 +216,17 @@ int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, u
  * AFTER ssba_set_distributed(world_size, rank) -- a collective call: it returns once all ranks have joined.  It
  * replaces any callback set with ssba_set_exchange.  librccl.so is loaded on first use. */
 #define SSBA_RCCL_UNIQUE_ID_BYTES 128
-int ssba_rccl_unique_id(void *out, uint64_t size);
-int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size);
+SSBA_API int ssba_rccl_unique_id(void *out, uint64_t size);
+SSBA_API int ssba_set_rccl(ssba_problem *p, const void *unique_id, uint64_t size);
 /* Both set-up calls above are time-limited (RCCL's own calls are not): after SSBA_RCCL_TIMEOUT_S seconds (environment,
  * default 180) they return SSBA_ERR_TIMEOUT and ssba_last_error() says which RCCL call did not return, which librccl.so
  * file the process had mapped (PyTorch ships its own copy) and its version, and the IPC / debug environment; the caller
  * can fall back to ssba_set_exchange.  ssba_rccl_describe writes that description of the loaded library at any time;
  * ssba_rccl_ranks returns ncclCommCount of the handle's communicator (0 without one). */
-int ssba_rccl_describe(char *buf, uint64_t size);
-int ssba_rccl_ranks(ssba_problem *p, int *count);
+SSBA_API int ssba_rccl_describe(char *buf, uint64_t size);
+SSBA_API int ssba_rccl_ranks(ssba_problem *p, int *count);
 /* number of doubles in the per-iteration reduced-system exchange */
-int ssba_exchange_size(ssba_problem *p, uint64_t *count);
+SSBA_API int ssba_exchange_size(ssba_problem *p, uint64_t *count);
 
 /* Kernel timing with HIP events on the library's stream.  mode 0 = off, 1 = time every
  * kernel class (eager launches).  ssba_kernel_times returns up to `capacity` rows. */
@@ -227,8 +235,12 @@ typedef struct {
     uint64_t launches;
     double total_ms;
 } ssba_kernel_time;
-int ssba_set_kernel_timing(ssba_problem *p, int mode);
-int ssba_kernel_times(ssba_problem *p, ssba_kernel_time *rows, int32_t capacity, int32_t *num);
+SSBA_API int ssba_set_kernel_timing(ssba_problem *p, int mode);
+SSBA_API int ssba_kernel_times(ssba_problem *p, ssba_kernel_time *rows, int32_t capacity, int32_t *num);
+
+/* Diagnostic builds only (-DSSBA_STAMPS: tools/stamps_bcr.py, tools/bcr_bench.hip): copies the first n (<= 8192) in-kernel
+ * time stamps of the handle's debug buffer; the buffer stays zero in a normal build. */
+SSBA_API int ssba_debug_stamps(ssba_problem *p, unsigned long long *out, int n);
 
 /* Problem statistics after ssba_finalize. */
 typedef struct {
@@ -244,24 +256,24 @@ typedef struct {
     uint32_t pcr_fused;            /* 1: one launch per step of that reduction (no border columns, single GPU; SSBA_NO_PCR_FUSED=1 in the environment of a solve keeps factor + reduce launches) */
     uint32_t reserved_;
 } ssba_stats;
-int ssba_get_stats(ssba_problem *p, ssba_stats *st);
+SSBA_API int ssba_get_stats(ssba_problem *p, ssba_stats *st);
 
 /* Destroyed handles leave their device buffers, pinned host buffers and streams in a process-wide cache for the next
  * handle (drivers that solve thousands of small windows are bound by hipMalloc / hipFree otherwise); SSBA_POOL_MB caps
  * the cached device bytes (default 2048, 0 = no caching).  This call frees what is cached now. */
-int ssba_release_cached_memory(void);
+SSBA_API int ssba_release_cached_memory(void);
 
 /* ---- test hooks (parity tests call these through the C ABI) ------------------------ */
 /* Normal-equation blocks at the caller's current parameters, in user index order:
  * cost, g_p (P*6), g_l (L*3), H_pp (P*36 row-major), H_ll (L*9).  Blocks of constant
  * poses are zero.  Any output may be NULL. */
-int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, double *H_pp,
+SSBA_API int ssba_evaluate(ssba_problem *p, double *cost, double *g_p, double *g_l, double *H_pp,
                   double *H_ll);
 /* Dense reduced camera system S (n*n row-major, n = 6*num_free_poses) and rhs (n) for
  * trust-region radius `radius` at the caller's current parameters (S * delta_p = rhs),
  * and the step the device solver computes from it: delta_p (P*6), delta_l (L*3) and the
  * model cost change.  Any output may be NULL. */
-int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S,
+SSBA_API int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *S,
                  double *rhs, double *delta_p, double *delta_l, double *model_cost_change);
 /* The scalar state machine of the projected line search [Ceres 1.x line_search.cc ArmijoLineSearch::DoSearch, CUBIC
  * interpolation; bounds: tests/dataset_ba_phong.cpp:143-181] replayed on a given sequence of evaluations: phi(0),
@@ -269,7 +281,7 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
  * n).  on_device = 0 runs it on the host (no GPU needed), 1 in a one-lane kernel on `device` -- the solver uses both (the
  * search rounds enqueued with an iteration, and the searches handed back to the host) and they must agree bit for bit.
  * Returns the number of steps asked for (<= n), a negative status on error; *optimal_step = the accepted step or -1. */
-int ssba_armijo_trace(const double *values, const double *gradients, int32_t n, double initial_cost,
+SSBA_API int ssba_armijo_trace(const double *values, const double *gradients, int32_t n, double initial_cost,
                       double initial_gradient, double dir_max_norm, double *steps_out, double *optimal_step,
                       int32_t on_device, int32_t device);
 
@@ -317,20 +329,20 @@ int ssba_armijo_trace(const double *values, const double *gradients, int32_t n, 
  * DOGLEG with free shared blocks on more than one rank return SSBA_ERR_UNSUPPORTED. */
 #define SSBA_MAX_MATERIALS 15
 enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };
-int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);
-int ssba_add_material_blocks(ssba_problem *p, double *phong, double *texture, uint32_t num_materials,
+SSBA_API int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);
+SSBA_API int ssba_add_material_blocks(ssba_problem *p, double *phong, double *texture, uint32_t num_materials,
                              const uint32_t *material_of_point, uint32_t num_points);
-int ssba_add_light_block(ssba_problem *p, double *light, int light_type);
-int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant);
-int ssba_set_shared_block_bounds(ssba_problem *p, int which, int index, double lower, double upper);
-int ssba_add_lighting_observations(ssba_problem *p, const double *intensity,
+SSBA_API int ssba_add_light_block(ssba_problem *p, double *light, int light_type);
+SSBA_API int ssba_set_shared_block_constant(ssba_problem *p, int which, int is_constant);
+SSBA_API int ssba_set_shared_block_bounds(ssba_problem *p, int which, int index, double lower, double upper);
+SSBA_API int ssba_add_lighting_observations(ssba_problem *p, const double *intensity,
                                    double intensity_stiffness, const double *normal_obs,
                                    const double normal_stiffness[9], uint64_t num);
 /* test hook: the border of the last ssba_lm_step -- nb = 3 [light] + 3M [Phong] + M [texture] as
  * freed (that column order), S_pb (6*num_free_poses x nb), S_bb (nb x nb, damped), rhs_b (nb) of
  *   [S S_pb; S_pb^T S_bb] [delta_p; delta_b] = [rhs; rhs_b]
  * and the border step delta_b (nb).  Any output may be NULL. */
-int ssba_border_system(ssba_problem *p, uint32_t *nb, double *S_pb, double *S_bb, double *rhs_b,
+SSBA_API int ssba_border_system(ssba_problem *p, uint32_t *nb, double *S_pb, double *S_bb, double *rhs_b,
                        double *delta_b);
 
 /* ---- Phong-lighting rows: batch evaluation on the device ------ */
@@ -348,7 +360,7 @@ int ssba_border_system(ssba_problem *p, uint32_t *nb, double *S_pb, double *S_bb
  * light 3], local coordinates), r_nrm (n x 3), J_nrm_pose (n x 18), J_nrm_n (n x 9).
  * This is the arithmetic of BASELINE config 3; its solver integration (6-D landmark blocks,
  * shared light/material border, bounds) is the next row. */
-int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *poses,
+SSBA_API int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *poses,
                         const double *points, const double *normals, const double *phong,
                         const double *texture, const double light[3], const double *colour,
                         double stiffness, const double *normal_obs, const double normal_stiffness[9],
@@ -358,7 +370,7 @@ int ssba_phong_evaluate(int device, int light_type, uint64_t n, const double *po
 /* replaces: problem.SetParameterBlockConstant(map_vertices[j].position().data()) on EVERY position block (stage 2 of
  * --multistage, tests/dataset_ba_phong.cpp:210-228; SetParameterBlockVariable afterwards = 0).  Lighting problems only:
  * the landmark block is then the normal alone.  Before ssba_finalize. */
-int ssba_set_point_blocks_constant(ssba_problem *p, int is_constant);
+SSBA_API int ssba_set_point_blocks_constant(ssba_problem *p, int is_constant);
 
 /* ---- unary pose residual blocks (tests/dataset_vo_sun.cpp:80-124) ------- */
 /* ssba_add_pose_prior replaces problem.AddResidualBlock(PoseErrorAutomatic::Create(T_k_0_ref, stiffness), loss,
@@ -369,13 +381,13 @@ int ssba_set_point_blocks_constant(ssba_problem *p, int is_constant);
  *   azimuth / zenith of R * expected_dir_g against the observation, wrap-around, outlier thresholds; 2 residuals;
  *   stiffness 2x2 row-major.  huber_a > 0 wraps the block in ceres::HuberLoss(huber_a) (:87-92), 0 = NULL loss.
  * Both before ssba_finalize; not on constant poses; not together with lighting terms or landmark sharding yet. */
-int ssba_add_pose_prior(ssba_problem *p, uint32_t pose, const double T_ref[12], const double stiffness[36], double huber_a);
+SSBA_API int ssba_add_pose_prior(ssba_problem *p, uint32_t pose, const double T_ref[12], const double stiffness[36], double huber_a);
 /* ssba_add_relative_pose replaces problem.AddResidualBlock(RelativePoseErrorAutomatic::Create(T_2_1_ref, stiffness), loss,
  *   pose1, pose2) (include/ceres_slam/relative_pose_error.hpp:22-57; tests/blowup_test.cpp:70-76):
  *   r = stiffness * log(T_2_1_ref * T_1 * T_2^-1), 6 residuals.  Problems with such blocks run the general-structure kernels. */
-int ssba_add_relative_pose(ssba_problem *p, uint32_t pose1, uint32_t pose2, const double T_2_1_ref[12], const double stiffness[36],
+SSBA_API int ssba_add_relative_pose(ssba_problem *p, uint32_t pose1, uint32_t pose2, const double T_2_1_ref[12], const double stiffness[36],
                            double huber_a);
-int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observed_dir_c[3],
+SSBA_API int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observed_dir_c[3],
                              const double expected_dir_g[3], const double stiffness[4], double az_err_thresh,
                              double zen_err_thresh, double huber_a);
 
@@ -383,7 +395,7 @@ int ssba_add_sun_observation(ssba_problem *p, uint32_t pose, const double observ
  * (tests/dataset_vo_sun.cpp:159-183): cov (6x6 row-major) = that pose's block of (J^T J)^-1 in local (tangent)
  * coordinates at the caller's current parameters, i.e. of the inverse of the undamped reduced camera system.
  * SSBA_ERR_NUMERICAL_FAILURE when the system is rank deficient (Ceres: "Covariance computation failed"). */
-int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]);
+SSBA_API int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]);
 
 /* ---- front end: the VO initial guess --------------------------------- */
 /* ssba_frontend_ransac replaces, for `num_pairs` pairs of consecutive states at once,
@@ -409,17 +421,17 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]);
  * [state_start[k], state_start[k+1]) of point_id / uvd (3 per observation).  poses: num_states x 12, poses[0] is the input;
  * map_points (num_points x 3) and initialized (num_points flags) are updated for newly initialised landmarks only.
  * match_count / inlier_count (num_states - 1; may be NULL).  SSBA_ERR_NUMERICAL_FAILURE: a pair has fewer than 3 matches. */
-int ssba_frontend_vo(const ssba_camera *camera, int device, uint32_t num_states, const uint32_t *state_start,
+SSBA_API int ssba_frontend_vo(const ssba_camera *camera, int device, uint32_t num_states, const uint32_t *state_start,
                      const uint32_t *point_id, const double *uvd, uint32_t num_points, uint32_t num_iters, double thresh,
                      int libstdcxx_variant, double *poses, double *map_points, uint8_t *initialized, uint32_t *match_count,
                      uint32_t *inlier_count, double *device_time_s);
-int ssba_ransac_samples(uint32_t n, uint32_t num_iters, int libstdcxx_variant, uint32_t *idx3);
-int ssba_frontend_ransac(const ssba_camera *camera, int device, uint32_t num_pairs, const uint32_t *offset,
+SSBA_API int ssba_ransac_samples(uint32_t n, uint32_t num_iters, int libstdcxx_variant, uint32_t *idx3);
+SSBA_API int ssba_frontend_ransac(const ssba_camera *camera, int device, uint32_t num_pairs, const uint32_t *offset,
                          const double *pts0, const double *pts1, const uint32_t *samples, uint32_t num_iters,
                          double thresh, double *T, uint8_t *inlier, uint32_t *count, double *device_time_s);
 
-const char *ssba_status_string(int status);
-const char *ssba_last_error(void);
+SSBA_API const char *ssba_status_string(int status);
+SSBA_API const char *ssba_last_error(void);
 
 #ifdef __cplusplus
 }

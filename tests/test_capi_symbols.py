@@ -28,6 +28,17 @@ def test_every_header_symbol_is_exported():
         assert hasattr(lib, name), name
 
 
+def test_the_dynamic_symbol_table_is_exactly_the_header():
+    """libssba.so is linked next to torch's RCCL and user code: it defines the entry points of include/ssba.h and nothing
+    else (-fvisibility=hidden + csrc/libssba.map) -- no unprefixed globals, no ssba:: C++ symbols."""
+    import subprocess
+    hdr = open(os.path.join(ROOT, "include", "ssba.h")).read()
+    declared = set(re.findall(r"\b(ssba_[a-z_]+)\s*\(", hdr)) - {"ssba_exchange_fn"}
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build_library()], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert defined == declared, defined ^ declared
+
+
 def test_struct_layouts_match_header_sizes():
     # ssba_options: 8 int32 + 9 double + 2 int32 ; ssba_summary: 4 int32 + 4 double + 4 int32 (line-search counters)
     assert ctypes.sizeof(capi.Options) == 8 * 4 + 9 * 8 + 2 * 4
