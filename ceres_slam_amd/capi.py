@@ -79,7 +79,7 @@ class Stats(C.Structure):
                 ("num_windows", C.c_uint32), ("num_superblocks", C.c_uint32),
                 ("num_reduced_blocks", C.c_uint32), ("pose_bandwidth", C.c_uint32),
                 ("device_bytes", C.c_uint64), ("general_structure", C.c_uint32), ("pcr_blocks", C.c_uint32),
-                ("pcr_fused", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("pcr_fused", C.c_uint32), ("wide_superblocks", C.c_uint32)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int)

@@ -24,6 +24,7 @@
 #include <rccl/rccl.h>
 
 #include "ssba_launch.h"
+#include "ssba_wide_layout.h"
 #include "ssba_linesearch.h"
 #include "ssba_types.h"
 
@@ -55,6 +56,7 @@ struct ssba_problem {
     double S[9] = {0};
     bool have_S = false, per_obs_S = false, points_const = false;
     bool no_closure_border = false;     // a caller asked for something the closure border does not cover (DOGLEG, covariance): general path
+    bool no_wide = false;               // ... or something the 144-row super-blocks of ssba_wide.hip do not cover (covariance): blocked Cholesky
     std::vector<double> obs_S;          // 9 per observation once two stereo blocks differ in stiffness
     std::vector<uint8_t> pose_const;
     double huber_a = 0.0;
@@ -783,11 +785,11 @@ int ssba_set_partition(ssba_problem *p, const uint32_t *separator_superblocks, u
 int ssba_exchange_size(ssba_problem *p, uint64_t *count) {
     if (!p || !count) return SSBA_ERR_INVALID_ARGUMENT;
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
-    *count = p->d.part ? p->d.sepv_count : p->d.xv_count;
+    *count = p->d.part ? p->d.sepv_count : p->d.xv_count + (p->d.wide ? p->launcher.wide.count : 0);
     return SSBA_OK;
 }
 
-// diagnostic: raw in-kernel stamp buffer (only filled by -DSSBA_STAMPS builds); not in ssba.h
+// diagnostic: raw in-kernel stamp buffer (only filled by -DSSBA_STAMPS builds)
 int ssba_debug_stamps(ssba_problem *p, unsigned long long *out, int n) {
     if (!p || !p->finalized || n > 8192) return SSBA_ERR_INVALID_ARGUMENT;
     HIPCHECK(hipStreamSynchronize(p->launcher.stream));
@@ -885,8 +887,10 @@ int ssba_finalize(ssba_problem *p) {
     // per-landmark sorted pose sets; envelope checks.  The windowed layout needs tracks <= TW and a pose co-visibility
     // span <= SBP (block-tridiagonal reduced system); anything else takes the general path with a dense reduced system.
     bool dense = false, span_violation = false;
+    bool dense_only = false;            // something only the blocked Cholesky of the general path covers (not the 144-row super-blocks)
+    int max_span = 0;                   // largest free-pose distance inside one landmark's track
     std::vector<uint32_t> wide;         // landmarks whose free poses span more than SBP
-    struct LmInfo { uint32_t j, kmin, kmax; };
+    struct LmInfo { uint32_t j, kmin, kmax; int flo, fhi; };
     std::vector<LmInfo> order;
     order.reserve(L);
     std::vector<uint32_t> lm_pose_sorted(N);      // per landmark (lm_start range): its poses, ascending
@@ -907,19 +911,20 @@ int ssba_finalize(ssba_problem *p) {
             std::stable_sort(ob, ob + n, [&](uint32_t x, uint32_t y) { return p->obs_pose[x] < p->obs_pose[y]; });
             for (uint32_t e = 0; e < n; ++e) ks[e] = p->obs_pose[ob[e]];
         }
-        if (std::adjacent_find(ks, ks + n) != ks + n) dense = true;     // two residual blocks on one (pose, landmark): no window slot for the second
-        order.push_back({j, ks[0], ks[n - 1]});
+        if (std::adjacent_find(ks, ks + n) != ks + n) dense = dense_only = true;     // two residual blocks on one (pose, landmark): no window slot for the second
         int flo = 1 << 30, fhi = -1;
         for (uint32_t e = 0; e < n; ++e) { const int f = p->pose_free[ks[e]]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
+        order.push_back({j, ks[0], ks[n - 1], fhi >= 0 ? flo : -1, fhi});
         if (fhi - flo > SBP) { span_violation = true; wide.push_back(j); }
+        if (fhi >= 0) max_span = std::max(max_span, fhi - flo);
     }
     if (p->points_const && !ph) {
         set_error("constant position blocks are only available with lighting terms (stage 2 of --multistage)");
         return SSBA_ERR_UNSUPPORTED;
     }
-    if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = true;
-    if (p->per_obs_S) dense = true;     // per-block stiffness lives in the general layout only
-    if (!p->rel_factors.empty()) dense = true;     // pose-pose couplings outside the landmark structure
+    if (const char *e = getenv("SSBA_FORCE_DENSE")) if (e[0] == '1') dense = dense_only = true;
+    if (p->per_obs_S) dense = dense_only = true;     // per-block stiffness lives in the general layout only
+    if (!p->rel_factors.empty()) dense = dense_only = true;     // pose-pose couplings outside the landmark structure
     // Closure border: when the only thing outside the windowed envelope is the co-visibility span of a few landmarks
     // (a loop closure: the last states see landmarks of the first ones), the far poses of those landmarks -- at most
     // NBP / 6 = 5 -- leave the chain and become a dense border of the block-tridiagonal system, solved with the
@@ -968,7 +973,29 @@ int ssba_finalize(ssba_problem *p) {
         if (!ok) dense = true;
     }
     const int nborder = nfree - nchain;
-    if (dense) {
+    // Long tracks on block-cyclic machinery: a problem that left the windowed layout only because its tracks are longer than
+    // TW observations (free poses within a span of WSP) keeps the general observation layout, but its reduced system is block
+    // tridiagonal over super-blocks of WSP = 24 poses: matrix-core Schur items + parallel cyclic reduction on 144-row blocks
+    // (ssba_wide.hip) instead of the blocked Cholesky.  SSBA_NO_WIDE=1 keeps the blocked Cholesky (A/B, tests).
+    bool wide_sys = false;
+    if (dense && !dense_only && !ph && !p->no_wide && max_span <= WSP - 1 && nfree > 0) {
+        const char *e = getenv("SSBA_NO_WIDE");
+        wide_sys = !(e && e[0] == '1');
+    }
+    if (wide_sys && p->sep_sb.size() > 2) {
+        set_error("ssba_set_partition: the partitioned reduced solve is built for the windowed layout (tracks <= SSBA_MAX_TRACK); long tracks "
+                  "shard with the all-reduce of the reduced system (no partition)");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    if (dense && wide_sys) {
+        // device order = (first free pose, last free pose, landmark): Schur items are runs of consecutive landmarks
+        std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) {
+            const uint32_t fa = a.flo < 0 ? 0xFFFFFFFFu : (uint32_t)a.flo, fb = b.flo < 0 ? 0xFFFFFFFFu : (uint32_t)b.flo;
+            if (fa != fb) return fa < fb;
+            if (a.fhi != b.fhi) return a.fhi < b.fhi;
+            return a.j < b.j;
+        });
+    } else if (dense) {
         // the reduced system of the general path is stored as a dense lower triangle + right-hand-side rows; only its
         // structurally non-zero tiles are ever touched (symbolic factorisation below), so its size is bounded by memory,
         // not by time: SSBA_DENSE_MAX_GB (default 160 of the 288 GB of an MI355X; 10 000 free poses = 28.8 GB)
@@ -1044,6 +1071,7 @@ int ssba_finalize(ssba_problem *p) {
     std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
     std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b, dn_pose_mat_start, dn_ztile;
     DensePlan dplan;
+    WideLayout wlay;
     if (dense) {
         dn_lm_start.assign(Lpad + 1, 0);
         for (uint32_t l = 0; l < Lact; ++l) {
@@ -1088,6 +1116,14 @@ int ssba_finalize(ssba_problem *p) {
         // and pose b's records in ascending order instead of striding through a landmark-major array
         dn_zpos.resize(dn_obs_pose.size());
         for (uint32_t i = 0; i < dn_pose_obs.size(); ++i) dn_zpos[dn_pose_obs[i]] = i;
+        if (wide_sys) {     // 144-row super-blocks: Schur items, slot table, gather lists (no pair lists, no symbolic Cholesky)
+            if (!build_wide_layout(nfree, Lact, Lpad, dn_lm_start.data(), dn_obs_pose.data(), p->pose_free.data(), 128u, wlay)) {
+                set_error("internal: a landmark's free poses span more than the wide window");
+                return SSBA_ERR_STATE;
+            }
+        }
+    }
+    if (dense && !wide_sys) {
         // blocks (a <= b) of S = H_pp - sum_l Y_l W_l^T and, per block, the observation pairs (ea, eb) of one
         // landmark that contribute Y_ea W_eb^T; sorted by block so that one wave owns one block (no atomics)
         struct Pr { uint32_t a, b, ea, eb; };
@@ -1631,7 +1667,32 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.pf_data, data)); TRY(dupload(p, &d.pf_S, S)); TRY(dupload(p, &d.pf_huber, hub));
         TRY(dzero(p, &d.pf_cost, (size_t)P));
     }
-    if (dense) {
+    p->launcher.wide = WideSys{};
+    if (dense && wide_sys) {
+        d.dense = 1;
+        d.n_dn = 6 * nfree;
+        d.dn_pad = (d.n_dn + DN_BS - 1) / DN_BS * DN_BS;
+        TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
+        TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
+        TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs)); TRY(dupload(p, &d.dn_zpos, dn_zpos));
+        WideSys &w = p->launcher.wide;
+        const uint64_t wblk = (uint64_t)WBD * WBD;
+        w.n = wlay.n; w.n_items = (int)wlay.n_items; w.n_blk = (int)wlay.blk_a.size();
+        w.steps = 0;
+        for (int s2 = 1; s2 < w.n; s2 <<= 1) ++w.steps;
+        w.off_L = (uint64_t)w.n * wblk; w.off_rhs = 2 * (uint64_t)w.n * wblk; w.count = w.off_rhs + (uint64_t)w.n * WBD;
+        TRY(dzero(p, &w.xw, w.count));
+        TRY(dupload(p, &w.item_begin, wlay.item_begin)); TRY(dupload(p, &w.item_end, wlay.item_end)); TRY(dupload(p, &w.item_base, wlay.item_base));
+        TRY(dupload(p, &w.slot_obs, wlay.slot_obs));
+        TRY(dzero(p, &w.slab, (size_t)std::max<uint32_t>(wlay.n_items, 1) * WSLAB_DOUBLES));
+        TRY(dupload(p, &w.blk_a, wlay.blk_a)); TRY(dupload(p, &w.blk_b, wlay.blk_b));
+        TRY(dupload(p, &w.blk_start, wlay.blk_start)); TRY(dupload(p, &w.blk_contrib, wlay.blk_contrib));
+        TRY(dupload(p, &w.prow_start, wlay.prow_start)); TRY(dupload(p, &w.prow_contrib, wlay.prow_contrib));
+        TRY(dzero(p, &w.U, (size_t)w.n * wblk)); TRY(dzero(p, &w.YL, (size_t)w.n * wblk)); TRY(dzero(p, &w.YU, (size_t)w.n * wblk));
+        TRY(dzero(p, &w.yr, (size_t)w.n * WBD));
+        std::vector<WideSys> wv(1, w);
+        TRY(dupload(p, &d.wide, wv));
+    } else if (dense) {
         d.dense = 1;
         d.n_dn = 6 * nfree;
         d.dn_pad = (d.n_dn + DN_BS - 1) / DN_BS * DN_BS;
@@ -1679,6 +1740,7 @@ int ssba_finalize(ssba_problem *p) {
             if (configure_schur()) { set_error("hipFuncSetAttribute(k_schur_windows) failed"); return SSBA_ERR_HIP; }
             if (configure_kernels()) { set_error("hipFuncSetAttribute failed"); return SSBA_ERR_HIP; }
             if (configure_dense()) { set_error("hipFuncSetAttribute(k_dn_*_mf) failed"); return SSBA_ERR_HIP; }
+            if (configure_wide()) { set_error("hipFuncSetAttribute(k_wd_*) failed"); return SSBA_ERR_HIP; }
             flags |= 1;
         }
         if (ph && !(flags & 2)) {
@@ -1700,7 +1762,13 @@ int ssba_finalize(ssba_problem *p) {
     p->stats.general_structure = dense ? 1u : nborder ? 2u : 0u;      // 2: windowed layout + closure border
     p->stats.pcr_blocks = d.pcr.level >= 0 ? (uint32_t)d.pcr.n : 0u;
     p->stats.pcr_fused = d.pcrf.on ? 1u : 0u;
-    if (dense) {      // the dense reduced system: its non-zero blocks and the real co-visibility span
+    p->stats.wide_superblocks = 0;
+    if (dense && wide_sys) {
+        p->stats.num_reduced_blocks = (uint32_t)wlay.blk_a.size();
+        p->stats.pose_bandwidth = wlay.bandwidth;
+        p->stats.num_windows = wlay.n_items;
+        p->stats.wide_superblocks = (uint32_t)wlay.n;
+    } else if (dense) {      // the dense reduced system: its non-zero blocks and the real co-visibility span
         p->stats.num_reduced_blocks = (uint32_t)dn_blk_a.size();
         for (size_t i = 0; i < dn_blk_a.size(); ++i) p->stats.pose_bandwidth = std::max(p->stats.pose_bandwidth, dn_blk_b[i] - dn_blk_a[i]);
     }
@@ -1975,6 +2043,7 @@ static int enqueue_front(ssba_problem *p) {
     if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl, check_in_schur); }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
+        if (d.wide && (rc = X(L.wide.xw, L.wide.count, 0))) return rc;      // long tracks: the 144-row super-blocks [D | L | rhs]
         if ((rc = X(d.gmax_l, 1, 1))) return rc;
         if (d.nb) {     // free shared blocks: every rank holds the border sums of ITS landmarks
             if ((rc = X(d.Spb, (uint64_t)d.nf_pad * 6 * NBP, 0))) return rc;
@@ -2020,6 +2089,27 @@ static int reset_solver(ssba_problem *p) {
 // The closure border (loop closures as a dense border of the block-tridiagonal system, LM only) does not cover everything
 // the general-structure path does.  A caller that asks for one of those things on a handle that was finalized with a
 // border gets the other layout: ssba_finalize runs again from the host-side problem graph the handle still holds.
+// The same hand-over for the 144-row super-blocks of long tracks (ssba_wide.hip: no covariance sweep): the blocked Cholesky has one.
+static int refinalize_without_wide(ssba_problem *p, const char *what) {
+    if (p->began) {
+        set_error(std::string(what) + ": not available on this handle once a solve has begun (long tracks run on 144-row super-blocks; ask "
+                  "before the first solve, or set SSBA_NO_WIDE=1)");
+        return SSBA_ERR_STATE;
+    }
+    const double nf = (double)p->free_pose.size();
+    const double dn_gb = (6.0 * nf + 2 * DN_BS) * (6.0 * nf + DN_BS) * 8.0 / 1e9;
+    const char *mg = getenv("SSBA_DENSE_MAX_GB");
+    const double dn_cap = mg ? atof(mg) : 160.0;
+    if (p->world_size > 1 || dn_gb > dn_cap || (6 * (long)p->free_pose.size() + DN_BS) / DN_BS >= 65535) {
+        set_error(std::string(what) + ": needs the blocked Cholesky of the general path (single GPU, reduced system within SSBA_DENSE_MAX_GB)");
+        return SSBA_ERR_UNSUPPORTED;
+    }
+    p->no_wide = true;
+    p->finalized = false;
+    const int rc = ssba_finalize(p);
+    if (rc) { p->no_wide = false; p->finalized = false; }
+    return rc;
+}
 static int refinalize_without_closure_border(ssba_problem *p, const char *what) {
     if (p->began) {
         set_error(std::string(what) + ": not available on the closure border of this handle once a solve has begun (the loop closure was "
@@ -2522,7 +2612,25 @@ int ssba_lm_step(ssba_problem *p, const ssba_options *o, double radius, double *
     HIPCHECK(hipStreamSynchronize(L.stream));
     HIPCHECK(hipGetLastError());
     const int nf = d.nfree, n = 6 * nf;
-    if ((S || rhs) && d.dense) {      // lower triangle + the right-hand-side row of the dense matrix
+    if ((S || rhs) && d.wide) {       // block tridiagonal over super-blocks of WSP poses: D row-major, L[I] = S(I, I - 1)
+        const WideSys &w = L.wide;
+        std::vector<double> M((size_t)w.count);
+        HIPCHECK(hipMemcpy(M.data(), w.xw, M.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const size_t wb = (size_t)WBD * WBD;
+        if (S) {
+            memset(S, 0, (size_t)n * n * sizeof(double));
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    const int I = i / WBD, J = j / WBD;
+                    double v = 0.0;
+                    if (I == J) v = M[(size_t)I * wb + (size_t)(i % WBD) * WBD + (j % WBD)];
+                    else if (I == J + 1) v = M[w.off_L + (size_t)I * wb + (size_t)(i % WBD) * WBD + (j % WBD)];
+                    else if (J == I + 1) v = M[w.off_L + (size_t)J * wb + (size_t)(j % WBD) * WBD + (i % WBD)];
+                    S[(size_t)i * n + j] = v;
+                }
+        }
+        if (rhs) for (int i = 0; i < n; ++i) rhs[i] = M[w.off_rhs + i];
+    } else if ((S || rhs) && d.dense) {      // lower triangle + the right-hand-side row of the dense matrix
         std::vector<double> M((size_t)(d.dn_pad + 1) * d.dn_pad);
         if (!M.empty()) HIPCHECK(hipMemcpy(M.data(), d.dn_S, M.size() * sizeof(double), hipMemcpyDeviceToHost));
         if (S)
@@ -2611,6 +2719,10 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
     if (!p->finalized) return SSBA_ERR_NOT_FINALIZED;
     if (p->d.cb) {      // the closure border has no covariance sweep: the general path has (symbolic phase again, once)
         int rc = refinalize_without_closure_border(p, "covariance");
+        if (rc) return rc;
+    }
+    if (p->d.wide) {
+        int rc = refinalize_without_wide(p, "covariance");
         if (rc) return rc;
     }
     if (p->d.part || p->d.phong) {

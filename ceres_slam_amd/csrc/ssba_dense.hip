@@ -587,6 +587,7 @@ int configure_dense() {
     return hipFuncSetAttribute((const void *)k_dn_trsm_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_TRSM_LDS) == hipSuccess ? 0 : -1;
 }
 void launch_dense_schur(Launcher &L, const Dev &d) {
+    if (d.wide) { launch_wide_schur(L, d); return; }       // banded, tracks of <= 24 observations: 144-row super-blocks (ssba_wide.hip)
     LAUNCH(KC_SMALL, k_dn_zero_tiles, dim3(d.dn_nztile), dim3(256), 0, d);
     if (d.phong) {       // 6-D landmark blocks: C^-1 first, W / Y are 6x6 (ssba_phong_solver.hip)
         launch_ph_dense_wy(L, d);
@@ -601,10 +602,12 @@ void launch_dense_schur(Launcher &L, const Dev &d) {
 }
 
 void launch_dense_finish(Launcher &L, const Dev &d) {
+    if (d.wide) { launch_wide_finish(L, d); return; }
     LAUNCH(KC_SMALL, k_dn_finish, dim3((d.dn_pad + 255) / 256), dim3(256), 0, d);
 }
 
 void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows) {
+    if (d.wide) { launch_wide_solve(L, d); return; }       // (a wide handle never gets here with extra right-hand-side rows: ssba_api.hip)
     const DensePlan &pl = L.dense;
     const int nbk = pl.nbk;
     // SSBA_DENSE_VALU=1: the panel solve and the trailing update on the fp64 VALU (the r01 kernels; A/B partner, tests)

@@ -44,6 +44,7 @@ struct Launcher {
     hipStream_t stream = nullptr;
     int timing = 0;
     DensePlan dense;
+    WideSys wide{};              // host copy of the wide system's sizes and pointers (Dev::wide is the device copy), n = 0: none
     struct Pending { int cls; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -156,5 +157,10 @@ void launch_bcr_multi_rhs(Launcher &L, const Dev &d);
 void launch_dense_schur(Launcher &L, const Dev &d);
 void launch_dense_finish(Launcher &L, const Dev &d);
 void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows = 1);   // rows of the rhs block row to back-substitute
+// general layout, banded with tracks of <= WSP observations: 144-row super-blocks (ssba_wide.hip)
+int configure_wide();
+void launch_wide_schur(Launcher &L, const Dev &d);
+void launch_wide_finish(Launcher &L, const Dev &d);
+void launch_wide_solve(Launcher &L, const Dev &d);
 
 }  // namespace ssba

@@ -137,6 +137,34 @@ struct PcrFused {
     double *Lkeep, *Ukeep;                      // n x BD x BD each, or null
 };
 
+// Long tracks on block-cyclic machinery (ssba_wide.hip): landmarks with 13 .. WSP observations (free poses within a span of
+// WSP) give a reduced system that is block tridiagonal over super-blocks of WSP = 24 poses (WBD = 144 rows).  The problem
+// keeps the general (landmark-major) observation layout; the middle of the iteration -- Schur product, assembly, reduced
+// solve -- runs on 144-wide blocks: matrix-core Schur items over windows of 24 consecutive free poses, a gather into the
+// block-tridiagonal system, parallel cyclic reduction with one factor + one reduce launch per step.  The struct lives in
+// device memory (Dev has no room for it by value); the host keeps a copy for the launch shapes.
+constexpr int WSP = 24;                 // poses per wide super-block = slots of a wide window
+constexpr int WBD = 6 * WSP;            // 144 = 9 tiles of 16
+constexpr int WNT = WBD / 16;           // 9
+constexpr int WSLAB_TILES = WNT * (WNT + 1) / 2 + WNT;      // 45 upper tiles + 9 tiles of the gradient column
+constexpr int WSLAB_DOUBLES = WSLAB_TILES * 256;
+struct WideSys {
+    int n, steps, n_items, n_blk;       // super-blocks, PCR steps = ceil(log2 n), Schur items, non-zero 6x6 blocks (a <= b)
+    // exchange vector of the wide system: [D (n x WBD x WBD, row-major) | L (n: L[I] = S[I, I-1]) | rhs (n x WBD)]
+    double *xw;
+    uint64_t off_L, off_rhs, count;
+    // Schur items: landmarks [begin, end) whose free poses lie in [base, base + WSP); slot s = free pose base + s
+    const uint32_t *item_begin, *item_end, *item_base;
+    const uint32_t *slot_obs;           // Lpad x WSP: observation (index into dn_u / dn_v / dn_d) of (landmark, slot) or 0xFFFFFFFF
+    double *slab;                       // n_items x WSLAB_DOUBLES, tile-major
+    // gather lists: per block the (item * WSP * WSP + slot_a * WSP + slot_b) it sums, per free pose the (item * WSP + slot)
+    const uint32_t *blk_a, *blk_b, *blk_start, *blk_contrib;
+    const uint32_t *prow_start, *prow_contrib;
+    // parallel cyclic reduction
+    double *U;                          // n blocks: U[e] = S[e, e + stride] from the second step on
+    double *YL, *YU, *yr;               // G^-1 [L | U | r] of the current step
+};
+
 struct Dev {
     // camera, stiffness, loss
     double fu, fv, cu, cv, b;
@@ -265,6 +293,8 @@ struct Dev {
     int dn_nztile;                                  // what an iteration zero-fills instead of the whole dense array
     double *dn_S;                                   // (dn_pad + DN_BS) x dn_pad, row-major, lower triangle; row dn_pad holds the
                                                     // right-hand side, so the factorisation leaves L^-1 rhs there
+    // general layout, banded with tracks of <= WSP observations: block-tridiagonal system of 144-wide blocks (ssba_wide.hip)
+    const WideSys *wide;                            // device copy, or null
 };
 // Every kernel takes Dev by value: explicit kernel arguments are limited to 4 KB, and the hidden arguments of the code
 // object (256 B) and the handful of scalars beside Dev have to fit next to it.

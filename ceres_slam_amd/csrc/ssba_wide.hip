@@ -1,0 +1,619 @@
+// Long tracks at windowed-path speed: the middle of the iteration for banded problems whose landmarks have up to WSP = 24
+// observations (ssba_types.h: WideSys).  Ceres takes whatever graph the dataset holds (tests/dataset_vo.cpp:41-56); stereo
+// tracks of 13 .. 24 frames are routine, and the 12-slot windows / 72-row super-blocks of ssba_kernels.hip do not hold them.
+// Such problems keep the general (landmark-major) layout for linearisation, back-substitution and trust-region control and
+// run, instead of the dense blocked Cholesky of ssba_dense.hip (a chain of n / 64 dependent potrf -> trsm -> syrk launches):
+//
+//   k_wd_schur     one 512-lane workgroup per window of 24 consecutive free poses: batches of 21 landmarks are half-linearised
+//                  by 504 (landmark, slot) producer lanes (W = J_p^T J_l recomputed, never stored; Z = W M^T with C^-1 = M^T M),
+//                  staged k-major in LDS (64 x 176 doubles; column 144 carries M g_l) and  S[144 x 145] += Zm^T Zm  is
+//                  accumulated output-stationary on v_mfma_f64_16x16x4_f64 by the eight waves: 45 upper tiles + 9 tiles of the
+//                  gradient column, 7 / 7 / 7 / 7 / 7 / 7 / 7 / 5 per wave in row segments (the A operand is read once per
+//                  segment and k-step).  One slab (54 tiles) per item, every entry one sum in landmark order: no atomics.
+//   k_wd_assemble  gather of the slabs into the block-tridiagonal system over super-blocks of 24 poses (D, L row-major
+//                  144 x 144, rhs) through host-built lists, fixed order; H_pp on the diagonal blocks
+//   k_wd_finish    Jacobi scale at iteration 0, LM damping on the diagonal, identity on the padding rows
+//   k_wd_factor    parallel cyclic reduction, step s: every block e factors D_e = U^T U in LDS (16 x 16 tiles: diagonal tile by
+//                  one wave with the inverse of its factor built alongside, row panel and trailing update on the matrix cores)
+//                  and solves  [YL | YU | yr] = U^-T [S(e, e-s) | S(e, e+s) | r]  with the right-hand-side tiles in accumulator
+//                  registers (one 16-column tile per wave, three workgroups per block each repeating the factorisation)
+//   k_wd_reduce    one wave per 16 x 16 output tile:  D' = D - YU(e-s)^T YU(e-s) - YL(e+s)^T YL(e+s),  r' likewise,
+//                  S'(e, e-2s) = -YU(e-s)^T YL(e-s),  S'(e, e+2s) = -YL(e+s)^T YU(e+s)   (operands straight from L2)
+//   k_wd_factor<1> after ceil(log2 n) steps the blocks are decoupled: factor, forward and backward solve, pose step into x0
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssba_device.h"
+#include "ssba_launch.h"
+#include "ssba_types.h"
+
+namespace ssba {
+
+typedef double wd4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ wd4 wmf(double a, double b, wd4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+static __device__ __forceinline__ double wd_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+// slab tiles: row tile i <= column tile j <= WNT (column tile WNT = the gradient column); upper tiles of a 9 x 9 block
+static __host__ __device__ __forceinline__ int wd_slab_tile(int i, int j) { return i * (WNT + 1) - (i * (i - 1)) / 2 + (j - i); }
+static __host__ __device__ __forceinline__ int wd_utile(int i, int j) { return i * WNT - (i * (i - 1)) / 2 + (j - i); }
+
+// ---- Schur items ---------------------------------------------------------------------------------------------
+constexpr int WS_THREADS = 512;
+constexpr int WS_BATCH = 21;                    // landmarks per batch: 21 x 24 slots = 504 producer lanes
+constexpr int WS_KB = 64;                       // 63 factor rows + one zero row = 16 matrix steps of k = 4
+constexpr int WS_RS = 176;                      // row stride of Zm: 352 words = 32 mod 64, the two k-groups of a half-wave read disjoint banks
+constexpr int WS_LDS_DOUBLES = WS_KB * WS_RS;   // 90 112 B
+
+__global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d) {
+    const State &st = *d.st;
+    const WideSys &w = *d.wide;
+    const int dead = st.terminated | st.dl_reuse;       // tested once the first operand reads are in flight
+    extern __shared__ __align__(16) double wd_lds[];
+    double *sZ = wd_lds;
+    const int item = (int)blockIdx.x;
+    const int lb = (int)w.item_begin[item], le = (int)w.item_end[item], base = (int)w.item_base[item];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool producer = t < WS_BATCH * WSP;
+    const int li = t / WSP, s = t - li * WSP;
+    // tiles of this wave: segment A = row wv from column colA0 (nA tiles), segment B fills the waves with short rows
+    const int rowA = wv, colA0 = wv, nA = wv < 4 ? 7 : WNT + 1 - wv;
+    const int rowB = wv == 4 ? 2 : wv == 5 ? 1 : wv == 6 ? 0 : 8;
+    const int colB0 = wv == 4 ? 9 : wv == 5 ? 8 : wv == 6 ? 7 : 8;
+    const int nB = wv < 4 ? 0 : wv == 4 ? 1 : wv == 5 ? 2 : wv == 6 ? 3 : 2;
+    wd4 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc[q] = wd4{0.0, 0.0, 0.0, 0.0};
+
+    // columns 145..159 (read by the gradient-column tiles) and the zero row k = 63 stay zero for the whole item
+    // (column 144 of the rows 0..62 is rewritten by the producers every batch: not touched here, so no barrier is needed)
+    for (int e = t; e < WS_KB * 15; e += WS_THREADS) sZ[(e / 15) * WS_RS + WBD + 1 + (e % 15)] = 0.0;
+    if (t <= WBD) sZ[(WS_KB - 1) * WS_RS + t] = 0.0;
+
+    bool pose_ok = false;
+    double T[12];
+    if (producer) {
+        const int f = base + s;
+        pose_ok = f < d.nfree;
+        if (pose_ok) {
+            const int k = d.free_pose[f];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) T[i] = d.poses[(size_t)k * 12 + i];
+        }
+    }
+    // raw inputs of this lane's (landmark, slot): the observation index two batches ahead, its data one batch ahead -- both
+    // stay in flight across the matrix phase of the batch before
+    struct Raw { double u, v, dd, h[6], sc[3], p[3], g[3]; bool in_range, have; } raw;
+    uint32_t e_next = 0xFFFFFFFFu;
+    auto fetch_slot = [&](int l0) {
+        const int l = l0 + li;
+        e_next = (producer && l < le) ? w.slot_obs[(size_t)l * WSP + s] : 0xFFFFFFFFu;
+    };
+    auto prefetch = [&](int l0) {
+        const int l = l0 + li;
+        raw.in_range = producer && l < le;
+        raw.have = raw.in_range && pose_ok && e_next != 0xFFFFFFFFu;
+        if (raw.in_range) {
+            if (raw.have) { raw.u = d.dn_u[e_next]; raw.v = d.dn_v[e_next]; raw.dd = d.dn_d[e_next]; }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) raw.h[c] = d.hll[(size_t)c * d.Lpad + l];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                raw.sc[c] = d.sl[(size_t)c * d.Lpad + l];
+                raw.p[c] = d.pts[(size_t)c * d.Lpad + l];
+                raw.g[c] = d.gl[(size_t)c * d.Lpad + l];
+            }
+        }
+    };
+    fetch_slot(lb);
+    prefetch(lb);
+    fetch_slot(lb + WS_BATCH);
+    if (dead) return;
+
+    for (int l0 = lb; l0 < le; l0 += WS_BATCH) {
+        if (producer) {
+            double z[18];       // [c][a]: three runs of six contiguous doubles in the k-major matrix
+            double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (raw.in_range) {
+                double dmp[3];
+                const double hd[3] = {raw.h[0], raw.h[3], raw.h[5]};
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
+                    const double s2 = raw.sc[c] * raw.sc[c];
+                    dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
+                }
+                if (!chol3_inv_fast(raw.h, dmp, m)) {
+                    d.st->step_failed = 1;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) m[c] = 0.0;
+                }
+            }
+            if (s == 0) {       // u = M g_l
+                sZ[(li * 3 + 0) * WS_RS + WBD] = raw.in_range ? m[0] * raw.g[0] : 0.0;
+                sZ[(li * 3 + 1) * WS_RS + WBD] = raw.in_range ? m[1] * raw.g[0] + m[2] * raw.g[1] : 0.0;
+                sZ[(li * 3 + 2) * WS_RS + WBD] = raw.in_range ? m[3] * raw.g[0] + m[4] * raw.g[1] + m[5] * raw.g[2] : 0.0;
+            }
+            if (raw.have) {
+                ObsLin o;
+                obs_linearize(d, T, raw.p[0], raw.p[1], raw.p[2], raw.u, raw.v, raw.dd, o);
+                double Jp[18], Jl[9];
+                jac_pose(o, Jp);
+                jac_point(o, T, Jl);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double wa[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) wa[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
+                    z[a] = wa[0] * m[0];                                      // Z = W M^T
+                    z[6 + a] = wa[0] * m[1] + wa[1] * m[2];
+                    z[12 + a] = wa[0] * m[3] + wa[1] * m[4] + wa[2] * m[5];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) z[i] = 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double2 *dz = reinterpret_cast<double2 *>(sZ + (li * 3 + c) * WS_RS + s * 6);     // 48-byte runs, 16-byte aligned
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dz[q] = make_double2(z[6 * c + 2 * q], z[6 * c + 2 * q + 1]);
+            }
+        }
+        __syncthreads();
+        prefetch(l0 + WS_BATCH);
+        fetch_slot(l0 + 2 * WS_BATCH);
+        {
+            const int kq = lane >> 4, i = lane & 15;
+            const double *zb = sZ + kq * WS_RS + i;
+#pragma unroll 2
+            for (int ks = 0; ks < WS_KB / 4; ++ks) {
+                const double *zr = zb + 4 * ks * WS_RS;
+                const double aA = zr[16 * rowA], aB = zr[16 * rowB];
+                double b[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) b[q] = zr[16 * (q < nA ? colA0 + q : colB0 + (q - nA))];
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q < nA + nB) acc[q] = wmf(q < nA ? aA : aB, b[q], acc[q]);
+            }
+        }
+        __syncthreads();
+    }
+    // one slab per item, tile-major: a register of a tile is 512 contiguous bytes
+    double *out = w.slab + (size_t)item * WSLAB_DOUBLES;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        if (q >= nA + nB) continue;
+        const int ti = q < nA ? rowA : rowB, tj = q < nA ? colA0 + q : colB0 + (q - nA);
+        double *pt = out + (size_t)wd_slab_tile(ti, tj) * 256 + (lane >> 4) * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pt[64 * r] = acc[q][r];
+    }
+}
+
+static __device__ __forceinline__ int wd_tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
+
+// one thread per (non-zero 6 x 6 block, element) + one per entry of the reduced gradient
+__global__ __launch_bounds__(256) void k_wd_assemble(Dev d) {
+    const State &st = *d.st;
+    const WideSys &w = *d.wide;
+    const int dead = st.terminated | st.dl_reuse;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_el = (size_t)w.n_blk * 36;
+    const size_t blk = (size_t)WBD * WBD;
+    if (gid < n_el) {
+        const uint32_t b = (uint32_t)(gid / 36);
+        const int e = (int)(gid - (size_t)b * 36);
+        const int r = e / 6, c = e - r * 6;
+        const uint32_t fa = w.blk_a[b], fb = w.blk_b[b];
+        const uint32_t ib = w.blk_start[b], ie = w.blk_start[b + 1];
+        if (dead) return;
+        int er = r, ec = c;
+        if (fa == fb && c < r) { er = c; ec = r; }      // the upper entry of a diagonal block: always inside a computed tile
+        double v = 0.0;
+        for (uint32_t i0 = ib; i0 < ie; i0 += 8) {
+            uint32_t cw[8];
+            double x[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cw[q] = i0 + q < ie ? w.blk_contrib[i0 + q] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                x[q] = 0.0;
+                if (cw[q] != 0xFFFFFFFFu) {
+                    const uint32_t it = cw[q] / (WSP * WSP), sp = cw[q] - it * (WSP * WSP);
+                    const int sa = (int)(sp / WSP), sb = (int)(sp - (uint32_t)sa * WSP);
+                    const int row = 6 * sa + er, col = 6 * sb + ec;
+                    x[q] = w.slab[(size_t)it * WSLAB_DOUBLES + (size_t)wd_slab_tile(row >> 4, col >> 4) * 256 + (row & 15) * 16 + (col & 15)];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += x[q];
+        }
+        v = -v;
+        if (fa == fb) v += d.hpp[(size_t)d.free_pose[fa] * 21 + wd_tri21(min(r, c), max(r, c))];
+        const uint32_t Ia = fa / WSP, Ib = fb / WSP;
+        const int row = (int)(fa - Ia * WSP) * 6 + r, col = (int)(fb - Ib * WSP) * 6 + c;
+        if (Ia == Ib) {
+            w.xw[(size_t)Ia * blk + (size_t)row * WBD + col] = v;
+            if (fa != fb) w.xw[(size_t)Ia * blk + (size_t)col * WBD + row] = v;
+        } else {        // S(Ia rows, Ib columns), Ib = Ia + 1: stored in L[Ib] = S(Ib, Ia) at (col, row)
+            w.xw[w.off_L + (size_t)Ib * blk + (size_t)col * WBD + row] = v;
+        }
+    } else if (dead) {
+        return;
+    } else if (gid < n_el + (size_t)d.nfree * 6) {
+        const size_t i = gid - n_el;
+        const uint32_t f = (uint32_t)(i / 6);
+        const int c = (int)(i - (size_t)f * 6);
+        const int k = d.free_pose[f];
+        const double g = d.gp[(size_t)k * 6 + c];
+        double v = g;
+        for (uint32_t j = w.prow_start[f]; j < w.prow_start[f + 1]; ++j) {
+            const uint32_t cw = w.prow_contrib[j], it = cw / WSP;
+            const int row = 6 * (int)(cw - it * WSP) + c;
+            v -= w.slab[(size_t)it * WSLAB_DOUBLES + (size_t)wd_slab_tile(row >> 4, WNT) * 256 + (row & 15) * 16];
+        }
+        w.xw[w.off_rhs + i] = -v;              // right-hand side = -reduced gradient (linear in the ranks' partial sums)
+        d.xv[d.off_gp + i] = g;
+        d.xv[d.off_hdiag + i] = d.hpp[(size_t)k * 21 + wd_tri21(c, c)];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wd_finish(Dev d) {
+    const State &st = *d.st;
+    const WideSys &w = *d.wide;
+    if (st.terminated || st.dl_reuse) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w.n * WBD) return;
+    const int I = i / WBD, r = i - I * WBD;
+    double *Dd = w.xw + (size_t)I * WBD * WBD + (size_t)r * WBD + r;
+    if (i < 6 * d.nfree) {
+        const double h = d.xv[d.off_hdiag + i];
+        if (st.iteration == 0) d.sp[i] = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0;
+        const double s = d.sp[i], s2 = s * s;
+        *Dd += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
+    } else {        // padding of the last super-block (its off-diagonal entries were allocated as zeros and are never written)
+        *Dd = 1.0;
+        w.xw[w.off_rhs + i] = 0.0;
+    }
+}
+
+// ---- parallel cyclic reduction over 144-row blocks ------------------------------------------------------------
+constexpr int WF_THREADS = 512;
+constexpr int WF_NU = WNT * (WNT + 1) / 2;      // 45 upper tiles of U
+constexpr int WF_LDS_DOUBLES = (WF_NU + WNT) * 256 + 2 * WBD + 32;      // U tiles | W = U_kk^-1 tiles | y | x | t
+
+// Diagonal tile (one wave): T = L L^T by columns with lane r holding row r (pivot column by v_readlane), and M = L^-1 built
+// alongside (row r of M in lane r: its updates are independent of the pivot chain and fill its latency).  Leaves U = L^T in
+// T (row-major, zeros below the diagonal) and Wt = U^-1 = M^T in W (row-major).
+static __device__ __forceinline__ bool wd_potrf_inv(double *__restrict__ T, double *__restrict__ W, int lane) {
+    const int r = lane & 15;
+    double a[16], tm[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { a[c] = T[r * 16 + c]; tm[c] = (c == r) ? 1.0 : 0.0; }
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const double piv = wd_readlane(a[c], c);
+        bad = bad || !(piv > 0.0) || !(piv < INFINITY);
+        const double rs = fast_rsqrt(piv);
+        const double l = a[c] * rs;       // L[r][c]
+        a[c] = l;
+#pragma unroll
+        for (int cc = c + 1; cc < 16; ++cc) a[cc] -= l * wd_readlane(l, cc);
+        // row c of M is final: M[c][j] = tm_c[j] / L[c][c]; the rows below subtract L[r][c] M[c][j]
+#pragma unroll
+        for (int j = 0; j <= c; ++j) {
+            const double fin = tm[j] * rs;
+            const double mc = wd_readlane(fin, c);
+            tm[j] = (r == c) ? fin : (r > c) ? tm[j] - l * mc : tm[j];      // (a finished row stays where it is)
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            T[c * 16 + r] = (c <= r) ? a[c] : 0.0;         // U[c][r] = L[r][c]
+            W[c * 16 + r] = (c <= r) ? tm[c] : 0.0;        // (U^-1)[c][r] = M[r][c]
+        }
+    }
+    return !bad;
+}
+// X = Wt^T T in place (Wt = U_kk^-1, row-major; T a 16 x 16 tile, row-major)
+static __device__ __forceinline__ void wd_tile_solve(const double *__restrict__ Wt, double *__restrict__ T, int lane) {
+    const int kq = lane >> 4, i = lane & 15;
+    wd4 acc = {0.0, 0.0, 0.0, 0.0};
+    double a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { a[s] = Wt[(4 * s + kq) * 16 + i]; b[s] = T[(4 * s + kq) * 16 + i]; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = wmf(a[s], b[s], acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[(4 * q + kq) * 16 + i] = acc[q];
+}
+// T_ij -= U_ki^T U_kj
+static __device__ __forceinline__ void wd_tile_update(const double *__restrict__ Uki, const double *__restrict__ Ukj, double *__restrict__ Tij, int lane) {
+    const int kq = lane >> 4, i = lane & 15;
+    wd4 acc;
+    double a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { a[s] = -Uki[(4 * s + kq) * 16 + i]; b[s] = Ukj[(4 * s + kq) * 16 + i]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = Tij[(4 * q + kq) * 16 + i];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = wmf(a[s], b[s], acc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Tij[(4 * q + kq) * 16 + i] = acc[q];
+}
+
+// FINAL = 0: a step of the reduction (grid n x ng, the right-hand-side tiles of [L | U | r] dealt to the 8 waves of ng
+// workgroups);  FINAL = 1: the decoupled last step (grid n): factor, forward and backward solve, pose step into x0
+template <int FINAL>
+__global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int ng) {
+    const WideSys &w = *d.wide;
+    const StateFlags sf = state_flags_vmem(d.st);
+    extern __shared__ __align__(16) double wf_lds[];
+    double *sU = wf_lds, *sW = wf_lds + WF_NU * 256, *sy = sW + WNT * 256, *sx = sy + WBD, *stv = sx + WBD;
+    __shared__ int s_bad;
+    const int e = (int)blockIdx.x / ng, part = (int)blockIdx.x - e * ng;
+    const int n = w.n, s = 1 << step;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, g = lane >> 4, jj = lane & 15;
+    const size_t blk = (size_t)WBD * WBD;
+    const bool hasL = !FINAL && e - s >= 0, hasU = !FINAL && e + s < n;
+    const double *Dg = w.xw + (size_t)e * blk;
+    const double *Lg = w.xw + w.off_L + (size_t)e * blk;
+    // S(e, e + s): the transpose of L[e + 1] in the first step, the reduce kernel's output afterwards
+    const double *Ug = step == 0 ? w.xw + w.off_L + (size_t)(hasU ? e + 1 : e) * blk : w.U + (size_t)e * blk;
+    const double *rg = w.xw + w.off_rhs + (size_t)e * WBD;
+    // this wave's column tile of [L | U | r]: waves 1..7 (wave 0 factors the diagonal tiles: it carries none)
+    const int c = wv == 0 ? -1 : FINAL ? (wv == 1 ? 2 * WNT : -1) : part + ng * (wv - 1);
+    const bool act = c >= 0 && c <= 2 * WNT && (c < WNT ? hasL : c < 2 * WNT ? hasU : true);
+    if (t == 0) s_bad = 0;
+    wd4 rt[WNT];
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) rt[j] = wd4{0.0, 0.0, 0.0, 0.0};
+    if (act) {
+        if (c == 2 * WNT) {
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rt[j][q] = jj == 0 ? rg[16 * j + 4 * q + g] : 0.0;
+        } else if (c < WNT) {
+            const double *pp = Lg + (size_t)g * WBD + 16 * c + jj;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rt[j][q] = pp[(16 * j + 4 * q) * WBD];
+        } else if (step == 0) {
+            const double *pp = Ug + (size_t)(16 * (c - WNT) + jj) * WBD + g;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rt[j][q] = pp[16 * j + 4 * q];
+        } else {
+            const double *pp = Ug + (size_t)g * WBD + 16 * (c - WNT) + jj;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rt[j][q] = pp[(16 * j + 4 * q) * WBD];
+        }
+    }
+    // upper tiles of D into LDS, tile by tile (row-major 16 x 16)
+    {
+        int ti = 0, tj = 0;
+        for (int tl = 0; tl < WF_NU; ++tl) {
+            if ((tl & 7) == wv) {
+                const double *pp = Dg + (size_t)(16 * ti + g) * WBD + 16 * tj + jj;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sU[tl * 256 + (4 * q + g) * 16 + jj] = pp[(size_t)4 * q * WBD];
+            }
+            if (++tj == WNT) { ++ti; tj = ti; }
+        }
+    }
+    if (sf.dead()) return;
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < WNT; ++k) {
+        // (a) diagonal tile
+        if (wv == 0) {
+            if (!wd_potrf_inv(sU + wd_utile(k, k) * 256, sW + k * 256, lane)) s_bad = 1;
+        }
+        __syncthreads();
+        // (b) row panel U_kj = U_kk^-T T_kj (one tile per wave) and block row k of the right-hand sides
+        {
+            const int j = k + 1 + wv;
+            if (j < WNT) wd_tile_solve(sW + k * 256, sU + wd_utile(k, j) * 256, lane);
+            if (act) {
+                wd4 y = {0.0, 0.0, 0.0, 0.0};
+                double a[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = sW[k * 256 + (4 * q + g) * 16 + jj];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y = wmf(a[q], rt[k][q], y);
+                rt[k] = y;
+            }
+        }
+        __syncthreads();
+        // (c) trailing update of the tiles (i, j), k < i <= j, dealt to the waves; the right-hand sides below block row k
+        {
+            int cnt = 0;
+#pragma unroll
+            for (int i = k + 1; i < WNT; ++i)
+#pragma unroll
+                for (int j = i; j < WNT; ++j, ++cnt)
+                    if ((cnt & 7) == wv) wd_tile_update(sU + wd_utile(k, i) * 256, sU + wd_utile(k, j) * 256, sU + wd_utile(i, j) * 256, lane);
+            if (act) {
+#pragma unroll
+                for (int j = k + 1; j < WNT; ++j) {
+                    double a[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a[q] = -sU[wd_utile(k, j) * 256 + (4 * q + g) * 16 + jj];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rt[j] = wmf(a[q], rt[k][q], rt[j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (s_bad) {        // non-positive pivot: Cholesky breakdown, the step is rejected (Ceres: LM retries with a smaller radius)
+        if (t == 0) d.st->step_failed = 1;
+        return;
+    }
+    if (!FINAL) {
+        if (!act) return;
+        if (c == 2 * WNT) {
+            double *py = w.yr + (size_t)e * WBD;
+            if (jj == 0) {
+#pragma unroll
+                for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) py[16 * j + 4 * q + g] = rt[j][q];
+            }
+        } else {
+            double *pp = (c < WNT ? w.YL : w.YU) + (size_t)e * blk + (size_t)g * WBD + 16 * (c < WNT ? c : c - WNT) + jj;
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pp[(16 * j + 4 * q) * WBD] = rt[j][q];
+        }
+        return;
+    }
+    // ---- decoupled block: U x = y by block rows from the bottom (the wave that holds y) ------------------------
+    if (wv != 1) return;
+    if (jj == 0) {
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sy[16 * j + 4 * q + g] = rt[j][q];
+    }
+    const int i = lane & 15, pt = lane >> 4;
+#pragma unroll
+    for (int k = WNT - 1; k >= 0; --k) {
+        double p = 0.0;
+#pragma unroll
+        for (int j = k + 1; j < WNT; ++j) {
+            const double *Ukj = sU + wd_utile(k, j) * 256 + i * 16;
+#pragma unroll
+            for (int cq = 0; cq < 4; ++cq) p += Ukj[pt + 4 * cq] * sx[16 * j + pt + 4 * cq];
+        }
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        if (lane < 16) stv[i] = sy[16 * k + i] - p;
+        const double *Wk = sW + k * 256 + i * 16;
+        double xk = 0.0;
+#pragma unroll
+        for (int cq = 0; cq < 4; ++cq) xk += Wk[pt + 4 * cq] * stv[pt + 4 * cq];
+        xk += __shfl_xor(xk, 16, 64);
+        xk += __shfl_xor(xk, 32, 64);
+        if (lane < 16) sx[16 * k + i] = xk;
+    }
+    for (int r = lane; r < WBD; r += 64) {
+        const size_t row = (size_t)e * WBD + r;
+        if (row < (size_t)d.nfree * 6) d.x0[row] = sx[r];
+    }
+}
+
+// one wave per 16 x 16 output tile of block e: jobs 0..44 tiles of D' (upper), 45..53 block rows of r', 54..134 tiles of
+// S'(e, e - 2s), 135..215 tiles of S'(e, e + 2s)
+constexpr int WR_JOBS = WF_NU + WNT + 2 * WNT * WNT;        // 216
+constexpr int WR_WG_PER_BLOCK = WR_JOBS / 4;                // 54 workgroups of four waves
+
+// acc -= A[:, 16 ti ..]^T B[:, 16 tj ..]  over the 144 rows (B = a vector in column 0 when bvec)
+static __device__ __forceinline__ wd4 wd_product(const double *__restrict__ A, const double *__restrict__ B, int ti, int tj, bool bvec, wd4 acc, int lane) {
+    const int kq = lane >> 4, i = lane & 15;
+    const double *pa = A + (size_t)kq * WBD + 16 * ti + i;
+    double a[WBD / 4], b[WBD / 4];
+    if (bvec) {
+#pragma unroll
+        for (int ks = 0; ks < WBD / 4; ++ks) { a[ks] = pa[(size_t)4 * ks * WBD]; b[ks] = i == 0 ? B[4 * ks + kq] : 0.0; }
+    } else {
+        const double *pb = B + (size_t)kq * WBD + 16 * tj + i;
+#pragma unroll
+        for (int ks = 0; ks < WBD / 4; ++ks) { a[ks] = pa[(size_t)4 * ks * WBD]; b[ks] = pb[(size_t)4 * ks * WBD]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < WBD / 4; ++ks) acc = wmf(-a[ks], b[ks], acc);
+    return acc;
+}
+
+__global__ __launch_bounds__(256, 2) void k_wd_reduce(Dev d, int step) {
+    const WideSys &w = *d.wide;
+    const StateFlags sf = state_flags_vmem(d.st);
+    const int e = (int)blockIdx.x / WR_WG_PER_BLOCK;
+    const int lane = threadIdx.x & 63, g = lane >> 4, jj = lane & 15;
+    const int job = ((int)blockIdx.x - e * WR_WG_PER_BLOCK) * 4 + (threadIdx.x >> 6);
+    const int n = w.n, s = 1 << step, prev = e - s, next = e + s;
+    const size_t blk = (size_t)WBD * WBD;
+    const bool hasP = prev >= 0, hasN = next < n;
+    if (sf.dead()) return;
+    if (job < WF_NU + WNT) {
+        if (!hasP && !hasN) return;
+        const bool vec = job >= WF_NU;
+        int ti = 0, tj = 0;
+        if (vec) { ti = job - WF_NU; tj = 0; }
+        else { int q = job; while (q >= WNT - ti) { q -= WNT - ti; ++ti; } tj = ti + q; }
+        wd4 acc;
+        double *out = vec ? w.xw + w.off_rhs + (size_t)e * WBD + 16 * ti + g : w.xw + (size_t)e * blk + (size_t)(16 * ti + g) * WBD + 16 * tj + jj;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = vec ? (jj == 0 ? out[4 * q] : 0.0) : out[(size_t)4 * q * WBD];
+        if (hasP) acc = wd_product(w.YU + (size_t)prev * blk, vec ? w.yr + (size_t)prev * WBD : w.YU + (size_t)prev * blk, ti, tj, vec, acc, lane);
+        if (hasN) acc = wd_product(w.YL + (size_t)next * blk, vec ? w.yr + (size_t)next * WBD : w.YL + (size_t)next * blk, ti, tj, vec, acc, lane);
+        if (vec) {
+            if (jj == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[4 * q] = acc[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out[(size_t)4 * q * WBD] = acc[q];
+        }
+        return;
+    }
+    const bool lower = job < WF_NU + WNT + WNT * WNT;
+    const int q2 = job - (WF_NU + WNT) - (lower ? 0 : WNT * WNT);
+    const int ti = q2 / WNT, tj = q2 - ti * WNT;
+    wd4 acc = {0.0, 0.0, 0.0, 0.0};
+    double *out;
+    if (lower) {        // S'(e, e - 2s) = -YU(prev)^T YL(prev): needs prev and its own lower neighbour
+        if (!hasP || prev - s < 0) return;
+        acc = wd_product(w.YU + (size_t)prev * blk, w.YL + (size_t)prev * blk, ti, tj, false, acc, lane);
+        out = w.xw + w.off_L + (size_t)e * blk;
+    } else {            // S'(e, e + 2s) = -YL(next)^T YU(next)
+        if (!hasN || next + s >= n) return;
+        acc = wd_product(w.YL + (size_t)next * blk, w.YU + (size_t)next * blk, ti, tj, false, acc, lane);
+        out = w.U + (size_t)e * blk;
+    }
+    out += (size_t)(16 * ti + g) * WBD + 16 * tj + jj;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[(size_t)4 * q * WBD] = acc[q];
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+int configure_wide() {
+    if (hipFuncSetAttribute((const void *)k_wd_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WS_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_wd_factor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WF_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    return hipFuncSetAttribute((const void *)k_wd_factor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WF_LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
+}
+void launch_wide_schur(Launcher &L, const Dev &d) {
+    const WideSys &w = L.wide;
+    LAUNCH(KC_SCHUR, k_wd_schur, dim3(w.n_items), dim3(WS_THREADS), WS_LDS_DOUBLES * sizeof(double), d);
+    LAUNCH(KC_ASSEMBLE, k_wd_assemble, dim3((unsigned)(((size_t)w.n_blk * 36 + (size_t)d.nfree * 6 + 255) / 256)), dim3(256), 0, d);
+}
+void launch_wide_finish(Launcher &L, const Dev &d) {
+    LAUNCH(KC_SMALL, k_wd_finish, dim3((L.wide.n * WBD + 255) / 256), dim3(256), 0, d);
+}
+void launch_wide_solve(Launcher &L, const Dev &d) {
+    const WideSys &w = L.wide;
+    const int ng = 3;
+    for (int q = 0; q < w.steps; ++q) {
+        LAUNCH(KC_BCR_FACTOR, k_wd_factor<0>, dim3(w.n * ng), dim3(WF_THREADS), WF_LDS_DOUBLES * sizeof(double), d, q, ng);
+        LAUNCH(KC_BCR_REDUCE, k_wd_reduce, dim3(w.n * WR_WG_PER_BLOCK), dim3(256), 0, d, q);
+    }
+    LAUNCH(KC_BCR_FACTOR, k_wd_factor<1>, dim3(w.n), dim3(WF_THREADS), WF_LDS_DOUBLES * sizeof(double), d, w.steps, 1);
+}
+
+}  // namespace ssba

@@ -254,7 +254,7 @@ typedef struct {
     uint32_t general_structure;    /* 1: tracks > SSBA_MAX_TRACK or span > 12 poses -> dense reduced system; 2: windowed layout + closure border */
     uint32_t pcr_blocks;           /* blocks handed to the parallel cyclic reduction (<= 128), 0 = plain BCR */
     uint32_t pcr_fused;            /* 1: one launch per step of that reduction (no border columns, single GPU; SSBA_NO_PCR_FUSED=1 in the environment of a solve keeps factor + reduce launches) */
-    uint32_t reserved_;
+    uint32_t wide_superblocks;     /* > 0: general layout whose tracks have 13..24 observations (free poses within a span of 24): the reduced system is block tridiagonal over this many super-blocks of 24 poses (144 rows), solved by parallel cyclic reduction (general_structure stays 1; SSBA_NO_WIDE=1 at ssba_finalize keeps the blocked Cholesky) */
 } ssba_stats;
 SSBA_API int ssba_get_stats(ssba_problem *p, ssba_stats *st);
 

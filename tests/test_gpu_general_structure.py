@@ -77,13 +77,79 @@ def test_forced_dense_solve_equals_windowed_solve():
     assert np.abs(ba_d.poses - ba_w.poses).max() < 1e-8
 
 
-@pytest.mark.parametrize("size", [(30, 1500, 20), (60, 2400, 40), (150, 4000, 16), (1400, 14000, 14)])
+@contextmanager
+def _no_wide():
+    os.environ["SSBA_NO_WIDE"] = "1"
+    try:
+        yield
+    finally:
+        del os.environ["SSBA_NO_WIDE"]
+
+
+@pytest.mark.parametrize("size", [(30, 1500, 20), (60, 2400, 40), (150, 4000, 16), (1400, 14000, 14), (1000, 20000, 24)])
 def test_long_tracks_match_oracle(size):
+    """Tracks of 13..24 observations run on 144-row super-blocks (ssba_wide.hip: matrix-core Schur items + parallel cyclic
+    reduction), longer ones on the blocked Cholesky of the general path; both against the oracle's whole solve."""
     prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=size[2])
     assert _track_lengths(prob).max() > 12
     ba, s, log, op, s2, log2 = _solve_both(prob)
-    assert ba.stats().general_structure == 1
+    st = ba.stats()
+    assert st.general_structure == 1
+    assert st.wide_superblocks == (0 if size[2] > 24 else (st.num_free_poses + 23) // 24)
     _assert_same_solve(ba, s, log, op, s2, log2)
+
+
+@pytest.mark.parametrize("radius", [1e4, 3.0])
+@pytest.mark.parametrize("size", [(14, 300, 13), (30, 900, 24), (75, 1800, 20), (200, 3000, 17)])     # 1, 2, 4 and 9 super-blocks of 24 poses
+def test_wide_reduced_system_and_step_match_oracle(size, radius):
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=3)
+    ba = StereoBA.from_synth(prob)
+    st = ba.stats()
+    assert st.general_structure == 1 and st.wide_superblocks == (st.num_free_poses + 23) // 24
+    op = orc.OracleProblem.from_synth(prob)
+    S, rhs, dp, dl, mcc = ba.lm_step(radius)
+    S2, rhs2, _ = op.reduced_system(radius)
+    dp2, dl2, mcc2 = op.lm_step(radius)
+    assert _rel(S, S2) < 1e-10 and _rel(rhs, rhs2) < 1e-10
+    assert _rel(dp, dp2) < 1e-8 and _rel(dl, dl2) < 1e-8
+    assert mcc == pytest.approx(mcc2, rel=1e-9)
+
+
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("huber_a", [0.0, 1.345])
+def test_wide_super_blocks_equal_the_blocked_cholesky(strategy, huber_a):
+    """The same long-track problem on the 144-row super-blocks and (SSBA_NO_WIDE=1) on the blocked Cholesky of the general
+    path: LM, TRADITIONAL and SUBSPACE dogleg, with and without a loss; and both against the oracle."""
+    prob = synth.make_problem(90, 2700, track_len=18, seed=11, outlier_fraction=0.1 if huber_a else 0.0)
+    opts = dict(trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    ba, s, log, op, s2, log2 = _solve_both(prob, opts=opts, huber_a=huber_a)
+    assert ba.stats().wide_superblocks == 4
+    _assert_same_solve(ba, s, log, op, s2, log2)
+    with _no_wide():
+        ba_d = StereoBA.from_synth(prob, huber_a=huber_a)
+    assert ba_d.stats().wide_superblocks == 0 and ba_d.stats().general_structure == 1
+    s_d, log_d = ba_d.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1, **opts))
+    assert s_d.num_iterations == s.num_iterations
+    assert log_d["step_is_successful"].tolist() == log["step_is_successful"].tolist()
+    ok = np.asarray(log["step_is_successful"], dtype=bool)
+    ok[0] = True
+    np.testing.assert_allclose(log_d["cost"][ok], log["cost"][ok], rtol=1e-9)
+    assert np.abs(ba_d.poses - ba.poses).max() < 1e-7
+
+
+def test_wide_handle_hands_over_to_the_blocked_cholesky_for_a_covariance():
+    """ceres::Covariance on a long-track problem (tests/dataset_vo_sun.cpp:159-183): the 144-row super-blocks have no
+    covariance sweep, the handle runs its symbolic phase again and continues on the blocked Cholesky."""
+    prob = synth.make_problem(40, 1200, track_len=16, seed=4)
+    ba = StereoBA.from_synth(prob)
+    assert ba.stats().wide_superblocks == 2
+    ba.solve(capi.default_options(max_num_iterations=1000, use_nonmonotonic_steps=1))
+    ba2 = StereoBA(prob.camera, ba.poses.copy(), ba.points.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness())
+    cov = ba2.pose_covariance(7)
+    assert ba2.stats().wide_superblocks == 0 and ba2.stats().general_structure == 1
+    with _no_wide():
+        ba3 = StereoBA(prob.camera, ba.poses.copy(), ba.points.copy(), prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness())
+    np.testing.assert_allclose(cov, ba3.pose_covariance(7), rtol=1e-9)
 
 
 def test_matrix_core_and_valu_factorisations_agree(monkeypatch):

@@ -175,8 +175,12 @@ def test_edge_cases_ragged_tracks_unobserved_blocks_and_errors():
     # (tests/test_gpu_general_structure.py); what that path does not cover is rejected loudly, not mis-solved
     long = synth.make_problem(20, 10, track_len=14, seed=5)
     assert StereoBA.from_synth(long).stats().general_structure == 1
+    # tracks of 13..24 observations shard (144-row super-blocks, all-reduce of the reduced system: tests/test_sharding.py);
+    # tracks beyond that need the blocked Cholesky of the general path, which is single GPU
+    assert StereoBA.from_synth(long, world_size=2, rank=0).stats().wide_superblocks == 1
+    longer = synth.make_problem(40, 10, track_len=30, seed=5)
     with pytest.raises(capi.SsbaError) as e:
-        StereoBA.from_synth(long, world_size=2, rank=0)
+        StereoBA.from_synth(longer, world_size=2, rank=0)
     assert e.value.status == -6
     # out-of-range index
     with pytest.raises(capi.SsbaError):

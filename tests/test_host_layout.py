@@ -1,0 +1,21 @@
+"""The host-only layout builder of the wide reduced system (ceres_slam_amd/csrc/ssba_wide_layout.cpp) is plain C++: it is
+compiled here for the CPU with -fsanitize=address,undefined and once with -fsanitize=thread and run over random banded
+problems (sanitizers on the CPU build only -- GPU ASan is not available on this pool)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ceres_slam_amd", "csrc")
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_wide_layout_builder_under_sanitizers(tmp_path, san):
+    exe = str(tmp_path / ("wide_layout_check_" + san.replace(",", "_")))
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + san, "-fno-sanitize-recover=all", "-I" + CSRC,
+           os.path.join(ROOT, "tests", "host", "wide_layout_check.cpp"), os.path.join(CSRC, "ssba_wide_layout.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "all invariants hold" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

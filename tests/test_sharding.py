@@ -85,6 +85,31 @@ def test_two_rank_sharded_gpu_solve_matches_unsharded_oracle(tmp_path):
     np.testing.assert_array_equal(res[0]["poses"], res[1]["poses"])          # ranks agree bit for bit
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,size", [(2, (60, 2400, 20)), (3, (130, 3900, 24))])
+def test_sharded_long_tracks_match_unsharded_oracle(tmp_path, world, size):
+    """Landmark sharding of a problem whose tracks have 13..24 observations (ssba_wide.hip): every rank forms the 144-row
+    super-blocks of ITS landmarks, they are summed over the ranks next to the gradient vectors, every rank runs the same
+    parallel cyclic reduction.  Same iterates as the unsharded oracle, ranks bit-identical."""
+    K = 25
+    res = _run_ranks("gpu", str(tmp_path / "wide"), world, size=size, extra_env={"SSBA_TEST_MAXIT": str(K)})
+    prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21)
+    assert np.bincount(prob.obs_point).max() > 12
+    op = orc.OracleProblem.from_synth(prob)
+    s, log = op.solve(orc.driver_options(num_threads=2, max_num_iterations=K))
+    for r in res:
+        assert r["num_iterations"] == s.num_iterations
+        assert r["accept"] == log["step_is_successful"].tolist()
+        ok = np.asarray(log["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-8)
+        assert r["final_cost"] == pytest.approx(s.final_cost, rel=1e-6)
+        assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-6
+        assert np.abs(np.array(r["points"]) - op.points[r["point_ids"]]).max() < 1e-5
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0]["poses"], r["poses"])
+
+
 def test_aligned_partition_cuts_at_superblock_boundaries():
     for P, L, W in ((40, 1600, 2), (60, 2400, 3), (300, 12000, 4)):
         prob = synth.make_problem(P, L)

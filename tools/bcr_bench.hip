@@ -324,6 +324,49 @@ int main(int argc, char **argv) {
                 }
                 printf("XCD placement: %d of %d workgroups on the same XCD in two consecutive launches; %d of %d follow (xcd of workgroup 0 + id) %% 8; "
                        "workgroup 0 on XCD %d then %d\n", same, nwg, rr, nwg, (int)(stp[4096 + 5] - 1000), (int)(stq[4096 + 5] - 1000));
+                // where do the workgroups of a block run, and do the producers of a block's operands (blocks e - h, e + h of the
+                // launch before) run on the XCD that consumes them?  xcd_map on the host: workgroup id -> (block, part)
+                auto host_map = [&](int id, int nn, int ny, int &e, int &y) {
+                    const int N = nn * ny, c = id & 7;
+                    const int q = (N + 7) >> 3, r = (N + 7) & 7;
+                    int idx = (id >> 3) + c * q - std::max(0, c - (r + 1));
+                    e = 0; y = 0;
+                    for (int k = 0; k < 8; ++k) {
+                        const int sk = ((nn - k + 7) >> 3) * ny;
+                        if (idx < sk) { const int bq = idx / ny; y = idx - bq * ny; e = k + 8 * bq; return; }
+                        idx -= sk;
+                    }
+                };
+                const int ny = n <= 85 ? 3 : 2;
+                std::vector<int> xa(n * ny, -1), xb(n * ny, -1);         // XCD of (block, part) in launch 3 / launch 4
+                for (int g = 0; g < nwg && g < 500; ++g) {
+                    int e, y;
+                    host_map(g, n, ny, e, y);
+                    xa[e * ny + y] = (int)(stp[4096 + 8 * g + 5] - 1000);
+                    xb[e * ny + y] = (int)(stq[4096 + 8 * g + 5] - 1000);
+                }
+                int together = 0, counted = 0, fed = 0, feeds = 0;
+                for (int e = 0; e < n; ++e) {
+                    if (xa[e * ny] < 0 || xb[e * ny] < 0) continue;
+                    ++counted;
+                    bool one = true;
+                    for (int y = 1; y < ny; ++y) one = one && xb[e * ny + y] == xb[e * ny];
+                    together += one;
+                    // launch 4 (stride 16) assembles block e from the Gram products blocks e - 8 and e + 8 formed in launch 3
+                    for (int h : {-8, 8}) {
+                        const int b = e + h;
+                        if (b < 0 || b >= n || xa[b * ny] < 0) continue;
+                        for (int y = 0; y < ny; ++y) {          // every part of the producer writes a share of the Gram tiles
+                            ++feeds;
+                            fed += xa[b * ny + y] == xb[e * ny];
+                        }
+                    }
+                }
+                printf("XCD placement by block: %d of %d blocks have all %d workgroups on one XCD (launch 4); %d of %d (producer part, consumer) "
+                       "pairs of launch 3 -> launch 4 (operands e -/+ 8) sit on the same XCD\n", together, counted, ny, fed, feeds);
+                printf("XCD of workgroup id 0..23 in launch 3:");
+                for (int g = 0; g < 24 && g < nwg; ++g) printf(" %d", (int)(stp[4096 + 8 * g + 5] - 1000));
+                printf("\n");
             }
             {
                 const int nwg = n * (n <= 85 ? 3 : n <= 128 ? 2 : 1);
@@ -335,7 +378,7 @@ int main(int argc, char **argv) {
                 std::sort(order.begin(), order.end());
                 for (int i = 0; i < nwg; i += (i < 8 || i >= nwg - 24) ? 1 : 16) {
                     const int g = order[i].second;
-                    printf("  wg %3d (xcd slot %d):", g, g & 7);
+                    printf("  wg %3d (id %% 8 = %d, XCC_ID %d):", g, g & 7, (int)(stp[4096 + 8 * g + 5] - 1000));
                     for (int k = 0; k < 5; ++k) printf(" %6.2f", (double)(long long)(stp[4096 + 8 * g + k] - lo) / 100.0);
                     printf("\n");
                 }
