@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "ssba_device.h"
 #include "ssba_launch.h"
 #include "ssba_types.h"
@@ -195,6 +197,17 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d) {
     }
 }
 
+// The reduction works in place on D, L and r (its steps overwrite whole blocks, structural zeros included), and the gather
+// below only stores the structurally non-zero entries: the blocks are cleared before every assembly.
+__global__ __launch_bounds__(256) void k_wd_zero(Dev d) {
+    const State &st = *d.st;
+    const WideSys &w = *d.wide;
+    if (st.terminated || st.dl_reuse) return;
+    double2 *z = reinterpret_cast<double2 *>(w.xw);
+    const size_t n2 = w.off_rhs / 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) z[i] = make_double2(0.0, 0.0);
+}
+
 static __device__ __forceinline__ int wd_tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
 // one thread per (non-zero 6 x 6 block, element) + one per entry of the reduced gradient
@@ -281,6 +294,12 @@ __global__ __launch_bounds__(256) void k_wd_finish(Dev d) {
         w.xw[w.off_rhs + i] = 0.0;
     }
 }
+
+// Lanes of ONE wave hand values to each other through LDS below (the LDS unit serves a wave's requests in issue order, so no
+// hardware wait is needed) -- but to the compiler a lane that skips a predicated store has not changed memory, and it reuses
+// what it loaded before the store (measured: the loads were sunk into the `if (lane < 16)` block, the other 48 lanes read
+// stale registers).  A compiler-level memory barrier makes it store what is pending and load again.
+#define WD_WAVE_LDS_SYNC() do { asm volatile("" ::: "memory"); } while (0)
 
 // ---- parallel cyclic reduction over 144-row blocks ------------------------------------------------------------
 constexpr int WF_THREADS = 512;
@@ -490,6 +509,7 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
 #pragma unroll
             for (int q = 0; q < 4; ++q) sy[16 * j + 4 * q + g] = rt[j][q];
     }
+    WD_WAVE_LDS_SYNC();
     const int i = lane & 15, pt = lane >> 4;
 #pragma unroll
     for (int k = WNT - 1; k >= 0; --k) {
@@ -503,6 +523,7 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
         p += __shfl_xor(p, 16, 64);
         p += __shfl_xor(p, 32, 64);
         if (lane < 16) stv[i] = sy[16 * k + i] - p;
+        WD_WAVE_LDS_SYNC();
         const double *Wk = sW + k * 256 + i * 16;
         double xk = 0.0;
 #pragma unroll
@@ -510,6 +531,7 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
         xk += __shfl_xor(xk, 16, 64);
         xk += __shfl_xor(xk, 32, 64);
         if (lane < 16) sx[16 * k + i] = xk;
+        WD_WAVE_LDS_SYNC();
     }
     for (int r = lane; r < WBD; r += 64) {
         const size_t row = (size_t)e * WBD + r;
@@ -600,6 +622,7 @@ int configure_wide() {
 }
 void launch_wide_schur(Launcher &L, const Dev &d) {
     const WideSys &w = L.wide;
+    LAUNCH(KC_SMALL, k_wd_zero, dim3(std::min(1024, w.n * 81)), dim3(256), 0, d);
     LAUNCH(KC_SCHUR, k_wd_schur, dim3(w.n_items), dim3(WS_THREADS), WS_LDS_DOUBLES * sizeof(double), d);
     LAUNCH(KC_ASSEMBLE, k_wd_assemble, dim3((unsigned)(((size_t)w.n_blk * 36 + (size_t)d.nfree * 6 + 255) / 256)), dim3(256), 0, d);
 }

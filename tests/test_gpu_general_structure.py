@@ -386,11 +386,17 @@ def test_pose_covariance_on_the_general_path(P):
 
 
 def test_structure_beyond_the_general_path_is_rejected_loudly():
-    # landmark sharding keeps the windowed layout only
+    # landmark sharding: the windowed layout and tracks of 13..24 observations (144-row super-blocks); what needs the blocked
+    # Cholesky of the general path -- longer tracks, or SSBA_NO_WIDE=1 -- is single GPU
     prob = synth.make_problem(20, 400, track_len=16, seed=1)
-    with pytest.raises(capi.SsbaError) as e:
-        StereoBA.from_synth(prob, world_size=2, rank=0)
+    assert StereoBA.from_synth(prob, world_size=2, rank=0).stats().wide_superblocks == 1
+    with _no_wide():
+        with pytest.raises(capi.SsbaError) as e:
+            StereoBA.from_synth(prob, world_size=2, rank=0)
     assert e.value.status == -6      # SSBA_ERR_UNSUPPORTED
+    with pytest.raises(capi.SsbaError) as e:
+        StereoBA.from_synth(synth.make_problem(40, 400, track_len=30, seed=1), world_size=2, rank=0)
+    assert e.value.status == -6
 
 
 # ---- lighting terms on the general layout (the Phong driver takes any dataset) ----
