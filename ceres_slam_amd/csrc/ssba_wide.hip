@@ -304,78 +304,123 @@ __global__ __launch_bounds__(256) void k_wd_finish(Dev d) {
 // ---- parallel cyclic reduction over 144-row blocks ------------------------------------------------------------
 constexpr int WF_THREADS = 512;
 constexpr int WF_NU = WNT * (WNT + 1) / 2;      // 45 upper tiles of U
-constexpr int WF_LDS_DOUBLES = (WF_NU + WNT) * 256 + 2 * WBD + 32;      // U tiles | W = U_kk^-1 tiles | y | x | t
+// U tiles | U_kk^-T tiles (decoupled step) | sub-step operands P, Q of two diagonal tiles | 1 / sqrt(pivot) of two | y | x | t
+constexpr int WF_OFF_W = WF_NU * 256, WF_OFF_P = WF_OFF_W + WNT * 256, WF_OFF_Q = WF_OFF_P + 2 * 256, WF_OFF_RS = WF_OFF_Q + 2 * 256,
+              WF_OFF_Y = WF_OFF_RS + 32, WF_OFF_X = WF_OFF_Y + WBD, WF_OFF_T = WF_OFF_X + WBD;
+constexpr int WF_LDS_DOUBLES = WF_OFF_T + 16;
 
-// Diagonal tile (one wave): T = L L^T by columns with lane r holding row r (pivot column by v_readlane), and M = L^-1 built
-// alongside (row r of M in lane r: its updates are independent of the pivot chain and fill its latency).  Leaves U = L^T in
-// T (row-major, zeros below the diagonal) and Wt = U^-1 = M^T in W (row-major).
-static __device__ __forceinline__ bool wd_potrf_inv(double *__restrict__ T, double *__restrict__ W, int lane) {
-    const int r = lane & 15;
-    double a[16], tm[16];
+// Diagonal tile T (16 x 16, accumulator layout: register q of lane (g, j) = row 4 q + g, column j), four sub-steps of four
+// pivots -- the scheme of ssba_bcr_mfma.hip's factor_tile: the 4 x 4 pivot block is factored LDL^T "uniformly" (every lane
+// computes the same scalars from v_readlane copies; the serial chain is four reciprocals), the inverse M of its unit-lower
+// factor becomes the A operand P of ONE instruction  c = M T[rows]  and the scaled pivot rows Q = -c / d the A operand of ONE
+// instruction that updates the rows below.  Every other tile of the block row (panel tiles, right-hand sides) follows with the
+// same two operands per sub-step (wd_apply).  Rows stay in the LDL^T scaling; rs = 1 / sqrt(d) normalises them afterwards.
+// sP / sQ: [sub-step][lane]; srs: 16 reciprocal square roots.  Returns false on a non-positive / non-finite pivot.
+static __device__ __forceinline__ bool wd_factor_tile(wd4 &T, double *__restrict__ sP, double *__restrict__ sQ, double *__restrict__ srs, int lane) {
+    const int g = lane >> 4, j = lane & 15;
+    const double kDiag = (j < 4 && g == j) ? 1.0 : 0.0, k10 = (j == 1 && g == 0) ? 1.0 : 0.0, k20 = (j == 2 && g == 0) ? 1.0 : 0.0,
+                 k21 = (j == 2 && g == 1) ? 1.0 : 0.0, k30 = (j == 3 && g == 0) ? 1.0 : 0.0, k31 = (j == 3 && g == 1) ? 1.0 : 0.0,
+                 k32 = (j == 3 && g == 2) ? 1.0 : 0.0;
+    const double kG0 = g == 0 ? 1.0 : 0.0, kG1 = g == 1 ? 1.0 : 0.0, kG2 = g == 2 ? 1.0 : 0.0, kG3 = g == 3 ? 1.0 : 0.0;
+    bool ok = true;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { a[c] = T[r * 16 + c]; tm[c] = (c == r) ? 1.0 : 0.0; }
-    bool bad = false;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const double piv = wd_readlane(a[c], c);
-        bad = bad || !(piv > 0.0) || !(piv < INFINITY);
-        const double rs = fast_rsqrt(piv);
-        const double l = a[c] * rs;       // L[r][c]
-        a[c] = l;
-#pragma unroll
-        for (int cc = c + 1; cc < 16; ++cc) a[cc] -= l * wd_readlane(l, cc);
-        // row c of M is final: M[c][j] = tm_c[j] / L[c][c]; the rows below subtract L[r][c] M[c][j]
-#pragma unroll
-        for (int j = 0; j <= c; ++j) {
-            const double fin = tm[j] * rs;
-            const double mc = wd_readlane(fin, c);
-            tm[j] = (r == c) ? fin : (r > c) ? tm[j] - l * mc : tm[j];      // (a finished row stays where it is)
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int b = 4 * r;      // S[a][c] = T[4r + a][4r + c] sits in register r of lane 16 a + 4r + c
+        const double tr = T[r];
+        const double s00 = wd_readlane(tr, b), s10 = wd_readlane(tr, 16 + b), s20 = wd_readlane(tr, 32 + b), s30 = wd_readlane(tr, 48 + b);
+        const double s11 = wd_readlane(tr, 16 + b + 1);
+        double s21 = wd_readlane(tr, 32 + b + 1), s31 = wd_readlane(tr, 48 + b + 1);
+        const double s22 = wd_readlane(tr, 32 + b + 2);
+        double s32 = wd_readlane(tr, 48 + b + 2);
+        const double s33 = wd_readlane(tr, 48 + b + 3);
+        const double x0 = __builtin_amdgcn_rcp(s00), e0 = fma(-s00, x0, 1.0);
+        const double t10 = s10 * x0, t20 = s20 * x0, t30 = s30 * x0;
+        const double l10 = fma(t10, e0, t10), l20 = fma(t20, e0, t20), l30 = fma(t30, e0, t30);
+        const double d1 = fma(-s10, l10, s11);
+        s21 = fma(-s20, l10, s21); s31 = fma(-s30, l10, s31);
+        const double x1 = __builtin_amdgcn_rcp(d1), e1 = fma(-d1, x1, 1.0);
+        const double t21 = s21 * x1, t31 = s31 * x1;
+        const double l21 = fma(t21, e1, t21), l31 = fma(t31, e1, t31);
+        const double d2 = fma(-s21, l21, fma(-s20, l20, s22));
+        s32 = fma(-s31, l21, fma(-s30, l20, s32));
+        const double x2 = __builtin_amdgcn_rcp(d2), e2 = fma(-d2, x2, 1.0);
+        const double t32 = s32 * x2;
+        const double l32 = fma(t32, e2, t32);
+        const double d3 = fma(-s32, l32, fma(-s31, l31, fma(-s30, l30, s33)));
+        const double x3 = __builtin_amdgcn_rcp(d3), e3 = fma(-d3, x3, 1.0);
+        const double rc0 = fma(x0, e0, x0), rc1 = fma(x1, e1, x1), rc2 = fma(x2, e2, x2), rc3 = fma(x3, e3, x3);
+        ok = ok && rc0 > 0.0 && rc1 > 0.0 && rc2 > 0.0 && rc3 > 0.0 && rc0 < INFINITY && rc1 < INFINITY && rc2 < INFINITY && rc3 < INFINITY;
+        // M = l^-1 (unit lower); P: lane (g, i = j) holds M[i][g] for i < 4
+        const double n20 = fma(l21, l10, -l20);
+        const double n31 = fma(l32, l21, -l31);
+        const double n30 = -fma(l32, n20, fma(l31, -l10, l30));
+        double Pv = fma(-l10, k10, kDiag);
+        Pv = fma(n20, k20, Pv);
+        Pv = fma(-l21, k21, Pv);
+        Pv = fma(n31, k31, Pv);
+        Pv = fma(-l32, k32, Pv);
+        Pv = fma(n30, k30, Pv);
+        const wd4 y4 = wmf(Pv, tr, wd4{0.0, 0.0, 0.0, 0.0});
+        const double rcg = fma(rc3, kG3, fma(rc2, kG2, fma(rc1, kG1, rc0 * kG0)));
+        const double qs = (j > b + 3) ? -rcg : 0.0;
+        const double y = y4[0];             // lane (g, j): unnormalised pivot row c_g[j]
+        T[r] = y;
+        const double Qv = y * qs;
+        if (r < 3) T = wmf(Qv, y, T);
+        sP[r * 64 + lane] = Pv;
+        sQ[r * 64 + lane] = Qv;
+        if (j == 0) srs[b + g] = sqrt(rcg);
     }
-    if (lane < 16) {
+    return ok;
+}
+// the four sub-steps on another tile of the block row (accumulator layout), then the rows normalised by 1 / sqrt(pivot)
+static __device__ __forceinline__ void wd_apply(wd4 &X, const double *__restrict__ sP, const double *__restrict__ sQ, const double *__restrict__ srs, int lane) {
+    double P[4], Q[4], rs[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            T[c * 16 + r] = (c <= r) ? a[c] : 0.0;         // U[c][r] = L[r][c]
-            W[c * 16 + r] = (c <= r) ? tm[c] : 0.0;        // (U^-1)[c][r] = M[r][c]
-        }
+    for (int r = 0; r < 4; ++r) { P[r] = sP[r * 64 + lane]; Q[r] = sQ[r * 64 + lane]; rs[r] = srs[4 * r + (lane >> 4)]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const wd4 y4 = wmf(P[r], X[r], wd4{0.0, 0.0, 0.0, 0.0});
+        X[r] = y4[0];
+        if (r < 3) X = wmf(Q[r], y4[0], X);
     }
-    return !bad;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] *= rs[r];
 }
-// X = Wt^T T in place (Wt = U_kk^-1, row-major; T a 16 x 16 tile, row-major)
-static __device__ __forceinline__ void wd_tile_solve(const double *__restrict__ Wt, double *__restrict__ T, int lane) {
-    const int kq = lane >> 4, i = lane & 15;
-    wd4 acc = {0.0, 0.0, 0.0, 0.0};
-    double a[4], b[4];
+static __device__ __forceinline__ wd4 wd_tile_load(const double *__restrict__ T, int lane) {
+    wd4 v;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { a[s] = Wt[(4 * s + kq) * 16 + i]; b[s] = T[(4 * s + kq) * 16 + i]; }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) acc = wmf(a[s], b[s], acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) T[(4 * q + kq) * 16 + i] = acc[q];
+    for (int q = 0; q < 4; ++q) v[q] = T[(4 * q + (lane >> 4)) * 16 + (lane & 15)];
+    return v;
 }
-// T_ij -= U_ki^T U_kj
-static __device__ __forceinline__ void wd_tile_update(const double *__restrict__ Uki, const double *__restrict__ Ukj, double *__restrict__ Tij, int lane) {
+static __device__ __forceinline__ void wd_tile_store(double *__restrict__ T, const wd4 &v, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[(4 * q + (lane >> 4)) * 16 + (lane & 15)] = v[q];
+}
+// T_ij -= U_ki^T U_kj  (normalised row tiles, row-major in LDS); returns the updated tile
+static __device__ __forceinline__ wd4 wd_tile_update(const double *__restrict__ Uki, const double *__restrict__ Ukj, const double *__restrict__ Tij, int lane) {
     const int kq = lane >> 4, i = lane & 15;
-    wd4 acc;
     double a[4], b[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) { a[s] = -Uki[(4 * s + kq) * 16 + i]; b[s] = Ukj[(4 * s + kq) * 16 + i]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = Tij[(4 * q + kq) * 16 + i];
+    wd4 acc = wd_tile_load(Tij, lane);
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = wmf(a[s], b[s], acc);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) Tij[(4 * q + kq) * 16 + i] = acc[q];
+    return acc;
 }
 
-// FINAL = 0: a step of the reduction (grid n x ng, the right-hand-side tiles of [L | U | r] dealt to the 8 waves of ng
-// workgroups);  FINAL = 1: the decoupled last step (grid n): factor, forward and backward solve, pose step into x0
+// FINAL = 0: a step of the reduction (grid n x ng, the right-hand-side tiles of [L | U | r] dealt to waves 1..7 of ng
+// workgroups);  FINAL = 1: the decoupled last step (grid n): factor, forward and backward solve, pose step into x0.
+// Schedule of a block row k: (b) the panel tiles (k, j > k) and the right-hand-side tiles take the sub-steps of diagonal tile
+// k; (c) wave 0 updates diagonal tile k + 1 and factors it at once (look-ahead) while the other waves update the rest of the
+// trailing tiles and the right-hand sides -- two workgroup barriers per block row, the pivot chain never waits for an update.
 template <int FINAL>
 __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int ng) {
     const WideSys &w = *d.wide;
     const StateFlags sf = state_flags_vmem(d.st);
     extern __shared__ __align__(16) double wf_lds[];
-    double *sU = wf_lds, *sW = wf_lds + WF_NU * 256, *sy = sW + WNT * 256, *sx = sy + WBD, *stv = sx + WBD;
+    double *sU = wf_lds, *sW = wf_lds + WF_OFF_W, *sP = wf_lds + WF_OFF_P, *sQ = wf_lds + WF_OFF_Q, *sRS = wf_lds + WF_OFF_RS;
+    double *sy = wf_lds + WF_OFF_Y, *sx = wf_lds + WF_OFF_X, *stv = wf_lds + WF_OFF_T;
     __shared__ int s_bad;
     const int e = (int)blockIdx.x / ng, part = (int)blockIdx.x - e * ng;
     const int n = w.n, s = 1 << step;
@@ -420,51 +465,68 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
                 for (int q = 0; q < 4; ++q) rt[j][q] = pp[(16 * j + 4 * q) * WBD];
         }
     }
-    // upper tiles of D into LDS, tile by tile (row-major 16 x 16)
+    // upper tiles of D into LDS, tile by tile (row-major 16 x 16); wave 0 keeps the first diagonal tile in registers
+    wd4 dg = {0.0, 0.0, 0.0, 0.0};
     {
         int ti = 0, tj = 0;
         for (int tl = 0; tl < WF_NU; ++tl) {
             if ((tl & 7) == wv) {
                 const double *pp = Dg + (size_t)(16 * ti + g) * WBD + 16 * tj + jj;
+                wd4 v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sU[tl * 256 + (4 * q + g) * 16 + jj] = pp[(size_t)4 * q * WBD];
+                for (int q = 0; q < 4; ++q) v[q] = pp[(size_t)4 * q * WBD];
+                if (tl == 0) dg = v;
+                else wd_tile_store(sU + tl * 256, v, lane);
             }
             if (++tj == WNT) { ++ti; tj = ti; }
         }
     }
     if (sf.dead()) return;
+    if (wv == 0) {
+        if (!wd_factor_tile(dg, sP, sQ, sRS, lane)) s_bad = 1;
+    }
     __syncthreads();
 
 #pragma unroll
     for (int k = 0; k < WNT; ++k) {
-        // (a) diagonal tile
-        if (wv == 0) {
-            if (!wd_potrf_inv(sU + wd_utile(k, k) * 256, sW + k * 256, lane)) s_bad = 1;
-        }
-        __syncthreads();
-        // (b) row panel U_kj = U_kk^-T T_kj (one tile per wave) and block row k of the right-hand sides
+        const double *kP = sP + (k & 1) * 256, *kQ = sQ + (k & 1) * 256, *kRS = sRS + (k & 1) * 16;
+        // (b) the panel tiles of block row k (one per wave) and block row k of the right-hand sides
         {
             const int j = k + 1 + wv;
-            if (j < WNT) wd_tile_solve(sW + k * 256, sU + wd_utile(k, j) * 256, lane);
-            if (act) {
-                wd4 y = {0.0, 0.0, 0.0, 0.0};
-                double a[4];
+            if (j < WNT) {
+                wd4 x = wd_tile_load(sU + wd_utile(k, j) * 256, lane);
+                wd_apply(x, kP, kQ, kRS, lane);
+                wd_tile_store(sU + wd_utile(k, j) * 256, x, lane);
+            }
+            if (act) wd_apply(rt[k], kP, kQ, kRS, lane);
+            if (FINAL && wv == 2) {        // U_kk^-T (row-major) for the backward solve: the sub-steps applied to the identity
+                wd4 x;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = sW[k * 256 + (4 * q + g) * 16 + jj];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) y = wmf(a[q], rt[k][q], y);
-                rt[k] = y;
+                for (int q = 0; q < 4; ++q) x[q] = (4 * q + g == jj) ? 1.0 : 0.0;
+                wd_apply(x, kP, kQ, kRS, lane);
+                wd_tile_store(sW + k * 256, x, lane);
             }
         }
         __syncthreads();
-        // (c) trailing update of the tiles (i, j), k < i <= j, dealt to the waves; the right-hand sides below block row k
-        {
-            int cnt = 0;
+        // (c) wave 0: diagonal tile k + 1, updated and factored at once; the others: the rest of the trailing tiles
+        //     (i, j), k < i <= j, and the right-hand sides below block row k
+        if (wv == 0) {
+            if (k + 1 < WNT) {
+                wd4 x = wd_tile_update(sU + wd_utile(k, k + 1) * 256, sU + wd_utile(k, k + 1) * 256, sU + wd_utile(k + 1, k + 1) * 256, lane);
+                if (!wd_factor_tile(x, sP + ((k + 1) & 1) * 256, sQ + ((k + 1) & 1) * 256, sRS + ((k + 1) & 1) * 16, lane)) s_bad = 1;
+            }
+        } else {
+            int cnt = -1;
 #pragma unroll
             for (int i = k + 1; i < WNT; ++i)
 #pragma unroll
-                for (int j = i; j < WNT; ++j, ++cnt)
-                    if ((cnt & 7) == wv) wd_tile_update(sU + wd_utile(k, i) * 256, sU + wd_utile(k, j) * 256, sU + wd_utile(i, j) * 256, lane);
+                for (int j = i; j < WNT; ++j, ++cnt) {
+                    if (cnt < 0) continue;          // (k + 1, k + 1) is wave 0's
+                    if (cnt % 7 == wv - 1) {
+                        const wd4 x = wd_tile_update(sU + wd_utile(k, i) * 256, sU + wd_utile(k, j) * 256, sU + wd_utile(i, j) * 256, lane);
+                        wd_tile_store(sU + wd_utile(i, j) * 256, x, lane);
+                    }
+                }
             if (act) {
 #pragma unroll
                 for (int j = k + 1; j < WNT; ++j) {
@@ -524,10 +586,10 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
         p += __shfl_xor(p, 32, 64);
         if (lane < 16) stv[i] = sy[16 * k + i] - p;
         WD_WAVE_LDS_SYNC();
-        const double *Wk = sW + k * 256 + i * 16;
+        const double *Wk = sW + k * 256 + i;        // (U_kk^-1)[i][c] = (U_kk^-T)[c][i]
         double xk = 0.0;
 #pragma unroll
-        for (int cq = 0; cq < 4; ++cq) xk += Wk[pt + 4 * cq] * stv[pt + 4 * cq];
+        for (int cq = 0; cq < 4; ++cq) xk += Wk[(pt + 4 * cq) * 16] * stv[pt + 4 * cq];
         xk += __shfl_xor(xk, 16, 64);
         xk += __shfl_xor(xk, 32, 64);
         if (lane < 16) sx[16 * k + i] = xk;
