@@ -48,7 +48,9 @@ def test_one_sided_breakdown_is_classified_by_the_radius_the_step_was_computed_w
     radius_gpu = [1e4, 6e8, 1.8e9, 8.9e8, 2.7e9]                # entry i: the radius AFTER iteration i
     gpu = _log([10, 5, 3, 3, 2.9], [0, 1, 1, 0, 1], radius=radius_gpu, step=[0, 1, 1, 0.0, 1], change=[0, 5, 2, 0.0, 0.1])
     orc_ = _log([10, 5, 3, 2.9, 2.8], [0, 1, 1, 1, 1], radius=[1e4, 6e8, 1.8e9, 5.3e9, 1.6e10])
-    assert fz.solver_breakdown(gpu, orc_, 5) == 3               # iteration 3 ran at 1.8e9 and produced no step on one side
+    # iteration 3 ran at 1.8e9 and produced no step on one side: counted -- and (r04) no longer an excuse: the horizon stays,
+    # so the differing accept / reject flag of iteration 3 is a mismatch like any other
+    assert fz.solver_breakdown(gpu, orc_, 5) == 5
     assert fz.SUMMARY["breakdown_first"] == {"gpu": 1, "oracle": 0}
     # an ordinary rejected step (a step was taken, the cost went up) is not a breakdown
     ordinary = _log([10, 5, 3, 3, 2.9], [0, 1, 1, 0, 1], radius=radius_gpu, step=[0, 1, 1, 0.7, 1], change=[0, 5, 2, -0.3, 0.1])
@@ -57,3 +59,23 @@ def test_one_sided_breakdown_is_classified_by_the_radius_the_step_was_computed_w
     small = _log([10, 5, 3, 3, 2.9], [0, 1, 1, 0, 1], radius=[1e4, 6e4, 1.8e5, 9e4, 2.7e5], step=[0, 1, 1, 0.0, 1], change=[0, 5, 2, 0.0, 0.1])
     assert fz.solver_breakdown(small, orc_, 5) == 5
     fz.SUMMARY["breakdown_first"] = {"gpu": 0, "oracle": 0}
+
+
+def test_a_count_ended_by_the_hip_run_is_not_agreement():
+    """conditioned_agreement says WHY it stopped; a case whose count the HIP run ended before MIN_HORIZON iterations -- the
+    oracle runs still agreeing with each other -- is recorded as a mismatch even when the strict verdict over a shorter
+    horizon was 'ok' (r03 printed such cases as ok and counted them as compared)."""
+    ref = _log([10, 5, 3, 2, 1.5], [0, 1, 1, 1, 1])
+    probe = _log([10, 5, 3, 2, 1.5], [0, 1, 1, 1, 1])
+    n, _ = fz.conditioned_agreement(_log([10, 5, 3 * (1 + 1e-5), 2, 1.5], [0, 1, 1, 1, 1]), ref, [probe], 5)
+    assert n == 2 and fz.LAST_STOP[0] == "hip"
+    fz.SUMMARY["classes"] = {}
+    fz.record("x", 1, True, n)          # strict horizon 1 (judged ok there), conditioned count 2, ended by the HIP run
+    assert fz.SUMMARY["classes"]["x"]["mismatch"] == 1 and fz.SUMMARY["classes"]["x"]["hip_left"] == 1
+    n, _ = fz.conditioned_agreement(ref, ref, [_log([10, 5, 3 * 1.001, 2, 1.5], [0, 1, 1, 1, 1])], 5)
+    assert n == 2 and fz.LAST_STOP[0] == "oracle"
+    fz.record("y", 1, True, n)          # the oracle itself is undetermined there: uncompared, not a mismatch
+    assert fz.SUMMARY["classes"]["y"]["mismatch"] == 0 and fz.SUMMARY["classes"]["y"]["uncompared"] == 1
+    n, _ = fz.conditioned_agreement(ref, ref, [probe], 5)
+    assert n == 5 and fz.LAST_STOP[0] == "end"
+    fz.SUMMARY["classes"] = {}

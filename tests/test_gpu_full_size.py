@@ -43,6 +43,37 @@ def test_c3_full_size_lighting_solve_matches_cpu_oracle():
     assert np.abs(np.linalg.norm(ba.normals, axis=1) - 1).max() < 1e-12
 
 
+def test_c3_full_size_lighting_solve_converges_like_the_cpu_oracle():
+    """configs[2] run to CONVERGENCE on both sides (tests/dataset_ba_phong.cpp:250-252 solves until Ceres stops): the same
+    iteration count and accept / reject sequence, final cost within 1e-6 relative (the north-star bar), trajectory and
+    normals within 1e-6 -- what test_c2_full_size_solve_matches_cpu_oracle (tests/test_gpu_parity.py) is for configs[1]."""
+    prob, ph = synth.make_phong_problem(*synth.CONFIGS["C2"])
+    d = ph.as_oracle_dict("truth")
+    opts = dict(max_num_iterations=1000, use_nonmonotonic_steps=1)
+    ba = StereoBA.from_synth(prob, lighting=d)
+    s, log = ba.solve(capi.default_options(**opts))
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=d)
+    s2, log2 = op.solve(orc.driver_options(num_threads=16))
+    assert s.termination_type == s2.termination_type == 0
+    _compare(s, log, s2, log2, ba, op, cost_rtol=1e-7)
+    assert np.abs(ba.normals - op.normals).max() < 1e-6
+
+
+def test_c4_full_size_single_gpu_converges_like_the_cpu_oracle():
+    """configs[3]'s problem (10 000 poses / 1 M landmarks / 12 M observations) on ONE GPU, run to convergence on both sides:
+    same iteration count, accept / reject sequence, final cost 1e-6, trajectory 1e-6 (the oracle's solve takes about a minute
+    on 16 host threads)."""
+    prob = synth.make_config("C4")
+    opts = dict(max_num_iterations=1000, use_nonmonotonic_steps=1)
+    ba = StereoBA.from_synth(prob)
+    s, log = ba.solve(capi.default_options(**opts))
+    op = orc.OracleProblem.from_synth(prob)
+    s2, log2 = op.solve(orc.driver_options(num_threads=16))
+    assert s.termination_type == s2.termination_type == 0
+    _compare(s, log, s2, log2, ba, op, cost_rtol=1e-7)
+
+
 def test_c3_full_size_in_the_phong_drivers_own_configuration():
     """configs[2] the way tests/dataset_ba_phong.cpp:84-87,143-181 configures it: SUBSPACE_DOGLEG, non-monotonic steps, light /
     material / texture blocks free, bounds on the material and texture blocks (projected Plus + Armijo line search -- on the

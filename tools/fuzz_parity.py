@@ -43,24 +43,33 @@ def conditioned_agreement(log, ref, probes, nmax, amp=30.0, spread_max=1e-5):
     agree to 1e-8 over the whole solve.)  Returns (iterations in agreement, worst deviation / allowance over them)."""
     m = min([nmax, len(log["cost"]), len(ref["cost"])] + [len(p["cost"]) for p in probes])
     worst, n = 0.0, 0
+    LAST_STOP[0] = "end"        # why the count stopped: the runs ended, the ORACLE runs parted, or the HIP run left them
     for i in range(m):
         flags = {int(p["step_is_successful"][i]) for p in probes} | {int(ref["step_is_successful"][i])}
         if len(flags) > 1:
+            LAST_STOP[0] = "oracle"
             break
         c = float(ref["cost"][i])
         spread = max([abs(float(p["cost"][i]) - c) / abs(c) for p in probes] + [0.0])
         accepted = bool(ref["step_is_successful"][i]) or i == 0
         if accepted and spread > spread_max:
+            LAST_STOP[0] = "oracle"
             break
         if int(log["step_is_successful"][i]) != int(ref["step_is_successful"][i]):
+            LAST_STOP[0] = "hip"
             break
         if accepted:
             ratio = abs(float(log["cost"][i]) - c) / abs(c) / max(1e-8, amp * spread)
             if ratio > 1.0:
+                LAST_STOP[0] = "hip"
                 break
             worst = max(worst, ratio)
         n = i + 1
     return n, worst
+
+
+#: why the last conditioned_agreement() count stopped ("end" / "oracle" / "hip")
+LAST_STOP = ["end"]
 
 
 #: bookkeeping of a sweep: comparison horizons per configuration class, and which side met a factorisation breakdown first
@@ -68,13 +77,21 @@ SUMMARY = {"classes": {}, "breakdown_first": {"gpu": 0, "oracle": 0}}
 MIN_HORIZON = 4         # a case compared over fewer iterations counts as "uncompared", not as "ok"
 
 
-def record(cls, nall, ok):
-    c = SUMMARY["classes"].setdefault(cls, {"cases": 0, "uncompared": 0, "mismatch": 0, "horizons": []})
+def record(cls, nall, ok, n2=None):
+    """nall: the strict horizon (over which `ok` was judged); n2: the conditioned count, LAST_STOP says why it stopped.  A case
+    whose conditioned count was ended BY THE HIP RUN (the oracle runs still agreeing with each other) before MIN_HORIZON
+    iterations is a mismatch whatever the strict verdict over a shorter horizon says; one ended by the HIP run later is counted
+    (hip_left) and reported."""
+    c = SUMMARY["classes"].setdefault(cls, {"cases": 0, "uncompared": 0, "mismatch": 0, "horizons": [], "hip_left": 0})
     c["cases"] += 1
-    c["horizons"].append(int(nall))
-    if not ok:
+    h = int(nall if n2 is None else max(nall, n2))
+    c["horizons"].append(h)
+    hip_left = n2 is not None and LAST_STOP[0] == "hip"
+    if hip_left:
+        c["hip_left"] += 1
+    if not ok or (hip_left and n2 < MIN_HORIZON and n2 >= nall):
         c["mismatch"] += 1
-    elif nall < MIN_HORIZON:
+    elif h < MIN_HORIZON:
         c["uncompared"] += 1
 
 
@@ -83,20 +100,23 @@ def print_summary():
     that early: nothing was compared beyond the first iterations -- reported, not counted as agreement), median horizon.
     Returns non-zero when a class is mostly uncompared or when factorisation breakdowns only ever hit the GPU side first."""
     rc = 0
-    print("class                      cases  mismatches  uncompared(<%d it)  median horizon" % MIN_HORIZON)
+    print("class                      cases  mismatches  uncompared(<%d it)  median horizon  conditioned count ended by the HIP run" % MIN_HORIZON)
     for cls, c in sorted(SUMMARY["classes"].items()):
         med = int(np.median(c["horizons"])) if c["horizons"] else 0
-        print(f"{cls:26s} {c['cases']:5d} {c['mismatch']:11d} {c['uncompared']:18d} {med:15d}")
+        print(f"{cls:26s} {c['cases']:5d} {c['mismatch']:11d} {c['uncompared']:18d} {med:15d} {c['hip_left']:10d}")
         if c["cases"] >= 8 and c["uncompared"] > c["cases"] // 2:
             print(f"  -> class '{cls}': more than half of the cases uncompared")
+            rc = 1
+        if c["mismatch"]:
             rc = 1
     b = SUMMARY["breakdown_first"]
     total = sum(c["cases"] for c in SUMMARY["classes"].values())
     print(f"factorisation breakdown at a radius > 1e9, first on the GPU side: {b['gpu']}, first on the oracle side: {b['oracle']} (of {total} cases)")
-    # both sides then reject the step, halve the radius and go on (Ceres: LINEAR_SOLVER_FAILURE); which elimination order meets
-    # the non-positive pivot first is a property of the order.  More than 1 % of the cases on ONE side would be a finding.
-    if b["gpu"] > max(3, total // 100) and b["oracle"] == 0:
-        print("  -> breakdowns only on the GPU side, in more than 1 % of the cases")
+    # (r04: a one-sided breakdown no longer ends the comparison horizon -- it is a different accept / reject decision, i.e. a
+    # mismatch like any other; r03 excused it.  The matrix-core factor takes ill-conditioned sub-steps in substitution form now:
+    # ssba_bcr_mfma.hip, MF_LBIG.)
+    if b["gpu"]:
+        print("  -> the HIP factorisation broke down where the oracle's did not")
         rc = 1
     return rc
 
@@ -106,15 +126,16 @@ def solver_breakdown(log_gpu, log_orc, n):
     unsuccessful -- the factorisation of the reduced system met a non-positive pivot).  With trust-region radii of 1e10 and more
     the damping is gone and a rank-deficient problem (tracks of 2-3 observations) leaves the reduced system singular to
     working precision; which elimination order breaks down first (block cyclic reduction here, a profile Cholesky in the
-    oracle) is then a property of the order, not of the problem: the comparison ends there."""
+    oracle) is then a property of the order, not of the problem.  r04: COUNTED, no longer excused -- the horizon is returned
+    unchanged, so a one-sided breakdown inside it shows as a different accept / reject sequence (a mismatch)."""
     m = min(n, len(log_gpu["cost"]), len(log_orc["cost"]))
     for i in range(1, m):
         bad = [int(lg["step_is_successful"][i]) == 0 and float(lg["step_norm"][i]) == 0.0 and float(lg["cost_change"][i]) == 0.0
                and float(lg["trust_region_radius"][i - 1]) > 1e9 for lg in (log_gpu, log_orc)]      # (entry i holds the radius AFTER iteration i: the step was computed with entry i - 1's)
         if bad[0] != bad[1]:
             SUMMARY["breakdown_first"]["gpu" if bad[0] else "oracle"] += 1
-            return i
-    return m
+            break
+    return n
 
 
 def lighting_case(rng, c, P, L, T, seed):
@@ -170,7 +191,7 @@ def lighting_case(rng, c, P, L, T, seed):
           f"iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} "
           f"conditioned: {n2:3d} it, {worst2:.2f} of the allowance {'ok' if ok else 'MISMATCH'}", flush=True)
     ba.close()
-    record(f"lighting {'dogleg' if dog >= 0 else 'LM'}{' bounds' if bounds else ''}", max(nall, n2), ok)
+    record(f"lighting {'dogleg' if dog >= 0 else 'LM'}{' bounds' if bounds else ''}", nall, ok, n2)
     return 0 if ok else 1
 
 
@@ -284,7 +305,7 @@ def main():
         print(f"case {c:3d} P={P:3d} L={L:5d} T={T:2d} huber={huber:5.3f} dogleg={dog:2d} const={int(pose_const.sum()):2d} "
               f"general={int(ba.stats().general_structure)} iters={int(s.num_iterations):3d}/{int(s2.num_iterations):3d} horizon={nall:3d} trace={trace:.1e} final={fin:.1e} "
               f"conditioned: {n2:3d} it, {worst2:.2f} of the allowance {'ok' if ok else 'MISMATCH'}", flush=True)
-        record(f"stereo {'dogleg' if dog >= 0 else 'LM'}", max(nall, n2), ok)
+        record(f"stereo {'dogleg' if dog >= 0 else 'LM'}", nall, ok, n2)
         ba.close()
     print("mismatches:", bad)
     return 1 if (bad or print_summary()) else 0
