@@ -117,8 +117,8 @@ struct ssba_problem {
     hipGraph_t graph2 = nullptr;            // GRAPH_ITERS iterations per replay (ssba_solve_step(n >= GRAPH_ITERS)): a tenth of the replay gaps
     hipGraphExec_t gexec2 = nullptr;
     // multi-rank: the kernel runs between the exchange points are captured as separate graphs
-    hipGraph_t seg_graph[3] = {nullptr, nullptr, nullptr};
-    hipGraphExec_t seg_exec[3] = {nullptr, nullptr, nullptr};
+    hipGraph_t seg_graph[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipGraphExec_t seg_exec[4] = {nullptr, nullptr, nullptr, nullptr};
     bool use_graph = true;
     int eager_iters = 0;                      // iterations enqueued kernel by kernel since the last graph was dropped (enqueue_iteration)
     // solve bookkeeping
@@ -217,7 +217,7 @@ static void drop_graph(ssba_problem *p) {
     if (p->gexec2) { hipGraphExecDestroy(p->gexec2); p->gexec2 = nullptr; }
     if (p->graph2) { hipGraphDestroy(p->graph2); p->graph2 = nullptr; }
     if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (p->seg_exec[i]) { hipGraphExecDestroy(p->seg_exec[i]); p->seg_exec[i] = nullptr; }
         if (p->seg_graph[i]) { hipGraphDestroy(p->seg_graph[i]); p->seg_graph[i] = nullptr; }
     }
@@ -870,8 +870,9 @@ int ssba_finalize(ssba_problem *p) {
         }
     }
     for (auto &f : pfs) pf_cnt[f.pose]++;
-    if (!pfs.empty() && (ph || p->world_size > 1)) {
-        set_error("pose priors / sun observations / relative-pose blocks are not available with lighting terms or landmark sharding yet");
+    if (!pfs.empty() && (ph || p->sep_sb.size() > 2)) {
+        set_error("pose priors / sun observations / relative-pose blocks are not available with lighting terms or with the partitioned "
+                  "reduced solve (ssba_set_partition); landmark sharding with the all-reduce of the reduced system takes them");
         return SSBA_ERR_UNSUPPORTED;
     }
     p->pose_free.assign(P, -1);
@@ -1663,6 +1664,7 @@ int ssba_finalize(ssba_problem *p) {
             }
         }
         d.n_pf = (int)F;
+        d.pf_owner = (p->world_size <= 1 || p->rank == 0) ? 1 : 0;
         TRY(dupload(p, &d.pf_start, start)); TRY(dupload(p, &d.pf_type, type));
         TRY(dupload(p, &d.pf_data, data)); TRY(dupload(p, &d.pf_S, S)); TRY(dupload(p, &d.pf_huber, hub));
         TRY(dzero(p, &d.pf_cost, (size_t)P));
@@ -1721,6 +1723,7 @@ int ssba_finalize(ssba_problem *p) {
     TRY(dzero(p, &d.part_pose, (size_t)(std::max(d.n_pose_blocks, d.Nsb) + 1) * NPP));   // + one entry for the border of shared blocks
     TRY(dzero(p, &d.part_dl, (size_t)(d.n_lm_blocks + d.n_pose_blocks + 1) * NDL));
     TRY(dzero(p, &d.scal2, (size_t)NSCAL));
+    TRY(dzero(p, &d.scal_dl, (size_t)NSCAL));
     TRY(dzero(p, &d.gmax_l, (size_t)1));
     TRY(dzero(p, &d.st, (size_t)1));
     TRY(dzero(p, &d.dbg, (size_t)8192));
@@ -2056,9 +2059,14 @@ static int enqueue_front(ssba_problem *p) {
             const bool fuse_upd = fuse_all && !d.dense && bcr_updates_poses(d);     // the last step of the reduced solve updates the poses
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d, true, fuse_upd); if (d.nb) launch_border_solve(L, d); }
-            if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d);
+            // DOGLEG with landmark sharding: the six sums of the dogleg model are summed over the ranks between the two halves
+            if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d, p->xfn ? 1 : 0, p->rank == 0 ? 1 : 0);
             else launch_update_eval(L, d, !p->xfn && !d.constrained, fuse_best, fuse_upd);
         }))) return rc;
+    if (p->xfn && p->opt.trust_region_strategy_type == 1) {
+        if ((rc = X(d.scal_dl, NSCAL, 0))) return rc;
+        if ((rc = run_segment(p, multi ? 3 : -1, [&] { launch_dogleg_eval(L, d, 2); }))) return rc;
+    }
     if (p->xfn && (rc = X(d.scal2, NSCAL, 0))) return rc;
     return SSBA_OK;
 }
@@ -2145,8 +2153,9 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (o->max_num_iterations < 0 || !(o->initial_trust_region_radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
     if (o->trust_region_strategy_type != 0 && o->trust_region_strategy_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->d.part && !p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
-    if (o->trust_region_strategy_type == 1 && p->xfn) {
-        set_error("DOGLEG is not available with landmark sharding yet (its norms need one more exchange point)");
+    if (o->trust_region_strategy_type == 1 && p->xfn && (p->d.part || p->d.nb)) {
+        set_error("DOGLEG with landmark sharding runs on the all-reduce of the reduced system with constant shared blocks (not with "
+                  "ssba_set_partition: the pose sums of its model need every rank's interior poses; not with free shared lighting blocks)");
         return SSBA_ERR_UNSUPPORTED;
     }
     if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;

@@ -219,9 +219,10 @@ template <bool DN, int NT, int CH> __device__ __forceinline__ void lin_pose_body
         if (threadIdx.x < 27)
 #pragma unroll
             for (int w = 0; w < NT / 64; ++w) v += sm[w][threadIdx.x];
-        if (d.n_pf) {
+        if (d.n_pf && d.pf_owner) {
             // unary residual blocks of this pose (pose prior, sun sensor): every one of the 28 lanes evaluates them
-            // and takes its own entry of J^T J (21), J^T r (6) or the cost (lane 27)
+            // and takes its own entry of J^T J (21), J^T r (6) or the cost (lane 27).  With landmark sharding the poses are
+            // replicated and these sums are added over the ranks: ONE rank contributes the unary blocks (pf_owner)
             int a = 0, c = 0;
             if (threadIdx.x < 21) { int n = threadIdx.x; while (n >= 6 - a) { n -= 6 - a; ++a; } c = a + n; }
             for (uint32_t e = d.pf_start[k]; e < d.pf_start[k + 1]; ++e) {
@@ -1446,14 +1447,37 @@ __device__ bool subspace_boundary_minimum(const State &st, double mo[2]) {
 
 // The scalar part of DoglegStrategy::ComputeStep: norms, Cauchy point, subspace model (when the point
 // is new) and beta, gamma, |step| of delta = beta * delta_gn + gamma * v for the current radius (1 block)
-__global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
+// Landmark sharding: the six dogleg sums (|gradient_|^2, |gn|^2, gradient_.gn, |J v|^2, |J gn|^2, Jv.Jgn) are sums over all
+// residual blocks and parameters.  Every rank forms the part of ITS landmarks (own_poses: the pose and shared-block terms --
+// replicated data, identical on every rank -- are counted by one rank only) into scal_dl; the ranks sum that vector (one more
+// exchange point); k_dogleg_interp(from_scal = 1) goes on from the summed values.
+__global__ __launch_bounds__(256) void k_dogleg_sum(Dev d, int own_poses) {
+    const State &st = *d.st;
+    __shared__ double sm[4];
+    double acc[NDL];
+#pragma unroll
+    for (int q = 0; q < NDL; ++q) acc[q] = 0.0;
+    if (!st.terminated && !st.dl_reuse) {
+        const int n = d.n_lm_blocks + (own_poses ? d.n_pose_blocks + (d.nb ? 1 : 0) : 0);
+        for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+            for (int q = 0; q < NDL; ++q) acc[q] += d.part_dl[(size_t)i * NDL + q];
+    }
+#pragma unroll
+    for (int q = 0; q < NDL; ++q) acc[q] = block_sum(acc[q], sm);
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int q = 0; q < NSCAL; ++q) d.scal_dl[q] = q < NDL ? acc[q] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_dogleg_interp(Dev d, int from_scal) {
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[4];
     double acc[NDL];
 #pragma unroll
     for (int q = 0; q < NDL; ++q) acc[q] = 0.0;
-    if (!st.dl_reuse) {
+    if (!st.dl_reuse && !from_scal) {
         const int n = d.n_lm_blocks + d.n_pose_blocks + (d.nb ? 1 : 0);   // last entry: border of shared blocks
         for (int i = threadIdx.x; i < n; i += 256)
 #pragma unroll
@@ -1462,6 +1486,10 @@ __global__ __launch_bounds__(256) void k_dogleg_interp(Dev d) {
 #pragma unroll
     for (int q = 0; q < NDL; ++q) acc[q] = block_sum(acc[q], sm);
     if (threadIdx.x != 0) return;
+    if (from_scal) {
+#pragma unroll
+        for (int q = 0; q < NDL; ++q) acc[q] = d.scal_dl[q];
+    }
     if (!st.dl_reuse) {
         st.grad_norm = sqrt(acc[0]); st.gn_norm = sqrt(acc[1]); st.g_dot_gn = acc[2];
         st.alpha = acc[0] / acc[3];   // ComputeCauchyPoint
@@ -1784,7 +1812,12 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
 // Window layout: several lanes per landmark pay off while one lane per landmark leaves the SIMDs short of waves (C2: 1.5
 // waves per SIMD); from ~4 waves per SIMD on the plain mapping wins (C4: 15 600 waves; measured 0.106 / 0.224 ms vs
 // 0.133 / 0.272 ms for the split kernels).
-static bool lm_split(const Dev &d) { return !d.dense && !d.phong && d.Lpad <= 262144; }
+// r04: above that size the window kernels run with ONE wave per 64 landmarks (SP = 1: the plain mapping's lane count) instead
+// of handing the problem to the generic kernels -- those lack the folded control work (commit inside the linearisation, best
+// copy inside the evaluation, k_check's sums per group), so C4 on one GPU paid five dependent single-block launches (60 us) per
+// iteration that C2 does not have.
+static bool lm_split(const Dev &d) { return !d.dense && !d.phong; }
+static int lm_sp(const Dev &d) { return d.Lpad <= 262144 ? LMW_SPLIT : 1; }
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
 static bool ctrl_fusable(const Dev &d) { return !d.dense && !d.part; }       // (lighting terms included: same partial sums, same reduced system)
@@ -1800,7 +1833,8 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
+        if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
+        else if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w<1>, dim3(d.n_groups), dim3(64), 0, d, fuse_all ? 1 : 0);
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         // 128 lanes per pose, five observations in flight per lane (sweep on C2, profiles/r02_pose_kernel_shape.txt: 64 / 128 / 192 /
         // 256 / 512 lanes x 3-10 observations: 24.5 us here, 31 us for 256 x 3, 51 us for 512 x 3)
@@ -1843,7 +1877,8 @@ void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_b
     const int fb = fuse_best && best_fusable(d) ? 1 : 0;
     if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
     if (d.phong) launch_ph_backsub_eval(L, d, fb);
-    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
+    else if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
+    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w<1>, dim3(d.n_groups), dim3(64), 0, d, pose_update_done ? 2 : fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks, d.part ? 1 : 0);
 }
@@ -1869,11 +1904,19 @@ void launch_pose_update(Launcher &L, const Dev &d, int ls_round) {
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, ls_round ? -1 : 0);
 }
 
-void launch_dogleg_eval(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks), dim3(256), 0, d);
-    if (d.phong) launch_ph_dogleg_gn(L, d);
-    else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_gn<true> : k_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d);
+// stage 0: everything (single GPU).  Landmark sharding: stage 1 = up to this rank's six sums (scal_dl; own_poses on one rank),
+// stage 2 = from the summed vector on
+void launch_dogleg_eval(Launcher &L, const Dev &d, int stage, int own_poses) {
+    if (stage != 2) {
+        LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks), dim3(256), 0, d);
+        if (d.phong) launch_ph_dogleg_gn(L, d);
+        else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_gn<true> : k_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
+    }
+    if (stage == 1) {
+        LAUNCH(KC_SMALL, k_dogleg_sum, dim3(1), dim3(256), 0, d, own_poses);
+        return;
+    }
+    LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d, stage == 2 ? 1 : 0);
     LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, 0);
     if (d.phong) launch_ph_dogleg_eval(L, d);
     else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_eval<true> : k_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);

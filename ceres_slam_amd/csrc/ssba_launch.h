@@ -129,7 +129,7 @@ void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false, bool pose_update_done = false);
-void launch_dogleg_eval(Launcher &L, const Dev &d);
+void launch_dogleg_eval(Launcher &L, const Dev &d, int stage = 0, int own_poses = 1);      // stage: see ssba_kernels.hip (landmark sharding: one more exchange point)
 void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false, int n_pose_parts = -1);
 // config 3 (ssba_phong_solver.hip)
 int upload_phong_tables(hipStream_t s);

@@ -223,6 +223,7 @@ struct Dev {
     double *part_eval;               // n_lm_blocks*4: cand cost, mcc, |dl|^2, nonfinite
     double *part_pose;               // ceil(P/256)*2: |dx_pose|^2, nonfinite
     double *scal2;                   // NSCAL: second exchange vector
+    double *scal_dl;                 // NSCAL: the six dogleg sums of this rank (landmark sharding: summed over the ranks between k_dogleg_sum and k_dogleg_interp)
     double *gmax_l;                  // 1: landmark part of the gradient max norm
     int n_pose_blocks;
     State *st;
@@ -266,6 +267,7 @@ struct Dev {
     double *part_ls;                                // n_lm_blocks * NLS line-search partials
     double *ls_out;                                 // NLS_OUT scalars the host reads per probe, then NLS_MACH doubles holding the device-side search's state (ssba_linesearch.h: Armijo)
     // unary pose residual blocks (pose prior, sun sensor), sorted by pose
+    int pf_owner;                                   // landmark sharding: this rank adds the unary blocks to the sums that are exchanged (H_pp, g_p, cost); every rank evaluates them at the candidate
     int n_pf, pos_const;                            // pos_const: every position block constant (--multistage stage 2; lighting problems)
     const uint32_t *pf_start;                       // P+1
     const int *pf_type;                             // F

@@ -28,12 +28,18 @@ def main():
     huber_a = float(os.environ.get("SSBA_TEST_HUBER", "0"))      # with it: 30 % outlier observations (BASELINE.json configs[4])
     lighting = None
     shared_free = 0
+    pose_factors = None
     if mode.endswith("_phong") or mode.endswith("_phongfree"):     # BASELINE.json configs[2] sharded: lighting terms of a landmark live on its rank
         shared_free = 7 if mode.endswith("free") else 0
         mode = mode[:mode.rindex("_")]
         prob, ph = synth.make_phong_problem(P, Lm, track_len=T, seed=21)
         # shared light / Phong / texture blocks constant, or free (their border sums ride next to the reduced system)
         lighting = ph.as_oracle_dict("perturbed" if shared_free else "truth")
+    elif mode.endswith("_sun"):        # unary pose residual blocks (pose prior + sun sensor, tests/dataset_vo_sun.cpp:80-124), no constant pose
+        mode = mode[:mode.rindex("_")]
+        from test_oracle_pose_factors import _sun_problem
+        prob, pose_factors = _sun_problem(P=P, L=Lm, seed=5, huber=huber_a)
+        huber_a = 0.0
     else:
         prob = synth.make_problem(P, Lm, track_len=T, seed=21, outlier_fraction=0.3 if huber_a > 0 else 0.0)
     partition = None
@@ -69,9 +75,13 @@ def main():
                       intensity=lighting["intensity"][sel], normal_obs=lighting["normal_obs"][sel])
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
                       prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a, lighting=lt,
-                      shared_free=shared_free)
+                      shared_free=shared_free, pose_factors=pose_factors,
+                      pose_const=np.zeros(prob.num_poses, dtype=np.uint8) if pose_factors else None)
         sharding.attach_torch_exchange(ba, dist)
-        s, log = ba.solve(capi.default_options(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1))
+        okw = dict(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1)
+        if "SSBA_TEST_DOGLEG" in os.environ:        # 0 TRADITIONAL_DOGLEG, 1 SUBSPACE_DOGLEG (tests/dataset_ba_phong.cpp:85-86)
+            okw.update(trust_region_strategy_type=1, dogleg_type=int(os.environ["SSBA_TEST_DOGLEG"]))
+        s, log = ba.solve(capi.default_options(**okw))
         res.update(termination=int(s.termination_type), num_iterations=int(s.num_iterations),
                    final_cost=float(s.final_cost), initial_cost=float(s.initial_cost), cost=log["cost"].tolist(),
                    poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist(),

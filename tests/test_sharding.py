@@ -110,6 +110,67 @@ def test_sharded_long_tracks_match_unsharded_oracle(tmp_path, world, size):
         np.testing.assert_array_equal(res[0]["poses"], r["poses"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,size,dogleg,mode", [(2, (16, 400, 6), 0, "gpu"), (3, (40, 1600, 12), 1, "gpu"), (2, (60, 2400, 20), 1, "gpu"),
+                                                    (2, (60, 2400, 12), 1, "gpu_phong")])
+def test_sharded_dogleg_solve_matches_unsharded_oracle(tmp_path, world, size, dogleg, mode):
+    """The trust-region strategy of the reference's BA driver (tests/dataset_ba_phong.cpp:85-86: DOGLEG, SUBSPACE_DOGLEG) with
+    landmark sharding: the six sums of the dogleg model (|gradient|^2, |gn|^2, gradient.gn, |Jv|^2, |Jgn|^2, Jv.Jgn) are
+    per-rank partial sums that the ranks add at one more exchange point; windowed layout, long tracks (144-row super-blocks)
+    and lighting terms with constant shared blocks.  Same iterates as the unsharded oracle, ranks bit-identical."""
+    K = 25
+    res = _run_ranks(mode, str(tmp_path / "dl"), world, size=size, extra_env={"SSBA_TEST_MAXIT": str(K), "SSBA_TEST_DOGLEG": str(dogleg)})
+    okw = dict(num_threads=2, max_num_iterations=K, trust_region_strategy_type=1, dogleg_type=dogleg)
+    if mode == "gpu_phong":
+        prob, ph = synth.make_phong_problem(size[0], size[1], track_len=size[2], seed=21)
+        op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                               prob.stiffness(), lighting=ph.as_oracle_dict("truth"))
+    else:
+        prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21)
+        op = orc.OracleProblem.from_synth(prob)
+    s, log = op.solve(orc.driver_options(**okw))
+    for r in res:
+        assert r["num_iterations"] == s.num_iterations
+        assert r["accept"] == log["step_is_successful"].tolist()
+        ok = np.asarray(log["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-8)
+        assert r["final_cost"] == pytest.approx(s.final_cost, rel=1e-6)
+        assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-6
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0]["poses"], r["poses"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dogleg,huber", [(2, None, 0.0), (3, 1, 0.5)])
+def test_sharded_solve_with_pose_factors_matches_unsharded_oracle(tmp_path, world, dogleg, huber):
+    """Pose prior + sun-sensor blocks (tests/dataset_vo_sun.cpp:80-124: no constant pose, the prior anchors the window;
+    HuberLoss on the sun blocks; the driver's SUBSPACE_DOGLEG) with landmark sharding: the poses are replicated, ONE rank
+    adds the unary blocks to the sums the ranks exchange, every rank evaluates them at the candidate."""
+    from test_oracle_pose_factors import _sun_problem
+    K = 20
+    env = {"SSBA_TEST_MAXIT": str(K), "SSBA_TEST_HUBER": str(huber)}
+    okw = dict(num_threads=2, max_num_iterations=K)
+    if dogleg is not None:
+        env["SSBA_TEST_DOGLEG"] = str(dogleg)
+        okw.update(trust_region_strategy_type=1, dogleg_type=dogleg)
+    res = _run_ranks("gpu_sun", str(tmp_path / "sun"), world, size=(30, 1500, 5), extra_env=env)
+    prob, factors = _sun_problem(P=30, L=1500, seed=5, huber=huber)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd, prob.stiffness(),
+                           pose_const=np.zeros(prob.num_poses, dtype=np.uint8), pose_factors=factors)
+    s, log = op.solve(orc.driver_options(**okw))
+    for r in res:
+        assert r["num_iterations"] == s.num_iterations
+        assert r["accept"] == log["step_is_successful"].tolist()
+        ok = np.asarray(log["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-7)
+        assert r["final_cost"] == pytest.approx(s.final_cost, rel=1e-6)
+        assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-5
+    for r in res[1:]:
+        np.testing.assert_array_equal(res[0]["poses"], r["poses"])
+
+
 def test_aligned_partition_cuts_at_superblock_boundaries():
     for P, L, W in ((40, 1600, 2), (60, 2400, 3), (300, 12000, 4)):
         prob = synth.make_problem(P, L)
