@@ -87,7 +87,6 @@ static __device__ __forceinline__ void xcd_map(int id, int n, int ny, int &e, in
 }
 static int xcd_grid(int n, int ny) { return n * ny; }
 
-constexpr double MF_LBIG = 1024.0;     // a sub-step with |l| beyond this is taken in substitution form (factor_tile)
 constexpr int MF_THREADS = 256;
 constexpr int NDT = 5;          // tile rows / column tiles of [D | r | 0]
 constexpr int NRT = 9;          // column tiles of [L | U^T]
@@ -250,7 +249,6 @@ struct FactorLds {
     double P[NDT][4][64], Q[NDT][4][64];    // sub-step operands of the diagonal tiles: [block row][sub-step][lane]
     double A[NDT - 1][4][4][64];            // finished D panels as A operands: [block row][column tile - 1][register][lane]
     double rc[80], rs[80];                  // 1 / pivot, 1 / sqrt(pivot) by row
-    double Ls[NDT][4][8];                   // sub-steps taken in substitution form (see factor_tile): l10 l20 l30 l21 l31 l32 | flag
     // hand-offs between the four waves (LDS words, monotonic): no workgroup barrier inside the factorisation
     int seqPQ;                              // sub-steps published so far: 4 k + r + 1
     int seqA[4];                            // per column tile - 1: block rows whose panel is published (k + 1)
@@ -563,38 +561,16 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
             Pv = fma(n31, k31, Pv);
             Pv = fma(-l32, k32, Pv);
             Pv = fma(n30, k30, Pv);
-            // P is the EXPLICIT inverse of the unit-lower factor: its entries are products of the l's, and c = P T cancels
-            // terms of size |l|^2 |T| where substitution cancels |l| |T| -- harmless while the pivots are healthy, but with a
-            // pivot of relative size ~1e-16 (rank-deficient problems at trust-region radii beyond 1e9: r03's fuzz sweeps) the later
-            // pivots of the block lost their sign a few iterations before the oracle's Cholesky did.  A sub-step whose block has
-            // |l| > MF_LBIG is therefore taken in substitution form: three elementary eliminations (columns 0, 1, 2 of l), one
-            // matrix instruction each -- the same result as row-by-row substitution -- and every consumer of the sub-step does the
-            // same (S.Ls: the six l's and the flag).  The test is wave-uniform (all lanes hold the same scalars); on healthy
-            // systems no sub-step is ever flagged.
-            const double lmax = fmax(fmax(fmax(fabs(l10), fabs(l20)), fmax(fabs(l30), fabs(l21))), fmax(fabs(l31), fabs(l32)));
-            const int big = __builtin_amdgcn_readfirstlane(lmax > MF_LBIG ? 1 : 0);
-            double y;                           // lane (g, j): unnormalised pivot row c_g[j] = (d l^T ...)[4r + g][j]
-            if (big) {
-                const double PA = fma(-l30, k30, fma(-l20, k20, fma(-l10, k10, kDiag)));
-                const double PB = fma(-l31, k31, fma(-l21, k21, kDiag));
-                const double PC = fma(-l32, k32, kDiag);
-                const mf_d4 a4 = mf(PA, tr, mf_d4{0.0, 0.0, 0.0, 0.0});
-                const mf_d4 b4 = mf(PB, a4[0], mf_d4{0.0, 0.0, 0.0, 0.0});
-                const mf_d4 c4 = mf(PC, b4[0], mf_d4{0.0, 0.0, 0.0, 0.0});
-                y = c4[0];
-            } else {
-                const mf_d4 y4 = mf(Pv, tr, mf_d4{0.0, 0.0, 0.0, 0.0});
-                y = y4[0];
-            }
+            const mf_d4 y4 = mf(Pv, tr, mf_d4{0.0, 0.0, 0.0, 0.0});
             const double rcg = fma(rc3, kG3, fma(rc2, kG2, fma(rc1, kG1, rc0 * kG0)));
             const double qs = (j > b + 3) ? -rcg : 0.0;
+            const double y = y4[0];             // lane (g, j): unnormalised pivot row c_g[j] = (d l^T ...)[4r + g][j]
             T[r] = y;
             const double Qv = y * qs;
             if (r + 1 < nsub) T = mf(Qv, y, T);
             S.P[k][r][lane] = Pv;
             S.Q[k][r][lane] = Qv;
             if (j == 0) S.rc[16 * k + b + g] = rcg;         // four lanes, one reciprocal pivot each
-            if (lane < 8) S.Ls[k][r][lane] = lane == 0 ? l10 : lane == 1 ? l20 : lane == 2 ? l30 : lane == 3 ? l21 : lane == 4 ? l31 : lane == 5 ? l32 : lane == 6 ? (double)big : 0.0;
             MF_POST(S.seqPQ, 4 * k + r + 1);
         }
     };
@@ -604,25 +580,10 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
     // operand of the update of the wave's OWN diagonal tile (dj, dj), and goes out to LDS as the A operand of
     // everybody's updates of block row dj.  The R stream (the wave's tiles of [L | U^T]) follows one block row behind
     // and fills the time the wave would otherwise spend waiting for the next diagonal tile.
-    // c = M x for the rows of sub-step (k, r): one instruction with the explicit inverse, or -- flagged sub-steps -- the three
-    // elementary eliminations the diagonal tile took (factor_tile)
-    auto apply_P = [&](int k, int r, double Pv, double bigf, double x) -> double {
-        if (__builtin_amdgcn_readfirstlane(bigf != 0.0 ? 1 : 0)) {
-            const double l10 = S.Ls[k][r][0], l20 = S.Ls[k][r][1], l30 = S.Ls[k][r][2], l21 = S.Ls[k][r][3], l31 = S.Ls[k][r][4], l32 = S.Ls[k][r][5];
-            const double PA = fma(-l30, k30, fma(-l20, k20, fma(-l10, k10, kDiag)));
-            const double PB = fma(-l31, k31, fma(-l21, k21, kDiag));
-            const double PC = fma(-l32, k32, kDiag);
-            const mf_d4 a4 = mf(PA, x, mf_d4{0.0, 0.0, 0.0, 0.0});
-            const mf_d4 b4 = mf(PB, a4[0], mf_d4{0.0, 0.0, 0.0, 0.0});
-            const mf_d4 c4 = mf(PC, b4[0], mf_d4{0.0, 0.0, 0.0, 0.0});
-            return c4[0];
-        }
-        const mf_d4 y4 = mf(Pv, x, mf_d4{0.0, 0.0, 0.0, 0.0});
-        return y4[0];
-    };
     auto d_panel = [&](int k) {
-        auto sub = [&](int r, double Pv, double Qv, double rcr, double bigf) {
-            const double y = apply_P(k, r, Pv, bigf, dt[k][r]);
+        auto sub = [&](int r, double Pv, double Qv, double rcr) {
+            const mf_d4 yd = mf(Pv, dt[k][r], mf_d4{0.0, 0.0, 0.0, 0.0});
+            const double y = yd[0];
             dt[k][r] = y;
             const double a = -y * rcr;
             S.A[k][max(dj, 1) - 1][r][lane] = a;       // (dj >= 1 wherever this runs)
@@ -635,29 +596,29 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
         // operand reads in one batch (otherwise every sub-step pays a flag read and an operand read round trip)
         if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&S.seqPQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 4 * k + 4) {
             asm volatile("" ::: "memory");
-            double Pa[4], Qa[4], ra[4], fa[4];
+            double Pa[4], Qa[4], ra[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { Pa[r] = S.P[k][r][lane]; Qa[r] = S.Q[k][r][lane]; ra[r] = S.rc[16 * k + 4 * r + g]; fa[r] = S.Ls[k][r][6]; }
+            for (int r = 0; r < 4; ++r) { Pa[r] = S.P[k][r][lane]; Qa[r] = S.Q[k][r][lane]; ra[r] = S.rc[16 * k + 4 * r + g]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sub(r, Pa[r], Qa[r], ra[r], fa[r]);
+            for (int r = 0; r < 4; ++r) sub(r, Pa[r], Qa[r], ra[r]);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // flag and operands in ONE batch of LDS reads (the LDS serves a wave's reads in order: operands read
                 // after a flag value that says "published" are the published ones); retried until the flag is there
-                double Pv, Qv, rcr, bigf;
+                double Pv, Qv, rcr;
                 int it_ = 0;
                 for (;;) {
                     const int f = __hip_atomic_load(&S.seqPQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     asm volatile("" ::: "memory");
-                    Pv = S.P[k][r][lane]; Qv = S.Q[k][r][lane]; rcr = S.rc[16 * k + 4 * r + g]; bigf = S.Ls[k][r][6];
+                    Pv = S.P[k][r][lane]; Qv = S.Q[k][r][lane]; rcr = S.rc[16 * k + 4 * r + g];
                     asm volatile("" ::: "memory");
                     if (__builtin_amdgcn_readfirstlane(f) >= 4 * k + r + 1) break;
                     if (++it_ > (1 << 20)) { S.bad = 2; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                sub(r, Pv, Qv, rcr, bigf);
+                sub(r, Pv, Qv, rcr);
             }
         }
         MF_POST(S.seqA[dj - 1], k + 1);
@@ -758,22 +719,22 @@ static __device__ __forceinline__ void factor_body(const Dev &d, FactorLds &S, d
     auto r_step = [&](int k) {
         const int nsub = k < 4 ? 4 : 2;
         MF_WAIT_GE(S.seqPQ, 4 * k + nsub);          // this stream lags: the whole diagonal tile is normally long done
-        double Pa[4], Qa[4], fa[4];
+        double Pa[4], Qa[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { Pa[r] = r < nsub ? S.P[k][r][lane] : 0.0; Qa[r] = r < nsub ? S.Q[k][r][lane] : 0.0; fa[r] = r < nsub ? S.Ls[k][r][6] : 0.0; }
+        for (int r = 0; r < 4; ++r) { Pa[r] = r < nsub ? S.P[k][r][lane] : 0.0; Qa[r] = r < nsub ? S.Q[k][r][lane] : 0.0; }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r >= nsub) break;
             const double Pv = Pa[r], Qv = Qa[r];
-            double yq[NRA];
+            mf_d4 yq[NRA];
 #pragma unroll
             for (int q = 0; q < NRW; ++q)
-                if (ract[q]) yq[q] = apply_P(k, r, Pv, fa[r], rt[q][k][r]);
+                if (ract[q]) yq[q] = mf(Pv, rt[q][k][r], mf_d4{0.0, 0.0, 0.0, 0.0});
 #pragma unroll
             for (int q = 0; q < NRW; ++q)
                 if (ract[q]) {
-                    rt[q][k][r] = yq[q];
-                    if (r + 1 < nsub) rt[q][k] = mf(Qv, yq[q], rt[q][k]);
+                    rt[q][k][r] = yq[q][0];
+                    if (r + 1 < nsub) rt[q][k] = mf(Qv, yq[q][0], rt[q][k]);
                 }
         }
         if (MODE == 2) y_rows(k);       // block row k of this wave's columns of [YL | YU] is final: into LDS for the Gram products

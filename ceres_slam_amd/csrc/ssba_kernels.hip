@@ -379,26 +379,29 @@ typedef double schur_d4 __attribute__((ext_vector_type(4)));
 
 // n_zero > 0: the first n_zero workgroups clear the block-tridiagonal reduced system (D and L of every super-block) that
 // k_assemble_reduced fills next -- a memset launch less per iteration, hidden beside the Schur items.
-// check_parts > 0 (single GPU, LM: launch_schur(.., check_in_schur)): one more work-group at the end of the grid does
+// check_parts > 0 (single GPU, LM: launch_schur(.., check_in_schur)): one more work-group at the head of the grid does
 // k_check's work (the sums of the linearisation partials, the projected-gradient norm over the poses, the convergence tests
 // and the iteration bookkeeping).  Everything it reads was written by the linearisation launches, nothing it writes is read by
 // the Schur items (radius, options and the termination flag apart -- a stale 0 there costs one wasted pass), so the
 // 10 us dependent launch disappears inside this 75 us one.  k_assemble_reduced, which now runs AFTER the iteration
 // counter was advanced, is told so (its `it0`).
 __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n_zero, int check_parts) {
-    if (check_parts > 0 && blockIdx.x == gridDim.x - 1) { check_body(d, check_parts, true); return; }
+    // (r04: the FIRST work-group of the grid, not the last -- at C4 its sums over 15 625 partial entries and 10 000 poses take
+    // longer than a Schur item, and as the last work-group it was the launch's tail: +80 us)
+    if (check_parts > 0 && blockIdx.x == 0) { check_body(d, check_parts, true); return; }
+    const int bid = (int)blockIdx.x - (check_parts > 0 ? 1 : 0);
     const State &st = *d.st;
     // the solver state is written by the previous launch on another XCD: its read is a ~2 us round trip.  It is tested
     // after the item's first operand reads have been issued, not before (a launch that returns at once measures 4.5 us
     // against 2.75 us for an empty kernel: that difference sits at the head of every kernel that tests the state first)
     const int dead = st.terminated | st.dl_reuse;
-    if ((int)blockIdx.x < n_zero) {
+    if (bid < n_zero) {
         if (dead) return;
         // D and L of every super-block; of this rank's chain only in a partitioned solve (the rest is never assembled)
         const size_t b0 = d.part ? (size_t)d.chain0 * BD * BD : 0;
         const size_t n2 = (d.part ? (size_t)(d.chain1 - d.chain0 + 1) : (size_t)d.Nsb) * (BD * BD / 2);       // double2 per range
         double2 *zD = reinterpret_cast<double2 *>(d.xv + d.off_D + b0), *zL = reinterpret_cast<double2 *>(d.xv + d.off_L + b0);
-        for (size_t i = (size_t)blockIdx.x * SCHUR_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * SCHUR_THREADS) {
+        for (size_t i = (size_t)bid * SCHUR_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * SCHUR_THREADS) {
             zD[i] = make_double2(0.0, 0.0);
             zL[i] = make_double2(0.0, 0.0);
         }
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
     }
     extern __shared__ __align__(16) double schur_lds[];
     double *sZ = schur_lds;                              // [k][col]
-    const int item = (int)blockIdx.x - n_zero;
+    const int item = bid - n_zero;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1816,7 +1819,10 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o) {
 // of handing the problem to the generic kernels -- those lack the folded control work (commit inside the linearisation, best
 // copy inside the evaluation, k_check's sums per group), so C4 on one GPU paid five dependent single-block launches (60 us) per
 // iteration that C2 does not have.
-static bool lm_split(const Dev &d) { return !d.dense && !d.phong; }
+static bool lm_split(const Dev &d) {
+    static const bool cliff = [] { const char *e = getenv("SSBA_LM_CLIFF"); return e && e[0] == '1'; }();      // r03's bound (A/B)
+    return !d.dense && !d.phong && (!cliff || d.Lpad <= 262144);
+}
 static int lm_sp(const Dev &d) { return d.Lpad <= 262144 ? LMW_SPLIT : 1; }
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check

@@ -531,17 +531,17 @@ template <bool BORDER> struct PhSchurCfg {
 };
 typedef double ph_d4 __attribute__((ext_vector_type(4)));
 
-// check_parts > 0: one more work-group at the end of the grid does k_check's work (see k_schur_windows, ssba_kernels.hip)
+// check_parts > 0: one more work-group at the head of the grid does k_check's work (see k_schur_windows, ssba_kernels.hip)
 template <bool BORDER> __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_schur_windows(Dev d, int check_parts) {
     typedef PhSchurCfg<BORDER> C;
     constexpr int PH_BATCH = C::BATCH, PH_KB = C::KB, PH_RS = C::RS, LMW = C::LMW, BC0 = C::BC0;
-    if (check_parts > 0 && blockIdx.x == gridDim.x - 1) { check_body(d, check_parts, true); return; }
+    if (check_parts > 0 && blockIdx.x == 0) { check_body(d, check_parts, true); return; }      // (the first work-group: it must not be the launch's tail)
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     extern __shared__ __align__(16) double ph_lds[];
     double *sZ = ph_lds;                         // [k][col]
     double *sLM = ph_lds + PH_KB * PH_RS;        // [landmark][M(21) | g_l(6) | pad | M V (42) | material]
-    const int item = blockIdx.x;
+    const int item = (int)blockIdx.x - (check_parts > 0 ? 1 : 0);
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;

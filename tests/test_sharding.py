@@ -134,7 +134,9 @@ def test_sharded_dogleg_solve_matches_unsharded_oracle(tmp_path, world, size, do
         assert r["accept"] == log["step_is_successful"].tolist()
         ok = np.asarray(log["step_is_successful"], dtype=bool)
         ok[0] = True
-        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-8)
+        # (SUBSPACE_DOGLEG on lighting problems amplifies rounding to ~1e-8 in its first iteration -- the Gauss-Newton solve with
+        # mu = 1e-8 --: tools/fuzz_parity.py conditioned_agreement; the unsharded lighting tests compare at 1e-6 too)
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-6 if mode == "gpu_phong" else 1e-8)
         assert r["final_cost"] == pytest.approx(s.final_cost, rel=1e-6)
         assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-6
     for r in res[1:]:
