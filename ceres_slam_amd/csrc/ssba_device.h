@@ -164,6 +164,70 @@ static __device__ __forceinline__ void jac_pose(const ObsLin &o, double Jp[18]) 
     }
 }
 
+// The Schur factor of one stereo observation,  Z = W M^T  (W = J_p^T J_l, 6 x 3; C^-1 = M^T M, M lower triangular
+// m00 m10 m11 m20 m21 m22), without forming the Jacobians:  J_p = A [I | -q^],  J_l = A R  give
+//     W = [X ; q x X]  with  X = G R,  G = A^T A    =>    Z = [B ; q x B],  B = G R M^T
+// -- 81 multiply-adds against the 120 of jac_pose + jac_point + W + Z (r04: the producer phase of the Schur kernels is fp64
+// VALU work on the datapath the matrix instructions need).  A = sqrt(rho') S J_pi as obs_linearize_S forms it; the residual
+// is only evaluated when a loss is set (it gives rho').  z[6 c + a] = Z[a][c].
+static __device__ __forceinline__ void obs_schur_factor(const Dev &d, const double *__restrict__ S, const double *__restrict__ T,
+                                                        double px, double py, double pz, double u, double v, double dd,
+                                                        const double m[6], double z[18]) {
+    const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
+    const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
+    const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
+    const double iz = 1.0 / q2;
+    const double j00 = d.fu * iz, j11 = d.fv * iz;
+    const double iz2 = iz * iz;
+    const double j02 = -d.fu * q0 * iz2, j12 = -d.fv * q1 * iz2, j22 = -d.fu * d.b * iz2;
+    double A[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double s0 = S[3 * i], s1 = S[3 * i + 1], s2 = S[3 * i + 2];
+        A[3 * i] = s0 * j00;
+        A[3 * i + 1] = s1 * j11;
+        A[3 * i + 2] = s0 * j02 + s1 * j12 + s2 * j22;
+    }
+    double w2 = 1.0;        // rho' (the corrector scales A by its square root: G by rho')
+    if (d.huber_a > 0.0) {
+        const double e0 = d.fu * q0 * iz + d.cu - u, e1 = d.fv * q1 * iz + d.cv - v, e2 = d.fu * d.b * iz - dd;
+        double sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r = S[3 * i] * e0 + S[3 * i + 1] * e1 + S[3 * i + 2] * e2;
+            sq += r * r;
+        }
+        if (sq > d.huber_a * d.huber_a) {
+            const double sc = sqrt(fmax(DBL_MIN, d.huber_a / sqrt(sq)));     // as obs_linearize_S: A *= sc
+#pragma unroll
+            for (int i = 0; i < 9; ++i) A[i] *= sc;
+        }
+    }
+    (void)w2;
+    const double g00 = A[0] * A[0] + A[3] * A[3] + A[6] * A[6], g01 = A[0] * A[1] + A[3] * A[4] + A[6] * A[7];
+    const double g02 = A[0] * A[2] + A[3] * A[5] + A[6] * A[8], g11 = A[1] * A[1] + A[4] * A[4] + A[7] * A[7];
+    const double g12 = A[1] * A[2] + A[4] * A[5] + A[7] * A[8], g22 = A[2] * A[2] + A[5] * A[5] + A[8] * A[8];
+    double B[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double ga0 = a == 0 ? g00 : a == 1 ? g01 : g02, ga1 = a == 0 ? g01 : a == 1 ? g11 : g12, ga2 = a == 0 ? g02 : a == 1 ? g12 : g22;
+        const double x0 = ga0 * T[3] + ga1 * T[6] + ga2 * T[9];          // X = G R
+        const double x1 = ga0 * T[4] + ga1 * T[7] + ga2 * T[10];
+        const double x2 = ga0 * T[5] + ga1 * T[8] + ga2 * T[11];
+        B[3 * a] = x0 * m[0];                                             // B = X M^T
+        B[3 * a + 1] = x0 * m[1] + x1 * m[2];
+        B[3 * a + 2] = x0 * m[3] + x1 * m[4] + x2 * m[5];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double b0 = B[c], b1 = B[3 + c], b2 = B[6 + c];
+        z[6 * c] = b0; z[6 * c + 1] = b1; z[6 * c + 2] = b2;
+        z[6 * c + 3] = q1 * b2 - q2 * b1;
+        z[6 * c + 4] = q2 * b0 - q0 * b2;
+        z[6 * c + 5] = q0 * b1 - q1 * b0;
+    }
+}
+
 // so3group.hpp:273-291 ; perturbations.hpp:61-62 with se3group.hpp:176-183,323-325
 static __device__ __forceinline__ void se3_plus(const double *__restrict__ T, const double *__restrict__ eps,
                                          double *__restrict__ out) {

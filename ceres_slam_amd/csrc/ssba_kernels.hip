@@ -489,21 +489,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
             }
             if (raw.in_range && pose_ok && ((raw.mask >> s) & 1u)) {
                 live = true;
-                ObsLin o;
-                obs_linearize(d, T, raw.p[0], raw.p[1], raw.p[2], raw.u, raw.v, raw.dd, o);
-                double Jp[18], Jl[9];
-                jac_pose(o, Jp);
-                jac_point(o, T, Jl);
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    double wa[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        wa[c] = Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c] + Jp[12 + a] * Jl[6 + c];
-                    z[a] = wa[0] * m[0];                                      // Z = W M^T
-                    z[6 + a] = wa[0] * m[1] + wa[1] * m[2];
-                    z[12 + a] = wa[0] * m[3] + wa[1] * m[4] + wa[2] * m[5];
-                }
+                obs_schur_factor(d, d.S, T, raw.p[0], raw.p[1], raw.p[2], raw.u, raw.v, raw.dd, m, z);       // Z = W M^T
             }
             if (!live) {
 #pragma unroll
