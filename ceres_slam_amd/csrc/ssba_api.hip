@@ -1069,7 +1069,7 @@ int ssba_finalize(ssba_problem *p) {
     p->user_of_dev.assign(Lpad, 0xFFFFFFFFu);
     // general path: landmark-major observation arrays + the pose-major index list into them
     std::vector<uint32_t> dn_lm_start, dn_obs_pose, dn_obs_lm, dn_pose_start, dn_pose_obs, dn_zpos;
-    std::vector<double> dn_u, dn_v, dn_d, dn_Sobs;
+    std::vector<double> dn_u, dn_v, dn_d, dn_Sobs, dn_prec;
     std::vector<uint32_t> dn_blk_a, dn_blk_b, dn_blk_start, dn_pair_a, dn_pair_b, dn_pose_mat_start, dn_ztile;
     DensePlan dplan;
     WideLayout wlay;
@@ -1117,6 +1117,15 @@ int ssba_finalize(ssba_problem *p) {
         // and pose b's records in ascending order instead of striding through a landmark-major array
         dn_zpos.resize(dn_obs_pose.size());
         for (uint32_t i = 0; i < dn_pose_obs.size(); ++i) dn_zpos[dn_pose_obs[i]] = i;
+        if (!ph && !p->per_obs_S) {      // pose-major copy of the observation records for k_linearize_poses
+            dn_prec.resize(4 * dn_pose_obs.size());
+            for (size_t i = 0; i < dn_pose_obs.size(); ++i) {
+                const uint32_t e = dn_pose_obs[i];
+                const int64_t lm = (int64_t)dn_obs_lm[e];
+                dn_prec[4 * i] = dn_u[e]; dn_prec[4 * i + 1] = dn_v[e]; dn_prec[4 * i + 2] = dn_d[e];
+                memcpy(&dn_prec[4 * i + 3], &lm, 8);
+            }
+        }
         if (wide_sys) {     // 144-row super-blocks: Schur items, slot table, gather lists (no pair lists, no symbolic Cholesky)
             if (!build_wide_layout(nfree, Lact, Lpad, dn_lm_start.data(), dn_obs_pose.data(), p->pose_free.data(), 128u, wlay)) {
                 set_error("internal: a landmark's free poses span more than the wide window");
@@ -1677,6 +1686,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.dn_lm_start, dn_lm_start)); TRY(dupload(p, &d.dn_obs_pose, dn_obs_pose)); TRY(dupload(p, &d.dn_obs_lm, dn_obs_lm));
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
         TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs)); TRY(dupload(p, &d.dn_zpos, dn_zpos));
+        if (!dn_prec.empty()) TRY(dupload(p, &d.dn_prec, dn_prec));
         WideSys &w = p->launcher.wide;
         const uint64_t wblk = (uint64_t)WBD * WBD;
         w.n = wlay.n; w.n_items = (int)wlay.n_items; w.n_blk = (int)wlay.blk_a.size();
@@ -1712,6 +1722,7 @@ int ssba_finalize(ssba_problem *p) {
         TRY(dupload(p, &d.dn_u, dn_u)); TRY(dupload(p, &d.dn_v, dn_v)); TRY(dupload(p, &d.dn_d, dn_d));
         if (p->per_obs_S) TRY(dupload(p, &d.dn_Sobs, dn_Sobs));
         TRY(dupload(p, &d.dn_pose_start, dn_pose_start)); TRY(dupload(p, &d.dn_pose_obs, dn_pose_obs)); TRY(dupload(p, &d.dn_zpos, dn_zpos));
+        if (!dn_prec.empty()) TRY(dupload(p, &d.dn_prec, dn_prec));
         TRY(dzero(p, &d.dn_Y, dn_obs_pose.size() * (ph ? 36 : 18)));
         d.dn_W = d.dn_Y;        // one factor Z = W M^T for both sides of a pair product (k_dn_wy, k_ph_dn_wy)
         TRY(dzero(p, &d.dn_Mg, (size_t)Lpad * (ph ? 6 : 3)));

@@ -178,7 +178,26 @@ template <bool DN, int NT, int CH> __device__ __forceinline__ void lin_pose_body
     double Sk[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) Sk[c] = d.S[c];
-    if (DN) {
+    if (DN && d.dn_prec) {
+        // as below; the records (u, v, d, landmark) of a pose's observations lie in list order (a copy made by ssba_finalize:
+        // through the landmark-major arrays every lane touched three cache lines of its own -- 87 -> 25 us at 600 poses x 2 400 observations)
+        for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += NT * CH) {
+            double4 rec[CH];
+            double pt[CH][3];
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (i0 + NT * q < e) rec[q] = reinterpret_cast<const double4 *>(d.dn_prec)[i0 + NT * q];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                if (i0 + NT * q >= e) continue;
+                const size_t l = (size_t)__double_as_longlong(rec[q].w);
+                pt[q][0] = PT[l]; pt[q][1] = PT[(size_t)d.Lpad + l]; pt[q][2] = PT[2 * (size_t)d.Lpad + l];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+                if (i0 + NT * q < e) accumulate(Sk, pt[q][0], pt[q][1], pt[q][2], rec[q].x, rec[q].y, rec[q].z);
+        }
+    } else if (DN) {
         for (uint32_t i = b + threadIdx.x; i < e; i += NT) {
             const uint32_t oi = d.dn_pose_obs[i];
             const int l = (int)d.dn_obs_lm[oi];
@@ -269,7 +288,10 @@ template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_linea
 // 1 / 2 / 3 / 4 / 6 waves -> 19.6 / 16.7 / 18.8 / 19.5 / 27.0 us (linearisation), 38.4 / 30.4 / 33.8 / 34.1 / 48.4 us (evaluation).
 constexpr int LMW_SPLIT = 2;
 // PS / PT / commit: see lin_pose_body
-template <int SP> __device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &st, int grp, const double *__restrict__ PS,
+// DN (landmark-major lists of the general layout instead of window slots): the same split, wave w takes the observations
+// w, w + SP, ... of every landmark's list (r04: 235 four-wave work-groups on 256 CUs at 60 000 landmarks left every SIMD
+// with ONE wave of 24 dependent fp64 chains; 940 work-groups of SP = 4 put 3.7 on it).
+template <bool DN, int SP> __device__ __forceinline__ void lin_landmarks_w_body(const Dev &d, const State &st, int grp, const double *__restrict__ PS,
                                                      const double *__restrict__ PT, bool commit) {
     __shared__ double sm[SP];
     __shared__ double red[SP > 1 ? SP - 1 : 1][10][LMG];
@@ -280,13 +302,19 @@ template <int SP> __device__ __forceinline__ void lin_landmarks_w_body(const Dev
     if (commit && w == 0) { d.pts[l] = px; d.pts[(size_t)d.Lpad + l] = py; d.pts[2 * (size_t)d.Lpad + l] = pz; }
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, cost = 0.0;
     if (mask) {
-        const LmObs<false> ob(d, l, mask);
-        for (int s = w; s < TW; s += SP) {
+        const LmObs<DN> ob(d, l, mask);
+        for (int s = w; s < ob.count(); s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
             const double *T = PS + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            if (DN) {
+                double Sk[9];
+                ob.stiffness(d, s, Sk);
+                obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            } else {
+                obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            }
             double Jl[9];
             jac_point(o, T, Jl);
             cost += o.half_rho;
@@ -348,11 +376,11 @@ template <int SP> __device__ __forceinline__ void lin_landmarks_w_body(const Dev
         d.part_lin[grp * 4 + 2] = c2;
     }
 }
-template <int SP> __global__ __launch_bounds__(64 * SP) void k_linearize_landmarks_w(Dev d, int fuse) {
+template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_linearize_landmarks_w(Dev d, int fuse) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     const bool commit = fuse && st.accepted;
-    lin_landmarks_w_body<SP>(d, st, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
+    lin_landmarks_w_body<DN, SP>(d, st, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
 
 
@@ -1079,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts, int n_p
 // delta_l itself (fixed order, so the SP lanes of a landmark hold identical candidates) and evaluates the candidate
 // cost of its own slots.
 // fuse_best: also does k_best's share for the points (see k_pose_update)
-template <int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_eval_w(Dev d, int fuse_best) {
+template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_eval_w(Dev d, int fuse_best) {
     const State &st = *d.st;
     __shared__ double sm[SP];
     __shared__ double red[SP][5][LMG];
@@ -1100,17 +1128,23 @@ template <int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_eval_w(De
     double ccost = 0.0, mcc = 0.0, dn = 0.0, nonfinite = 0.0;
     double nx = px, ny = py, nz = pz;
     const bool act = mask && !st.step_failed;
-    const LmObs<false> ob(d, l, mask);
+    const LmObs<DN> ob(d, l, mask);
     double tp[3] = {0.0, 0.0, 0.0}, er = 0.0, ee = 0.0;
     if (act) {
-        for (int s = w; s < TW; s += SP) {
+        for (int s = w; s < ob.count(); s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
             const int f = d.pose_free[k];
             if (f < 0) continue;
             const double *T = d.poses + (size_t)k * 12;
             ObsLin o;
-            obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            if (DN) {
+                double Sk[9];
+                ob.stiffness(d, s, Sk);
+                obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            } else {
+                obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            }
             double Jp[18], Jl[9], jd[3];
             jac_pose(o, Jp);
             jac_point(o, T, Jl);
@@ -1160,10 +1194,16 @@ template <int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_eval_w(De
             const double dt = dl[0] * (tt[0] - gl[0]) + dl[1] * (tt[1] - gl[1]) + dl[2] * (tt[2] - gl[2]);
             mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + (dl[0] * hd0 + dl[1] * hd1 + dl[2] * hd2));
         }
-        for (int s = w; s < TW; s += SP) {
+        for (int s = w; s < ob.count(); s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
-            ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
+            if (DN) {
+                double Sk[9];
+                ob.stiffness(d, s, Sk);
+                ccost += obs_cost_S(d, Sk, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
+            } else {
+                ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
+            }
         }
     }
     if (w == 0) {
@@ -1810,6 +1850,16 @@ static bool lm_split(const Dev &d) {
     return !d.dense && !d.phong && (!cliff || d.Lpad <= 262144);
 }
 static int lm_sp(const Dev &d) { return d.Lpad <= 262144 ? LMW_SPLIT : 1; }
+// General layout (landmark-major lists): waves per 64 landmarks of the two landmark passes; 0 = one lane per landmark in
+// work-groups of 256 (the r03 kernels; SSBA_DN_SPLIT=0/1/2/4 for A/B).
+static int dn_sp(const Dev &d) {
+    static const int forced = [] { const char *e = getenv("SSBA_DN_SPLIT"); return e ? atoi(e) : -1; }();
+    if (!d.dense || d.phong) return 0;
+    if (forced >= 0) return forced == 1 || forced == 2 || forced == 4 ? forced : 0;
+    return d.Lpad <= 131072 ? 4 : (d.Lpad <= 262144 ? 2 : 1);
+}
+// entries of part_lin / part_eval: one per group of 64 landmarks, or per block of 256
+static int lm_parts(const Dev &d) { return lm_split(d) || dn_sp(d) ? d.n_groups : d.n_lm_blocks; }
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
 static bool ctrl_fusable(const Dev &d) { return !d.dense && !d.part; }       // (lighting terms included: same partial sums, same reduced system)
@@ -1825,14 +1875,17 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
-        if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
-        else if (lm_split(d)) LAUNCH(KC_LIN_LM, k_linearize_landmarks_w<1>, dim3(d.n_groups), dim3(64), 0, d, fuse_all ? 1 : 0);
+        if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<false, LMW_SPLIT>), dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
+        else if (lm_split(d)) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<false, 1>), dim3(d.n_groups), dim3(64), 0, d, fuse_all ? 1 : 0);
+        else if (dn_sp(d) == 4) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, 0);
+        else if (dn_sp(d) == 2) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 2>), dim3(d.n_groups), dim3(128), 0, d, 0);
+        else if (dn_sp(d) == 1) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 1>), dim3(d.n_groups), dim3(64), 0, d, 0);
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         // 128 lanes per pose, five observations in flight per lane (sweep on C2, profiles/r02_pose_kernel_shape.txt: 64 / 128 / 192 /
         // 256 / 512 lanes x 3-10 observations: 24.5 us here, 31 us for 256 x 3, 51 us for 512 x 3)
         LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true, LP_THREADS, LP_CHUNK> : k_linearize_poses<false, LP_THREADS, LP_CHUNK>), dim3(d.P), dim3(LP_THREADS), 0, d, fuse_all ? 1 : 0);
     }
-    if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks);
+    if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_parts(d));
 }
 
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl, bool check_in_schur) {
@@ -1858,7 +1911,7 @@ void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_be
     check_in_schur = check_in_schur && fuse_ctrl && (d.phong || lm_split(d));
     if (d.dense) launch_dense_finish(L, d);
     else if (!fuse_ctrl) LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
-    if (!check_in_schur) LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0);
+    if (!check_in_schur) LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? lm_parts(d) : 0);
     if (fuse_best && best_fusable(d)) return;
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
@@ -1869,14 +1922,17 @@ void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_b
     const int fb = fuse_best && best_fusable(d) ? 1 : 0;
     if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
     if (d.phong) launch_ph_backsub_eval(L, d, fb);
-    else if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w<LMW_SPLIT>, dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
-    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, k_backsub_eval_w<1>, dim3(d.n_groups), dim3(64), 0, d, pose_update_done ? 2 : fb);
+    else if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<false, LMW_SPLIT>), dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
+    else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<false, 1>), dim3(d.n_groups), dim3(64), 0, d, pose_update_done ? 2 : fb);
+    else if (dn_sp(d) == 4) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, 0);
+    else if (dn_sp(d) == 2) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 2>), dim3(d.n_groups), dim3(128), 0, d, 0);
+    else if (dn_sp(d) == 1) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 1>), dim3(d.n_groups), dim3(64), 0, d, 0);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_split(d) ? d.n_groups : d.n_lm_blocks, d.part ? 1 : 0);
+    if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_parts(d), d.part ? 1 : 0);
 }
 
 void launch_sep_pack(Launcher &L, const Dev &d) {       // (the separator vector was cleared by k_finish_reduced)
-    LAUNCH(KC_SMALL, k_sep_pack, dim3(4), dim3(256), 0, d, d.phong ? 0 : (lm_split(d) ? d.n_groups : d.n_lm_blocks));
+    LAUNCH(KC_SMALL, k_sep_pack, dim3(4), dim3(256), 0, d, d.phong ? 0 : lm_parts(d));
 }
 void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best) {
     LAUNCH(KC_SMALL, k_sep_finish, dim3((d.n_sep * BD + 255) / 256), dim3(256), 0, d);
@@ -1916,7 +1972,7 @@ void launch_dogleg_eval(Launcher &L, const Dev &d, int stage, int own_poses) {
 }
 
 void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all, int n_pose_parts) {
-    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? (lm_split(d) ? d.n_groups : d.n_lm_blocks) : 0,
+    LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? lm_parts(d) : 0,
            n_pose_parts >= 0 ? n_pose_parts : d.n_pose_blocks);
     if (fuse_all) return;       // the next linearisation commits (launch_linearize)
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;

@@ -281,6 +281,7 @@ struct Dev {
     const double *dn_Sobs;                          // N*9 or null: one stiffness per stereo residual block (dataset_vo_sun.cpp:56-65)
     const uint32_t *dn_pose_start, *dn_pose_obs;    // P+1, N: landmark-major observation indices of a pose
     const uint32_t *dn_obs_lm;                      // N: landmark of an observation
+    const double *dn_prec;                          // N x 4 or null: (u, v, d, landmark as integer bits) in the order of dn_pose_obs
     double *dn_W, *dn_Y;                            // per observation: ONE buffer of N*18 (lighting: N*36), Z = W M^T with C^-1 = M^T M
     const uint32_t *dn_zpos;                        // observation -> its record in dn_Y (pose-major)
     double *dn_Mg;                                  // M g_l per landmark (3 or 6 x Lpad)
