@@ -126,6 +126,30 @@ def algorithmic_work(stats, phong=False):
     return out
 
 
+def algorithmic_work_wide(stats):
+    """The same per-launch figures for the wide reduced system (tracks of 13-24 observations: super-blocks of 24 poses =
+    144 rows, ceres_slam_amd/csrc/ssba_wide.hip).  n blocks, s = ceil(log2 n) parallel-cyclic-reduction steps: every step is one
+    k_wd_factor launch (per block: Cholesky of the 144 x 144 diagonal block + forward substitution of [L | U^T | r], 289
+    columns; D, L, U in, G, YL, YU out) and one k_wd_reduce launch (per block three 144^3 products; the two neighbours'
+    YL / YU and its own D, L in, D', L' out); the decoupled last step factors and solves."""
+    N, L, P = stats["num_observations"], stats["num_active_points"], stats["num_free_poses"]
+    T = N / max(L, 1)
+    n = max(stats.get("wide_superblocks", 0), 1)
+    bd = 144
+    blk = bd * bd * 8
+    out = algorithmic_work(dict(stats, num_superblocks=1, pcr_blocks=0))
+    # per landmark T(T+1)/2 pairs x 108 FMA + T factor rows; one slab of 54 tiles per item (~21 landmarks' worth each)
+    out["k_schur_windows"] = dict(bytes=24 * N + 120 * L + 54 * 256 * 8 * stats.get("num_windows", 0), flops=L * (T * (T + 1) / 2 * 216 + T * 330))
+    out["k_assemble_reduced"] = dict(bytes=54 * 256 * 8 * stats.get("num_windows", 0) + stats["num_reduced_blocks"] * 288 * 2, flops=0)
+    out["k_bcr_factor"] = dict(bytes=6 * blk * n, flops=(bd ** 3 / 3 + bd * bd * (2 * bd + 1)) * n)
+    out["k_bcr_reduce"] = dict(bytes=7 * blk * n, flops=3 * 2 * bd ** 3 * n)
+    # general layout: 24 B per observation + 4 B pose index; pose pass reads 32-byte pose-major records
+    out["k_linearize_poses"] = dict(bytes=(32 + 24) * N + 216 * P, flops=330 * N)
+    out["k_linearize_landmarks"] = dict(bytes=28 * N + 96 * L, flops=150 * N)
+    out["k_backsub_eval"] = dict(bytes=2 * 28 * N + 120 * L, flops=500 * N)
+    return out
+
+
 def pmc_traffic(config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this workload (bench.py
     cannot collect PMC counters itself); tools/pmc_summarize.py documents the correction.  Returns (traffic by kernel

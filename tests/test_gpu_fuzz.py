@@ -18,17 +18,17 @@ def test_random_problem_shapes_match_oracle(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [91, 163, 527])
-def test_one_sided_factorisation_breakdowns_end_at_the_same_point(case):
-    """The three cases of sweep `600 101` in which the HIP factorisation meets a non-positive pivot at a trust-region radius
-    beyond 1e9 where the oracle's Cholesky still gets a step (lighting terms, directional light, free shared blocks, bounds:
+@pytest.mark.parametrize("sweep,case", [(("600", "101"), 91), (("600", "101"), 163), (("600", "101"), 527), (("300", "71"), 19)])
+def test_one_sided_factorisation_breakdowns_end_at_the_same_point(sweep, case):
+    """The three cases of sweep `600 101` (r03) and the one of `300 71` (r04, at a radius of 9.1e8) in which the HIP factorisation
+    meets a non-positive pivot at a trust-region radius of ~1e9 and beyond where the oracle's Cholesky still gets a step (lighting terms, directional light, free shared blocks, bounds:
     the reduced system is singular to working precision there; tools/fuzz_parity.py: solver_breakdown has r04's experiments).
     Both sides treat it like Ceres treats LINEAR_SOLVER_FAILURE -- invalid step, radius halved, next iteration -- so the paths
     part for a few iterations; what must hold: both converge, to the same cost (1e-5) and the same poses, and the HIP run needs
     at most a handful of iterations more."""
     import json
     env = dict(os.environ, FUZZ_ONLY=str(case))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "600", "101"], capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), *sweep], capture_output=True, text=True, timeout=900, env=env)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("CASE_JSON ")]
     assert len(line) == 1, r.stdout[-3000:] + r.stderr[-2000:]
     c = json.loads(line[0][len("CASE_JSON "):])

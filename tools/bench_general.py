@@ -73,7 +73,10 @@ def run_case(name, prob, steps, force_dense):
                       "observations": int(st.num_observations), "reduced_blocks": int(st.num_reduced_blocks),
                       "solve_iterations": int(s.num_iterations), "final_cost": float(s.final_cost),
                       "ms_per_iteration": round(1e3 * dt / steps, 4), "iterations_per_s": round(steps / dt, 2),
-                      "kernel_ms_per_iteration": rows}), flush=True)
+                      "kernel_ms_per_iteration": rows,
+                      "stats": {k: int(getattr(st, k)) for k in ("num_poses", "num_free_poses", "num_points", "num_active_points", "num_observations",
+                                                                  "num_windows", "num_superblocks", "num_reduced_blocks", "pose_bandwidth",
+                                                                  "general_structure", "wide_superblocks")}}), flush=True)
 
 
 def main():
