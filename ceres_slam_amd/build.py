@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libssba.so")
-SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_bcr_mfma.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip", "ssba_pool.hip", "ssba_wide.hip", "ssba_wide_layout.cpp"]
+SOURCES = ["ssba_api.hip", "ssba_kernels.hip", "ssba_bcr.hip", "ssba_bcr_mfma.hip", "ssba_phong.hip", "ssba_phong_solver.hip", "ssba_border.hip", "ssba_frontend.hip", "ssba_dense.hip", "ssba_pool.hip", "ssba_wide.hip", "ssba_wide_layout.cpp", "ssba_layout.cpp"]
 HEADERS = ["ssba_types.h", "ssba_wide_layout.h", "ssba_pool.h", "ssba_launch.h", "ssba_device.h", "ssba_phong_device.h", "ssba_linesearch.h", "ssba_posefactor_device.h", "libssba.map", os.path.join("..", "..", "include", "ssba.h")]
 # -fvisibility=hidden + the version script below: the dynamic symbol table of libssba.so holds the entry points of
 # include/ssba.h (SSBA_API) and nothing else -- no unprefixed helpers, no ssba:: C++ symbols next to torch's RCCL or user code

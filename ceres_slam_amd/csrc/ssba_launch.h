@@ -4,6 +4,7 @@
 
 #include <vector>
 
+#include "ssba_layout.h"     // DensePlan
 #include "ssba_types.h"
 
 namespace ssba {
@@ -29,14 +30,6 @@ static const char *const kKernelClassName[KC_COUNT] = {
     "k_bcr_factor", "k_bcr_reduce", "k_bcr_backsub", "k_backsub_eval", "k_dogleg_gn+k_dogleg_eval", "border(shared blocks)", "copy(k_best,k_commit)",
     "small(control,reductions)"};
 
-// Launch plan of the blocked Cholesky of the general-structure path (host copy of the offsets into the index arrays
-// Dev::dn_rows / dn_ti / dn_tk / dn_cols; built by the symbolic phase of ssba_finalize)
-struct DensePlan {
-    int nbk = 0;
-    std::vector<uint32_t> rows, ti, tk, cols;                    // uploaded
-    std::vector<uint32_t> row_start, tile_start, col_start;      // per block column / block row
-    std::vector<uint8_t> upd_last;                               // block (i, i-1) non-zero
-};
 
 // Stream + optional per-kernel-class HIP-event timing (events are recorded on the
 // same stream the kernels run on and resolved lazily by collect()).
