@@ -52,7 +52,7 @@ static __device__ __forceinline__ void check_body(Dev &d, int fused_parts, bool 
         // interior poses of every rank went into those sums before the exchange (k_sep_pack); what is left
         // are the separator poses, whose gradient is the sum over ranks held in the separator vector
         const int npose = d.part ? d.n_sep * SBP : d.nfree;
-        if (fused_parts > 0 && !in_schur) {       // per pose by k_assemble_reduced(.., fuse_finish)
+        if (fused_parts > 0 && !in_schur && !d.dense) {       // per pose by k_assemble_reduced(.., fuse_finish); the general layout has no such pass: the poses are walked below
             for (int q = threadIdx.x; q < d.nfree; q += (int)blockDim.x) { gm = fmax(gm, d.part_chk[2 * q]); xn += d.part_chk[2 * q + 1]; }
         } else
         for (int q = threadIdx.x; q < npose; q += (int)blockDim.x) {

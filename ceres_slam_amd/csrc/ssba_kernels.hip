@@ -1004,7 +1004,7 @@ __device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts,
     if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_reduce_eval(.., add_pose)), summed over ranks
     const Options &o = st.opt;
     const double candidate_cost_raw = d.scal2[0] + pcc;      // + unary pose residual blocks
-    const double mcc = d.scal2[1] + pmc;
+    const double mcc = o.strategy ? st.dl_mcc : d.scal2[1] + pmc;      // dogleg: from the sums of its model, all residual rows included
     const double step_norm = sqrt(d.scal2[2] + a);
     const bool finite_step = (d.scal2[3] + b) == 0.0 && !st.step_failed;
     st.model_cost_change = mcc;
@@ -1522,6 +1522,7 @@ __global__ __launch_bounds__(256) void k_dogleg_interp(Dev d, int from_scal) {
     if (!st.dl_reuse) {
         st.grad_norm = sqrt(acc[0]); st.gn_norm = sqrt(acc[1]); st.g_dot_gn = acc[2];
         st.alpha = acc[0] / acc[3];   // ComputeCauchyPoint
+        st.dl_jv2 = acc[3]; st.dl_jg2 = acc[4]; st.dl_jvg = acc[5];
         st.dl_reuse = 1;              // reuse_ = true until the next accepted / invalid step
         if (st.opt.dogleg_type == 1) {
             const double jj[3] = {acc[3], acc[4], acc[5]};
@@ -1530,21 +1531,26 @@ __global__ __launch_bounds__(256) void k_dogleg_interp(Dev d, int from_scal) {
     }
     if (st.opt.dogleg_type != 1) {
         traditional_dogleg(st);
-        return;
-    }
-    // ComputeSubspaceDoglegStep
-    double m2[2];
-    if (st.gn_norm <= st.radius) {
-        st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
-    } else if (st.sub_one_dim) {
-        st.beta = 0.0; st.gamma = -st.radius / st.grad_norm; st.dl_step_norm = st.radius;
-    } else if (!subspace_boundary_minimum(st, m2)) {
-        traditional_dogleg(st);           // "Taking traditional dogleg step instead."
     } else {
-        st.gamma = m2[0] * st.sub_e[0][0] + m2[1] * st.sub_e[1][0];    // coefficient of gradient_ -> v
-        st.beta = m2[0] * st.sub_e[0][1] + m2[1] * st.sub_e[1][1];     // coefficient of gauss_newton_step_
-        st.dl_step_norm = st.radius;
+        // ComputeSubspaceDoglegStep
+        double m2[2];
+        if (st.gn_norm <= st.radius) {
+            st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
+        } else if (st.sub_one_dim) {
+            st.beta = 0.0; st.gamma = -st.radius / st.grad_norm; st.dl_step_norm = st.radius;
+        } else if (!subspace_boundary_minimum(st, m2)) {
+            traditional_dogleg(st);           // "Taking traditional dogleg step instead."
+        } else {
+            st.gamma = m2[0] * st.sub_e[0][0] + m2[1] * st.sub_e[1][0];    // coefficient of gradient_ -> v
+            st.beta = m2[0] * st.sub_e[0][1] + m2[1] * st.sub_e[1][1];     // coefficient of gauss_newton_step_
+            st.dl_step_norm = st.radius;
+        }
     }
+    // Model cost change of delta = beta gn + gamma v [trust_region_minimizer.cc: -model_residuals . (residuals + model_residuals / 2),
+    // model_residuals = J delta]:  -(delta . g) - |J delta|^2 / 2  with  delta . g = beta (g . gn) + gamma (g . v),  g . v = |gradient_|^2
+    // and |J delta|^2 from the three row-space sums -- the evaluation kernels need no Jacobian pass for it (r04).
+    const double b = st.beta, g = st.gamma;
+    st.dl_mcc = -(b * st.g_dot_gn + g * st.grad_norm * st.grad_norm) - 0.5 * (b * b * st.dl_jg2 + 2.0 * b * g * st.dl_jvg + g * g * st.dl_jv2);
 }
 
 // per landmark: delta_l = beta * gn + gamma * v, candidate point, model cost change, candidate cost
@@ -1568,29 +1574,10 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_eval(Dev d) {
         for (int s = 0; s < ob.count(); ++s) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
-            const int f = d.pose_free[k];
-            const double *T = d.poses + (size_t)k * 12;
             const double u = ob.u(d, s), v = ob.v(d, s), dd = ob.dd(d, s);
-            ObsLin o;
             double Sk[9];
             ob.stiffness(d, s, Sk);
-            obs_linearize_S(d, Sk, T, px, py, pz, u, v, dd, o);
-            double Jl[9], jd[3];
-            jac_point(o, T, Jl);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) jd[i] = Jl[3 * i] * dl[0] + Jl[3 * i + 1] * dl[1] + Jl[3 * i + 2] * dl[2];
-            if (f >= 0) {
-                double Jp[18];
-                jac_pose(o, Jp);
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const double dpc = st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) jd[i] += Jp[6 * i + c] * dpc;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) mcc -= jd[i] * (o.r[i] + 0.5 * jd[i]);
+            // (the model cost change comes from the six sums of the dogleg model: k_dogleg_interp, State::dl_mcc)
             ccost += obs_cost_S(d, Sk, d.cand_poses + (size_t)k * 12, nx, ny, nz, u, v, dd);
         }
     }
@@ -1862,11 +1849,13 @@ static int dn_sp(const Dev &d) {
 static int lm_parts(const Dev &d) { return lm_split(d) || dn_sp(d) ? d.n_groups : d.n_lm_blocks; }
 
 // fuse_ctrl (single GPU, windowed stereo layout; see k_check): k_reduce_lin's sums are formed by k_check
-static bool ctrl_fusable(const Dev &d) { return !d.dense && !d.part; }       // (lighting terms included: same partial sums, same reduced system)
+// r04: the general layout too (stereo blocks: wide super-blocks and blocked Cholesky) -- k_check forms the sums of k_reduce_lin and
+// walks the poses itself (check_body)
+static bool ctrl_fusable(const Dev &d) { return !d.part && (!d.dense || !d.phong); }       // (lighting terms included on the windowed layout: same partial sums, same reduced system)
 // fuse_best (the copy of x to the best iterate rides in the update / evaluation kernels): no exchange sits between k_check's
 // decision and those kernels in any mode, so the partitioned multi-GPU solve takes it too
-static bool best_fusable(const Dev &d) { return !d.dense && !d.nb && (d.phong || lm_split(d)); }       // (free shared blocks have a best copy of their own: k_best)
-bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && !d.phong && lm_split(d); }
+static bool best_fusable(const Dev &d) { return !d.nb && (d.phong ? !d.dense : (lm_split(d) || dn_sp(d) > 0)); }       // (free shared blocks have a best copy of their own: k_best)
+bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && !d.phong && (lm_split(d) || dn_sp(d) > 0); }
 // fuse_all (single GPU, LM, windowed stereo layout, launch_can_fuse_all): the linearisation kernels commit the accepted
 // step on the way (no k_commit launch)
 // skip_reduce (partitioned solve): k_sep_pack(.., n_lin_parts) forms the sums of the partials
@@ -1877,9 +1866,9 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
     } else {
         if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<false, LMW_SPLIT>), dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
         else if (lm_split(d)) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<false, 1>), dim3(d.n_groups), dim3(64), 0, d, fuse_all ? 1 : 0);
-        else if (dn_sp(d) == 4) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, 0);
-        else if (dn_sp(d) == 2) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 2>), dim3(d.n_groups), dim3(128), 0, d, 0);
-        else if (dn_sp(d) == 1) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 1>), dim3(d.n_groups), dim3(64), 0, d, 0);
+        else if (dn_sp(d) == 4) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, fuse_all ? 1 : 0);
+        else if (dn_sp(d) == 2) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 2>), dim3(d.n_groups), dim3(128), 0, d, fuse_all ? 1 : 0);
+        else if (dn_sp(d) == 1) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 1>), dim3(d.n_groups), dim3(64), 0, d, fuse_all ? 1 : 0);
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         // 128 lanes per pose, five observations in flight per lane (sweep on C2, profiles/r02_pose_kernel_shape.txt: 64 / 128 / 192 /
         // 256 / 512 lanes x 3-10 observations: 24.5 us here, 31 us for 256 x 3, 51 us for 512 x 3)
@@ -1924,9 +1913,9 @@ void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_b
     if (d.phong) launch_ph_backsub_eval(L, d, fb);
     else if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<false, LMW_SPLIT>), dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
     else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<false, 1>), dim3(d.n_groups), dim3(64), 0, d, pose_update_done ? 2 : fb);
-    else if (dn_sp(d) == 4) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, 0);
-    else if (dn_sp(d) == 2) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 2>), dim3(d.n_groups), dim3(128), 0, d, 0);
-    else if (dn_sp(d) == 1) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 1>), dim3(d.n_groups), dim3(64), 0, d, 0);
+    else if (dn_sp(d) == 4) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
+    else if (dn_sp(d) == 2) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 2>), dim3(d.n_groups), dim3(128), 0, d, pose_update_done ? 2 : fb);
+    else if (dn_sp(d) == 1) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 1>), dim3(d.n_groups), dim3(64), 0, d, pose_update_done ? 2 : fb);
     else LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_backsub_eval<true> : k_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (!fuse_reduce) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, lm_parts(d), d.part ? 1 : 0);
 }

@@ -1342,12 +1342,6 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_eval(De
             dl[c] = st.beta * d.dl_gn[(size_t)c * d.Lpad + l] + st.gamma * d.vl[(size_t)c * d.Lpad + l];
             if (!isfinite(dl[c])) nonfinite = 1.0;
         }
-        double dbq[NBQ];
-#pragma unroll
-        for (int q = 0; q < NBQ; ++q) {
-            const int c = d.nb ? bcol(d, x.mat, q) : -1;
-            dbq[q] = c >= 0 ? st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c] : 0.0;
-        }
         np_[0] = x.p[0] + dl[0]; np_[1] = x.p[1] + dl[1]; np_[2] = x.p[2] + dl[2];
         unit_plus(x.n, dl + 3, nn);
         dn = dl[0] * dl[0] + dl[1] * dl[1] + dl[2] * dl[2] + (nn[0] - x.n[0]) * (nn[0] - x.n[0]) +
@@ -1355,31 +1349,11 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_eval(De
         for (int s = 0; s < sl.count(); ++s) {
             if (!sl.has(s)) continue;
             const uint32_t k = sl.pose(d, s);
-            const int f = d.pose_free[k];
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
             const double u = d.ou[oi], v = d.ov[oi], dd = d.od[oi], inten = d.oi[oi];
-            double dp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (f >= 0) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) dp[c] = st.beta * d.x0[(size_t)f * 6 + c] + st.gamma * d.vp[(size_t)k * 6 + c];
-            }
-            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, u, v, dd, inten, nobs, f >= 0,
-                    [&](auto part, int, double r, const double *jp, const double *jl, const double *jb) {
-                        constexpr int P = decltype(part)::value;
-                        double jd = 0.0;
-#pragma unroll
-                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) jd += jl[c] * dl[c];
-                        if (f >= 0) {
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) jd += jp[c] * dp[c];
-                        }
-                        if (P == 1) {
-#pragma unroll
-                            for (int q = 0; q < NBQ; ++q) jd += jb[q] * dbq[q];
-                        }
-                        mcc -= jd * (r + 0.5 * jd);
-                    });
+            // (the model cost change comes from the six sums of the dogleg model: k_dogleg_interp, State::dl_mcc -- r04: this
+            // kernel made a full Jacobian pass for it)
             ccost += obs_ph_cost(d, d.cand_sh, d.cand_poses + (size_t)k * 12, np_, nn, x.mat, u, v, dd, inten, nobs);
         }
     }
@@ -1552,7 +1526,7 @@ __global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d) {
         bgd += d.bsys[BS_G + c] * v;
     }
     // ComputeTrustRegionStep: the search only runs on a valid step (as k_ph_ls_reduce's ls_out[6])
-    const bool valid = !st.step_failed && (d.scal2[3] + pbad) == 0.0 && d.scal2[1] > 0.0;
+    const bool valid = !st.step_failed && (d.scal2[3] + pbad) == 0.0 && (st.opt.strategy ? st.dl_mcc : d.scal2[1]) > 0.0;
     if (!valid) return;
     const double phi0 = st.x_cost, dphi0 = lgd + pgd + bgd, phi1 = d.scal2[0];
     const bool value_ok = isfinite(phi1);
@@ -1607,7 +1581,7 @@ __global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int 
     d.ls_out[4] = fmax(fmax(lmax, qmax), bmax);
     d.ls_out[5] = lgd + qgd + bgd;
     // ComputeTrustRegionStep: valid iff the solve succeeded, the step is finite and model_cost_change > 0
-    d.ls_out[6] = (!st.step_failed && (d.scal2[3] + qbad) == 0.0 && d.scal2[1] > 0.0) ? 1.0 : 0.0;
+    d.ls_out[6] = (!st.step_failed && (d.scal2[3] + qbad) == 0.0 && (st.opt.strategy ? st.dl_mcc : d.scal2[1]) > 0.0) ? 1.0 : 0.0;
     d.ls_out[7] = st.x_cost;
     if (!ls_round) return;
     static_assert(sizeof(Armijo) <= NLS_MACH * sizeof(double), "the search state lives behind ls_out");

@@ -69,6 +69,8 @@ struct State {
     double initial_cost;
     // DoglegStrategy [Ceres dogleg_strategy.cc]
     double mu, alpha, dl_step_norm, grad_norm, gn_norm, g_dot_gn, beta, gamma;
+    double dl_jv2, dl_jg2, dl_jvg;        // |J v|^2, |J gn|^2, (J v).(J gn) of this linearisation point (kept while dl_reuse)
+    double dl_mcc;                        // model cost change of delta = beta gn + gamma v, from the six sums (k_dogleg_interp)
     // SUBSPACE_DOGLEG model: u_i = sub_e[i][0] * gradient_ + sub_e[i][1] * gauss_newton_step_
     int sub_one_dim, sub_pad_;
     double sub_e[2][2], sub_g[2], sub_B[3];
