@@ -1513,7 +1513,7 @@ static int enqueue_front(ssba_problem *p) {
     const char *cl_env = getenv("SSBA_CHECK_LAUNCH");       // (read at every capture: tests switch it between handles)
     const bool check_launch = cl_env && cl_env[0] == '1';
     const bool check_in_schur = fuse_ctrl && p->opt.trust_region_strategy_type != 1 && (fuse_all || d.phong) && !check_launch;
-    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d); else launch_schur(L, d, fuse_ctrl, check_in_schur); }))) return rc;
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d, fuse_ctrl && launch_ctrl_fusable(d)); else launch_schur(L, d, fuse_ctrl, check_in_schur); }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if (d.wide && (rc = X(L.wide.xw, L.wide.count, 0))) return rc;      // long tracks: the 144-row super-blocks [D | L | rhs]

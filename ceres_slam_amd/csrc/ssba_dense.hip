@@ -586,8 +586,8 @@ int configure_dense() {
     if (hipFuncSetAttribute((const void *)k_dn_syrk_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_SYRK_LDS) != hipSuccess) return -1;
     return hipFuncSetAttribute((const void *)k_dn_trsm_mf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DN_TRSM_LDS) == hipSuccess ? 0 : -1;
 }
-void launch_dense_schur(Launcher &L, const Dev &d) {
-    if (d.wide) { launch_wide_schur(L, d); return; }       // banded, tracks of <= 24 observations: 144-row super-blocks (ssba_wide.hip)
+void launch_dense_schur(Launcher &L, const Dev &d, bool fuse_finish) {
+    if (d.wide) { launch_wide_schur(L, d, fuse_finish); return; }       // banded, tracks of <= 24 observations: 144-row super-blocks (ssba_wide.hip)
     LAUNCH(KC_SMALL, k_dn_zero_tiles, dim3(d.dn_nztile), dim3(256), 0, d);
     if (d.phong) {       // 6-D landmark blocks: C^-1 first, W / Y are 6x6 (ssba_phong_solver.hip)
         launch_ph_dense_wy(L, d);
@@ -601,8 +601,8 @@ void launch_dense_schur(Launcher &L, const Dev &d) {
     LAUNCH(KC_ASSEMBLE, k_dn_rhs<3>, dim3((d.nfree + 3) / 4), dim3(256), 0, d);
 }
 
-void launch_dense_finish(Launcher &L, const Dev &d) {
-    if (d.wide) { launch_wide_finish(L, d); return; }
+void launch_dense_finish(Launcher &L, const Dev &d, bool fused) {
+    if (d.wide) { launch_wide_finish(L, d, fused); return; }
     LAUNCH(KC_SMALL, k_dn_finish, dim3((d.dn_pad + 255) / 256), dim3(256), 0, d);
 }
 

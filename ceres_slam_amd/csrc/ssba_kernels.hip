@@ -1855,6 +1855,7 @@ static bool ctrl_fusable(const Dev &d) { return !d.part && (!d.dense || !d.phong
 // fuse_best (the copy of x to the best iterate rides in the update / evaluation kernels): no exchange sits between k_check's
 // decision and those kernels in any mode, so the partitioned multi-GPU solve takes it too
 static bool best_fusable(const Dev &d) { return !d.nb && (d.phong ? !d.dense : (lm_split(d) || dn_sp(d) > 0)); }       // (free shared blocks have a best copy of their own: k_best)
+bool launch_ctrl_fusable(const Dev &d) { return ctrl_fusable(d); }
 bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && !d.phong && (lm_split(d) || dn_sp(d) > 0); }
 // fuse_all (single GPU, LM, windowed stereo layout, launch_can_fuse_all): the linearisation kernels commit the accepted
 // step on the way (no k_commit launch)
@@ -1898,7 +1899,7 @@ void launch_finish_local(Launcher &L, const Dev &d) {
 void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_best, bool check_in_schur) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
     check_in_schur = check_in_schur && fuse_ctrl && (d.phong || lm_split(d));
-    if (d.dense) launch_dense_finish(L, d);
+    if (d.dense) launch_dense_finish(L, d, fuse_ctrl);
     else if (!fuse_ctrl) LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
     if (!check_in_schur) LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? lm_parts(d) : 0);
     if (fuse_best && best_fusable(d)) return;

@@ -147,13 +147,14 @@ void launch_ph_dense_wy(Launcher &L, const Dev &d);
 void launch_ph_dense_border(Launcher &L, const Dev &d);
 void launch_bcr_multi_rhs(Launcher &L, const Dev &d);
 // general structure: dense reduced camera system (ssba_dense.hip)
-void launch_dense_schur(Launcher &L, const Dev &d);
-void launch_dense_finish(Launcher &L, const Dev &d);
+void launch_dense_schur(Launcher &L, const Dev &d, bool fuse_finish = false);      // fuse_finish (wide system, single GPU): the assembly also finishes the system
+void launch_dense_finish(Launcher &L, const Dev &d, bool fused = false);          // fused: launch_dense_schur(.., true) did it (wide system)
 void launch_dense_solve(Launcher &L, const Dev &d, int n_rhs_rows = 1);   // rows of the rhs block row to back-substitute
 // general layout, banded with tracks of <= WSP observations: 144-row super-blocks (ssba_wide.hip)
 int configure_wide();
-void launch_wide_schur(Launcher &L, const Dev &d);
-void launch_wide_finish(Launcher &L, const Dev &d);
+void launch_wide_schur(Launcher &L, const Dev &d, bool fuse_finish);
+void launch_wide_finish(Launcher &L, const Dev &d, bool fused);
+bool launch_ctrl_fusable(const Dev &d);       // ssba_kernels.hip: k_check forms the linearisation sums itself on this layout
 void launch_wide_solve(Launcher &L, const Dev &d);
 
 }  // namespace ssba

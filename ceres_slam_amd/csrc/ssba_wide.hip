@@ -51,13 +51,22 @@ constexpr int WS_KB = 64;                       // 63 factor rows + one zero row
 constexpr int WS_RS = 176;                      // row stride of Zm: 352 words = 32 mod 64, the two k-groups of a half-wave read disjoint banks
 constexpr int WS_LDS_DOUBLES = WS_KB * WS_RS;   // 90 112 B
 
-__global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d) {
+// n_zero: the first n_zero work-groups clear D | L of the block-tridiagonal system that k_wd_assemble fills next (a launch less per
+// iteration, as in k_schur_windows): the in-place reduction of the previous iteration left products in structural zeros.
+__global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
     const State &st = *d.st;
     const WideSys &w = *d.wide;
     const int dead = st.terminated | st.dl_reuse;       // tested once the first operand reads are in flight
+    if ((int)blockIdx.x < n_zero) {
+        if (dead) return;
+        double2 *z = reinterpret_cast<double2 *>(w.xw);
+        const size_t n2 = w.off_rhs / 2;
+        for (size_t i = (size_t)blockIdx.x * WS_THREADS + threadIdx.x; i < n2; i += (size_t)n_zero * WS_THREADS) z[i] = make_double2(0.0, 0.0);
+        return;
+    }
     extern __shared__ __align__(16) double wd_lds[];
     double *sZ = wd_lds;
-    const int item = (int)blockIdx.x;
+    const int item = (int)blockIdx.x - n_zero;
     const int lb = (int)w.item_begin[item], le = (int)w.item_end[item], base = (int)w.item_base[item];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const bool producer = t < WS_BATCH * WSP;
@@ -186,19 +195,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d) {
 
 // The reduction works in place on D, L and r (its steps overwrite whole blocks, structural zeros included), and the gather
 // below only stores the structurally non-zero entries: the blocks are cleared before every assembly.
-__global__ __launch_bounds__(256) void k_wd_zero(Dev d) {
-    const State &st = *d.st;
-    const WideSys &w = *d.wide;
-    if (st.terminated || st.dl_reuse) return;
-    double2 *z = reinterpret_cast<double2 *>(w.xw);
-    const size_t n2 = w.off_rhs / 2;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t)gridDim.x * 256) z[i] = make_double2(0.0, 0.0);
-}
-
 static __device__ __forceinline__ int wd_tri21(int r, int c) { return r * 6 - (r * (r - 1)) / 2 + (c - r); }
 
 // one thread per (non-zero 6 x 6 block, element) + one per entry of the reduced gradient
-__global__ __launch_bounds__(256) void k_wd_assemble(Dev d) {
+// fuse_finish (single GPU: nothing is exchanged between this kernel and the solve): k_wd_finish's work is done here -- Jacobi
+// scale at iteration 0 and LM damping by the lane that writes a diagonal entry, identity rows of the padding by lanes of their own
+__global__ __launch_bounds__(256) void k_wd_assemble(Dev d, int fuse_finish) {
     const State &st = *d.st;
     const WideSys &w = *d.wide;
     const int dead = st.terminated | st.dl_reuse;
@@ -234,7 +236,18 @@ __global__ __launch_bounds__(256) void k_wd_assemble(Dev d) {
             for (int q = 0; q < 8; ++q) v += x[q];
         }
         v = -v;
-        if (fa == fb) v += d.hpp[(size_t)d.free_pose[fa] * 21 + wd_tri21(min(r, c), max(r, c))];
+        if (fa == fb) {
+            const double h = d.hpp[(size_t)d.free_pose[fa] * 21 + wd_tri21(min(r, c), max(r, c))];
+            v += h;
+            if (fuse_finish && r == c) {
+                const size_t i = (size_t)fa * 6 + r;
+                double sc;
+                if (st.iteration == 0) { sc = st.opt.jacobi_scaling ? 1.0 / (1.0 + sqrt(h)) : 1.0; d.sp[i] = sc; }
+                else sc = d.sp[i];
+                const double s2 = sc * sc;
+                v += fmin(fmax(h * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) / (damp_radius(st) * s2);
+            }
+        }
         const uint32_t Ia = fa / WSP, Ib = fb / WSP;
         const int row = (int)(fa - Ia * WSP) * 6 + r, col = (int)(fb - Ib * WSP) * 6 + c;
         if (Ia == Ib) {
@@ -260,6 +273,11 @@ __global__ __launch_bounds__(256) void k_wd_assemble(Dev d) {
         w.xw[w.off_rhs + i] = -v;              // right-hand side = -reduced gradient (linear in the ranks' partial sums)
         d.xv[d.off_gp + i] = g;
         d.xv[d.off_hdiag + i] = d.hpp[(size_t)k * 21 + wd_tri21(c, c)];
+    } else if (fuse_finish && gid < n_el + (size_t)w.n * WBD) {        // padding of the last super-block
+        const size_t i = gid - n_el;
+        const size_t I = i / WBD, r = i - I * WBD;
+        w.xw[I * blk + r * WBD + r] = 1.0;
+        w.xw[w.off_rhs + i] = 0.0;
     }
 }
 
@@ -669,13 +687,15 @@ int configure_wide() {
     if (hipFuncSetAttribute((const void *)k_wd_factor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WF_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     return hipFuncSetAttribute((const void *)k_wd_factor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WF_LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
 }
-void launch_wide_schur(Launcher &L, const Dev &d) {
+// fuse_finish: see k_wd_assemble (then launch_wide_finish(.., true) launches nothing)
+void launch_wide_schur(Launcher &L, const Dev &d, bool fuse_finish) {
     const WideSys &w = L.wide;
-    LAUNCH(KC_SMALL, k_wd_zero, dim3(std::min(1024, w.n * 81)), dim3(256), 0, d);
-    LAUNCH(KC_SCHUR, k_wd_schur, dim3(w.n_items), dim3(WS_THREADS), WS_LDS_DOUBLES * sizeof(double), d);
-    LAUNCH(KC_ASSEMBLE, k_wd_assemble, dim3((unsigned)(((size_t)w.n_blk * 36 + (size_t)d.nfree * 6 + 255) / 256)), dim3(256), 0, d);
+    const int n_zero = std::min(64, std::max(1, w.n * 4));
+    LAUNCH(KC_SCHUR, k_wd_schur, dim3(w.n_items + n_zero), dim3(WS_THREADS), WS_LDS_DOUBLES * sizeof(double), d, n_zero);
+    LAUNCH(KC_ASSEMBLE, k_wd_assemble, dim3((unsigned)(((size_t)w.n_blk * 36 + (size_t)w.n * WBD + 255) / 256)), dim3(256), 0, d, fuse_finish ? 1 : 0);
 }
-void launch_wide_finish(Launcher &L, const Dev &d) {
+void launch_wide_finish(Launcher &L, const Dev &d, bool fused) {
+    if (fused) return;
     LAUNCH(KC_SMALL, k_wd_finish, dim3((L.wide.n * WBD + 255) / 256), dim3(256), 0, d);
 }
 void launch_wide_solve(Launcher &L, const Dev &d) {
