@@ -166,8 +166,30 @@ static void stage_release(ssba_problem *p) {
     p->stage_cur = nullptr;
     p->stage_left = 0;
 }
-template <class T>
-static int dupload(ssba_problem *p, const T **out, const std::vector<T> &v) {
+// host copy into the pinned staging chunk; large arrays (the ELL observation arrays of C4 are 96 MB each) on four threads
+static void stage_copy(char *dst, const void *src, size_t bytes) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (bytes >= ((size_t)16 << 20) && hw > 1) ? (int)std::min<unsigned>(hw, 4u) : 1;
+    if (nt == 1) { memcpy(dst, src, bytes); return; }
+    const size_t piece = (bytes / (size_t)nt + 4095) / 4096 * 4096;
+    std::vector<std::thread> th;
+    size_t done = 0;
+    try {
+        for (int t = 1; t < nt; ++t) {
+            const size_t o = (size_t)t * piece;
+            if (o >= bytes) break;
+            th.emplace_back([=] { memcpy(dst + o, (const char *)src + o, std::min(piece, bytes - o)); });
+            done = std::min(bytes, o + piece);
+        }
+    } catch (const std::system_error &) {
+    }
+    memcpy(dst, src, std::min(piece, bytes));
+    for (auto &x : th) x.join();
+    const size_t covered = std::max(done, std::min(piece, bytes));
+    if (covered < bytes) memcpy(dst + covered, (const char *)src + covered, bytes - covered);       // pieces whose thread could not be started
+}
+template <class T, class A>
+static int dupload(ssba_problem *p, const T **out, const std::vector<T, A> &v) {
     T *ptr = nullptr;
     int rc = dalloc(p, &ptr, v.size());
     if (rc) return rc;
@@ -175,7 +197,7 @@ static int dupload(ssba_problem *p, const T **out, const std::vector<T> &v) {
         const size_t bytes = v.size() * sizeof(T);
         char *h = nullptr;
         if ((rc = stage_alloc(p, bytes, &h))) return rc;
-        memcpy(h, v.data(), bytes);
+        stage_copy(h, v.data(), bytes);
         HIPCHECK(hipMemcpyAsync(ptr, h, bytes, hipMemcpyHostToDevice, p->launcher.stream));
     }
     *out = ptr;

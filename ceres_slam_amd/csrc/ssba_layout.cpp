@@ -13,6 +13,33 @@
 
 namespace ssba {
 
+// pieces [0, n) of a loop on up to 16 host threads: fn(t) for t = 0 .. nt - 1 (piece 0 on the caller's thread; pieces whose thread
+// cannot be started run here too)
+template <class F> static void run_pieces(int nt, F &&fn) {
+    std::vector<std::thread> th;
+    int started = 1;
+    try {
+        for (; started < nt; ++started) th.emplace_back(fn, started);
+    } catch (const std::system_error &) {
+    }
+    fn(0);
+    for (int t = started; t < nt; ++t) fn(t);
+    for (auto &x : th) x.join();
+}
+static int host_threads(uint64_t work, uint64_t threshold) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (work >= threshold && hw > 1) ? (int)std::min<unsigned>(hw, 16u) : 1;
+}
+// stable counting sort (keys < nkeys)
+template <class T, class K> static void stable_count_sort(std::vector<T> &v, std::vector<T> &tmp, size_t nkeys, K key) {
+    std::vector<uint32_t> at(nkeys + 1, 0);
+    for (auto &x : v) at[(size_t)key(x) + 1]++;
+    for (size_t q = 0; q < nkeys; ++q) at[q + 1] += at[q];
+    tmp.resize(v.size());
+    for (auto &x : v) tmp[at[(size_t)key(x)]++] = x;
+    v.swap(tmp);
+}
+
 int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std::function<void(const char *)> &mark) {
     out = Layout{};
     const uint32_t P = in.P, L = in.L;
@@ -80,31 +107,59 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
     std::vector<uint32_t> wide;         // landmarks whose free poses span more than SBP
     struct LmInfo { uint32_t j, kmin, kmax; int flo, fhi; };
     std::vector<LmInfo> order;
-    order.reserve(L);
     std::vector<uint32_t> lm_pose_sorted(N);      // per landmark (lm_start range): its poses, ascending
     std::vector<uint32_t> lm_obs_by_pose;         // lm_obs in that order, where it differs from the caller's (else empty)
-    for (uint32_t j = 0; j < L; ++j) {
-        const uint32_t n = lm_start[j + 1] - lm_start[j];
-        if (n == 0) continue;
-        if (n > (uint32_t)TW) dense = true;     // longer tracks than the window layout holds: general (dense) path
-        uint32_t *ks = &lm_pose_sorted[lm_start[j]];
-        bool sorted = true;
-        for (uint32_t e = 0; e < n; ++e) {
-            ks[e] = in.obs_pose[lm_obs[lm_start[j] + e]];
-            if (e && ks[e] < ks[e - 1]) sorted = false;
+    {
+        // the scan of the landmarks is cut into pieces (one per host thread at large sizes: 1 M landmarks took 38 ms on one);
+        // every piece collects what the single pass collected, the pieces are joined in order
+        struct Piece {
+            std::vector<LmInfo> order;
+            std::vector<uint32_t> wide;
+            std::vector<std::pair<uint32_t, uint32_t>> fix;      // (position in lm_obs, observation) of landmarks listed out of pose order
+            bool dense = false, dense_only = false, span = false;
+            int max_span = 0;
+        };
+        const int nt = host_threads(N, 400000);
+        std::vector<Piece> pc((size_t)nt);
+        run_pieces(nt, [&](int t) {
+            Piece &a = pc[(size_t)t];
+            const uint32_t j0 = (uint32_t)((uint64_t)L * (uint64_t)t / (uint64_t)nt), j1 = (uint32_t)((uint64_t)L * (uint64_t)(t + 1) / (uint64_t)nt);
+            a.order.reserve(j1 - j0);
+            std::vector<uint32_t> ob;
+            for (uint32_t j = j0; j < j1; ++j) {
+                const uint32_t n = lm_start[j + 1] - lm_start[j];
+                if (n == 0) continue;
+                if (n > (uint32_t)TW) a.dense = true;     // longer tracks than the window layout holds: general (dense) path
+                uint32_t *ks = &lm_pose_sorted[lm_start[j]];
+                bool sorted = true;
+                for (uint32_t e = 0; e < n; ++e) {
+                    ks[e] = in.obs_pose[lm_obs[lm_start[j] + e]];
+                    if (e && ks[e] < ks[e - 1]) sorted = false;
+                }
+                if (!sorted) {      // rare (datasets list a landmark's observations by state): order the observation indices with the poses
+                    ob.assign(lm_obs.begin() + lm_start[j], lm_obs.begin() + lm_start[j + 1]);
+                    std::stable_sort(ob.begin(), ob.end(), [&](uint32_t x, uint32_t y) { return in.obs_pose[x] < in.obs_pose[y]; });
+                    for (uint32_t e = 0; e < n; ++e) { ks[e] = in.obs_pose[ob[e]]; a.fix.push_back({lm_start[j] + e, ob[e]}); }
+                }
+                if (std::adjacent_find(ks, ks + n) != ks + n) a.dense = a.dense_only = true;     // two residual blocks on one (pose, landmark): no window slot for the second
+                int flo = 1 << 30, fhi = -1;
+                for (uint32_t e = 0; e < n; ++e) { const int f = out.pose_free[ks[e]]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
+                a.order.push_back({j, ks[0], ks[n - 1], fhi >= 0 ? flo : -1, fhi});
+                if (fhi - flo > SBP) { a.span = true; a.wide.push_back(j); }
+                if (fhi >= 0) a.max_span = std::max(a.max_span, fhi - flo);
+            }
+        });
+        size_t n_order = 0, n_fix = 0;
+        for (auto &a : pc) { n_order += a.order.size(); n_fix += a.fix.size(); }
+        order.reserve(n_order);
+        if (n_fix) lm_obs_by_pose = lm_obs;
+        for (auto &a : pc) {
+            order.insert(order.end(), a.order.begin(), a.order.end());
+            wide.insert(wide.end(), a.wide.begin(), a.wide.end());
+            for (auto &f : a.fix) lm_obs_by_pose[f.first] = f.second;
+            dense |= a.dense; dense_only |= a.dense_only; span_violation |= a.span;
+            max_span = std::max(max_span, a.max_span);
         }
-        if (!sorted) {      // rare (datasets list a landmark's observations by state): order the observation indices with the poses
-            if (lm_obs_by_pose.empty()) lm_obs_by_pose = lm_obs;
-            uint32_t *ob = &lm_obs_by_pose[lm_start[j]];
-            std::stable_sort(ob, ob + n, [&](uint32_t x, uint32_t y) { return in.obs_pose[x] < in.obs_pose[y]; });
-            for (uint32_t e = 0; e < n; ++e) ks[e] = in.obs_pose[ob[e]];
-        }
-        if (std::adjacent_find(ks, ks + n) != ks + n) dense = dense_only = true;     // two residual blocks on one (pose, landmark): no window slot for the second
-        int flo = 1 << 30, fhi = -1;
-        for (uint32_t e = 0; e < n; ++e) { const int f = out.pose_free[ks[e]]; if (f >= 0) { flo = std::min(flo, f); fhi = std::max(fhi, f); } }
-        order.push_back({j, ks[0], ks[n - 1], fhi >= 0 ? flo : -1, fhi});
-        if (fhi - flo > SBP) { span_violation = true; wide.push_back(j); }
-        if (fhi >= 0) max_span = std::max(max_span, fhi - flo);
     }
     if (in.points_const && !ph) {
         set_error("constant position blocks are only available with lighting terms (stage 2 of --multistage)");
@@ -177,12 +232,10 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
     }
     if (dense && wide_sys) {
         // device order = (first free pose, last free pose, landmark): Schur items are runs of consecutive landmarks
-        std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) {
-            const uint32_t fa = a.flo < 0 ? 0xFFFFFFFFu : (uint32_t)a.flo, fb = b.flo < 0 ? 0xFFFFFFFFu : (uint32_t)b.flo;
-            if (fa != fb) return fa < fb;
-            if (a.fhi != b.fhi) return a.fhi < b.fhi;
-            return a.j < b.j;
-        });
+        // (`order` was generated in landmark order: two stable counting sorts, last key first)
+        std::vector<LmInfo> tmp;
+        stable_count_sort(order, tmp, (size_t)nfree + 1, [](const LmInfo &a) { return (uint32_t)(a.fhi + 1); });
+        stable_count_sort(order, tmp, (size_t)nfree + 1, [&](const LmInfo &a) { return a.flo < 0 ? (uint32_t)nfree : (uint32_t)a.flo; });
     } else if (dense) {
         // the reduced system of the general path is stored as a dense lower triangle + right-hand-side rows; only its
         // structurally non-zero tiles are ever touched (symbolic factorisation below), so its size is bounded by memory,
@@ -195,13 +248,14 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
                       "single GPU only, and its array must fit SSBA_DENSE_MAX_GB (default 160)");
             return SSBA_ERR_UNSUPPORTED;
         }
-        std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) { return a.j < b.j; });
-    } else
-    std::sort(order.begin(), order.end(), [](const LmInfo &a, const LmInfo &b) {
-        if (a.kmin != b.kmin) return a.kmin < b.kmin;
-        if (a.kmax != b.kmax) return a.kmax < b.kmax;
-        return a.j < b.j;
-    });
+        // device order = landmark order (`order` was generated that way)
+    } else {
+        // device order = (first pose, last pose, landmark): two stable counting sorts, last key first (a comparison sort of a
+        // million landmarks took 30 ms)
+        std::vector<LmInfo> tmp;
+        stable_count_sort(order, tmp, (size_t)P, [](const LmInfo &a) { return a.kmax; });
+        stable_count_sort(order, tmp, (size_t)P, [](const LmInfo &a) { return a.kmin; });
+    }
     const uint32_t Lact = (uint32_t)order.size();
     const uint32_t Lpad = std::max<uint32_t>(256, (Lact + 255) / 256 * 256);
 
@@ -240,14 +294,25 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
     phase.mark("finalize: 3 windows");
     // ELL observation arrays, masks
     const uint32_t n_groups = Lpad / LMG;
-    std::vector<double> ou((size_t)n_groups * TW * LMG, 0.0), ov(ou.size(), 0.0), od(ou.size(), 1.0);
+    // (not zeroed here: the threads that fill the slots write the defaults of their groups first, u = v = 0, d = 1)
+    const size_t n_ell = (size_t)n_groups * TW * LMG;
+    raw_vector<double> ou(n_ell), ov(n_ell), od(n_ell);
     std::vector<uint32_t> lm_mask(Lpad, 0);
-    std::vector<double> oint, onx, ony, onz;
+    raw_vector<double> oint, onx, ony, onz;
     std::vector<uint32_t> lm_mat;
     if (ph) {
-        oint.assign(ou.size(), 0.0); onx.assign(ou.size(), 0.0); ony.assign(ou.size(), 0.0); onz.assign(ou.size(), 1.0);
+        oint.resize(n_ell); onx.resize(n_ell); ony.resize(n_ell); onz.resize(n_ell);
         lm_mat.assign(Lpad, 0);
     }
+    auto ell_defaults = [&](uint32_t g0, uint32_t g1) {      // groups [g0, g1) of 64 landmarks
+        const size_t a = (size_t)g0 * TW * LMG, b = (size_t)g1 * TW * LMG;
+        std::fill(ou.begin() + a, ou.begin() + b, 0.0); std::fill(ov.begin() + a, ov.begin() + b, 0.0); std::fill(od.begin() + a, od.begin() + b, 1.0);
+        if (ph) {
+            std::fill(oint.begin() + a, oint.begin() + b, 0.0); std::fill(onx.begin() + a, onx.begin() + b, 0.0);
+            std::fill(ony.begin() + a, ony.begin() + b, 0.0); std::fill(onz.begin() + a, onz.begin() + b, 1.0);
+        }
+    };
+    if (dense) ell_defaults(0, n_groups);       // the general layout does not use them (lighting terms: re-assigned below)
     if (dense && ph) {
         const size_t n1 = std::max<size_t>(N, 1);
         ou.assign(n1, 0.0); ov.assign(n1, 0.0); od.assign(n1, 1.0);
@@ -395,7 +460,8 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
     // ELL slots and the pose-major reference list (landmark*16 + slot) in one pass: a landmark's poses and its window's
     // pose list are both ascending (one merge per landmark), and landmarks are visited in device order, so counting
     // leaves every pose's references ascending
-    std::vector<uint32_t> pose_obs_start(P + 1, 0), pose_obs_ref(dense ? 0 : N);
+    std::vector<uint32_t> pose_obs_start(P + 1, 0);
+    raw_vector<uint32_t> pose_obs_ref(dense ? 0 : N);
     std::vector<uint32_t> pose_mat_start;   // config 3: references of a pose sorted by material, P*(M+1) offsets
     const uint32_t Mm = ph ? in.M : 0;
     if (!dense) {
@@ -433,28 +499,18 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
         // Large problems: the landmark range is cut into one piece per host thread.  A first pass counts every piece's
         // references per pose, a prefix over the pieces gives each its own write positions -- the lists come out exactly as
         // the single pass leaves them (12 M observations at C4: 121 ms of a 330 ms ssba_finalize on one thread).
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int nt = (N >= 400000 && hw > 1) ? (int)std::min<unsigned>(hw, 16u) : 1;
+        // Pieces end on group boundaries (64 landmarks): a piece first writes the defaults of its groups, then its slots.
+        const int nt = host_threads(N, 400000);
+        auto piece = [&](int t) { return t >= nt ? Lpad : (uint32_t)((uint64_t)Lact * (uint64_t)t / (uint64_t)nt) / LMG * LMG; };
         if (nt == 1) {
             std::vector<uint32_t> at(pose_obs_start.begin(), pose_obs_start.end() - 1);
+            ell_defaults(0, n_groups);
             fill(0, Lact, at.data());
         } else {
             std::vector<std::vector<uint32_t>> at((size_t)nt, std::vector<uint32_t>(P, 0));
-            auto piece = [&](int t) { return (uint32_t)((uint64_t)Lact * (uint64_t)t / (uint64_t)nt); };
-            auto run = [&](auto &&fn) {         // pieces 1 .. nt - 1 on threads of their own (or here, if none can be started)
-                std::vector<std::thread> th;
-                int started = 1;
-                try {
-                    for (; started < nt; ++started) th.emplace_back(fn, started);
-                } catch (const std::system_error &) {
-                }
-                fn(0);
-                for (int t = started; t < nt; ++t) fn(t);
-                for (auto &x : th) x.join();
-            };
-            run([&](int t) {
+            run_pieces(nt, [&](int t) {
                 uint32_t *c = at[(size_t)t].data();
-                for (uint32_t l = piece(t); l < piece(t + 1); ++l) {
+                for (uint32_t l = piece(t); l < std::min(piece(t + 1), Lact); ++l) {
                     const uint32_t j = order[l].j;
                     for (uint32_t e = lm_start[j]; e < lm_start[j + 1]; ++e) ++c[lm_pose_sorted[e]];
                 }
@@ -463,7 +519,10 @@ int build_layout(const LayoutInput &in, Layout &out, std::string &err, const std
                 uint32_t pos = pose_obs_start[k];
                 for (int t = 0; t < nt; ++t) { const uint32_t c = at[(size_t)t][k]; at[(size_t)t][k] = pos; pos += c; }
             }
-            run([&](int t) { fill(piece(t), piece(t + 1), at[(size_t)t].data()); });
+            run_pieces(nt, [&](int t) {
+                ell_defaults(piece(t) / LMG, piece(t + 1) / LMG);
+                fill(piece(t), std::min(piece(t + 1), Lact), at[(size_t)t].data());
+            });
         }
     }
     for (uint32_t k = 0; k < P && ph && !dense; ++k) {

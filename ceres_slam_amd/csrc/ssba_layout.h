@@ -9,12 +9,26 @@
 #include <stdint.h>
 
 #include <functional>
+#include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "ssba_wide_layout.h"
 
 namespace ssba {
+
+// std::vector that does not zero its storage (the ELL observation arrays are hundreds of MB at C4: every element is written
+// by the threads that fill them, a single-threaded zero-fill first cost as much as the fill)
+template <class T> struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using raw_vector = std::vector<T, default_init_allocator<T>>;
 
 // unary pose residual blocks (pose prior, sun sensor; types 2 / 3: the two halves of a relative-pose block)
 struct PoseFactor { uint32_t pose; int type; double data[18], S[36], huber; };
@@ -57,8 +71,9 @@ struct Layout {
     bool dense = false, wide_sys = false;
     uint32_t Lact = 0, Lpad = 0, n_groups = 0, n_windows = 0, n_slabs = 0, n_sblk = 0, bandwidth = 0;
     // windowed layout
-    std::vector<uint32_t> win_pose, lm_win, lm_mask, lm_mat, pose_obs_start, pose_obs_ref, pose_mat_start;
-    std::vector<double> ou, ov, od, oint, onx, ony, onz;
+    std::vector<uint32_t> win_pose, lm_win, lm_mask, lm_mat, pose_obs_start, pose_mat_start;
+    raw_vector<uint32_t> pose_obs_ref;
+    raw_vector<double> ou, ov, od, oint, onx, ony, onz;
     std::vector<uint32_t> slab_win, slab_b, slab_e, sblk_a, sblk_b, sblk_start, sblk_contrib, prow_start, prow_contrib;
     std::vector<uint32_t> cb_a, cb_b, cb_start, cb_contrib;      // closure border
     // general layout
