@@ -272,13 +272,14 @@ def measure(args, name, P, L, ctx, kernel_timing, phong=False, robust=False):
         prob, ph = synth.make_phong_problem(P, L)
         lighting = ph.as_oracle_dict("perturbed" if args.shared_free else "truth")
     else:
-        prob = synth.make_problem(P, L, outlier_fraction=0.3 if robust else 0.0)
+        prob = synth.make_problem(P, L, outlier_fraction=0.3 if robust else 0.0, track_len=synth.CONFIG_TRACK.get(name, 12))
     partition = None
     if world > 1:
         # landmark ranges cut at super-block boundaries -> partitioned reduced solve (only the separator system is
         # exchanged); SSBA_NO_PARTITION=1 or an unalignable problem falls back to summing the whole reduced system
         # (free shared lighting blocks: their border sums are exchanged in the all-reduce mode only)
-        cut = None if os.environ.get("SSBA_NO_PARTITION") == "1" or (phong and args.shared_free) else sharding.aligned_partition(
+        # (long tracks -- the wide reduced system -- shard with the all-reduce too: the partitioned solve is built for 72-row blocks)
+        cut = None if os.environ.get("SSBA_NO_PARTITION") == "1" or (phong and args.shared_free) or name in synth.CONFIG_TRACK else sharding.aligned_partition(
             prob.obs_pose, prob.obs_point, prob.num_poses, prob.num_points, world)
         if cut is not None:
             shard = sharding.shard_by_landmarks(prob, world, rank, ranges=cut[0])
@@ -403,7 +404,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default=None, help="C2 (default at N = 1), C3, C4, C5; default at N > 1: N x C2 for N = 2, 4 and "
+    ap.add_argument("--config", default=None, help="C2 (default at N = 1), C3, C4, C5, LT24 (600 poses / 60 000 landmarks / 24 observations per landmark: the wide reduced system); default at N > 1: N x C2 for N = 2, 4 and "
                                                    "C4 exactly (10 000 poses / 1 M landmarks, BASELINE configs[3]) at N = 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=1000, help="iteration cap of the CPU-oracle sample (it converges in ~80)")
@@ -447,6 +448,8 @@ def main():
     cfg = args.config or ("C2" if world < 8 else "C4")
     phong = cfg == "C3"                   # BASELINE.json configs[2]: C2 + Phong lighting residual blocks
     robust = cfg == "C5"                  # BASELINE.json configs[4]: Huber loss, 30 % outlier observations (C2 shape per GPU)
+    if cfg not in ("C2", "C3", "C4", "C5", "LT24"):
+        raise SystemExit(f"unknown --config {cfg}")
     P1, L1 = synth.CONFIGS["C2" if (phong or robust) else cfg]
     C2P, C2L = synth.CONFIGS["C2"]
     # the joint problem: C4 is a fixed size (strong-scaled over the ranks); the C2-shaped configurations grow with the ranks
@@ -484,6 +487,8 @@ def bench_line(args, m, weak, world, cfg, strong=None, single=None, single_c2=No
     # `value` counts C2-sized units of work: one iteration of a joint problem with k x 100 000 landmarks is k units
     # (N x C2 at N ranks: N units; C4: 10 units)
     units = m["landmarks"] / C2L
+    if cfg in synth.CONFIG_TRACK:         # another problem shape (24 observations per landmark): plain iterations/s of that problem
+        units = 1.0
     out = {
         "metric": "gauss_newton_iters_per_sec",
         "value": joint_ips * units,
@@ -551,7 +556,7 @@ def bench_line(args, m, weak, world, cfg, strong=None, single=None, single_c2=No
             out["strong_scaling_C2"]["single_gpu_iters_per_sec"] = c_ips
             out["strong_scaling_C2"]["speedup_vs_1gpu_same_problem"] = g_ips / c_ips
     if any(v[0] for v in ktimes.values()):
-        work = algorithmic_work(stats, phong)
+        work = algorithmic_work_wide(stats) if stats.get("wide_superblocks") else algorithmic_work(stats, phong)
         per_kernel = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in ktimes.items()}   # avg ms
         iter_kernel_ms = {k: v[1] / args.steps for k, v in ktimes.items()}
         dom = max((k for k in iter_kernel_ms if k in work), key=lambda k: iter_kernel_ms[k])

@@ -31,7 +31,9 @@ CONFIGS = {
     "C1": (50, 2_000),
     "C2": (1_000, 100_000),
     "C4": (10_000, 1_000_000),
+    "LT24": (600, 60_000),       # long tracks: 24 observations per landmark (the wide reduced system; tools/bench_general.py's P600 case)
 }
+CONFIG_TRACK = {"LT24": 24}       # track length where it is not 12
 
 
 @dataclass
@@ -291,6 +293,7 @@ def add_loop_closure(prob: StereoBAProblem, num_states: int = 3, num_landmarks: 
 
 def make_config(name: str, **kw) -> StereoBAProblem:
     P, L = CONFIGS[name]
+    kw.setdefault("track_len", CONFIG_TRACK.get(name, 12))
     return make_problem(P, L, **kw)
 
 

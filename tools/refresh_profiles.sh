@@ -13,6 +13,7 @@ python3 bench.py --config C3 > $out/bench_c3.json 2> $out/bench_c3.err
 python3 bench.py --config C3 --shared-free 7 > $out/bench_c3_free_shared.json 2> $out/bench_c3_free_shared.err
 python3 bench.py --config C3 --shared-free 7 --bounds --dogleg 1 > $out/bench_c3_driver_config.json 2> $out/bench_c3_driver_config.err
 python3 bench.py --config C5 > $out/bench_c5.json 2> $out/bench_c5.err
+python3 bench.py --config LT24 > $out/bench_lt24.json 2> $out/bench_lt24.err
 python3 bench.py --config C4 --steps 50 --warmup 5 > $out/bench_c4_single_gpu.json 2> $out/bench_c4_single_gpu.err
 SSBA_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 > $out/bench_rehearsal_2_ranks_gloo.json 2> $out/bench_rehearsal_2_ranks_gloo.err
 python3 tools/rank_compute_time.py 1 2 4 8 > $out/rank_compute_time.json 2> $out/rank_compute_time.err
@@ -35,6 +36,7 @@ stats bench_c3_free_shared python3 bench.py --config C3 --shared-free 7 --steps 
 stats bench_c3_driver_config python3 bench.py --config C3 --shared-free 7 --bounds --dogleg 1 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 stats bench_c4_single_gpu python3 bench.py --config C4 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 stats bench_c5 python3 bench.py --config C5 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
+stats bench_lt24 python3 bench.py --config LT24 --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing
 stats loop_closure_border python3 tools/bench_general.py --case C2_loop_closure_border --steps 10
 stats general_path_p600 python3 tools/bench_general.py --case P600 --steps 5
 stats general_path_p200 python3 tools/bench_general.py --case P200 --steps 5
