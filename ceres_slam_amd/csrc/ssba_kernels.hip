@@ -403,6 +403,8 @@ constexpr int SCHUR_BATCH = 21;                  // landmarks per batch: 21 x 12
 constexpr int SCHUR_KB = 64;                     // 63 factor rows + one zero row = 16 MFMA steps of k = 4
 constexpr int SCHUR_RS = 80;                     // row stride of Zm: 5 tiles; 80 % 32 = 16 keeps the half-wave reads conflict-free
 constexpr int SCHUR_LDS_DOUBLES = SCHUR_KB * SCHUR_RS;     // 40 960 B
+constexpr int SCHUR_ITEM_MAX = 128;              // landmarks per work item at most (ssba_layout.cpp: kItemMax)
+constexpr int SCHUR_LDS_BYTES = (SCHUR_LDS_DOUBLES + 9 * SCHUR_ITEM_MAX) * 8;       // + M and M g_l of the item's landmarks: 50 176 B
 typedef double schur_d4 __attribute__((ext_vector_type(4)));
 
 // n_zero > 0: the first n_zero workgroups clear the block-tridiagonal reduced system (D and L of every super-block) that
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
     }
     extern __shared__ __align__(16) double schur_lds[];
     double *sZ = schur_lds;                              // [k][col]
+    double *sM = schur_lds + SCHUR_LDS_DOUBLES;          // [c][landmark of the item]: M (6), u = M g_l (3) -- once per landmark, not once per (landmark, slot)
     const int item = bid - n_zero;
     const uint32_t win = d.slab_win[item];
     const int lb = (int)d.slab_lm_begin[item], le = (int)d.slab_lm_end[item];
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
     // Raw inputs of this lane's (landmark, slot) for the NEXT batch are fetched from HBM while the
     // matrix phase works on the current one (the loads stay in flight across the barrier and are only
     // waited for at the top of the next producer phase).
-    struct Raw { double u, v, dd, h[6], sc[3], p[3], g[3]; uint32_t mask; bool in_range; } raw;
+    struct Raw { double u, v, dd, p[3]; uint32_t mask; bool in_range; } raw;
     auto prefetch = [&](int l0) {
         const int l = l0 + li;
         raw.in_range = producer && l < le;
@@ -479,41 +482,56 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
             const size_t oi = (size_t)(l >> 6) * (TW * LMG) + (size_t)s * LMG + (l & 63);
             raw.u = d.ou[oi]; raw.v = d.ov[oi]; raw.dd = d.od[oi];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) raw.h[c] = d.hll[(size_t)c * d.Lpad + l];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                raw.sc[c] = d.sl[(size_t)c * d.Lpad + l];
-                raw.p[c] = d.pts[(size_t)c * d.Lpad + l];
-                raw.g[c] = d.gl[(size_t)c * d.Lpad + l];
-            }
+            for (int c = 0; c < 3; ++c) raw.p[c] = d.pts[(size_t)c * d.Lpad + l];
         }
     };
     prefetch(lb);
+    // the damped 3 x 3 block factor of every landmark of the item, by one lane each (r04: it was formed by all twelve slot lanes of
+    // a landmark in every batch -- a quarter of the producer's fp64 instructions, on the pipe the matrix instructions need)
+    double lh[6], lsc[3], lg[3];
+    const bool lm_lane = t < le - lb;
+    if (lm_lane) {
+        const int l = lb + t;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) lh[c] = d.hll[(size_t)c * d.Lpad + l];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lsc[c] = d.sl[(size_t)c * d.Lpad + l]; lg[c] = d.gl[(size_t)c * d.Lpad + l]; }
+    }
     if (dead) return;
+    if (lm_lane) {
+        double dmp[3], m[6];
+        const double hd[3] = {lh[0], lh[3], lh[5]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
+            const double s2 = lsc[c] * lsc[c];
+            dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
+        }
+        if (!chol3_inv_fast(lh, dmp, m)) {
+            d.st->step_failed = 1;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) m[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sM[c * SCHUR_ITEM_MAX + t] = m[c];
+        sM[6 * SCHUR_ITEM_MAX + t] = m[0] * lg[0];
+        sM[7 * SCHUR_ITEM_MAX + t] = m[1] * lg[0] + m[2] * lg[1];
+        sM[8 * SCHUR_ITEM_MAX + t] = m[3] * lg[0] + m[4] * lg[1] + m[5] * lg[2];
+    }
+    __syncthreads();
 
     for (int l0 = lb; l0 < le; l0 += SCHUR_BATCH) {
         if (producer) {
             double z[18];       // [c][a]: three runs of six contiguous doubles in the k-major matrix
             double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             bool live = false;
+            const int il = l0 - lb + li;        // landmark of the item (its factor: sM)
             if (raw.in_range) {
-                double dmp[3];
-                const double hd[3] = {raw.h[0], raw.h[3], raw.h[5]};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
-                    const double s2 = raw.sc[c] * raw.sc[c];
-                    dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
-                }
-                if (!chol3_inv_fast(raw.h, dmp, m)) {
-                    d.st->step_failed = 1;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) m[c] = 0.0;
-                }
+                for (int c = 0; c < 6; ++c) m[c] = sM[c * SCHUR_ITEM_MAX + il];
             }
             if (s == 0) {       // u = M g_l
-                sZ[(li * 3 + 0) * SCHUR_RS + 72] = raw.in_range ? m[0] * raw.g[0] : 0.0;
-                sZ[(li * 3 + 1) * SCHUR_RS + 72] = raw.in_range ? m[1] * raw.g[0] + m[2] * raw.g[1] : 0.0;
-                sZ[(li * 3 + 2) * SCHUR_RS + 72] = raw.in_range ? m[3] * raw.g[0] + m[4] * raw.g[1] + m[5] * raw.g[2] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sZ[(li * 3 + c) * SCHUR_RS + 72] = raw.in_range ? sM[(6 + c) * SCHUR_ITEM_MAX + il] : 0.0;
             }
             if (raw.in_range && pose_ok && ((raw.mask >> s) & 1u)) {
                 live = true;
@@ -1817,8 +1835,7 @@ void launch_zero_ranges(hipStream_t stream, const ZeroRange *ranges, int n) {
 
 // ----------------------------------------------------------------- launchers ---
 int configure_schur() {
-    return hipFuncSetAttribute((const void *)k_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(SCHUR_LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
+    return hipFuncSetAttribute((const void *)k_schur_windows, hipFuncAttributeMaxDynamicSharedMemorySize, SCHUR_LDS_BYTES) == hipSuccess ? 0 : -1;
 }
 
 void launch_reset(Launcher &L, const Dev &d, const Options &o) {
@@ -1884,7 +1901,7 @@ void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl, bool check_in_schur
     // the reduced system is cleared on the way: by 128 extra workgroups of the stereo Schur launch, by k_ph_invert with lighting terms
     const int n_zero = 128;
     if (d.phong) launch_ph_schur(L, d, check_in_schur);
-    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero + (check_in_schur ? 1 : 0)), dim3(SCHUR_THREADS), SCHUR_LDS_DOUBLES * sizeof(double), d, n_zero, check_in_schur ? d.n_groups : 0);
+    else LAUNCH(KC_SCHUR, k_schur_windows, dim3(d.n_slabs + n_zero + (check_in_schur ? 1 : 0)), dim3(SCHUR_THREADS), SCHUR_LDS_BYTES, d, n_zero, check_in_schur ? d.n_groups : 0);
     const size_t n = (size_t)d.n_sblk * 36 + (size_t)(fuse_ctrl ? d.nf_pad : d.nfree) * 6 + (fuse_ctrl ? (size_t)d.nfree : 0);
     LAUNCH(KC_ASSEMBLE, k_assemble_reduced, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, fuse_ctrl ? 1 : 0, check_in_schur ? 1 : 0);
     if (d.cb) LAUNCH(KC_BORDER, k_cb_assemble, dim3((unsigned)(((size_t)d.n_cb * 36 + 255) / 256)), dim3(256), 0, d);

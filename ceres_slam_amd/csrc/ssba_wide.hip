@@ -50,6 +50,8 @@ constexpr int WS_BATCH = 21;                    // landmarks per batch: 21 x 24 
 constexpr int WS_KB = 64;                       // 63 factor rows + one zero row = 16 matrix steps of k = 4
 constexpr int WS_RS = 176;                      // row stride of Zm: 352 words = 32 mod 64, the two k-groups of a half-wave read disjoint banks
 constexpr int WS_LDS_DOUBLES = WS_KB * WS_RS;   // 90 112 B
+constexpr int WS_ITEM_MAX = 128;                // landmarks per item at most (ssba_layout.cpp: build_wide_layout(.., 128, ..))
+constexpr int WS_LDS_BYTES = (WS_LDS_DOUBLES + 9 * WS_ITEM_MAX) * 8;
 
 // n_zero: the first n_zero work-groups clear D | L of the block-tridiagonal system that k_wd_assemble fills next (a launch less per
 // iteration, as in k_schur_windows): the in-place reduction of the previous iteration left products in structural zeros.
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
     }
     extern __shared__ __align__(16) double wd_lds[];
     double *sZ = wd_lds;
+    double *sM = wd_lds + WS_LDS_DOUBLES;       // [c][landmark of the item]: M (6), M g_l (3)
     const int item = (int)blockIdx.x - n_zero;
     const int lb = (int)w.item_begin[item], le = (int)w.item_end[item], base = (int)w.item_base[item];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
     }
     // raw inputs of this lane's (landmark, slot): the observation index two batches ahead, its data one batch ahead -- both
     // stay in flight across the matrix phase of the batch before
-    struct Raw { double u, v, dd, h[6], sc[3], p[3], g[3]; bool in_range, have; } raw;
+    struct Raw { double u, v, dd, p[3]; bool in_range, have; } raw;
     uint32_t e_next = 0xFFFFFFFFu;
     auto fetch_slot = [&](int l0) {
         const int l = l0 + li;
@@ -111,42 +114,57 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
         if (raw.in_range) {
             if (raw.have) { raw.u = d.dn_u[e_next]; raw.v = d.dn_v[e_next]; raw.dd = d.dn_d[e_next]; }
 #pragma unroll
-            for (int c = 0; c < 6; ++c) raw.h[c] = d.hll[(size_t)c * d.Lpad + l];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                raw.sc[c] = d.sl[(size_t)c * d.Lpad + l];
-                raw.p[c] = d.pts[(size_t)c * d.Lpad + l];
-                raw.g[c] = d.gl[(size_t)c * d.Lpad + l];
-            }
+            for (int c = 0; c < 3; ++c) raw.p[c] = d.pts[(size_t)c * d.Lpad + l];
         }
     };
     fetch_slot(lb);
     prefetch(lb);
     fetch_slot(lb + WS_BATCH);
+    // the damped 3 x 3 block factor M and u = M g_l of every landmark of the item, by one lane each (it was formed by all 24 slot
+    // lanes of a landmark in every batch, on the pipe the matrix instructions need)
+    double lh[6], lsc[3], lg[3];
+    const bool lm_lane = t < le - lb;
+    if (lm_lane) {
+        const int l = lb + t;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) lh[c] = d.hll[(size_t)c * d.Lpad + l];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lsc[c] = d.sl[(size_t)c * d.Lpad + l]; lg[c] = d.gl[(size_t)c * d.Lpad + l]; }
+    }
     if (dead) return;
+    if (lm_lane) {
+        double dmp[3], m[6];
+        const double hd[3] = {lh[0], lh[3], lh[5]};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
+            const double s2 = lsc[c] * lsc[c];
+            dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
+        }
+        if (!chol3_inv_fast(lh, dmp, m)) {
+            d.st->step_failed = 1;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) m[c] = 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sM[c * WS_ITEM_MAX + t] = m[c];
+        sM[6 * WS_ITEM_MAX + t] = m[0] * lg[0];
+        sM[7 * WS_ITEM_MAX + t] = m[1] * lg[0] + m[2] * lg[1];
+        sM[8 * WS_ITEM_MAX + t] = m[3] * lg[0] + m[4] * lg[1] + m[5] * lg[2];
+    }
+    __syncthreads();
 
     for (int l0 = lb; l0 < le; l0 += WS_BATCH) {
         if (producer) {
             double z[18];       // [c][a]: three runs of six contiguous doubles in the k-major matrix
             double m[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const int il = l0 - lb + li;        // landmark of the item (its factor: sM)
             if (raw.in_range) {
-                double dmp[3];
-                const double hd[3] = {raw.h[0], raw.h[3], raw.h[5]};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {   // LM diagonal in unscaled coordinates (landmark_damping)
-                    const double s2 = raw.sc[c] * raw.sc[c];
-                    dmp[c] = fmin(fmax(hd[c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag) * fast_rcp(damp_radius(st) * s2);
-                }
-                if (!chol3_inv_fast(raw.h, dmp, m)) {
-                    d.st->step_failed = 1;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) m[c] = 0.0;
-                }
+                for (int c = 0; c < 6; ++c) m[c] = sM[c * WS_ITEM_MAX + il];
             }
             if (s == 0) {       // u = M g_l
-                sZ[(li * 3 + 0) * WS_RS + WBD] = raw.in_range ? m[0] * raw.g[0] : 0.0;
-                sZ[(li * 3 + 1) * WS_RS + WBD] = raw.in_range ? m[1] * raw.g[0] + m[2] * raw.g[1] : 0.0;
-                sZ[(li * 3 + 2) * WS_RS + WBD] = raw.in_range ? m[3] * raw.g[0] + m[4] * raw.g[1] + m[5] * raw.g[2] : 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sZ[(li * 3 + c) * WS_RS + WBD] = raw.in_range ? sM[(6 + c) * WS_ITEM_MAX + il] : 0.0;
             }
             if (raw.have) {
                 obs_schur_factor(d, d.S, T, raw.p[0], raw.p[1], raw.p[2], raw.u, raw.v, raw.dd, m, z);       // Z = W M^T
@@ -683,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void k_wd_reduce(Dev d, int step) {
 
 // ---- host side ---------------------------------------------------------------------------------------------------
 int configure_wide() {
-    if (hipFuncSetAttribute((const void *)k_wd_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WS_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void *)k_wd_schur, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES) != hipSuccess) return -1;
     if (hipFuncSetAttribute((const void *)k_wd_factor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WF_LDS_DOUBLES * sizeof(double))) != hipSuccess) return -1;
     return hipFuncSetAttribute((const void *)k_wd_factor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WF_LDS_DOUBLES * sizeof(double))) == hipSuccess ? 0 : -1;
 }
@@ -691,7 +709,7 @@ int configure_wide() {
 void launch_wide_schur(Launcher &L, const Dev &d, bool fuse_finish) {
     const WideSys &w = L.wide;
     const int n_zero = std::min(64, std::max(1, w.n * 4));
-    LAUNCH(KC_SCHUR, k_wd_schur, dim3(w.n_items + n_zero), dim3(WS_THREADS), WS_LDS_DOUBLES * sizeof(double), d, n_zero);
+    LAUNCH(KC_SCHUR, k_wd_schur, dim3(w.n_items + n_zero), dim3(WS_THREADS), WS_LDS_BYTES, d, n_zero);
     LAUNCH(KC_ASSEMBLE, k_wd_assemble, dim3((unsigned)(((size_t)w.n_blk * 36 + (size_t)w.n * WBD + 255) / 256)), dim3(256), 0, d, fuse_finish ? 1 : 0);
 }
 void launch_wide_finish(Launcher &L, const Dev &d, bool fused) {
