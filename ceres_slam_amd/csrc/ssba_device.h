@@ -170,13 +170,14 @@ static __device__ __forceinline__ void jac_pose(const ObsLin &o, double Jp[18]) 
 // -- 81 multiply-adds against the 120 of jac_pose + jac_point + W + Z (r04: the producer phase of the Schur kernels is fp64
 // VALU work on the datapath the matrix instructions need).  A = sqrt(rho') S J_pi as obs_linearize_S forms it; the residual
 // is only evaluated when a loss is set (it gives rho').  z[6 c + a] = Z[a][c].
+static __device__ __forceinline__ double fast_rcp(double a);
 static __device__ __forceinline__ void obs_schur_factor(const Dev &d, const double *__restrict__ S, const double *__restrict__ T,
                                                         double px, double py, double pz, double u, double v, double dd,
                                                         const double m[6], double z[18]) {
     const double q0 = T[3] * px + T[4] * py + T[5] * pz + T[0];
     const double q1 = T[6] * px + T[7] * py + T[8] * pz + T[1];
     const double q2 = T[9] * px + T[10] * py + T[11] * pz + T[2];
-    const double iz = 1.0 / q2;
+    const double iz = fast_rcp(q2);         // (the factor only shapes the step, like M's reciprocal square roots; cost and gradient keep the IEEE divide)
     const double j00 = d.fu * iz, j11 = d.fv * iz;
     const double iz2 = iz * iz;
     const double j02 = -d.fu * q0 * iz2, j12 = -d.fv * q1 * iz2, j22 = -d.fu * d.b * iz2;
