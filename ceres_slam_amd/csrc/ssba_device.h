@@ -164,6 +164,33 @@ static __device__ __forceinline__ void jac_pose(const ObsLin &o, double Jp[18]) 
     }
 }
 
+// J_p dp without forming J_p = A [I | -q^]:  A (dp_t + dp_r x q)
+static __device__ __forceinline__ void pose_step_rows(const ObsLin &o, const double *__restrict__ dp, double jd[3]) {
+    const double w0 = dp[0] + (dp[4] * o.q[2] - dp[5] * o.q[1]);
+    const double w1 = dp[1] + (dp[5] * o.q[0] - dp[3] * o.q[2]);
+    const double w2 = dp[2] + (dp[3] * o.q[1] - dp[4] * o.q[0]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) jd[i] = o.A[3 * i] * w0 + o.A[3 * i + 1] * w1 + o.A[3 * i + 2] * w2;
+}
+// acc[0..20] += upper triangle of J_p^T J_p (row-major: (0,0) (0,1) .. (0,5) (1,1) ..), acc[21..26] += J_p^T r.
+// (r04 tried E^T G E with G = A^T A, E = [I | -q^]: 57 multiply-adds instead of 81, -1.5 us at C2 -- but its rotation block is a
+// difference of products of SUMS where this form adds squares of per-row differences: the undamped covariance test, whose Schur
+// complement cancels eight digits, lost a factor 1.6 in accuracy.  Kept the Jacobian form.)
+static __device__ __forceinline__ void pose_normal_terms(const ObsLin &o, double acc[27]) {
+    double Jp[18];
+    jac_pose(o, Jp);
+    int n = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c) {
+            acc[n] += Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c] + Jp[12 + a] * Jp[12 + c];
+            ++n;
+        }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += Jp[a] * o.r[0] + Jp[6 + a] * o.r[1] + Jp[12 + a] * o.r[2];
+}
+
 // The Schur factor of one stereo observation,  Z = W M^T  (W = J_p^T J_l, 6 x 3; C^-1 = M^T M, M lower triangular
 // m00 m10 m11 m20 m21 m22), without forming the Jacobians:  J_p = A [I | -q^],  J_l = A R  give
 //     W = [X ; q x X]  with  X = G R,  G = A^T A    =>    Z = [B ; q x B],  B = G R M^T

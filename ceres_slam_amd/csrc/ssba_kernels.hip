@@ -162,18 +162,7 @@ template <bool DN, int NT, int CH> __device__ __forceinline__ void lin_pose_body
     auto accumulate = [&](const double *Sk, double px, double py, double pz, double ou, double ov, double od) {
         ObsLin o;
         obs_linearize_S(d, Sk, T, px, py, pz, ou, ov, od, o);
-        double Jp[18];
-        jac_pose(o, Jp);
-        int n = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int c = a; c < 6; ++c) {
-                acc[n] += Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c] + Jp[12 + a] * Jp[12 + c];
-                ++n;
-            }
-#pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] += Jp[a] * o.r[0] + Jp[6 + a] * o.r[1] + Jp[12 + a] * o.r[2];
+        pose_normal_terms(o, acc);
     };
     double Sk[9];
 #pragma unroll
@@ -926,20 +915,15 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
             double Sk[9];
             ob.stiffness(d, s, Sk);
             obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
-            double Jp[18], Jl[9], jd[3];
-            jac_pose(o, Jp);
-            jac_point(o, T, Jl);
-            const double *dp = d.x0 + (size_t)f * 6;
+            const double *dp = d.x0 + (size_t)f * 6;      // (as in k_backsub_eval_w: no Jacobians formed)
+            double jd[3], y[3];
+            pose_step_rows(o, dp, jd);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                jd[i] = 0.0;
+            for (int i = 0; i < 3; ++i) { er += jd[i] * o.r[i]; ee += jd[i] * jd[i]; }
 #pragma unroll
-                for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
-                er += jd[i] * o.r[i];
-                ee += jd[i] * jd[i];
-            }
+            for (int c = 0; c < 3; ++c) y[c] = o.A[c] * jd[0] + o.A[3 + c] * jd[1] + o.A[6 + c] * jd[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) tt[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+            for (int c = 0; c < 3; ++c) tt[c] += T[3 + c] * y[0] + T[6 + c] * y[1] + T[9 + c] * y[2];
         }
         double h[6], dmp[3], Ci[6];
 #pragma unroll
@@ -1163,20 +1147,17 @@ template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_
             } else {
                 obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
             }
-            double Jp[18], Jl[9], jd[3];
-            jac_pose(o, Jp);
-            jac_point(o, T, Jl);
+            // J_p dp = A (dp_t + dp_r x q)  and  J_l^T (J_p dp) = R^T (A^T (J_p dp)):  33 multiply-adds instead of the 72 through
+            // J_p = A [I | -q^] and J_l = A R (r04: at C4 this pass is bound by its fp64 instruction count, not by HBM)
             const double *dp = d.x0 + (size_t)f * 6;
+            double jd[3], y[3];
+            pose_step_rows(o, dp, jd);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                jd[i] = 0.0;
+            for (int i = 0; i < 3; ++i) { er += jd[i] * o.r[i]; ee += jd[i] * jd[i]; }
 #pragma unroll
-                for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
-                er += jd[i] * o.r[i];
-                ee += jd[i] * jd[i];
-            }
+            for (int c = 0; c < 3; ++c) y[c] = o.A[c] * jd[0] + o.A[3 + c] * jd[1] + o.A[6 + c] * jd[2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) tp[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+            for (int c = 0; c < 3; ++c) tp[c] += T[3 + c] * y[0] + T[6 + c] * y[1] + T[9 + c] * y[2];
         }
     }
     red[w][0][li] = tp[0]; red[w][1][li] = tp[1]; red[w][2][li] = tp[2]; red[w][3][li] = er; red[w][4][li] = ee;
