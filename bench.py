@@ -21,6 +21,8 @@ Contract (one JSON line on rank 0):
     problem scores more units per second on one GPU already, so value(N) / value(1) is not a scaling factor) and
     `strong_scaling_C2` (BASELINE.json's literal metric problem, 1 000 / 100 000, cut into N shards); `scaling` says
     "strong" for C4 and "weak" for N x C2.
+  * `--config LT24`: the long-track workload (600 poses / 60 000 landmarks / 24 observations per landmark: the wide reduced
+    system of ceres_slam_amd/csrc/ssba_wide.hip); `value` is then that problem's plain iterations/s.
   * `roofline`: the dominant kernel's algorithmic bytes or flops per launch / its average
     duration measured with HIP events on the library's stream during the timed region;
   * `cpu_baseline`: the CPU oracle (a port with Ceres-equivalent semantics, NOT Ceres --
