@@ -114,14 +114,33 @@ def test_c5_shape_full_size_huber_outliers_matches_cpu_oracle():
     _compare(s, log, s2, log2, ba, op)
 
 
-def test_general_path_beyond_4096_poses_matches_cpu_oracle():
-    """Long tracks (the general-structure path, ssba_dense.hip) on 5 000 poses: the dense array of the reduced system
-    (7 GB) is bounded by memory, not by a pose count -- an iteration zero-fills and factors only its structurally
-    non-zero tiles (r02 stopped at 4 096 free poses)."""
+def test_lt24_full_size_converges_like_the_cpu_oracle():
+    """bench.py --config LT24 (600 poses / 60 000 landmarks / 24 observations per landmark: the wide reduced system of
+    ssba_wide.hip), run to convergence on both sides: same iteration count, accept / reject sequence, final cost, trajectory."""
+    prob = synth.make_config("LT24")
+    ba = StereoBA.from_synth(prob)
+    assert ba.stats().wide_superblocks == 25
+    opts = dict(max_num_iterations=1000, use_nonmonotonic_steps=1)
+    s, log = ba.solve(capi.default_options(**opts))
+    op = orc.OracleProblem.from_synth(prob)
+    s2, log2 = op.solve(orc.driver_options(num_threads=16))
+    assert s.termination_type == s2.termination_type == 0
+    _compare(s, log, s2, log2, ba, op)
+
+
+@pytest.mark.parametrize("wide", [True, False])
+def test_general_path_beyond_4096_poses_matches_cpu_oracle(wide, monkeypatch):
+    """Long tracks on 5 000 poses.  wide: 209 super-blocks of 24 poses (ssba_wide.hip: eight steps of parallel cyclic reduction).
+    Not wide (SSBA_NO_WIDE=1): the blocked Cholesky of ssba_dense.hip -- the dense array of its reduced system (7 GB) is bounded
+    by memory, not by a pose count: an iteration zero-fills and factors only its structurally non-zero tiles (r02 stopped at
+    4 096 free poses)."""
     K = 5
+    if not wide:
+        monkeypatch.setenv("SSBA_NO_WIDE", "1")
     prob = synth.make_problem(5000, 40000, track_len=16, seed=31)
     ba = StereoBA.from_synth(prob)
     assert ba.stats().general_structure == 1 and ba.stats().num_free_poses == 4999
+    assert (ba.stats().wide_superblocks > 0) == wide
     s, log = ba.solve(capi.default_options(max_num_iterations=K, use_nonmonotonic_steps=1))
     op = orc.OracleProblem.from_synth(prob)
     s2, log2 = op.solve(orc.driver_options(num_threads=16, max_num_iterations=K))
