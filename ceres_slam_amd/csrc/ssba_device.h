@@ -64,6 +64,17 @@ static __device__ __forceinline__ double block_max(double v, double *sm) {
     return t;
 }
 
+// Work-group -> item for launches whose neighbouring items share operands (poses that see the same landmarks): work-groups are
+// dealt to the eight XCDs round-robin (work-group id mod 8, verified with HW_REG_XCC_ID stamps: profiles/r04_bcr_bench_stamps_n84.txt)
+// and every XCD has its own L2, so consecutive items on consecutive work-groups pull every shared line into all eight.  XCD x takes the
+// contiguous range [x * ceil(n / 8), ...) instead.  Launch ceil(n / 8) * 8 work-groups; returns -1 for the padding.
+static __device__ __forceinline__ int xcd_contiguous_item(int wg, int n) {
+    const int chunk = (n + 7) >> 3;
+    const int item = (wg & 7) * chunk + (wg >> 3);
+    return ((wg >> 3) < chunk && item < n) ? item : -1;
+}
+static __host__ __device__ __forceinline__ int xcd_contiguous_grid(int n) { return ((n + 7) >> 3) << 3; }
+
 struct ObsLin {
     double r[3];     // loss-corrected residual
     double A[9];     // sqrt(rho') * S * J_pi(q)

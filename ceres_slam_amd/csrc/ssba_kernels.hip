@@ -256,17 +256,17 @@ template <bool DN, int NT, int CH> __device__ __forceinline__ void lin_pose_body
 template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_linearize_poses(Dev d, int fuse) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
-    if (d.pose_free[blockIdx.x] < 0) return;
+    const int k = xcd_contiguous_item((int)blockIdx.x, d.P);      // neighbouring poses (they see the same landmarks) on one XCD's L2
+    if (k < 0 || d.pose_free[k] < 0) return;
     const bool commit = fuse && st.accepted;
     if (!fuse) {
         // a landmark shard sees a fraction of the poses (rank r of N: its own ~P/N and the neighbours' edges): the blocks
         // of a pose nothing refers to here stay at the zeros they were allocated with, and the workgroup leaves at once
         // (rank 4 of 8 at C2 x 8: 98 -> ~30 us per launch)
-        const int k = (int)blockIdx.x;
         const bool no_obs = DN ? d.dn_pose_start[k] == d.dn_pose_start[k + 1] : d.pose_obs_start[k] == d.pose_obs_start[k + 1];
         if (no_obs && (!d.n_pf || d.pf_start[k] == d.pf_start[k + 1])) return;
     }
-    lin_pose_body<DN, NT, CH>(d, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
+    lin_pose_body<DN, NT, CH>(d, k, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
 
 // Window layout, SP lanes per landmark: one block = one group of 64 landmarks (the ELL unit), wave w takes the slots
@@ -1871,7 +1871,7 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
         else LAUNCH(KC_LIN_LM, (d.dense ? k_linearize_landmarks<true> : k_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
         // 128 lanes per pose, five observations in flight per lane (sweep on C2, profiles/r02_pose_kernel_shape.txt: 64 / 128 / 192 /
         // 256 / 512 lanes x 3-10 observations: 24.5 us here, 31 us for 256 x 3, 51 us for 512 x 3)
-        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true, LP_THREADS, LP_CHUNK> : k_linearize_poses<false, LP_THREADS, LP_CHUNK>), dim3(d.P), dim3(LP_THREADS), 0, d, fuse_all ? 1 : 0);
+        LAUNCH(KC_LIN_POSE, (d.dense ? k_linearize_poses<true, LP_THREADS, LP_CHUNK> : k_linearize_poses<false, LP_THREADS, LP_CHUNK>), dim3(xcd_contiguous_grid(d.P)), dim3(LP_THREADS), 0, d, fuse_all ? 1 : 0);
     }
     if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_parts(d));
 }

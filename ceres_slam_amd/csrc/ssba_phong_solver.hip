@@ -454,13 +454,19 @@ template <bool DN, int NT, int CH> static __device__ __forceinline__ void ph_lin
         else d.gp[(size_t)k * 6 + (threadIdx.x - 21)] = v;
     }
 }
-template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_ph_linearize_poses(Dev d) { ph_lin_pose_body<DN, NT, CH>(d, (int)blockIdx.x); }
+template <bool DN, int NT, int CH> __global__ __launch_bounds__(NT) void k_ph_linearize_poses(Dev d) {
+    const int k = xcd_contiguous_item((int)blockIdx.x, d.P);      // neighbouring poses share their landmarks: one XCD's L2 (ssba_device.h)
+    if (k >= 0) ph_lin_pose_body<DN, NT, CH>(d, k);
+}
 // Pose linearisation and the inversion of the damped landmark blocks in ONE launch (windowed layout, constant shared
 // blocks): both only need the landmark linearisation, so the n_lm_blocks inversion work-groups run beside the P pose
 // work-groups instead of as a launch of their own between them and the Schur kernel (-20 us on the chain at C3).
 __global__ __launch_bounds__(256, 2) void k_ph_linpose_invert(Dev d) {
-    if ((int)blockIdx.x < d.P) ph_lin_pose_body<false, 256, 2>(d, (int)blockIdx.x);
-    else ph_invert_body(d, (int)blockIdx.x - d.P, d.n_lm_blocks);
+    const int np = xcd_contiguous_grid(d.P);
+    if ((int)blockIdx.x < np) {
+        const int k = xcd_contiguous_item((int)blockIdx.x, d.P);
+        if (k >= 0) ph_lin_pose_body<false, 256, 2>(d, k);
+    } else ph_invert_body(d, (int)blockIdx.x - np, d.n_lm_blocks);
 }
 
 // Output-stationary Schur complement for 6-D landmark blocks on the fp64 matrix cores: the structure of
@@ -1622,9 +1628,9 @@ void launch_ph_linearize(Launcher &L, const Dev &d) {
     LAUNCH(KC_LIN_LM, (d.dense ? k_ph_linearize_landmarks<true> : k_ph_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     // two observations in flight per lane: 54 us against 60 for the rolled loop at C3; three need 274 registers and lose (75 us),
     // 128 lanes per pose lose too (64-76 us) -- unlike the stereo kernel, whose 175 registers leave room for five
-    if (d.dense) LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<true, 256, 1>), dim3(d.P), dim3(256), 0, d);
-    else if (ph_invert_with_poses(d)) LAUNCH(KC_LIN_POSE, k_ph_linpose_invert, dim3(d.P + d.n_lm_blocks), dim3(256), 0, d);
-    else LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<false, 256, 2>), dim3(d.P), dim3(256), 0, d);
+    if (d.dense) LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<true, 256, 1>), dim3(xcd_contiguous_grid(d.P)), dim3(256), 0, d);
+    else if (ph_invert_with_poses(d)) LAUNCH(KC_LIN_POSE, k_ph_linpose_invert, dim3(xcd_contiguous_grid(d.P) + d.n_lm_blocks), dim3(256), 0, d);
+    else LAUNCH(KC_LIN_POSE, (k_ph_linearize_poses<false, 256, 2>), dim3(xcd_contiguous_grid(d.P)), dim3(256), 0, d);
     if (d.nb) LAUNCH(KC_BORDER, (d.dense ? k_ph_border_landmarks<true> : k_ph_border_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     if (d.lmMV) LAUNCH(KC_BORDER, k_ph_hpb, dim3(d.P * d.M), dim3(64), 0, d);
 }
