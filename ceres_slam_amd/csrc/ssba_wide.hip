@@ -332,6 +332,12 @@ constexpr int WF_OFF_W = WF_NU * 256, WF_OFF_P = WF_OFF_W + WNT * 256, WF_OFF_Q 
               WF_OFF_Y = WF_OFF_RS + 32, WF_OFF_X = WF_OFF_Y + WBD, WF_OFF_T = WF_OFF_X + WBD;
 constexpr int WF_LDS_DOUBLES = WF_OFF_T + 16;
 
+#ifdef WD_STAMPS      // tools/wide_bench.hip -DWD_STAMPS: shader-clock stamps of one middle work-group (waves 0 and 1) into Dev::dbg
+#define WD_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2) d.dbg[64 * (threadIdx.x >> 6) + (i)] = clock64(); } while (0)
+#else
+#define WD_STAMP(i) do { } while (0)
+#endif
+
 // Diagonal tile T (16 x 16, accumulator layout: register q of lane (g, j) = row 4 q + g, column j), four sub-steps of four
 // pivots -- the scheme of ssba_bcr_mfma.hip's factor_tile: the 4 x 4 pivot block is factored LDL^T "uniformly" (every lane
 // computes the same scalars from v_readlane copies; the serial chain is four reciprocals), the inverse M of its unit-lower
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
     const int c = wv == 0 ? -1 : FINAL ? (wv == 1 ? 2 * WNT : -1) : part + ng * (wv - 1);
     const bool act = c >= 0 && c <= 2 * WNT && (c < WNT ? hasL : c < 2 * WNT ? hasU : true);
     if (t == 0) s_bad = 0;
+    WD_STAMP(0);
     wd4 rt[WNT];
 #pragma unroll
     for (int j = 0; j < WNT; ++j) rt[j] = wd4{0.0, 0.0, 0.0, 0.0};
@@ -489,26 +496,40 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
         }
     }
     // upper tiles of D into LDS, tile by tile (row-major 16 x 16); wave 0 keeps the first diagonal tile in registers
+    // (r04, stamps of tools/wide_bench.hip -DWD_STAMPS: a rolled loop waited for every tile before it asked for the next one --
+    // six dependent round trips per wave, 13.5 k of the launch's 95 k cycles; all of a wave's tiles are in flight together now)
     wd4 dg = {0.0, 0.0, 0.0, 0.0};
     {
-        int ti = 0, tj = 0;
-        for (int tl = 0; tl < WF_NU; ++tl) {
-            if ((tl & 7) == wv) {
-                const double *pp = Dg + (size_t)(16 * ti + g) * WBD + 16 * tj + jj;
-                wd4 v;
+        constexpr int WF_TPW = (WF_NU + 7) / 8;       // tiles per wave: 6
+        wd4 v[WF_TPW];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = pp[(size_t)4 * q * WBD];
-                if (tl == 0) dg = v;
-                else wd_tile_store(sU + tl * 256, v, lane);
+        for (int m = 0; m < WF_TPW; ++m) {
+            const int tl = wv + 8 * m;
+            if (tl < WF_NU) {
+                int ti = 0, rem = tl;                   // tile tl = (ti, tj) of the upper triangle, row by row
+                while (rem >= WNT - ti) { rem -= WNT - ti; ++ti; }
+                const int tj = ti + rem;
+                const double *pp = Dg + (size_t)(16 * ti + g) * WBD + 16 * tj + jj;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[m][q] = pp[(size_t)4 * q * WBD];
             }
-            if (++tj == WNT) { ++ti; tj = ti; }
+        }
+#pragma unroll
+        for (int m = 0; m < WF_TPW; ++m) {
+            const int tl = wv + 8 * m;
+            if (tl >= WF_NU) continue;
+            if (tl == 0) dg = v[m];
+            else wd_tile_store(sU + tl * 256, v[m], lane);
         }
     }
     if (sf.dead()) return;
+    WD_STAMP(1);
     if (wv == 0) {
         if (!wd_factor_tile(dg, sP, sQ, sRS, lane)) s_bad = 1;
     }
+    WD_STAMP(2);
     __syncthreads();
+    WD_STAMP(3);
 
 #pragma unroll
     for (int k = 0; k < WNT; ++k) {
@@ -521,7 +542,6 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
                 wd_apply(x, kP, kQ, kRS, lane);
                 wd_tile_store(sU + wd_utile(k, j) * 256, x, lane);
             }
-            if (act) wd_apply(rt[k], kP, kQ, kRS, lane);
             if (FINAL && wv == 2) {        // U_kk^-T (row-major) for the backward solve: the sub-steps applied to the identity
                 wd4 x;
 #pragma unroll
@@ -530,7 +550,9 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
                 wd_tile_store(sW + k * 256, x, lane);
             }
         }
+        WD_STAMP(4 + 4 * k);
         __syncthreads();
+        WD_STAMP(5 + 4 * k);
         // (c) wave 0: diagonal tile k + 1, updated and factored at once; the others: the rest of the trailing tiles
         //     (i, j), k < i <= j, and the right-hand sides below block row k
         if (wv == 0) {
@@ -545,11 +567,15 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
 #pragma unroll
                 for (int j = i; j < WNT; ++j, ++cnt) {
                     if (cnt < 0) continue;          // (k + 1, k + 1) is wave 0's
-                    if (cnt % 7 == wv - 1) {
+                    // (wave 4 shares its SIMD -- one fp64 pipe -- with the pivot wave: it takes no trailing tiles; 91.0 k -> 87.9 k cycles)
+                    if (wv != 4 && cnt % 6 == (wv < 4 ? wv - 1 : wv - 2)) {
                         const wd4 x = wd_tile_update(sU + wd_utile(k, i) * 256, sU + wd_utile(k, j) * 256, sU + wd_utile(i, j) * 256, lane);
                         wd_tile_store(sU + wd_utile(i, j) * 256, x, lane);
                     }
                 }
+            // block row k of the right-hand sides: here, under the pivot wave's factorisation, not in phase (b) where that wave waits
+            // for it (stamps, tools/wide_bench.hip -DWD_STAMPS: 87.9 k -> 83.8 k cycles per launch)
+            if (act) wd_apply(rt[k], kP, kQ, kRS, lane);
             if (act) {
 #pragma unroll
                 for (int j = k + 1; j < WNT; ++j) {
@@ -561,7 +587,9 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
                 }
             }
         }
+        WD_STAMP(6 + 4 * k);
         __syncthreads();
+        WD_STAMP(7 + 4 * k);
     }
     if (s_bad) {        // non-positive pivot: Cholesky breakdown, the step is rejected (Ceres: LM retries with a smaller radius)
         if (t == 0) d.st->step_failed = 1;
@@ -569,6 +597,7 @@ __global__ __launch_bounds__(WF_THREADS) void k_wd_factor(Dev d, int step, int n
     }
     if (!FINAL) {
         if (!act) return;
+        WD_STAMP(40);
         if (c == 2 * WNT) {
             double *py = w.yr + (size_t)e * WBD;
             if (jj == 0) {

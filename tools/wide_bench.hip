@@ -46,6 +46,7 @@ int main(int argc, char **argv) {
     d.st = dalloc<State>(1);
     d.nfree = n * WSP;
     d.x0 = dalloc<double>((size_t)N);
+    d.dbg = dalloc<unsigned long long>(256);        // (-DWD_STAMPS: every launch of k_wd_factor stamps into it)
     WideSys w;
     memset(&w, 0, sizeof w);
     w.n = n;
@@ -168,6 +169,23 @@ int main(int argc, char **argv) {
     };
     upload();
     printf("factor (step 0, 3 workgroups per block): %.2f us / launch\n", time_us([&] { LAUNCH(KC_BCR_FACTOR, k_wd_factor<0>, dim3(n * 3), dim3(WF_THREADS), WF_LDS_DOUBLES * sizeof(double), d, 0, 3); }, 20));
+#ifdef WD_STAMPS
+    {
+        LAUNCH(KC_BCR_FACTOR, k_wd_factor<0>, dim3(n * 3), dim3(WF_THREADS), WF_LDS_DOUBLES * sizeof(double), d, 0, 3);
+        LAUNCH(KC_BCR_FACTOR, k_wd_factor<0>, dim3(n * 3), dim3(WF_THREADS), WF_LDS_DOUBLES * sizeof(double), d, 0, 3);
+        CHK(hipDeviceSynchronize());
+        unsigned long long h[128];
+        CHK(hipMemcpy(h, d.dbg, sizeof h, hipMemcpyDeviceToHost));
+        for (int wv = 0; wv < 2; ++wv) {
+            printf("stamps of wave %d of a middle work-group (shader cycles after entry): load %llu | first tile factored %llu | barrier %llu\n", wv,
+                   h[64 * wv + 1] - h[64 * wv], h[64 * wv + 2] - h[64 * wv], h[64 * wv + 3] - h[64 * wv]);
+            for (int k = 0; k < WNT; ++k)
+                printf("   k = %d: panel done %llu, barrier %llu, trailing / next factor done %llu, barrier %llu\n", k, h[64 * wv + 4 + 4 * k] - h[64 * wv],
+                       h[64 * wv + 5 + 4 * k] - h[64 * wv], h[64 * wv + 6 + 4 * k] - h[64 * wv], h[64 * wv + 7 + 4 * k] - h[64 * wv]);
+            if (wv) printf("   stores begin %llu\n", h[64 * wv + 40] - h[64 * wv]);
+        }
+    }
+#endif
     printf("reduce (step 0):                         %.2f us / launch\n", time_us([&] { LAUNCH(KC_BCR_REDUCE, k_wd_reduce, dim3(n * WR_WG_PER_BLOCK), dim3(256), 0, d, 0); }, 20));
     upload();
     printf("factor (decoupled last step):            %.2f us / launch\n", time_us([&] { LAUNCH(KC_BCR_FACTOR, k_wd_factor<1>, dim3(n), dim3(WF_THREADS), WF_LDS_DOUBLES * sizeof(double), d, w.steps, 1); }, 20));
