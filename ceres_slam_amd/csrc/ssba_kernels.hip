@@ -440,7 +440,8 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
     const int ti1 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 3, tj1 = wv == 0 ? 1 : wv == 1 ? 1 : wv == 2 ? 2 : 4;
     const int ti2 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj2 = wv == 0 ? 2 : wv == 1 ? 2 : wv == 2 ? 3 : 4;
     const int ti3 = wv == 0 ? 0 : wv == 1 ? 1 : wv == 2 ? 2 : 4, tj3 = wv == 0 ? 3 : wv == 1 ? 3 : wv == 2 ? 4 : 4;
-    const bool has3 = wv != 3;
+    const bool has3 = wv != 3;              // (wave 3's fourth product repeats its third: not stored)
+    const bool a1x = wv == 0 || wv == 3;    // A operands: tile 0 row ti0, tiles 2 and 3 row ti3 (= ti2), tile 1 row ti1 = ti0 or ti3
     schur_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
 
     // padding columns 73..79 and the zero row k = 63 stay zero for the whole item (column 72 is rewritten every batch)
@@ -540,14 +541,26 @@ __global__ __launch_bounds__(SCHUR_THREADS, 2) void k_schur_windows(Dev d, int n
         __syncthreads();
         prefetch(l0 + SCHUR_BATCH);
         {
+            // Branch-free and software-pipelined (r04: the rolled form waited for its six LDS reads in front of every k-step's
+            // matrix instructions and branched around wave 3's missing fourth tile): the operands of k-step ks + 1 are requested
+            // before the four instructions of k-step ks are issued; wave 3 multiplies its last tile twice (the second result is
+            // never stored), so all waves run the same straight-line code.  Same-box A/B at C2: -3.4 us.  (One instantiation per
+            // wave with compile-time tile lists -- what pays in k_wd_schur -- measured +5 us here.)
             const int kq = lane >> 4, i = lane & 15;
-#pragma unroll 4
+            const double *z0 = sZ + kq * SCHUR_RS + i;
+            double ax = z0[16 * ti0], ay = z0[16 * ti3], b0 = z0[16 * tj0], b1 = z0[16 * tj1], b2 = z0[16 * tj2], b3 = z0[16 * tj3];
+#pragma unroll
             for (int ks = 0; ks < SCHUR_KB / 4; ++ks) {
-                const double *zr = sZ + (4 * ks + kq) * SCHUR_RS + i;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti0], zr[16 * tj0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti1], zr[16 * tj1], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti2], zr[16 * tj2], acc2, 0, 0, 0);
-                if (has3) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti3], zr[16 * tj3], acc3, 0, 0, 0);
+                double nax = 0.0, nay = 0.0, nb0 = 0.0, nb1 = 0.0, nb2 = 0.0, nb3 = 0.0;
+                if (ks + 1 < SCHUR_KB / 4) {
+                    const double *zr = z0 + 4 * (ks + 1) * SCHUR_RS;
+                    nax = zr[16 * ti0]; nay = zr[16 * ti3]; nb0 = zr[16 * tj0]; nb1 = zr[16 * tj1]; nb2 = zr[16 * tj2]; nb3 = zr[16 * tj3];
+                }
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1x ? ax : ay, b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b2, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b3, acc3, 0, 0, 0);
+                ax = nax; ay = nay; b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
             }
         }
         __syncthreads();

@@ -44,6 +44,14 @@ static __device__ __forceinline__ double wd_readlane(double v, int lane) {
 static __host__ __device__ __forceinline__ int wd_slab_tile(int i, int j) { return i * (WNT + 1) - (i * (i - 1)) / 2 + (j - i); }
 static __host__ __device__ __forceinline__ int wd_utile(int i, int j) { return i * WNT - (i * (i - 1)) / 2 + (j - i); }
 
+#ifdef WD_STAMPS      // -DWD_STAMPS (tools/wide_bench.hip, tools/stamps_wide.py): shader-clock stamps of one middle work-group into Dev::dbg
+#define WD_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2) d.dbg[64 * (threadIdx.x >> 6) + (i)] = clock64(); } while (0)
+#define WS_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) & 3) == 0) d.dbg[256 + 64 * (threadIdx.x >> 8) + (i)] = clock64(); } while (0)
+#else
+#define WD_STAMP(i) do { } while (0)
+#define WS_STAMP(i) do { } while (0)
+#endif
+
 // ---- Schur items ---------------------------------------------------------------------------------------------
 constexpr int WS_THREADS = 512;
 constexpr int WS_BATCH = 21;                    // landmarks per batch: 21 x 24 slots = 504 producer lanes
@@ -52,6 +60,41 @@ constexpr int WS_RS = 176;                      // row stride of Zm: 352 words =
 constexpr int WS_LDS_DOUBLES = WS_KB * WS_RS;   // 90 112 B
 constexpr int WS_ITEM_MAX = 128;                // landmarks per item at most (ssba_layout.cpp: build_wide_layout(.., 128, ..))
 constexpr int WS_LDS_BYTES = (WS_LDS_DOUBLES + 9 * WS_ITEM_MAX) * 8;
+
+// The products of one batch for wave WV: its tiles are row WV from column WV on (segment A) and, for the waves with short rows, a
+// second segment that fills them up (WsTiles); 16 k-steps, the operands of k-step ks + 1 requested before the products of ks are issued.
+template <int WV> struct WsTiles {
+    static constexpr int rowA = WV, colA0 = WV, nA = WV < 4 ? 7 : WNT + 1 - WV;
+    static constexpr int rowB = WV == 4 ? 2 : WV == 5 ? 1 : WV == 6 ? 0 : 8;
+    static constexpr int colB0 = WV == 4 ? 9 : WV == 5 ? 8 : WV == 6 ? 7 : 8;
+    static constexpr int nB = WV < 4 ? 0 : WV == 4 ? 1 : WV == 5 ? 2 : WV == 6 ? 3 : 2;
+};
+template <int WV> static __device__ __forceinline__ void wd_products(const double *sZ, int lane, wd4 (&acc)[7]) {
+    using W = WsTiles<WV>;
+    constexpr int NT = W::nA + W::nB;
+    const double *zb = sZ + (lane >> 4) * WS_RS + (lane & 15);
+    double aA = zb[16 * W::rowA], aB = W::nB ? zb[16 * W::rowB] : 0.0, b[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) b[q] = zb[16 * (q < W::nA ? W::colA0 + q : W::colB0 + (q - W::nA))];
+#pragma unroll
+    for (int ks = 0; ks < WS_KB / 4; ++ks) {
+        double naA = 0.0, naB = 0.0, nb[NT];
+        if (ks + 1 < WS_KB / 4) {
+            const double *zr = zb + 4 * (ks + 1) * WS_RS;
+            naA = zr[16 * W::rowA];
+            if (W::nB) naB = zr[16 * W::rowB];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) nb[q] = zr[16 * (q < W::nA ? W::colA0 + q : W::colB0 + (q - W::nA))];
+        }
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = wmf(q < W::nA ? aA : aB, b[q], acc[q]);
+        if (ks + 1 < WS_KB / 4) {
+            aA = naA; aB = naB;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) b[q] = nb[q];
+        }
+    }
+}
 
 // n_zero: the first n_zero work-groups clear D | L of the block-tridiagonal system that k_wd_assemble fills next (a launch less per
 // iteration, as in k_schur_windows): the in-place reduction of the previous iteration left products in structural zeros.
@@ -69,6 +112,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
     extern __shared__ __align__(16) double wd_lds[];
     double *sZ = wd_lds;
     double *sM = wd_lds + WS_LDS_DOUBLES;       // [c][landmark of the item]: M (6), M g_l (3)
+    WS_STAMP(0);
     const int item = (int)blockIdx.x - n_zero;
     const int lb = (int)w.item_begin[item], le = (int)w.item_end[item], base = (int)w.item_base[item];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -152,6 +196,9 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
         sM[8 * WS_ITEM_MAX + t] = m[3] * lg[0] + m[4] * lg[1] + m[5] * lg[2];
     }
     __syncthreads();
+    WS_STAMP(1);
+    int ws_b = 0;
+    (void)ws_b;
 
     for (int l0 = lb; l0 < le; l0 += WS_BATCH) {
         if (producer) {
@@ -179,25 +226,28 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
                 for (int q = 0; q < 3; ++q) dz[q] = make_double2(z[6 * c + 2 * q], z[6 * c + 2 * q + 1]);
             }
         }
+        WS_STAMP(2 + 4 * ws_b);
         __syncthreads();
+        WS_STAMP(3 + 4 * ws_b);
         prefetch(l0 + WS_BATCH);
         fetch_slot(l0 + 2 * WS_BATCH);
-        {
-            const int kq = lane >> 4, i = lane & 15;
-            const double *zb = sZ + kq * WS_RS + i;
-#pragma unroll 2
-            for (int ks = 0; ks < WS_KB / 4; ++ks) {
-                const double *zr = zb + 4 * ks * WS_RS;
-                const double aA = zr[16 * rowA], aB = zr[16 * rowB];
-                double b[7];
-#pragma unroll
-                for (int q = 0; q < 7; ++q) b[q] = zr[16 * (q < nA ? colA0 + q : colB0 + (q - nA))];
-#pragma unroll
-                for (int q = 0; q < 7; ++q)
-                    if (q < nA + nB) acc[q] = wmf(q < nA ? aA : aB, b[q], acc[q]);
-            }
+        // One straight-line instantiation per wave (stamps, tools/stamps_wide.py: the rolled form with run-time tile lists branched
+        // around every product of a wave with fewer than seven tiles, selected its A operand with vector moves and waited for its
+        // nine LDS reads in front of each k-step -- 20 k cycles per batch where the matrix instructions need 13.8 k)
+        switch (wv) {
+            case 0: wd_products<0>(sZ, lane, acc); break;
+            case 1: wd_products<1>(sZ, lane, acc); break;
+            case 2: wd_products<2>(sZ, lane, acc); break;
+            case 3: wd_products<3>(sZ, lane, acc); break;
+            case 4: wd_products<4>(sZ, lane, acc); break;
+            case 5: wd_products<5>(sZ, lane, acc); break;
+            case 6: wd_products<6>(sZ, lane, acc); break;
+            default: wd_products<7>(sZ, lane, acc); break;
         }
+        WS_STAMP(4 + 4 * ws_b);
         __syncthreads();
+        WS_STAMP(5 + 4 * ws_b);
+        if (ws_b < 8) ++ws_b;
     }
     // one slab per item, tile-major: a register of a tile is 512 contiguous bytes
     double *out = w.slab + (size_t)item * WSLAB_DOUBLES;
@@ -209,6 +259,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_wd_schur(Dev d, int n_zero) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pt[64 * r] = acc[q][r];
     }
+    WS_STAMP(60);
 }
 
 // The reduction works in place on D, L and r (its steps overwrite whole blocks, structural zeros included), and the gather
@@ -331,12 +382,6 @@ constexpr int WF_NU = WNT * (WNT + 1) / 2;      // 45 upper tiles of U
 constexpr int WF_OFF_W = WF_NU * 256, WF_OFF_P = WF_OFF_W + WNT * 256, WF_OFF_Q = WF_OFF_P + 2 * 256, WF_OFF_RS = WF_OFF_Q + 2 * 256,
               WF_OFF_Y = WF_OFF_RS + 32, WF_OFF_X = WF_OFF_Y + WBD, WF_OFF_T = WF_OFF_X + WBD;
 constexpr int WF_LDS_DOUBLES = WF_OFF_T + 16;
-
-#ifdef WD_STAMPS      // tools/wide_bench.hip -DWD_STAMPS: shader-clock stamps of one middle work-group (waves 0 and 1) into Dev::dbg
-#define WD_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 2) d.dbg[64 * (threadIdx.x >> 6) + (i)] = clock64(); } while (0)
-#else
-#define WD_STAMP(i) do { } while (0)
-#endif
 
 // Diagonal tile T (16 x 16, accumulator layout: register q of lane (g, j) = row 4 q + g, column j), four sub-steps of four
 // pivots -- the scheme of ssba_bcr_mfma.hip's factor_tile: the 4 x 4 pivot block is factored LDL^T "uniformly" (every lane
