@@ -654,19 +654,41 @@ template <bool BORDER> __global__ __launch_bounds__(PH_THREADS, 2) void k_ph_sch
         __syncthreads();
         // phase 2: S += Zm^T Zm  (BORDER: + Zm^T [M V])
         {
+            // Branch-free and software-pipelined like k_schur_windows (ssba_kernels.hip): operands of k-step ks + 1 requested before the
+            // products of ks are issued; a wave without a fourth main tile / a third border tile repeats its last one (not stored).
             const int kq = lane >> 4, i = lane & 15;
-#pragma unroll 2
+            const double *z0 = sZ + kq * PH_RS + i;
+            const bool a1x = wv == 0 || wv == 3;        // A operand of the second main tile: row ti0 or ti3 (see k_schur_windows)
+            const int bi2e = hasb2 ? bi2 : bi1, bc2e = BC0 + 16 * ((hasb2 ? bj2 : bj1) - 5);
+            double ax = z0[16 * ti0], ay = z0[16 * ti3], b0 = z0[16 * tj0], b1 = z0[16 * tj1], b2 = z0[16 * tj2], b3 = z0[16 * tj3];
+            double ba0 = 0.0, ba1 = 0.0, ba2 = 0.0, bb0 = 0.0, bb1 = 0.0, bb2 = 0.0;
+            if (BORDER) {
+                ba0 = z0[16 * bi0]; ba1 = z0[16 * bi1]; ba2 = z0[16 * bi2e];
+                bb0 = z0[BC0 + 16 * (bj0 - 5)]; bb1 = z0[BC0 + 16 * (bj1 - 5)]; bb2 = z0[bc2e];
+            }
+#pragma unroll
             for (int ks = 0; ks < PH_KB / 4; ++ks) {
-                const double *zr = sZ + (4 * ks + kq) * PH_RS + i;
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti0], zr[16 * tj0], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti1], zr[16 * tj1], acc1, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti2], zr[16 * tj2], acc2, 0, 0, 0);
-                if (has3) acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * ti3], zr[16 * tj3], acc3, 0, 0, 0);
-                if (BORDER) {
-                    bac0 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * bi0], zr[BC0 + 16 * (bj0 - 5)], bac0, 0, 0, 0);
-                    bac1 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * bi1], zr[BC0 + 16 * (bj1 - 5)], bac1, 0, 0, 0);
-                    if (hasb2) bac2 = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[16 * bi2], zr[BC0 + 16 * (bj2 - 5)], bac2, 0, 0, 0);
+                double nax = 0.0, nay = 0.0, nb0 = 0.0, nb1 = 0.0, nb2 = 0.0, nb3 = 0.0;
+                double nba0 = 0.0, nba1 = 0.0, nba2 = 0.0, nbb0 = 0.0, nbb1 = 0.0, nbb2 = 0.0;
+                if (ks + 1 < PH_KB / 4) {
+                    const double *zr = z0 + 4 * (ks + 1) * PH_RS;
+                    nax = zr[16 * ti0]; nay = zr[16 * ti3]; nb0 = zr[16 * tj0]; nb1 = zr[16 * tj1]; nb2 = zr[16 * tj2]; nb3 = zr[16 * tj3];
+                    if (BORDER) {
+                        nba0 = zr[16 * bi0]; nba1 = zr[16 * bi1]; nba2 = zr[16 * bi2e];
+                        nbb0 = zr[BC0 + 16 * (bj0 - 5)]; nbb1 = zr[BC0 + 16 * (bj1 - 5)]; nbb2 = zr[bc2e];
+                    }
                 }
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1x ? ax : ay, b1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b2, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, b3, acc3, 0, 0, 0);
+                if (BORDER) {
+                    bac0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ba0, bb0, bac0, 0, 0, 0);
+                    bac1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ba1, bb1, bac1, 0, 0, 0);
+                    bac2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ba2, bb2, bac2, 0, 0, 0);
+                }
+                ax = nax; ay = nay; b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+                ba0 = nba0; ba1 = nba1; ba2 = nba2; bb0 = nbb0; bb1 = nbb1; bb2 = nbb2;
             }
         }
         __syncthreads();
