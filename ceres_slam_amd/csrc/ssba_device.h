@@ -66,14 +66,20 @@ static __device__ __forceinline__ double block_max(double v, double *sm) {
 
 // Work-group -> item for launches whose neighbouring items share operands (poses that see the same landmarks): work-groups are
 // dealt to the eight XCDs round-robin (work-group id mod 8, verified with HW_REG_XCC_ID stamps: profiles/r04_bcr_bench_stamps_n84.txt)
-// and every XCD has its own L2, so consecutive items on consecutive work-groups pull every shared line into all eight.  XCD x takes the
-// contiguous range [x * ceil(n / 8), ...) instead.  Launch ceil(n / 8) * 8 work-groups; returns -1 for the padding.
+// and every XCD has its own L2, so consecutive items on consecutive work-groups pull every shared line into all eight.  Items go
+// to the XCDs in GROUPS of 16 consecutive ones instead (group g on XCD g mod 8).  (One contiguous eighth per XCD shares more, but a
+// landmark shard of a multi-GPU run has observations on a contiguous seventh of the poses only: all its work landed on one XCD,
+// 0.537 -> 0.609 ms per iteration of rank 4 of 8.)  Launch xcd_grouped_grid(n) work-groups; returns -1 for the padding.
+constexpr int XCD_GROUP = 16;
 static __device__ __forceinline__ int xcd_contiguous_item(int wg, int n) {
-    const int chunk = (n + 7) >> 3;
-    const int item = (wg & 7) * chunk + (wg >> 3);
-    return ((wg >> 3) < chunk && item < n) ? item : -1;
+    const int q = wg >> 3;                                   // position among this XCD's work-groups
+    const int item = ((q / XCD_GROUP) * 8 + (wg & 7)) * XCD_GROUP + (q % XCD_GROUP);
+    return item < n ? item : -1;
 }
-static __host__ __device__ __forceinline__ int xcd_contiguous_grid(int n) { return ((n + 7) >> 3) << 3; }
+static __host__ __device__ __forceinline__ int xcd_contiguous_grid(int n) {
+    const int groups = (n + XCD_GROUP - 1) / XCD_GROUP;
+    return ((groups + 7) / 8) * 8 * XCD_GROUP;
+}
 
 struct ObsLin {
     double r[3];     // loss-corrected residual
