@@ -290,35 +290,64 @@ template <bool DN, int SP> __device__ __forceinline__ void lin_landmarks_w_body(
     const double px = PT[l], py = PT[(size_t)d.Lpad + l], pz = PT[2 * (size_t)d.Lpad + l];
     if (commit && w == 0) { d.pts[l] = px; d.pts[(size_t)d.Lpad + l] = py; d.pts[2 * (size_t)d.Lpad + l] = pz; }
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, cost = 0.0;
-    if (mask) {
+    auto accumulate = [&](const ObsLin &o, const double *T) {
+        double Jl[9];
+        jac_point(o, T, Jl);
+        cost += o.half_rho;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            h[0] += Jl[3 * i] * Jl[3 * i];
+            h[1] += Jl[3 * i] * Jl[3 * i + 1];
+            h[2] += Jl[3 * i] * Jl[3 * i + 2];
+            h[3] += Jl[3 * i + 1] * Jl[3 * i + 1];
+            h[4] += Jl[3 * i + 1] * Jl[3 * i + 2];
+            h[5] += Jl[3 * i + 2] * Jl[3 * i + 2];
+            g[0] += Jl[3 * i] * o.r[i];
+            g[1] += Jl[3 * i + 1] * o.r[i];
+            g[2] += Jl[3 * i + 2] * o.r[i];
+        }
+    };
+    if (mask && !DN) {
+        // window layout: the pose indices of this lane's slots up front, the operands of slot q + 1 requested before slot q is worked
+        // on (the rolled loop made two dependent round trips per slot: see k_backsub_eval_w)
+        const LmObs<DN> ob(d, l, mask);
+        constexpr int NS = DN ? 1 : TW / SP;
+        uint32_t kk[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) kk[q] = ob.has(w + q * SP) ? ob.pose(d, w + q * SP) : 0xFFFFFFFFu;
+        struct In { double T[12], u, v, dd; };
+        auto fetch = [&](int q, In &in) {
+            if (kk[q] == 0xFFFFFFFFu) return;
+            const int s = w + q * SP;
+            const double *T = PS + (size_t)kk[q] * 12;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) in.T[c] = T[c];
+            in.u = ob.u(d, s); in.v = ob.v(d, s); in.dd = ob.dd(d, s);
+        };
+        In cur, nxt;
+        fetch(0, cur);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (q + 1 < NS) fetch(q + 1, nxt);
+            if (kk[q] != 0xFFFFFFFFu) {
+                ObsLin o;
+                obs_linearize(d, cur.T, px, py, pz, cur.u, cur.v, cur.dd, o);
+                accumulate(o, cur.T);
+            }
+            if (q + 1 < NS) cur = nxt;
+        }
+    }
+    if (mask && DN) {
         const LmObs<DN> ob(d, l, mask);
         for (int s = w; s < ob.count(); s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
             const double *T = PS + (size_t)k * 12;
             ObsLin o;
-            if (DN) {
-                double Sk[9];
-                ob.stiffness(d, s, Sk);
-                obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
-            } else {
-                obs_linearize(d, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
-            }
-            double Jl[9];
-            jac_point(o, T, Jl);
-            cost += o.half_rho;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                h[0] += Jl[3 * i] * Jl[3 * i];
-                h[1] += Jl[3 * i] * Jl[3 * i + 1];
-                h[2] += Jl[3 * i] * Jl[3 * i + 2];
-                h[3] += Jl[3 * i + 1] * Jl[3 * i + 1];
-                h[4] += Jl[3 * i + 1] * Jl[3 * i + 2];
-                h[5] += Jl[3 * i + 2] * Jl[3 * i + 2];
-                g[0] += Jl[3 * i] * o.r[i];
-                g[1] += Jl[3 * i + 1] * o.r[i];
-                g[2] += Jl[3 * i + 2] * o.r[i];
-            }
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
+            accumulate(o, T);
         }
     }
     if (w > 0) {
@@ -1145,7 +1174,51 @@ template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_
     const bool act = mask && !st.step_failed;
     const LmObs<DN> ob(d, l, mask);
     double tp[3] = {0.0, 0.0, 0.0}, er = 0.0, ee = 0.0;
-    if (act) {
+    // Window layout: the pose index of every slot of this lane and its free index are requested up front, and the operands of slot
+    // q + 1 before slot q is worked on (r04, from the ISA: the rolled loop made three dependent round trips per slot -- pose index,
+    // free index, pose / step / observation -- 18 for the six slots of a lane, and the second sweep twelve more)
+    constexpr int NS = DN ? 1 : TW / SP;
+    uint32_t kk[NS];
+    int ff[NS];
+    if (!DN) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) kk[q] = (act && ob.has(w + q * SP)) ? ob.pose(d, w + q * SP) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) ff[q] = kk[q] != 0xFFFFFFFFu ? d.pose_free[kk[q]] : -1;
+    }
+    if (!DN && act) {
+        struct In { double T[12], u, v, dd, dp[6]; };
+        auto fetch = [&](int q, In &in) {
+            if (ff[q] < 0) return;
+            const int s = w + q * SP;
+            const double *T = d.poses + (size_t)kk[q] * 12, *dp = d.x0 + (size_t)ff[q] * 6;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) in.T[c] = T[c];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) in.dp[c] = dp[c];
+            in.u = ob.u(d, s); in.v = ob.v(d, s); in.dd = ob.dd(d, s);
+        };
+        In cur, nxt;
+        fetch(0, cur);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            if (q + 1 < NS) fetch(q + 1, nxt);
+            if (ff[q] >= 0) {
+                ObsLin o;
+                obs_linearize(d, cur.T, px, py, pz, cur.u, cur.v, cur.dd, o);
+                double jd[3], y[3];
+                pose_step_rows(o, cur.dp, jd);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { er += jd[i] * o.r[i]; ee += jd[i] * jd[i]; }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) y[c] = o.A[c] * jd[0] + o.A[3 + c] * jd[1] + o.A[6 + c] * jd[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tp[c] += cur.T[3 + c] * y[0] + cur.T[6 + c] * y[1] + cur.T[9 + c] * y[2];
+            }
+            if (q + 1 < NS) cur = nxt;
+        }
+    }
+    if (DN && act) {
         for (int s = w; s < ob.count(); s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
@@ -1206,16 +1279,31 @@ template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_
             const double dt = dl[0] * (tt[0] - gl[0]) + dl[1] * (tt[1] - gl[1]) + dl[2] * (tt[2] - gl[2]);
             mcc = -(er + dg) - 0.5 * (ee + 2.0 * dt + (dl[0] * hd0 + dl[1] * hd1 + dl[2] * hd2));
         }
-        for (int s = w; s < ob.count(); s += SP) {
+        if (!DN) {      // candidate cost of this lane's slots: pose indices from above, operands one slot ahead
+            struct In2 { double T[12], u, v, dd; };
+            auto fetch2 = [&](int q, In2 &in) {
+                if (kk[q] == 0xFFFFFFFFu) return;
+                const int s = w + q * SP;
+                const double *T = d.cand_poses + (size_t)kk[q] * 12;
+#pragma unroll
+                for (int c = 0; c < 12; ++c) in.T[c] = T[c];
+                in.u = ob.u(d, s); in.v = ob.v(d, s); in.dd = ob.dd(d, s);
+            };
+            In2 cur, nxt;
+            fetch2(0, cur);
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                if (q + 1 < NS) fetch2(q + 1, nxt);
+                if (kk[q] != 0xFFFFFFFFu) ccost += obs_cost(d, cur.T, nx, ny, nz, cur.u, cur.v, cur.dd);
+                if (q + 1 < NS) cur = nxt;
+            }
+        }
+        for (int s = w; DN && s < ob.count(); s += SP) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
-            if (DN) {
-                double Sk[9];
-                ob.stiffness(d, s, Sk);
-                ccost += obs_cost_S(d, Sk, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
-            } else {
-                ccost += obs_cost(d, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
-            }
+            double Sk[9];
+            ob.stiffness(d, s, Sk);
+            ccost += obs_cost_S(d, Sk, d.cand_poses + (size_t)k * 12, nx, ny, nz, ob.u(d, s), ob.v(d, s), ob.dd(d, s));
         }
     }
     if (w == 0) {
