@@ -30,15 +30,35 @@ static __device__ __forceinline__ StateFlags state_flags_vmem(const State *st) {
     return f;
 }
 
-static __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+// Wave reductions on the DPP path (row shifts inside the rows of 16 lanes, then row_bcast:15 / :31): a fixed tree like the
+// __shfl_down one they replace (r04), but a shuffle of a double is two ds_bpermute_b32 through the LDS crossbar per step --
+// tools/proto/dpp_reduce_test.hip: 2.1 x the throughput, and no LDS round trip on the dependent chain of the single-work-group
+// control kernels.  The total arrives in lane 63 and is broadcast: every lane returns it.
+template <int CTRL, int ROW_MASK> static __device__ __forceinline__ double wave_dpp(double v, double identity) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-static __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    return v;
+static __device__ __forceinline__ double wave_lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+static __device__ __forceinline__ double wave_sum(double v) {
+    v += wave_dpp<0x111, 0xf>(v, 0.0);      // row_shr:1
+    v += wave_dpp<0x112, 0xf>(v, 0.0);      // row_shr:2
+    v += wave_dpp<0x114, 0xf>(v, 0.0);      // row_shr:4
+    v += wave_dpp<0x118, 0xf>(v, 0.0);      // row_shr:8: lane 15 of every row holds the row's sum
+    v += wave_dpp<0x142, 0xa>(v, 0.0);      // row_bcast:15 into rows 1 and 3
+    v += wave_dpp<0x143, 0xc>(v, 0.0);      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    return wave_lane63(v);
+}
+static __device__ __forceinline__ double wave_max(double v) {       // (of non-negative values or with -inf as the floor: identity = v itself)
+    v = fmax(v, wave_dpp<0x111, 0xf>(v, v));
+    v = fmax(v, wave_dpp<0x112, 0xf>(v, v));
+    v = fmax(v, wave_dpp<0x114, 0xf>(v, v));
+    v = fmax(v, wave_dpp<0x118, 0xf>(v, v));
+    v = fmax(v, wave_dpp<0x142, 0xa>(v, v));
+    v = fmax(v, wave_dpp<0x143, 0xc>(v, v));
+    return wave_lane63(v);
 }
 // Deterministic block sum; result valid on thread 0.  sm needs blockDim/64 doubles.
 static __device__ __forceinline__ double block_sum(double v, double *sm) {
@@ -190,9 +210,10 @@ static __device__ __forceinline__ void pose_step_rows(const ObsLin &o, const dou
     for (int i = 0; i < 3; ++i) jd[i] = o.A[3 * i] * w0 + o.A[3 * i + 1] * w1 + o.A[3 * i + 2] * w2;
 }
 // acc[0..20] += upper triangle of J_p^T J_p (row-major: (0,0) (0,1) .. (0,5) (1,1) ..), acc[21..26] += J_p^T r.
-// (r04 tried E^T G E with G = A^T A, E = [I | -q^]: 57 multiply-adds instead of 81, -1.5 us at C2 -- but its rotation block is a
-// difference of products of SUMS where this form adds squares of per-row differences: the undamped covariance test, whose Schur
-// complement cancels eight digits, lost a factor 1.6 in accuracy.  Kept the Jacobian form.)
+// (r04 tried E^T G E with G = A^T A, E = [I | -q^]: 57 multiply-adds instead of 81, -1.5 us at C2.  Its rotation block is a
+// difference of products of SUMS where this form adds squares of per-row differences; the undamped covariance test, whose Schur
+// complement cancels eight digits, moved from 1.x e-2 to 3.3e-2 -- which later turned out to be within what a change of the
+// summation order alone does to that figure.  The Jacobian form stayed: sums of squares on the diagonal.)
 static __device__ __forceinline__ void pose_normal_terms(const ObsLin &o, double acc[27]) {
     double Jp[18];
     jac_pose(o, Jp);
