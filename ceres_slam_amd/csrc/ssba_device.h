@@ -72,6 +72,27 @@ static __device__ __forceinline__ double block_sum(double v, double *sm) {
         for (int i = 0; i < nw; ++i) t += sm[i];
     return t;
 }
+// N sums at once: one pair of barriers instead of N (the single-work-group control kernels are chains of these).  sm needs
+// N * blockDim/64 doubles; results valid on thread 0.
+template <int N> static __device__ __forceinline__ void block_sums(double (&v)[N], double *sm) {
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = wave_sum(v[q]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) sm[q * nw + w] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            double t = 0.0;
+            for (int i = 0; i < nw; ++i) t += sm[q * nw + i];
+            v[q] = t;
+        }
+    }
+}
 static __device__ __forceinline__ double block_max(double v, double *sm) {
     v = wave_max(v);
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;

@@ -1018,31 +1018,30 @@ template <bool DN> __global__ __launch_bounds__(256) void k_backsub_eval(Dev d) 
 // n_eval_parts > 0 (single GPU, no exchange between the evaluation and the decision): the sums of k_reduce_eval are
 // formed here, one launch less per iteration.
 __device__ __forceinline__ void decide_body(Dev &d, State &st, int n_eval_parts, int n_pose_parts) {
-    __shared__ double sm[4];
+    // (r04: four partial entries in flight per lane -- the rolled loop made seven dependent round trips at C2 -- and the eight sums
+    // of this kernel in ONE block reduction: it was 8.5 us of dependent launch per iteration)
+    __shared__ double sm[8 * 4];
+    double red[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // e0..e3 | a, b, pcc, pmc
     if (n_eval_parts > 0) {
-        double e0 = 0.0, e1 = 0.0, e2 = 0.0, e3 = 0.0;
-        for (int i = threadIdx.x; i < n_eval_parts; i += 256) {
-            e0 += d.part_eval[i * 4];
-            e1 += d.part_eval[i * 4 + 1];
-            e2 += d.part_eval[i * 4 + 2];
-            e3 += d.part_eval[i * 4 + 3];
+        for (int i0 = threadIdx.x; i0 < n_eval_parts; i0 += 4 * 256) {
+            double4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + 256 * q;
+                x[q] = i < n_eval_parts ? reinterpret_cast<const double4 *>(d.part_eval)[i] : make_double4(0.0, 0.0, 0.0, 0.0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { red[0] += x[q].x; red[1] += x[q].y; red[2] += x[q].z; red[3] += x[q].w; }
         }
-        e0 = block_sum(e0, sm);
-        e1 = block_sum(e1, sm);
-        e2 = block_sum(e2, sm);
-        e3 = block_sum(e3, sm);
-        if (threadIdx.x == 0) { d.scal2[0] = e0; d.scal2[1] = e1; d.scal2[2] = e2; d.scal2[3] = e3; }
     }
-    double a = 0.0, b = 0.0, pcc = 0.0, pmc = 0.0;
     for (int i = threadIdx.x; i < n_pose_parts + (d.nb ? 1 : 0); i += 256) {   // last entry: border of shared blocks
-        a += d.part_pose[i * NPP];
-        b += d.part_pose[i * NPP + 1];
-        if (d.n_pf && i < n_pose_parts) { pcc += d.part_pose[i * NPP + 2]; pmc += d.part_pose[i * NPP + 3]; }
+        red[4] += d.part_pose[i * NPP];
+        red[5] += d.part_pose[i * NPP + 1];
+        if (d.n_pf && i < n_pose_parts) { red[6] += d.part_pose[i * NPP + 2]; red[7] += d.part_pose[i * NPP + 3]; }
     }
-    a = block_sum(a, sm);
-    b = block_sum(b, sm);
-    pcc = block_sum(pcc, sm);
-    pmc = block_sum(pmc, sm);
+    block_sums(red, sm);
+    if (n_eval_parts > 0 && threadIdx.x == 0) { d.scal2[0] = red[0]; d.scal2[1] = red[1]; d.scal2[2] = red[2]; d.scal2[3] = red[3]; }
+    double a = red[4], b = red[5], pcc = red[6], pmc = red[7];
     // (the solver state is a cold read at the head of a launch: tested here, with the partial sums already formed)
     if (threadIdx.x != 0 || st.terminated) return;
     if (d.part) { a = 0.0; b = 0.0; }     // already in scal2 (k_reduce_eval(.., add_pose)), summed over ranks
