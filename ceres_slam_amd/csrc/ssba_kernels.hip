@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_decide(Dev d, int n_eval_parts, int n_p
 // fuse_best: also does k_best's share for the points (see k_pose_update)
 template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_eval_w(Dev d, int fuse_best) {
     const State &st = *d.st;
-    __shared__ double sm[SP];
+    __shared__ double sm4[4 * SP];
     __shared__ double red[SP][5][LMG];
     const int w = threadIdx.x >> 6, li = threadIdx.x & 63;
     const int l = blockIdx.x * LMG + li;
@@ -1310,16 +1310,9 @@ template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_
         d.cand_pts[(size_t)d.Lpad + l] = ny;
         d.cand_pts[2 * (size_t)d.Lpad + l] = nz;
     }
-    const double a = block_sum(ccost, sm);
-    const double b = block_sum(mcc, sm);
-    const double c = block_sum(dn, sm);
-    const double e = block_sum(nonfinite, sm);
-    if (threadIdx.x == 0) {
-        d.part_eval[blockIdx.x * 4 + 0] = a;
-        d.part_eval[blockIdx.x * 4 + 1] = b;
-        d.part_eval[blockIdx.x * 4 + 2] = c;
-        d.part_eval[blockIdx.x * 4 + 3] = e;
-    }
+    double r4[4] = {ccost, mcc, dn, nonfinite};       // one block reduction for the four sums
+    block_sums(r4, sm4);
+    if (threadIdx.x == 0) reinterpret_cast<double4 *>(d.part_eval)[blockIdx.x] = make_double4(r4[0], r4[1], r4[2], r4[3]);
 }
 
 
