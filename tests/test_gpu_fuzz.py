@@ -36,3 +36,21 @@ def test_one_sided_factorisation_breakdowns_end_at_the_same_point(sweep, case):
     assert abs(c["gpu_final"] - c["oracle_final"]) <= 3e-4 * c["oracle_final"]
     assert 0 <= c["gpu_iterations"] - c["oracle_iterations"] <= 8
     assert c["pose_diff"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_subspace_dogleg_case_whose_spread_one_probe_understated():
+    """Sweep `600 91`, case 415 (26 poses, 624 landmarks, 5 materials, directional light, all shared blocks free, SUBSPACE_DOGLEG):
+    the oracle re-run from landmarks moved by 1e-14 scatters between 1.5e-9 and 1.1e-7 at iteration 3 depending on the sign
+    pattern; with the single pattern r03 used the HIP run's 2.2e-7 there counted as having left the oracle runs.  What must
+    hold with the spread taken over four probes: same decisions over the whole solve, end point and poses equal."""
+    import json
+    env = dict(os.environ, FUZZ_ONLY="415")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "600", "91"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("CASE_JSON ")]
+    assert len(line) == 1, r.stdout[-3000:] + r.stderr[-2000:]
+    c = json.loads(line[0][len("CASE_JSON "):])
+    assert c["gpu_iterations"] == c["oracle_iterations"] == 8
+    assert abs(c["gpu_final"] - c["oracle_final"]) <= 1e-9 * c["oracle_final"]
+    assert c["pose_diff"] < 1e-8
