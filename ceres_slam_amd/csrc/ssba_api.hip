@@ -1417,6 +1417,8 @@ static int enqueue_iteration(ssba_problem *p) {
 }
 
 static int enqueue_front(ssba_problem *p);
+// bounds on one GPU: k_ph_ls_fast forms the sums of the evaluation kernel's partials (no exchange sits between them)
+static bool ls_reduces_eval(const ssba_problem *p) { return p->d.constrained && !p->xfn; }
 
 // GRAPH_ITERS iterations in one graph replay (the plain single-GPU path, ssba_solve_step): the sequence is fixed and
 // every kernel turns into a no-op once the state says "terminated", so a batch is safe to enqueue blindly; it saves
@@ -1455,7 +1457,7 @@ static int enqueue_kernels(ssba_problem *p) {
     const bool fuse_upd = fuse_all_launches(p) && !p->d.dense && bcr_updates_poses(p->d);       // the reduced solve updated the poses, one partial per block
     // bounds [trust_region_minimizer.cc DoLineSearch]: the Armijo test of the full step runs on the device; when it fails
     // (rare) the state is parked and the host drives the search at its next look at the state (finish_pending_search)
-    if (p->d.constrained) launch_ph_ls_fast(p->launcher, p->d);
+    if (p->d.constrained) launch_ph_ls_fast(p->launcher, p->d, ls_reduces_eval(p));
     if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p), fuse_upd ? p->d.pcr.n : -1); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
@@ -1535,7 +1537,7 @@ static int enqueue_front(ssba_problem *p) {
     const char *cl_env = getenv("SSBA_CHECK_LAUNCH");       // (read at every capture: tests switch it between handles)
     const bool check_launch = cl_env && cl_env[0] == '1';
     const bool check_in_schur = fuse_ctrl && p->opt.trust_region_strategy_type != 1 && (fuse_all || d.phong) && !check_launch;
-    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d, fuse_ctrl && launch_ctrl_fusable(d)); else launch_schur(L, d, fuse_ctrl, check_in_schur); }))) return rc;
+    if ((rc = run_segment(p, multi ? 0 : -1, [&] { launch_linearize(L, d, fuse_ctrl, fuse_all); if (d.dense) launch_dense_schur(L, d, fuse_ctrl && launch_ctrl_fusable(d)); else { L.spb_in_place_ok = !p->xfn; launch_schur(L, d, fuse_ctrl, check_in_schur); L.spb_in_place_ok = false; } }))) return rc;
     if (p->xfn) {
         if ((rc = X(d.xv, d.xv_count, 0))) return rc;
         if (d.wide && (rc = X(L.wide.xw, L.wide.count, 0))) return rc;      // long tracks: the 144-row super-blocks [D | L | rhs]
@@ -1552,8 +1554,9 @@ static int enqueue_front(ssba_problem *p) {
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d, true, fuse_upd); if (d.nb) launch_border_solve(L, d); }
             // DOGLEG with landmark sharding: the six sums of the dogleg model are summed over the ranks between the two halves
-            if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d, p->xfn ? 1 : 0, p->rank == 0 ? 1 : 0);
-            else launch_update_eval(L, d, !p->xfn && !d.constrained, fuse_best, fuse_upd);
+            // (bounds on one GPU: the evaluation sums are formed by the Armijo test's launch -- launch_ph_ls_fast in enqueue_kernels)
+            if (p->opt.trust_region_strategy_type == 1) launch_dogleg_eval(L, d, p->xfn ? 1 : 0, p->rank == 0 ? 1 : 0, ls_reduces_eval(p));
+            else launch_update_eval(L, d, !p->xfn, fuse_best, fuse_upd);
         }))) return rc;
     if (p->xfn && p->opt.trust_region_strategy_type == 1) {
         if ((rc = X(d.scal_dl, NSCAL, 0))) return rc;

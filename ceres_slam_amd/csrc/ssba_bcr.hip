@@ -793,11 +793,13 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
     const size_t sh_backsub = (size_t)3 * BD * BD * sizeof(double);
     const int nl = d.n_levels;
     const bool ride = allow_pcr && bcr_border_rides(d);
+    const bool spb_rides = L.spb_rides;     // k_ph_spb_assemble has written the border columns in place (launch_ph_schur of this iteration)
+    L.spb_rides = false;
     if (!d.part && allow_pcr && d.pcr.level >= 0) {
         // cyclic reduction down to the plan's level, parallel cyclic reduction of what is left (no back-substitution
         // sweep over those levels: log2(n) x (factor + reduce) + one decoupled solve), back-substitution of the rest
         const int k = d.pcr.level, n = d.pcr.n;
-        if (ride)       // (a plan with border columns always starts at level 0: ssba_finalize)
+        if (ride && !spb_rides)       // (a plan with border columns always starts at level 0: ssba_finalize)
             hipMemcpyAsync(d.pcr.Bb, d.Spb, (size_t)n * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
         for (int l = 0; l < k; ++l) {
             const int nn = d.lev[l].n;
@@ -825,7 +827,7 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
         return;
     }
     if (!d.part) {
-        if (ride) hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
+        if (ride && !spb_rides) hipMemcpyAsync(d.lev[0].B, d.Spb, (size_t)d.Nsb * BD * NBP * sizeof(double), hipMemcpyDeviceToDevice, L.stream);
         for (int l = 0; l + 1 < nl; ++l) {
             const int n = d.lev[l].n;
             launch_factor(L, d, n / 2, l, 0, 0, true, ride);

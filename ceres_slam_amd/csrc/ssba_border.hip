@@ -300,27 +300,27 @@ __global__ __launch_bounds__(1024) void k_border_solve(Dev d) {
     __shared__ double rb[NBP];
     const int t = threadIdx.x, a = t / NBP, b = t - a * NBP, nb = d.nb;
     {
-        // partial sums in list order, eight loads in flight at a time; the transpose comes from LDS
+        // partial sums in list order, GF loads in flight at a time (r04: 8 -- eight dependent trips for the 64 partials, most of
+        // this launch's 34 us; the order of the additions is the same); the transpose comes from LDS
+        constexpr int GF = 16;
         __shared__ double G[NBP * (NBP + 1)];
-        double g = 0.0;
-        for (int q0 = 0; q0 < d.n_gram; q0 += 8) {
-            double x[8];
+        double g = 0.0, gv = 0.0;
+        for (int q0 = 0; q0 < d.n_gram; q0 += GF) {
+            double x[GF], y[GF];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = q0 + u < d.n_gram ? d.part_g[(size_t)(q0 + u) * (NBP * NBP + NBP) + a * NBP + b] : 0.0;
+            for (int u = 0; u < GF; ++u) x[u] = q0 + u < d.n_gram ? d.part_g[(size_t)(q0 + u) * (NBP * NBP + NBP) + a * NBP + b] : 0.0;
+            if (b == 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g += x[u];
-        }
-        G[a * (NBP + 1) + b] = g;
-        double gv = 0.0;
-        if (b == 0) {
-            for (int q0 = 0; q0 < d.n_gram; q0 += 8) {
-                double x[8];
+                for (int u = 0; u < GF; ++u) y[u] = q0 + u < d.n_gram ? d.part_g[(size_t)(q0 + u) * (NBP * NBP + NBP) + NBP * NBP + a] : 0.0;
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = q0 + u < d.n_gram ? d.part_g[(size_t)(q0 + u) * (NBP * NBP + NBP) + NBP * NBP + a] : 0.0;
+            for (int u = 0; u < GF; ++u) g += x[u];
+            if (b == 0) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) gv += x[u];
+                for (int u = 0; u < GF; ++u) gv += y[u];
             }
         }
+        G[a * (NBP + 1) + b] = g;
         __syncthreads();
         const double gt = G[b * (NBP + 1) + a];
         // symmetrised against rounding (only the lower triangle is read below)

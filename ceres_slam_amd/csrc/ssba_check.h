@@ -77,6 +77,13 @@ static __device__ __forceinline__ void check_body(Dev &d, int fused_parts, bool 
             }
         }
     }
+    // free shared blocks: lane 0's walk below reads the blocks and their gradient from LDS (up to r04 from global memory, entry
+    // by entry -- two dozen dependent round trips in front of the termination tests); the barriers of the sums publish the copy
+    __shared__ double s_sh[64], s_gb[NBP];
+    if (d.nb && lin) {
+        if ((int)threadIdx.x < d.nsh && threadIdx.x < 64) s_sh[threadIdx.x] = d.sh[threadIdx.x];
+        if ((int)threadIdx.x < d.nb) s_gb[threadIdx.x] = d.bsys[BS_G + threadIdx.x];
+    }
     const double gmp = block_max(gm, sm);
     const double xnp = block_sum(xn, sm);
     (void)cost;
@@ -91,24 +98,24 @@ static __device__ __forceinline__ void check_body(Dev &d, int fused_parts, bool 
         st.x_cost = sc[0];
         double xnb = 0.0, gmb = 0.0;
         if (d.nb) {   // free shared blocks: |x_b|^2 and |x_b - Plus(x_b, -g_b)|_inf
-            const double *gb = d.bsys + BS_G;
+            const double *gb = s_gb, *sh = s_sh;
             if (d.b_light >= 0) {
                 double ng[3] = {-gb[d.b_light], -gb[d.b_light + 1], -gb[d.b_light + 2]}, nl[3];
-                if (d.light_type == 1) unit_plus(d.sh, ng, nl);
-                else for (int c = 0; c < 3; ++c) nl[c] = d.sh[c] + ng[c];
-                for (int c = 0; c < 3; ++c) { xnb += d.sh[c] * d.sh[c]; gmb = fmax(gmb, fabs(nl[c] - d.sh[c])); }
+                if (d.light_type == 1) unit_plus(sh, ng, nl);
+                else for (int c = 0; c < 3; ++c) nl[c] = sh[c] + ng[c];
+                for (int c = 0; c < 3; ++c) { xnb += sh[c] * sh[c]; gmb = fmax(gmb, fabs(nl[c] - sh[c])); }
             }
             // Plus projects onto the bounds [Ceres ParameterBlock::Plus], so the projected gradient does too
             if (d.b_phong >= 0)
                 for (int c = 0; c < 3 * d.M; ++c) {
-                    const double v = d.sh[3 + c];
+                    const double v = sh[3 + c];
                     double nv = v - gb[d.b_phong + c];
                     if (d.constrained) nv = fmin(fmax(nv, d.blo[c % 3]), d.bhi[c % 3]);
                     xnb += v * v; gmb = fmax(gmb, fabs(nv - v));
                 }
             if (d.b_tex >= 0)
                 for (int c = 0; c < d.M; ++c) {
-                    const double v = d.sh[3 + 3 * d.M + c];
+                    const double v = sh[3 + 3 * d.M + c];
                     double nv = v - gb[d.b_tex + c];
                     if (d.constrained) nv = fmin(fmax(nv, d.blo[3]), d.bhi[3]);
                     xnb += v * v; gmb = fmax(gmb, fabs(nv - v));

@@ -541,5 +541,73 @@ static __device__ __forceinline__ void unit_plus(const double x[3], const double
     out[0] = y0 / nrm; out[1] = y1 / nrm; out[2] = y2 / nrm;
 }
 
+// Candidate shared blocks (light, materials, texture) = projected Plus(x, alpha * delta_b) and their part of |dx|^2 / the
+// non-finite flag, by the first wave of a 256-lane work-group.  Up to r04 a launch of its own (k_ph_border_update, 5.8 us:
+// three per iteration with the device-side line search); now the work-group behind the pose blocks of k_pose_update -- its
+// inputs are complete when that launch starts.  ls_round: a round of the device-side search, a no-op unless one is under way.
+static __device__ __forceinline__ void ph_border_update_block(const Dev &d, int ls_round, double *sdf /* 64 doubles of LDS */) {
+    const State &st = *d.st;
+    if (st.terminated || (ls_round && !st.ls_active)) return;
+    const int i = threadIdx.x, M3 = 3 * d.M;
+    const bool in = i < d.nsh;
+    const double old = in ? d.sh[i] : 0.0;
+    double nw = old, bad = 0.0;
+    const bool moved = !st.step_failed && d.nb;
+    if (moved) {
+        int col = -1;       // border column of this entry (-1: its block is constant)
+        if (i < 3) col = d.b_light >= 0 ? d.b_light + i : -1;
+        else if (i < 3 + M3) col = d.b_phong >= 0 ? d.b_phong + (i - 3) : -1;
+        else if (in) col = d.b_tex >= 0 ? d.b_tex + (i - 3 - M3) : -1;
+        double db = 0.0;    // LM: beta = 1, gamma = 0; dogleg: beta * delta_gn + gamma * v
+        if (col >= 0) {
+            db = st.ls_alpha * (st.beta * d.bsys[BS_DB + col] + st.gamma * d.bsys[BS_VB + col]);
+            if (!isfinite(db)) bad = 1.0;
+        }
+        const double x3[3] = {__shfl(old, 0, 64), __shfl(old, 1, 64), __shfl(old, 2, 64)};
+        const double d3[3] = {__shfl(db, 0, 64), __shfl(db, 1, 64), __shfl(db, 2, 64)};
+        if (col >= 0) {
+            if (i < 3 && d.light_type == 1) {
+                double o3[3];
+                unit_plus(x3, d3, o3);
+                nw = o3[i];
+            } else {
+                nw = old + db;
+            }
+            if (d.constrained && i >= 3) {   // ParameterBlock::Plus projects onto the box constraints
+                const int bi = i < 3 + M3 ? (i - 3) % 3 : 3;
+                nw = fmin(fmax(nw, d.blo[bi]), d.bhi[bi]);
+            }
+        }
+    }
+    if (in) d.cand_sh[i] = nw;
+    if (i < 64) sdf[i] = (nw - old) * (nw - old);
+    const bool any_bad = __ballot(bad != 0.0) != 0ull;      // (the entries all sit in wave 0, and so does lane 0)
+    __syncthreads();
+    if (i != 0) return;
+    double dn = 0.0;
+    if (moved)
+        for (int k = 0; k < d.nsh; ++k) dn += sdf[k];
+    d.part_pose[d.n_pose_blocks * NPP] = dn;
+    d.part_pose[d.n_pose_blocks * NPP + 1] = any_bad ? 1.0 : 0.0;
+}
+
+// border part of the dogleg vectors: v_b = s^2 g / D^2 and its share of |gradient_|^2, |gn|^2, gradient_.gn (one lane;
+// the work-group behind the pose blocks of k_dogleg_vec, a launch of its own -- k_ph_dogleg_border, 8.1 us -- up to r04)
+static __device__ __forceinline__ void ph_dogleg_border_lane(const Dev &d) {
+    const State &st = *d.st;
+    if (st.terminated || st.dl_reuse) return;
+    double gsq = 0.0, nsq = 0.0, dot = 0.0;
+    for (int c = 0; c < d.nb; ++c) {
+        const double s = d.bsys[BS_S + c], s2 = s * s, g = d.bsys[BS_G + c], gn = d.bsys[BS_DB + c];
+        const double D2 = fmin(fmax(d.bsys[BS_H + c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
+        d.bsys[BS_VB + c] = s2 * g / D2;
+        gsq += s2 * g * g / D2;
+        nsq += D2 * gn * gn / s2;
+        dot += g * gn;
+    }
+    double *o = d.part_dl + (size_t)(d.n_lm_blocks + d.n_pose_blocks) * NDL;
+    o[0] = gsq; o[1] = nsq; o[2] = dot; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0;
+}
+
 
 }  // namespace ssba

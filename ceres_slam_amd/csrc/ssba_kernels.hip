@@ -831,7 +831,13 @@ __global__ __launch_bounds__(256) void k_best(Dev d) {
 // fuse_best: also does k_best's share for the poses (x -> best when the k_check of this iteration saw the cost improve;
 // like k_best, before the termination test -- the improving iterate may be the converged one); -1: the trial point of a
 // device-side line-search round (bounds), a no-op unless a search is under way
+// With free shared blocks (lighting terms) the launch has one more work-group, which moves those (ph_border_update_block).
 __global__ __launch_bounds__(256) void k_pose_update(Dev d, int fuse_best) {
+    if (blockIdx.x == (unsigned)d.n_pose_blocks) {
+        __shared__ double sdf[64];
+        ph_border_update_block(d, fuse_best < 0 ? 1 : 0, sdf);
+        return;
+    }
     const State &st = *d.st;
     __shared__ double sm[4];
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -1323,7 +1329,12 @@ template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_backsub_
 // step returned to the minimiser is  delta = beta * delta_gn + gamma * v.
 
 // per pose: v_p and the pose parts of |gradient_|^2, |gn|^2, gradient_.gn
+// (free shared blocks: one more work-group, whose first lane does the border part -- ph_dogleg_border_lane)
 __global__ __launch_bounds__(256) void k_dogleg_vec(Dev d) {
+    if (blockIdx.x == (unsigned)d.n_pose_blocks) {
+        if (threadIdx.x == 0) ph_dogleg_border_lane(d);
+        return;
+    }
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
     __shared__ double sm[4];
@@ -1591,58 +1602,69 @@ __global__ __launch_bounds__(256) void k_dogleg_sum(Dev d, int own_poses) {
     for (int q = 0; q < NSCAL; ++q) d.scal_dl[q] = q < NDL ? acc[q] : 0.0;
 }
 
+// The solver state is worked on in LDS: the scalar part below is ONE lane's chain of some sixty reads and writes of State
+// fields (and the subspace model's eigen-decomposition and root finder between them), each a round trip to L2 while the struct
+// sits in global memory (21 us for this launch up to r04).  The work-group copies the struct in with the loads of the partial
+// sums in flight, lane 0 works on the copy, the work-group writes it back.
 __global__ __launch_bounds__(256) void k_dogleg_interp(Dev d, int from_scal) {
-    State &st = *d.st;
-    if (st.terminated) return;
-    __shared__ double sm[4];
+    __shared__ State st;
+    __shared__ double sm[NDL * 4];
+    static_assert(sizeof(State) % sizeof(unsigned long long) == 0, "State is copied in 8-byte words");
+    constexpr int NWORDS = (int)(sizeof(State) / sizeof(unsigned long long));
+    unsigned long long *gw = reinterpret_cast<unsigned long long *>(d.st), *lw = reinterpret_cast<unsigned long long *>(&st);
+    for (int i = threadIdx.x; i < NWORDS; i += 256) lw[i] = gw[i];
     double acc[NDL];
 #pragma unroll
     for (int q = 0; q < NDL; ++q) acc[q] = 0.0;
-    if (!st.dl_reuse && !from_scal) {
+    if (!from_scal) {       // (not used while dl_reuse holds)
         const int n = d.n_lm_blocks + d.n_pose_blocks + (d.nb ? 1 : 0);   // last entry: border of shared blocks
         for (int i = threadIdx.x; i < n; i += 256)
 #pragma unroll
             for (int q = 0; q < NDL; ++q) acc[q] += d.part_dl[(size_t)i * NDL + q];
     }
+    __syncthreads();
+    if (st.terminated) return;
+    block_sums<NDL>(acc, sm);
+    if (threadIdx.x == 0) {
+        if (from_scal) {
 #pragma unroll
-    for (int q = 0; q < NDL; ++q) acc[q] = block_sum(acc[q], sm);
-    if (threadIdx.x != 0) return;
-    if (from_scal) {
-#pragma unroll
-        for (int q = 0; q < NDL; ++q) acc[q] = d.scal_dl[q];
-    }
-    if (!st.dl_reuse) {
-        st.grad_norm = sqrt(acc[0]); st.gn_norm = sqrt(acc[1]); st.g_dot_gn = acc[2];
-        st.alpha = acc[0] / acc[3];   // ComputeCauchyPoint
-        st.dl_jv2 = acc[3]; st.dl_jg2 = acc[4]; st.dl_jvg = acc[5];
-        st.dl_reuse = 1;              // reuse_ = true until the next accepted / invalid step
-        if (st.opt.dogleg_type == 1) {
-            const double jj[3] = {acc[3], acc[4], acc[5]};
-            if (!subspace_model(st, acc[0], acc[1], acc[2], jj)) st.step_failed = 1;   // LINEAR_SOLVER_FAILURE
+            for (int q = 0; q < NDL; ++q) acc[q] = d.scal_dl[q];
         }
-    }
-    if (st.opt.dogleg_type != 1) {
-        traditional_dogleg(st);
-    } else {
-        // ComputeSubspaceDoglegStep
-        double m2[2];
-        if (st.gn_norm <= st.radius) {
-            st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
-        } else if (st.sub_one_dim) {
-            st.beta = 0.0; st.gamma = -st.radius / st.grad_norm; st.dl_step_norm = st.radius;
-        } else if (!subspace_boundary_minimum(st, m2)) {
-            traditional_dogleg(st);           // "Taking traditional dogleg step instead."
+        if (!st.dl_reuse) {
+            st.grad_norm = sqrt(acc[0]); st.gn_norm = sqrt(acc[1]); st.g_dot_gn = acc[2];
+            st.alpha = acc[0] / acc[3];   // ComputeCauchyPoint
+            st.dl_jv2 = acc[3]; st.dl_jg2 = acc[4]; st.dl_jvg = acc[5];
+            st.dl_reuse = 1;              // reuse_ = true until the next accepted / invalid step
+            if (st.opt.dogleg_type == 1) {
+                const double jj[3] = {acc[3], acc[4], acc[5]};
+                if (!subspace_model(st, acc[0], acc[1], acc[2], jj)) st.step_failed = 1;   // LINEAR_SOLVER_FAILURE
+            }
+        }
+        if (st.opt.dogleg_type != 1) {
+            traditional_dogleg(st);
         } else {
-            st.gamma = m2[0] * st.sub_e[0][0] + m2[1] * st.sub_e[1][0];    // coefficient of gradient_ -> v
-            st.beta = m2[0] * st.sub_e[0][1] + m2[1] * st.sub_e[1][1];     // coefficient of gauss_newton_step_
-            st.dl_step_norm = st.radius;
+            // ComputeSubspaceDoglegStep
+            double m2[2];
+            if (st.gn_norm <= st.radius) {
+                st.beta = 1.0; st.gamma = 0.0; st.dl_step_norm = st.gn_norm;
+            } else if (st.sub_one_dim) {
+                st.beta = 0.0; st.gamma = -st.radius / st.grad_norm; st.dl_step_norm = st.radius;
+            } else if (!subspace_boundary_minimum(st, m2)) {
+                traditional_dogleg(st);           // "Taking traditional dogleg step instead."
+            } else {
+                st.gamma = m2[0] * st.sub_e[0][0] + m2[1] * st.sub_e[1][0];    // coefficient of gradient_ -> v
+                st.beta = m2[0] * st.sub_e[0][1] + m2[1] * st.sub_e[1][1];     // coefficient of gauss_newton_step_
+                st.dl_step_norm = st.radius;
+            }
         }
+        // Model cost change of delta = beta gn + gamma v [trust_region_minimizer.cc: -model_residuals . (residuals + model_residuals / 2),
+        // model_residuals = J delta]:  -(delta . g) - |J delta|^2 / 2  with  delta . g = beta (g . gn) + gamma (g . v),  g . v = |gradient_|^2
+        // and |J delta|^2 from the three row-space sums -- the evaluation kernels need no Jacobian pass for it (r04).
+        const double b = st.beta, g = st.gamma;
+        st.dl_mcc = -(b * st.g_dot_gn + g * st.grad_norm * st.grad_norm) - 0.5 * (b * b * st.dl_jg2 + 2.0 * b * g * st.dl_jvg + g * g * st.dl_jv2);
     }
-    // Model cost change of delta = beta gn + gamma v [trust_region_minimizer.cc: -model_residuals . (residuals + model_residuals / 2),
-    // model_residuals = J delta]:  -(delta . g) - |J delta|^2 / 2  with  delta . g = beta (g . gn) + gamma (g . v),  g . v = |gradient_|^2
-    // and |J delta|^2 from the three row-space sums -- the evaluation kernels need no Jacobian pass for it (r04).
-    const double b = st.beta, g = st.gamma;
-    st.dl_mcc = -(b * st.g_dot_gn + g * st.grad_norm * st.grad_norm) - 0.5 * (b * b * st.dl_jg2 + 2.0 * b * g * st.dl_jvg + g * g * st.dl_jv2);
+    __syncthreads();
+    for (int i = threadIdx.x; i < NWORDS; i += 256) gw[i] = lw[i];
 }
 
 // per landmark: delta_l = beta * gn + gamma * v, candidate point, model cost change, candidate cost
@@ -1945,6 +1967,8 @@ static int lm_parts(const Dev &d) { return lm_split(d) || dn_sp(d) ? d.n_groups 
 static bool ctrl_fusable(const Dev &d) { return !d.part && (!d.dense || !d.phong); }       // (lighting terms included on the windowed layout: same partial sums, same reduced system)
 // fuse_best (the copy of x to the best iterate rides in the update / evaluation kernels): no exchange sits between k_check's
 // decision and those kernels in any mode, so the partitioned multi-GPU solve takes it too
+// lighting terms with free shared blocks: k_pose_update / k_dogleg_vec get one more work-group for the border entries
+static int border_block(const Dev &d) { return d.phong && d.nb ? 1 : 0; }
 static bool best_fusable(const Dev &d) { return !d.nb && (d.phong ? !d.dense : (lm_split(d) || dn_sp(d) > 0)); }       // (free shared blocks have a best copy of their own: k_best)
 bool launch_ctrl_fusable(const Dev &d) { return ctrl_fusable(d); }
 bool launch_can_fuse_all(const Dev &d) { return ctrl_fusable(d) && !d.phong && (lm_split(d) || dn_sp(d) > 0); }
@@ -2001,8 +2025,8 @@ void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_be
 // fuse_reduce: the caller's launch_decide_commit(.., true) forms the evaluation sums (no exchange in between)
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_best, bool pose_update_done) {
     const int fb = fuse_best && best_fusable(d) ? 1 : 0;
-    if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, fb);
-    if (d.phong) launch_ph_backsub_eval(L, d, fb);
+    if (!pose_update_done) LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks + border_block(d)), dim3(256), 0, d, fb);
+    if (d.phong) launch_ph_backsub_eval(L, d, fb, !pose_update_done);
     else if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<false, LMW_SPLIT>), dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, pose_update_done ? 2 : fb);
     else if (lm_split(d)) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<false, 1>), dim3(d.n_groups), dim3(64), 0, d, pose_update_done ? 2 : fb);
     else if (dn_sp(d) == 4) LAUNCH(KC_BACKSUB_EVAL, (k_backsub_eval_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, pose_update_done ? 2 : fb);
@@ -2030,14 +2054,15 @@ void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses) {
 }
 
 void launch_pose_update(Launcher &L, const Dev &d, int ls_round) {
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, ls_round ? -1 : 0);
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks + border_block(d)), dim3(256), 0, d, ls_round ? -1 : 0);
 }
 
 // stage 0: everything (single GPU).  Landmark sharding: stage 1 = up to this rank's six sums (scal_dl; own_poses on one rank),
 // stage 2 = from the summed vector on
-void launch_dogleg_eval(Launcher &L, const Dev &d, int stage, int own_poses) {
+int eval_parts(const Dev &d) { return d.phong ? d.n_lm_blocks : lm_parts(d); }
+void launch_dogleg_eval(Launcher &L, const Dev &d, int stage, int own_poses, bool reduce_later) {
     if (stage != 2) {
-        LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks), dim3(256), 0, d);
+        LAUNCH(KC_SMALL, k_dogleg_vec, dim3(d.n_pose_blocks + border_block(d)), dim3(256), 0, d);
         if (d.phong) launch_ph_dogleg_gn(L, d);
         else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_gn<true> : k_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     }
@@ -2046,10 +2071,10 @@ void launch_dogleg_eval(Launcher &L, const Dev &d, int stage, int own_poses) {
         return;
     }
     LAUNCH(KC_SMALL, k_dogleg_interp, dim3(1), dim3(256), 0, d, stage == 2 ? 1 : 0);
-    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks), dim3(256), 0, d, 0);
+    LAUNCH(KC_SMALL, k_pose_update, dim3(d.n_pose_blocks + border_block(d)), dim3(256), 0, d, 0);
     if (d.phong) launch_ph_dogleg_eval(L, d);
     else LAUNCH(KC_DOGLEG, (d.dense ? k_dogleg_eval<true> : k_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks, 0);
+    if (!reduce_later) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks, 0);
 }
 
 void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all, int n_pose_parts) {

@@ -37,6 +37,8 @@ struct Launcher {
     hipStream_t stream = nullptr;
     int timing = 0;
     DensePlan dense;
+    bool spb_in_place_ok = false;    // set by the iteration's front part on one GPU (no exchange sums Spb between the Schur launches and the reduced solve)
+    bool spb_rides = false;      // launch_ph_schur -> launch_bcr: k_ph_spb_assemble has also written the border columns where they ride (no copy)
     WideSys wide{};              // host copy of the wide system's sizes and pointers (Dev::wide is the device copy), n = 0: none
     struct Pending { int cls; hipEvent_t a, b; };
     std::vector<Pending> pending;
@@ -121,21 +123,22 @@ void launch_sep_finish_check(Launcher &L, const Dev &d, bool fuse_best = false);
 void launch_bcr_separators(Launcher &L, const Dev &d);
 void launch_sep_scatter(Launcher &L, const Dev &d);
 void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
+int eval_parts(const Dev &d);      // partial sums the evaluation kernel of this layout leaves
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false, bool pose_update_done = false);
-void launch_dogleg_eval(Launcher &L, const Dev &d, int stage = 0, int own_poses = 1);      // stage: see ssba_kernels.hip (landmark sharding: one more exchange point)
+void launch_dogleg_eval(Launcher &L, const Dev &d, int stage = 0, int own_poses = 1, bool reduce_later = false);     // reduce_later: launch_ph_ls_fast forms the evaluation sums;      // stage: see ssba_kernels.hip (landmark sharding: one more exchange point)
 void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false, int n_pose_parts = -1);
 // config 3 (ssba_phong_solver.hip)
 int upload_phong_tables(hipStream_t s);
 int configure_phong();
 void launch_ph_linearize(Launcher &L, const Dev &d);
 void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur = false);
-void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best = 0);
+void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best = 0, bool border_moved = false);   // border_moved: k_pose_update has run with its border work-group
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d);
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d);
 void launch_pose_update(Launcher &L, const Dev &d, int ls_round = 0);
 void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved);
 void launch_ph_ls_accept(Launcher &L, const Dev &d);
-void launch_ph_ls_fast(Launcher &L, const Dev &d);          // bounds: the Armijo test of the full step on the device, then d.ls_rounds blindly enqueued rounds of the search (no-ops unless the test failed); what they cannot finish parks the solver for the host
+void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval = false);          // bounds: the Armijo test of the full step on the device, then d.ls_rounds blindly enqueued rounds of the search (no-ops unless the test failed); what they cannot finish parks the solver for the host
 void launch_ls_resume(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();

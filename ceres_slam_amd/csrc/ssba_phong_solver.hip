@@ -775,11 +775,26 @@ __global__ __launch_bounds__(64) void k_ph_hpb(Dev d) {
 
 // S_pb = H_pb - sum over the Schur items of their border tiles (k_ph_schur_windows<true>): one thread per entry, the
 // items of a pose in list order (the prow lists of k_assemble_reduced)
-__global__ __launch_bounds__(256) void k_ph_spb_assemble(Dev d) {
+// The work-groups behind the first n_asm sum the columns of the border partials (k_ph_border_colsum's launch up to r04: both only
+// need k_ph_border_schur's and the Schur launch's output).  ride_dst: where the border columns ride through the reduced solve
+// (launch_bcr copied Spb there, one more 5 us node per iteration) -- ride_count entries, the padding rows included.
+__global__ __launch_bounds__(256) void k_ph_spb_assemble(Dev d, int n_asm, double *ride_dst, size_t ride_count) {
     const State &st = *d.st;
     if (st.terminated || st.dl_reuse) return;
+    if ((int)blockIdx.x >= n_asm) {
+        if (threadIdx.x >= 64) return;
+        const int idx = (int)blockIdx.x - n_asm, lane = threadIdx.x;
+        double a = 0.0;
+        for (int b = lane; b < d.n_lm_blocks; b += 64) a += d.part_b[(size_t)b * d.M * NBV + idx];
+        a = wave_sum(a);
+        if (lane == 0) d.part_b[(size_t)d.n_lm_blocks * d.M * NBV + idx] = a;
+        return;
+    }
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (size_t)d.nfree * 6 * NBP) return;
+    if (gid >= (size_t)d.nfree * 6 * NBP) {
+        if (ride_dst && gid < ride_count) ride_dst[gid] = d.Spb[gid];
+        return;
+    }
     const int col = (int)(gid % NBP), row = (int)(gid / NBP), f = row / 6, a = row - 6 * f;
     double v = d.Hpb[gid];
     if (d.b_light >= 0 && col >= d.b_light && col < d.b_light + 3) {        // light columns: the materials' partials, in order
@@ -793,10 +808,30 @@ __global__ __launch_bounds__(256) void k_ph_spb_assemble(Dev d) {
             v -= d.slabB[((size_t)(cw / TW) * 72 + (cw % TW) * 6 + a) * NBP + col];
         }
     d.Spb[gid] = v;
+    if (ride_dst && gid < ride_count) ride_dst[gid] = v;
 }
 
 // fuse_best (constant shared blocks): also does k_best's share for the landmarks (x -> best when the k_check of this
 // iteration saw the cost improve; before the termination test, like k_backsub_eval_w)
+// bounds: the landmark part of the projected line search's alpha-independent terms -- max|delta_l| (its min_step_size test)
+// and g_l . delta_l (phi'(0)) -- one partial pair per work-group for k_ph_ls_fast / k_ph_ls_reduce.  Formed by the evaluation
+// kernel that has delta_l in registers (a launch of its own, k_ph_ls_dir, up to r04: 5.4 us per iteration).
+static __device__ __forceinline__ void ph_ls_dir_terms(const Dev &d, int l, bool moved, const double dl[6], double *sm) {
+    double dmax = 0.0, gd = 0.0;
+    if (moved) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            dmax = fmax(dmax, fabs(dl[c]));
+            gd += d.gl[(size_t)c * d.Lpad + l] * dl[c];
+        }
+    }
+    const double f2 = block_max(dmax, sm), g2 = block_sum(gd, sm);
+    if (threadIdx.x == 0) {
+        double *o = d.part_ls + (size_t)blockIdx.x * NLS;
+        o[4] = f2; o[5] = g2;
+    }
+}
+
 template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_backsub_eval(Dev d, int fuse_best) {
     const State &st = *d.st;
     __shared__ double sm[4];
@@ -902,6 +937,7 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_backsub_eval(D
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) d.dlm[(size_t)c * d.Lpad + l] = dl[c];
+    if (d.constrained) ph_ls_dir_terms(d, l, mask && !st.step_failed, dl, sm);
     const double a = block_sum(ccost, sm), b = block_sum(mcc, sm), c = block_sum(dn, sm), e = block_sum(nonfinite, sm);
     if (threadIdx.x == 0) {
         d.part_eval[blockIdx.x * 4 + 0] = a;
@@ -1174,71 +1210,14 @@ template <bool DN> __global__ __launch_bounds__(BP_THREADS) void k_ph_border_pos
 // light (dataset_ba_phong.cpp:201-204); its |dx|^2 and non-finite flag join the pose partials
 // (one lane per entry of the shared blocks [light 3 | phong 3 M | texture M], nsh <= 63: the serial version spent 18 us in
 // chains of dependent loads; |dx|^2 is still summed in index order)
+// (the body lives in ssba_device.h: it usually runs as the last work-group of k_pose_update; this launch is left for the
+// iterations whose poses the reduced solve has already moved)
 __global__ __launch_bounds__(64) void k_ph_border_update(Dev d, int ls_round) {
-    const State &st = *d.st;
-    if (st.terminated || blockIdx.x != 0 || (ls_round && !st.ls_active)) return;
     __shared__ double sdf[64];
-    const int i = threadIdx.x, M3 = 3 * d.M;
-    const bool in = i < d.nsh;
-    const double old = in ? d.sh[i] : 0.0;
-    double nw = old, bad = 0.0;
-    const bool moved = !st.step_failed && d.nb;
-    if (moved) {
-        int col = -1;       // border column of this entry (-1: its block is constant)
-        if (i < 3) col = d.b_light >= 0 ? d.b_light + i : -1;
-        else if (i < 3 + M3) col = d.b_phong >= 0 ? d.b_phong + (i - 3) : -1;
-        else if (in) col = d.b_tex >= 0 ? d.b_tex + (i - 3 - M3) : -1;
-        double db = 0.0;    // LM: beta = 1, gamma = 0; dogleg: beta * delta_gn + gamma * v
-        if (col >= 0) {
-            db = st.ls_alpha * (st.beta * d.bsys[BS_DB + col] + st.gamma * d.bsys[BS_VB + col]);
-            if (!isfinite(db)) bad = 1.0;
-        }
-        const double x3[3] = {__shfl(old, 0, 64), __shfl(old, 1, 64), __shfl(old, 2, 64)};
-        const double d3[3] = {__shfl(db, 0, 64), __shfl(db, 1, 64), __shfl(db, 2, 64)};
-        if (col >= 0) {
-            if (i < 3 && d.light_type == 1) {
-                double o3[3];
-                unit_plus(x3, d3, o3);
-                nw = o3[i];
-            } else {
-                nw = old + db;
-            }
-            if (d.constrained && i >= 3) {   // ParameterBlock::Plus projects onto the box constraints
-                const int bi = i < 3 + M3 ? (i - 3) % 3 : 3;
-                nw = fmin(fmax(nw, d.blo[bi]), d.bhi[bi]);
-            }
-        }
-    }
-    if (in) d.cand_sh[i] = nw;
-    sdf[i] = (nw - old) * (nw - old);
-    const bool any_bad = __ballot(bad != 0.0) != 0ull;
-    __syncthreads();
-    if (i != 0) return;
-    double dn = 0.0;
-    if (moved)
-        for (int k = 0; k < d.nsh; ++k) dn += sdf[k];
-    d.part_pose[d.n_pose_blocks * NPP] = dn;
-    d.part_pose[d.n_pose_blocks * NPP + 1] = any_bad ? 1.0 : 0.0;
+    if (blockIdx.x == 0) ph_border_update_block(d, ls_round, sdf);
 }
 
 // ------------------------------------------------------------------ dogleg (config 3) ---
-// border part of the dogleg vectors: v_b = s^2 g / D^2 and its share of |gradient_|^2, |gn|^2, gradient_.gn
-__global__ void k_ph_dogleg_border(Dev d) {
-    const State &st = *d.st;
-    if (st.terminated || st.dl_reuse || threadIdx.x != 0 || blockIdx.x != 0) return;
-    double gsq = 0.0, nsq = 0.0, dot = 0.0;
-    for (int c = 0; c < d.nb; ++c) {
-        const double s = d.bsys[BS_S + c], s2 = s * s, g = d.bsys[BS_G + c], gn = d.bsys[BS_DB + c];
-        const double D2 = fmin(fmax(d.bsys[BS_H + c] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
-        d.bsys[BS_VB + c] = s2 * g / D2;
-        gsq += s2 * g * g / D2;
-        nsq += D2 * gn * gn / s2;
-        dot += g * gn;
-    }
-    double *o = d.part_dl + (size_t)(d.n_lm_blocks + d.n_pose_blocks) * NDL;
-    o[0] = gsq; o[1] = nsq; o[2] = dot; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0;
-}
-
 // per landmark: Gauss-Newton back-substitution, v_l, the landmark parts of the norms and the products
 // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn) over the landmark's observations
 template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_gn(Dev d) {
@@ -1392,6 +1371,7 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_eval(De
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) d.dlm[(size_t)c * d.Lpad + l] = dl[c];
+    if (d.constrained) ph_ls_dir_terms(d, l, mask && !st.step_failed, dl, sm);
     const double a = block_sum(ccost, sm), b = block_sum(mcc, sm), c = block_sum(dn, sm), e = block_sum(nonfinite, sm);
     if (threadIdx.x == 0) {
         d.part_eval[blockIdx.x * 4 + 0] = a;
@@ -1495,8 +1475,8 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_ls_probe(Dev d
 //     phi(1) <= phi(0) + 1e-4 phi'(0),    phi(1) = the candidate cost the evaluation kernel has just formed,
 //     phi'(0) = g . delta (every block: landmarks, poses, shared blocks).
 // phi'(1), which Ceres also evaluates there, is only USED by the interpolation of a rejected sample.  So the accepted full
-// step needs no probe at all: k_ph_ls_dir forms the landmark part of g . delta and max|delta| (the search's
-// min_step_size test), k_ph_ls_fast adds the pose / border parts and decides.  A rejected full step parks the solver
+// step needs no probe at all: the evaluation kernel forms the landmark part of g . delta and max|delta| (the search's
+// min_step_size test; ph_ls_dir_terms), k_ph_ls_fast adds the pose / border parts and decides.  A rejected full step parks the solver
 // (terminated with LS_PENDING) until the host has driven the search (ssba_api.hip: finish_pending_search) -- exactly the
 // evaluations Ceres makes, starting with phi'(1).
 __device__ inline void ls_park(State &st) {
@@ -1505,32 +1485,38 @@ __device__ inline void ls_park(State &st) {
     st.terminated = 1;
     st.termination_type = LS_PENDING;
 }
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_ls_dir(Dev d) {
-    const State &st = *d.st;
-    if (st.terminated) return;
-    __shared__ double sm[4];
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t mask = d.lm_mask[l];
-    double dmax = 0.0, gd = 0.0;
-    if (mask && !st.step_failed) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double dl = d.dlm[(size_t)c * d.Lpad + l];
-            dmax = fmax(dmax, fabs(dl));
-            gd += d.gl[(size_t)c * d.Lpad + l] * dl;
-        }
-    }
-    const double f2 = block_max(dmax, sm), g2 = block_sum(gd, sm);
-    if (threadIdx.x == 0) {
-        double *o = d.part_ls + (size_t)blockIdx.x * NLS;
-        o[4] = f2; o[5] = g2;
+// The border entries of the step (delta_b = beta db + gamma vb) and of the gradient for lane 0's loop below: loaded by nb lanes
+// at once into LDS (lane 0 walked them in global memory up to r04 -- 23 dependent round trips in front of the decision).  The
+// caller's next barrier (block_sum) publishes them; the additions keep their order.
+static __device__ __forceinline__ void ls_stage_border(const Dev &d, const State &st, double *sv, double *sg) {
+    const int c = threadIdx.x;
+    if (c < d.nb) {
+        sv[c] = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
+        sg[c] = d.bsys[BS_G + c];
     }
 }
 // (1024 lanes: the loops below are chains of cold loads, six trips instead of 24 -- 29 us -> see profiles/README.md)
-__global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d) {
+// n_eval_parts > 0: the launch forms the evaluation sums first (k_reduce_eval's launch up to r04: the same 256 lanes add the
+// same partials in the same order, the other waves add zeros)
+__global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts) {
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[16];
+    if (n_eval_parts > 0) {
+        double a = 0.0, b = 0.0, c = 0.0, e = 0.0;
+        if (threadIdx.x < 256)
+            for (int i = threadIdx.x; i < n_eval_parts; i += 256) {
+                a += d.part_eval[i * 4];
+                b += d.part_eval[i * 4 + 1];
+                c += d.part_eval[i * 4 + 2];
+                e += d.part_eval[i * 4 + 3];
+            }
+        a = block_sum(a, sm);
+        b = block_sum(b, sm);
+        c = block_sum(c, sm);
+        e = block_sum(e, sm);
+        if (threadIdx.x == 0) { d.scal2[0] = a; d.scal2[1] = b; d.scal2[2] = c; d.scal2[3] = e; }      // (read again by this lane below)
+    }
     double lmax = 0.0, lgd = 0.0;
     for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
         const double *o = d.part_ls + (size_t)i * NLS;
@@ -1544,14 +1530,16 @@ __global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d) {
         pgd += d.xv[d.off_gp + i] * dpc;
     }
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
+    __shared__ double sbv[NBP], sbg[NBP];
+    ls_stage_border(d, st, sbv, sbg);
     lmax = block_max(lmax, sm); lgd = block_sum(lgd, sm);
     pmax = block_max(pmax, sm); pgd = block_sum(pgd, sm); pbad = block_sum(pbad, sm);
     if (threadIdx.x != 0) return;
     double bmax = 0.0, bgd = 0.0;
     for (int c = 0; c < d.nb; ++c) {
-        const double v = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
+        const double v = sbv[c];
         bmax = fmax(bmax, fabs(v));
-        bgd += d.bsys[BS_G + c] * v;
+        bgd += sbg[c] * v;
     }
     // ComputeTrustRegionStep: the search only runs on a valid step (as k_ph_ls_reduce's ls_out[6])
     const bool valid = !st.step_failed && (d.scal2[3] + pbad) == 0.0 && (st.opt.strategy ? st.dl_mcc : d.scal2[1]) > 0.0;
@@ -1595,15 +1583,17 @@ __global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int 
         pgd += d.xv[d.off_gp + i] * dpc;
     }
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
+    __shared__ double sbv[NBP], sbg[NBP];
+    ls_stage_border(d, st, sbv, sbg);
     const double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
     const double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
     const double qmax = block_max(pmax, sm), qgd = block_sum(pgd, sm), qbad = block_sum(pbad, sm);
     if (threadIdx.x != 0) return;
     double bmax = 0.0, bgd = 0.0;
     for (int c = 0; c < d.nb; ++c) {
-        const double v = st.beta * d.bsys[BS_DB + c] + st.gamma * d.bsys[BS_VB + c];
+        const double v = sbv[c];
         bmax = fmax(bmax, fabs(v));
-        bgd += d.bsys[BS_G + c] * v;
+        bgd += sbg[c] * v;
     }
     d.ls_out[0] = cost; d.ls_out[1] = dphi; d.ls_out[2] = dn; d.ls_out[3] = bad;
     d.ls_out[4] = fmax(fmax(lmax, qmax), bmax);
@@ -1721,45 +1711,55 @@ void launch_ph_schur(Launcher &L, const Dev &d, bool check_in_schur) {
     else LAUNCH(KC_SCHUR, k_ph_schur_windows<false>, dim3(d.n_slabs + xg), dim3(PH_THREADS), PhSchurCfg<false>::LDS_DOUBLES * sizeof(double), d, cp);
     if (d.nb) {
         LAUNCH(KC_BORDER, k_ph_border_schur, dim3(d.n_lm_blocks), dim3(256), 0, d);
-        LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
-        LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(1024), 0, d);
         // pose rows of the border: from the Schur product's border tiles (windowed layout), or pose by pose
-        if (d.lmMV) LAUNCH(KC_BORDER, k_ph_spb_assemble, dim3((unsigned)(((size_t)d.nfree * 6 * NBP + 255) / 256)), dim3(256), 0, d);
-        else LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(BP_THREADS), 0, d);
+        L.spb_rides = false;
+        if (d.lmMV) {
+            // single GPU: the columns go straight to where they ride through the reduced solve (launch_bcr)
+            double *dst = nullptr;
+            size_t cnt = 0;
+            if (L.spb_in_place_ok && bcr_border_rides(d)) {
+                dst = d.pcr.level >= 0 ? d.pcr.Bb : d.lev[0].B;
+                cnt = (size_t)(d.pcr.level >= 0 ? d.pcr.n : d.Nsb) * BD * NBP;
+                if (cnt > (size_t)d.nf_pad * 6 * NBP) { dst = nullptr; cnt = 0; }      // (Spb has nf_pad rows: never with the plans ssba_finalize makes)
+            }
+            L.spb_rides = dst != nullptr;
+            const size_t entries = std::max((size_t)d.nfree * 6 * NBP, cnt);
+            const int n_asm = (int)((entries + 255) / 256);
+            LAUNCH(KC_BORDER, k_ph_spb_assemble, dim3(n_asm + d.M * NBV), dim3(256), 0, d, n_asm, dst, cnt);
+        } else {
+            LAUNCH(KC_SMALL, k_ph_border_colsum, dim3(d.M * NBV), dim3(64), 0, d);
+            LAUNCH(KC_BORDER, (d.dense ? k_ph_border_poses<true> : k_ph_border_poses<false>), dim3(d.P), dim3(BP_THREADS), 0, d);
+        }
+        LAUNCH(KC_SMALL, k_ph_border_reduce, dim3(1), dim3(1024), 0, d);
     }
 }
-void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best) {
-    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
+void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best, bool border_moved) {
+    if (d.nb && !border_moved) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
     LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_backsub_eval<true> : k_ph_backsub_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, fuse_best);
 }
-void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {
-    if (d.nb) LAUNCH(KC_SMALL, k_ph_dogleg_border, dim3(1), dim3(64), 0, d);
+void launch_ph_dogleg_gn(Launcher &L, const Dev &d) {       // (the border part: last work-group of k_dogleg_vec)
     LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_gn<true> : k_ph_dogleg_gn<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
-void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {
-    if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
+void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {     // (the candidate shared blocks: last work-group of k_pose_update)
     LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_eval<true> : k_ph_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 // one evaluation of the line-search function at step `alpha` (alpha < 0: keep the current one)
 void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
     if (alpha >= 0.0) hipLaunchKernelGGL(k_ls_set_alpha, dim3(1), dim3(64), 0, L.stream, d, alpha);
     if (moved) {
-        launch_pose_update(L, d);
-        if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 0);
+        launch_pose_update(L, d);       // (and the shared blocks)
     }
     LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 0);
     LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 0, 0);
 }
 // the device-side test of the full step (the common case) and the search rounds behind it
-void launch_ph_ls_fast(Launcher &L, const Dev &d) {
-    LAUNCH(KC_SMALL, (d.dense ? k_ph_ls_dir<true> : k_ph_ls_dir<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
-    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(1024), 0, d);
+void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval) {
+    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(1024), 0, d, reduce_eval ? eval_parts(d) : 0);
     // the search itself, enqueued blindly like the trust-region loop: round 0 evaluates phi and phi' at the full step (the
     // candidate of the update kernels is that trial point), every further round moves the candidate to st.ls_alpha first
     for (int r = 0; r < d.ls_rounds; ++r) {
         if (r) {
-            launch_pose_update(L, d, 1);
-            if (d.nb) LAUNCH(KC_SMALL, k_ph_border_update, dim3(1), dim3(64), 0, d, 1);
+            launch_pose_update(L, d, 1);        // (and the shared blocks)
         }
         LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 1);
         LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 1, r == d.ls_rounds - 1 ? 1 : 0);
