@@ -1648,9 +1648,9 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (o->max_num_iterations < 0 || !(o->initial_trust_region_radius > 0.0)) return SSBA_ERR_INVALID_ARGUMENT;
     if (o->trust_region_strategy_type != 0 && o->trust_region_strategy_type != 1) return SSBA_ERR_INVALID_ARGUMENT;
     if (p->d.part && !p->xfn) { set_error("a partitioned problem needs an exchange callback"); return SSBA_ERR_STATE; }
-    if (o->trust_region_strategy_type == 1 && p->xfn && (p->d.part || p->d.nb)) {
-        set_error("DOGLEG with landmark sharding runs on the all-reduce of the reduced system with constant shared blocks (not with "
-                  "ssba_set_partition: the pose sums of its model need every rank's interior poses; not with free shared lighting blocks)");
+    if (o->trust_region_strategy_type == 1 && p->xfn && p->d.part) {
+        set_error("DOGLEG with landmark sharding runs on the all-reduce of the reduced system (not with ssba_set_partition: the pose "
+                  "sums of its model need every rank's interior poses)");
         return SSBA_ERR_UNSUPPORTED;
     }
     if (o->dogleg_type != 0 && o->dogleg_type != 1) return SSBA_ERR_INVALID_ARGUMENT;

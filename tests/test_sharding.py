@@ -112,7 +112,8 @@ def test_sharded_long_tracks_match_unsharded_oracle(tmp_path, world, size):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,size,dogleg,mode", [(2, (16, 400, 6), 0, "gpu"), (3, (40, 1600, 12), 1, "gpu"), (2, (60, 2400, 20), 1, "gpu"),
-                                                    (2, (60, 2400, 12), 1, "gpu_phong")])
+                                                    (2, (60, 2400, 12), 1, "gpu_phong"), (2, (60, 2400, 12), 1, "gpu_phongfree"),
+                                                    (3, (60, 2400, 12), 0, "gpu_phongfree")])
 def test_sharded_dogleg_solve_matches_unsharded_oracle(tmp_path, world, size, dogleg, mode):
     """The trust-region strategy of the reference's BA driver (tests/dataset_ba_phong.cpp:85-86: DOGLEG, SUBSPACE_DOGLEG) with
     landmark sharding: the six sums of the dogleg model (|gradient|^2, |gn|^2, gradient.gn, |Jv|^2, |Jgn|^2, Jv.Jgn) are
@@ -121,10 +122,11 @@ def test_sharded_dogleg_solve_matches_unsharded_oracle(tmp_path, world, size, do
     K = 25
     res = _run_ranks(mode, str(tmp_path / "dl"), world, size=size, extra_env={"SSBA_TEST_MAXIT": str(K), "SSBA_TEST_DOGLEG": str(dogleg)})
     okw = dict(num_threads=2, max_num_iterations=K, trust_region_strategy_type=1, dogleg_type=dogleg)
-    if mode == "gpu_phong":
+    if mode in ("gpu_phong", "gpu_phongfree"):     # gpu_phongfree: light, Phong and texture blocks free (the driver's problem; its border part of the sums is counted by one rank)
+        free = mode == "gpu_phongfree"
         prob, ph = synth.make_phong_problem(size[0], size[1], track_len=size[2], seed=21)
         op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
-                               prob.stiffness(), lighting=ph.as_oracle_dict("truth"))
+                               prob.stiffness(), lighting=ph.as_oracle_dict("perturbed" if free else "truth"), shared_free=7 if free else 0)
     else:
         prob = synth.make_problem(size[0], size[1], track_len=size[2], seed=21)
         op = orc.OracleProblem.from_synth(prob)
@@ -136,7 +138,7 @@ def test_sharded_dogleg_solve_matches_unsharded_oracle(tmp_path, world, size, do
         ok[0] = True
         # (SUBSPACE_DOGLEG on lighting problems amplifies rounding to ~1e-8 in its first iteration -- the Gauss-Newton solve with
         # mu = 1e-8 --: tools/fuzz_parity.py conditioned_agreement; the unsharded lighting tests compare at 1e-6 too)
-        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-6 if mode == "gpu_phong" else 1e-8)
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log["cost"][ok], rtol=1e-6 if mode.startswith("gpu_phong") else 1e-8)
         assert r["final_cost"] == pytest.approx(s.final_cost, rel=1e-6)
         assert np.abs(np.array(r["poses"]) - op.poses).max() < 1e-6
     for r in res[1:]:
