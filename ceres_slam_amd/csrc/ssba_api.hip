@@ -965,7 +965,7 @@ int ssba_finalize(ssba_problem *p) {
             TRY(dzero(p, &d.part_g, (size_t)d.n_gram * (NBP * NBP + NBP)));
         }
         TRY(dzero(p, &d.part_ls, (size_t)(Lpad / 256) * NLS));
-        TRY(dzero(p, &d.ls_out, (size_t)NLS_OUT + NLS_MACH));
+        TRY(dzero(p, &d.ls_out, (size_t)NLS_OUT + NLS_MACH + NLS_X + NLS_X_RANKS));
     }
     TRY(dzero(p, &d.hpp, (size_t)P * 21)); TRY(dzero(p, &d.gp, (size_t)P * 6));
     TRY(dzero(p, &d.sp, (size_t)d.nf_pad * 6));
@@ -1419,6 +1419,10 @@ static int enqueue_iteration(ssba_problem *p) {
 static int enqueue_front(ssba_problem *p);
 // bounds on one GPU: k_ph_ls_fast forms the sums of the evaluation kernel's partials (no exchange sits between them)
 static bool ls_reduces_eval(const ssba_problem *p) { return p->d.constrained && !p->xfn; }
+static double *ls_x(const Dev &d) { return d.ls_out + NLS_OUT + NLS_MACH; }
+// bounds with landmark sharding: the host looks at the state after EVERY iteration -- an iteration enqueued behind a parked one
+// would run its exchanges over buffers whose kernels did nothing and sum the linearisation of a rejected step a second time
+static bool lockstep(const ssba_problem *p) { return p->d.constrained && p->xfn; }
 
 // GRAPH_ITERS iterations in one graph replay (the plain single-GPU path, ssba_solve_step): the sequence is fixed and
 // every kernel turns into a no-op once the state says "terminated", so a batch is safe to enqueue blindly; it saves
@@ -1457,7 +1461,12 @@ static int enqueue_kernels(ssba_problem *p) {
     const bool fuse_upd = fuse_all_launches(p) && !p->d.dense && bcr_updates_poses(p->d);       // the reduced solve updated the poses, one partial per block
     // bounds [trust_region_minimizer.cc DoLineSearch]: the Armijo test of the full step runs on the device; when it fails
     // (rare) the state is parked and the host drives the search at its next look at the state (finish_pending_search)
-    if (p->d.constrained) launch_ph_ls_fast(p->launcher, p->d, ls_reduces_eval(p));
+    if (p->d.constrained && p->xfn) {
+        // landmark sharding: the landmark part of g . delta and max|delta| are sums / maxima over the ranks
+        launch_ph_ls_pack(p->launcher, p->d, p->rank, p->world_size);
+        if (p->xfn(p->xctx, ls_x(p->d), (uint64_t)(NLS_X + p->world_size), 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        launch_ph_ls_fast(p->launcher, p->d, false, p->world_size);
+    } else if (p->d.constrained) launch_ph_ls_fast(p->launcher, p->d, ls_reduces_eval(p));
     if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p), fuse_upd ? p->d.pcr.n : -1); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
@@ -1480,8 +1489,16 @@ static int finish_pending_search(ssba_problem *p) {
         HIPCHECK(hipStreamSynchronize(L.stream));
         return SSBA_OK;
     };
+    // one evaluation of the line-search function; with landmark sharding the landmark sums of the ranks are added in the middle of it
+    auto probe = [&](double alpha) -> int {
+        if (!p->xfn) { launch_ph_ls_probe(L, d, alpha, 1); return SSBA_OK; }
+        launch_ph_ls_probe(L, d, alpha, 1, 1, p->rank, p->world_size);
+        if (p->xfn(p->xctx, ls_x(d), (uint64_t)(NLS_X + p->world_size), 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
+        launch_ph_ls_probe(L, d, -1.0, 0, 2, p->rank, p->world_size);
+        return SSBA_OK;
+    };
     launch_ls_resume(L, d);                 // the evaluation kernels test `terminated`
-    launch_ph_ls_probe(L, d, 1.0, 1);       // the full step again, with phi'(1) this time (rounds of the device-side search may have moved the candidate)
+    if ((rc = probe(1.0))) return rc;       // the full step again, with phi'(1) this time (rounds of the device-side search may have moved the candidate)
     ++p->num_line_searches_by_host;
     if ((rc = fetch())) return rc;
     if (!p->h_state->terminated && p->h_ls[6] != 0.0) {
@@ -1492,13 +1509,13 @@ static int finish_pending_search(ssba_problem *p) {
         ++p->num_line_search_steps;
         while (!a.done) {
             at = a.current.x;
-            launch_ph_ls_probe(L, d, at, 1);
+            if ((rc = probe(at))) return rc;
             if ((rc = fetch())) return rc;
             a.feed(p->h_ls[0], p->h_ls[1]);
             ++p->num_line_search_steps;
         }
         const double want = a.success ? a.optimal_step : 1.0;    // a failed search leaves delta alone
-        if (want != at) launch_ph_ls_probe(L, d, want, 1);
+        if (want != at && (rc = probe(want))) return rc;
         if (want != 1.0 || at != 1.0) launch_ph_ls_accept(L, d);
     }
     launch_decide_commit(L, d);
@@ -1660,8 +1677,8 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         int rc = refinalize_without_closure_border(p, "DOGLEG");
         if (rc) return rc;
     }
-    if (p->d.phong && p->xfn && p->d.nb && (p->d.constrained || p->d.dense)) {
-        set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
+    if (p->d.phong && p->xfn && p->d.nb && (p->d.dense || (p->d.constrained && p->world_size > NLS_X_RANKS))) {
+        set_error("lighting terms: landmark sharding with free shared blocks is not available on the general layout (nor with bounds on more than 64 ranks)");
         return SSBA_ERR_UNSUPPORTED;
     }
     if (p->opt.trust_region_strategy_type != o->trust_region_strategy_type)
@@ -1671,6 +1688,7 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
         // that needs more is finished by the host.  SSBA_LS_ROUNDS in the environment of a solve (0: host only -- A/B, tests)
         int rounds = 3;
         if (const char *e = getenv("SSBA_LS_ROUNDS")) rounds = std::min(20, std::max(0, atoi(e)));
+        if (p->xfn) rounds = 0;     // landmark sharding: every evaluation has an exchange in it, the host drives the search (finish_pending_search)
         if (rounds != p->d.ls_rounds) { p->d.ls_rounds = rounds; drop_graph(p); }
     }
     HIPCHECK(hipSetDevice(p->device));
@@ -1737,6 +1755,14 @@ int ssba_solve_step(ssba_problem *p, int n) {
     int rc = fetch_state(p);
     if (rc) return rc;
     if (search_pending(p) && (rc = finish_pending_search(p))) return rc;
+    if (lockstep(p)) {
+        for (int i = 0; i < n; ++i) {
+            if ((rc = enqueue_iteration(p))) return rc;
+            if ((rc = fetch_state(p))) return rc;
+            if (search_pending(p) && (rc = finish_pending_search(p))) return rc;
+        }
+        return SSBA_OK;
+    }
     int judged = 0;                 // iterations of this call that reached their accept / reject decision
     long it = 0;
     bool outstanding = false;       // an enqueued iteration whose state has not been looked at
@@ -1877,6 +1903,15 @@ int ssba_solve(ssba_problem *p, const ssba_options *o, ssba_summary *s) {
         rc = enqueue_iteration(p);      // (one iteration per replay here: the host polls one round behind, and idle iterations
                                         // after termination would cost what pairs save)
         if (rc) break;
+        if (lockstep(p)) {
+            if ((rc = fetch_state(p))) break;
+            if (search_pending(p)) {
+                if ((rc = finish_pending_search(p))) break;
+                if ((rc = fetch_state(p))) break;
+            }
+            if (p->h_state->terminated) done = true;
+            continue;
+        }
         const int slot = (int)(it & 1);
         hipMemcpyAsync(&ring[slot], p->d.st, sizeof(State), hipMemcpyDeviceToHost, st);
         hipEventRecord(ev[slot], st);
@@ -1975,8 +2010,8 @@ static int begin_hook(ssba_problem *p, const ssba_options *o, double radius) {
     ssba_options opt;
     if (o) opt = *o; else ssba_default_options(&opt);
     if (radius > 0.0) opt.initial_trust_region_radius = radius;
-    if (p->d.phong && p->xfn && p->d.nb && (p->d.constrained || p->d.dense)) {
-        set_error("lighting terms: landmark sharding with free shared blocks is not available with bounds or on the general layout");
+    if (p->d.phong && p->xfn && p->d.nb && (p->d.dense || (p->d.constrained && p->world_size > NLS_X_RANKS))) {
+        set_error("lighting terms: landmark sharding with free shared blocks is not available on the general layout (nor with bounds on more than 64 ranks)");
         return SSBA_ERR_UNSUPPORTED;
     }
     if (p->opt.trust_region_strategy_type != opt.trust_region_strategy_type)

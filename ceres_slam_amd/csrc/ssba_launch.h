@@ -136,9 +136,10 @@ void launch_ph_backsub_eval(Launcher &L, const Dev &d, int fuse_best = 0, bool b
 void launch_ph_dogleg_gn(Launcher &L, const Dev &d);
 void launch_ph_dogleg_eval(Launcher &L, const Dev &d);
 void launch_pose_update(Launcher &L, const Dev &d, int ls_round = 0);
-void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved);
+void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved, int stage = 0, int rank = 0, int world = 1);     // stage: landmark sharding (1: up to the packed sums, 2: from the exchanged vector on)
+void launch_ph_ls_pack(Launcher &L, const Dev &d, int rank, int world);
 void launch_ph_ls_accept(Launcher &L, const Dev &d);
-void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval = false);          // bounds: the Armijo test of the full step on the device, then d.ls_rounds blindly enqueued rounds of the search (no-ops unless the test failed); what they cannot finish parks the solver for the host
+void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval = false, int x_world = 0);          // bounds: the Armijo test of the full step on the device, then d.ls_rounds blindly enqueued rounds of the search (no-ops unless the test failed); what they cannot finish parks the solver for the host
 void launch_ls_resume(Launcher &L, const Dev &d);
 // border of free shared blocks (ssba_border.hip): multi-right-hand-side BCR solve + arrowhead system
 int configure_border();

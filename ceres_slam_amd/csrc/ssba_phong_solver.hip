@@ -1498,7 +1498,8 @@ static __device__ __forceinline__ void ls_stage_border(const Dev &d, const State
 // (1024 lanes: the loops below are chains of cold loads, six trips instead of 24 -- 29 us -> see profiles/README.md)
 // n_eval_parts > 0: the launch forms the evaluation sums first (k_reduce_eval's launch up to r04: the same 256 lanes add the
 // same partials in the same order, the other waves add zeros)
-__global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts) {
+// x_world > 0 (landmark sharding): the landmark part of max|delta| and g . delta comes from the exchanged vector (k_ph_ls_pack)
+__global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts, int x_world) {
     State &st = *d.st;
     if (st.terminated) return;
     __shared__ double sm[16];
@@ -1518,10 +1519,11 @@ __global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts) {
         if (threadIdx.x == 0) { d.scal2[0] = a; d.scal2[1] = b; d.scal2[2] = c; d.scal2[3] = e; }      // (read again by this lane below)
     }
     double lmax = 0.0, lgd = 0.0;
-    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
-        const double *o = d.part_ls + (size_t)i * NLS;
-        lmax = fmax(lmax, o[4]); lgd += o[5];
-    }
+    if (!x_world)
+        for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
+            const double *o = d.part_ls + (size_t)i * NLS;
+            lmax = fmax(lmax, o[4]); lgd += o[5];
+        }
     double pmax = 0.0, pgd = 0.0, pbad = 0.0;
     for (int i = threadIdx.x; i < d.nfree * 6; i += 1024) {
         const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
@@ -1535,6 +1537,11 @@ __global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts) {
     lmax = block_max(lmax, sm); lgd = block_sum(lgd, sm);
     pmax = block_max(pmax, sm); pgd = block_sum(pgd, sm); pbad = block_sum(pbad, sm);
     if (threadIdx.x != 0) return;
+    if (x_world) {
+        const double *x = d.ls_out + NLS_OUT + NLS_MACH;
+        lgd = x[4];
+        for (int r = 0; r < x_world; ++r) lmax = fmax(lmax, x[NLS_X + r]);
+    }
     double bmax = 0.0, bgd = 0.0;
     for (int c = 0; c < d.nb; ++c) {
         const double v = sbv[c];
@@ -1549,6 +1556,25 @@ __global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts) {
     if (value_ok && !(phi1 > phi0 + 1e-4 * dphi0 * 1.0)) { st.ls_steps += 1; return; }       // the full step satisfies the Armijo condition: nothing to search (one evaluation in Ceres' count)
     if (d.ls_rounds > 0) { st.ls_active = 1; return; }                // the search rounds behind this launch wake up
     ls_park(st);
+}
+// Landmark sharding with bounds: this rank's landmark sums of the last evaluation (k_ph_ls_probe; or only the direction terms the
+// evaluation kernel of the iteration left: slots 4 and 5 of the partials) packed for the exchange -- layout at NLS_X (ssba_types.h).
+// The maximum travels through the SUM exchange in one slot per rank.  Always writes the vector (zeros while the solver is parked).
+__global__ __launch_bounds__(1024) void k_ph_ls_pack(Dev d, int rank, int world) {
+    const State &st = *d.st;
+    __shared__ double sm[16];
+    double acc[NLS] = {0, 0, 0, 0, 0, 0};
+    if (!st.terminated)
+        for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
+            const double *o = d.part_ls + (size_t)i * NLS;
+            acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; acc[4] = fmax(acc[4], o[4]); acc[5] += o[5];
+        }
+    const double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
+    const double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
+    if (threadIdx.x != 0) return;
+    double *x = d.ls_out + NLS_OUT + NLS_MACH;
+    x[0] = cost; x[1] = dphi; x[2] = dn; x[3] = bad; x[4] = lgd; x[5] = 0.0; x[6] = 0.0; x[7] = 0.0;
+    for (int r = 0; r < world; ++r) x[NLS_X + r] = r == rank ? lmax : 0.0;
 }
 __global__ void k_ls_resume(Dev d) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1566,15 +1592,17 @@ __global__ void k_ls_resume(Dev d) {
 // on (st.ls_alpha = the next step: the following round evaluates it) or is handed to the host (`last` round and still not
 // done, or a failed search that would have to restore the full step: the host starts that search again from the top --
 // the evaluations are deterministic, it takes the same path)
-__global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int last) {
+// x_world > 0 (landmark sharding): the landmark sums come from the exchanged vector (k_ph_ls_pack) instead of this rank's partials
+__global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int last, int x_world) {
     State &st = *d.st;
     if (st.terminated || (ls_round && !st.ls_active)) return;
     __shared__ double sm[16];
     double acc[NLS] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
-        const double *o = d.part_ls + (size_t)i * NLS;
-        acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; acc[4] = fmax(acc[4], o[4]); acc[5] += o[5];
-    }
+    if (!x_world)
+        for (int i = threadIdx.x; i < d.n_lm_blocks; i += 1024) {
+            const double *o = d.part_ls + (size_t)i * NLS;
+            acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; acc[4] = fmax(acc[4], o[4]); acc[5] += o[5];
+        }
     double pmax = 0.0, pgd = 0.0, pbad = 0.0;
     for (int i = threadIdx.x; i < d.nfree * 6; i += 1024) {
         const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
@@ -1585,10 +1613,15 @@ __global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int 
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
     __shared__ double sbv[NBP], sbg[NBP];
     ls_stage_border(d, st, sbv, sbg);
-    const double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
-    const double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
+    double cost = block_sum(acc[0], sm), dphi = block_sum(acc[1], sm), dn = block_sum(acc[2], sm), bad = block_sum(acc[3], sm);
+    double lmax = block_max(acc[4], sm), lgd = block_sum(acc[5], sm);
     const double qmax = block_max(pmax, sm), qgd = block_sum(pgd, sm), qbad = block_sum(pbad, sm);
     if (threadIdx.x != 0) return;
+    if (x_world) {
+        const double *x = d.ls_out + NLS_OUT + NLS_MACH;
+        cost = x[0]; dphi = x[1]; dn = x[2]; bad = x[3]; lgd = x[4];
+        for (int r = 0; r < x_world; ++r) lmax = fmax(lmax, x[NLS_X + r]);
+    }
     double bmax = 0.0, bgd = 0.0;
     for (int c = 0; c < d.nb; ++c) {
         const double v = sbv[c];
@@ -1744,17 +1777,24 @@ void launch_ph_dogleg_eval(Launcher &L, const Dev &d) {     // (the candidate sh
     LAUNCH(KC_DOGLEG, (d.dense ? k_ph_dogleg_eval<true> : k_ph_dogleg_eval<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
 }
 // one evaluation of the line-search function at step `alpha` (alpha < 0: keep the current one)
-void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved) {
-    if (alpha >= 0.0) hipLaunchKernelGGL(k_ls_set_alpha, dim3(1), dim3(64), 0, L.stream, d, alpha);
-    if (moved) {
-        launch_pose_update(L, d);       // (and the shared blocks)
+// stage 0: one GPU.  Landmark sharding: stage 1 = up to this rank's packed landmark sums, stage 2 = from the summed vector on.
+void launch_ph_ls_probe(Launcher &L, const Dev &d, double alpha, int moved, int stage, int rank, int world) {
+    if (stage != 2) {
+        if (alpha >= 0.0) hipLaunchKernelGGL(k_ls_set_alpha, dim3(1), dim3(64), 0, L.stream, d, alpha);
+        if (moved) {
+            launch_pose_update(L, d);       // (and the shared blocks)
+        }
+        LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 0);
     }
-    LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 0);
-    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 0, 0);
+    if (stage == 1) { launch_ph_ls_pack(L, d, rank, world); return; }
+    LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 0, 0, stage == 2 ? world : 0);
+}
+void launch_ph_ls_pack(Launcher &L, const Dev &d, int rank, int world) {
+    LAUNCH(KC_SMALL, k_ph_ls_pack, dim3(1), dim3(1024), 0, d, rank, world);
 }
 // the device-side test of the full step (the common case) and the search rounds behind it
-void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval) {
-    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(1024), 0, d, reduce_eval ? eval_parts(d) : 0);
+void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval, int x_world) {
+    LAUNCH(KC_SMALL, k_ph_ls_fast, dim3(1), dim3(1024), 0, d, reduce_eval ? eval_parts(d) : 0, x_world);
     // the search itself, enqueued blindly like the trust-region loop: round 0 evaluates phi and phi' at the full step (the
     // candidate of the update kernels is that trial point), every further round moves the candidate to st.ls_alpha first
     for (int r = 0; r < d.ls_rounds; ++r) {
@@ -1762,7 +1802,7 @@ void launch_ph_ls_fast(Launcher &L, const Dev &d, bool reduce_eval) {
             launch_pose_update(L, d, 1);        // (and the shared blocks)
         }
         LAUNCH(KC_BACKSUB_EVAL, (d.dense ? k_ph_ls_probe<true> : k_ph_ls_probe<false>), dim3(d.n_lm_blocks), dim3(256), 0, d, 1);
-        LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 1, r == d.ls_rounds - 1 ? 1 : 0);
+        LAUNCH(KC_SMALL, k_ph_ls_reduce, dim3(1), dim3(1024), 0, d, 1, r == d.ls_rounds - 1 ? 1 : 0, 0);
     }
 }
 void launch_ls_resume(Launcher &L, const Dev &d) {

@@ -308,6 +308,9 @@ constexpr int DN_BS = 64;                           // block size of the dense C
 constexpr int NLS = 6;        // per block: cost, phi', |dx_l|^2, nonfinite, max|delta_l|, g_l . delta_l
 constexpr int NLS_MACH = 24;
 constexpr int NLS_OUT = 8;    // cost, phi', |dx_l|^2, nonfinite_l, max|delta|, g . delta, valid, x_cost
+// landmark sharding with bounds: the exchange vector of a line-search evaluation, behind the search state in ls_out:
+// [cost, phi', |dx_l|^2, nonfinite_l, g_l . delta_l, 0, 0, 0 | max|delta_l| of rank r in slot 8 + r (a maximum through the SUM exchange)]
+constexpr int NLS_X = 8, NLS_X_RANKS = 64;
 constexpr int BS_SBB = 0, BS_RHS = NBP * NBP, BS_G = BS_RHS + NBP, BS_H = BS_G + NBP, BS_S = BS_H + NBP,
               BS_DB = BS_S + NBP, BS_VB = BS_DB + NBP, BS_COUNT = BS_VB + NBP;   // VB: dogleg v_b = s^2 g / D^2
 

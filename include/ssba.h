@@ -325,8 +325,9 @@ SSBA_API int ssba_armijo_trace(const double *values, const double *gradients, in
  * g_l (L*6), H_ll (L*36), delta_l (L*6, local coordinates).  ssba_set_huber_loss keeps its meaning
  * (the loss sits on the stereo residual blocks; lighting blocks take a NULL loss, :113,186).  Lighting
  * terms shard by landmarks like the stereo terms (ssba_set_distributed); with FREE shared blocks the
- * border sums are exchanged in the all-reduce mode only -- the partitioned reduced solve, bounds and
- * DOGLEG with free shared blocks on more than one rank return SSBA_ERR_UNSUPPORTED. */
+ * border sums are exchanged in the all-reduce mode only (DOGLEG and bounds included: the projected line
+ * search adds its sums over the ranks at every evaluation and is driven by the host in lockstep) -- the
+ * partitioned reduced solve with free shared blocks returns SSBA_ERR_UNSUPPORTED. */
 #define SSBA_MAX_MATERIALS 15
 enum { SSBA_BLOCK_LIGHT = 0, SSBA_BLOCK_PHONG = 1, SSBA_BLOCK_TEXTURE = 2 };
 SSBA_API int ssba_add_normal_blocks(ssba_problem *p, double *normals, uint32_t num);

@@ -29,8 +29,10 @@ def main():
     lighting = None
     shared_free = 0
     pose_factors = None
-    if mode.endswith("_phong") or mode.endswith("_phongfree"):     # BASELINE.json configs[2] sharded: lighting terms of a landmark live on its rank
-        shared_free = 7 if mode.endswith("free") else 0
+    use_bounds = False
+    if mode.endswith("_phong") or mode.endswith("_phongfree") or mode.endswith("_phongfreeb"):     # BASELINE.json configs[2] sharded: lighting terms of a landmark live on its rank
+        use_bounds = mode.endswith("b")        # tests/dataset_ba_phong.cpp:142-180: bounds on the Phong and texture blocks -> projected line search
+        shared_free = 7 if (mode.endswith("free") or use_bounds) else 0
         mode = mode[:mode.rindex("_")]
         prob, ph = synth.make_phong_problem(P, Lm, track_len=T, seed=21)
         # shared light / Phong / texture blocks constant, or free (their border sums ride next to the reduced system)
@@ -75,7 +77,7 @@ def main():
                       intensity=lighting["intensity"][sel], normal_obs=lighting["normal_obs"][sel])
         ba = StereoBA(prob.camera, shard.poses, shard.points, shard.obs_pose, shard.obs_point, shard.obs_uvd,
                       prob.stiffness(), device=0, world_size=world, rank=rank, partition=partition, huber_a=huber_a, lighting=lt,
-                      shared_free=shared_free, pose_factors=pose_factors,
+                      shared_free=shared_free, use_bounds=use_bounds, pose_factors=pose_factors,
                       pose_const=np.zeros(prob.num_poses, dtype=np.uint8) if pose_factors else None)
         sharding.attach_torch_exchange(ba, dist)
         okw = dict(max_num_iterations=int(os.environ.get("SSBA_TEST_MAXIT", "1000")), use_nonmonotonic_steps=1)
@@ -87,6 +89,8 @@ def main():
                    poses=ba.poses.tolist(), points=ba.points.tolist(), point_ids=shard.point_ids.tolist(),
                    partition=None if partition is None else partition.tolist(), accept=log["step_is_successful"].tolist(),
                    gmax=log["gradient_max_norm"].tolist(), step_norm=log["step_norm"].tolist())
+        if use_bounds:
+            res["line_search_steps"] = int(s.num_line_search_steps)
         if lt is not None:
             res["normals"] = ba.normals.tolist()
             res["light"] = np.asarray(ba.light).tolist()

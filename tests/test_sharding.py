@@ -354,6 +354,42 @@ def test_sharded_lighting_terms_with_free_shared_blocks(tmp_path):
     assert res[0]["poses"] == res[1]["poses"] and res[0]["light"] == res[1]["light"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dogleg", [(2, 1), (3, None)])
+def test_sharded_lighting_driver_configuration_with_bounds(tmp_path, world, dogleg):
+    """The BA driver's own problem on more than one rank (tests/dataset_ba_phong.cpp:84-87,142-180): free light / Phong / texture
+    blocks, bounds on the Phong and texture blocks -- so every iteration ends in Ceres' projected Armijo line search -- and
+    SUBSPACE_DOGLEG.  With landmark sharding the search's sums (phi, phi', |dx|^2 over the landmarks' rows; max|delta| through
+    one slot per rank) are added over the ranks at every evaluation; the full step is tested on the device, a rejected one is
+    searched by the host in lockstep on all ranks.  Same iterates and the same number of line-search evaluations as the
+    unsharded oracle, ranks bit-identical."""
+    size, K = (60, 2400, 12), 20
+    env = {"SSBA_TEST_MAXIT": str(K)}
+    okw = dict(num_threads=2, max_num_iterations=K)
+    if dogleg is not None:
+        env["SSBA_TEST_DOGLEG"] = str(dogleg)
+        okw.update(trust_region_strategy_type=1, dogleg_type=dogleg)
+    res = _run_ranks("gpu_phongfreeb", str(tmp_path / "phb"), world, size=size, extra_env=env)
+    prob, ph = synth.make_phong_problem(size[0], size[1], track_len=size[2], seed=21)
+    op = orc.OracleProblem(prob.camera, prob.poses_init, prob.points_init, prob.obs_pose, prob.obs_point, prob.obs_uvd,
+                           prob.stiffness(), lighting=ph.as_oracle_dict("perturbed"), shared_free=7, use_bounds=True)
+    s2, log2 = op.solve(orc.driver_options(**okw))
+    assert s2.num_line_search_steps > s2.num_iterations        # (some full steps were rejected: the search itself ran)
+    for r in res:
+        assert r["num_iterations"] == s2.num_iterations
+        assert r["accept"] == log2["step_is_successful"].tolist()
+        assert r["line_search_steps"] == s2.num_line_search_steps
+        ok = np.asarray(log2["step_is_successful"], dtype=bool)
+        ok[0] = True
+        np.testing.assert_allclose(np.asarray(r["cost"])[ok], log2["cost"][ok], rtol=1e-6)
+        assert r["final_cost"] == pytest.approx(s2.final_cost, rel=1e-6)
+        assert np.abs(np.asarray(r["poses"]) - op.poses).max() < 1e-6
+        np.testing.assert_allclose(r["phong"], op.phong, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(r["texture"], op.texture, rtol=1e-6)
+    for r in res[1:]:
+        assert res[0]["poses"] == r["poses"] and res[0]["phong"] == r["phong"]
+
+
 def _bench(args, env_extra, timeout=900):
     import json
     import subprocess
