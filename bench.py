@@ -630,6 +630,10 @@ def cpu_baseline(prob, iters, gpu_final_cost, lighting=None, args=None, huber_a=
             return {"value": m / el, "unit": "iters/s", "cores": threads, "ms_per_iter": 1e3 * el / m, "iterations": m}
         variants["jet_autodiff_jacobians"] = sample(cores, True)
         variants["closed_form_8_threads"] = sample(min(8, cores), False)
+        # SURVEY.md 8(d) "all host cores": `cores` is the CPU share of a one-GPU box (16); the host shows more (usable_cpus) -- a
+        # bounded sample with 64 threads says what they add to this solve (memory-bound sweeps, a serial band Cholesky)
+        if host["usable_cpus"] > cores:
+            variants["closed_form_%d_threads" % min(host["usable_cpus"], 64)] = sample(min(host["usable_cpus"], 64), False, cap=8)
     return {"value": n / dt, "unit": "iters/s", "cores": cores, "kind": "port", "host": host, "variants": variants,
             "sample": f"{n} trust-region iterations (termination {int(s.termination_type)}) of the same "
                       f"{prob.num_obs}-observation solve: CPU restatement with Ceres-equivalent semantics, NOT Ceres "

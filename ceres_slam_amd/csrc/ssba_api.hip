@@ -2264,6 +2264,8 @@ int ssba_pose_covariance(ssba_problem *p, uint32_t pose, double cov[36]) {
         int rc = refinalize_without_wide(p, "covariance");
         if (rc) return rc;
     }
+    // (lighting terms: the 3-wide local parameterisation of a unit normal has rank 2 -- UnitVectorPerturbation, perturbations.hpp:98-102 --
+    // so the UNDAMPED landmark blocks this sweep needs are singular; the oracle's reduced system at radius 1e300 fails the same way)
     if (p->d.part || p->d.phong) {
         set_error("covariance: not available on partitioned problems or with lighting terms");
         return SSBA_ERR_UNSUPPORTED;
