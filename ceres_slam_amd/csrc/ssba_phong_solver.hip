@@ -1234,9 +1234,9 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_gn(Dev 
         const PhSlots<DN> sl(d, l, mask);
         LmIn x;
         load_lm(d, l, x);
-        double gl[6], tt[6];
+        double gl[6], tt[6], tv[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) { gl[c] = d.gl[(size_t)c * d.Lpad + l]; tt[c] = gl[c]; }
+        for (int c = 0; c < 6; ++c) { gl[c] = d.gl[(size_t)c * d.Lpad + l]; tt[c] = gl[c]; tv[c] = 0.0; }
         double gbq[NBQ], vbq[NBQ];   // border Gauss-Newton step and v seen by this landmark's material
 #pragma unroll
         for (int q = 0; q < NBQ; ++q) {
@@ -1244,31 +1244,52 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_gn(Dev 
             gbq[q] = c >= 0 ? d.bsys[BS_DB + c] : 0.0;
             vbq[q] = c >= 0 ? d.bsys[BS_VB + c] : 0.0;
         }
+        // ONE pass over the landmark's rows (r04: a second one formed J v and J gn row by row).  With e_g = J_p gn_p + J_b gn_b and
+        // e_v = J_p v_p + J_b v_b of a row,  J gn = J_l dl + e_g  and  J v = J_l vl + e_v,  so over the landmark's rows
+        //   |J gn|^2 = dl^T H_ll dl + 2 dl . sum J_l^T e_g + sum e_g^2     (H_ll = sum J_l^T J_l: the linearisation's block,
+        //   |J v|^2  = vl^T H_ll vl + 2 vl . sum J_l^T e_v + sum e_v^2      rows of constant poses included)
+        //   Jv . Jgn = vl^T H_ll dl + vl . sum J_l^T e_g + dl . sum J_l^T e_v + sum e_v e_g
+        // and  sum J_l^T e_g = tt - g_l  is what the back-substitution forms anyway (the scheme of k_ph_backsub_eval's model cost).
+        double see = 0.0, svv = 0.0, sev = 0.0;
         for (int s = 0; s < sl.count(); ++s) {
             if (!sl.has(s)) continue;
             const uint32_t k = sl.pose(d, s);
             const int f = d.pose_free[k];
-            if (f < 0) continue;
+            if (f < 0 && !d.nb) continue;       // (a constant pose's intensity row still has e = J_b . border step with free shared blocks)
             const size_t oi = sl.at(s);
             const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            double dp[6];
+            double dp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, vp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            if (f >= 0) {
 #pragma unroll
-            for (int c = 0; c < 6; ++c) dp[c] = d.x0[(size_t)f * 6 + c];
-            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, true,
-                    [&](auto part, int, double, const double *jp, const double *jl, const double *) {
+                for (int c = 0; c < 6; ++c) { dp[c] = d.x0[(size_t)f * 6 + c]; vp[c] = d.vp[(size_t)k * 6 + c]; }
+            }
+            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0,
+                    [&](auto part, int, double, const double *jp, const double *jl, const double *jb) {
                         constexpr int P = decltype(part)::value;
-                        double jd = 0.0;
+                        double jd = 0.0, jv = 0.0;
+                        if (f >= 0) {
 #pragma unroll
-                        for (int c = 0; c < 6; ++c) jd += jp[c] * dp[c];
+                            for (int c = 0; c < 6; ++c) { jd += jp[c] * dp[c]; jv += jp[c] * vp[c]; }
 #pragma unroll
-                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) tt[c] += jl[c] * jd;
+                            for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) { tt[c] += jl[c] * jd; tv[c] += jl[c] * jv; }
+                        }
+                        double eg = jd, ev = jv;      // (the border part of sum J_l^T e comes from V_j below, as before)
+                        if (P == 1) {
+#pragma unroll
+                            for (int q = 0; q < NBQ; ++q) { eg += jb[q] * gbq[q]; ev += jb[q] * vbq[q]; }
+                        }
+                        see += eg * eg; svv += ev * ev; sev += ev * eg;
                     });
         }
         if (d.nb) {
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int q = 0; q < NBQ; ++q) tt[a] += d.lmV[(size_t)(a * NBQ + q) * d.Lpad + l] * gbq[q];
+                for (int q = 0; q < NBQ; ++q) {
+                    const double V = d.lmV[(size_t)(a * NBQ + q) * d.Lpad + l];
+                    tt[a] += V * gbq[q];
+                    tv[a] += V * vbq[q];
+                }
         }
         double Ci[21];
 #pragma unroll
@@ -1280,43 +1301,40 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_dogleg_gn(Dev 
             for (int q = 0; q < 6; ++q) v += Ci[q <= a ? tri6(q, a) : tri6(a, q)] * tt[q];
             dl[a] = -v;
         }
+        double H[21];
+#pragma unroll
+        for (int c = 0; c < 21; ++c) H[c] = d.hll[(size_t)c * d.Lpad + l];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const double s = d.sl[(size_t)c * d.Lpad + l], s2 = s * s;
-            const double D2 = fmin(fmax(d.hll[(size_t)tri6(c, c) * d.Lpad + l] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
+            const double D2 = fmin(fmax(H[tri6(c, c)] * s2, st.opt.min_lm_diag), st.opt.max_lm_diag);
             vl[c] = s2 * gl[c] / D2;
             sums[0] += s2 * gl[c] * gl[c] / D2;
             sums[1] += D2 * dl[c] * dl[c] / s2;
             sums[2] += gl[c] * dl[c];
         }
-        for (int s = 0; s < sl.count(); ++s) {
-            if (!sl.has(s)) continue;
-            const uint32_t k = sl.pose(d, s);
-            const int f = d.pose_free[k];
-            const size_t oi = sl.at(s);
-            const double nobs[3] = {d.onx[oi], d.ony[oi], d.onz[oi]};
-            double vp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, gp[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            if (f >= 0) {
+        double Hd[6], Hv[6];
 #pragma unroll
-                for (int c = 0; c < 6; ++c) { vp[c] = d.vp[(size_t)k * 6 + c]; gp[c] = d.x0[(size_t)f * 6 + c]; }
+        for (int a = 0; a < 6; ++a) {
+            double hd = 0.0, hv = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const double h = H[q <= a ? tri6(q, a) : tri6(a, q)];
+                hd += h * dl[q];
+                hv += h * vl[q];
             }
-            ph_rows(d, d.sh, d.poses + (size_t)k * 12, x, d.ou[oi], d.ov[oi], d.od[oi], d.oi[oi], nobs, f >= 0,
-                    [&](auto part, int, double, const double *jp, const double *jl, const double *jb) {
-                        constexpr int P = decltype(part)::value;
-                        double jv = 0.0, jg = 0.0;
-#pragma unroll
-                        for (int c = ph_jl_lo(P); c < ph_jl_hi(P); ++c) { jv += jl[c] * vl[c]; jg += jl[c] * dl[c]; }
-                        if (f >= 0) {
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) { jv += jp[c] * vp[c]; jg += jp[c] * gp[c]; }
-                        }
-                        if (P == 1) {
-#pragma unroll
-                            for (int q = 0; q < NBQ; ++q) { jv += jb[q] * vbq[q]; jg += jb[q] * gbq[q]; }
-                        }
-                        sums[3] += jv * jv; sums[4] += jg * jg; sums[5] += jv * jg;
-                    });
+            Hd[a] = hd; Hv[a] = hv;
         }
+        double vHv = 0.0, dHd = 0.0, vHd = 0.0, vtv = 0.0, dtg = 0.0, vtg = 0.0, dtv = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double tg = tt[c] - gl[c];
+            vHv += vl[c] * Hv[c]; dHd += dl[c] * Hd[c]; vHd += vl[c] * Hd[c];
+            vtv += vl[c] * tv[c]; dtg += dl[c] * tg; vtg += vl[c] * tg; dtv += dl[c] * tv[c];
+        }
+        sums[3] = vHv + 2.0 * vtv + svv;
+        sums[4] = dHd + 2.0 * dtg + see;
+        sums[5] = vHd + vtg + dtv + sev;
     }
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
