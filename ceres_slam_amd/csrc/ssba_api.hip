@@ -1420,6 +1420,12 @@ static int enqueue_front(ssba_problem *p);
 // bounds on one GPU: k_ph_ls_fast forms the sums of the evaluation kernel's partials (no exchange sits between them)
 static bool ls_reduces_eval(const ssba_problem *p) { return p->d.constrained && !p->xfn; }
 static double *ls_x(const Dev &d) { return d.ls_out + NLS_OUT + NLS_MACH; }
+// single GPU, where neither the update / evaluation kernels nor the linearisation carry k_best's copy (bounds, free shared blocks,
+// dogleg, lighting terms on the general layout): the commit launch of the same iteration does it
+static bool best_in_commit(const ssba_problem *p) {
+    const bool fuse_best = !p->d.constrained && !p->d.nb && p->opt.trust_region_strategy_type != 1;
+    return !p->xfn && !p->d.part && !(fuse_best && launch_best_fusable(p->d));
+}
 // bounds with landmark sharding: the host looks at the state after EVERY iteration -- an iteration enqueued behind a parked one
 // would run its exchanges over buffers whose kernels did nothing and sum the linearisation of a rejected step a second time
 static bool lockstep(const ssba_problem *p) { return p->d.constrained && p->xfn; }
@@ -1467,7 +1473,7 @@ static int enqueue_kernels(ssba_problem *p) {
         if (p->xfn(p->xctx, ls_x(p->d), (uint64_t)(NLS_X + p->world_size), 0)) { set_error("exchange callback failed"); return SSBA_ERR_STATE; }
         launch_ph_ls_fast(p->launcher, p->d, false, p->world_size);
     } else if (p->d.constrained) launch_ph_ls_fast(p->launcher, p->d, ls_reduces_eval(p));
-    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p), fuse_upd ? p->d.pcr.n : -1); }))) return rc;
+    if ((rc = run_segment(p, p->xfn ? 2 : -1, [&] { launch_decide_commit(p->launcher, p->d, fuse, fuse_all_launches(p), fuse_upd ? p->d.pcr.n : -1, best_in_commit(p)); }))) return rc;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
@@ -1518,7 +1524,7 @@ static int finish_pending_search(ssba_problem *p) {
         if (want != at && (rc = probe(want))) return rc;
         if (want != 1.0 || at != 1.0) launch_ph_ls_accept(L, d);
     }
-    launch_decide_commit(L, d);
+    launch_decide_commit(L, d, false, false, -1, best_in_commit(p));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return SSBA_ERR_HIP; }
     return SSBA_OK;
@@ -1566,7 +1572,7 @@ static int enqueue_front(ssba_problem *p) {
     }
     if ((rc = run_segment(p, multi ? 1 : -1, [&] {
             if (p->xfn && d.nb) launch_border_scale(L, d);      // Jacobi scale of the border from the SUMMED diagonal
-            launch_finish_check(L, d, fuse_ctrl, fuse_best, check_in_schur);
+            launch_finish_check(L, d, fuse_ctrl, fuse_best, check_in_schur, best_in_commit(p));
             const bool fuse_upd = fuse_all && !d.dense && bcr_updates_poses(d);     // the last step of the reduced solve updates the poses
             if (d.dense) launch_dense_solve(L, d);      // incl. the rows of the free shared blocks
             else { launch_bcr(L, d, true, fuse_upd); if (d.nb) launch_border_solve(L, d); }

@@ -1758,10 +1758,25 @@ __global__ __launch_bounds__(256) void k_reduce_eval(Dev d, int n_parts, int add
     }
 }
 
-__global__ __launch_bounds__(256) void k_commit(Dev d) {
+// with_best: the launch also does k_best's copy (x -> best when the k_check of THIS iteration saw the cost improve) in front of
+// its own -- nothing reads the best iterate or moves x between the two places, and like k_best that part does not test
+// `terminated` (the improving iterate may be the converged one).  Where neither the update / evaluation kernels (fuse_best) nor
+// the linearisation (fuse_all) carry the copies -- bounds, free shared blocks, dogleg -- this saves the k_best launch.
+__global__ __launch_bounds__(256) void k_commit(Dev d, int with_best) {
     const State &st = *d.st;
-    if (st.terminated || !st.accepted) return;
+    const bool best = with_best && st.copy_best == st.check_count;
+    const bool commit = !st.terminated && st.accepted;
+    if (!best && !commit) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (best) {
+        if (i < (size_t)d.P * 12) d.best_poses[i] = d.poses[i];
+        if (i < (size_t)d.Lpad * 3) {
+            d.best_pts[i] = d.pts[i];
+            if (d.phong) d.best_nrm[i] = d.nrm[i];
+        }
+        if (d.phong && i < (size_t)d.nsh) d.best_sh[i] = d.sh[i];
+    }
+    if (!commit) return;
     if (i < (size_t)d.P * 12) d.poses[i] = d.cand_poses[i];
     if (i < (size_t)d.Lpad * 3) {
         d.pts[i] = d.cand_pts[i];
@@ -2011,13 +2026,14 @@ void launch_finish_local(Launcher &L, const Dev &d) {
 
 // fuse_ctrl: one launch instead of k_finish_reduced + k_check (+ the k_reduce_lin skipped by launch_linearize);
 // fuse_best: k_best's copy is done by the update / evaluation kernels of launch_update_eval(.., fuse_best)
-void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_best, bool check_in_schur) {
+bool launch_best_fusable(const Dev &d) { return best_fusable(d); }
+void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_best, bool check_in_schur, bool best_in_commit) {
     fuse_ctrl = fuse_ctrl && ctrl_fusable(d);
     check_in_schur = check_in_schur && fuse_ctrl && (d.phong || lm_split(d));
     if (d.dense) launch_dense_finish(L, d, fuse_ctrl);
     else if (!fuse_ctrl) LAUNCH(KC_SMALL, k_finish_reduced, dim3((d.nf_pad * 6 + 255) / 256), dim3(256), 0, d);
     if (!check_in_schur) LAUNCH(KC_SMALL, k_check, dim3(1), dim3(1024), 0, d, fuse_ctrl ? lm_parts(d) : 0);
-    if (fuse_best && best_fusable(d)) return;
+    if ((fuse_best && best_fusable(d)) || best_in_commit) return;
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
     LAUNCH(KC_COPY, k_best, dim3((unsigned)std::min<size_t>((n + 255) / 256, 512)), dim3(256), 0, d);
 }
@@ -2077,12 +2093,12 @@ void launch_dogleg_eval(Launcher &L, const Dev &d, int stage, int own_poses, boo
     if (!reduce_later) LAUNCH(KC_SMALL, k_reduce_eval, dim3(1), dim3(256), 0, d, d.n_lm_blocks, 0);
 }
 
-void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all, int n_pose_parts) {
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce, bool fuse_all, int n_pose_parts, bool with_best) {
     LAUNCH(KC_SMALL, k_decide, dim3(1), dim3(256), 0, d, fuse_reduce ? lm_parts(d) : 0,
            n_pose_parts >= 0 ? n_pose_parts : d.n_pose_blocks);
     if (fuse_all) return;       // the next linearisation commits (launch_linearize)
     const size_t n = (size_t)d.P * 12 > (size_t)d.Lpad * 3 ? (size_t)d.P * 12 : (size_t)d.Lpad * 3;
-    LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d);
+    LAUNCH(KC_COPY, k_commit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d, with_best ? 1 : 0);
 }
 
 }  // namespace ssba

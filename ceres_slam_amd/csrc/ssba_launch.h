@@ -110,7 +110,8 @@ void launch_reset(Launcher &L, const Dev &d, const Options &o);
 bool launch_can_fuse_all(const Dev &d);
 void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_all = false, bool skip_reduce = false);    // fuse_ctrl / fuse_best / fuse_all: see ssba_kernels.hip (k_check, launch_linearize)
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool check_in_schur = false);
-void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false, bool check_in_schur = false);
+bool launch_best_fusable(const Dev &d);
+void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false, bool check_in_schur = false, bool best_in_commit = false);     // best_in_commit: launch_decide_commit(.., with_best) of the same iteration does k_best's copy
 bool bcr_border_rides(const Dev &d);      // the border columns go through the forward part of the solve inside the factor / reduce launches
 // fuse_update: the last step of the plan also updates the poses (bcr_updates_poses(d) must hold)
 bool bcr_updates_poses(const Dev &d);
@@ -126,7 +127,7 @@ void launch_mask_unowned_poses(Launcher &L, const Dev &d, double *poses);
 int eval_parts(const Dev &d);      // partial sums the evaluation kernel of this layout leaves
 void launch_update_eval(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_best = false, bool pose_update_done = false);
 void launch_dogleg_eval(Launcher &L, const Dev &d, int stage = 0, int own_poses = 1, bool reduce_later = false);     // reduce_later: launch_ph_ls_fast forms the evaluation sums;      // stage: see ssba_kernels.hip (landmark sharding: one more exchange point)
-void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false, int n_pose_parts = -1);
+void launch_decide_commit(Launcher &L, const Dev &d, bool fuse_reduce = false, bool fuse_all = false, int n_pose_parts = -1, bool with_best = false);
 // config 3 (ssba_phong_solver.hip)
 int upload_phong_tables(hipStream_t s);
 int configure_phong();
