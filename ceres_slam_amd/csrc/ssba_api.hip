@@ -45,6 +45,7 @@ static void set_error(const std::string &s) { g_last_error = s; }
         }                                                                                \
     } while (0)
 
+constexpr int LS_ROUNDS_FIRST = 2, LS_ROUNDS_MOST = 4;      // device-side evaluations of the projected line search per iteration (ssba_solve_begin)
 struct ssba_problem {
     ssba_camera cam{};
     int device = 0;
@@ -80,6 +81,7 @@ struct ssba_problem {
     std::vector<RelFactor> rel_factors;
     double *h_ls = nullptr;                // pinned: line-search scalars + state
     int num_line_search_steps = 0, num_line_searches_by_host = 0;      // evaluations / searches driven by the host (the device counts its own in the state)
+    int ls_rounds_wanted = LS_ROUNDS_FIRST;    // search evaluations enqueued with every iteration: grows when a search ran out of them (finish_pending_search)
     std::vector<double> ph_intensity, ph_nobs;
     double ph_int_stiff = 0.0, ph_Sn[9] = {0};
     bool lighting() const { return !ph_intensity.empty(); }
@@ -1521,6 +1523,11 @@ static int finish_pending_search(ssba_problem *p) {
             ++p->num_line_search_steps;
         }
         const double want = a.success ? a.optimal_step : 1.0;    // a failed search leaves delta alone
+        // the device-side rounds ran out on a search that does finish: enqueue as many as it took from now on
+        if (a.success && !p->xfn && !getenv("SSBA_LS_ROUNDS") && a.num_feeds > d.ls_rounds && d.ls_rounds < LS_ROUNDS_MOST) {
+            p->ls_rounds_wanted = d.ls_rounds = std::min(a.num_feeds, LS_ROUNDS_MOST);
+            drop_graph(p);
+        }
         if (want != at && (rc = probe(want))) return rc;
         if (want != 1.0 || at != 1.0) launch_ph_ls_accept(L, d);
     }
@@ -1692,7 +1699,10 @@ int ssba_solve_begin(ssba_problem *p, const ssba_options *o, int ignore_converge
     if (p->d.constrained) {
         // bounds: evaluations of the projected line search enqueued with every iteration (device-side search); a search
         // that needs more is finished by the host.  SSBA_LS_ROUNDS in the environment of a solve (0: host only -- A/B, tests)
-        int rounds = 3;
+        // LS_ROUNDS_FIRST evaluations to begin with (a round that is not needed still costs its three launches: ~9 us per
+        // iteration at C3); a handle whose search once needed more is given what that search took (up to LS_ROUNDS_MOST) from
+        // then on -- one search finished by the host is the price of finding out
+        int rounds = p->ls_rounds_wanted;
         if (const char *e = getenv("SSBA_LS_ROUNDS")) rounds = std::min(20, std::max(0, atoi(e)));
         if (p->xfn) rounds = 0;     // landmark sharding: every evaluation has an exchange in it, the host drives the search (finish_pending_search)
         if (rounds != p->d.ls_rounds) { p->d.ls_rounds = rounds; drop_graph(p); }

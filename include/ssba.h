@@ -318,7 +318,8 @@ SSBA_API int ssba_armijo_trace(const double *values, const double *gradients, in
  *                             does: Plus projects onto the box and every trust-region step goes through
  *                             a projected Armijo line search.  The search runs on the device inside the
  *                             iteration's hipGraph: the test of the full step, then up to SSBA_LS_ROUNDS
- *                             (environment, default 3) further evaluations; a search that needs more parks the
+ *                             (environment; unset: two, and as many as a search took -- at most four -- once
+ *                             one has run out of them) further evaluations; a search that needs more parks the
  *                             solver until the host -- inside ssba_solve / ssba_solve_step / ssba_solve_end --
  *                             has run it (same state machine, same bits: csrc/ssba_linesearch.h).
  * With lighting observations present ssba_evaluate / ssba_lm_step return 6-wide landmark blocks:

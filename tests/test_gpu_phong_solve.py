@@ -205,15 +205,19 @@ def test_bounded_solve_matches_oracle(light_type, init, strategy):
 @pytest.mark.parametrize("strategy", [(0, 0), (1, 1)])
 def test_line_search_on_the_device_is_the_search_the_host_drives(strategy, monkeypatch):
     """The Armijo state machine (csrc/ssba_linesearch.h) runs in k_ph_ls_reduce for the evaluations enqueued with every
-    iteration (SSBA_LS_ROUNDS, default 3); SSBA_LS_ROUNDS=0 leaves every search to the host (the r02 path), 1 makes the
+    iteration (SSBA_LS_ROUNDS; unset: two, and as many as a search took once one ran out of them -- at most four);
+    SSBA_LS_ROUNDS=0 leaves every search to the host (the r02 path), 1 makes the
     hand-over of a search that needs more evaluations than were enqueued the common case.  Same code, same evaluations:
     the solves must agree bit for bit, and the evaluation count must be the oracle's (Summary::num_line_search_steps)."""
     prob, ph = synth.make_phong_problem(50, 2000)
     d = ph.as_oracle_dict("reference")
     kw = dict(max_num_iterations=25, use_nonmonotonic_steps=1, trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
     runs = {}
-    for rounds in ("3", "0", "1", "20"):
-        monkeypatch.setenv("SSBA_LS_ROUNDS", rounds)
+    for rounds in ("3", "0", "1", "20", "unset"):
+        if rounds == "unset":
+            monkeypatch.delenv("SSBA_LS_ROUNDS")
+        else:
+            monkeypatch.setenv("SSBA_LS_ROUNDS", rounds)
         ba = StereoBA.from_synth(prob, lighting=d, shared_free=7, use_bounds=True)
         s, log = ba.solve(capi.default_options(**kw))
         runs[rounds] = (s, log, ba.poses.copy(), ba.texture.copy())
@@ -221,7 +225,7 @@ def test_line_search_on_the_device_is_the_search_the_host_drives(strategy, monke
     assert s3.num_line_searches_on_device > 0 and runs["0"][0].num_line_searches_on_device == 0
     assert runs["0"][0].num_line_searches_by_host == s3.num_line_searches_on_device + s3.num_line_searches_by_host
     assert runs["1"][0].num_line_searches_by_host > 0 and runs["20"][0].num_line_searches_by_host == 0
-    for rounds in ("0", "1", "20"):
+    for rounds in ("0", "1", "20", "unset"):
         s, log, poses, tex = runs[rounds]
         assert s.num_iterations == s3.num_iterations and s.num_line_search_steps == s3.num_line_search_steps
         assert log["step_is_successful"].tolist() == log3["step_is_successful"].tolist()
