@@ -116,7 +116,7 @@ typedef struct {
     double total_time_s;             /* wall time of ssba_solve incl. write-back       */
     double device_time_s;            /* GPU time of the iteration loop (HIP events)    */
     /* bounds [Solver::Summary::num_line_search_steps]: evaluations of the projected line search, and how many searches
-     * ran entirely on the device / were finished by the host (SSBA_LS_ROUNDS, default 3 evaluations enqueued per iteration) */
+     * ran entirely on the device / were finished by the host (SSBA_LS_ROUNDS; unset: 2 evaluations enqueued per iteration, up to 4 once a search needed more) */
     int32_t num_line_search_steps;
     int32_t num_line_searches_on_device;
     int32_t num_line_searches_by_host;
