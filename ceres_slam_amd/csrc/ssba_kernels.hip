@@ -1408,7 +1408,11 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
         const LmObs<DN> ob(d, l, mask);
         const double px = d.pts[l], py = d.pts[(size_t)d.Lpad + l], pz = d.pts[2 * (size_t)d.Lpad + l];
         const double gl[3] = {d.gl[l], d.gl[(size_t)d.Lpad + l], d.gl[2 * (size_t)d.Lpad + l]};
-        double tt[3] = {gl[0], gl[1], gl[2]};
+        double tt[3] = {gl[0], gl[1], gl[2]}, tv[3] = {0.0, 0.0, 0.0};
+        // ONE pass over the landmark's rows (r04: a second one formed J v and J gn row by row): with e_g = J_p gn_p and e_v = J_p v_p
+        // of an observation,  |J gn|^2 = dl^T H_ll dl + 2 dl . sum J_l^T e_g + sum |e_g|^2  (H_ll = sum J_l^T J_l, the rows of constant
+        // poses included: their e is 0; sum J_l^T e_g = tt - g_l), |J v|^2 and Jv . Jgn alike -- see k_ph_dogleg_gn
+        double see = 0.0, svv = 0.0, sev = 0.0;
         for (int s = 0; s < ob.count(); ++s) {
             if (!ob.has(s)) continue;
             const uint32_t k = ob.pose(d, s);
@@ -1419,22 +1423,29 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
             double Sk[9];
             ob.stiffness(d, s, Sk);
             obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
-            double Jp[18], Jl[9], jd[3];
+            double Jp[18], Jl[9], jd[3], jv[3];
             jac_pose(o, Jp);
             jac_point(o, T, Jl);
-            const double *dp = d.x0 + (size_t)f * 6;
+            const double *dp = d.x0 + (size_t)f * 6, *vp = d.vp + (size_t)k * 6;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                jd[i] = 0.0;
+                jd[i] = 0.0; jv[i] = 0.0;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) jd[i] += Jp[6 * i + c] * dp[c];
+                for (int c = 0; c < 6; ++c) { jd[i] += Jp[6 * i + c] * dp[c]; jv[i] += Jp[6 * i + c] * vp[c]; }
             }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) tt[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+            for (int c = 0; c < 3; ++c) {
+                tt[c] += Jl[c] * jd[0] + Jl[3 + c] * jd[1] + Jl[6 + c] * jd[2];
+                tv[c] += Jl[c] * jv[0] + Jl[3 + c] * jv[1] + Jl[6 + c] * jv[2];
+            }
+            see += jd[0] * jd[0] + jd[1] * jd[1] + jd[2] * jd[2];
+            svv += jv[0] * jv[0] + jv[1] * jv[1] + jv[2] * jv[2];
+            sev += jv[0] * jd[0] + jv[1] * jd[1] + jv[2] * jd[2];
         }
         double h[6], dmp[3], Ci[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) h[c] = d.hll[(size_t)c * d.Lpad + l];
+        const double H[6] = {h[0], h[1], h[2], h[3], h[4], h[5]};       // (undamped: inv3_spd may work on h in place)
         landmark_damping(d, st, l, h, dmp);
         if (inv3_spd(h, dmp, Ci)) {
             dl[0] = -(Ci[0] * tt[0] + Ci[1] * tt[1] + Ci[2] * tt[2]);
@@ -1443,7 +1454,7 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
         } else {
             d.st->step_failed = 1;
         }
-        const double hd[3] = {h[0], h[3], h[5]};
+        const double hd[3] = {H[0], H[3], H[5]};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double s = d.sl[(size_t)c * d.Lpad + l], s2 = s * s;
@@ -1453,35 +1464,19 @@ template <bool DN> __global__ __launch_bounds__(256) void k_dogleg_gn(Dev d) {
             nsq += D2 * dl[c] * dl[c] / s2;
             dot += gl[c] * dl[c];
         }
-        for (int s = 0; s < ob.count(); ++s) {   // |J v|^2, |J delta_gn|^2, (J v).(J delta_gn)
-            if (!ob.has(s)) continue;
-            const uint32_t k = ob.pose(d, s);
-            const int f = d.pose_free[k];
-            const double *T = d.poses + (size_t)k * 12;
-            ObsLin o;
-            double Sk[9];
-            ob.stiffness(d, s, Sk);
-            obs_linearize_S(d, Sk, T, px, py, pz, ob.u(d, s), ob.v(d, s), ob.dd(d, s), o);
-            double Jl[9], jv[3], jg[3];
-            jac_point(o, T, Jl);
+        // upper triangle H = [h0 h1 h2; . h3 h4; . . h5]
+        const double Hd[3] = {H[0] * dl[0] + H[1] * dl[1] + H[2] * dl[2], H[1] * dl[0] + H[3] * dl[1] + H[4] * dl[2], H[2] * dl[0] + H[4] * dl[1] + H[5] * dl[2]};
+        const double Hv[3] = {H[0] * vl[0] + H[1] * vl[1] + H[2] * vl[2], H[1] * vl[0] + H[3] * vl[1] + H[4] * vl[2], H[2] * vl[0] + H[4] * vl[1] + H[5] * vl[2]};
+        double vHv = 0.0, dHd = 0.0, vHd = 0.0, vtv = 0.0, dtg = 0.0, vtg = 0.0, dtv = 0.0;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                jv[i] = Jl[3 * i] * vl[0] + Jl[3 * i + 1] * vl[1] + Jl[3 * i + 2] * vl[2];
-                jg[i] = Jl[3 * i] * dl[0] + Jl[3 * i + 1] * dl[1] + Jl[3 * i + 2] * dl[2];
-            }
-            if (f >= 0) {
-                double Jp[18];
-                jac_pose(o, Jp);
-                const double *vp = d.vp + (size_t)k * 6, *gp = d.x0 + (size_t)f * 6;
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) { jv[i] += Jp[6 * i + c] * vp[c]; jg[i] += Jp[6 * i + c] * gp[c]; }
-            }
-            jv2 += jv[0] * jv[0] + jv[1] * jv[1] + jv[2] * jv[2];
-            jg2 += jg[0] * jg[0] + jg[1] * jg[1] + jg[2] * jg[2];
-            jvg += jv[0] * jg[0] + jv[1] * jg[1] + jv[2] * jg[2];
+        for (int c = 0; c < 3; ++c) {
+            const double tg = tt[c] - gl[c];
+            vHv += vl[c] * Hv[c]; dHd += dl[c] * Hd[c]; vHd += vl[c] * Hd[c];
+            vtv += vl[c] * tv[c]; dtg += dl[c] * tg; vtg += vl[c] * tg; dtv += dl[c] * tv[c];
         }
+        jv2 = vHv + 2.0 * vtv + svv;
+        jg2 = dHd + 2.0 * dtg + see;
+        jvg = vHd + vtg + dtv + sev;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
