@@ -787,6 +787,13 @@ static bool bcr_fused_steps(const Dev &d) {
     const char *e = getenv("SSBA_NO_PCR_FUSED");        // read per call: tests switch it between handles
     return d.pcrf.on && !d.part && !d.pcr.keep && d.nb == 0 && !bcr_legacy() && !(e && e[0] == '1');
 }
+// Border columns riding through the parallel plan: the right-hand side of the decoupled last step is solved as column NBP - 1 (a
+// padding column while nb < NBP) of the border columns' backward sweep -- k_bcrm_bwd does for 32 columns what k_bcr_backsub does for
+// one, lane for lane in the same order -- so k_bcr_backsub's launch (11 us) is not needed.  SSBA_NO_RHS_RIDE=1 keeps it (A/B, tests).
+bool bcr_rhs_rides_in_bwd(const Dev &d) {
+    const char *e = getenv("SSBA_NO_RHS_RIDE");
+    return bcr_border_rides(d) && d.nb < NBP && d.pcr.level >= 0 && d.pcr.keep && !d.pcr.pin0 && !d.pcr.pin1 && !(e && e[0] == '1');
+}
 bool bcr_updates_poses(const Dev &d) { return bcr_fused_solve(d) && d.pcr.level == 0 && d.n_pf == 0; }
 
 void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
@@ -821,7 +828,7 @@ void launch_bcr(Launcher &L, const Dev &d, bool allow_pcr, bool fuse_update) {
         // the decoupled last step solves its blocks itself (matrix-core kernels, no border columns): no k_bcr_backsub launch
         launch_factor(L, d, n, d.pcr.steps, 1, 2, false, ride, solve);
         }
-        if (!fsolve) LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
+        if (!fsolve && !(ride && bcr_rhs_rides_in_bwd(d))) LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(n), dim3(BS_THREADS), sh_backsub, d, k, 1, 2);
         for (int l = k - 1; l >= 0; --l)
             LAUNCH(KC_BCR_BACKSUB, k_bcr_backsub, dim3(d.lev[l].n / 2), dim3(BS_THREADS), sh_backsub, d, l, 0, 0);
         return;

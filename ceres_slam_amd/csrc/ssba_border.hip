@@ -186,7 +186,9 @@ __global__ __launch_bounds__(UPD_THREADS) void k_bcrm_upd(Dev d, int lev, int wh
 
 // odd blocks, top-down: X_i = G^-T (yb_i - YL_i X_{i-1} - YU_i X_{i+1}); X lives in d.Zb at level-0 positions
 // which = 2 (with top): the decoupled blocks of the parallel plan, X = G^-T yB for every block
-__global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top, int which) {
+// ride_r (which = 2): column NBP - 1 -- padding of the border -- carries the right-hand side of the reduced system instead: read
+// from the level's r, solved by the same sweep (k_bcr_backsub's arithmetic, lane for lane), written to x0
+__global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top, int which, int ride_r) {
     const State &st = *d.st;
     if (st.terminated || st.step_failed || st.dl_reuse) return;
     extern __shared__ __align__(16) double lds[];
@@ -205,8 +207,10 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
     const double *B = which == 2 ? d.pcr.yB + (size_t)blk * BD * NBP : L.B + (size_t)blk * BD * NBP;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, c0 = 2 * w, c1 = c0 + 1;
     const bool hiRow = lane < BD - 64;
-    double lo0 = B[lane * NBP + c0], lo1 = B[lane * NBP + c1];
-    double hi0 = hiRow ? B[(64 + lane) * NBP + c0] : 0.0, hi1 = hiRow ? B[(64 + lane) * NBP + c1] : 0.0;
+    const bool rr = ride_r && which == 2 && c1 == NBP - 1;      // (wave-uniform: the last wave's second column)
+    const double *rv = L.r + (size_t)blk * BD;
+    double lo0 = B[lane * NBP + c0], lo1 = rr ? rv[lane] : B[lane * NBP + c1];
+    double hi0 = hiRow ? B[(64 + lane) * NBP + c0] : 0.0, hi1 = hiRow ? (rr ? rv[64 + lane] : B[(64 + lane) * NBP + c1]) : 0.0;
     __syncthreads();
     if (!top) {
         for (int k = 0; k < BD; ++k) {
@@ -246,8 +250,15 @@ __global__ __launch_bounds__(MR_THREADS) void k_bcrm_bwd(Dev d, int lev, int top
     }
     double *X = d.Zb + ((which == 2 ? (size_t)L.pos[blk] : ((size_t)blk << lev)) * BD) * NBP;
     X[lane * NBP + c0] = lo0;
-    X[lane * NBP + c1] = lo1;
-    if (hiRow) { X[(64 + lane) * NBP + c0] = hi0; X[(64 + lane) * NBP + c1] = hi1; }
+    if (hiRow) X[(64 + lane) * NBP + c0] = hi0;
+    if (rr) {
+        double *xi = d.x0 + (size_t)d.chain0 * BD + (size_t)L.pos[blk] * BD;
+        xi[lane] = lo1;
+        if (hiRow) xi[64 + lane] = hi1;
+    } else {
+        X[lane * NBP + c1] = lo1;
+        if (hiRow) X[(64 + lane) * NBP + c1] = hi1;
+    }
 }
 
 // partial sums of S_pb^T [Zb | x0] over a slice of pose rows: thread (a, b) of the NBP x NBP result.  The slice goes
@@ -425,9 +436,9 @@ void launch_bcr_multi_rhs(Launcher &L, const Dev &d) {
         LAUNCH(KC_BORDER, k_bcrm_upd, dim3((n + 1) / 2), dim3(UPD_THREADS), SH_UPD, d, l, 0);
     }
     LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1, 0);
-    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0);
+    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0, 0);
     for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0);
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0, 0);
 }
 
 // after launch_bcr: x0 = S_pp^-1 (-g_p^) and the level factors are in place
@@ -446,7 +457,7 @@ void launch_border_solve(Launcher &L, const Dev &d) {
             }
             LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(n), dim3(MR_THREADS), SH_FWD, d, d.pcr.steps, 1, 2);
         }
-        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(n), dim3(MR_THREADS), SH_BWD, d, 0, 1, 2);
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(n), dim3(MR_THREADS), SH_BWD, d, 0, 1, 2, rode && bcr_rhs_rides_in_bwd(d) ? 1 : 0);
         launch_border_finish(L, d);
         return;
     }
@@ -460,9 +471,9 @@ void launch_border_solve(Launcher &L, const Dev &d) {
         }
         LAUNCH(KC_BORDER, k_bcrm_fwd, dim3(1), dim3(MR_THREADS), SH_FWD, d, nl - 1, 1, 0);
     }
-    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0);
+    LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(1), dim3(MR_THREADS), SH_BWD, d, nl - 1, 1, 0, 0);
     for (int l = nl - 2; l >= 0; --l)
-        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0);
+        LAUNCH(KC_BORDER, k_bcrm_bwd, dim3(d.lev[l].n / 2), dim3(MR_THREADS), SH_BWD, d, l, 0, 0, 0);
     launch_border_finish(L, d);
 }
 

@@ -112,6 +112,7 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fu
 void launch_schur(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool check_in_schur = false);
 bool launch_best_fusable(const Dev &d);
 void launch_finish_check(Launcher &L, const Dev &d, bool fuse_ctrl = false, bool fuse_best = false, bool check_in_schur = false, bool best_in_commit = false);     // best_in_commit: launch_decide_commit(.., with_best) of the same iteration does k_best's copy
+bool bcr_rhs_rides_in_bwd(const Dev &d);      // the decoupled last step's right-hand side is solved by k_bcrm_bwd as one more column (no k_bcr_backsub launch)
 bool bcr_border_rides(const Dev &d);      // the border columns go through the forward part of the solve inside the factor / reduce launches
 // fuse_update: the last step of the plan also updates the poses (bcr_updates_poses(d) must hold)
 bool bcr_updates_poses(const Dev &d);

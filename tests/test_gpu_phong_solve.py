@@ -499,3 +499,23 @@ def test_inversion_beside_the_pose_linearisation_is_the_same_arithmetic(monkeypa
     (s0, l0, p0, x0), (s1, l1, p1, x1) = out
     assert s0.num_iterations == s1.num_iterations
     assert np.array_equal(l0["cost"], l1["cost"]) and np.array_equal(p0, p1) and np.array_equal(x0, x1)
+
+
+@pytest.mark.parametrize("strategy", [(0, 0), (1, 1)])
+def test_right_hand_side_in_the_border_columns_backward_sweep_is_bit_identical(strategy, monkeypatch):
+    """With the border columns riding through the parallel plan, the decoupled last step's right-hand side is solved by
+    k_bcrm_bwd as one more column (the padding column NBP - 1) instead of by a k_bcr_backsub launch of its own: the same sweep,
+    lane for lane in the same order.  SSBA_NO_RHS_RIDE=1 keeps the launch: the two solves must agree bit for bit."""
+    prob, ph = synth.make_phong_problem(50, 2000)
+    d = ph.as_oracle_dict("perturbed")
+    kw = dict(max_num_iterations=15, use_nonmonotonic_steps=1, trust_region_strategy_type=strategy[0], dogleg_type=strategy[1])
+    runs = []
+    for off in ("0", "1"):
+        monkeypatch.setenv("SSBA_NO_RHS_RIDE", off)
+        ba = StereoBA.from_synth(prob, lighting=d, shared_free=7)
+        s, log = ba.solve(capi.default_options(**kw))
+        runs.append((log["cost"].copy(), ba.poses.copy(), ba.texture.copy()))
+        ba.close()
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    np.testing.assert_array_equal(runs[0][2], runs[1][2])
