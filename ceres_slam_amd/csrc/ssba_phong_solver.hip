@@ -1513,6 +1513,38 @@ static __device__ __forceinline__ void ls_stage_border(const Dev &d, const State
         sg[c] = d.bsys[BS_G + c];
     }
 }
+// The pose part of max|delta| and g . delta for a 1024-lane work-group: entry i = 6 f + c of the pose step.  Eight trips' loads in
+// flight at a time, the pose index first and what depends on it behind (the rolled loop paid two dependent round trips per
+// trip: free_pose, then vp -- twelve in a row at C3, most of k_ph_ls_fast's 15 us); every lane still adds its entries in ascending order.
+static __device__ __forceinline__ void ls_pose_terms(const Dev &d, const State &st, double &pmax, double &pgd) {
+    constexpr int Q = 8;
+    const int n = d.nfree * 6;
+    const bool dog = st.opt.strategy != 0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * Q) {
+        int k[Q];
+        double x[Q], g[Q], v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = i0 + 1024 * q;
+            k[q] = (dog && i < n) ? d.free_pose[i / 6] : 0;
+            x[q] = i < n ? d.x0[i] : 0.0;
+            g[q] = i < n ? d.xv[d.off_gp + i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = i0 + 1024 * q, c = i - (i / 6) * 6;
+            v[q] = (dog && i < n) ? d.vp[(size_t)k[q] * 6 + c] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int i = i0 + 1024 * q;
+            if (i >= n) continue;
+            const double dpc = dog ? st.beta * x[q] + st.gamma * v[q] : x[q];
+            pmax = fmax(pmax, fabs(dpc));
+            pgd += g[q] * dpc;
+        }
+    }
+}
 // (1024 lanes: the loops below are chains of cold loads, six trips instead of 24 -- 29 us -> see profiles/README.md)
 // n_eval_parts > 0: the launch forms the evaluation sums first (k_reduce_eval's launch up to r04: the same 256 lanes add the
 // same partials in the same order, the other waves add zeros)
@@ -1543,12 +1575,7 @@ __global__ __launch_bounds__(1024) void k_ph_ls_fast(Dev d, int n_eval_parts, in
             lmax = fmax(lmax, o[4]); lgd += o[5];
         }
     double pmax = 0.0, pgd = 0.0, pbad = 0.0;
-    for (int i = threadIdx.x; i < d.nfree * 6; i += 1024) {
-        const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
-        const double dpc = st.opt.strategy ? st.beta * d.x0[i] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[i];
-        pmax = fmax(pmax, fabs(dpc));
-        pgd += d.xv[d.off_gp + i] * dpc;
-    }
+    ls_pose_terms(d, st, pmax, pgd);
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
     __shared__ double sbv[NBP], sbg[NBP];
     ls_stage_border(d, st, sbv, sbg);
@@ -1622,12 +1649,7 @@ __global__ __launch_bounds__(1024) void k_ph_ls_reduce(Dev d, int ls_round, int 
             acc[0] += o[0]; acc[1] += o[1]; acc[2] += o[2]; acc[3] += o[3]; acc[4] = fmax(acc[4], o[4]); acc[5] += o[5];
         }
     double pmax = 0.0, pgd = 0.0, pbad = 0.0;
-    for (int i = threadIdx.x; i < d.nfree * 6; i += 1024) {
-        const int f = i / 6, c = i - f * 6, k = d.free_pose[f];
-        const double dpc = st.opt.strategy ? st.beta * d.x0[i] + st.gamma * d.vp[(size_t)k * 6 + c] : d.x0[i];
-        pmax = fmax(pmax, fabs(dpc));
-        pgd += d.xv[d.off_gp + i] * dpc;
-    }
+    ls_pose_terms(d, st, pmax, pgd);
     for (int i = threadIdx.x; i < d.n_pose_blocks + (d.nb ? 1 : 0); i += 1024) pbad += d.part_pose[i * NPP + 1];
     __shared__ double sbv[NBP], sbg[NBP];
     ls_stage_border(d, st, sbv, sbg);
