@@ -400,6 +400,29 @@ template <bool DN, int SP> __global__ __launch_bounds__(64 * SP) void k_lineariz
     const bool commit = fuse && st.accepted;
     lin_landmarks_w_body<DN, SP>(d, st, (int)blockIdx.x, commit ? d.cand_poses : d.poses, commit ? d.cand_pts : d.pts, commit);
 }
+// Both linearisation passes of the window layout in ONE launch: the first n_groups work-groups are k_linearize_landmarks_w<false,
+// LMW_SPLIT>'s, the others k_linearize_poses<false, 128, 5>'s -- same block shape, neither reads what the other writes (with the
+// commit folded in both read the candidate buffers and write x).  The second pass's ramp fills the first one's tail: 31.1 -> 28.4 us
+// at C2 (0.3458 -> 0.3431 ms per iteration, same bits).  SSBA_LIN_TWO_LAUNCHES=1 keeps the two launches (A/B, tests).
+__global__ __launch_bounds__(LP_THREADS) void k_linearize_both(Dev d, int fuse, int n_groups) {
+    static_assert(LP_THREADS == 64 * LMW_SPLIT, "one block shape for both passes");
+    const State &st = *d.st;
+    if (st.terminated || !st.need_linearize) return;
+    const bool commit = fuse && st.accepted;
+    const double *PS = commit ? d.cand_poses : d.poses, *PT = commit ? d.cand_pts : d.pts;
+    // (the landmark groups first: with the pose work-groups -- the longer ones -- in front the launch measured 10 us SLOWER at C2)
+    if ((int)blockIdx.x < n_groups) {
+        lin_landmarks_w_body<false, LMW_SPLIT>(d, st, (int)blockIdx.x, PS, PT, commit);
+        return;
+    }
+    const int k = xcd_contiguous_item((int)blockIdx.x - n_groups, d.P);
+    if (k < 0 || d.pose_free[k] < 0) return;
+    if (!fuse) {
+        const bool no_obs = d.pose_obs_start[k] == d.pose_obs_start[k + 1];
+        if (no_obs && (!d.n_pf || d.pf_start[k] == d.pf_start[k + 1])) return;
+    }
+    lin_pose_body<false, LP_THREADS, LP_CHUNK>(d, k, PS, PT, commit);
+}
 
 
 // Schur complement contributions, output-stationary on the fp64 matrix cores: one 256-thread block per work item (a
@@ -1990,6 +2013,12 @@ void launch_linearize(Launcher &L, const Dev &d, bool fuse_ctrl, bool fuse_all, 
     if (d.phong) {
         launch_ph_linearize(L, d);
     } else {
+        static const bool one_launch = [] { const char *e = getenv("SSBA_LIN_TWO_LAUNCHES"); return !(e && e[0] == '1'); }();
+        if (one_launch && lm_split(d) && lm_sp(d) == LMW_SPLIT && !d.dense) {
+            LAUNCH(KC_LIN_LM, k_linearize_both, dim3(d.n_groups + xcd_contiguous_grid(d.P)), dim3(LP_THREADS), 0, d, fuse_all ? 1 : 0, d.n_groups);
+            if (!fuse_ctrl && !skip_reduce) LAUNCH(KC_SMALL, k_reduce_lin, dim3(1), dim3(256), 0, d, lm_parts(d));
+            return;
+        }
         if (lm_split(d) && lm_sp(d) == LMW_SPLIT) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<false, LMW_SPLIT>), dim3(d.n_groups), dim3(64 * LMW_SPLIT), 0, d, fuse_all ? 1 : 0);
         else if (lm_split(d)) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<false, 1>), dim3(d.n_groups), dim3(64), 0, d, fuse_all ? 1 : 0);
         else if (dn_sp(d) == 4) LAUNCH(KC_LIN_LM, (k_linearize_landmarks_w<true, 4>), dim3(d.n_groups), dim3(256), 0, d, fuse_all ? 1 : 0);
