@@ -335,11 +335,12 @@ static __device__ __forceinline__ void ph_invert_body(const Dev &d, int blk, int
 }
 __global__ __launch_bounds__(256) void k_ph_invert(Dev d) { ph_invert_body(d, (int)blockIdx.x, (int)gridDim.x); }
 
-template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_landmarks(Dev d) {
+// blk: the group of 256 landmarks (the work-group index of k_ph_linearize_landmarks; an offset one inside k_ph_linearize_all)
+template <bool DN> static __device__ __forceinline__ void ph_lin_landmarks_body(const Dev &d, int blk) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
     __shared__ double sm[4];
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blk * 256 + threadIdx.x;
     const uint32_t mask = d.lm_mask[l];
     double cost = 0.0, xn = 0.0, gm = 0.0;
     if (mask) {
@@ -389,11 +390,12 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_land
     const double c1 = block_sum(xn, sm);
     const double c2 = block_max(gm, sm);
     if (threadIdx.x == 0) {
-        d.part_lin[blockIdx.x * 4 + 0] = c0;
-        d.part_lin[blockIdx.x * 4 + 1] = c1;
-        d.part_lin[blockIdx.x * 4 + 2] = c2;
+        d.part_lin[blk * 4 + 0] = c0;
+        d.part_lin[blk * 4 + 1] = c1;
+        d.part_lin[blk * 4 + 2] = c2;
     }
 }
+template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_linearize_landmarks(Dev d) { ph_lin_landmarks_body<DN>(d, (int)blockIdx.x); }
 
 template <bool DN, int NT, int CH> static __device__ __forceinline__ void ph_lin_pose_body(const Dev &d, int k) {
     const State &st = *d.st;
@@ -960,10 +962,10 @@ template <bool DN> __global__ __launch_bounds__(256, 2) void k_ph_backsub_eval(D
 __device__ __forceinline__ int tri7(int r, int c) { return r * 7 - (r * (r - 1)) / 2 + (c - r); }   // r <= c
 
 // one lane per landmark, on linearisation: V_j (42), H_bb,j (28 unique), g_b,j (7)
-template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) {
+template <bool DN> static __device__ __forceinline__ void ph_border_landmarks_body(const Dev &d, int blk) {
     const State &st = *d.st;
     if (st.terminated || !st.need_linearize) return;
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = blk * 256 + threadIdx.x;
     const uint32_t mask = d.lm_mask[l];
     double V[42], H[28], G[7];
 #pragma unroll
@@ -1001,6 +1003,19 @@ template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_landmarks(
     for (int i = 0; i < 28; ++i) d.lmH[(size_t)i * d.Lpad + l] = H[i];
 #pragma unroll
     for (int i = 0; i < 7; ++i) d.lmG[(size_t)i * d.Lpad + l] = G[i];
+}
+template <bool DN> __global__ __launch_bounds__(256) void k_ph_border_landmarks(Dev d) { ph_border_landmarks_body<DN>(d, (int)blockIdx.x); }
+// Free shared blocks on the window layout: the landmark pass and the pose pass of a linearisation read the same inputs and neither
+// reads what the other writes (with constant shared blocks the pose pass shares its launch with the inversion instead:
+// k_ph_linpose_invert).  The landmark pass puts 1 564 waves on a machine that holds 2 048 at its register count -- one under-filled
+// round; in ONE launch, landmark groups first, the pose work-groups fill what it leaves: 53 + 54 us -> 96 at C3 (-11 us per
+// iteration, same bits).  The border pass of the landmarks (k_ph_border_landmarks) in the same launch as well: slower by 19 us -- the
+// three bodies in one kernel need 292 bytes of scratch per lane at two waves per SIMD.  SSBA_PH_LIN_LAUNCHES=1 keeps the launches apart.
+__global__ __launch_bounds__(256, 2) void k_ph_linearize_all(Dev d, int n_lm) {
+    const int b = (int)blockIdx.x;
+    if (b < n_lm) { ph_lin_landmarks_body<false>(d, b); return; }
+    const int k = xcd_contiguous_item(b - n_lm, d.P);
+    if (k >= 0) ph_lin_pose_body<false, 256, 2>(d, k);
 }
 
 // one lane per landmark, every iteration (after k_ph_invert): the landmark's contribution to
@@ -1710,6 +1725,13 @@ static bool ph_invert_with_poses(const Dev &d) {
     return !d.dense && !d.nb && !(e && e[0] == '1');
 }
 void launch_ph_linearize(Launcher &L, const Dev &d) {
+    static const bool separate = [] { const char *e = getenv("SSBA_PH_LIN_LAUNCHES"); return e && e[0] == '1'; }();
+    if (!separate && d.nb && !d.dense && !ph_invert_with_poses(d)) {
+        LAUNCH(KC_LIN_LM, k_ph_linearize_all, dim3(d.n_lm_blocks + xcd_contiguous_grid(d.P)), dim3(256), 0, d, d.n_lm_blocks);
+        LAUNCH(KC_BORDER, k_ph_border_landmarks<false>, dim3(d.n_lm_blocks), dim3(256), 0, d);
+        if (d.lmMV) LAUNCH(KC_BORDER, k_ph_hpb, dim3(d.P * d.M), dim3(64), 0, d);
+        return;
+    }
     LAUNCH(KC_LIN_LM, (d.dense ? k_ph_linearize_landmarks<true> : k_ph_linearize_landmarks<false>), dim3(d.n_lm_blocks), dim3(256), 0, d);
     // two observations in flight per lane: 54 us against 60 for the rolled loop at C3; three need 274 registers and lose (75 us),
     // 128 lanes per pose lose too (64-76 us) -- unlike the stereo kernel, whose 175 registers leave room for five
